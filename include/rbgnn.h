@@ -1,0 +1,186 @@
+/*
+ * rbgnn.h — C ABI of librbgnn.so, the MI355X (gfx950) LightGCN / NGCF propagation engine.
+ *
+ * This is the drop-in boundary for ONE path of RUCAIBox/RecBole-GNN: the normalized-adjacency
+ * message passing  E(k+1) = Â · E(k)  behind GeneralGraphRecommender
+ * (get_norm_adj_mat / forward / full_sort_predict).  The reference has no FFI of its own (it is
+ * Python calling torch_sparse / PyG); every entry point below names the reference interface it
+ * replaces (paths are relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain C types only; no torch types cross this boundary.
+ *   - every function returns RBG_OK (0) or a negative RBG_E* code; the message for the calling
+ *     thread is available from rbg_last_error().  Nothing aborts or throws across the ABI.
+ *   - device pointers are fp32, row-major, contiguous; the caller (PyTorch) owns every embedding /
+ *     score buffer.  The library owns graph handles and their HBM arrays.
+ *   - `stream` is a hipStream_t (0 = the null stream).  Kernels are enqueued and the call returns
+ *     without synchronizing.  No allocation happens on a hot call.
+ *   - a graph handle is immutable after creation: concurrent calls on different streams are safe.
+ */
+#ifndef RBGNN_H
+#define RBGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBG_ABI_VERSION 1
+
+/* error codes */
+#define RBG_OK            0
+#define RBG_EINVAL       (-1)  /* bad argument (null pointer, negative size, id out of range) */
+#define RBG_ENOMEM       (-2)  /* host or device allocation failed */
+#define RBG_EHIP         (-3)  /* a HIP runtime call failed; message carries hipGetErrorString */
+#define RBG_ESHAPE       (-4)  /* shape mismatch between the graph and the dense operands */
+#define RBG_ENODEV       (-5)  /* a device graph/op was requested but no GPU is visible */
+#define RBG_EUNSUPPORTED (-6)  /* valid request this build does not implement (e.g. nnz >= 2^31) */
+
+/* rbg_graph_create* flags */
+#define RBG_GRAPH_DEFAULT        0u
+#define RBG_GRAPH_KEEP_HOST      1u  /* keep the host CSR next to the device copy (export without D2H) */
+#define RBG_GRAPH_BUILD_ON_HOST  2u  /* force the host (C++) builder even for a device graph */
+#define RBG_GRAPH_NATURAL_ORDER  4u  /* do not degree-bin rows; rows are processed in id order */
+
+/* rbg_lightgcn_forward_f32 flags */
+#define RBG_FWD_DEFAULT          0u
+#define RBG_FWD_KEEP_LAST_LAYER  1u  /* also write E_K into layers[K-1] (autograd needs only E_1..E_{K-1}) */
+
+/* rbg_bignn_conv_f32 flags */
+#define RBG_BIGNN_CONV_ONLY      0u  /* exactly BiGNNConv.forward */
+#define RBG_BIGNN_LEAKY_NORM     1u  /* + LeakyReLU(slope) + row L2-normalize (NGCF.forward's per-layer tail) */
+
+#define RBG_MAX_FUSED_LAYERS     8   /* K up to this is fused into K launches; larger K still works (unfused mean) */
+
+typedef struct rbg_graph rbg_graph;
+
+/* ---------------------------------------------------------------------------------------------
+ * library
+ * ------------------------------------------------------------------------------------------- */
+int         rbg_abi_version(void);
+const char *rbg_last_error(void);           /* thread-local; never NULL */
+int         rbg_device_count(int *count);   /* RBG_OK with *count = 0 when no GPU is visible */
+
+/* Tuning knobs of the degree-binned SpMM (process-wide; read when a graph is created).
+ *   short_max : rows with degree <= short_max are handled one row per lane-group (D/4 lanes)
+ *   wave_max  : rows with degree <= wave_max by one wavefront; longer rows by a whole workgroup
+ *   seg_len   : workgroup rows longer than this are split into seg_len-entry segments whose
+ *               partial sums are combined in fixed order by the last segment to finish
+ * Pass a negative value to keep a knob unchanged. */
+int rbg_set_tuning(int short_max, int wave_max, int seg_len);
+int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
+
+/* ---------------------------------------------------------------------------------------------
+ * graph construction
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces GeneralGraphDataset.get_norm_adj_mat(enable_sparse=True)
+ *   recbole_gnn/data/dataset.py:49-75 (+ edge_index_to_adj_t :41-47, gcn_norm [PyG] at :74).
+ * uid/iid are the two id columns of inter_feat (HOST pointers, int64, uid in [0,n_users),
+ * iid in [0,n_items)); node ids are users first, then items (iid + n_users, dataset.py:61).
+ * Builds Â = D^-1/2 A D^-1/2 (no self loops, duplicates kept as separate edges) as CSR of
+ * adj_t with int32 columns sorted within a row and fp32 values  val = (dis[row]*1)*dis[col],
+ * dis = 1/sqrt(deg) with inf -> 0.  device = -1 keeps the graph on the host (build / export
+ * only; ops need a device graph), device >= 0 places it in that GPU's HBM. */
+int rbg_graph_create(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
+                     const int64_t *uid, const int64_t *iid, int device, uint32_t flags);
+
+/* Replaces SGL.random_graph_augment's graph rebuild for one view
+ *   recbole_gnn/model/general_recommender/sgl.py:107-126 (ED / RW) and :97-106 (ND, via the mask).
+ * keep[e] != 0 keeps interaction e; the view is re-normalized on ITS OWN degrees (sgl.py:119-124).
+ * keep == NULL is rbg_graph_create. */
+int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
+                            const int64_t *uid, const int64_t *iid, const uint8_t *keep,
+                            int device, uint32_t flags);
+
+/* A pre-built (already weighted) CSR, possibly rectangular: rows = output nodes, cols = index
+ * space of the dense operand.  Used for node-range shards ([local | halo] column space) and for
+ * callers that hold the reference's SparseTensor storage (rowptr,col,value of adj_t;
+ * recbole_gnn/model/abstract_recommender.py:15-18).  HOST pointers. */
+int rbg_graph_create_csr(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                         const int32_t *col, const float *val, int device, uint32_t flags);
+
+/* The (edge_index, edge_weight) form, i.e. get_norm_adj_mat(enable_sparse=False|None)
+ *   recbole_gnn/data/dataset.py:60-66,77-79.
+ * Writes edge_index as int64 [2][2*n_inter] (row 0 = source, row 1 = target; first all u->i,
+ * then all i->u, order preserved) and edge_weight fp32 [2*n_inter].  Pure host function. */
+int rbg_norm_edges(int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
+                   const int64_t *iid, int64_t *edge_index, float *edge_weight);
+
+/* Build a graph from the reference's dense-branch pair (edge_index int64 [2][nnz], edge_weight
+ * fp32 [nnz], HOST pointers): Y[target] += w * X[source]  (layers.py:16-17 + PyG scatter).
+ * This is how a model holding `self.edge_index, self.edge_weight` hands its graph over. */
+int rbg_graph_create_coo(rbg_graph **out, int64_t n_nodes, int64_t nnz, const int64_t *edge_index,
+                         const float *edge_weight, int device, uint32_t flags);
+
+int rbg_graph_info(const rbg_graph *g, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *device);
+
+/* Row-binning statistics (diagnostics / DESIGN.md): counts of lane-group rows, wavefront rows,
+ * workgroup tasks, split rows, and the launch grid. Any pointer may be NULL. */
+int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
+                   int64_t *n_split_rows, int64_t *grid_blocks);
+
+/* Copy the CSR out to HOST buffers: rowptr int64 [n_rows+1], col int32 [nnz], val fp32 [nnz].
+ * Any pointer may be NULL.  Works for host and device graphs (D2H copy + sync for the latter). */
+int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val);
+
+void rbg_graph_destroy(rbg_graph *g);
+
+/* ---------------------------------------------------------------------------------------------
+ * operators (device graphs only; X, Y, ... are DEVICE pointers)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces LightGCNConv.forward(x, edge_index, edge_weight)
+ *   recbole_gnn/model/layers.py:13-20  (torch_sparse.matmul(adj_t, x, reduce='add') at :19-20,
+ *   or edge_weight.view(-1,1) * x_j + scatter-add at :16-17).
+ * Y[n_rows, d] = Â · X[n_cols, d]  (accumulate = 0)   or   Y += Â · X  (accumulate != 0).
+ * X and Y must not alias.  Rows of Â with no entries produce zeros.  Also the autograd backward
+ * (Â symmetric):  dL/dX = Â · dL/dY. */
+int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, void *stream);
+
+/* Replaces LightGCN.get_ego_embeddings + LightGCN.forward
+ *   recbole_gnn/model/general_recommender/lightgcn.py:60-68,70-81  (and SGL.forward,
+ *   sgl.py:128-145, where layer k may use its own graph).
+ * graphs: n_graphs == 1 (same Â every layer) or n_graphs == K (layer k uses graphs[k]).
+ * user_emb [n_users, d], item_emb [n_items, d]: the two embedding tables (no concatenated copy is
+ * made; n_users + n_items must equal the graph's node count, n_users is taken from the graph or,
+ * for CSR/COO-built graphs, from `n_users`).
+ * out_mean [N, d] = mean(E_0..E_K) (lightgcn.py:77-78); rows [0,n_users) are user_all_embeddings,
+ * the rest item_all_embeddings (the split at :80 is a view).
+ * layers: caller-provided [K][N][d] fp32 buffer; E_k is written to layers[k-1] for k < K (and for
+ * k == K with RBG_FWD_KEEP_LAST_LAYER).  Needed by the next layer and by autograd. */
+int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64_t n_users,
+                             const float *user_emb, const float *item_emb, float *out_mean,
+                             float *layers, int d, int K, uint32_t flags, void *stream);
+
+/* Replaces BiGNNConv.forward(x, edge_index, edge_weight)
+ *   recbole_gnn/model/layers.py:54-58:  P = ÂX;  Y = lin1(P + X) + lin2(P ⊙ X)
+ * and, with RBG_BIGNN_LEAKY_NORM, NGCF.forward's per-layer tail
+ *   recbole_gnn/model/general_recommender/ngcf.py:96,98: LeakyReLU(slope) then F.normalize(p=2, dim=1)
+ *   (message dropout, ngcf.py:97, is not applied: parity is defined at message_dropout = 0).
+ * W1, W2: [d_out, d_in] row-major (nn.Linear.weight), b1, b2: [d_out].
+ * Y [N, d_out] is written with row stride ldy floats (ldy >= d_out) so the caller can place layer
+ * outputs directly inside the concatenated [N, sum(d)] buffer (ngcf.py:100).
+ * X [N, d_in] is read with row stride ldx floats.  P_save (optional, [N, d_in]) receives ÂX for the
+ * autograd backward. */
+int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
+                       const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save,
+                       int d_in, int d_out, uint32_t flags, float slope, void *stream);
+
+/* Replaces the scoring GEMM of full_sort_predict
+ *   recbole_gnn/model/general_recommender/lightgcn.py:131 (ngcf.py:147, sgl.py:240):
+ *   scores = u_embeddings @ restore_item_e.T
+ * S[B, n] = U[B, d] · I[n, d]^T, fp32 MFMA (v_mfma_f32_32x32x2_f32), ldu/ldi = row strides in floats. */
+int rbg_score_f32(const float *U, int64_t ldu, const float *I, int64_t ldi, float *S, int64_t B,
+                  int64_t n, int d, void *stream);
+
+/* Row gather: dst[i, :] = src[idx[i], :]  (restore_user_e[user], lightgcn.py:128; also packs the
+ * halo send buffer of the node-range sharded path).  idx is a DEVICE int64 array. */
+int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,
+                        int d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBGNN_H */

@@ -1,0 +1,14 @@
+"""recbole-gnn_amd — MI355X-native LightGCN / NGCF propagation engine behind RecBole-GNN's
+GeneralGraphRecommender interface (get_norm_adj_mat / forward / full_sort_predict).
+
+The package directory name carries a hyphen; import it as ``recbole_gnn_amd`` (the shim module at
+the repository root) or with ``importlib.import_module("recbole-gnn_amd")``.
+Importing fails loudly if librbgnn.so (the HIP extension) has not been built; there is no CPU path.
+"""
+from . import _lib, graph, models, ops, sharded, synth  # noqa: F401
+from ._lib import LIB_PATH, RbgError  # noqa: F401
+from .graph import GraphHandle, InteractionDataset, device_count, get_tuning, norm_edges, set_tuning  # noqa: F401
+from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN  # noqa: F401
+from .ops import BiGNNConv, LightGCNConv, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,210 @@
+// bignn.hip — NGCF's bi-interaction layer on gfx950.
+//
+// Replaces BiGNNConv.forward  (recbole_gnn/model/layers.py:54-58)
+//     x_prop  = propagate(x)                 -> P = ÂX           (one SpMM, spmm.hip)
+//     x_trans = lin1(x_prop + x)
+//     x_inter = lin2(x_prop * x)             -> the "Hadamard term": (ÂX) ⊙ X, an epilogue, not a 2nd SpMM
+//     return x_trans + x_inter
+// and, with RBG_BIGNN_LEAKY_NORM, the per-layer tail of NGCF.forward (ngcf.py:96,98):
+//     LeakyReLU(0.2) -> F.normalize(p=2, dim=1)   (message dropout, ngcf.py:97, is not applied)
+//
+// The dense part is ONE GEMM with the two linears concatenated along k:
+//     Y = [P+X | P⊙X] (N x 2d_in) · [W1^T ; W2^T] (2d_in x d_out) + (b1 + b2)
+// run on v_mfma_f32_32x32x2_f32 (exact fp32).  A wavefront owns 32 rows and all d_out columns, so the
+// row L2 norm is a 32-lane butterfly inside the wave.  The A operand is built in registers straight
+// from the lane's contiguous 128-byte runs of P and X (same k-walk trick as score.hip); the
+// concatenated weight matrix is staged once per workgroup in LDS in the MFMA's k order, so a B
+// operand is one conflict-free ds_read_b32.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "internal.h"
+
+namespace rbg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct BignnParams {
+    const float *P;  // [N, d_in] contiguous
+    const float *X;
+    int64_t ldx;
+    const float *W1, *b1, *W2, *b2;
+    float *Y;
+    int64_t ldy;
+    int64_t n_rows;
+    int d_in, d_out;
+    int leaky_norm;
+    float slope;
+};
+
+__device__ __forceinline__ void load_run32(const float *p, bool ok, int k0, int d, bool vec, float (&r)[32]) {
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
+            r[4 * q + 0] = v.x;
+            r[4 * q + 1] = v.y;
+            r[4 * q + 2] = v.z;
+            r[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) r[s] = (ok && k0 + s < d) ? p[k0 + s] : 0.f;
+    }
+}
+
+// NT = number of 32-column output tiles held by a wave (d_out <= 32*NT).
+// LDS holds W as Wl[kk][h][j], kk = chunk*32 + s walking k = 64*(chunk % nch) + 32*h + s of
+// part (chunk / nch) (0: W1 against P+X, 1: W2 against P⊙X); width DP = 32*NT.
+template <int NT>
+__global__ __launch_bounds__(256) void bignn_dense_kernel(const BignnParams p, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float Wl[];
+    constexpr int DP = 32 * NT;
+    const int nch = (p.d_in + 63) / 64;  // k chunks per part
+    const int total = 2 * nch * 32 * 2 * DP;
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
+        const int j = idx % DP;
+        const int h = (idx / DP) & 1;
+        const int kk = idx / (2 * DP);
+        const int chunk = kk >> 5, s = kk & 31;
+        const int part = chunk / nch;
+        const int k = 64 * (chunk % nch) + 32 * h + s;
+        const float *W = part ? p.W2 : p.W1;
+        Wl[idx] = (j < p.d_out && k < p.d_in) ? W[(int64_t)j * p.d_in + k] : 0.f;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    float bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int c = t * 32 + i;
+        bias[t] = c < p.d_out ? p.b1[c] + p.b2[c] : 0.f;
+    }
+    const int64_t n_tiles = (p.n_rows + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t r = tile * 32 + i;
+        const bool ok = r < p.n_rows;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nch; ++c) {
+            float a1[32], a2[32];
+            load_run32(p.P + r * p.d_in, ok, 64 * c + 32 * h, p.d_in, vec, a1);
+            load_run32(p.X + r * p.ldx, ok, 64 * c + 32 * h, p.d_in, vec, a2);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float pv = a1[s], xv = a2[s];
+                a1[s] = pv + xv;  // lin1 operand (layers.py:56)
+                a2[s] = pv * xv;  // lin2 operand (layers.py:57)
+            }
+            const float *w1 = Wl + ((c * 32) * 2 + h) * DP + i;
+            const float *w2 = Wl + (((nch + c) * 32) * 2 + h) * DP + i;
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s * 2 * DP + t * 32], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w2[s * 2 * DP + t * 32], acc[t], 0, 0, 0);
+            }
+        }
+        // epilogue on the C layout: col = 32t + (lane&31), row = (reg&3) + 8*(reg>>2) + 4*h
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            float v[NT];
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float x = acc[t][reg] + bias[t];
+                if (p.leaky_norm) x = x > 0.f ? x : x * p.slope;
+                v[t] = x;
+                ss = fmaf(x, x, ss);  // padded columns hold exact zeros
+            }
+            if (p.leaky_norm) {
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) ss += __shfl_xor(ss, off);
+                const float denom = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = v[t] / denom;
+            }
+            const int64_t row = tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < p.n_rows) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int c = t * 32 + i;
+                    if (c < p.d_out) p.Y[row * p.ldy + c] = v[t];
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static int launch_dense(const BignnParams &p, int vec, hipStream_t s) {
+    const int nch = (p.d_in + 63) / 64;
+    const size_t lds = (size_t)2 * nch * 32 * 2 * 32 * NT * sizeof(float);
+    if (lds > 160 * 1024) return fail(RBG_EUNSUPPORTED, "BiGNNConv %d x %d needs %zu bytes of LDS", p.d_in, p.d_out, lds);
+    if (lds > 64 * 1024) {
+        RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dense_kernel<NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const int64_t n_tiles = (p.n_rows + 31) / 32;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 512));
+    hipLaunchKernelGGL((bignn_dense_kernel<NT>), dim3((unsigned)grid), dim3(256), lds, s, p, vec);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, int d_in,
+                                  int d_out, uint32_t flags, float slope, void *stream) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
+    if (g->n_rows != g->n_cols) return fail(RBG_ESHAPE, "graph is not square");
+    if (d_in <= 0 || d_out <= 0 || ldx < d_in || ldy < d_out)
+        return fail(RBG_ESHAPE, "d_in = %d, d_out = %d, ldx = %lld, ldy = %lld", d_in, d_out, (long long)ldx, (long long)ldy);
+    if (d_out > 256) return fail(RBG_EUNSUPPORTED, "d_out = %d > 256", d_out);
+    if (g->n_rows == 0) return RBG_OK;
+    if (!X || !W1 || !b1 || !W2 || !b2 || !Y) return fail(RBG_EINVAL, "NULL pointer");
+    if (!P_save) return fail(RBG_EINVAL, "P_save is NULL: the caller provides the [N, d_in] buffer that receives ÂX");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = spmm_strided(g, X, ldx, P_save, d_in, d_in, 0, s))) return rc;
+    BignnParams p{};
+    p.P = P_save;
+    p.X = X;
+    p.ldx = ldx;
+    p.W1 = W1;
+    p.b1 = b1;
+    p.W2 = W2;
+    p.b2 = b2;
+    p.Y = Y;
+    p.ldy = ldy;
+    p.n_rows = g->n_rows;
+    p.d_in = d_in;
+    p.d_out = d_out;
+    p.leaky_norm = (flags & RBG_BIGNN_LEAKY_NORM) ? 1 : 0;
+    p.slope = slope;
+    const int vec = (d_in % 4 == 0) && (ldx % 4 == 0) &&
+                    ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P_save)) & 15u) == 0;
+    if (d_out <= 32) return launch_dense<1>(p, vec, s);
+    if (d_out <= 64) return launch_dense<2>(p, vec, s);
+    if (d_out <= 128) return launch_dense<4>(p, vec, s);
+    return launch_dense<8>(p, vec, s);
+}

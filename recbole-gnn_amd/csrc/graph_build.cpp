@@ -1,0 +1,510 @@
+// graph_build.cpp — host side of librbgnn.so: error plumbing, the normalized-adjacency builder
+// (replaces GeneralGraphDataset.get_norm_adj_mat, recbole_gnn/data/dataset.py:49-79, and SGL's view
+// rebuild, sgl.py:107-126), degree binning for the SpMM launch, upload to HBM, export.
+//
+// Layout produced (see DESIGN.md "Data layout in HBM"):
+//   rowptr int32 [N+1], col int32 [nnz] (ascending within a row), val fp32 [nnz]
+//   row_order int32 [N]   rows by degree, descending (ties by row id)
+//   tasks BlockTask[]     one per workgroup row segment
+// Users come first, items after (col = iid + n_users, dataset.py:61).  Duplicated interactions stay
+// separate entries, each counted in the degree (PyG gcn_norm does the same).
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <new>
+#include <thread>
+
+#include "internal.h"
+
+namespace rbg {
+
+static thread_local std::string t_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_error = buf;
+    return code;
+}
+void clear_error() { t_error.clear(); }
+
+static std::atomic<int> g_short_max{16}, g_wave_max{192}, g_seg_len{768};
+
+Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
+
+int set_device_for(int device) {
+    int cur = -1;
+    RBG_HIP(hipGetDevice(&cur));
+    if (cur != device) RBG_HIP(hipSetDevice(device));
+    return RBG_OK;
+}
+
+// Run fn(t, n_threads) on a small pool; used for the row-parallel passes of the builder.
+template <class F>
+static void parallel_run(int64_t work, F &&fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)std::min<int64_t>(hw ? hw : 1, std::max<int64_t>(1, work / (1 << 16)));
+    if (n <= 1) {
+        fn(0, 1);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (int t = 0; t < n; ++t) th.emplace_back([&fn, t, n] { fn(t, n); });
+    for (auto &x : th) x.join();
+}
+
+// Scatter pass: append (other + offset) to row `key[e]` while visiting interactions in ascending
+// order of `other` (counting sort), so every row comes out column-sorted without a per-row sort.
+static void fill_side(int64_t n_inter, const int64_t *key, const int64_t *other, const uint8_t *keep,
+                      int64_t key_offset, int64_t other_offset, int64_t n_other,
+                      const std::vector<int32_t> &rowptr, std::vector<int32_t> &col) {
+    std::vector<int64_t> start((size_t)n_other + 1, 0);
+    for (int64_t e = 0; e < n_inter; ++e)
+        if (!keep || keep[e]) start[(size_t)other[e] + 1]++;
+    for (int64_t i = 0; i < n_other; ++i) start[(size_t)i + 1] += start[(size_t)i];
+    const int64_t kept = start[(size_t)n_other];
+    std::vector<int64_t> order((size_t)kept);
+    for (int64_t e = 0; e < n_inter; ++e)
+        if (!keep || keep[e]) order[(size_t)start[(size_t)other[e]]++] = e;
+    // cursors of the destination rows
+    std::vector<int32_t> cur;
+    {
+        // only the [key_offset, key_offset + n_key) rows are touched; copy their starts lazily
+        cur.assign(rowptr.begin(), rowptr.end() - 1);
+    }
+    for (int64_t k = 0; k < kept; ++k) {
+        const int64_t e = order[(size_t)k];
+        const int64_t r = key[e] + key_offset;
+        col[(size_t)cur[(size_t)r]++] = (int32_t)(other[e] + other_offset);
+    }
+}
+
+int build_host_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
+                   const int64_t *iid, const uint8_t *keep) {
+    if (n_users < 0 || n_items < 0 || n_inter < 0) return fail(RBG_EINVAL, "negative size");
+    if (n_inter > 0 && (!uid || !iid)) return fail(RBG_EINVAL, "uid/iid is NULL");
+    const int64_t n = n_users + n_items;
+    if (n >= (int64_t)INT32_MAX) return fail(RBG_EUNSUPPORTED, "node count %lld >= 2^31", (long long)n);
+    int64_t kept = 0;
+    for (int64_t e = 0; e < n_inter; ++e) {
+        if (keep && !keep[e]) continue;
+        if (uid[e] < 0 || uid[e] >= n_users)
+            return fail(RBG_EINVAL, "uid[%lld] = %lld out of [0,%lld)", (long long)e, (long long)uid[e], (long long)n_users);
+        if (iid[e] < 0 || iid[e] >= n_items)
+            return fail(RBG_EINVAL, "iid[%lld] = %lld out of [0,%lld)", (long long)e, (long long)iid[e], (long long)n_items);
+        ++kept;
+    }
+    if (2 * kept >= (int64_t)INT32_MAX)
+        return fail(RBG_EUNSUPPORTED, "nnz %lld >= 2^31 (int32 rowptr build)", (long long)(2 * kept));
+    try {
+        g->n_rows = g->n_cols = n;
+        g->n_users = n_users;
+        g->nnz = 2 * kept;
+        g->h_rowptr.assign((size_t)n + 1, 0);
+        for (int64_t e = 0; e < n_inter; ++e) {
+            if (keep && !keep[e]) continue;
+            g->h_rowptr[(size_t)uid[e] + 1]++;
+            g->h_rowptr[(size_t)(iid[e] + n_users) + 1]++;
+        }
+        for (int64_t r = 0; r < n; ++r) g->h_rowptr[(size_t)r + 1] += g->h_rowptr[(size_t)r];
+        g->h_col.assign((size_t)g->nnz, 0);
+        g->h_val.assign((size_t)g->nnz, 0.f);
+        // user rows list items (ascending), item rows list users (ascending)
+        fill_side(n_inter, uid, iid, keep, 0, n_users, n_items, g->h_rowptr, g->h_col);
+        fill_side(n_inter, iid, uid, keep, n_users, 0, n_users, g->h_rowptr, g->h_col);
+        // gcn_norm(add_self_loops=False): deg = row sums of ones; dis = deg^-0.5 (inf -> 0), computed
+        // as the IEEE 1/sqrt ATen's CPU pow(x,-0.5) uses; val = (dis[row] * 1) * dis[col], fp32.
+        std::vector<float> dis((size_t)n);
+        for (int64_t r = 0; r < n; ++r) {
+            const float deg = (float)(g->h_rowptr[(size_t)r + 1] - g->h_rowptr[(size_t)r]);
+            const float s = 1.0f / sqrtf(deg);
+            dis[(size_t)r] = isinf(s) ? 0.0f : s;
+        }
+        const int32_t *rp = g->h_rowptr.data();
+        const int32_t *cp = g->h_col.data();
+        float *vp = g->h_val.data();
+        const float *dp = dis.data();
+        parallel_run(g->nnz, [=](int t, int nt) {
+            const int64_t r0 = n * t / nt, r1 = n * (t + 1) / nt;
+            for (int64_t r = r0; r < r1; ++r) {
+                const float dr = dp[r] * 1.0f;
+                for (int32_t e = rp[r]; e < rp[r + 1]; ++e) vp[e] = dr * dp[cp[e]];
+            }
+        });
+    } catch (const std::bad_alloc &) {
+        return fail(RBG_ENOMEM, "host allocation failed while building the CSR");
+    }
+    return RBG_OK;
+}
+
+int plan_bins(const rbg_graph *g, std::vector<int32_t> &row_order, std::vector<BlockTask> &tasks,
+              int64_t &n_block_rows, int64_t &n_wave, int64_t &n_short, int64_t &n_split, int64_t &n_slots,
+              int32_t &max_deg) {
+    const int64_t n = g->n_rows;
+    const int32_t *rp = g->h_rowptr.data();
+    const Tuning tn = g->tuning;
+    row_order.resize((size_t)n);
+    tasks.clear();
+    n_block_rows = n_wave = n_short = n_split = n_slots = 0;
+    max_deg = 0;
+    for (int64_t r = 0; r < n; ++r) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
+    if (g->flags & RBG_GRAPH_NATURAL_ORDER) {
+        for (int64_t r = 0; r < n; ++r) row_order[(size_t)r] = (int32_t)r;
+        n_short = n;
+        return RBG_OK;
+    }
+    // counting sort by degree, descending; ties keep ascending row id
+    std::vector<int64_t> start((size_t)max_deg + 2, 0);
+    for (int64_t r = 0; r < n; ++r) start[(size_t)(max_deg - (rp[r + 1] - rp[r])) + 1]++;
+    for (int32_t k = 0; k <= max_deg; ++k) start[(size_t)k + 1] += start[(size_t)k];
+    for (int64_t r = 0; r < n; ++r) row_order[(size_t)start[(size_t)(max_deg - (rp[r + 1] - rp[r]))]++] = (int32_t)r;
+    for (int64_t k = 0; k < n; ++k) {
+        const int32_t r = row_order[(size_t)k];
+        const int32_t deg = rp[r + 1] - rp[r];
+        if (deg > tn.wave_max) {
+            ++n_block_rows;
+            const int32_t nseg = (deg + tn.seg_len - 1) / tn.seg_len;
+            // equal-length segments, rounded up to a multiple of 64 entries
+            int32_t len = (deg + nseg - 1) / nseg;
+            len = (len + 63) / 64 * 64;
+            const int32_t real = (deg + len - 1) / len;
+            for (int32_t s = 0; s < real; ++s) {
+                BlockTask t{};
+                t.row = r;
+                t.beg = rp[r] + s * len;
+                t.end = std::min(rp[r + 1], t.beg + len);
+                t.seg = s;
+                t.nseg = real;
+                t.part_base = real > 1 ? (int32_t)n_slots : 0;
+                t.ctr = real > 1 ? (int32_t)n_split : 0;
+                tasks.push_back(t);
+            }
+            if (real > 1) {
+                n_slots += real;
+                ++n_split;
+            }
+        } else if (deg > tn.short_max) {
+            ++n_wave;
+        } else {
+            ++n_short;
+        }
+    }
+    return RBG_OK;
+}
+
+static void free_device(rbg_graph *g) {
+    if (g->device < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
+    (void)hipFree(g->d_rowptr);
+    (void)hipFree(g->d_col);
+    (void)hipFree(g->d_val);
+    (void)hipFree(g->d_row_order);
+    (void)hipFree(g->d_tasks);
+    (void)hipFree(g->d_partials);
+    (void)hipFree(g->d_counters);
+    g->d_rowptr = g->d_col = g->d_row_order = nullptr;
+    g->d_val = g->d_partials = nullptr;
+    g->d_tasks = nullptr;
+    g->d_counters = nullptr;
+    if (cur != g->device) (void)hipSetDevice(cur);
+}
+
+template <class T>
+static int to_device(T **dst, const T *src, size_t count) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc((void **)dst, bytes);
+    if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    if (count) RBG_HIP(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RBG_OK;
+}
+
+int upload_graph(rbg_graph *g) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(RBG_ENODEV, "a device graph was requested but no GPU is visible");
+    if (g->device >= n_dev) return fail(RBG_EINVAL, "device %d out of range (%d visible)", g->device, n_dev);
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    std::vector<int32_t> order;
+    std::vector<BlockTask> tasks;
+    int64_t nb, nw, ns, nsplit, nslots;
+    int32_t maxdeg;
+    try {
+        rc = plan_bins(g, order, tasks, nb, nw, ns, nsplit, nslots, maxdeg);
+    } catch (const std::bad_alloc &) {
+        return fail(RBG_ENOMEM, "host allocation failed while binning rows");
+    }
+    if (rc) return rc;
+    g->n_block_rows = nb;
+    g->n_wave = nw;
+    g->n_short = ns;
+    g->n_tasks = (int64_t)tasks.size();
+    g->n_split_rows = nsplit;
+    g->n_partial_slots = nslots;
+    g->max_degree = maxdeg;
+    if ((rc = to_device(&g->d_rowptr, g->h_rowptr.data(), g->h_rowptr.size()))) return rc;
+    if ((rc = to_device(&g->d_col, g->h_col.data(), g->h_col.size()))) return rc;
+    if ((rc = to_device(&g->d_val, g->h_val.data(), g->h_val.size()))) return rc;
+    if ((rc = to_device(&g->d_row_order, order.data(), order.size()))) return rc;
+    if ((rc = to_device(&g->d_tasks, tasks.data(), tasks.size()))) return rc;
+    {
+        const size_t pb = std::max<size_t>((size_t)nslots, 1) * kPartialSlotFloats * sizeof(float);
+        hipError_t e = hipMalloc((void **)&g->d_partials, pb);
+        if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", pb, hipGetErrorString(e));
+        const size_t cb = std::max<size_t>((size_t)nsplit, 1) * sizeof(uint32_t);
+        e = hipMalloc((void **)&g->d_counters, cb);
+        if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", cb, hipGetErrorString(e));
+        RBG_HIP(hipMemset(g->d_counters, 0, cb));
+    }
+    RBG_HIP(hipDeviceSynchronize());
+    if (!(g->flags & RBG_GRAPH_KEEP_HOST)) {
+        std::vector<int32_t>().swap(g->h_rowptr);
+        std::vector<int32_t>().swap(g->h_col);
+        std::vector<float>().swap(g->h_val);
+    }
+    return RBG_OK;
+}
+
+static int finish_create(rbg_graph **out, rbg_graph *g, int rc) {
+    if (rc == RBG_OK && g->device >= 0) rc = upload_graph(g);
+    if (rc != RBG_OK) {
+        free_device(g);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return RBG_OK;
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_abi_version(void) { return RBG_ABI_VERSION; }
+
+const char *rbg_last_error(void) { return rbg::t_error.c_str(); }
+
+int rbg_device_count(int *count) {
+    if (!count) return fail(RBG_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return RBG_OK;
+}
+
+int rbg_set_tuning(int short_max, int wave_max, int seg_len) {
+    const Tuning cur = current_tuning();
+    const int s = short_max < 0 ? cur.short_max : short_max;
+    const int w = wave_max < 0 ? cur.wave_max : wave_max;
+    const int l = seg_len < 0 ? cur.seg_len : seg_len;
+    if (w < s) return fail(RBG_EINVAL, "wave_max (%d) < short_max (%d)", w, s);
+    if (l < 64) return fail(RBG_EINVAL, "seg_len (%d) < 64", l);
+    g_short_max = s;
+    g_wave_max = w;
+    g_seg_len = l;
+    return RBG_OK;
+}
+
+int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len) {
+    const Tuning cur = current_tuning();
+    if (short_max) *short_max = cur.short_max;
+    if (wave_max) *wave_max = cur.wave_max;
+    if (seg_len) *seg_len = cur.seg_len;
+    return RBG_OK;
+}
+
+int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
+                            const int64_t *uid, const int64_t *iid, const uint8_t *keep, int device,
+                            uint32_t flags) {
+    clear_error();
+    if (!out) return fail(RBG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (device < -1) return fail(RBG_EINVAL, "device %d", device);
+    rbg_graph *g = new (std::nothrow) rbg_graph();
+    if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
+    g->device = device;
+    g->flags = flags | (device < 0 ? RBG_GRAPH_KEEP_HOST : 0u);
+    g->tuning = current_tuning();
+    return finish_create(out, g, build_host_csr(g, n_users, n_items, n_inter, uid, iid, keep));
+}
+
+int rbg_graph_create(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
+                     const int64_t *iid, int device, uint32_t flags) {
+    return rbg_graph_create_masked(out, n_users, n_items, n_inter, uid, iid, nullptr, device, flags);
+}
+
+int rbg_graph_create_csr(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                         const int32_t *col, const float *val, int device, uint32_t flags) {
+    clear_error();
+    if (!out) return fail(RBG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_rows < 0 || n_cols < 0 || !rowptr) return fail(RBG_EINVAL, "bad shape or NULL rowptr");
+    if (device < -1) return fail(RBG_EINVAL, "device %d", device);
+    if (n_rows >= (int64_t)INT32_MAX || n_cols >= (int64_t)INT32_MAX)
+        return fail(RBG_EUNSUPPORTED, "dimension >= 2^31");
+    if (rowptr[0] != 0) return fail(RBG_EINVAL, "rowptr[0] != 0");
+    for (int64_t r = 0; r < n_rows; ++r)
+        if (rowptr[r + 1] < rowptr[r]) return fail(RBG_EINVAL, "rowptr not monotone at row %lld", (long long)r);
+    const int64_t nnz = rowptr[n_rows];
+    if (nnz >= (int64_t)INT32_MAX) return fail(RBG_EUNSUPPORTED, "nnz %lld >= 2^31", (long long)nnz);
+    if (nnz > 0 && (!col || !val)) return fail(RBG_EINVAL, "col/val is NULL");
+    for (int64_t e = 0; e < nnz; ++e)
+        if (col[e] < 0 || col[e] >= n_cols)
+            return fail(RBG_EINVAL, "col[%lld] = %d out of [0,%lld)", (long long)e, col[e], (long long)n_cols);
+    rbg_graph *g = new (std::nothrow) rbg_graph();
+    if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
+    g->device = device;
+    g->flags = flags | (device < 0 ? RBG_GRAPH_KEEP_HOST : 0u);
+    g->tuning = current_tuning();
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    int rc = RBG_OK;
+    try {
+        g->h_rowptr.resize((size_t)n_rows + 1);
+        for (int64_t r = 0; r <= n_rows; ++r) g->h_rowptr[(size_t)r] = (int32_t)rowptr[r];
+        g->h_col.assign(col, col + nnz);
+        g->h_val.assign(val, val + nnz);
+    } catch (const std::bad_alloc &) {
+        rc = fail(RBG_ENOMEM, "host allocation failed while copying the CSR");
+    }
+    return finish_create(out, g, rc);
+}
+
+int rbg_graph_create_coo(rbg_graph **out, int64_t n_nodes, int64_t nnz, const int64_t *edge_index,
+                         const float *edge_weight, int device, uint32_t flags) {
+    clear_error();
+    if (!out) return fail(RBG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_nodes < 0 || nnz < 0) return fail(RBG_EINVAL, "negative size");
+    if (nnz > 0 && (!edge_index || !edge_weight)) return fail(RBG_EINVAL, "edge_index/edge_weight is NULL");
+    if (device < -1) return fail(RBG_EINVAL, "device %d", device);
+    if (n_nodes >= (int64_t)INT32_MAX || nnz >= (int64_t)INT32_MAX)
+        return fail(RBG_EUNSUPPORTED, "size >= 2^31");
+    const int64_t *src = edge_index, *dst = edge_index + nnz;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (src[e] < 0 || src[e] >= n_nodes || dst[e] < 0 || dst[e] >= n_nodes)
+            return fail(RBG_EINVAL, "edge %lld (%lld -> %lld) out of [0,%lld)", (long long)e, (long long)src[e],
+                        (long long)dst[e], (long long)n_nodes);
+    rbg_graph *g = new (std::nothrow) rbg_graph();
+    if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
+    g->device = device;
+    g->flags = flags | (device < 0 ? RBG_GRAPH_KEEP_HOST : 0u);
+    g->tuning = current_tuning();
+    g->n_rows = g->n_cols = n_nodes;
+    g->nnz = nnz;
+    int rc = RBG_OK;
+    try {
+        // adj_t: row = target, col = source; sort by (target, source) via counting sort on source then
+        // a stable scatter on target (SparseTensor sorts on construction, dataset.py:43-47).
+        g->h_rowptr.assign((size_t)n_nodes + 1, 0);
+        for (int64_t e = 0; e < nnz; ++e) g->h_rowptr[(size_t)dst[e] + 1]++;
+        for (int64_t r = 0; r < n_nodes; ++r) g->h_rowptr[(size_t)r + 1] += g->h_rowptr[(size_t)r];
+        std::vector<int64_t> start((size_t)n_nodes + 1, 0);
+        for (int64_t e = 0; e < nnz; ++e) start[(size_t)src[e] + 1]++;
+        for (int64_t r = 0; r < n_nodes; ++r) start[(size_t)r + 1] += start[(size_t)r];
+        std::vector<int64_t> order((size_t)nnz);
+        for (int64_t e = 0; e < nnz; ++e) order[(size_t)start[(size_t)src[e]]++] = e;
+        std::vector<int32_t> cur(g->h_rowptr.begin(), g->h_rowptr.end() - 1);
+        g->h_col.assign((size_t)nnz, 0);
+        g->h_val.assign((size_t)nnz, 0.f);
+        for (int64_t k = 0; k < nnz; ++k) {
+            const int64_t e = order[(size_t)k];
+            const int32_t p = cur[(size_t)dst[e]]++;
+            g->h_col[(size_t)p] = (int32_t)src[e];
+            g->h_val[(size_t)p] = edge_weight[e];
+        }
+    } catch (const std::bad_alloc &) {
+        rc = fail(RBG_ENOMEM, "host allocation failed while building the CSR");
+    }
+    return finish_create(out, g, rc);
+}
+
+int rbg_norm_edges(int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid, const int64_t *iid,
+                   int64_t *edge_index, float *edge_weight) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || n_inter < 0) return fail(RBG_EINVAL, "negative size");
+    if (n_inter > 0 && (!uid || !iid || !edge_index || !edge_weight)) return fail(RBG_EINVAL, "NULL argument");
+    const int64_t n = n_users + n_items, m = 2 * n_inter;
+    std::vector<float> deg;
+    try {
+        deg.assign((size_t)std::max<int64_t>(n, 1), 0.f);
+    } catch (const std::bad_alloc &) {
+        return fail(RBG_ENOMEM, "host allocation failed");
+    }
+    int64_t *src = edge_index, *dst = edge_index + m;
+    for (int64_t e = 0; e < n_inter; ++e) {
+        if (uid[e] < 0 || uid[e] >= n_users || iid[e] < 0 || iid[e] >= n_items)
+            return fail(RBG_EINVAL, "interaction %lld (%lld,%lld) out of range", (long long)e, (long long)uid[e],
+                        (long long)iid[e]);
+        const int64_t u = uid[e], i = iid[e] + n_users;
+        src[e] = u;
+        dst[e] = i;
+        src[n_inter + e] = i;
+        dst[n_inter + e] = u;
+    }
+    // deg = scatter_add(w, col) with w = 1 (exact in fp32 below 2^24; beyond, add in the same
+    // edge order as torch's sequential CPU scatter_add_)
+    for (int64_t e = 0; e < m; ++e) deg[(size_t)dst[e]] += 1.0f;
+    for (int64_t r = 0; r < n; ++r) {
+        const float s = 1.0f / sqrtf(deg[(size_t)r]);
+        deg[(size_t)r] = isinf(s) ? 0.0f : s;
+    }
+    for (int64_t e = 0; e < m; ++e) edge_weight[e] = (deg[(size_t)src[e]] * 1.0f) * deg[(size_t)dst[e]];
+    return RBG_OK;
+}
+
+int rbg_graph_info(const rbg_graph *g, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int *device) {
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_cols) *n_cols = g->n_cols;
+    if (nnz) *nnz = g->nnz;
+    if (device) *device = g->device;
+    return RBG_OK;
+}
+
+int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (!g->h_rowptr.empty()) {
+        if (rowptr)
+            for (int64_t r = 0; r <= g->n_rows; ++r) rowptr[r] = g->h_rowptr[(size_t)r];
+        if (col && g->nnz) memcpy(col, g->h_col.data(), sizeof(int32_t) * (size_t)g->nnz);
+        if (val && g->nnz) memcpy(val, g->h_val.data(), sizeof(float) * (size_t)g->nnz);
+        return RBG_OK;
+    }
+    if (g->device < 0) return fail(RBG_EINVAL, "graph holds no CSR");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    RBG_HIP(hipDeviceSynchronize());
+    if (rowptr) {
+        std::vector<int32_t> tmp((size_t)g->n_rows + 1);
+        RBG_HIP(hipMemcpy(tmp.data(), g->d_rowptr, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r <= g->n_rows; ++r) rowptr[r] = tmp[(size_t)r];
+    }
+    if (col && g->nnz) RBG_HIP(hipMemcpy(col, g->d_col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyDeviceToHost));
+    if (val && g->nnz) RBG_HIP(hipMemcpy(val, g->d_val, sizeof(float) * (size_t)g->nnz, hipMemcpyDeviceToHost));
+    return RBG_OK;
+}
+
+void rbg_graph_destroy(rbg_graph *g) {
+    if (!g) return;
+    free_device(g);
+    delete g;
+}
+
+}  // extern "C"

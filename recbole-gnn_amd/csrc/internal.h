@@ -1,0 +1,93 @@
+// internal.h — shared declarations of librbgnn.so (not part of the public ABI; see include/rbgnn.h)
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "rbgnn.h"
+
+namespace rbg {
+
+// ---- error plumbing ------------------------------------------------------------------------
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+#define RBG_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::rbg::fail(RBG_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                               __FILE__, __LINE__);                                            \
+    } while (0)
+
+// ---- tuning (rbg_set_tuning) ---------------------------------------------------------------
+struct Tuning {
+    int short_max;  // degree <= short_max : one row per lane-group
+    int wave_max;   // degree <= wave_max  : one row per wavefront; above: workgroup tasks
+    int seg_len;    // workgroup rows are cut into segments of this many entries
+};
+Tuning current_tuning();
+
+// One workgroup task: a row (or one segment of a split row).
+struct BlockTask {
+    int32_t row;        // output row
+    int32_t beg, end;   // CSR entry range of this segment
+    int32_t seg, nseg;  // segment index / number of segments of the row (1 = unsplit)
+    int32_t part_base;  // first partial-sum slot of the row (split rows only)
+    int32_t ctr;        // arrival counter index of the row (split rows only)
+    int32_t pad;
+};
+static_assert(sizeof(BlockTask) == 32, "BlockTask must stay 32 bytes (loaded as 2 x int4)");
+
+constexpr int kPartialSlotFloats = 256;  // split-row partial slots are sized for d <= 256
+
+}  // namespace rbg
+
+// The graph handle.  Arrays named d_* live in HBM (device >= 0); h_* on the host.
+struct rbg_graph {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t n_users = -1;  // -1 when built from CSR/COO (unknown split)
+    int device = -1;
+    uint32_t flags = 0;
+
+    // host CSR (always present for host graphs; kept for device graphs with RBG_GRAPH_KEEP_HOST)
+    std::vector<int32_t> h_rowptr;
+    std::vector<int32_t> h_col;
+    std::vector<float> h_val;
+
+    // device CSR
+    int32_t *d_rowptr = nullptr;
+    int32_t *d_col = nullptr;
+    float *d_val = nullptr;
+
+    // degree binning (device): rows sorted by degree descending; the first n_block_rows rows are
+    // workgroup rows (expanded to d_tasks), then n_wave rows, then n_short rows.
+    rbg::Tuning tuning{};
+    int32_t *d_row_order = nullptr;  // [n_rows]; positions [n_block_rows, n_rows) are used by the kernel
+    int64_t n_block_rows = 0, n_wave = 0, n_short = 0;
+    rbg::BlockTask *d_tasks = nullptr;
+    int64_t n_tasks = 0, n_split_rows = 0, n_partial_slots = 0;
+    float *d_partials = nullptr;    // [n_partial_slots][kPartialSlotFloats]
+    uint32_t *d_counters = nullptr;  // [n_split_rows], zero between launches
+    int32_t max_degree = 0;
+};
+
+namespace rbg {
+
+// graph_build.cpp
+int build_host_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
+                   const int64_t *iid, const uint8_t *keep);
+int plan_bins(const rbg_graph *g, std::vector<int32_t> &row_order, std::vector<BlockTask> &tasks,
+              int64_t &n_block_rows, int64_t &n_wave, int64_t &n_short, int64_t &n_split, int64_t &n_slots,
+              int32_t &max_deg);
+int upload_graph(rbg_graph *g);  // host CSR + bins -> device
+int set_device_for(int device);
+
+// spmm.hip — Y[n_rows, d] (row stride ldy) = Â · X (row stride ldx), optionally accumulating.
+int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
+                 hipStream_t s);
+
+}  // namespace rbg

@@ -1,0 +1,523 @@
+// spmm.hip — the hot path: Y = Â·X on gfx950 (MI355X), CSR in HBM, fp32.
+//
+// Replaces LightGCNConv.message_and_aggregate / message+aggregate
+//   (recbole_gnn/model/layers.py:13-20 -> torch_sparse.matmul / PyG gather-scatter)
+// and the layer loop + stack/mean of LightGCN.forward / SGL.forward
+//   (recbole_gnn/model/general_recommender/lightgcn.py:70-81, sgl.py:128-145).
+//
+// Design: HBM/L2-bound gather.  A dense row of d floats is covered by a
+// lane-group of d/4 lanes holding one float4 each, so a 64-wide wavefront has 64/(d/4) lane-groups
+// (4 at d = 64) and every gathered neighbour row is one fully coalesced d*4-byte read.  Rows are
+// degree-binned at graph build (graph_build.cpp):
+//   short rows   (deg <= short_max): one row per lane-group, neighbours visited in column order
+//   wave rows    (deg <= wave_max) : the lane-groups of one wavefront split the row, DPP/bpermute reduce
+//   block rows   (deg  > wave_max) : a 256-thread workgroup per row segment, LDS reduce; rows longer
+//                                    than seg_len are split into segments whose partial sums are added
+//                                    in fixed segment order by the last segment to finish
+// (col,val) are fetched lane-parallel (one coalesced non-temporal read per lane-group chunk) and
+// broadcast with ds_bpermute; U neighbour rows are in flight per lane-group before the FMAs.
+// No float atomics anywhere: the result is bit-stable run to run.
+// The layer-mean of LightGCN.forward is fused into the last layer's epilogue.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "internal.h"
+
+namespace rbg {
+
+struct RowSrc {  // where dense rows live: row r is p0 + r*ld (r < split) or p1 + (r-split)*ld
+    const float *p0;
+    const float *p1;
+    int32_t split;
+    int32_t pad;
+    int64_t ld;
+};
+
+enum { MODE_STORE = 0, MODE_ACCUM = 1, MODE_MEAN = 2 };
+
+struct SpmmParams {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const float *val;
+    const int32_t *row_order;
+    const BlockTask *tasks;
+    float *partials;
+    uint32_t *counters;
+    RowSrc x;
+    float *y;  // may be NULL in MODE_MEAN
+    int64_t ldy;
+    int32_t n_rows;
+    int32_t n_wave, n_short;
+    int32_t pos_wave, pos_short;     // start positions of the two bins inside row_order
+    int32_t blocks_task, blocks_wave;  // grid partition: [tasks | wave rows | short rows]
+    int32_t mode;
+    // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom
+    float *mean_out;
+    RowSrc e0;
+    const float *prev[RBG_MAX_FUSED_LAYERS];
+    int32_t n_prev;
+    float denom;
+};
+
+__device__ __forceinline__ const float *src_row(const RowSrc &s, int r) {
+    const bool lo = r < s.split;
+    const float *base = lo ? s.p0 : s.p1;
+    const int rr = lo ? r : r - s.split;
+    return base + (int64_t)rr * s.ld;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+    return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
+    return make_float4(fmaf(s, x.x, a.x), fmaf(s, x.y, a.y), fmaf(s, x.z, a.z), fmaf(s, x.w, a.w));
+}
+
+// Sum of val[e] * X[col[e], 4*sl .. 4*sl+3] over the chunks of [beg,end) owned by lane-group g of G.
+// A chunk is LPR consecutive entries; lane sl of the group fetches entry sl of the chunk.
+template <int D, int U>
+__device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl) {
+    constexpr int LPR = D / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = beg + g * LPR; e < end; e += G * LPR) {
+        const int idx = e + sl;
+        int c = 0;
+        float v = 0.f;
+        if (idx < end) {
+            c = __builtin_nontemporal_load(p.col + idx);
+            v = __builtin_nontemporal_load(p.val + idx);
+        }
+        const int cnt = min(LPR, end - e);
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            float4 xv[U];
+            float vv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cj = __shfl(c, j + u, LPR);
+                vv[u] = __shfl(v, j + u, LPR);
+                xv[u] = ld4(src_row(p.x, cj) + sl * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma4(vv[u], xv[u], acc);
+        }
+        if (j < cnt) {  // fewer than U entries left in this chunk: issue them together, predicated
+            float4 xv[U - 1];
+            float vv[U - 1];
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                const int src = min(j + u, LPR - 1);
+                const int cj = __shfl(c, src, LPR);
+                const float vj = __shfl(v, src, LPR);
+                const bool on = (j + u) < cnt;
+                vv[u] = on ? vj : 0.f;
+                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on) xv[u] = ld4(src_row(p.x, cj) + sl * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) acc = fma4(vv[u], xv[u], acc);
+        }
+    }
+    return acc;
+}
+
+// Add the lane-groups of a wavefront together (every lane ends with the total of its column slice).
+template <int D>
+__device__ __forceinline__ float4 reduce_groups(float4 a) {
+    constexpr int LPR = D / 4;
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        a.x += __shfl_xor(a.x, off);
+        a.y += __shfl_xor(a.y, off);
+        a.z += __shfl_xor(a.z, off);
+        a.w += __shfl_xor(a.w, off);
+    }
+    return a;
+}
+
+// Row epilogue, executed by the LPR lanes that hold the finished row.
+__device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D) {
+    if (p.mode == MODE_MEAN) {
+        float4 s = ld4(src_row(p.e0, row) + sl * 4);
+        for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + sl * 4));
+        s = add4(s, acc);
+        s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
+        st4(p.mean_out + (int64_t)row * D + sl * 4, s);
+        if (p.y) st4(p.y + (int64_t)row * p.ldy + sl * 4, acc);
+    } else {
+        float *dst = p.y + (int64_t)row * p.ldy + sl * 4;
+        if (p.mode == MODE_ACCUM) acc = add4(acc, ld4(dst));
+        st4(dst, acc);
+    }
+}
+
+template <int D, int U>
+__global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
+    constexpr int LPR = D / 4;
+    constexpr int SUBS = 64 / LPR;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR;
+    const int sl = lane % LPR;
+    const int b = blockIdx.x;
+
+    if (b < p.blocks_task) {
+        // ---- one workgroup per row segment ------------------------------------------------------
+        __shared__ float red[4][D];
+        __shared__ int last_flag;
+        const int4 t0 = *reinterpret_cast<const int4 *>(&p.tasks[b]);
+        const int4 t1 = *(reinterpret_cast<const int4 *>(&p.tasks[b]) + 1);
+        const int row = t0.x, beg = t0.y, end = t0.z, seg = t0.w;
+        const int nseg = t1.x, part_base = t1.y, ctr = t1.z;
+        float4 acc = gather_range<D, U>(p, beg, end, wave * SUBS + sub, 4 * SUBS, sl);
+        acc = reduce_groups<D>(acc);
+        if (sub == 0) st4(&red[wave][sl * 4], acc);
+        __syncthreads();
+        if (wave != 0 || sub != 0) {
+            if (nseg == 1) return;
+        } else {
+            acc = add4(add4(ld4(&red[0][sl * 4]), ld4(&red[1][sl * 4])),
+                       add4(ld4(&red[2][sl * 4]), ld4(&red[3][sl * 4])));
+            if (nseg == 1) {
+                finish_row(p, row, acc, sl, D);
+                return;
+            }
+            // split row: publish this segment's partial sum (plain stores, released below)
+            st4(p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + sl * 4, acc);
+        }
+        // All threads of a split-row task reach this point.  Arrival protocol (guide §6 G16):
+        // drain stores -> barrier -> one lane: agent release, drained, relaxed agent RMW on the row's
+        // counter; the last arriver acquires and adds the partials in segment order.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned old = __hip_atomic_fetch_add(p.counters + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == (unsigned)(nseg - 1));
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // self-cleaning: the next (stream-ordered) launch finds the counter at zero
+                __hip_atomic_store(p.counters + ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last_flag = last;
+        }
+        __syncthreads();
+        if (last_flag && wave == 0 && sub == 0) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < nseg; ++i) {
+                const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + sl * 4;
+                float4 q;  // agent-scope loads: served from L2, never from this CU's L1
+                q.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q.w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s = add4(s, q);
+            }
+            finish_row(p, row, s, sl, D);
+        }
+        return;
+    }
+
+    if (b < p.blocks_task + p.blocks_wave) {
+        // ---- one wavefront per row --------------------------------------------------------------
+        const int slot = (b - p.blocks_task) * 4 + wave;
+        if (slot >= p.n_wave) return;
+        const int row = p.row_order[p.pos_wave + slot];
+        const int beg = p.rowptr[row], end = p.rowptr[row + 1];
+        float4 acc = gather_range<D, U>(p, beg, end, sub, SUBS, sl);
+        acc = reduce_groups<D>(acc);
+        if (sub == 0) finish_row(p, row, acc, sl, D);
+        return;
+    }
+
+    // ---- one lane-group per row (degree-sorted, so the groups of a wave have similar lengths) ----
+    const int slot = ((b - p.blocks_task - p.blocks_wave) * 4 + wave) * SUBS + sub;
+    if (slot >= p.n_short) return;
+    const int row = p.row_order[p.pos_short + slot];
+    const int beg = p.rowptr[row], end = p.rowptr[row + 1];
+    const float4 acc = gather_range<D, U>(p, beg, end, 0, 1, sl);
+    finish_row(p, row, acc, sl, D);
+}
+
+// Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
+__global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, int d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave;
+    if (slot >= p.n_rows) return;
+    const int row = p.row_order[slot];
+    const int beg = p.rowptr[row], end = p.rowptr[row + 1];
+    for (int k0 = 0; k0 < d; k0 += 64) {
+        const int k = k0 + lane;
+        float acc = 0.f;
+        for (int e = beg; e < end; e += 64) {
+            const int idx = e + lane;
+            int c = 0;
+            float v = 0.f;
+            if (idx < end) {
+                c = p.col[idx];
+                v = p.val[idx];
+            }
+            const int cnt = min(64, end - e);
+            for (int j = 0; j < cnt; ++j) {
+                const int cj = __shfl(c, j, 64);
+                const float vj = __shfl(v, j, 64);
+                if (k < d) acc = fmaf(vj, src_row(p.x, cj)[k], acc);
+            }
+        }
+        if (k < d) {
+            if (p.mode == MODE_MEAN) {
+                float s = src_row(p.e0, row)[k];
+                for (int i = 0; i < p.n_prev; ++i) s += p.prev[i][(int64_t)row * d + k];
+                s += acc;
+                p.mean_out[(int64_t)row * d + k] = s / p.denom;
+                if (p.y) p.y[(int64_t)row * p.ldy + k] = acc;
+            } else {
+                float *dst = p.y + (int64_t)row * p.ldy + k;
+                *dst = (p.mode == MODE_ACCUM) ? (*dst + acc) : acc;
+            }
+        }
+    }
+}
+
+// out = (e0 + sum_k layers[k]) / (K+1) — only for K beyond the fused range.
+__global__ void layer_mean_kernel(RowSrc e0, const float *layers, int64_t n_rows, int d, int K, float *out) {
+    const int64_t nd = n_rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / d), k = (int)(i % d);
+        float s = src_row(e0, r)[k];
+        for (int l = 0; l < K; ++l) s += layers[(int64_t)l * nd + i];
+        out[i] = s / (float)(K + 1);
+    }
+}
+
+__global__ void gather_rows_kernel(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,
+                                   int d, int vec) {
+    if (vec) {
+        const int q = d / 4;
+        const int64_t total = n_idx * q;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / q;
+            const int k = (int)(t % q) * 4;
+            st4(dst + i * d + k, ld4(src + idx[i] * lds + k));
+        }
+    } else {
+        const int64_t total = n_idx * d;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / d;
+            const int k = (int)(t % d);
+            dst[i * d + k] = src[idx[i] * lds + k];
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+
+static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static bool vec_ok(const RowSrc &s) { return aligned16(s.p0) && aligned16(s.p1) && (s.ld % 4) == 0; }
+
+static void fill_graph(const rbg_graph *g, SpmmParams &p) {
+    p.rowptr = g->d_rowptr;
+    p.col = g->d_col;
+    p.val = g->d_val;
+    p.row_order = g->d_row_order;
+    p.tasks = g->d_tasks;
+    p.partials = g->d_partials;
+    p.counters = g->d_counters;
+    p.n_rows = (int32_t)g->n_rows;
+    p.n_wave = (int32_t)g->n_wave;
+    p.n_short = (int32_t)g->n_short;
+    p.pos_wave = (int32_t)g->n_block_rows;
+    p.pos_short = (int32_t)(g->n_block_rows + g->n_wave);
+}
+
+template <int D>
+static void grid_for(const rbg_graph *g, SpmmParams &p, int64_t &grid) {
+    constexpr int SUBS = 64 / (D / 4);
+    p.blocks_task = (int32_t)g->n_tasks;
+    p.blocks_wave = (int32_t)((g->n_wave + 3) / 4);
+    const int64_t blocks_short = (g->n_short + 4 * SUBS - 1) / (4 * SUBS);
+    grid = (int64_t)p.blocks_task + p.blocks_wave + blocks_short;
+}
+
+template <int D>
+static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
+    int64_t grid;
+    grid_for<D>(g, p, grid);
+    if (grid == 0) return RBG_OK;
+    if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL((spmm_binned_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+// One SpMM launch with the epilogue described by p (graph fields are filled here).
+static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) {
+    fill_graph(g, p);
+    if (g->n_rows == 0) return RBG_OK;
+    bool vec = (d % 4 == 0) && vec_ok(p.x) && (p.ldy % 4 == 0) && (!p.y || aligned16(p.y));
+    if (p.mode == MODE_MEAN) {
+        vec = vec && vec_ok(p.e0) && aligned16(p.mean_out);
+        for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
+    }
+    if (vec) {
+        switch (d) {
+            case 32: return launch_binned<32>(g, p, s);
+            case 64: return launch_binned<64>(g, p, s);
+            case 128: return launch_binned<128>(g, p, s);
+            case 256: return launch_binned<256>(g, p, s);
+            default: break;
+        }
+    }
+    const int64_t grid = (g->n_rows + 3) / 4;
+    hipLaunchKernelGGL(spmm_generic_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, d);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
+                 hipStream_t s) {
+    SpmmParams p{};
+    p.x = RowSrc{X, X, 0, 0, ldx};
+    p.y = Y;
+    p.ldy = ldy;
+    p.mode = accumulate ? MODE_ACCUM : MODE_STORE;
+    return launch_spmm(g, p, d, s);
+}
+
+static int check_device_graph(const rbg_graph *g) {
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
+    return RBG_OK;
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
+                   int64_t *n_split_rows, int64_t *grid_blocks) {
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (n_short) *n_short = g->n_short;
+    if (n_wave) *n_wave = g->n_wave;
+    if (n_block_tasks) *n_block_tasks = g->n_tasks;
+    if (n_split_rows) *n_split_rows = g->n_split_rows;
+    if (grid_blocks) {
+        SpmmParams p{};
+        int64_t grid = (g->n_rows + 3) / 4;
+        switch (d) {
+            case 32: grid_for<32>(g, p, grid); break;
+            case 64: grid_for<64>(g, p, grid); break;
+            case 128: grid_for<128>(g, p, grid); break;
+            case 256: grid_for<256>(g, p, grid); break;
+            default: break;
+        }
+        *grid_blocks = grid;
+    }
+    return RBG_OK;
+}
+
+int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, void *stream) {
+    clear_error();
+    int rc = check_device_graph(g);
+    if (rc) return rc;
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    if (g->n_rows == 0) return RBG_OK;
+    if (!X || !Y) return fail(RBG_EINVAL, "X or Y is NULL");
+    if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
+    if ((rc = set_device_for(g->device))) return rc;
+    return spmm_strided(g, X, d, Y, d, d, accumulate, (hipStream_t)stream);
+}
+
+int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64_t n_users, const float *user_emb,
+                             const float *item_emb, float *out_mean, float *layers, int d, int K, uint32_t flags,
+                             void *stream) {
+    clear_error();
+    if (!graphs || n_graphs < 1) return fail(RBG_EINVAL, "graphs is NULL or empty");
+    if (K < 0) return fail(RBG_EINVAL, "K = %d", K);
+    if (n_graphs != 1 && n_graphs != K) return fail(RBG_ESHAPE, "n_graphs = %d but K = %d", n_graphs, K);
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    int rc;
+    for (int i = 0; i < n_graphs; ++i) {
+        if ((rc = check_device_graph(graphs[i]))) return rc;
+        if (graphs[i]->n_rows != graphs[0]->n_rows || graphs[i]->n_cols != graphs[0]->n_rows ||
+            graphs[i]->device != graphs[0]->device)
+            return fail(RBG_ESHAPE, "graph %d is not a square graph of the same size/device as graph 0", i);
+    }
+    const rbg_graph *g0 = graphs[0];
+    const int64_t n = g0->n_rows;
+    if (g0->n_cols != n) return fail(RBG_ESHAPE, "graph is not square (%lld x %lld)", (long long)n, (long long)g0->n_cols);
+    if (g0->n_users >= 0 && n_users != g0->n_users)
+        return fail(RBG_ESHAPE, "n_users = %lld but the graph was built with %lld", (long long)n_users,
+                    (long long)g0->n_users);
+    if (n_users < 0 || n_users > n) return fail(RBG_ESHAPE, "n_users = %lld out of [0,%lld]", (long long)n_users, (long long)n);
+    if (n == 0) return RBG_OK;
+    if (!out_mean || (n_users > 0 && !user_emb) || (n_users < n && !item_emb)) return fail(RBG_EINVAL, "NULL embedding pointer");
+    if (K > 1 && !layers) return fail(RBG_EINVAL, "layers buffer is NULL (needed for K > 1)");
+    if ((flags & RBG_FWD_KEEP_LAST_LAYER) && K > 0 && !layers) return fail(RBG_EINVAL, "layers buffer is NULL");
+    if ((rc = set_device_for(g0->device))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t nd = n * d;
+    const RowSrc e0{user_emb ? user_emb : item_emb, item_emb ? item_emb : user_emb, (int32_t)n_users, 0, d};
+    if (K == 0) {  // mean of the single layer E0
+        if (n_users) RBG_HIP(hipMemcpyAsync(out_mean, user_emb, sizeof(float) * n_users * d, hipMemcpyDeviceToDevice, s));
+        if (n_users < n)
+            RBG_HIP(hipMemcpyAsync(out_mean + n_users * d, item_emb, sizeof(float) * (n - n_users) * d,
+                                   hipMemcpyDeviceToDevice, s));
+        return RBG_OK;
+    }
+    const bool fused = (K - 1) <= RBG_MAX_FUSED_LAYERS;
+    if (!fused && !layers) return fail(RBG_EINVAL, "layers buffer is NULL");
+    for (int k = 0; k < K; ++k) {
+        const rbg_graph *g = graphs[n_graphs == 1 ? 0 : k];
+        SpmmParams p{};
+        if (k == 0)
+            p.x = e0;
+        else
+            p.x = RowSrc{layers + (int64_t)(k - 1) * nd, layers + (int64_t)(k - 1) * nd, 0, 0, d};
+        p.ldy = d;
+        const bool last = (k == K - 1);
+        if (last && fused) {
+            p.mode = MODE_MEAN;
+            p.y = (flags & RBG_FWD_KEEP_LAST_LAYER) ? layers + (int64_t)k * nd : nullptr;
+            p.mean_out = out_mean;
+            p.e0 = e0;
+            p.n_prev = K - 1;
+            for (int i = 0; i < K - 1; ++i) p.prev[i] = layers + (int64_t)i * nd;
+            p.denom = (float)(K + 1);
+        } else {
+            p.mode = MODE_STORE;
+            p.y = layers + (int64_t)k * nd;
+        }
+        if ((rc = launch_spmm(g, p, d, s))) return rc;
+    }
+    if (!fused) {
+        hipLaunchKernelGGL(layer_mean_kernel, dim3(2048), dim3(256), 0, s, e0, layers, n, d, K, out_mean);
+        RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx, int d,
+                        void *stream) {
+    clear_error();
+    if (n_idx < 0 || d <= 0 || lds < d) return fail(RBG_ESHAPE, "n_idx = %lld, d = %d, lds = %lld", (long long)n_idx, d, (long long)lds);
+    if (n_idx == 0) return RBG_OK;
+    if (!src || !idx || !dst) return fail(RBG_EINVAL, "NULL pointer");
+    const int vec = (d % 4 == 0) && (lds % 4 == 0) && aligned16(src) && aligned16(dst);
+    const int64_t work = n_idx * (vec ? d / 4 : d);
+    const int64_t grid = std::min<int64_t>((work + 255) / 256, 4096);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, lds, idx, dst,
+                       n_idx, d, vec);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+}  // extern "C"

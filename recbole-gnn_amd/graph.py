@@ -1,0 +1,219 @@
+"""Graph handles: the normalized user-item adjacency resident in HBM.
+
+Host-side mirror of ``GeneralGraphDataset.get_norm_adj_mat`` / ``edge_index_to_adj_t``
+(reference ``recbole_gnn/data/dataset.py:41-79``) above the C ABI of ``include/rbgnn.h``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import c_i64, c_int, c_vp, check, lib
+
+
+def _np_i64(a):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _device_index(device):
+    """None / 'cpu' -> -1 (host graph); 'cuda' / 'cuda:i' / int / torch.device -> GPU index."""
+    if device is None:
+        return -1
+    if isinstance(device, int):
+        return device
+    dev = torch.device(device)
+    if dev.type == "cpu":
+        return -1
+    if dev.type != "cuda":
+        raise ValueError(f"unsupported device {device!r}")
+    return torch.cuda.current_device() if dev.index is None else dev.index
+
+
+class GraphHandle:
+    """Owns one ``rbg_graph*``.  Opaque to models, exactly like the reference's ``self.edge_index``
+    (a torch_sparse SparseTensor when ``enable_sparse``; abstract_recommender.py:15-18)."""
+
+    def __init__(self, ptr, symmetric, n_users=None):
+        self._ptr = c_vp(ptr)
+        self.symmetric = bool(symmetric)
+        n_rows, n_cols, nnz, dev = c_i64(), c_i64(), c_i64(), c_int()
+        check(lib.rbg_graph_info(self._ptr, ctypes.byref(n_rows), ctypes.byref(n_cols), ctypes.byref(nnz),
+                                 ctypes.byref(dev)))
+        self.n_rows, self.n_cols, self.nnz, self.device_index = n_rows.value, n_cols.value, nnz.value, dev.value
+        self.n_users = n_users
+        self._transpose = None
+
+    # ---- constructors -----------------------------------------------------------------------
+    @classmethod
+    def from_interactions(cls, uid, iid, n_users, n_items, device=None, keep=None, flags=0):
+        """dataset.py:60-75 (keep=None) or one SGL view (sgl.py:107-126) when ``keep`` is a mask."""
+        uid, iid = _np_i64(uid), _np_i64(iid)
+        if uid.shape != iid.shape or uid.ndim != 1:
+            raise ValueError("uid and iid must be 1-D arrays of equal length")
+        out = c_vp()
+        if keep is None:
+            check(lib.rbg_graph_create(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
+                                       _device_index(device), flags))
+        else:
+            if isinstance(keep, torch.Tensor):
+                keep = keep.detach().cpu().numpy()
+            keep = np.ascontiguousarray(keep, dtype=np.uint8)
+            if keep.shape != uid.shape:
+                raise ValueError("keep mask must have one entry per interaction")
+            check(lib.rbg_graph_create_masked(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
+                                              _ptr(keep), _device_index(device), flags))
+        return cls(out.value, symmetric=True, n_users=int(n_users))
+
+    @classmethod
+    def from_csr(cls, rowptr, col, val, n_cols, device=None, symmetric=False, flags=0):
+        rowptr = _np_i64(rowptr)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        out = c_vp()
+        check(lib.rbg_graph_create_csr(ctypes.byref(out), rowptr.shape[0] - 1, n_cols, _ptr(rowptr), _ptr(col),
+                                       _ptr(val), _device_index(device), flags))
+        return cls(out.value, symmetric=symmetric)
+
+    @classmethod
+    def from_edge_index(cls, edge_index, edge_weight, num_nodes, device=None, symmetric=True, flags=0):
+        """The reference's dense-branch pair (dataset.py:77-79): target rows gather from sources."""
+        ei = _np_i64(edge_index)
+        if ei.ndim != 2 or ei.shape[0] != 2:
+            raise ValueError("edge_index must be [2, nnz]")
+        w = edge_weight.detach().cpu().numpy() if isinstance(edge_weight, torch.Tensor) else edge_weight
+        w = np.ascontiguousarray(w, dtype=np.float32)
+        if w.shape != (ei.shape[1],):
+            raise ValueError("edge_weight must be [nnz]")
+        out = c_vp()
+        check(lib.rbg_graph_create_coo(ctypes.byref(out), num_nodes, ei.shape[1], _ptr(ei), _ptr(w),
+                                       _device_index(device), flags))
+        return cls(out.value, symmetric=symmetric)
+
+    # ---- queries ----------------------------------------------------------------------------
+    @property
+    def ptr(self):
+        if not self._ptr:
+            raise RuntimeError("graph handle was destroyed")
+        return self._ptr
+
+    @property
+    def is_device(self):
+        return self.device_index >= 0
+
+    @property
+    def device(self):
+        return torch.device("cuda", self.device_index) if self.is_device else torch.device("cpu")
+
+    def export_csr(self):
+        rowptr = np.empty(self.n_rows + 1, dtype=np.int64)
+        col = np.empty(self.nnz, dtype=np.int32)
+        val = np.empty(self.nnz, dtype=np.float32)
+        check(lib.rbg_graph_export_csr(self.ptr, _ptr(rowptr), _ptr(col), _ptr(val)))
+        return rowptr, col, val
+
+    def bins(self, d):
+        vals = [c_i64() for _ in range(5)]
+        check(lib.rbg_graph_bins(self.ptr, d, *[ctypes.byref(v) for v in vals]))
+        keys = ("n_short", "n_wave", "n_block_tasks", "n_split_rows", "grid_blocks")
+        return dict(zip(keys, (v.value for v in vals)))
+
+    def transpose(self):
+        """Handle of Â^T (needed for the backward of a non-symmetric graph)."""
+        if self.symmetric:
+            return self
+        if self._transpose is None:
+            rowptr, col, val = self.export_csr()
+            rows = np.repeat(np.arange(self.n_rows, dtype=np.int64), np.diff(rowptr))
+            order = np.lexsort((rows, col))
+            t_rowptr = np.zeros(self.n_cols + 1, dtype=np.int64)
+            np.add.at(t_rowptr, col.astype(np.int64) + 1, 1)
+            t_rowptr = np.cumsum(t_rowptr)
+            self._transpose = GraphHandle.from_csr(t_rowptr, rows[order].astype(np.int32), val[order], self.n_rows,
+                                                   device=self.device if self.is_device else None)
+            self._transpose._transpose = self
+        return self._transpose
+
+    def to(self, device):
+        """Mirror of ``SparseTensor.to(device)`` (abstract_recommender.py:18)."""
+        idx = _device_index(device)
+        if idx == self.device_index:
+            return self
+        rowptr, col, val = self.export_csr()
+        out = c_vp()
+        check(lib.rbg_graph_create_csr(ctypes.byref(out), self.n_rows, self.n_cols, _ptr(rowptr), _ptr(col), _ptr(val),
+                                       idx, 0))
+        return GraphHandle(out.value, symmetric=self.symmetric, n_users=self.n_users)
+
+    def destroy(self):
+        if getattr(self, "_ptr", None):
+            lib.rbg_graph_destroy(self._ptr)
+            self._ptr = c_vp()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return (f"GraphHandle({self.n_rows}x{self.n_cols}, nnz={self.nnz}, "
+                f"device={'cuda:%d' % self.device_index if self.is_device else 'host'})")
+
+
+def norm_edges(uid, iid, n_users, n_items):
+    """``get_norm_adj_mat(enable_sparse=False)`` (dataset.py:60-66,77-79) -> CPU tensors
+    (edge_index int64 [2, 2E], edge_weight fp32 [2E])."""
+    uid, iid = _np_i64(uid), _np_i64(iid)
+    e = uid.shape[0]
+    edge_index = np.empty((2, 2 * e), dtype=np.int64)
+    edge_weight = np.empty(2 * e, dtype=np.float32)
+    check(lib.rbg_norm_edges(n_users, n_items, e, _ptr(uid), _ptr(iid), _ptr(edge_index), _ptr(edge_weight)))
+    return torch.from_numpy(edge_index), torch.from_numpy(edge_weight)
+
+
+def set_tuning(short_max=-1, wave_max=-1, seg_len=-1):
+    check(lib.rbg_set_tuning(short_max, wave_max, seg_len))
+
+
+def get_tuning():
+    a, b, c = c_int(), c_int(), c_int()
+    check(lib.rbg_get_tuning(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return {"short_max": a.value, "wave_max": b.value, "seg_len": c.value}
+
+
+def device_count():
+    n = c_int()
+    check(lib.rbg_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class InteractionDataset:
+    """The slice of ``GeneralGraphDataset`` the path touches (dataset.py:24-79): the training
+    interactions plus ``user_num`` / ``item_num`` (both include the PAD id 0), ``is_sparse`` and
+    ``get_norm_adj_mat``."""
+
+    def __init__(self, uid, iid, n_users, n_items):
+        self.uid = torch.as_tensor(_np_i64(uid))
+        self.iid = torch.as_tensor(_np_i64(iid))
+        self.user_num = int(n_users)
+        self.item_num = int(n_items)
+        self.is_sparse = True  # the HIP engine is the sparse backend; it is always available
+
+    def num(self, field):
+        return self.user_num if field == "user_id" else self.item_num
+
+    def get_norm_adj_mat(self, enable_sparse=False, device=None):
+        """dataset.py:49-79.  enable_sparse truthy -> (GraphHandle, None) [the SparseTensor branch];
+        falsy (None / False, the reference default) -> (edge_index, edge_weight) CPU tensors."""
+        if enable_sparse:
+            return GraphHandle.from_interactions(self.uid, self.iid, self.user_num, self.item_num, device=device), None
+        return norm_edges(self.uid, self.iid, self.user_num, self.item_num)

@@ -1,0 +1,356 @@
+"""Host-side mirror of the reference's model interface for the accelerated path:
+``GeneralGraphRecommender`` (recbole_gnn/model/abstract_recommender.py:7-20), ``LightGCN``
+(general_recommender/lightgcn.py), ``NGCF`` (ngcf.py) and ``SGL``'s propagation (sgl.py:73-145,235-240).
+
+Same attribute names (``edge_index``, ``edge_weight``, ``use_sparse``, ``restore_user_e`` ...),
+same method names and argument meaning, same cache/invalidate behaviour; the arithmetic runs in
+librbgnn.so.  ``config`` is any mapping (missing keys read as None, like RecBole's Config);
+``interaction`` is any mapping of field name -> tensor.  RecBole's own pieces used on the path
+(BPRLoss, EmbLoss, Xavier init; recbole==1.1.1) are restated minimally below.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import GraphHandle, InteractionDataset
+
+
+class _Config(dict):
+    def __getitem__(self, k):
+        return self.get(k, None)
+
+
+class BPRLoss(nn.Module):
+    """recbole.model.loss.BPRLoss: -log(gamma + sigmoid(pos - neg)).mean(), gamma = 1e-10."""
+
+    def __init__(self, gamma=1e-10):
+        super().__init__()
+        self.gamma = gamma
+
+    def forward(self, pos_score, neg_score):
+        return -torch.log(self.gamma + torch.sigmoid(pos_score - neg_score)).mean()
+
+
+class EmbLoss(nn.Module):
+    """recbole.model.loss.EmbLoss(norm=2)."""
+
+    def __init__(self, norm=2):
+        super().__init__()
+        self.norm = norm
+
+    def forward(self, *embeddings, require_pow=False):
+        emb_loss = torch.zeros(1, device=embeddings[-1].device)
+        if require_pow:
+            for e in embeddings:
+                emb_loss = emb_loss + torch.pow(input=torch.norm(e, p=self.norm), exponent=self.norm)
+            emb_loss = emb_loss / embeddings[-1].shape[0]
+            emb_loss = emb_loss / self.norm
+        else:
+            for e in embeddings:
+                emb_loss = emb_loss + torch.norm(e, p=self.norm)
+            emb_loss = emb_loss / embeddings[-1].shape[0]
+        return emb_loss
+
+
+def xavier_uniform_initialization(module):
+    if isinstance(module, nn.Embedding):
+        nn.init.xavier_uniform_(module.weight.data)
+    elif isinstance(module, nn.Linear):
+        nn.init.xavier_uniform_(module.weight.data)
+        if module.bias is not None:
+            nn.init.constant_(module.bias.data, 0)
+
+
+def xavier_normal_initialization(module):
+    if isinstance(module, nn.Embedding):
+        nn.init.xavier_normal_(module.weight.data)
+    elif isinstance(module, nn.Linear):
+        nn.init.xavier_normal_(module.weight.data)
+        if module.bias is not None:
+            nn.init.constant_(module.bias.data, 0)
+
+
+class GeneralGraphRecommender(nn.Module):
+    """abstract_recommender.py:7-20.  Asks the dataset for Â, decides ``use_sparse`` and moves the
+    graph to the device.  With ``enable_sparse`` falsy the reference's ``(edge_index, edge_weight)``
+    tensors are kept (API parity) and the same normalized graph is also placed in HBM as a handle —
+    both branches run the one CSR kernel."""
+
+    USER_ID, ITEM_ID, NEG_ITEM_ID = "user_id", "item_id", "neg_item_id"
+
+    def __init__(self, config, dataset):
+        super().__init__()
+        config = _Config(config)
+        self.config = config
+        self.device = torch.device(config["device"] or "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("the MI355X engine needs config['device'] = 'cuda' (no CPU path)")
+        self.n_users = dataset.num(self.USER_ID)
+        self.n_items = dataset.num(self.ITEM_ID)
+        self.dataset = dataset
+        self.use_sparse = bool(config["enable_sparse"] and dataset.is_sparse)
+        if self.use_sparse:
+            self.edge_index, self.edge_weight = dataset.get_norm_adj_mat(enable_sparse=True, device=self.device)
+            self.graph = self.edge_index
+        else:
+            ei, ew = dataset.get_norm_adj_mat(enable_sparse=config["enable_sparse"])
+            self.edge_index, self.edge_weight = ei.to(self.device), ew.to(self.device)
+            self.graph = GraphHandle.from_interactions(dataset.uid, dataset.iid, self.n_users, self.n_items,
+                                                       device=self.device)
+
+
+class LightGCN(GeneralGraphRecommender):
+    """general_recommender/lightgcn.py:36-133."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self.latent_dim = config["embedding_size"] or 64
+        self.n_layers = config["n_layers"] if config["n_layers"] is not None else 2
+        self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
+        self.require_pow = bool(config["require_pow"])
+        self.fused = config["fused_forward"] if config["fused_forward"] is not None else True
+
+        self.user_embedding = nn.Embedding(self.n_users, self.latent_dim)
+        self.item_embedding = nn.Embedding(self.n_items, self.latent_dim)
+        self.gcn_conv = ops.LightGCNConv(dim=self.latent_dim)
+        self.mf_loss = BPRLoss()
+        self.reg_loss = EmbLoss()
+        self.restore_user_e = None
+        self.restore_item_e = None
+        self.apply(xavier_uniform_initialization)
+        self.other_parameter_name = ["restore_user_e", "restore_item_e"]
+        self.to(self.device)
+
+    def get_ego_embeddings(self):
+        return torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
+
+    def forward(self):
+        if self.fused:  # K launches, no cat / stack / mean passes (lightgcn.py:70-81 in one call)
+            mean = ops.lightgcn_forward(self.graph, self.user_embedding.weight, self.item_embedding.weight,
+                                        self.n_layers)
+        else:  # the reference's op-by-op structure on the same kernel
+            all_embeddings = self.get_ego_embeddings()
+            embeddings_list = [all_embeddings]
+            for _ in range(self.n_layers):
+                all_embeddings = self.gcn_conv(all_embeddings, self.graph, None)
+                embeddings_list.append(all_embeddings)
+            mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+        return torch.split(mean, [self.n_users, self.n_items])
+
+    def calculate_loss(self, interaction):
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        user = interaction[self.USER_ID]
+        pos_item = interaction[self.ITEM_ID]
+        neg_item = interaction[self.NEG_ITEM_ID]
+        user_all, item_all = self.forward()
+        u_e, pos_e, neg_e = user_all[user], item_all[pos_item], item_all[neg_item]
+        pos_scores = torch.mul(u_e, pos_e).sum(dim=1)
+        neg_scores = torch.mul(u_e, neg_e).sum(dim=1)
+        mf_loss = self.mf_loss(pos_scores, neg_scores)
+        reg_loss = self.reg_loss(self.user_embedding(user), self.item_embedding(pos_item),
+                                 self.item_embedding(neg_item), require_pow=self.require_pow)
+        return mf_loss + self.reg_weight * reg_loss
+
+    def predict(self, interaction):
+        user = interaction[self.USER_ID]
+        item = interaction[self.ITEM_ID]
+        user_all, item_all = self.forward()
+        return torch.mul(user_all[user], item_all[item]).sum(dim=1)
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID]
+        if self.restore_user_e is None or self.restore_item_e is None:
+            with torch.no_grad():
+                self.restore_user_e, self.restore_item_e = self.forward()
+        u_embeddings = ops.gather_rows(self.restore_user_e, user)
+        scores = ops.score(u_embeddings, self.restore_item_e)
+        return scores.view(-1)
+
+
+class NGCF(GeneralGraphRecommender):
+    """general_recommender/ngcf.py:36-149, at node_dropout = 0 (edge dropout, ngcf.py:74-90, is not
+    part of the accelerated path).  ``message_dropout`` defaults to 0 here: the reference's
+    ``nn.Dropout(p)(x)`` (ngcf.py:97) is active even in eval, so parity is defined at 0."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self.embedding_size = config["embedding_size"] or 64
+        self.hidden_size_list = [self.embedding_size] + list(config["hidden_size_list"] or [64, 64, 64])
+        self.node_dropout = config["node_dropout"] or 0.0
+        self.message_dropout = config["message_dropout"] or 0.0
+        self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
+        if self.node_dropout != 0:
+            raise NotImplementedError("node_dropout > 0 (ngcf.py:74-90) is outside the accelerated path")
+        self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)
+        self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
+        self.GNNlayers = nn.ModuleList(
+            ops.BiGNNConv(i, o) for i, o in zip(self.hidden_size_list[:-1], self.hidden_size_list[1:]))
+        self.mf_loss = BPRLoss()
+        self.reg_loss = EmbLoss()
+        self.restore_user_e = None
+        self.restore_item_e = None
+        self.apply(xavier_normal_initialization)
+        self.other_parameter_name = ["restore_user_e", "restore_item_e"]
+        self.to(self.device)
+
+    def get_ego_embeddings(self):
+        return torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
+
+    def forward(self):
+        if not torch.is_grad_enabled() and self.message_dropout == 0:
+            return self._forward_fused()
+        all_embeddings = self.get_ego_embeddings()
+        embeddings_list = [all_embeddings]
+        for gnn in self.GNNlayers:
+            all_embeddings = gnn(all_embeddings, self.graph, None)
+            all_embeddings = F.leaky_relu(all_embeddings, negative_slope=0.2)
+            all_embeddings = nn.Dropout(self.message_dropout)(all_embeddings)
+            all_embeddings = F.normalize(all_embeddings, p=2, dim=1)
+            embeddings_list += [all_embeddings]
+        ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
+        return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])
+
+    def _forward_fused(self):
+        """Inference: every layer writes straight into its column block of the concatenated
+        [N, sum(d)] buffer (ngcf.py:100) with the LeakyReLU + L2-normalize tail fused."""
+        n = self.n_users + self.n_items
+        widths = self.hidden_size_list
+        out = torch.empty((n, sum(widths)), dtype=torch.float32, device=self.device)
+        out[: self.n_users, : widths[0]] = self.user_embedding.weight
+        out[self.n_users:, : widths[0]] = self.item_embedding.weight
+        off = 0
+        for gnn, d_in, d_out in zip(self.GNNlayers, widths[:-1], widths[1:]):
+            x = out[:, off: off + d_in]
+            y = out[:, off + d_in: off + d_in + d_out]
+            ops.bignn_conv_raw(self.graph, x, gnn.lin1.weight, gnn.lin1.bias, gnn.lin2.weight, gnn.lin2.bias, out=y,
+                               leaky_norm=True, slope=0.2)
+            off += d_in
+        return torch.split(out, [self.n_users, self.n_items])
+
+    def calculate_loss(self, interaction):
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        user = interaction[self.USER_ID]
+        pos_item = interaction[self.ITEM_ID]
+        neg_item = interaction[self.NEG_ITEM_ID]
+        user_all, item_all = self.forward()
+        u_e, pos_e, neg_e = user_all[user], item_all[pos_item], item_all[neg_item]
+        pos_scores = torch.mul(u_e, pos_e).sum(dim=1)
+        neg_scores = torch.mul(u_e, neg_e).sum(dim=1)
+        mf_loss = self.mf_loss(pos_scores, neg_scores)
+        reg_loss = self.reg_loss(u_e, pos_e, neg_e)
+        return mf_loss + self.reg_weight * reg_loss
+
+    def predict(self, interaction):
+        user = interaction[self.USER_ID]
+        item = interaction[self.ITEM_ID]
+        user_all, item_all = self.forward()
+        return torch.mul(user_all[user], item_all[item]).sum(dim=1)
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID]
+        if self.restore_user_e is None or self.restore_item_e is None:
+            with torch.no_grad():
+                self.restore_user_e, self.restore_item_e = self.forward()
+        u_embeddings = ops.gather_rows(self.restore_user_e, user)
+        scores = ops.score(u_embeddings, self.restore_item_e)
+        return scores.view(-1)
+
+
+class SGL(GeneralGraphRecommender):
+    """The propagation side of general_recommender/sgl.py: view construction (:73-126), ``forward``
+    with an optional per-layer graph list (:128-145) and ``full_sort_predict`` (:235-240).  The SSL /
+    BPR losses (:147-209) are a "next" row in SURVEY.md §8(f) and are not restated here."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self._user = dataset.uid
+        self._item = dataset.iid
+        self.embed_dim = config["embedding_size"] or 64
+        self.n_layers = int(config["n_layers"] if config["n_layers"] is not None else 3)
+        self.aug_type = config["type"] or "ED"
+        self.drop_ratio = config["drop_ratio"] if config["drop_ratio"] is not None else 0.1
+        self.user_embedding = nn.Embedding(self.n_users, self.embed_dim)
+        self.item_embedding = nn.Embedding(self.n_items, self.embed_dim)
+        self.gcn_conv = ops.LightGCNConv(dim=self.embed_dim)
+        self.restore_user_e = None
+        self.restore_item_e = None
+        self.apply(xavier_uniform_initialization)
+        self.other_parameter_name = ["restore_user_e", "restore_item_e"]
+        self.sub_graph1 = self.sub_graph2 = None
+        self.to(self.device)
+
+    def train(self, mode: bool = True):
+        t = super().train(mode=mode)
+        if mode:
+            self.graph_construction()
+        return t
+
+    def graph_construction(self):
+        if self.aug_type in ("ND", "ED"):
+            self.sub_graph1 = [self.random_graph_augment()] * self.n_layers
+            self.sub_graph2 = [self.random_graph_augment()] * self.n_layers
+        elif self.aug_type == "RW":
+            self.sub_graph1 = [self.random_graph_augment() for _ in range(self.n_layers)]
+            self.sub_graph2 = [self.random_graph_augment() for _ in range(self.n_layers)]
+
+    def random_graph_augment(self):
+        """sgl.py:93-126: sample with numpy's global RNG exactly as the reference does, then rebuild
+        and re-normalize the view (native builder, keep-mask form)."""
+        def rand_sample(high, size=None, replace=True):
+            return np.random.choice(np.arange(high), size=size, replace=replace)
+
+        n_inter = len(self._user)
+        keep_mask = np.zeros(n_inter, dtype=np.uint8)
+        if self.aug_type == "ND":
+            drop_user = rand_sample(self.n_users, size=int(self.n_users * self.drop_ratio), replace=False)
+            drop_item = rand_sample(self.n_items, size=int(self.n_items * self.drop_ratio), replace=False)
+            mask = np.isin(self._user.numpy(), drop_user)
+            mask |= np.isin(self._item.numpy(), drop_item)
+            keep_mask[~mask] = 1
+        elif self.aug_type in ("ED", "RW"):
+            keep = rand_sample(n_inter, size=int(n_inter * (1 - self.drop_ratio)), replace=False)
+            keep_mask[keep] = 1
+        graph = GraphHandle.from_interactions(self._user, self._item, self.n_users, self.n_items, device=self.device,
+                                              keep=keep_mask)
+        return graph, None
+
+    def forward(self, graph=None):
+        if graph is None:
+            graphs = [self.graph]
+        else:
+            graphs = [g for g, _ in graph]
+            if all(g is graphs[0] for g in graphs):
+                graphs = graphs[:1]
+        mean = ops.lightgcn_forward(graphs, self.user_embedding.weight, self.item_embedding.weight, self.n_layers)
+        return torch.split(mean, [self.n_users, self.n_items], dim=0)
+
+    def propagate_views(self):
+        """The three propagations of one SGL training step (sgl.py:219-221): the full graph and the two
+        augmented views.  Returns [(user_all, item_all)] x 3."""
+        if self.sub_graph1 is None:
+            self.graph_construction()
+        return [self.forward(), self.forward(self.sub_graph1), self.forward(self.sub_graph2)]
+
+    def predict(self, interaction):
+        if self.restore_user_e is None or self.restore_item_e is None:
+            with torch.no_grad():
+                self.restore_user_e, self.restore_item_e = self.forward()
+        user = self.restore_user_e[interaction[self.USER_ID]]
+        item = self.restore_item_e[interaction[self.ITEM_ID]]
+        return torch.sum(user * item, dim=1)
+
+    def full_sort_predict(self, interaction):
+        if self.restore_user_e is None or self.restore_item_e is None:
+            with torch.no_grad():
+                self.restore_user_e, self.restore_item_e = self.forward()
+        user = ops.gather_rows(self.restore_user_e, interaction[self.USER_ID])
+        return ops.score(user, self.restore_item_e)

@@ -1,0 +1,269 @@
+"""Operators: thin torch wrappers over the C ABI (tensors go in as ``data_ptr()``, the current HIP
+stream as ``torch.cuda.current_stream().cuda_stream``).  Mirrors ``recbole_gnn/model/layers.py``
+(LightGCNConv :8-23, BiGNNConv :41-67) so call sites read like the reference's.
+
+Everything here needs a GPU-resident graph: there is no CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import c_vp, check, lib
+from .graph import GraphHandle
+
+
+def _stream(t):
+    return c_vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _check_dense(t, name, graph=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP engine has no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if graph is not None and graph.device_index != t.device.index:
+        raise RuntimeError(f"{name} is on {t.device} but the graph is on cuda:{graph.device_index}")
+
+
+def _require_device_graph(graph):
+    if not isinstance(graph, GraphHandle):
+        raise TypeError(f"expected a GraphHandle, got {type(graph)}")
+    if not graph.is_device:
+        raise RuntimeError("operator called with a host graph; create it with device='cuda'")
+
+
+def spmm_raw(graph, x, out=None, accumulate=False):
+    """Y = Â·X (no autograd).  x: [n_cols, d] contiguous fp32 on the graph's GPU."""
+    _require_device_graph(graph)
+    _check_dense(x, "x", graph)
+    if x.dim() != 2 or x.shape[0] != graph.n_cols:
+        raise ValueError(f"x must be [{graph.n_cols}, d], got {tuple(x.shape)}")
+    x = x.contiguous()
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an explicit out tensor")
+        out = torch.empty((graph.n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    else:
+        _check_dense(out, "out", graph)
+        if tuple(out.shape) != (graph.n_rows, x.shape[1]) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [n_rows, d] tensor")
+    with torch.cuda.device(x.device):
+        check(lib.rbg_spmm_f32(graph.ptr, c_vp(x.data_ptr()), c_vp(out.data_ptr()), x.shape[1], int(bool(accumulate)),
+                               _stream(x)))
+    return out
+
+
+class _Spmm(torch.autograd.Function):
+    """Autograd for Y = Â·X.  backward = Â^T·dY — the same kernel, because Â is symmetric
+    (dataset.py:62-64 builds both directions; SGL views too, sgl.py:113-115)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        ctx.graph = graph
+        return spmm_raw(graph, x)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return spmm_raw(ctx.graph.transpose(), grad_out.contiguous()), None
+
+
+def spmm(graph, x):
+    return _Spmm.apply(x, graph)
+
+
+# Graph handles for models that hold the reference's dense pair (edge_index, edge_weight).
+_coo_cache = {}
+
+
+def graph_from_pair(edge_index, edge_weight, num_nodes, device):
+    key = (edge_index.data_ptr(), edge_weight.data_ptr(), edge_index.shape[1], int(num_nodes), str(device))
+    g = _coo_cache.get(key)
+    if g is None:
+        g = GraphHandle.from_edge_index(edge_index, edge_weight, num_nodes, device=device, symmetric=False)
+        if len(_coo_cache) > 64:
+            _coo_cache.clear()
+        _coo_cache[key] = g
+    return g
+
+
+class LightGCNConv(nn.Module):
+    """recbole_gnn/model/layers.py:8-23.  ``forward(x, edge_index, edge_weight)``: ``edge_index`` is
+    either a GraphHandle (the ``enable_sparse`` branch, where the reference holds a SparseTensor and
+    ``edge_weight`` is None) or the int64 ``[2, nnz]`` tensor with fp32 ``edge_weight`` (the default
+    branch); both run the same CSR kernel."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x, edge_index, edge_weight=None):
+        if isinstance(edge_index, GraphHandle):
+            return spmm(edge_index, x)
+        return spmm(graph_from_pair(edge_index, edge_weight, x.shape[0], x.device), x)
+
+    def __repr__(self):
+        return "{}({})".format(self.__class__.__name__, self.dim)
+
+
+# ---- fused LightGCN propagation ------------------------------------------------------------
+
+def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False):
+    """cat -> K x (Â·) -> mean, one C call (lightgcn.py:60-81).  Returns (mean [N,d], layers or None)."""
+    graphs = list(graphs) if isinstance(graphs, (list, tuple)) else [graphs]
+    for g in graphs:
+        _require_device_graph(g)
+    _check_dense(user_w, "user embedding", graphs[0])
+    _check_dense(item_w, "item embedding", graphs[0])
+    user_w, item_w = user_w.contiguous(), item_w.contiguous()
+    n_users, d = user_w.shape
+    n = n_users + item_w.shape[0]
+    if item_w.shape[1] != d:
+        raise ValueError("user and item embeddings differ in width")
+    if n != graphs[0].n_rows:
+        raise ValueError(f"graph has {graphs[0].n_rows} nodes but the tables hold {n} rows")
+    out = torch.empty((n, d), dtype=torch.float32, device=user_w.device)
+    layers = torch.empty((max(n_layers, 1), n, d), dtype=torch.float32, device=user_w.device)
+    arr = (c_vp * len(graphs))(*[g.ptr for g in graphs])
+    flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_DEFAULT
+    with torch.cuda.device(user_w.device):
+        check(lib.rbg_lightgcn_forward_f32(arr, len(graphs), n_users, c_vp(user_w.data_ptr()), c_vp(item_w.data_ptr()),
+                                           c_vp(out.data_ptr()), c_vp(layers.data_ptr()), d, n_layers, flags,
+                                           _stream(user_w)))
+    return out, (layers if keep_layers else None)
+
+
+class _LightGCNForward(torch.autograd.Function):
+    """mean_k(Â^k E0) is linear in E0, so backward needs no saved activations:
+    dE0 = c + Â_0(c + Â_1(... + Â_{K-1} c)), c = dOut/(K+1)  (Horner, K SpMMs; Â symmetric)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, n_layers, *graphs):
+        ctx.graphs, ctx.n_layers, ctx.n_users = graphs, n_layers, user_w.shape[0]
+        out, _ = lightgcn_forward_raw(graphs, user_w, item_w, n_layers)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        k_layers = ctx.n_layers
+        c = (grad_out / float(k_layers + 1)).contiguous()
+        t = c
+        for k in reversed(range(k_layers)):
+            g = ctx.graphs[0] if len(ctx.graphs) == 1 else ctx.graphs[k]
+            nxt = c.clone()
+            spmm_raw(g.transpose(), t, out=nxt, accumulate=True)
+            t = nxt
+        return (t[:ctx.n_users], t[ctx.n_users:], None) + (None,) * len(ctx.graphs)
+
+
+def lightgcn_forward(graphs, user_w, item_w, n_layers):
+    """Differentiable fused propagation -> [N, d] mean embedding."""
+    graphs = list(graphs) if isinstance(graphs, (list, tuple)) else [graphs]
+    return _LightGCNForward.apply(user_w, item_w, n_layers, *graphs)
+
+
+# ---- NGCF ----------------------------------------------------------------------------------
+
+def bignn_conv_raw(graph, x, w1, b1, w2, b2, out=None, leaky_norm=False, slope=0.2):
+    """BiGNNConv.forward (layers.py:54-58) [+ LeakyReLU + L2-normalize, ngcf.py:96,98].
+    x may be a column slice of a wider row-major buffer (row stride = x.stride(0)); same for out.
+    Returns (out, P) with P = Â·x."""
+    _require_device_graph(graph)
+    _check_dense(x, "x", graph)
+    for t, nm in ((w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")):
+        _check_dense(t, nm, graph)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be 2-D with unit column stride")
+    n, d_in = x.shape
+    d_out = w1.shape[0]
+    if tuple(w1.shape) != (d_out, d_in) or tuple(w2.shape) != (d_out, d_in):
+        raise ValueError("W1/W2 must be [d_out, d_in]")
+    if out is None:
+        out = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+    elif out.stride(1) != 1 or tuple(out.shape) != (n, d_out):
+        raise ValueError("out must be [N, d_out] with unit column stride")
+    p = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
+    flags = _lib.BIGNN_LEAKY_NORM if leaky_norm else _lib.BIGNN_CONV_ONLY
+    with torch.cuda.device(x.device):
+        check(lib.rbg_bignn_conv_f32(graph.ptr, c_vp(x.data_ptr()), x.stride(0), c_vp(w1.contiguous().data_ptr()),
+                                     c_vp(b1.contiguous().data_ptr()), c_vp(w2.contiguous().data_ptr()),
+                                     c_vp(b2.contiguous().data_ptr()), c_vp(out.data_ptr()), out.stride(0),
+                                     c_vp(p.data_ptr()), d_in, d_out, flags, float(slope), _stream(x)))
+    return out, p
+
+
+class _BiGNNConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, graph):
+        out, p = bignn_conv_raw(graph, x, w1, b1, w2, b2)
+        ctx.graph = graph
+        ctx.save_for_backward(x, p, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, p, w1, w2 = ctx.saved_tensors
+        g = g.contiguous()
+        gt = g @ w1            # d/d(P+X)
+        gi = g @ w2            # d/d(P*X)
+        gp = gt + gi * x
+        gx = gt + gi * p + spmm_raw(ctx.graph.transpose(), gp.contiguous())
+        gw1 = g.t() @ (p + x)
+        gw2 = g.t() @ (p * x)
+        gb = g.sum(dim=0)
+        return gx, gw1, gb, gw2, gb, None
+
+
+class BiGNNConv(nn.Module):
+    """recbole_gnn/model/layers.py:41-67: lin1(ÂX + X) + lin2(ÂX ⊙ X)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin1 = nn.Linear(in_features=in_channels, out_features=out_channels)
+        self.lin2 = nn.Linear(in_features=in_channels, out_features=out_channels)
+
+    def forward(self, x, edge_index, edge_weight=None):
+        graph = edge_index if isinstance(edge_index, GraphHandle) else graph_from_pair(edge_index, edge_weight,
+                                                                                       x.shape[0], x.device)
+        return _BiGNNConv.apply(x, self.lin1.weight, self.lin1.bias, self.lin2.weight, self.lin2.bias, graph)
+
+    def __repr__(self):
+        return "{}({},{})".format(self.__class__.__name__, self.in_channels, self.out_channels)
+
+
+# ---- scoring -------------------------------------------------------------------------------
+
+def score(u, items):
+    """u [B, d] · items [n, d]^T -> [B, n]  (lightgcn.py:131), fp32 MFMA."""
+    _check_dense(u, "u")
+    _check_dense(items, "items")
+    if u.dim() != 2 or items.dim() != 2 or u.shape[1] != items.shape[1]:
+        raise ValueError("u must be [B, d] and items [n, d]")
+    if u.stride(1) != 1:
+        u = u.contiguous()
+    if items.stride(1) != 1:
+        items = items.contiguous()
+    out = torch.empty((u.shape[0], items.shape[0]), dtype=torch.float32, device=u.device)
+    with torch.cuda.device(u.device):
+        check(lib.rbg_score_f32(c_vp(u.data_ptr()), u.stride(0) if u.shape[0] > 1 else u.shape[1],
+                                c_vp(items.data_ptr()), items.stride(0) if items.shape[0] > 1 else items.shape[1],
+                                c_vp(out.data_ptr()), u.shape[0], items.shape[0], u.shape[1], _stream(u)))
+    return out
+
+
+def gather_rows(src, idx):
+    """src[idx] for a 2-D fp32 src with unit column stride (lightgcn.py:128)."""
+    _check_dense(src, "src")
+    idx = idx.to(device=src.device, dtype=torch.int64).contiguous()
+    if src.stride(1) != 1:
+        src = src.contiguous()
+    out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        check(lib.rbg_gather_rows_f32(c_vp(src.data_ptr()), src.stride(0) if src.shape[0] > 1 else src.shape[1],
+                                      c_vp(idx.data_ptr()), c_vp(out.data_ptr()), idx.shape[0], src.shape[1],
+                                      _stream(src)))
+    return out

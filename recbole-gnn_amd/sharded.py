@@ -1,0 +1,244 @@
+"""Node-range sharding of the propagation across the GPUs of one node.
+
+The reference is single-device (no distributed code at all), so there is no reference interface to
+mirror here; this module extends ``LightGCN.forward`` (lightgcn.py:70-81) to P ranks:
+
+* rank p owns a set of nodes (users AND items, so loads balance by nnz) — rows of Â and of every
+  layer's embedding matrix;
+* Y[owned] = Â[owned, :]·X needs X for the columns its rows reference: local ones plus a HALO.
+  The halo is trimmed: per peer q only the rows p actually references (``send lists``), packed with
+  ``rbg_gather_rows_f32`` and exchanged with one all-to-all-v per layer (RCCL over xGMI);
+* the local CSR is split into an interior part (columns owned by p) and a halo part (columns in the
+  receive buffer), so the interior SpMM runs on the compute stream WHILE the exchange runs on a
+  second stream; then Y += Â_halo·X_halo.
+
+Host logic (partition plan, send lists) is numpy; the weights are computed from GLOBAL degrees with
+the same fp32 operations as the single-GPU builder, so a sharded run reproduces the single-GPU
+matrix bit for bit.  The compute backend is injectable: the default is the HIP engine (needs a GPU);
+tests inject a CPU backend to check plan + exchange under gloo.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ---- partition plan (pure numpy) ---------------------------------------------------------------
+
+def balanced_ranges(deg, world):
+    """Contiguous ranges with (almost) equal total degree.  Returns owner[len(deg)]."""
+    n = len(deg)
+    owner = np.zeros(n, dtype=np.int32)
+    if n == 0 or world == 1:
+        return owner
+    c = np.cumsum(deg.astype(np.float64) + 1e-3)  # +eps keeps isolated nodes spread too
+    bounds = np.searchsorted(c, c[-1] * np.arange(1, world) / world, side="left")
+    owner[:] = np.searchsorted(bounds, np.arange(n), side="right")
+    return owner
+
+
+def default_partition(uid, iid, n_users, n_items, world):
+    """Users and items are each cut into `world` contiguous nnz-balanced ranges."""
+    du = np.bincount(uid, minlength=n_users)
+    di = np.bincount(iid, minlength=n_items)
+    return np.concatenate([balanced_ranges(du, world), balanced_ranges(di, world)])
+
+
+def striped_partition(n_users, n_items, world):
+    """Node r of each side -> rank (r-1) % world (PAD id 0 -> rank 0): the layout of the synthetic
+    generator's community blocks (synth.powerlaw_bipartite(n_blocks=world))."""
+    pu = (np.arange(n_users) - 1) % world
+    pi = (np.arange(n_items) - 1) % world
+    pu[0] = 0
+    pi[0] = 0
+    return np.concatenate([pu, pi]).astype(np.int32)
+
+
+class ShardPlan:
+    """Everything rank `rank` needs: its rows, the two local CSR blocks, send / receive lists."""
+
+    def __init__(self, rank, world, owned, n_users_owned, int_csr, halo_csr, halo_ids, recv_counts, send_idx,
+                 send_counts):
+        self.rank, self.world = rank, world
+        self.owned = owned                    # global node ids, ascending (users first)
+        self.n_users_owned = n_users_owned
+        self.int_csr = int_csr                # (rowptr, col(local idx), val), n_cols = len(owned)
+        self.halo_csr = halo_csr              # (rowptr, col(halo slot), val), n_cols = len(halo_ids)
+        self.halo_ids = halo_ids              # global ids of the halo slots, grouped by owner rank
+        self.recv_counts = recv_counts        # [world] rows received from each peer
+        self.send_idx = send_idx              # local row indices to pack, grouped by destination rank
+        self.send_counts = send_counts        # [world]
+
+    @property
+    def n_owned(self):
+        return len(self.owned)
+
+    @property
+    def n_halo(self):
+        return len(self.halo_ids)
+
+
+def _csr_from_sorted(rows_local, cols, vals, n_rows):
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(rowptr, rows_local + 1, 1)
+    return np.cumsum(rowptr), cols.astype(np.int32), vals.astype(np.float32)
+
+
+def build_plans(uid, iid, n_users, n_items, world, owner=None, ranks=None):
+    """Plans for `ranks` (default: all).  Deterministic and communication-free: every rank holds the
+    interaction list (as in the reference, where the dataset is replicated on the host)."""
+    uid = np.ascontiguousarray(uid, dtype=np.int64)
+    iid = np.ascontiguousarray(iid, dtype=np.int64)
+    n = n_users + n_items
+    if owner is None:
+        owner = default_partition(uid, iid, n_users, n_items, world)
+    owner = np.asarray(owner, dtype=np.int32)
+    assert owner.shape == (n,) and owner.min(initial=0) >= 0 and owner.max(initial=0) < world
+    # directed edges of the symmetric graph: target row <- source col  (dataset.py:60-64)
+    rows = np.concatenate([uid, iid + n_users])
+    cols = np.concatenate([iid + n_users, uid])
+    # gcn_norm on GLOBAL degrees, fp32 exactly as the single-GPU builder (graph_build.cpp)
+    deg = np.bincount(rows, minlength=n).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        dis = (np.float32(1.0) / np.sqrt(deg)).astype(np.float32)
+    dis[np.isinf(dis)] = 0.0
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    vals = (dis[rows] * np.float32(1.0)) * dis[cols]
+    row_owner, col_owner = owner[rows], owner[cols]
+    # who needs what: unique (needing rank, remote column) pairs
+    remote = row_owner != col_owner
+    need_key = np.unique(row_owner[remote].astype(np.int64) * n + cols[remote])
+    need_rank, need_col = need_key // n, need_key % n
+    need_owner = owner[need_col]
+    local_index = np.full(n, -1, dtype=np.int64)
+    plans = {}
+    for p in (range(world) if ranks is None else ranks):
+        owned = np.flatnonzero(owner == p)
+        local_index[:] = -1
+        local_index[owned] = np.arange(len(owned))
+        mine = row_owner == p
+        r_l = local_index[rows[mine]]
+        c, v, interior = cols[mine], vals[mine], col_owner[mine] == p
+        int_csr = _csr_from_sorted(r_l[interior], local_index[c[interior]], v[interior], len(owned))
+        # halo slots: remote columns this rank needs, ordered by (owner, global id)
+        sel = need_rank == p
+        h_cols, h_owner = need_col[sel], need_owner[sel]
+        ho = np.lexsort((h_cols, h_owner))
+        halo_ids = h_cols[ho]
+        recv_counts = np.bincount(h_owner, minlength=world).astype(np.int64)
+        slot = np.full(n, -1, dtype=np.int64)
+        slot[halo_ids] = np.arange(len(halo_ids))
+        halo_csr = _csr_from_sorted(r_l[~interior], slot[c[~interior]], v[~interior], len(owned))
+        # send lists: what every q needs from p, in q's halo order (ascending global id per owner)
+        sel = need_owner == p
+        s_rank, s_col = need_rank[sel], need_col[sel]
+        so = np.lexsort((s_col, s_rank))
+        send_idx = local_index[s_col[so]]
+        send_counts = np.bincount(s_rank, minlength=world).astype(np.int64)
+        plans[p] = ShardPlan(p, world, owned, int(np.count_nonzero(owned < n_users)), int_csr, halo_csr, halo_ids,
+                             recv_counts, send_idx, send_counts)
+    return plans
+
+
+# ---- compute backends ----------------------------------------------------------------------------
+
+class HipBackend:
+    """The product backend: librbgnn.so kernels on this rank's GPU."""
+
+    def __init__(self, device):
+        from . import ops
+        from .graph import GraphHandle
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HipBackend needs a cuda device (no CPU path)")
+        self._ops, self._GraphHandle = ops, GraphHandle
+
+    def make_graph(self, csr, n_cols):
+        return self._GraphHandle.from_csr(csr[0], csr[1], csr[2], n_cols, device=self.device)
+
+    def spmm(self, graph, x, out, accumulate):
+        return self._ops.spmm_raw(graph, x, out=out, accumulate=accumulate)
+
+    def gather_rows(self, src, idx):
+        return self._ops.gather_rows(src, idx)
+
+
+# ---- the sharded propagation ---------------------------------------------------------------------
+
+class ShardedPropagation:
+    """K-layer LightGCN propagation over a ShardPlan.  ``transport``: "nccl" (device buffers straight
+    into RCCL all_to_all_single, exchange on a second HIP stream) or "staged" (buffers staged through
+    the host and exchanged with point-to-point send/recv; works with gloo — used by tests and when two
+    ranks must share one GPU)."""
+
+    def __init__(self, plan, backend, group=None, transport="nccl"):
+        self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
+        dev = getattr(backend, "device", torch.device("cpu"))
+        self.device = dev
+        self.g_int = backend.make_graph(plan.int_csr, plan.n_owned)
+        self.g_halo = backend.make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
+        self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
+        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.bytes_received_per_layer = None
+
+    # -- halo exchange ---------------------------------------------------------------------------
+    def _exchange_staged(self, x, halo):
+        plan = self.plan
+        send = self.backend.gather_rows(x, self.send_idx).cpu() if len(plan.send_idx) else x.new_zeros((0, x.shape[1])).cpu()
+        recv = torch.empty((plan.n_halo, x.shape[1]), dtype=x.dtype)
+        ops, so, ro = [], 0, 0
+        for q in range(plan.world):
+            sc, rc = int(plan.send_counts[q]), int(plan.recv_counts[q])
+            if q != plan.rank:
+                if sc:
+                    ops.append(dist.P2POp(dist.isend, send[so:so + sc].contiguous(), q, group=self.group))
+                if rc:
+                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], q, group=self.group))
+            so += sc
+            ro += rc
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        halo.copy_(recv)
+
+    def _exchange_nccl(self, x, halo):
+        plan = self.plan
+        send = self.backend.gather_rows(x, self.send_idx)
+        dist.all_to_all_single(halo, send, output_split_sizes=[int(c) for c in plan.recv_counts],
+                               input_split_sizes=[int(c) for c in plan.send_counts], group=self.group)
+
+    def spmm(self, x):
+        """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows."""
+        plan = self.plan
+        d = x.shape[1]
+        y = torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
+        if plan.world == 1:
+            return self.backend.spmm(self.g_int, x, y, False)
+        halo = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
+        if self.transport == "nccl":
+            # all_to_all_single is a collective: every rank takes part every layer, even one whose
+            # own send and receive lists are empty.
+            main = torch.cuda.current_stream(x.device)
+            self.comm_stream.wait_stream(main)            # x is ready
+            with torch.cuda.stream(self.comm_stream):
+                self._exchange_nccl(x, halo[: plan.n_halo])
+            self.backend.spmm(self.g_int, x, y, False)    # overlaps with the exchange
+            main.wait_stream(self.comm_stream)
+        else:
+            self.backend.spmm(self.g_int, x, y, False)
+            self._exchange_staged(x, halo[: plan.n_halo])  # point-to-point: only non-empty pairs talk
+        if self.g_halo is not None:
+            self.backend.spmm(self.g_halo, halo, y, True)
+        return y
+
+    def forward(self, e0, n_layers):
+        """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users."""
+        acc = e0.clone()
+        x = e0
+        for _ in range(n_layers):
+            x = self.spmm(x)
+            acc += x
+        acc /= float(n_layers + 1)
+        return acc

@@ -1,0 +1,451 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded
+inputs, against the committed golden vectors, and — at BASELINE.json's full sizes — through
+size-independent properties.  Tolerance: 1e-5 fp32 (BASELINE.json north_star), applied as
+|hip - oracle| <= 1e-5 * max(1, max|oracle|); graph construction is bit-exact.
+Needs a real MI355X: run with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import known_graphs
+from oracle import coracle as C
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def close(got, ref, tol=TOL):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if ref.size else 0.0
+    assert err <= tol * scale, f"max abs err {err:.3e} > {tol * scale:.3e}"
+    return err
+
+
+def randn(shape, seed, dev):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float32).to(dev)
+
+
+# ---- graph construction on the device -------------------------------------------------------
+
+def test_device_graph_is_bit_exact(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    assert h.is_device
+    rowptr, col, val = h.export_csr()
+    assert np.array_equal(rowptr, g["rowptr"]) and np.array_equal(col, g["col"]) and np.array_equal(val, g["val"])
+    v = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=g["sgl_keep"])
+    vrp, vcol, vval = v.export_csr()
+    assert np.array_equal(vrp, g["sgl_rowptr"]) and np.array_equal(vcol, g["sgl_col"]) and np.array_equal(vval, g["sgl_val"])
+
+
+# ---- SpMM -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", list(known_graphs()))
+def test_spmm_known_answers(rbg, cuda, name):
+    kg = known_graphs()[name]
+    n = kg["n_users"] + kg["n_items"]
+    h = rbg.GraphHandle.from_interactions(kg["uid"], kg["iid"], kg["n_users"], kg["n_items"], device=cuda)
+    for d in (4, 64):
+        x = randn((n, d), 3, cuda)
+        y = rbg.ops.spmm_raw(h, x)
+        close(y, kg["dense"] @ x.cpu().numpy().astype(np.float64))
+        assert torch.all(y[0] == 0) and torch.all(y[kg["n_users"]] == 0)  # PAD rows are written as zeros
+
+
+@pytest.mark.parametrize("d", [64, 32, 128, 256, 8, 100, 1, 67])
+def test_spmm_vs_oracle(rbg, cuda, golden, d):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    x = randn((nu + ni, d), 11 + d, cuda)
+    x_poison = torch.full_like(x, float("nan"))
+    y = rbg.ops.spmm_raw(h, x, out=x_poison)  # every output element must be overwritten
+    ref = C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], x.cpu().numpy())
+    close(y, ref)
+    y2 = rbg.ops.spmm_raw(h, x, out=y.clone(), accumulate=True)
+    close(y2, 2 * ref)
+    assert torch.equal(rbg.ops.spmm_raw(h, x), y)  # bit-stable run to run (no float atomics)
+
+
+def test_spmm_golden_layers(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    x = torch.from_numpy(g["e0_d16"]).to(cuda)
+    for k in (1, 2, 3):
+        x = rbg.ops.spmm_raw(h, x)
+        close(x, g[f"e{k}_d16"])
+
+
+@pytest.mark.parametrize("tuning", [(0, 0, 64), (2, 4, 64), (4, 16, 128), (1000, 1000, 4096)])
+def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning):
+    """Force rows through each mapping: lane-group, wavefront, workgroup, and split workgroup rows whose
+    partial sums are combined by the last-arriving segment."""
+    old = rbg.get_tuning()
+    try:
+        rbg.set_tuning(*tuning)
+        rng = np.random.default_rng(5)
+        nu, ni = 40, 3000
+        # user 1 is a hub with 2500 items (degree >> seg_len), user 2 has 700, the rest are short
+        uid = np.concatenate([np.full(2500, 1), np.full(700, 2), rng.integers(3, nu, 4000)])
+        iid = np.concatenate([rng.permutation(ni - 1)[:2500] + 1, rng.permutation(ni - 1)[:700] + 1,
+                              rng.integers(1, ni, 4000)])
+        h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+        bins = h.bins(64)
+        if tuning[2] == 64 and tuning[1] < 1000:
+            assert bins["n_split_rows"] >= 2
+        rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+        for d in (64, 128, 32, 256):
+            x = randn((nu + ni, d), d, cuda)
+            ref = C.spmm(rowptr, col, val, x.cpu().numpy())
+            for _ in range(3):  # the split-row counters must be back at zero after every launch
+                close(rbg.ops.spmm_raw(h, x), ref)
+        hn = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, flags=rbg._lib.GRAPH_NATURAL_ORDER)
+        x = randn((nu + ni, 64), 1, cuda)
+        close(rbg.ops.spmm_raw(hn, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
+    finally:
+        rbg.set_tuning(**old)
+
+
+def test_spmm_empty_and_rectangular(rbg, cuda):
+    h = rbg.GraphHandle.from_interactions([], [], 3, 4, device=cuda)
+    y = rbg.ops.spmm_raw(h, randn((7, 64), 0, cuda))
+    assert y.shape == (7, 64) and torch.all(y == 0)
+    rowptr = np.array([0, 2, 2, 3], dtype=np.int64)
+    col = np.array([0, 4, 1], dtype=np.int32)
+    val = np.array([0.5, 2.0, -1.0], dtype=np.float32)
+    hr = rbg.GraphHandle.from_csr(rowptr, col, val, 5, device=cuda)
+    x = randn((5, 64), 2, cuda)
+    y = rbg.ops.spmm_raw(hr, x)
+    close(y, torch.stack([0.5 * x[0] + 2.0 * x[4], torch.zeros(64, device=cuda), -x[1]]))
+    with pytest.raises(ValueError):
+        rbg.ops.spmm_raw(hr, randn((4, 64), 2, cuda))
+    with pytest.raises(RuntimeError):
+        rbg.ops.spmm_raw(hr, torch.zeros(5, 64))  # CPU tensor: no CPU path
+
+
+def test_dense_pair_branch_runs_the_same_kernel(rbg, cuda, golden):
+    """LightGCNConv.forward(x, edge_index, edge_weight) with the reference's default (non-sparse) pair."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    ei, ew = rbg.norm_edges(g["uid"], g["iid"], nu, ni)
+    conv = rbg.LightGCNConv(64)
+    x = randn((nu + ni, 64), 9, cuda)
+    y_pair = conv(x, ei.to(cuda), ew.to(cuda))
+    y_ref = O.conv_dense(x.cpu(), ei, ew)
+    close(y_pair, y_ref)
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    close(conv(x, h, None), y_ref)
+
+
+# ---- LightGCN forward -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("k_layers", [0, 1, 2, 3, 4, 10])
+def test_lightgcn_forward_vs_oracle(rbg, cuda, golden, k_layers):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    e0 = torch.from_numpy(g["e0_d64"]).to(cuda)
+    mean, layers = rbg.ops.lightgcn_forward_raw(h, e0[:nu], e0[nu:], k_layers, keep_layers=True)
+    ref, ref_layers = C.lightgcn_forward(g["rowptr"], g["col"].astype(np.int64), g["val"], g["e0_d64"][:nu],
+                                         g["e0_d64"][nu:], k_layers, return_layers=True)
+    close(mean, ref)
+    for k in range(k_layers):
+        close(layers[k], ref_layers[k + 1])
+    if k_layers == 3:
+        close(mean, g["mean_k3_d64"])
+    # PAD rows: mean[pad] = E0[pad] / (K+1)
+    close(mean[0], e0[0] / (k_layers + 1))
+    close(mean[nu], e0[nu] / (k_layers + 1))
+
+
+def test_lightgcn_forward_golden_d16(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    e0 = torch.from_numpy(g["e0_d16"]).to(cuda)
+    for k in (1, 2, 3):
+        mean, _ = rbg.ops.lightgcn_forward_raw(h, e0[:nu], e0[nu:], k)
+        close(mean, g[f"mean_k{k}_d16"])
+    err64 = np.abs(mean.cpu().numpy() - g["mean_k3_d16_f64"]).max()
+    assert err64 <= TOL
+
+
+def test_sgl_per_layer_graphs(rbg, cuda, golden):
+    """SGL.forward(graph=[view]*K or K different views), sgl.py:136-139."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    rng = np.random.default_rng(3)
+    masks = [(rng.random(len(g["uid"])) < 0.9).astype(np.uint8) for _ in range(3)]
+    views = [rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=m) for m in masks]
+    csrs = [C.build_norm_csr(g["uid"], g["iid"], nu, ni, keep=m) for m in masks]
+    e0 = torch.from_numpy(g["e0_d64"])
+    convs = [lambda t, c=c: torch.from_numpy(C.spmm(c[0], c[1], c[2], t.numpy())) for c in csrs]
+    u_ref, i_ref = O.lightgcn_forward(e0[:nu], e0[nu:], convs, 3)
+    mean, _ = rbg.ops.lightgcn_forward_raw(views, e0[:nu].to(cuda), e0[nu:].to(cuda), 3)
+    close(mean, torch.cat([u_ref, i_ref]))
+
+
+# ---- models: the reference's interface ------------------------------------------------------
+
+def make_model(rbg, cls, cuda, golden, **cfg):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    torch.manual_seed(4)
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3}
+    config.update(cfg)
+    return cls(config, ds), ds
+
+
+@pytest.mark.parametrize("enable_sparse", [True, None, False])
+def test_lightgcn_model_forward_and_full_sort(rbg, cuda, golden, enable_sparse):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=enable_sparse)
+    assert model.use_sparse == bool(enable_sparse)
+    if not enable_sparse:
+        assert model.edge_index.shape == (2, 2 * len(g["uid"])) and model.edge_weight.is_cuda
+    uw = model.user_embedding.weight.detach().cpu().numpy()
+    iw = model.item_embedding.weight.detach().cpu().numpy()
+    ref = C.lightgcn_forward(g["rowptr"], g["col"].astype(np.int64), g["val"], uw, iw, 3)
+    with torch.no_grad():
+        user_all, item_all = model.forward()
+    assert user_all.shape == (nu, 64) and item_all.shape == (ni, 64)
+    close(torch.cat([user_all, item_all]), ref)
+    model.fused = False  # the reference's op-by-op structure over the same kernel
+    with torch.no_grad():
+        u2, i2 = model.forward()
+    close(torch.cat([u2, i2]), ref)
+    model.fused = True
+    users = torch.tensor([1, 2, nu - 1], device=cuda)
+    scores = model.full_sort_predict({"user_id": users})
+    assert scores.shape == (3 * ni,)
+    ref_scores = O.full_sort_predict(torch.from_numpy(ref[:nu]), torch.from_numpy(ref[nu:]), users.cpu())
+    close(scores, ref_scores)
+    # cache semantics (lightgcn.py:85-86,125-126)
+    assert model.restore_user_e is not None
+    cached = model.restore_user_e
+    model.full_sort_predict({"user_id": users})
+    assert model.restore_user_e is cached
+    batch = {"user_id": torch.tensor([1, 2, 3], device=cuda), "item_id": torch.tensor([1, 2, 3], device=cuda),
+             "neg_item_id": torch.tensor([4, 5, 6], device=cuda)}
+    model.calculate_loss(batch)
+    assert model.restore_user_e is None and model.restore_item_e is None
+
+
+def test_lightgcn_training_gradients(rbg, cuda, golden):
+    """calculate_loss + backward through the fused op == torch autograd through the oracle's dense branch."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True)
+    batch = {"user_id": torch.tensor([1, 2, 3, 7], device=cuda), "item_id": torch.tensor([1, 2, 3, 9], device=cuda),
+             "neg_item_id": torch.tensor([4, 5, 6, 11], device=cuda)}
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    uw = model.user_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    iw = model.item_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    ei, ew = O.get_norm_adj_mat(g["uid"], g["iid"], nu, ni, enable_sparse=False)
+    u_all, i_all = O.lightgcn_forward(uw, iw, lambda t: O.conv_dense(t, ei, ew), 3)
+    u, p, q = batch["user_id"].cpu(), batch["item_id"].cpu(), batch["neg_item_id"].cpu()
+    pos = (u_all[u] * i_all[p]).sum(1)
+    neg = (u_all[u] * i_all[q]).sum(1)
+    mf = -torch.log(1e-10 + torch.sigmoid(pos - neg)).mean()
+    reg = (uw[u].norm() ** 2 + iw[p].norm() ** 2 + iw[q].norm() ** 2) / 4 / 2
+    ref_loss = mf + 1e-5 * reg
+    ref_loss.backward()
+    close(loss, ref_loss)
+    close(model.user_embedding.weight.grad, uw.grad, tol=1e-6)
+    close(model.item_embedding.weight.grad, iw.grad, tol=1e-6)
+    # unfused structure gives the same gradients
+    model.zero_grad()
+    model.fused = False
+    model.calculate_loss(batch).backward()
+    close(model.user_embedding.weight.grad, uw.grad, tol=1e-6)
+
+
+def test_sgl_model_views(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    for aug in ("ED", "RW", "ND"):
+        model, _ = make_model(rbg, rbg.SGL, cuda, golden, enable_sparse=True, type=aug, drop_ratio=0.1)
+        np.random.seed(11)
+        model.train()
+        assert len(model.sub_graph1) == 3
+        if aug == "RW":
+            assert model.sub_graph1[0][0] is not model.sub_graph1[1][0]
+        else:
+            assert model.sub_graph1[0][0] is model.sub_graph1[1][0]
+        # replay the reference's sampling with the same global numpy stream
+        np.random.seed(11)
+        n_views = 6 if aug == "RW" else 2
+        refs = []
+        for _ in range(n_views):
+            if aug == "ND":
+                du = np.random.choice(np.arange(nu), size=int(nu * 0.1), replace=False)
+                di = np.random.choice(np.arange(ni), size=int(ni * 0.1), replace=False)
+                keep = ~(np.isin(g["uid"], du) | np.isin(g["iid"], di))
+            else:
+                idx = np.random.choice(np.arange(len(g["uid"])), size=int(len(g["uid"]) * 0.9), replace=False)
+                keep = np.zeros(len(g["uid"]), dtype=bool)
+                keep[idx] = True
+            refs.append(C.build_norm_csr(g["uid"], g["iid"], nu, ni, keep=keep.astype(np.uint8)))
+        got = model.sub_graph1[0][0].export_csr()
+        assert all(np.array_equal(a, b) for a, b in zip(got, refs[0]))
+        with torch.no_grad():
+            outs = model.propagate_views()
+        uw = model.user_embedding.weight.detach().cpu()
+        iw = model.item_embedding.weight.detach().cpu()
+        sub1 = refs[:3] if aug == "RW" else [refs[0]] * 3
+        convs = [lambda t, c=c: torch.from_numpy(C.spmm(c[0], c[1], c[2], t.numpy())) for c in sub1]
+        u_ref, i_ref = O.lightgcn_forward(uw, iw, convs, 3)
+        close(torch.cat(outs[1]), torch.cat([u_ref, i_ref]))
+        s = model.full_sort_predict({"user_id": torch.tensor([1, 5], device=cuda)})
+        assert s.shape == (2, ni)  # SGL returns the un-flattened matrix (sgl.py:240)
+
+
+# ---- NGCF -----------------------------------------------------------------------------------
+
+def test_bignn_conv_golden(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    e0 = torch.from_numpy(g["e0_d16"]).to(cuda)
+    p0 = [torch.from_numpy(g[f"ngcf_{nm}_0"]).to(cuda) for nm in ("w1", "b1", "w2", "b2")]
+    out, p = rbg.ops.bignn_conv_raw(h, e0, *p0)
+    close(out, g["bignn_conv0"])
+    close(p, g["e1_d16"])
+    # whole forward: 16 -> 16 -> 8, fused LeakyReLU + L2 normalize, written into the concat buffer
+    n = nu + ni
+    buf = torch.empty((n, 40), device=cuda)
+    buf[:, :16] = e0
+    p1 = [torch.from_numpy(g[f"ngcf_{nm}_1"]).to(cuda) for nm in ("w1", "b1", "w2", "b2")]
+    rbg.ops.bignn_conv_raw(h, buf[:, :16], *p0, out=buf[:, 16:32], leaky_norm=True)
+    rbg.ops.bignn_conv_raw(h, buf[:, 16:32], *p1, out=buf[:, 32:40], leaky_norm=True)
+    close(buf, g["ngcf_out"])
+
+
+@pytest.mark.parametrize("dims", [(64, 64), (64, 32), (32, 128), (128, 64), (20, 12), (64, 200)])
+def test_bignn_conv_shapes(rbg, cuda, golden, dims):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    d_in, d_out = dims
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    x = randn((nu + ni, d_in), 21, cuda)
+    w1 = randn((d_out, d_in), 22, cuda) * (2.0 / (d_in + d_out)) ** 0.5
+    w2 = randn((d_out, d_in), 23, cuda) * (2.0 / (d_in + d_out)) ** 0.5
+    b1, b2 = randn((d_out,), 24, cuda) * 0.1, randn((d_out,), 25, cuda) * 0.1
+    conv = lambda t: torch.from_numpy(C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], t.numpy()))  # noqa: E731
+    ref = O.bignn_conv(x.cpu(), conv, w1.cpu(), b1.cpu(), w2.cpu(), b2.cpu())
+    out, _ = rbg.ops.bignn_conv_raw(h, x, w1, b1, w2, b2)
+    close(out, ref)
+    ref_n = torch.nn.functional.normalize(torch.nn.functional.leaky_relu(ref, 0.2), p=2, dim=1)
+    out_n, _ = rbg.ops.bignn_conv_raw(h, x, w1, b1, w2, b2, leaky_norm=True)
+    close(out_n, ref_n)
+
+
+def test_ngcf_model(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.NGCF, cuda, golden, enable_sparse=True, hidden_size_list=[64, 64, 64])
+    for layer in model.GNNlayers:  # non-zero biases exercise the bias path
+        torch.nn.init.normal_(layer.lin1.bias, std=0.05)
+        torch.nn.init.normal_(layer.lin2.bias, std=0.05)
+    conv = lambda t: torch.from_numpy(C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], t.numpy()))  # noqa: E731
+    params = [(l.lin1.weight.detach().cpu(), l.lin1.bias.detach().cpu(), l.lin2.weight.detach().cpu(),
+               l.lin2.bias.detach().cpu()) for l in model.GNNlayers]
+    u_ref, i_ref = O.ngcf_forward(model.user_embedding.weight.detach().cpu(), model.item_embedding.weight.detach().cpu(),
+                                  conv, params)
+    with torch.no_grad():
+        u, i = model.forward()  # fused inference path
+    assert u.shape == (nu, 256) and i.shape == (ni, 256)
+    close(torch.cat([u, i]), torch.cat([u_ref, i_ref]))
+    u2, i2 = model.forward()  # autograd path (BiGNNConv modules)
+    close(torch.cat([u2, i2]), torch.cat([u_ref, i_ref]))
+    scores = model.full_sort_predict({"user_id": torch.tensor([3, 4], device=cuda)})
+    close(scores, O.full_sort_predict(u_ref, i_ref, [3, 4]))
+    # gradients of the BiGNNConv autograd function against torch autograd through the oracle
+    x = randn((nu + ni, 64), 31, cuda).requires_grad_(True)
+    layer = model.GNNlayers[0]
+    y = layer(x, model.graph, None)
+    y.square().sum().backward()
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    ei, ew = O.get_norm_adj_mat(g["uid"], g["iid"], nu, ni, enable_sparse=False)
+    w1 = layer.lin1.weight.detach().cpu().clone().requires_grad_(True)
+    w2 = layer.lin2.weight.detach().cpu().clone().requires_grad_(True)
+    yr = O.bignn_conv(xr, lambda t: O.conv_dense(t, ei, ew), w1, layer.lin1.bias.detach().cpu(), w2,
+                      layer.lin2.bias.detach().cpu())
+    yr.square().sum().backward()
+    close(x.grad, xr.grad, tol=2e-5)
+    close(layer.lin1.weight.grad, w1.grad, tol=2e-5)
+    close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
+
+
+# ---- scoring GEMM ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(1, 1125, 64), (3, 1125, 64), (130, 1000, 64), (33, 70, 256), (5, 40, 128),
+                                   (7, 33, 20), (4, 50, 300), (64, 64, 66)])
+def test_score_vs_fp64(rbg, cuda, shape):
+    b, n, d = shape
+    u = randn((b, d), 41, cuda)
+    it = randn((n, d), 42, cuda)
+    s = rbg.score(u, it)
+    ref = u.cpu().double() @ it.cpu().double().T
+    close(s, ref, tol=2e-6 * max(1, d / 64))
+    # transpose-detecting: asymmetric operands, compare a single known element too
+    assert abs(float(s[b - 1, 0]) - float(ref[b - 1, 0])) < 1e-4
+    idx = torch.tensor([0, b - 1], device=cuda)
+    assert torch.equal(rbg.gather_rows(u, idx), u[idx])
+
+
+# ---- full-size properties (BASELINE.json config #2 shape) -----------------------------------
+
+@pytest.fixture(scope="module")
+def gowalla(rbg, cuda):
+    uid, iid, nu, ni = rbg.synth.make("gowalla")
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    return uid, iid, nu, ni, h
+
+
+def test_full_size_vs_c_oracle(rbg, cuda, gowalla):
+    uid, iid, nu, ni, h = gowalla
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    got = h.export_csr()
+    assert np.array_equal(got[0], rowptr) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
+    x = randn((nu + ni, 64), 51, cuda)
+    close(rbg.ops.spmm_raw(h, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
+    gen = torch.Generator().manual_seed(2020)
+    uw, iw = O.xavier_uniform(nu, 64, gen), O.xavier_uniform(ni, 64, gen)
+    mean, _ = rbg.ops.lightgcn_forward_raw(h, uw.to(cuda), iw.to(cuda), 3)
+    ref = C.lightgcn_forward(rowptr, col, val, uw.numpy(), iw.numpy(), 3)
+    err = np.abs(mean.cpu().numpy() - ref).max()
+    assert err <= 1e-5 and err <= 1e-5 * np.abs(ref).max() * 10  # absolute AND (loosely) normalized
+
+
+def test_full_size_properties(rbg, cuda, gowalla):
+    uid, iid, nu, ni, h = gowalla
+    n = nu + ni
+    deg = np.bincount(np.concatenate([uid, iid + nu]), minlength=n).astype(np.float64)
+    # Â (D^1/2 1) = D^1/2 1 on non-isolated nodes, 0 on isolated ones
+    s = torch.from_numpy(np.sqrt(deg)).float().to(cuda)
+    x = s[:, None].repeat(1, 64).contiguous()
+    y = rbg.ops.spmm_raw(h, x)
+    close(y / s.clamp(min=1)[:, None], (x > 0).float() * 1.0, tol=2e-5)
+    # linearity and determinism
+    a, b = randn((n, 64), 61, cuda), randn((n, 64), 62, cuda)
+    ya, yb = rbg.ops.spmm_raw(h, a), rbg.ops.spmm_raw(h, b)
+    close(rbg.ops.spmm_raw(h, 2 * a - b), 2 * ya - yb, tol=2e-5)
+    assert torch.equal(rbg.ops.spmm_raw(h, a), ya)
+    # symmetry: <Âa, b> = <a, Âb>
+    lhs, rhs = (ya.double() * b.double()).sum(), (a.double() * yb.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * max(1.0, abs(float(lhs)))
+    # bipartite: user outputs depend only on item inputs
+    a2 = a.clone()
+    a2[:nu] += 1.0
+    assert torch.equal(rbg.ops.spmm_raw(h, a2)[:nu], ya[:nu])

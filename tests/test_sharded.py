@@ -1,0 +1,142 @@
+"""Node-range sharding: the partition plan and the halo exchange, checked on CPU —
+in-process for the plan algebra, and with two gloo processes for the N > 1 exchange path.  The compute
+backend is injected (the oracle's CPU SpMM) because the product backend needs a GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from oracle import coracle as C
+
+
+class CpuBackend:
+    """Test double for sharded.HipBackend: same three calls, computed by the CPU oracle."""
+    device = torch.device("cpu")
+
+    def make_graph(self, csr, n_cols):
+        return (np.asarray(csr[0]), np.asarray(csr[1], dtype=np.int64), np.asarray(csr[2]), n_cols)
+
+    def spmm(self, graph, x, out, accumulate):
+        y = torch.from_numpy(C.spmm(graph[0], graph[1], graph[2], x.numpy()))
+        if accumulate:
+            out += y
+        else:
+            out.copy_(y)
+        return out
+
+    def gather_rows(self, src, idx):
+        return src[idx]
+
+
+def global_reference(uid, iid, nu, ni, e0, k_layers):
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    return C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers), (rowptr, col, val)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("layout", ["ranges", "striped"])
+def test_plan_algebra(rbg, ref_inter, world, layout):
+    uid, iid, nu, ni = ref_inter
+    n = nu + ni
+    sh = rbg.sharded
+    owner = None if layout == "ranges" else sh.striped_partition(nu, ni, world)
+    plans = sh.build_plans(uid, iid, nu, ni, world, owner=owner)
+    x = np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    y_ref = C.spmm(rowptr, col, val, x)
+    seen = np.zeros(n, dtype=int)
+    for p, plan in plans.items():
+        seen[plan.owned] += 1
+        assert np.all(np.diff(plan.owned) > 0)
+        assert plan.n_users_owned == np.count_nonzero(plan.owned < nu)
+        # the rows of the two blocks together are exactly the global rows (bit-exact weights)
+        for r_local in (0, plan.n_owned // 2, plan.n_owned - 1):
+            g_row = plan.owned[r_local]
+            ent = {}
+            b, e = plan.int_csr[0][r_local], plan.int_csr[0][r_local + 1]
+            for c, v in zip(plan.int_csr[1][b:e], plan.int_csr[2][b:e]):
+                ent[int(plan.owned[c])] = v
+            b, e = plan.halo_csr[0][r_local], plan.halo_csr[0][r_local + 1]
+            for c, v in zip(plan.halo_csr[1][b:e], plan.halo_csr[2][b:e]):
+                ent[int(plan.halo_ids[c])] = v
+            gb, ge = rowptr[g_row], rowptr[g_row + 1]
+            assert sorted(ent) == sorted(col[gb:ge].tolist())
+            assert all(ent[int(c)] == v for c, v in zip(col[gb:ge], val[gb:ge]))
+        # send lists mirror the peers' receive lists
+        so = 0
+        for q in range(world):
+            sc = int(plan.send_counts[q])
+            other = plans[q]
+            ro = int(other.recv_counts[:p].sum())
+            assert sc == int(other.recv_counts[p])
+            assert np.array_equal(plan.owned[plan.send_idx[so:so + sc]], other.halo_ids[ro:ro + sc])
+            so += sc
+        assert int(plan.send_counts[p]) == 0 and int(plan.recv_counts[p]) == 0
+        # Y[owned] = A_int X_local + A_halo X_halo
+        y = C.spmm(plan.int_csr[0], plan.int_csr[1].astype(np.int64), plan.int_csr[2], x[plan.owned])
+        if plan.n_halo:
+            y = y + C.spmm(plan.halo_csr[0], plan.halo_csr[1].astype(np.int64), plan.halo_csr[2], x[plan.halo_ids])
+        np.testing.assert_allclose(y, y_ref[plan.owned], atol=1e-6)
+    assert np.all(seen == 1)  # a partition: every node owned exactly once
+    if layout == "ranges" and world > 1:
+        nnz = [p.int_csr[0][-1] + p.halo_csr[0][-1] for p in plans.values()]
+        assert max(nnz) < 1.6 * (sum(nnz) / world)  # nnz-balanced
+
+
+def test_block_structure_trims_the_halo(rbg):
+    sh = rbg.sharded
+    world = 4
+    nu, ni, e = 401, 801, 6000
+    sizes = {}
+    for p_in in (0.0, 0.9, 1.0):
+        uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=3, n_blocks=world, p_in=p_in)
+        plans = sh.build_plans(uid, iid, nu, ni, world, owner=sh.striped_partition(nu, ni, world))
+        sizes[p_in] = sum(p.n_halo for p in plans.values())
+    assert sizes[1.0] == 0 and sizes[0.9] < 0.5 * sizes[0.0]
+
+
+def _worker(rank, world, port, uid, iid, nu, ni, k_layers, layout, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        owner = None if layout == "ranges" else sh.striped_partition(nu, ni, world)
+        plan = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank])[rank]
+        e0 = np.random.default_rng(1).standard_normal((nu + ni, 16)).astype(np.float32)  # same on every rank
+        prop = sh.ShardedPropagation(plan, CpuBackend(), transport="staged")
+        mean_local = prop.forward(torch.from_numpy(e0[plan.owned]), k_layers)
+        ref, _ = global_reference(uid, iid, nu, ni, e0, k_layers)
+        err = float(np.abs(mean_local.numpy() - ref[plan.owned]).max())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, err, plan.n_halo, int(plan.send_counts.sum())))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", ["ranges", "striped"])
+def test_two_process_gloo_exchange(ref_inter, layout):
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (7 if layout == "striped" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, uid, iid, nu, ni, 3, layout, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(res) == 2
+    for rank, err, n_halo, n_send in res:
+        assert err <= 1e-5, (rank, err)
+        assert n_halo > 0 and n_send > 0  # the exchange path really ran
