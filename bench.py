@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — LightGCN propagations/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A step is ONE propagation = LightGCN.forward (lightgcn.py:70-81): K = 3 SpMM layers E(k+1) = Â·E(k) plus
+the layer mean, 64-d fp32, inputs resident in HBM before the timed region.
+
+N = 1: BASELINE.json configs[1] — the Gowalla-shaped synthetic power-law graph (29,859 users / 40,982
+       items / 1,027,370 interactions incl. the two PAD rows).
+N > 1: the node-range sharded path (recbole-gnn_amd/sharded.py): every rank owns one Gowalla-shaped
+       block of a P-times larger graph (weak scaling); a fraction p_in of each user's interactions stays
+       inside the rank's block, the rest references other ranks and is served by a per-layer halo
+       exchange (RCCL all_to_all over xGMI, overlapped with the interior SpMM on a second stream).
+       value counts shard-propagations: one global forward over P shards = P propagations.
+
+Also reported: "roofline" (algorithmic bytes of one SpMM launch / its average duration from HIP events on
+the launch stream, against the 8 TB/s HBM peak) and "cpu_baseline" (the oracle's C restatement of the
+reference's CPU path, timed on this host's cores on a bounded sample — a reported baseline, not a target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="gowalla")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--p-in", type=float, default=0.9, help="N>1: fraction of interactions inside a rank's block")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
+    ap.add_argument("--seed", type=int, default=2020)
+    return ap.parse_args()
+
+
+def xavier(rows, d, gen):
+    bound = float(np.sqrt(6.0 / (rows + d)))
+    return (torch.rand(rows, d, generator=gen, dtype=torch.float32) * 2 - 1) * bound
+
+
+def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
+    """The oracle's C restatement of torch_sparse's spmm_cpu loop (OpenMP over rows), all host cores."""
+    from oracle import coracle
+    rowptr, col, val = coracle.build_norm_csr(uid, iid, nu, ni)
+    coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 500:
+            break
+    return {"value": reps / el, "unit": "propagations/s", "cores": coracle.num_threads(), "kind": "port",
+            "sample": f"{reps} full propagations of the same workload in {el:.1f} s "
+                      f"(oracle/rbg_oracle.c, OpenMP, {os.cpu_count()} logical cpus visible)"}
+
+
+def traffic_from_profiles(workload):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(workload)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import recbole_gnn_amd as rbg
+    from recbole_gnn_amd import sharded as sh
+
+    nu, ni, n_inter = rbg.synth.shape(args.workload)
+    d, k_layers = args.dim, args.layers
+    n = nu + ni
+    b_layer, b_prop = rbg.synth.algorithmic_bytes(n, 2 * n_inter, d, k_layers)
+    gen = torch.Generator().manual_seed(args.seed + rank)
+    extra = {}
+
+    if world == 1:
+        uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, n_inter, seed=args.seed)
+        graph = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+        uw_h, iw_h = xavier(nu, d, gen), xavier(ni, d, gen)
+        uw, iw = uw_h.to(dev), iw_h.to(dev)
+        out = torch.empty((n, d), device=dev)
+        layers = torch.empty((max(k_layers, 1), n, d), device=dev)
+
+        def step():
+            rbg.ops.lightgcn_forward_raw(graph, uw, iw, k_layers, out=out, layers=layers)
+
+        # parity gate on the very buffers that get timed (1e-5 fp32, BASELINE.json north_star)
+        from oracle import coracle
+        step()
+        torch.cuda.synchronize()
+        rowptr, col, val = coracle.build_norm_csr(uid, iid, nu, ni)
+        ref = coracle.lightgcn_forward(rowptr, col, val, uw_h.numpy(), iw_h.numpy(), k_layers)
+        err = float(np.abs(out.cpu().numpy() - ref).max())
+        if not err <= 1e-5:
+            raise SystemExit(f"parity gate failed: max|E_hip - E_oracle| = {err:.3e} > 1e-5")
+        extra.update(max_abs_err_vs_oracle=err, bins=graph.bins(d), tuning=rbg.get_tuning())
+        launches_per_step = k_layers
+        units_per_step = 1
+        workload = (f"{args.workload}-shape synthetic power-law bipartite graph: {nu} users / {ni} items / "
+                    f"{n_inter} interactions (PAD rows included), nnz(A_hat) = {2 * n_inter}")
+    else:
+        nu_g, ni_g = (nu - 1) * world + 1, (ni - 1) * world + 1
+        uid, iid = rbg.synth.powerlaw_bipartite(nu_g, ni_g, n_inter * world, seed=args.seed, n_blocks=world,
+                                                p_in=args.p_in)
+        owner = sh.striped_partition(nu_g, ni_g, world)
+        plan = sh.build_plans(uid, iid, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
+        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="nccl")
+        e0 = xavier(plan.n_owned, d, gen).to(dev)
+
+        def step():
+            prop.forward(e0, k_layers)
+
+        launches_per_step = k_layers
+        units_per_step = world
+        extra.update(p_in=args.p_in, halo_rows_rank0=int(plan.n_halo), owned_rows_rank0=int(plan.n_owned),
+                     halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4)
+        workload = (f"{world} x {args.workload}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
+                    f"{n_inter * world} interactions, p_in = {args.p_in}, trimmed halo all_to_all per layer")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream every kernel is launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        launch_us = ev_ms * 1e3 / (args.steps * launches_per_step)
+        achieved = b_layer / (launch_us * 1e-6) / 1e9
+        result = {
+            "metric": "LightGCN propagations/sec",
+            "value": units_per_step * args.steps / elapsed,
+            "unit": "propagations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload, "embedding_dim": d, "n_layers": k_layers,
+                       "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
+                       "sharding": "none" if world == 1 else f"node-range x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
+                         "kernel": "spmm_binned_kernel<64,4>", "avg_launch_us": launch_us,
+                         "launches_per_step": launches_per_step,
+                         "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "
+                                 "time of the timed region / launches, so inter-kernel gaps and (N>1) halo waits count"},
+            "cpu_baseline": None,
+        }
+        result.update(extra)
+        if world == 1 and args.cpu_seconds > 0:
+            result["cpu_baseline"] = cpu_baseline(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers, args.cpu_seconds)
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,6 +71,11 @@ int         rbg_device_count(int *count);   /* RBG_OK with *count = 0 when no GP
 int rbg_set_tuning(int short_max, int wave_max, int seg_len);
 int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
 
+/* Named process-wide options (experimentation / A-B runs; defaults are the tuned values).
+ *   "spmm_unroll" : neighbour rows in flight per lane-group before the FMAs (2, 4 or 8; default 4) */
+int rbg_set_option(const char *key, int64_t value);
+int rbg_get_option(const char *key, int64_t *value);
+
 /* ---------------------------------------------------------------------------------------------
  * graph construction
  * ------------------------------------------------------------------------------------------- */

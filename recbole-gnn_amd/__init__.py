@@ -7,7 +7,8 @@ Importing fails loudly if librbgnn.so (the HIP extension) has not been built; th
 """
 from . import _lib, graph, models, ops, sharded, synth  # noqa: F401
 from ._lib import LIB_PATH, RbgError  # noqa: F401
-from .graph import GraphHandle, InteractionDataset, device_count, get_tuning, norm_edges, set_tuning  # noqa: F401
+from .graph import (GraphHandle, InteractionDataset, device_count, get_option, get_tuning, norm_edges,  # noqa: F401
+                    set_option, set_tuning)
 from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN  # noqa: F401
 from .ops import BiGNNConv, LightGCNConv, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
 

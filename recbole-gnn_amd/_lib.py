@@ -26,6 +26,8 @@ SIGNATURES = {
     "rbg_device_count": (c_int, [P(c_int)]),
     "rbg_set_tuning": (c_int, [c_int, c_int, c_int]),
     "rbg_get_tuning": (c_int, [P(c_int), P(c_int), P(c_int)]),
+    "rbg_set_option": (c_int, [ctypes.c_char_p, c_i64]),
+    "rbg_get_option": (c_int, [ctypes.c_char_p, P(c_i64)]),
     "rbg_graph_create": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_u32]),
     "rbg_graph_create_masked": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),
     "rbg_graph_create_csr": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),

@@ -38,6 +38,9 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{16}, g_wave_max{192}, g_seg_len{768};
 
+static std::atomic<int> g_spmm_unroll{4};
+int spmm_unroll() { return g_spmm_unroll.load(); }
+
 Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
 
 int set_device_for(int device) {
@@ -325,6 +328,25 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len) {
     if (wave_max) *wave_max = cur.wave_max;
     if (seg_len) *seg_len = cur.seg_len;
     return RBG_OK;
+}
+
+int rbg_set_option(const char *key, int64_t value) {
+    if (!key) return fail(RBG_EINVAL, "key is NULL");
+    if (!strcmp(key, "spmm_unroll")) {
+        if (value != 2 && value != 4 && value != 8) return fail(RBG_EINVAL, "spmm_unroll must be 2, 4 or 8");
+        g_spmm_unroll = (int)value;
+        return RBG_OK;
+    }
+    return fail(RBG_EINVAL, "unknown option '%s'", key);
+}
+
+int rbg_get_option(const char *key, int64_t *value) {
+    if (!key || !value) return fail(RBG_EINVAL, "NULL argument");
+    if (!strcmp(key, "spmm_unroll")) {
+        *value = g_spmm_unroll.load();
+        return RBG_OK;
+    }
+    return fail(RBG_EINVAL, "unknown option '%s'", key);
 }
 
 int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,

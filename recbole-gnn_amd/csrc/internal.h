@@ -30,6 +30,7 @@ struct Tuning {
     int seg_len;    // workgroup rows are cut into segments of this many entries
 };
 Tuning current_tuning();
+int spmm_unroll();
 
 // One workgroup task: a row (or one segment of a split row).
 struct BlockTask {

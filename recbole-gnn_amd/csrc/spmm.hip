@@ -351,7 +351,11 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     grid_for<D>(g, p, grid);
     if (grid == 0) return RBG_OK;
     if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
-    hipLaunchKernelGGL((spmm_binned_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    switch (spmm_unroll()) {
+        case 2: hipLaunchKernelGGL((spmm_binned_kernel<D, 2>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
+        case 8: hipLaunchKernelGGL((spmm_binned_kernel<D, 8>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((spmm_binned_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""GPU measurement harness (one process, interleaved A/B): SpMM tuning sweep, propagation, scoring GEMM,
+BiGNN layer and a copy-bandwidth calibration.  Writes JSON lines to gpurun_out/tune.jsonl.
+
+  python tools/tune_spmm.py [--shapes gowalla,amazon-book] [--quick] [--big]
+"""
+import argparse
+import itertools
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import recbole_gnn_amd as rbg  # noqa: E402
+
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+LOG = open(os.path.join(OUT, "tune.jsonl"), "a")
+
+
+def emit(**kw):
+    line = json.dumps(kw)
+    print(line, flush=True)
+    LOG.write(line + "\n")
+    LOG.flush()
+
+
+def time_us(fn, iters=200, warmup=20, rounds=3):
+    for _ in range(warmup):
+        fn()
+    best = []
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) * 1e3 / iters)
+    return float(np.median(best)), float(np.min(best))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shapes", default="gowalla,amazon-book")
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--big", action="store_true", help="also the 1.3M-node shape (X = 333 MB > Infinity Cache)")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    emit(kind="device", name=torch.cuda.get_device_name(0), cus=torch.cuda.get_device_properties(0).multi_processor_count)
+
+    # copy bandwidth calibration (read + write of 1 GiB)
+    a = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    med, mn = time_us(lambda: b.copy_(a), iters=20, warmup=3)
+    emit(kind="copy_bw", gbps=2 * a.numel() * 4 / (mn * 1e-6) / 1e9, us=mn)
+    del a, b
+
+    shapes = args.shapes.split(",") + (["g-1.3m"] if args.big else [])
+    for name in shapes:
+        t0 = time.time()
+        uid, iid, nu, ni = rbg.synth.make(name)
+        n, nnz = nu + ni, 2 * len(uid)
+        b_layer, b_prop = rbg.synth.algorithmic_bytes(n, nnz, 64, 3)
+        emit(kind="shape", name=name, n=n, nnz=nnz, gen_s=time.time() - t0, b_layer=b_layer)
+        x = torch.randn(n, 64, device=dev)
+        y = torch.empty_like(x)
+        if args.quick:
+            grid = [(16, 192, 768)]
+        else:
+            grid = [(s, w, l) for s, w, l in itertools.product((4, 8, 16, 32, 64), (64, 128, 256, 512), (512, 1024, 4096))
+                    if w >= s]
+        results = []
+        for (s, w, l) in grid:
+            rbg.set_tuning(s, w, l)
+            g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+            for unroll in ((4,) if args.quick else (2, 4, 8)):
+                rbg.set_option("spmm_unroll", unroll)
+                med, mn = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y), iters=100, warmup=10)
+                results.append((med, s, w, l, unroll))
+                emit(kind="spmm", shape=name, short_max=s, wave_max=w, seg_len=l, unroll=unroll, us=med, us_min=mn,
+                     gbps=b_layer / (med * 1e-6) / 1e9, frac=b_layer / (med * 1e-6) / 8e12, bins=g.bins(64))
+            del g
+        results.sort()
+        emit(kind="best", shape=name, top=results[:5])
+        # natural order (no binning) for comparison, with the best tuning otherwise
+        med0, s, w, l, unroll = results[0]
+        rbg.set_tuning(s, w, l)
+        rbg.set_option("spmm_unroll", unroll)
+        gn = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, flags=rbg._lib.GRAPH_NATURAL_ORDER)
+        med, mn = time_us(lambda: rbg.ops.spmm_raw(gn, x, out=y), iters=50, warmup=5)
+        emit(kind="spmm_natural_order", shape=name, us=med)
+        del gn
+        g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+        # torch.sparse CSR on the same GPU (rocSPARSE) as a vendor-library yardstick
+        try:
+            rp, col, val = g.export_csr()
+            a = torch.sparse_csr_tensor(torch.from_numpy(rp).to(dev), torch.from_numpy(col.astype(np.int64)).to(dev),
+                                        torch.from_numpy(val).to(dev), size=(n, n))
+            med, mn = time_us(lambda: torch.matmul(a, x), iters=30, warmup=5)
+            emit(kind="torch_sparse_csr_gpu", shape=name, us=med, gbps=b_layer / (med * 1e-6) / 1e9)
+            del a
+        except Exception as ex:  # noqa: BLE001
+            emit(kind="torch_sparse_csr_gpu", shape=name, error=str(ex)[:200])
+        # whole propagation (K = 3, fused mean), d = 64 and 128
+        for d in (64, 128):
+            uw, iw = torch.randn(nu, d, device=dev), torch.randn(ni, d, device=dev)
+            out = torch.empty(n, d, device=dev)
+            layers = torch.empty(3, n, d, device=dev)
+            med, mn = time_us(lambda: rbg.ops.lightgcn_forward_raw(g, uw, iw, 3, out=out, layers=layers), iters=100)
+            bl, bp = rbg.synth.algorithmic_bytes(n, nnz, d, 3)
+            emit(kind="propagation", shape=name, d=d, us=med, prop_per_s=1e6 / med, gbps_prop=bp / (med * 1e-6) / 1e9,
+                 frac_layer=3 * bl / (med * 1e-6) / 8e12)
+        # scoring GEMM
+        for bsz in (1, 128, 4096):
+            u = torch.randn(bsz, 64, device=dev)
+            it = torch.randn(ni, 64, device=dev)
+            med, mn = time_us(lambda: rbg.score(u, it), iters=30, warmup=3)
+            med_t, _ = time_us(lambda: torch.matmul(u, it.T), iters=30, warmup=3)
+            byt = 4 * (bsz * 64 + ni * 64 + bsz * ni)
+            emit(kind="score", shape=name, B=bsz, us=med, us_torch=med_t, gbps=byt / (med * 1e-6) / 1e9,
+                 tflops=2 * bsz * ni * 64 / (med * 1e-6) / 1e12)
+        # NGCF layer 64 -> 64
+        w1, w2 = torch.randn(64, 64, device=dev) * 0.1, torch.randn(64, 64, device=dev) * 0.1
+        b1, b2 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        yo = torch.empty(n, 64, device=dev)
+        med, mn = time_us(lambda: rbg.ops.bignn_conv_raw(g, x, w1, b1, w2, b2, out=yo, leaky_norm=True), iters=50, warmup=5)
+        emit(kind="bignn_layer", shape=name, us=med)
+        del g
+
+
+if __name__ == "__main__":
+    main()

@@ -190,6 +190,16 @@ def get_tuning():
     return {"short_max": a.value, "wave_max": b.value, "seg_len": c.value}
 
 
+def set_option(key, value):
+    check(lib.rbg_set_option(key.encode(), int(value)))
+
+
+def get_option(key):
+    v = c_i64()
+    check(lib.rbg_get_option(key.encode(), ctypes.byref(v)))
+    return v.value
+
+
 def device_count():
     n = c_int()
     check(lib.rbg_device_count(ctypes.byref(n)))

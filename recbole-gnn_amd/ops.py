@@ -111,8 +111,9 @@ class LightGCNConv(nn.Module):
 
 # ---- fused LightGCN propagation ------------------------------------------------------------
 
-def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False):
-    """cat -> K x (Â·) -> mean, one C call (lightgcn.py:60-81).  Returns (mean [N,d], layers or None)."""
+def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, out=None, layers=None):
+    """cat -> K x (Â·) -> mean, one C call (lightgcn.py:60-81).  Returns (mean [N,d], layers or None).
+    ``out`` / ``layers`` let a caller reuse its own buffers ([N,d] and [max(K,1),N,d])."""
     graphs = list(graphs) if isinstance(graphs, (list, tuple)) else [graphs]
     for g in graphs:
         _require_device_graph(g)
@@ -125,8 +126,15 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False):
         raise ValueError("user and item embeddings differ in width")
     if n != graphs[0].n_rows:
         raise ValueError(f"graph has {graphs[0].n_rows} nodes but the tables hold {n} rows")
-    out = torch.empty((n, d), dtype=torch.float32, device=user_w.device)
-    layers = torch.empty((max(n_layers, 1), n, d), dtype=torch.float32, device=user_w.device)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=user_w.device)
+    if layers is None:
+        layers = torch.empty((max(n_layers, 1), n, d), dtype=torch.float32, device=user_w.device)
+    if tuple(out.shape) != (n, d) or tuple(layers.shape) != (max(n_layers, 1), n, d) or \
+            not (out.is_contiguous() and layers.is_contiguous()):
+        raise ValueError("out must be contiguous [N, d] and layers contiguous [max(K,1), N, d]")
+    _check_dense(out, "out", graphs[0])
+    _check_dense(layers, "layers", graphs[0])
     arr = (c_vp * len(graphs))(*[g.ptr for g in graphs])
     flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_DEFAULT
     with torch.cuda.device(user_w.device):
