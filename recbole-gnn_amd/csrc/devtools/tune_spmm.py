@@ -2,7 +2,7 @@
 """GPU measurement harness (one process, interleaved A/B): SpMM tuning sweep, propagation, scoring GEMM,
 BiGNN layer and a copy-bandwidth calibration.  Writes JSON lines to gpurun_out/tune.jsonl.
 
-  python tools/tune_spmm.py [--shapes gowalla,amazon-book] [--quick] [--big]
+  python devtools/tune_spmm.py [--shapes gowalla,amazon-book] [--quick] [--big]
 """
 import argparse
 import itertools
