@@ -1,0 +1,114 @@
+// Microbenchmarks that calibrate the speed of light for the SpMM's access pattern on MI355X:
+//   mb_gather : random 256-byte row gathers (16 lanes x float4) from a table of R rows, idx pre-generated
+//   mb_stream : streaming float4 read of a buffer (L2 / Infinity Cache / HBM depending on size)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+template <int U>
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ tab, const int* __restrict__ idx,
+                                                     int64_t m, float* __restrict__ out, int per_group) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
+    int64_t beg = group * per_group, end = beg + per_group;
+    if (end > m) end = m;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int64_t e = beg; e < end; e += 16) {
+        int c = (e + sl < end) ? idx[e + sl] : 0;
+        int cnt = (int)((end - e) < 16 ? (end - e) : 16);
+        for (int j = 0; j + U <= cnt; j += U) {
+            float4 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int cj = __shfl(c, j + u, 16);
+                x[u] = *reinterpret_cast<const float4*>(tab + (int64_t)cj * 64 + sl * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { acc.x += x[u].x; acc.y += x[u].y; acc.z += x[u].z; acc.w += x[u].w; }
+        }
+    }
+    if (acc.x == 12345.678f) out[group] = acc.x + acc.y + acc.z + acc.w;  // keep the loads alive
+}
+
+__global__ __launch_bounds__(256) void stream_kernel(const float4* __restrict__ buf, int64_t n4, int reps, float* out) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < reps; ++r)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            float4 v = buf[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    if (acc.x == 12345.678f) out[0] = acc.x + acc.y + acc.z + acc.w;
+}
+
+extern "C" int mb_gather(const float* tab, const int* idx, int64_t m, float* out, int per_group, int unroll, void* stream) {
+    int64_t groups = (m + per_group - 1) / per_group;
+    int64_t blocks = (groups + 15) / 16;
+    dim3 g((unsigned)blocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (unroll) {
+        case 2: hipLaunchKernelGGL(gather_kernel<2>, g, b, 0, s, tab, idx, m, out, per_group); break;
+        case 4: hipLaunchKernelGGL(gather_kernel<4>, g, b, 0, s, tab, idx, m, out, per_group); break;
+        case 8: hipLaunchKernelGGL(gather_kernel<8>, g, b, 0, s, tab, idx, m, out, per_group); break;
+        default: hipLaunchKernelGGL(gather_kernel<16>, g, b, 0, s, tab, idx, m, out, per_group); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int mb_stream(const float* buf, int64_t n_floats, int reps, int blocks, float* out, void* stream) {
+    hipLaunchKernelGGL(stream_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)buf, n_floats / 4, reps, out);
+    return (int)hipGetLastError();
+}
+
+// Per-XCD private working set: blocks with (blockIdx & 7) == x sweep region x (bytes_per_xcd each) `reps` times.
+__global__ __launch_bounds__(256) void xcd_private_kernel(const float4* __restrict__ buf, int64_t n4_per_xcd, int reps, float* out) {
+    const int x = blockIdx.x & 7;
+    const int64_t lb = blockIdx.x >> 3, nb = gridDim.x >> 3;
+    const float4* base = buf + (int64_t)x * n4_per_xcd;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int r = 0; r < reps; ++r)
+        for (int64_t i = lb * 256 + threadIdx.x; i < n4_per_xcd; i += nb * 256) {
+            float4 v = base[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    if (acc.x == 12345.678f) out[0] = acc.x + acc.y + acc.z + acc.w;
+}
+extern "C" int mb_xcd_private(const float* buf, int64_t floats_per_xcd, int reps, int blocks, float* out, void* stream) {
+    hipLaunchKernelGGL(xcd_private_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)buf, floats_per_xcd / 4, reps, out);
+    return (int)hipGetLastError();
+}
+
+// Gather with a hot/cold split: rows with index >= hot_rows are fetched with non-temporal loads.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int U>
+__global__ __launch_bounds__(256) void gather_nt_kernel(const float* __restrict__ tab, const int* __restrict__ idx,
+                                                        int64_t m, float* __restrict__ out, int per_group, int hot_rows) {
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+    const int64_t group = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + sub;
+    int64_t beg = group * per_group, end = beg + per_group;
+    if (end > m) end = m;
+    v4f acc = {0, 0, 0, 0};
+    for (int64_t e = beg; e < end; e += 16) {
+        int c = (e + sl < end) ? idx[e + sl] : 0;
+        int cnt = (int)((end - e) < 16 ? (end - e) : 16);
+        for (int j = 0; j + U <= cnt; j += U) {
+            v4f x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int cj = __shfl(c, j + u, 16);
+                const v4f* p = reinterpret_cast<const v4f*>(tab + (int64_t)cj * 64 + sl * 4);
+                x[u] = (v4f){0, 0, 0, 0};
+                // explicit cache-policy bit: the two flavours run under complementary exec masks
+                if (cj >= hot_rows) asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(x[u]) : "v"(p) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(x[u]) : "v"(p) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += x[u];
+        }
+    }
+    if (acc.x == 12345.678f) out[group] = acc.x + acc.y + acc.z + acc.w;
+}
+extern "C" int mb_gather_nt(const float* tab, const int* idx, int64_t m, float* out, int per_group, int hot_rows, void* stream) {
+    int64_t groups = (m + per_group - 1) / per_group;
+    hipLaunchKernelGGL(gather_nt_kernel<8>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, (hipStream_t)stream, tab, idx, m, out, per_group, hot_rows);
+    return (int)hipGetLastError();
+}

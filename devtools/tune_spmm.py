@@ -74,25 +74,32 @@ def main():
         if args.quick:
             grid = [(16, 192, 768)]
         else:
-            grid = [(s, w, l) for s, w, l in itertools.product((4, 8, 16, 32, 64), (64, 128, 256, 512), (512, 1024, 4096))
+            grid = [(s, w, l) for s, w, l in itertools.product((32, 64, 128, 256), (256, 1024), (1024, 4096, 16384))
                     if w >= s]
         results = []
         for (s, w, l) in grid:
             rbg.set_tuning(s, w, l)
-            g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
-            for unroll in ((4,) if args.quick else (2, 4, 8)):
-                rbg.set_option("spmm_unroll", unroll)
-                med, mn = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y), iters=100, warmup=10)
-                results.append((med, s, w, l, unroll))
-                emit(kind="spmm", shape=name, short_max=s, wave_max=w, seg_len=l, unroll=unroll, us=med, us_min=mn,
-                     gbps=b_layer / (med * 1e-6) / 1e9, frac=b_layer / (med * 1e-6) / 8e12, bins=g.bins(64))
-            del g
+            for split in (1, 0):
+                rbg.set_option("xcd_split", split)
+                g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+                for unroll in ((4,) if args.quick else (4, 8)):
+                    for nt in (1, 0):
+                        rbg.set_option("spmm_unroll", unroll)
+                        rbg.set_option("nt_store", nt)
+                        med, mn = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y), iters=100, warmup=10)
+                        results.append((med, s, w, l, unroll, split, nt))
+                        emit(kind="spmm", shape=name, short_max=s, wave_max=w, seg_len=l, unroll=unroll, xcd_split=split,
+                             nt_store=nt, us=med, us_min=mn, gbps=b_layer / (med * 1e-6) / 1e9,
+                             frac=b_layer / (med * 1e-6) / 8e12, bins=g.bins(64))
+                del g
         results.sort()
         emit(kind="best", shape=name, top=results[:5])
         # natural order (no binning) for comparison, with the best tuning otherwise
-        med0, s, w, l, unroll = results[0]
+        med0, s, w, l, unroll, split, nt = results[0]
         rbg.set_tuning(s, w, l)
         rbg.set_option("spmm_unroll", unroll)
+        rbg.set_option("xcd_split", split)
+        rbg.set_option("nt_store", nt)
         gn = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, flags=rbg._lib.GRAPH_NATURAL_ORDER)
         med, mn = time_us(lambda: rbg.ops.spmm_raw(gn, x, out=y), iters=50, warmup=5)
         emit(kind="spmm_natural_order", shape=name, us=med)

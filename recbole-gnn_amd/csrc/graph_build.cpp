@@ -4,7 +4,7 @@
 //
 // Layout produced (see DESIGN.md "Data layout in HBM"):
 //   rowptr int32 [N+1], col int32 [nnz] (ascending within a row), val fp32 [nnz]
-//   row_order int32 [N]   rows by degree, descending (ties by row id)
+//   desc  RowDesc[]       {row, beg, end} of wavefront / lane-group rows, by degree descending per row class
 //   tasks BlockTask[]     one per workgroup row segment
 // Users come first, items after (col = iid + n_users, dataset.py:61).  Duplicated interactions stay
 // separate entries, each counted in the degree (PyG gcn_norm does the same).
@@ -36,10 +36,12 @@ int fail(int code, const char *fmt, ...) {
 }
 void clear_error() { t_error.clear(); }
 
-static std::atomic<int> g_short_max{16}, g_wave_max{192}, g_seg_len{768};
+static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{4};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{1}, g_nt_store{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
+int opt_xcd_split() { return g_xcd_split.load(); }
+int opt_nt_store() { return g_nt_store.load(); }
 
 Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
 
@@ -149,57 +151,88 @@ int build_host_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_int
     return RBG_OK;
 }
 
-int plan_bins(const rbg_graph *g, std::vector<int32_t> &row_order, std::vector<BlockTask> &tasks,
-              int64_t &n_block_rows, int64_t &n_wave, int64_t &n_short, int64_t &n_split, int64_t &n_slots,
-              int32_t &max_deg) {
-    const int64_t n = g->n_rows;
+// Degree-bin the rows [r0, r1) of the CSR into one GroupPlan (appends to plan.desc / plan.tasks).
+static void plan_group(const rbg_graph *g, int64_t r0, int64_t r1, BinPlan &plan, GroupPlan &gp) {
     const int32_t *rp = g->h_rowptr.data();
     const Tuning tn = g->tuning;
-    row_order.resize((size_t)n);
-    tasks.clear();
-    n_block_rows = n_wave = n_short = n_split = n_slots = 0;
-    max_deg = 0;
-    for (int64_t r = 0; r < n; ++r) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
-    if (g->flags & RBG_GRAPH_NATURAL_ORDER) {
-        for (int64_t r = 0; r < n; ++r) row_order[(size_t)r] = (int32_t)r;
-        n_short = n;
+    const int64_t n = r1 - r0;
+    int32_t max_deg = 0;
+    for (int64_t r = r0; r < r1; ++r) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
+    plan.max_deg = std::max(plan.max_deg, max_deg);
+    // counting sort by degree, descending; ties keep ascending row id
+    std::vector<int32_t> order((size_t)n);
+    std::vector<int64_t> start((size_t)max_deg + 2, 0);
+    for (int64_t r = r0; r < r1; ++r) start[(size_t)(max_deg - (rp[r + 1] - rp[r])) + 1]++;
+    for (int32_t k = 0; k <= max_deg; ++k) start[(size_t)k + 1] += start[(size_t)k];
+    for (int64_t r = r0; r < r1; ++r) order[(size_t)start[(size_t)(max_deg - (rp[r + 1] - rp[r]))]++] = (int32_t)r;
+    gp = GroupPlan{};
+    gp.task_base = (int32_t)plan.tasks.size();
+    int64_t k = 0;
+    for (; k < n; ++k) {  // workgroup rows
+        const int32_t r = order[(size_t)k];
+        const int32_t deg = rp[r + 1] - rp[r];
+        if (deg <= tn.wave_max) break;
+        ++plan.n_block_rows;
+        const int32_t nseg = (deg + tn.seg_len - 1) / tn.seg_len;
+        int32_t len = (deg + nseg - 1) / nseg;  // equal-length segments, a multiple of 64 entries
+        len = (len + 63) / 64 * 64;
+        const int32_t real = (deg + len - 1) / len;
+        for (int32_t s = 0; s < real; ++s) {
+            BlockTask t{};
+            t.row = r;
+            t.beg = rp[r] + s * len;
+            t.end = std::min(rp[r + 1], t.beg + len);
+            t.seg = s;
+            t.nseg = real;
+            t.part_base = real > 1 ? (int32_t)plan.n_slots : 0;
+            t.ctr = real > 1 ? (int32_t)plan.n_split : 0;
+            plan.tasks.push_back(t);
+        }
+        if (real > 1) {
+            plan.n_slots += real;
+            ++plan.n_split;
+        }
+    }
+    gp.n_tasks = (int32_t)plan.tasks.size() - gp.task_base;
+    gp.pos_wave = (int32_t)plan.desc.size();
+    for (; k < n; ++k) {  // wavefront rows
+        const int32_t r = order[(size_t)k];
+        if (rp[r + 1] - rp[r] <= tn.short_max) break;
+        plan.desc.push_back(RowDesc{r, rp[r], rp[r + 1], 0});
+    }
+    gp.n_wave = (int32_t)plan.desc.size() - gp.pos_wave;
+    gp.pos_short = (int32_t)plan.desc.size();
+    for (; k < n; ++k) {  // lane-group rows
+        const int32_t r = order[(size_t)k];
+        plan.desc.push_back(RowDesc{r, rp[r], rp[r + 1], 0});
+    }
+    gp.n_short = (int32_t)plan.desc.size() - gp.pos_short;
+    plan.n_wave += gp.n_wave;
+    plan.n_short += gp.n_short;
+}
+
+int plan_bins(const rbg_graph *g, BinPlan &plan) {
+    const int64_t n = g->n_rows;
+    plan = BinPlan{};
+    plan.desc.reserve((size_t)n);
+    if (g->flags & RBG_GRAPH_NATURAL_ORDER) {  // no binning: every row is a lane-group row, in id order
+        const int32_t *rp = g->h_rowptr.data();
+        for (int64_t r = 0; r < n; ++r) {
+            plan.desc.push_back(RowDesc{(int32_t)r, rp[r], rp[r + 1], 0});
+            plan.max_deg = std::max(plan.max_deg, rp[r + 1] - rp[r]);
+        }
+        plan.groups[0].n_short = (int32_t)n;
+        plan.n_short = n;
         return RBG_OK;
     }
-    // counting sort by degree, descending; ties keep ascending row id
-    std::vector<int64_t> start((size_t)max_deg + 2, 0);
-    for (int64_t r = 0; r < n; ++r) start[(size_t)(max_deg - (rp[r + 1] - rp[r])) + 1]++;
-    for (int32_t k = 0; k <= max_deg; ++k) start[(size_t)k + 1] += start[(size_t)k];
-    for (int64_t r = 0; r < n; ++r) row_order[(size_t)start[(size_t)(max_deg - (rp[r + 1] - rp[r]))]++] = (int32_t)r;
-    for (int64_t k = 0; k < n; ++k) {
-        const int32_t r = row_order[(size_t)k];
-        const int32_t deg = rp[r + 1] - rp[r];
-        if (deg > tn.wave_max) {
-            ++n_block_rows;
-            const int32_t nseg = (deg + tn.seg_len - 1) / tn.seg_len;
-            // equal-length segments, rounded up to a multiple of 64 entries
-            int32_t len = (deg + nseg - 1) / nseg;
-            len = (len + 63) / 64 * 64;
-            const int32_t real = (deg + len - 1) / len;
-            for (int32_t s = 0; s < real; ++s) {
-                BlockTask t{};
-                t.row = r;
-                t.beg = rp[r] + s * len;
-                t.end = std::min(rp[r + 1], t.beg + len);
-                t.seg = s;
-                t.nseg = real;
-                t.part_base = real > 1 ? (int32_t)n_slots : 0;
-                t.ctr = real > 1 ? (int32_t)n_split : 0;
-                tasks.push_back(t);
-            }
-            if (real > 1) {
-                n_slots += real;
-                ++n_split;
-            }
-        } else if (deg > tn.short_max) {
-            ++n_wave;
-        } else {
-            ++n_short;
-        }
+    // XCD specialisation needs the user/item boundary (graphs built from interactions) and both classes
+    const bool split = opt_xcd_split() && g->n_users > 0 && g->n_users < n && g->n_rows == g->n_cols;
+    if (split) {
+        plan.n_groups = 2;
+        plan_group(g, 0, g->n_users, plan, plan.groups[0]);
+        plan_group(g, g->n_users, n, plan, plan.groups[1]);
+    } else {
+        plan_group(g, 0, n, plan, plan.groups[0]);
     }
     return RBG_OK;
 }
@@ -212,11 +245,12 @@ static void free_device(rbg_graph *g) {
     (void)hipFree(g->d_rowptr);
     (void)hipFree(g->d_col);
     (void)hipFree(g->d_val);
-    (void)hipFree(g->d_row_order);
+    (void)hipFree(g->d_desc);
     (void)hipFree(g->d_tasks);
     (void)hipFree(g->d_partials);
     (void)hipFree(g->d_counters);
-    g->d_rowptr = g->d_col = g->d_row_order = nullptr;
+    g->d_rowptr = g->d_col = nullptr;
+    g->d_desc = nullptr;
     g->d_val = g->d_partials = nullptr;
     g->d_tasks = nullptr;
     g->d_counters = nullptr;
@@ -240,28 +274,29 @@ int upload_graph(rbg_graph *g) {
     if (g->device >= n_dev) return fail(RBG_EINVAL, "device %d out of range (%d visible)", g->device, n_dev);
     int rc = set_device_for(g->device);
     if (rc) return rc;
-    std::vector<int32_t> order;
-    std::vector<BlockTask> tasks;
-    int64_t nb, nw, ns, nsplit, nslots;
-    int32_t maxdeg;
+    BinPlan plan;
     try {
-        rc = plan_bins(g, order, tasks, nb, nw, ns, nsplit, nslots, maxdeg);
+        rc = plan_bins(g, plan);
     } catch (const std::bad_alloc &) {
         return fail(RBG_ENOMEM, "host allocation failed while binning rows");
     }
     if (rc) return rc;
-    g->n_block_rows = nb;
-    g->n_wave = nw;
-    g->n_short = ns;
-    g->n_tasks = (int64_t)tasks.size();
-    g->n_split_rows = nsplit;
-    g->n_partial_slots = nslots;
-    g->max_degree = maxdeg;
+    g->n_groups = plan.n_groups;
+    g->groups[0] = plan.groups[0];
+    g->groups[1] = plan.groups[1];
+    g->n_block_rows = plan.n_block_rows;
+    g->n_wave = plan.n_wave;
+    g->n_short = plan.n_short;
+    g->n_tasks = (int64_t)plan.tasks.size();
+    g->n_split_rows = plan.n_split;
+    g->n_partial_slots = plan.n_slots;
+    g->max_degree = plan.max_deg;
+    const int64_t nsplit = plan.n_split, nslots = plan.n_slots;
     if ((rc = to_device(&g->d_rowptr, g->h_rowptr.data(), g->h_rowptr.size()))) return rc;
     if ((rc = to_device(&g->d_col, g->h_col.data(), g->h_col.size()))) return rc;
     if ((rc = to_device(&g->d_val, g->h_val.data(), g->h_val.size()))) return rc;
-    if ((rc = to_device(&g->d_row_order, order.data(), order.size()))) return rc;
-    if ((rc = to_device(&g->d_tasks, tasks.data(), tasks.size()))) return rc;
+    if ((rc = to_device(&g->d_desc, plan.desc.data(), plan.desc.size()))) return rc;
+    if ((rc = to_device(&g->d_tasks, plan.tasks.data(), plan.tasks.size()))) return rc;
     {
         const size_t pb = std::max<size_t>((size_t)nslots, 1) * kPartialSlotFloats * sizeof(float);
         hipError_t e = hipMalloc((void **)&g->d_partials, pb);
@@ -333,8 +368,16 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len) {
 int rbg_set_option(const char *key, int64_t value) {
     if (!key) return fail(RBG_EINVAL, "key is NULL");
     if (!strcmp(key, "spmm_unroll")) {
-        if (value != 2 && value != 4 && value != 8) return fail(RBG_EINVAL, "spmm_unroll must be 2, 4 or 8");
+        if (value != 4 && value != 8) return fail(RBG_EINVAL, "spmm_unroll must be 4 or 8");
         g_spmm_unroll = (int)value;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "xcd_split")) {
+        g_xcd_split = value ? 1 : 0;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "nt_store")) {
+        g_nt_store = value ? 1 : 0;
         return RBG_OK;
     }
     return fail(RBG_EINVAL, "unknown option '%s'", key);
@@ -344,6 +387,14 @@ int rbg_get_option(const char *key, int64_t *value) {
     if (!key || !value) return fail(RBG_EINVAL, "NULL argument");
     if (!strcmp(key, "spmm_unroll")) {
         *value = g_spmm_unroll.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "xcd_split")) {
+        *value = g_xcd_split.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "nt_store")) {
+        *value = g_nt_store.load();
         return RBG_OK;
     }
     return fail(RBG_EINVAL, "unknown option '%s'", key);

@@ -31,6 +31,8 @@ struct Tuning {
 };
 Tuning current_tuning();
 int spmm_unroll();
+int opt_xcd_split();
+int opt_nt_store();
 
 // One workgroup task: a row (or one segment of a split row).
 struct BlockTask {
@@ -44,6 +46,20 @@ struct BlockTask {
 static_assert(sizeof(BlockTask) == 32, "BlockTask must stay 32 bytes (loaded as 2 x int4)");
 
 constexpr int kPartialSlotFloats = 256;  // split-row partial slots are sized for d <= 256
+
+// One wavefront / lane-group row: everything the kernel needs in a single 16-byte load.
+struct RowDesc {
+    int32_t row, beg, end, pad;
+};
+static_assert(sizeof(RowDesc) == 16, "RowDesc must stay 16 bytes");
+
+// Launch plan of one row class.  With XCD specialisation there are two classes (user rows run on XCDs
+// 0-3, item rows on XCDs 4-7, so each XCD's L2 only ever holds ONE embedding table); otherwise one.
+struct GroupPlan {
+    int32_t n_tasks, task_base;  // workgroup tasks  [task_base, task_base + n_tasks)
+    int32_t n_wave, pos_wave;    // wavefront rows   desc[pos_wave  .. +n_wave)
+    int32_t n_short, pos_short;  // lane-group rows  desc[pos_short .. +n_short)
+};
 
 }  // namespace rbg
 
@@ -64,10 +80,12 @@ struct rbg_graph {
     int32_t *d_col = nullptr;
     float *d_val = nullptr;
 
-    // degree binning (device): rows sorted by degree descending; the first n_block_rows rows are
-    // workgroup rows (expanded to d_tasks), then n_wave rows, then n_short rows.
+    // degree binning (device): per row class, rows sorted by degree descending and cut into workgroup
+    // rows (expanded to d_tasks), wavefront rows and lane-group rows (both described by d_desc).
     rbg::Tuning tuning{};
-    int32_t *d_row_order = nullptr;  // [n_rows]; positions [n_block_rows, n_rows) are used by the kernel
+    int n_groups = 1;
+    rbg::GroupPlan groups[2] = {};
+    rbg::RowDesc *d_desc = nullptr;  // [n_wave + n_short over all groups]
     int64_t n_block_rows = 0, n_wave = 0, n_short = 0;
     rbg::BlockTask *d_tasks = nullptr;
     int64_t n_tasks = 0, n_split_rows = 0, n_partial_slots = 0;
@@ -81,9 +99,15 @@ namespace rbg {
 // graph_build.cpp
 int build_host_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
                    const int64_t *iid, const uint8_t *keep);
-int plan_bins(const rbg_graph *g, std::vector<int32_t> &row_order, std::vector<BlockTask> &tasks,
-              int64_t &n_block_rows, int64_t &n_wave, int64_t &n_short, int64_t &n_split, int64_t &n_slots,
-              int32_t &max_deg);
+struct BinPlan {
+    std::vector<RowDesc> desc;
+    std::vector<BlockTask> tasks;
+    int n_groups = 1;
+    GroupPlan groups[2] = {};
+    int64_t n_block_rows = 0, n_wave = 0, n_short = 0, n_split = 0, n_slots = 0;
+    int32_t max_deg = 0;
+};
+int plan_bins(const rbg_graph *g, BinPlan &plan);
 int upload_graph(rbg_graph *g);  // host CSR + bins -> device
 int set_device_for(int device);
 

@@ -14,6 +14,9 @@
 //   block rows   (deg  > wave_max) : a 256-thread workgroup per row segment, LDS reduce; rows longer
 //                                    than seg_len are split into segments whose partial sums are added
 //                                    in fixed segment order by the last segment to finish
+// For graphs built from interactions the rows are additionally split by class: workgroups on XCDs 0-3 take
+// user rows (they gather item embeddings only), XCDs 4-7 item rows — each XCD's private 4 MB L2 then
+// caches one embedding table, not two (measured: the kernel is bound by L2 misses).
 // (col,val) are fetched lane-parallel (one coalesced non-temporal read per lane-group chunk) and
 // broadcast with ds_bpermute; U neighbour rows are in flight per lane-group before the FMAs.
 // No float atomics anywhere: the result is bit-stable run to run.
@@ -27,8 +30,8 @@
 
 namespace rbg {
 
-struct RowSrc {  // where dense rows live: row r is p0 + r*ld (r < split) or p1 + (r-split)*ld
-    const float *p0;
+struct RowSrc {  // where dense rows live: row r is p0 + r*ld (r < split) or p1 + r*ld (r >= split);
+    const float *p0;  // p1 is PRE-OFFSET by the host (second table base minus split*ld), see make_src()
     const float *p1;
     int32_t split;
     int32_t pad;
@@ -41,7 +44,7 @@ struct SpmmParams {
     const int32_t *rowptr;
     const int32_t *col;
     const float *val;
-    const int32_t *row_order;
+    const RowDesc *desc;
     const BlockTask *tasks;
     float *partials;
     uint32_t *counters;
@@ -49,10 +52,10 @@ struct SpmmParams {
     float *y;  // may be NULL in MODE_MEAN
     int64_t ldy;
     int32_t n_rows;
-    int32_t n_wave, n_short;
-    int32_t pos_wave, pos_short;     // start positions of the two bins inside row_order
-    int32_t blocks_task, blocks_wave;  // grid partition: [tasks | wave rows | short rows]
+    int32_t split_xcd;  // 1: blocks with (blockIdx & 7) < 4 run grp[0] (user rows), the others grp[1] (item rows)
+    GroupPlan grp[2];
     int32_t mode;
+    int32_t nt_store;
     // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom
     float *mean_out;
     RowSrc e0;
@@ -62,14 +65,27 @@ struct SpmmParams {
 };
 
 __device__ __forceinline__ const float *src_row(const RowSrc &s, int r) {
-    const bool lo = r < s.split;
-    const float *base = lo ? s.p0 : s.p1;
-    const int rr = lo ? r : r - s.split;
-    return base + (int64_t)rr * s.ld;
+    return (r < s.split ? s.p0 : s.p1) + (int64_t)r * s.ld;
 }
+// same with a compile-time row stride (the common contiguous case): one select + one shift-add
+template <int LD>
+__device__ __forceinline__ const float *src_row_c(const RowSrc &s, int r) {
+    return (r < s.split ? s.p0 : s.p1) + (int64_t)r * LD;
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// streaming store: the row is not read again by this launch, so it should not displace gathered rows in L2
+__device__ __forceinline__ void st4_stream(float *p, float4 v, int nt) {
+    if (nt) {
+        const v4f w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p));
+    } else {
+        st4(p, v);
+    }
+}
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
@@ -79,7 +95,7 @@ __device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
 
 // Sum of val[e] * X[col[e], 4*sl .. 4*sl+3] over the chunks of [beg,end) owned by lane-group g of G.
 // A chunk is LPR consecutive entries; lane sl of the group fetches entry sl of the chunk.
-template <int D, int U>
+template <int D, int U, bool CONTIG>
 __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl) {
     constexpr int LPR = D / 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -100,7 +116,7 @@ __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, j + u, LPR);
                 vv[u] = __shfl(v, j + u, LPR);
-                xv[u] = ld4(src_row(p.x, cj) + sl * 4);
+                xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc = fma4(vv[u], xv[u], acc);
@@ -116,7 +132,7 @@ __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int
                 const bool on = (j + u) < cnt;
                 vv[u] = on ? vj : 0.f;
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (on) xv[u] = ld4(src_row(p.x, cj) + sl * 4);
+                if (on) xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
             }
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) acc = fma4(vv[u], xv[u], acc);
@@ -146,16 +162,19 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
         for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + sl * 4));
         s = add4(s, acc);
         s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
-        st4(p.mean_out + (int64_t)row * D + sl * 4, s);
-        if (p.y) st4(p.y + (int64_t)row * p.ldy + sl * 4, acc);
+        st4_stream(p.mean_out + (int64_t)row * D + sl * 4, s, p.nt_store);
+        if (p.y) st4_stream(p.y + (int64_t)row * p.ldy + sl * 4, acc, p.nt_store);
     } else {
         float *dst = p.y + (int64_t)row * p.ldy + sl * 4;
-        if (p.mode == MODE_ACCUM) acc = add4(acc, ld4(dst));
-        st4(dst, acc);
+        if (p.mode == MODE_ACCUM) {
+            st4(dst, add4(acc, ld4(dst)));
+        } else {
+            st4_stream(dst, acc, p.nt_store);
+        }
     }
 }
 
-template <int D, int U>
+template <int D, int U, bool CONTIG>
 __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     constexpr int LPR = D / 4;
     constexpr int SUBS = 64 / LPR;
@@ -163,55 +182,64 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int sl = lane % LPR;
-    const int b = blockIdx.x;
+    // Row class of this workgroup.  Workgroup b is dispatched to XCD b % 8 (observed, used for speed only):
+    // XCDs 0-3 take class 0 (user rows, gather item embeddings), XCDs 4-7 class 1, so an XCD's 4 MB L2 is
+    // shared by ONE embedding table instead of two.
+    int grp = 0, vb = blockIdx.x;
+    if (p.split_xcd) {
+        const int x = blockIdx.x & 7;
+        grp = x >> 2;
+        vb = (blockIdx.x >> 3) * 4 + (x & 3);
+    }
+    const GroupPlan gp = p.grp[grp];
+    const int blocks_wave = (gp.n_wave + 3) >> 2;
 
-    if (b < p.blocks_task) {
+    if (vb < gp.n_tasks) {
         // ---- one workgroup per row segment ------------------------------------------------------
         __shared__ float red[4][D];
         __shared__ int last_flag;
-        const int4 t0 = *reinterpret_cast<const int4 *>(&p.tasks[b]);
-        const int4 t1 = *(reinterpret_cast<const int4 *>(&p.tasks[b]) + 1);
+        const int4 t0 = *reinterpret_cast<const int4 *>(&p.tasks[gp.task_base + vb]);
+        const int4 t1 = *(reinterpret_cast<const int4 *>(&p.tasks[gp.task_base + vb]) + 1);
         const int row = t0.x, beg = t0.y, end = t0.z, seg = t0.w;
         const int nseg = t1.x, part_base = t1.y, ctr = t1.z;
-        float4 acc = gather_range<D, U>(p, beg, end, wave * SUBS + sub, 4 * SUBS, sl);
+        float4 acc = gather_range<D, U, CONTIG>(p, beg, end, wave * SUBS + sub, 4 * SUBS, sl);
         acc = reduce_groups<D>(acc);
         if (sub == 0) st4(&red[wave][sl * 4], acc);
         __syncthreads();
-        if (wave != 0 || sub != 0) {
-            if (nseg == 1) return;
-        } else {
+        const bool owner = (wave == 0 && sub == 0);
+        if (owner)
             acc = add4(add4(ld4(&red[0][sl * 4]), ld4(&red[1][sl * 4])),
                        add4(ld4(&red[2][sl * 4]), ld4(&red[3][sl * 4])));
-            if (nseg == 1) {
-                finish_row(p, row, acc, sl, D);
-                return;
-            }
-            // split row: publish this segment's partial sum (plain stores, released below)
-            st4(p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + sl * 4, acc);
+        if (nseg == 1) {
+            if (owner) finish_row(p, row, acc, sl, D);
+            return;
         }
-        // All threads of a split-row task reach this point.  Arrival protocol (guide §6 G16):
-        // drain stores -> barrier -> one lane: agent release, drained, relaxed agent RMW on the row's
-        // counter; the last arriver acquires and adds the partials in segment order.
+        // Split row.  Publish this segment's partial sum WRITE-THROUGH (agent-scope relaxed stores = sc1, no
+        // L2-flushing release fence), drain, then one lane bumps the row's arrival counter; the last segment
+        // to arrive re-reads all partials with agent-scope loads (served past L1) and adds them in segment
+        // order, so the result does not depend on arrival order (MI355X guide §6 G16, form R1).
+        if (owner) {
+            float *dst = p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + sl * 4;
+            __hip_atomic_store(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 3, acc.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned old = __hip_atomic_fetch_add(p.counters + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (old == (unsigned)(nseg - 1));
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // self-cleaning: the next (stream-ordered) launch finds the counter at zero
+            if (last)  // self-cleaning: the next (stream-ordered) launch finds the counter at zero
                 __hip_atomic_store(p.counters + ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             last_flag = last;
         }
         __syncthreads();
-        if (last_flag && wave == 0 && sub == 0) {
+        if (last_flag && owner) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int i = 0; i < nseg; ++i) {
                 const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + sl * 4;
-                float4 q;  // agent-scope loads: served from L2, never from this CU's L1
+                float4 q;
                 q.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -223,33 +251,30 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         return;
     }
 
-    if (b < p.blocks_task + p.blocks_wave) {
+    if (vb < gp.n_tasks + blocks_wave) {
         // ---- one wavefront per row --------------------------------------------------------------
-        const int slot = (b - p.blocks_task) * 4 + wave;
-        if (slot >= p.n_wave) return;
-        const int row = p.row_order[p.pos_wave + slot];
-        const int beg = p.rowptr[row], end = p.rowptr[row + 1];
-        float4 acc = gather_range<D, U>(p, beg, end, sub, SUBS, sl);
+        const int slot = (vb - gp.n_tasks) * 4 + wave;
+        if (slot >= gp.n_wave) return;
+        const int4 dsc = *reinterpret_cast<const int4 *>(&p.desc[gp.pos_wave + slot]);
+        float4 acc = gather_range<D, U, CONTIG>(p, dsc.y, dsc.z, sub, SUBS, sl);
         acc = reduce_groups<D>(acc);
-        if (sub == 0) finish_row(p, row, acc, sl, D);
+        if (sub == 0) finish_row(p, dsc.x, acc, sl, D);
         return;
     }
 
     // ---- one lane-group per row (degree-sorted, so the groups of a wave have similar lengths) ----
-    const int slot = ((b - p.blocks_task - p.blocks_wave) * 4 + wave) * SUBS + sub;
-    if (slot >= p.n_short) return;
-    const int row = p.row_order[p.pos_short + slot];
-    const int beg = p.rowptr[row], end = p.rowptr[row + 1];
-    const float4 acc = gather_range<D, U>(p, beg, end, 0, 1, sl);
-    finish_row(p, row, acc, sl, D);
+    const int slot = ((vb - gp.n_tasks - blocks_wave) * 4 + wave) * SUBS + sub;
+    if (slot >= gp.n_short) return;
+    const int4 dsc = *reinterpret_cast<const int4 *>(&p.desc[gp.pos_short + slot]);
+    const float4 acc = gather_range<D, U, CONTIG>(p, dsc.y, dsc.z, 0, 1, sl);
+    finish_row(p, dsc.x, acc, sl, D);
 }
 
 // Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
 __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, int d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + wave;
-    if (slot >= p.n_rows) return;
-    const int row = p.row_order[slot];
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= p.n_rows) return;
     const int beg = p.rowptr[row], end = p.rowptr[row + 1];
     for (int k0 = 0; k0 < d; k0 += 64) {
         const int k = k0 + lane;
@@ -317,6 +342,17 @@ __global__ void gather_rows_kernel(const float *src, int64_t lds, const int64_t 
 
 // ---- host side ---------------------------------------------------------------------------------
 
+// Row source over one table (split = 0) or two tables (rows [0,split) in a, the rest in b).
+static RowSrc make_src(const float *a, const float *b, int64_t split, int64_t ld) {
+    RowSrc s;
+    s.p0 = a ? a : b;
+    s.p1 = (b ? b : a) - split * ld;  // pre-offset: row r >= split is p1 + r*ld
+    s.split = (int32_t)split;
+    s.pad = 0;
+    s.ld = ld;
+    return s;
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static bool vec_ok(const RowSrc &s) { return aligned16(s.p0) && aligned16(s.p1) && (s.ld % 4) == 0; }
@@ -325,36 +361,44 @@ static void fill_graph(const rbg_graph *g, SpmmParams &p) {
     p.rowptr = g->d_rowptr;
     p.col = g->d_col;
     p.val = g->d_val;
-    p.row_order = g->d_row_order;
+    p.desc = g->d_desc;
     p.tasks = g->d_tasks;
     p.partials = g->d_partials;
     p.counters = g->d_counters;
     p.n_rows = (int32_t)g->n_rows;
-    p.n_wave = (int32_t)g->n_wave;
-    p.n_short = (int32_t)g->n_short;
-    p.pos_wave = (int32_t)g->n_block_rows;
-    p.pos_short = (int32_t)(g->n_block_rows + g->n_wave);
+    p.split_xcd = g->n_groups == 2 ? 1 : 0;
+    p.grp[0] = g->groups[0];
+    p.grp[1] = g->groups[1];
+    p.nt_store = opt_nt_store();
+}
+
+static int64_t group_blocks(const GroupPlan &gp, int subs) {
+    return (int64_t)gp.n_tasks + (gp.n_wave + 3) / 4 + (gp.n_short + 4 * subs - 1) / (4 * subs);
 }
 
 template <int D>
-static void grid_for(const rbg_graph *g, SpmmParams &p, int64_t &grid) {
+static int64_t grid_for(const rbg_graph *g) {
     constexpr int SUBS = 64 / (D / 4);
-    p.blocks_task = (int32_t)g->n_tasks;
-    p.blocks_wave = (int32_t)((g->n_wave + 3) / 4);
-    const int64_t blocks_short = (g->n_short + 4 * SUBS - 1) / (4 * SUBS);
-    grid = (int64_t)p.blocks_task + p.blocks_wave + blocks_short;
+    if (g->n_groups == 2) {
+        const int64_t m = std::max(group_blocks(g->groups[0], SUBS), group_blocks(g->groups[1], SUBS));
+        return 8 * ((m + 3) / 4);
+    }
+    return group_blocks(g->groups[0], SUBS);
 }
 
 template <int D>
 static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
-    int64_t grid;
-    grid_for<D>(g, p, grid);
+    const int64_t grid = grid_for<D>(g);
     if (grid == 0) return RBG_OK;
     if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
-    switch (spmm_unroll()) {
-        case 2: hipLaunchKernelGGL((spmm_binned_kernel<D, 2>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
-        case 8: hipLaunchKernelGGL((spmm_binned_kernel<D, 8>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((spmm_binned_kernel<D, 4>), dim3((unsigned)grid), dim3(256), 0, s, p); break;
+    const bool contig = (p.x.ld == D);
+    const dim3 gr((unsigned)grid), bl(256);
+    if (spmm_unroll() == 8) {
+        if (contig) hipLaunchKernelGGL((spmm_binned_kernel<D, 8, true>), gr, bl, 0, s, p);
+        else hipLaunchKernelGGL((spmm_binned_kernel<D, 8, false>), gr, bl, 0, s, p);
+    } else {
+        if (contig) hipLaunchKernelGGL((spmm_binned_kernel<D, 4, true>), gr, bl, 0, s, p);
+        else hipLaunchKernelGGL((spmm_binned_kernel<D, 4, false>), gr, bl, 0, s, p);
     }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
@@ -387,7 +431,7 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
 int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
                  hipStream_t s) {
     SpmmParams p{};
-    p.x = RowSrc{X, X, 0, 0, ldx};
+    p.x = make_src(X, X, 0, ldx);
     p.y = Y;
     p.ldy = ldy;
     p.mode = accumulate ? MODE_ACCUM : MODE_STORE;
@@ -414,13 +458,12 @@ int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave,
     if (n_block_tasks) *n_block_tasks = g->n_tasks;
     if (n_split_rows) *n_split_rows = g->n_split_rows;
     if (grid_blocks) {
-        SpmmParams p{};
         int64_t grid = (g->n_rows + 3) / 4;
         switch (d) {
-            case 32: grid_for<32>(g, p, grid); break;
-            case 64: grid_for<64>(g, p, grid); break;
-            case 128: grid_for<128>(g, p, grid); break;
-            case 256: grid_for<256>(g, p, grid); break;
+            case 32: grid = grid_for<32>(g); break;
+            case 64: grid = grid_for<64>(g); break;
+            case 128: grid = grid_for<128>(g); break;
+            case 256: grid = grid_for<256>(g); break;
             default: break;
         }
         *grid_blocks = grid;
@@ -469,7 +512,7 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     if ((rc = set_device_for(g0->device))) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int64_t nd = n * d;
-    const RowSrc e0{user_emb ? user_emb : item_emb, item_emb ? item_emb : user_emb, (int32_t)n_users, 0, d};
+    const RowSrc e0 = make_src(user_emb, item_emb, n_users, d);
     if (K == 0) {  // mean of the single layer E0
         if (n_users) RBG_HIP(hipMemcpyAsync(out_mean, user_emb, sizeof(float) * n_users * d, hipMemcpyDeviceToDevice, s));
         if (n_users < n)
@@ -485,7 +528,7 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
         if (k == 0)
             p.x = e0;
         else
-            p.x = RowSrc{layers + (int64_t)(k - 1) * nd, layers + (int64_t)(k - 1) * nd, 0, 0, d};
+            p.x = make_src(layers + (int64_t)(k - 1) * nd, layers + (int64_t)(k - 1) * nd, 0, d);
         p.ldy = d;
         const bool last = (k == K - 1);
         if (last && fused) {

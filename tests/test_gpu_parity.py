@@ -85,12 +85,14 @@ def test_spmm_golden_layers(rbg, cuda, golden):
 
 
 @pytest.mark.parametrize("tuning", [(0, 0, 64), (2, 4, 64), (4, 16, 128), (1000, 1000, 4096)])
-def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning):
+@pytest.mark.parametrize("xcd_split", [1, 0])
+def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning, xcd_split):
     """Force rows through each mapping: lane-group, wavefront, workgroup, and split workgroup rows whose
     partial sums are combined by the last-arriving segment."""
     old = rbg.get_tuning()
     try:
         rbg.set_tuning(*tuning)
+        rbg.set_option("xcd_split", xcd_split)
         rng = np.random.default_rng(5)
         nu, ni = 40, 3000
         # user 1 is a hub with 2500 items (degree >> seg_len), user 2 has 700, the rest are short
@@ -103,15 +105,20 @@ def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning):
             assert bins["n_split_rows"] >= 2
         rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
         for d in (64, 128, 32, 256):
+            rbg.set_option("spmm_unroll", 8 if d == 128 else 4)
+            rbg.set_option("nt_store", 0 if d == 32 else 1)
             x = randn((nu + ni, d), d, cuda)
             ref = C.spmm(rowptr, col, val, x.cpu().numpy())
             for _ in range(3):  # the split-row counters must be back at zero after every launch
                 close(rbg.ops.spmm_raw(h, x), ref)
+        rbg.set_option("spmm_unroll", 4)
+        rbg.set_option("nt_store", 1)
         hn = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, flags=rbg._lib.GRAPH_NATURAL_ORDER)
         x = randn((nu + ni, 64), 1, cuda)
         close(rbg.ops.spmm_raw(hn, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
     finally:
         rbg.set_tuning(**old)
+        rbg.set_option("xcd_split", 1)
 
 
 def test_spmm_empty_and_rectangular(rbg, cuda):
@@ -260,7 +267,7 @@ def test_lightgcn_training_gradients(rbg, cuda, golden):
     reg = (uw[u].norm() ** 2 + iw[p].norm() ** 2 + iw[q].norm() ** 2) / 4 / 2
     ref_loss = mf + 1e-5 * reg
     ref_loss.backward()
-    close(loss, ref_loss)
+    close(loss.reshape(()), ref_loss.reshape(()))
     close(model.user_embedding.weight.grad, uw.grad, tol=1e-6)
     close(model.item_embedding.weight.grad, iw.grad, tol=1e-6)
     # unfused structure gives the same gradients
