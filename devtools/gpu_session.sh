@@ -9,7 +9,7 @@ echo "== smoke ==" ; timeout 600 python -c "import __graft_entry__ as g; g.smoke
 echo "== pytest -m gpu ==" ; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.log
 echo "== bench ==" ; timeout 600 python bench.py 2>&1 | tail -3 | tee gpurun_out/bench.log
 if [ "${1:-}" != "notune" ]; then
-  echo "== tune ==" ; timeout 1500 python devtools/tune_spmm.py ${TUNE_ARGS:-} 2>&1 | tail -60 > gpurun_out/tune_tail.log
+  echo "== tune ==" ; timeout 1500 python devtools/tune_spmm.py --quick --big 2>&1 | tail -60 > gpurun_out/tune_tail.log
 fi
 echo "== rocprof ==" 
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 100 --warmup 10 --cpu-seconds 0 > "$OLDPWD/gpurun_out/rocprof_bench.log" 2>&1 )

@@ -78,7 +78,7 @@ extern "C" int mb_xcd_private(const float* buf, int64_t floats_per_xcd, int reps
 
 // Gather with a hot/cold split: rows with index >= hot_rows are fetched with non-temporal loads.
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int U>
+template <int U, int POL>
 __global__ __launch_bounds__(256) void gather_nt_kernel(const float* __restrict__ tab, const int* __restrict__ idx,
                                                         int64_t m, float* __restrict__ out, int per_group, int hot_rows) {
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
@@ -97,8 +97,14 @@ __global__ __launch_bounds__(256) void gather_nt_kernel(const float* __restrict_
                 const v4f* p = reinterpret_cast<const v4f*>(tab + (int64_t)cj * 64 + sl * 4);
                 x[u] = (v4f){0, 0, 0, 0};
                 // explicit cache-policy bit: the two flavours run under complementary exec masks
-                if (cj >= hot_rows) asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(x[u]) : "v"(p) : "memory");
-                else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(x[u]) : "v"(p) : "memory");
+                if (cj >= hot_rows) {
+                    if (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(x[u]) : "v"(p) : "memory");
+                    if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "+v"(x[u]) : "v"(p) : "memory");
+                    if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(x[u]) : "v"(p) : "memory");
+                    if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "+v"(x[u]) : "v"(p) : "memory");
+                    if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "+v"(x[u]) : "v"(p) : "memory");
+                    if (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "+v"(x[u]) : "v"(p) : "memory");
+                } else asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(x[u]) : "v"(p) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -107,8 +113,17 @@ __global__ __launch_bounds__(256) void gather_nt_kernel(const float* __restrict_
     }
     if (acc.x == 12345.678f) out[group] = acc.x + acc.y + acc.z + acc.w;
 }
-extern "C" int mb_gather_nt(const float* tab, const int* idx, int64_t m, float* out, int per_group, int hot_rows, void* stream) {
+extern "C" int mb_gather_nt(const float* tab, const int* idx, int64_t m, float* out, int per_group, int hot_rows, int pol, void* stream) {
     int64_t groups = (m + per_group - 1) / per_group;
-    hipLaunchKernelGGL(gather_nt_kernel<8>, dim3((unsigned)((groups + 15) / 16)), dim3(256), 0, (hipStream_t)stream, tab, idx, m, out, per_group, hot_rows);
+    dim3 g((unsigned)((groups + 15) / 16)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (pol) {
+        case 0: hipLaunchKernelGGL((gather_nt_kernel<8, 0>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+        case 1: hipLaunchKernelGGL((gather_nt_kernel<8, 1>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+        case 2: hipLaunchKernelGGL((gather_nt_kernel<8, 2>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+        case 3: hipLaunchKernelGGL((gather_nt_kernel<8, 3>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+        case 4: hipLaunchKernelGGL((gather_nt_kernel<8, 4>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+        default: hipLaunchKernelGGL((gather_nt_kernel<8, 5>), g, b, 0, s, tab, idx, m, out, per_group, hot_rows); break;
+    }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Condense the rocprofv3 CSVs of devtools/profile_session.sh into small files fit for profiles/."""
+import csv, glob, json, os, sys, collections
+
+root = sys.argv[1]
+out = {}
+# kernel stats
+for f in glob.glob(os.path.join(root, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    out["kernel_stats"] = rows
+    print("kernel stats:")
+    for r in rows[:8]:
+        print("  ", {k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+# PMC: per-dispatch counter values, averaged over the timed dispatches of the spmm kernel
+pmc = {}
+for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "spmm_binned" in r.get("Kernel_Name", ""):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        v = v[len(v) // 4:]  # skip warm-up dispatches
+        pmc[k] = {"mean": sum(v) / len(v), "n": len(v), "min": min(v), "max": max(v)}
+out["pmc_spmm_per_launch"] = pmc
+print("pmc:", json.dumps(pmc, indent=1))
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md §HBM: counters are in KiB-ish units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests
+    # at 64 B, so the read side is doubled before comparing with a byte count.
+    traffic = (2 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024
+    out["traffic_bytes_per_launch"] = traffic
+    print("traffic bytes per spmm launch (2*FETCH + WRITE)*1024 =", traffic)
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
