@@ -48,8 +48,30 @@ __device__ __forceinline__ void load_run(const float *base, int64_t ld, int64_t 
     }
 }
 
-// NCHUNK > 0: d <= 64*NCHUNK and the user fragment stays in registers across item tiles.
-// NCHUNK == 0: any d, the user fragment is re-read per item tile (L1/L2 resident).
+// One 64-wide k chunk of one 32x32 tile: 32 exact-fp32 MFMAs.
+__device__ __forceinline__ f32x16 mfma_chunk(const float (&a)[32], const float (&b)[32], f32x16 acc) {
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// C/D layout of the 32x32 MFMA: col = lane&31 (item), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (user).
+__device__ __forceinline__ void store_tile(float *__restrict__ S, int64_t n, int64_t B, int64_t user0, int64_t item, int h,
+                                           const f32x16 &acc) {
+    if (item < n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t u = user0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (u < B) S[u * n + item] = acc[r];
+        }
+    }
+}
+
+// NCHUNK > 0: d <= 64*NCHUNK and the user fragment stays in registers across item tiles; the item
+// fragment of the NEXT (tile, chunk) is fetched into the other buffer BEFORE the current tile's stores are
+// issued.  gfx950's vmcnt counts stores too, so an un-pipelined loop would drain every tile's 16 stores
+// (HBM write latency) before its next operand load could complete — measured MFMA busy 30 %.
+// NCHUNK == 0: any d, un-pipelined (user fragment re-read per tile).
 template <int NCHUNK, bool VEC>
 __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ U, int64_t ldu,
                                                     const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
@@ -60,44 +82,55 @@ __global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ U,
     const int64_t ur = user_tile * 32 + i;
     if (user_tile * 32 >= B) return;  // whole wave out of range (no barriers below)
     const bool u_ok = ur < B;
-    const int nchunk = (d + 63) / 64;
-
-    float a[(NCHUNK > 0 ? NCHUNK : 1)][32];
-    if (NCHUNK > 0) {
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a[c]);
-    }
-
     const int64_t n_tiles = (n + 31) / 32;
     const int64_t t0 = (int64_t)blockIdx.x * kTilesPerWave;
-    for (int64_t t = t0; t < t0 + kTilesPerWave && t < n_tiles; ++t) {
-        const int64_t jr = t * 32 + i;
-        const bool j_ok = jr < n;
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (NCHUNK > 0) {
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-                float b[32];
-                load_run<VEC>(I, ldi, jr, j_ok, c * 64 + h * 32, d, b);
-#pragma unroll
-                for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s], b[s], acc, 0, 0, 0);
-            }
-        } else {
+    const int64_t t1 = (t0 + kTilesPerWave < n_tiles) ? t0 + kTilesPerWave : n_tiles;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (NCHUNK == 0) {
+        const int nchunk = (d + 63) / 64;
+        for (int64_t t = t0; t < t1; ++t) {
+            const int64_t jr = t * 32 + i;
+            f32x16 acc = zero;
             for (int c = 0; c < nchunk; ++c) {
-                float b[32];
-                load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a[0]);
-                load_run<VEC>(I, ldi, jr, j_ok, c * 64 + h * 32, d, b);
-#pragma unroll
-                for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], b[s], acc, 0, 0, 0);
+                float a[32], b[32];
+                load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a);
+                load_run<VEC>(I, ldi, jr, jr < n, c * 64 + h * 32, d, b);
+                acc = mfma_chunk(a, b, acc);
             }
+            store_tile(S, n, B, user_tile * 32, jr, h, acc);
         }
-        // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        const int64_t item = t * 32 + i;
-        if (item < n) {
+    } else {
+        float a[NCHUNK][32];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t u = user_tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (u < B) S[u * n + item] = acc[r];
+        for (int c = 0; c < NCHUNK; ++c) load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a[c]);
+        float b0[32], b1[32];
+        load_run<VEC>(I, ldi, t0 * 32 + i, t0 * 32 + i < n, h * 32, d, b0);
+        if constexpr (NCHUNK == 1) {
+            for (int64_t t = t0; t < t1; t += 2) {  // two tiles per trip so the buffer choice is static
+                const int64_t j0 = t * 32 + i, j1 = j0 + 32, j2 = j0 + 64;
+                if (t + 1 < t1) load_run<VEC>(I, ldi, j1, j1 < n, h * 32, d, b1);
+                f32x16 acc = mfma_chunk(a[0], b0, zero);
+                store_tile(S, n, B, user_tile * 32, j0, h, acc);
+                if (t + 2 < t1) load_run<VEC>(I, ldi, j2, j2 < n, h * 32, d, b0);
+                if (t + 1 < t1) {
+                    acc = mfma_chunk(a[0], b1, zero);
+                    store_tile(S, n, B, user_tile * 32, j1, h, acc);
+                }
+            }
+        } else {  // NCHUNK even: chunk c uses buffer c & 1; the next tile's chunk 0 lands in b0 during the last chunk
+            for (int64_t t = t0; t < t1; ++t) {
+                const int64_t jr = t * 32 + i, jn = jr + 32;
+                f32x16 acc = zero;
+#pragma unroll
+                for (int c = 0; c < NCHUNK; c += 2) {
+                    load_run<VEC>(I, ldi, jr, jr < n, (c + 1) * 64 + h * 32, d, b1);
+                    acc = mfma_chunk(a[c], b0, acc);
+                    if (c + 2 < NCHUNK) load_run<VEC>(I, ldi, jr, jr < n, (c + 2) * 64 + h * 32, d, b0);
+                    else if (t + 1 < t1) load_run<VEC>(I, ldi, jn, jn < n, h * 32, d, b0);
+                    acc = mfma_chunk(a[c + 1], b1, acc);
+                }
+                store_tile(S, n, B, user_tile * 32, jr, h, acc);
             }
         }
     }
