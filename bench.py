@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--p-in", type=float, default=0.9, help="N>1: fraction of interactions inside a rank's block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
+    ap.add_argument("--transport", choices=["nccl", "staged"], default="nccl",
+                    help="N>1 halo transport: RCCL all_to_all (default) or host-staged gloo send/recv (self-test: lets "
+                         "several ranks share one GPU)")
     return ap.parse_args()
 
 
@@ -88,12 +91,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.transport == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.transport == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import recbole_gnn_amd as rbg
     from recbole_gnn_amd import sharded as sh
@@ -136,7 +143,7 @@ def main():
                                                 p_in=args.p_in)
         owner = sh.striped_partition(nu_g, ni_g, world)
         plan = sh.build_plans(uid, iid, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
-        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="nccl")
+        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport=args.transport)
         e0 = xavier(plan.n_owned, d, gen).to(dev)
 
         def step():
@@ -168,9 +175,34 @@ def main():
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed, ev_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev if args.transport == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
+
+    if world > 1:
+        # phase breakdown of one sharded layer (each phase alone, back to back; rank-0 view) so the scaling
+        # number comes with its explanation: halo exchange vs interior SpMM vs halo SpMM
+        def phase_us(fn, iters=20):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) * 1e3 / iters
+
+        halo_buf = torch.empty((max(plan.n_halo, 1), d), device=dev)
+        y_buf = torch.empty((plan.n_owned, d), device=dev)
+        extra["phase_us"] = {
+            "halo_exchange(pack + all_to_all)": phase_us(
+                lambda: (prop._exchange_nccl if args.transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
+            "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
+            "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
+        }
 
     if rank == 0:
         launch_us = ev_ms * 1e3 / (args.steps * launches_per_step)
@@ -190,10 +222,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "embedding_dim": d, "n_layers": k_layers,
                        "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
-                       "sharding": "none" if world == 1 else f"node-range x{world}"},
+                       "sharding": "none" if world == 1 else f"node-range x{world}, transport={args.transport}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
-                         "kernel": "spmm_binned_kernel<64,4>", "avg_launch_us": launch_us,
+                         "kernel": "spmm_binned_kernel<64,8,true>", "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "
                                  "time of the timed region / launches, so inter-kernel gaps and (N>1) halo waits count"},

@@ -72,18 +72,18 @@ def main():
         x = torch.randn(n, 64, device=dev)
         y = torch.empty_like(x)
         if args.quick:
-            grid = [(16, 192, 768)]
+            grid = [(64, 256, 4096)]
         else:
             grid = [(s, w, l) for s, w, l in itertools.product((32, 64, 128, 256), (256, 1024), (1024, 4096, 16384))
                     if w >= s]
         results = []
         for (s, w, l) in grid:
             rbg.set_tuning(s, w, l)
-            for split in (1, 0):
+            for split in (4, 5, 3, 0):
                 rbg.set_option("xcd_split", split)
                 g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
-                for unroll in ((4,) if args.quick else (4, 8)):
-                    for nt in (1, 0):
+                for unroll in ((8,) if args.quick else (4, 8)):
+                    for nt in ((1,) if args.quick else (1, 0)):
                         rbg.set_option("spmm_unroll", unroll)
                         rbg.set_option("nt_store", nt)
                         med, mn = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y), iters=100, warmup=10)

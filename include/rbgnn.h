@@ -73,8 +73,8 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
 
 /* Named process-wide options (experimentation / A-B runs; defaults are the tuned values).
  *   "spmm_unroll" : neighbour rows in flight per lane-group before the FMAs (4 or 8)
- *   "xcd_split"   : 1 = user rows on XCDs 0-3, item rows on XCDs 4-7 (graphs built from interactions; read at
- *                   graph creation), 0 = one row class on all XCDs
+ *   "xcd_split"   : S in 1..7 = user rows on XCDs [0,S), item rows on XCDs [S,8) (graphs built from interactions;
+ *                   read at graph creation; default 4), 0 = one row class on all XCDs
  *   "nt_store"    : 1 = non-temporal output stores */
 int rbg_set_option(const char *key, int64_t value);
 int rbg_get_option(const char *key, int64_t *value);

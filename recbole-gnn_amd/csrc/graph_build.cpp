@@ -38,7 +38,7 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{1}, g_nt_store{1};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
 int opt_xcd_split() { return g_xcd_split.load(); }
 int opt_nt_store() { return g_nt_store.load(); }
@@ -282,6 +282,7 @@ int upload_graph(rbg_graph *g) {
     }
     if (rc) return rc;
     g->n_groups = plan.n_groups;
+    g->xcd_split = std::min(7, std::max(1, opt_xcd_split()));
     g->groups[0] = plan.groups[0];
     g->groups[1] = plan.groups[1];
     g->n_block_rows = plan.n_block_rows;
@@ -373,7 +374,8 @@ int rbg_set_option(const char *key, int64_t value) {
         return RBG_OK;
     }
     if (!strcmp(key, "xcd_split")) {
-        g_xcd_split = value ? 1 : 0;
+        if (value < 0 || value > 7) return fail(RBG_EINVAL, "xcd_split must be 0 (off) or 1..7 XCDs for user rows");
+        g_xcd_split = (int)value;
         return RBG_OK;
     }
     if (!strcmp(key, "nt_store")) {

@@ -84,6 +84,7 @@ struct rbg_graph {
     // rows (expanded to d_tasks), wavefront rows and lane-group rows (both described by d_desc).
     rbg::Tuning tuning{};
     int n_groups = 1;
+    int xcd_split = 4;  // XCDs serving groups[0] when n_groups == 2
     rbg::GroupPlan groups[2] = {};
     rbg::RowDesc *d_desc = nullptr;  // [n_wave + n_short over all groups]
     int64_t n_block_rows = 0, n_wave = 0, n_short = 0;
@@ -103,6 +104,7 @@ struct BinPlan {
     std::vector<RowDesc> desc;
     std::vector<BlockTask> tasks;
     int n_groups = 1;
+    int xcd_split = 4;  // XCDs serving groups[0] when n_groups == 2
     GroupPlan groups[2] = {};
     int64_t n_block_rows = 0, n_wave = 0, n_short = 0, n_split = 0, n_slots = 0;
     int32_t max_deg = 0;

@@ -52,7 +52,7 @@ struct SpmmParams {
     float *y;  // may be NULL in MODE_MEAN
     int64_t ldy;
     int32_t n_rows;
-    int32_t split_xcd;  // 1: blocks with (blockIdx & 7) < 4 run grp[0] (user rows), the others grp[1] (item rows)
+    int32_t split_xcd;  // S > 0: workgroups on XCDs [0,S) run grp[0] (user rows), XCDs [S,8) grp[1] (item rows)
     GroupPlan grp[2];
     int32_t mode;
     int32_t nt_store;
@@ -187,9 +187,9 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     // shared by ONE embedding table instead of two.
     int grp = 0, vb = blockIdx.x;
     if (p.split_xcd) {
-        const int x = blockIdx.x & 7;
-        grp = x >> 2;
-        vb = (blockIdx.x >> 3) * 4 + (x & 3);
+        const int x = blockIdx.x & 7, S = p.split_xcd;
+        grp = x >= S;
+        vb = grp ? (blockIdx.x >> 3) * (8 - S) + (x - S) : (blockIdx.x >> 3) * S + x;
     }
     const GroupPlan gp = p.grp[grp];
     const int blocks_wave = (gp.n_wave + 3) >> 2;
@@ -366,7 +366,7 @@ static void fill_graph(const rbg_graph *g, SpmmParams &p) {
     p.partials = g->d_partials;
     p.counters = g->d_counters;
     p.n_rows = (int32_t)g->n_rows;
-    p.split_xcd = g->n_groups == 2 ? 1 : 0;
+    p.split_xcd = g->n_groups == 2 ? g->xcd_split : 0;
     p.grp[0] = g->groups[0];
     p.grp[1] = g->groups[1];
     p.nt_store = opt_nt_store();
@@ -380,8 +380,10 @@ template <int D>
 static int64_t grid_for(const rbg_graph *g) {
     constexpr int SUBS = 64 / (D / 4);
     if (g->n_groups == 2) {
-        const int64_t m = std::max(group_blocks(g->groups[0], SUBS), group_blocks(g->groups[1], SUBS));
-        return 8 * ((m + 3) / 4);
+        const int64_t S = g->xcd_split;
+        const int64_t m = std::max((group_blocks(g->groups[0], SUBS) + S - 1) / S,
+                                   (group_blocks(g->groups[1], SUBS) + (8 - S) - 1) / (8 - S));
+        return 8 * m;
     }
     return group_blocks(g->groups[0], SUBS);
 }

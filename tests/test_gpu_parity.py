@@ -85,7 +85,7 @@ def test_spmm_golden_layers(rbg, cuda, golden):
 
 
 @pytest.mark.parametrize("tuning", [(0, 0, 64), (2, 4, 64), (4, 16, 128), (1000, 1000, 4096)])
-@pytest.mark.parametrize("xcd_split", [1, 0])
+@pytest.mark.parametrize("xcd_split", [4, 0, 5, 1])
 def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning, xcd_split):
     """Force rows through each mapping: lane-group, wavefront, workgroup, and split workgroup rows whose
     partial sums are combined by the last-arriving segment."""
@@ -118,7 +118,7 @@ def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning, xcd_split):
         close(rbg.ops.spmm_raw(hn, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
     finally:
         rbg.set_tuning(**old)
-        rbg.set_option("xcd_split", 1)
+        rbg.set_option("xcd_split", 4)
 
 
 def test_spmm_empty_and_rectangular(rbg, cuda):
