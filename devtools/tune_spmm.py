@@ -69,6 +69,15 @@ def main():
         n, nnz = nu + ni, 2 * len(uid)
         b_layer, b_prop = rbg.synth.algorithmic_bytes(n, nnz, 64, 3)
         emit(kind="shape", name=name, n=n, nnz=nnz, gen_s=time.time() - t0, b_layer=b_layer)
+        for label, flags in (("device", 0), ("host", rbg._lib.GRAPH_BUILD_ON_HOST)):
+            ts = []
+            for _ in range(3):
+                t0 = time.time()
+                gb = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, flags=flags)
+                torch.cuda.synchronize()
+                ts.append(time.time() - t0)
+                del gb
+            emit(kind="graph_build", shape=name, builder=label, ms=min(ts) * 1e3, ms_all=[round(t * 1e3, 2) for t in ts])
         x = torch.randn(n, 64, device=dev)
         y = torch.empty_like(x)
         if args.quick:

@@ -267,13 +267,20 @@ static int to_device(T **dst, const T *src, size_t count) {
     return RBG_OK;
 }
 
-int upload_graph(rbg_graph *g) {
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
-        return fail(RBG_ENODEV, "a device graph was requested but no GPU is visible");
-    if (g->device >= n_dev) return fail(RBG_EINVAL, "device %d out of range (%d visible)", g->device, n_dev);
-    int rc = set_device_for(g->device);
-    if (rc) return rc;
+int to_device_raw(void **dst, const void *src, size_t bytes) {
+    *dst = nullptr;
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        *dst = nullptr;
+        return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
+    if (src && bytes) RBG_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return RBG_OK;
+}
+
+// Launch plan (row classes, degree bins, split-row scratch) from the host copy of rowptr.
+int upload_plan(rbg_graph *g) {
+    int rc;
     BinPlan plan;
     try {
         rc = plan_bins(g, plan);
@@ -292,22 +299,30 @@ int upload_graph(rbg_graph *g) {
     g->n_split_rows = plan.n_split;
     g->n_partial_slots = plan.n_slots;
     g->max_degree = plan.max_deg;
-    const int64_t nsplit = plan.n_split, nslots = plan.n_slots;
+    if ((rc = to_device(&g->d_desc, plan.desc.data(), plan.desc.size()))) return rc;
+    if ((rc = to_device(&g->d_tasks, plan.tasks.data(), plan.tasks.size()))) return rc;
+    const size_t pb = std::max<size_t>((size_t)plan.n_slots, 1) * kPartialSlotFloats * sizeof(float);
+    hipError_t e = hipMalloc((void **)&g->d_partials, pb);
+    if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", pb, hipGetErrorString(e));
+    const size_t cb = std::max<size_t>((size_t)plan.n_split, 1) * sizeof(uint32_t);
+    e = hipMalloc((void **)&g->d_counters, cb);
+    if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", cb, hipGetErrorString(e));
+    RBG_HIP(hipMemset(g->d_counters, 0, cb));
+    RBG_HIP(hipDeviceSynchronize());
+    return RBG_OK;
+}
+
+int upload_graph(rbg_graph *g) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(RBG_ENODEV, "a device graph was requested but no GPU is visible");
+    if (g->device >= n_dev) return fail(RBG_EINVAL, "device %d out of range (%d visible)", g->device, n_dev);
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
     if ((rc = to_device(&g->d_rowptr, g->h_rowptr.data(), g->h_rowptr.size()))) return rc;
     if ((rc = to_device(&g->d_col, g->h_col.data(), g->h_col.size()))) return rc;
     if ((rc = to_device(&g->d_val, g->h_val.data(), g->h_val.size()))) return rc;
-    if ((rc = to_device(&g->d_desc, plan.desc.data(), plan.desc.size()))) return rc;
-    if ((rc = to_device(&g->d_tasks, plan.tasks.data(), plan.tasks.size()))) return rc;
-    {
-        const size_t pb = std::max<size_t>((size_t)nslots, 1) * kPartialSlotFloats * sizeof(float);
-        hipError_t e = hipMalloc((void **)&g->d_partials, pb);
-        if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", pb, hipGetErrorString(e));
-        const size_t cb = std::max<size_t>((size_t)nsplit, 1) * sizeof(uint32_t);
-        e = hipMalloc((void **)&g->d_counters, cb);
-        if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", cb, hipGetErrorString(e));
-        RBG_HIP(hipMemset(g->d_counters, 0, cb));
-    }
-    RBG_HIP(hipDeviceSynchronize());
+    if ((rc = upload_plan(g))) return rc;
     if (!(g->flags & RBG_GRAPH_KEEP_HOST)) {
         std::vector<int32_t>().swap(g->h_rowptr);
         std::vector<int32_t>().swap(g->h_col);
@@ -414,6 +429,27 @@ int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, i
     g->device = device;
     g->flags = flags | (device < 0 ? RBG_GRAPH_KEEP_HOST : 0u);
     g->tuning = current_tuning();
+    if (device >= 0 && !(flags & RBG_GRAPH_BUILD_ON_HOST)) {
+        // device builder: sort / scan / weights in HBM, only rowptr returns for the launch plan
+        int rc = build_device_csr(g, n_users, n_items, n_inter, uid, iid, keep);
+        if (rc == RBG_OK) rc = upload_plan(g);
+        if (rc == RBG_OK && (flags & RBG_GRAPH_KEEP_HOST)) {
+            g->h_col.resize((size_t)g->nnz);
+            g->h_val.resize((size_t)g->nnz);
+            if (g->nnz && (hipMemcpy(g->h_col.data(), g->d_col, sizeof(int32_t) * (size_t)g->nnz, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(g->h_val.data(), g->d_val, sizeof(float) * (size_t)g->nnz, hipMemcpyDeviceToHost) != hipSuccess))
+                rc = fail(RBG_EHIP, "D2H copy of the CSR failed");
+        } else if (rc == RBG_OK) {
+            std::vector<int32_t>().swap(g->h_rowptr);
+        }
+        if (rc != RBG_OK) {
+            free_device(g);
+            delete g;
+            return rc;
+        }
+        *out = g;
+        return RBG_OK;
+    }
     return finish_create(out, g, build_host_csr(g, n_users, n_items, n_inter, uid, iid, keep));
 }
 

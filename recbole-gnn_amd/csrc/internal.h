@@ -110,7 +110,12 @@ struct BinPlan {
     int32_t max_deg = 0;
 };
 int plan_bins(const rbg_graph *g, BinPlan &plan);
-int upload_graph(rbg_graph *g);  // host CSR + bins -> device
+int upload_graph(rbg_graph *g);  // host CSR + launch plan -> device
+int upload_plan(rbg_graph *g);   // launch plan from g->h_rowptr -> device (CSR already resident)
+int to_device_raw(void **dst, const void *src, size_t bytes);  // hipMalloc (+ H2D copy when src != NULL)
+// graph_build_device.hip
+int build_device_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_inter, const int64_t *uid,
+                     const int64_t *iid, const uint8_t *keep);
 int set_device_for(int device);
 
 // spmm.hip — Y[n_rows, d] (row stride ldy) = Â · X (row stride ldx), optionally accumulating.

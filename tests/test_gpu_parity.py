@@ -33,16 +33,44 @@ def randn(shape, seed, dev):
 
 # ---- graph construction on the device -------------------------------------------------------
 
-def test_device_graph_is_bit_exact(rbg, cuda, golden):
+@pytest.mark.parametrize("builder", ["device", "host"])
+def test_device_graph_is_bit_exact(rbg, cuda, golden, builder):
+    """Both builders (HBM-side sort/scan/weights, and host C++ + upload) give the oracle's CSR bit for bit."""
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
-    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    flags = rbg._lib.GRAPH_BUILD_ON_HOST if builder == "host" else 0
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, flags=flags)
     assert h.is_device
     rowptr, col, val = h.export_csr()
     assert np.array_equal(rowptr, g["rowptr"]) and np.array_equal(col, g["col"]) and np.array_equal(val, g["val"])
-    v = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=g["sgl_keep"])
+    v = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=g["sgl_keep"], flags=flags)
     vrp, vcol, vval = v.export_csr()
     assert np.array_equal(vrp, g["sgl_rowptr"]) and np.array_equal(vcol, g["sgl_col"]) and np.array_equal(vval, g["sgl_val"])
+    hk = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, flags=flags | rbg._lib.GRAPH_KEEP_HOST)
+    for a, b in zip(hk.export_csr(), (g["rowptr"], g["col"], g["val"])):
+        assert np.array_equal(a, b)
+
+
+def test_device_builder_random_graphs(rbg, cuda):
+    """Duplicated interactions, masks, isolated nodes, empty graphs and bad ids through the device builder."""
+    rng = np.random.default_rng(12)
+    for trial in range(12):
+        nu, ni = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        e = int(rng.integers(0, 400))
+        uid, iid = rng.integers(0, nu, e), rng.integers(0, ni, e)
+        keep = (rng.random(e) < 0.7).astype(np.uint8)
+        for k in (None, keep):
+            h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, keep=k)
+            ref = C.build_norm_csr(uid, iid, nu, ni, keep=k)
+            for a, b in zip(h.export_csr(), ref):
+                assert np.array_equal(a, b)
+            x = randn((nu + ni, 32), trial, cuda)
+            close(rbg.ops.spmm_raw(h, x), C.spmm(ref[0], ref[1], ref[2], x.cpu().numpy()))
+    h = rbg.GraphHandle.from_interactions([], [], 3, 4, device=cuda)
+    assert h.nnz == 0 and h.n_rows == 7
+    with pytest.raises(rbg.RbgError) as ei:
+        rbg.GraphHandle.from_interactions([1, 9], [1, 1], 3, 3, device=cuda)
+    assert ei.value.code == rbg._lib.RBG_EINVAL
 
 
 # ---- SpMM -----------------------------------------------------------------------------------
@@ -423,8 +451,11 @@ def gowalla(rbg, cuda):
 def test_full_size_vs_c_oracle(rbg, cuda, gowalla):
     uid, iid, nu, ni, h = gowalla
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
-    got = h.export_csr()
+    got = h.export_csr()  # built by the device builder
     assert np.array_equal(got[0], rowptr) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
+    hh = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, flags=rbg._lib.GRAPH_BUILD_ON_HOST)
+    for a, b in zip(hh.export_csr(), got):
+        assert np.array_equal(a, b)
     x = randn((nu + ni, 64), 51, cuda)
     close(rbg.ops.spmm_raw(h, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
     gen = torch.Generator().manual_seed(2020)
