@@ -133,6 +133,27 @@ def main():
             bl, bp = rbg.synth.algorithmic_bytes(n, nnz, d, 3)
             emit(kind="propagation", shape=name, d=d, us=med, prop_per_s=1e6 / med, gbps_prop=bp / (med * 1e-6) / 1e9,
                  frac_layer=3 * bl / (med * 1e-6) / 8e12)
+        # one training step of LightGCN (forward + BPR/reg loss + backward + Adam), batch 2048 (RecBole default)
+        try:
+            ds = rbg.InteractionDataset(uid, iid, nu, ni)
+            model = rbg.LightGCN({"device": "cuda:0", "enable_sparse": True, "embedding_size": 64, "n_layers": 3}, ds)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            bu = torch.randint(1, nu, (2048,), device=dev)
+            bp = torch.randint(1, ni, (2048,), device=dev)
+            bn = torch.randint(1, ni, (2048,), device=dev)
+            batch = {"user_id": bu, "item_id": bp, "neg_item_id": bn}
+
+            def train_step():
+                opt.zero_grad(set_to_none=True)
+                loss = model.calculate_loss(batch)
+                loss.backward()
+                opt.step()
+
+            med, mn = time_us(train_step, iters=50, warmup=5)
+            emit(kind="train_step", shape=name, us=med, steps_per_s=1e6 / med)
+            del model, opt
+        except Exception as ex:  # noqa: BLE001
+            emit(kind="train_step", shape=name, error=str(ex)[:300])
         # scoring GEMM
         for bsz in (1, 128, 4096):
             u = torch.randn(bsz, 64, device=dev)

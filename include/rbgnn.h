@@ -162,6 +162,15 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
                              const float *user_emb, const float *item_emb, float *out_mean,
                              float *layers, int d, int K, uint32_t flags, void *stream);
 
+/* Backward of rbg_lightgcn_forward_f32 with respect to the two embedding tables (what torch autograd does through
+ * LightGCN.forward, lightgcn.py:70-81, during loss.backward()): the propagation is linear, so no activations are
+ * needed:  dE0 = (g + Â_0 (g + Â_1 (... (g + Â_{K-1} g)))) / (K+1),  g = dL/d(out_mean)  — K launches of the same
+ * SpMM with a fused "+ g" epilogue.  The graphs must be symmetric (they are: dataset.py:62-64, sgl.py:113-115) or
+ * the caller passes the transposed handles.  grad_e0 [N, d]: rows [0,n_users) are the user-table gradient, the rest
+ * the item-table gradient.  work: [N, d] scratch, needed for K >= 2.  No buffer may alias another. */
+int rbg_lightgcn_backward_f32(const rbg_graph *const *graphs, int n_graphs, const float *grad_out, float *grad_e0,
+                              float *work, int d, int K, void *stream);
+
 /* Replaces BiGNNConv.forward(x, edge_index, edge_weight)
  *   recbole_gnn/model/layers.py:54-58:  P = ÂX;  Y = lin1(P + X) + lin2(P ⊙ X)
  * and, with RBG_BIGNN_LEAKY_NORM, NGCF.forward's per-layer tail

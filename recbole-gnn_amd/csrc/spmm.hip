@@ -38,7 +38,7 @@ struct RowSrc {  // where dense rows live: row r is p0 + r*ld (r < split) or p1 
     int64_t ld;
 };
 
-enum { MODE_STORE = 0, MODE_ACCUM = 1, MODE_MEAN = 2 };
+enum { MODE_STORE = 0, MODE_ACCUM = 1, MODE_MEAN = 2, MODE_HORNER = 3 };
 
 struct SpmmParams {
     const int32_t *rowptr;
@@ -56,6 +56,8 @@ struct SpmmParams {
     GroupPlan grp[2];
     int32_t mode;
     int32_t nt_store;
+    // MODE_HORNER: y[row] = (addend[row] + acc) / denom   (one step of the backward chain)
+    const float *addend;
     // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom
     float *mean_out;
     RowSrc e0;
@@ -164,6 +166,10 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
         s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
         st4_stream(p.mean_out + (int64_t)row * D + sl * 4, s, p.nt_store);
         if (p.y) st4_stream(p.y + (int64_t)row * p.ldy + sl * 4, acc, p.nt_store);
+    } else if (p.mode == MODE_HORNER) {
+        float4 s = add4(ld4(p.addend + (int64_t)row * D + sl * 4), acc);
+        s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
+        st4_stream(p.y + (int64_t)row * p.ldy + sl * 4, s, p.nt_store);
     } else {
         float *dst = p.y + (int64_t)row * p.ldy + sl * 4;
         if (p.mode == MODE_ACCUM) {
@@ -301,6 +307,8 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, i
                 s += acc;
                 p.mean_out[(int64_t)row * d + k] = s / p.denom;
                 if (p.y) p.y[(int64_t)row * p.ldy + k] = acc;
+            } else if (p.mode == MODE_HORNER) {
+                p.y[(int64_t)row * p.ldy + k] = (p.addend[(int64_t)row * d + k] + acc) / p.denom;
             } else {
                 float *dst = p.y + (int64_t)row * p.ldy + k;
                 *dst = (p.mode == MODE_ACCUM) ? (*dst + acc) : acc;
@@ -411,6 +419,7 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     fill_graph(g, p);
     if (g->n_rows == 0) return RBG_OK;
     bool vec = (d % 4 == 0) && vec_ok(p.x) && (p.ldy % 4 == 0) && (!p.y || aligned16(p.y));
+    if (p.mode == MODE_HORNER) vec = vec && aligned16(p.addend);
     if (p.mode == MODE_MEAN) {
         vec = vec && vec_ok(p.e0) && aligned16(p.mean_out);
         for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
@@ -550,6 +559,50 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     if (!fused) {
         hipLaunchKernelGGL(layer_mean_kernel, dim3(2048), dim3(256), 0, s, e0, layers, n, d, K, out_mean);
         RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+int rbg_lightgcn_backward_f32(const rbg_graph *const *graphs, int n_graphs, const float *grad_out, float *grad_e0,
+                              float *work, int d, int K, void *stream) {
+    clear_error();
+    if (!graphs || n_graphs < 1) return fail(RBG_EINVAL, "graphs is NULL or empty");
+    if (K < 0) return fail(RBG_EINVAL, "K = %d", K);
+    if (n_graphs != 1 && n_graphs != K) return fail(RBG_ESHAPE, "n_graphs = %d but K = %d", n_graphs, K);
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    int rc;
+    for (int i = 0; i < n_graphs; ++i) {
+        if ((rc = check_device_graph(graphs[i]))) return rc;
+        if (graphs[i]->n_rows != graphs[0]->n_rows || graphs[i]->n_cols != graphs[0]->n_rows ||
+            graphs[i]->device != graphs[0]->device)
+            return fail(RBG_ESHAPE, "graph %d is not a square graph of the same size/device as graph 0", i);
+    }
+    const int64_t n = graphs[0]->n_rows;
+    if (n == 0) return RBG_OK;
+    if (!grad_out || !grad_e0) return fail(RBG_EINVAL, "NULL gradient pointer");
+    if (grad_out == grad_e0 || work == grad_out || (work && work == grad_e0)) return fail(RBG_EINVAL, "buffers alias");
+    if (K >= 2 && !work) return fail(RBG_EINVAL, "work buffer is NULL (needed for K >= 2)");
+    if ((rc = set_device_for(graphs[0]->device))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 0) {
+        RBG_HIP(hipMemcpyAsync(grad_e0, grad_out, sizeof(float) * n * d, hipMemcpyDeviceToDevice, s));
+        return RBG_OK;
+    }
+    // dE0 = (g + Â_0 (g + Â_1 (... (g + Â_{K-1} g)))) / (K+1): step i uses graph K-1-i; outputs ping-pong so that the
+    // last one lands in grad_e0.
+    const float *x = grad_out;
+    for (int i = 0; i < K; ++i) {
+        const rbg_graph *g = graphs[n_graphs == 1 ? 0 : K - 1 - i];
+        float *y = ((K - 1 - i) % 2 == 0) ? grad_e0 : work;
+        SpmmParams p{};
+        p.x = make_src(x, x, 0, d);
+        p.y = y;
+        p.ldy = d;
+        p.mode = MODE_HORNER;
+        p.addend = grad_out;
+        p.denom = (i == K - 1) ? (float)(K + 1) : 1.0f;
+        if ((rc = launch_spmm(g, p, d, s))) return rc;
+        x = y;
     }
     return RBG_OK;
 }

@@ -157,14 +157,17 @@ class _LightGCNForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         k_layers = ctx.n_layers
-        c = (grad_out / float(k_layers + 1)).contiguous()
-        t = c
-        for k in reversed(range(k_layers)):
-            g = ctx.graphs[0] if len(ctx.graphs) == 1 else ctx.graphs[k]
-            nxt = c.clone()
-            spmm_raw(g.transpose(), t, out=nxt, accumulate=True)
-            t = nxt
-        return (t[:ctx.n_users], t[ctx.n_users:], None) + (None,) * len(ctx.graphs)
+        g = grad_out.contiguous()
+        _check_dense(g, "grad_out", ctx.graphs[0])
+        grad_e0 = torch.empty_like(g)
+        work = torch.empty_like(g) if k_layers >= 2 else None
+        graphs = [gr.transpose() for gr in ctx.graphs]  # the handle itself when symmetric
+        arr = (c_vp * len(graphs))(*[gr.ptr for gr in graphs])
+        with torch.cuda.device(g.device):
+            check(lib.rbg_lightgcn_backward_f32(arr, len(graphs), c_vp(g.data_ptr()), c_vp(grad_e0.data_ptr()),
+                                                c_vp(work.data_ptr()) if work is not None else None, g.shape[1], k_layers,
+                                                _stream(g)))
+        return (grad_e0[:ctx.n_users], grad_e0[ctx.n_users:], None) + (None,) * len(ctx.graphs)
 
 
 def lightgcn_forward(graphs, user_w, item_w, n_layers):

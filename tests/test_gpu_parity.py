@@ -149,6 +149,46 @@ def test_spmm_every_bin_and_split_rows(rbg, cuda, tuning, xcd_split):
         rbg.set_option("xcd_split", 4)
 
 
+def test_hub_rows_at_scale(rbg, cuda):
+    """Config-#5-like hubs: rows of degree 250 000 / 100 000 (dozens of split segments each, default tuning),
+    next to 300 k short rows; d = 64 and 128; repeated launches must leave the arrival counters at zero."""
+    rng = np.random.default_rng(8)
+    nu, ni = 2000, 300_001
+    hub1 = rng.permutation(ni - 1)[:250_000] + 1
+    hub2 = rng.permutation(ni - 1)[:100_000] + 1
+    uid = np.concatenate([np.full(len(hub1), 1), np.full(len(hub2), 2), rng.integers(3, nu, 200_000)])
+    iid = np.concatenate([hub1, hub2, rng.integers(1, ni, 200_000)])
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    bins = h.bins(64)
+    assert bins["n_split_rows"] >= 2 and bins["n_block_tasks"] >= 80
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    got = h.export_csr()
+    assert np.array_equal(got[0], rowptr) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
+    # A 250 000-term fp32 sum accumulated strictly left to right (the reference's CPU loop, = the C oracle) is itself
+    # ~1e-4 away from the exact value, so for these rows the bar is float64 truth: the HIP result (segmented sums)
+    # must be within 1e-5 of it, and no further from the fp32 oracle than the oracle is from the truth.
+    for d in (64, 128):
+        x = randn((nu + ni, d), d, cuda)
+        truth = O.conv_csr_f64(x.cpu().numpy(), rowptr, col, val)
+        ref32 = C.spmm(rowptr, col, val, x.cpu().numpy())
+        y0 = rbg.ops.spmm_raw(h, x)
+        err_hip = close(y0, truth)
+        err_ref = float(np.abs(ref32 - truth).max())
+        assert err_hip <= err_ref + 1e-6
+        short = np.diff(rowptr) <= 4096  # every ordinary row still matches the fp32 oracle itself
+        close(y0[torch.from_numpy(short).to(cuda)], ref32[short])
+        for _ in range(3):
+            assert torch.equal(rbg.ops.spmm_raw(h, x), y0)  # bit-stable, counters self-clean
+    uw, iw = randn((nu, 64), 1, cuda), randn((ni, 64), 2, cuda)
+    mean, _ = rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)
+    e64 = np.concatenate([uw.cpu().numpy(), iw.cpu().numpy()]).astype(np.float64)
+    acc, cur = e64.copy(), e64
+    for _ in range(3):
+        cur = O.conv_csr_f64(cur, rowptr, col, val)
+        acc = acc + cur
+    close(mean, acc / 4.0)
+
+
 def test_spmm_empty_and_rectangular(rbg, cuda):
     h = rbg.GraphHandle.from_interactions([], [], 3, 4, device=cuda)
     y = rbg.ops.spmm_raw(h, randn((7, 64), 0, cuda))
@@ -303,6 +343,34 @@ def test_lightgcn_training_gradients(rbg, cuda, golden):
     model.fused = False
     model.calculate_loss(batch).backward()
     close(model.user_embedding.weight.grad, uw.grad, tol=1e-6)
+
+
+@pytest.mark.parametrize("k_layers,per_layer", [(0, False), (1, False), (2, False), (3, False), (4, True), (3, True)])
+def test_fused_backward_vs_torch_autograd(rbg, cuda, golden, k_layers, per_layer):
+    """rbg_lightgcn_backward_f32 (Horner chain, fused '+ g' epilogue) against torch autograd through the oracle's
+    dense-branch formulation; also SGL's per-layer graphs (sgl.py:136-139)."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    rng = np.random.default_rng(21)
+    n_graphs = k_layers if per_layer else 1
+    masks = [None] * max(n_graphs, 1) if not per_layer else [(rng.random(len(g["uid"])) < 0.9).astype(np.uint8) for _ in range(n_graphs)]
+    handles = [rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=m) for m in masks]
+    pairs = []
+    for m in masks:
+        keep = np.ones(len(g["uid"]), dtype=bool) if m is None else m.astype(bool)
+        pairs.append(O.get_norm_adj_mat(g["uid"][keep], g["iid"][keep], nu, ni, enable_sparse=False))
+    uw = randn((nu, 64), 5, cuda).requires_grad_(True)
+    iw = randn((ni, 64), 6, cuda).requires_grad_(True)
+    w = randn((nu + ni, 64), 7, cuda)
+    out = rbg.lightgcn_forward(handles if per_layer else handles[0], uw, iw, k_layers)
+    (out * w).sum().backward()
+    uw_r = uw.detach().cpu().clone().requires_grad_(True)
+    iw_r = iw.detach().cpu().clone().requires_grad_(True)
+    convs = [(lambda t, p=p: O.conv_dense(t, p[0], p[1])) for p in pairs]
+    u_all, i_all = O.lightgcn_forward(uw_r, iw_r, convs if per_layer else convs[0], k_layers)
+    (torch.cat([u_all, i_all]) * w.cpu()).sum().backward()
+    close(uw.grad, uw_r.grad)
+    close(iw.grad, iw_r.grad)
 
 
 def test_sgl_model_views(rbg, cuda, golden):
