@@ -150,7 +150,11 @@ def main():
                 opt.step()
 
             med, mn = time_us(train_step, iters=50, warmup=5)
-            emit(kind="train_step", shape=name, us=med, steps_per_s=1e6 / med)
+            emit(kind="train_step", shape=name, path="torch autograd + torch Adam", us=med, steps_per_s=1e6 / med)
+            model.require_pow = True
+            fused = rbg.FusedBPRAdam(model, lr=1e-3)
+            med, mn = time_us(lambda: fused.step(batch), iters=50, warmup=5)
+            emit(kind="train_step", shape=name, path="fused (5 C-ABI calls)", us=med, steps_per_s=1e6 / med)
             del model, opt
         except Exception as ex:  # noqa: BLE001
             emit(kind="train_step", shape=name, error=str(ex)[:300])

@@ -192,6 +192,30 @@ int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const fl
 int rbg_score_f32(const float *U, int64_t ldu, const float *I, int64_t ldi, float *S, int64_t B,
                   int64_t n, int d, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fused mini-batch training step.  All pointers are DEVICE pointers; `loss` is a
+ * device scalar.  Row scatters use float atomics like torch's GPU index backward.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces lightgcn.py:93-100 + their autograd: pos/neg scores of (user, pos, neg) triples on out_mean [N,d]
+ * (rows [0,n_users) users, then items), BPRLoss(gamma = 1e-10) = -mean(log(gamma + sigmoid(pos - neg))).
+ * Zeroes grad_mean [N,d] and *loss, then writes dLoss/d(out_mean) and the loss value. */
+int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, const int64_t *user, const int64_t *pos,
+                     const int64_t *neg, int64_t B, int d, float *grad_mean, float *loss, void *stream);
+
+/* Replaces lightgcn.py:103-108 with require_pow = True: reg_weight * EmbLoss(U0[user], I0[pos], I0[neg]) on the EGO
+ * embeddings; ADDS its value to *loss and its sparse-row gradient onto grad_e0 [N,d] (call after
+ * rbg_lightgcn_backward_f32). */
+int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n_users, const int64_t *user,
+                         const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight, float *grad_e0,
+                         float *loss, void *stream);
+
+/* Replaces optimizer.step() of torch.optim.Adam (RecBole's default learner; no weight decay, no amsgrad) for the
+ * two embedding tables in one pass.  grad / exp_avg / exp_avg_sq are [N,d]; step counts from 1. */
+int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                      float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
+                      void *stream);
+
 /* Row gather: dst[i, :] = src[idx[i], :]  (restore_user_e[user], lightgcn.py:128; also packs the
  * halo send buffer of the node-range sharded path).  idx is a DEVICE int64 array. */
 int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,

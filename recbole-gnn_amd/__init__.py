@@ -5,11 +5,13 @@ The package directory name carries a hyphen; import it as ``recbole_gnn_amd`` (t
 the repository root) or with ``importlib.import_module("recbole-gnn_amd")``.
 Importing fails loudly if librbgnn.so (the HIP extension) has not been built; there is no CPU path.
 """
-from . import _lib, graph, models, ops, sharded, synth  # noqa: F401
+from . import _lib, graph, models, ops, sharded, synth, train  # noqa: F401
 from ._lib import LIB_PATH, RbgError  # noqa: F401
 from .graph import (GraphHandle, InteractionDataset, device_count, get_option, get_tuning, norm_edges,  # noqa: F401
                     set_option, set_tuning)
 from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN  # noqa: F401
 from .ops import BiGNNConv, LightGCNConv, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
+
+from .train import FusedBPRAdam  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -1,0 +1,159 @@
+// train.hip — the mini-batch step around the propagation, fused.
+//
+// Replaces, for LightGCN.calculate_loss (recbole_gnn/model/general_recommender/lightgcn.py:83-110) followed by
+// loss.backward() and optimizer.step() in RecBole's Trainer._train_epoch [recbole==1.1.1]:
+//   rbg_bpr_grad_f32   : pos/neg scores (lightgcn.py:98-99), BPRLoss(gamma=1e-10) (:100), and dLoss/d(out_mean)
+//                        scattered into a dense [N,d] buffer (what torch's index backward does)
+//   rbg_emb_reg_grad_f32: EmbLoss on the EGO embeddings with require_pow=True (:103-108): loss term and its
+//                        sparse-row gradient added onto dE0 after the backward chain
+//   rbg_adam_step_f32  : torch.optim.Adam (defaults: no weight decay, no amsgrad) over both embedding tables
+// Row scatters use float atomics, like torch's GPU index_put_(accumulate=True): duplicated ids inside a batch
+// make the low bits of those rows order-dependent.
+
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+
+#include <algorithm>
+
+#include "internal.h"
+
+namespace rbg {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// one wavefront per batch element
+__global__ __launch_bounds__(256) void bpr_grad_kernel(const float *__restrict__ mean, int64_t n_users,
+                                                       const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
+                                                       const int64_t *__restrict__ neg, int64_t B, int d, float gamma,
+                                                       float *__restrict__ grad_mean, float *__restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *ue = mean + user[b] * d;
+    const float *pe = mean + (n_users + pos[b]) * d;
+    const float *ne = mean + (n_users + neg[b]) * d;
+    float sp = 0.f, sn = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float u = ue[k];
+        sp = fmaf(u, pe[k], sp);
+        sn = fmaf(u, ne[k], sn);
+    }
+    sp = wave_sum(sp);
+    sn = wave_sum(sn);
+    const float x = sp - sn;
+    const float sig = 1.0f / (1.0f + expf(-x));
+    // L = -mean(log(gamma + sig));  dL/dx = -(sig (1 - sig)) / (gamma + sig) / B
+    const float c = -(sig * (1.0f - sig)) / (gamma + sig) / (float)B;
+    float *gu = grad_mean + user[b] * d;
+    float *gp = grad_mean + (n_users + pos[b]) * d;
+    float *gn = grad_mean + (n_users + neg[b]) * d;
+    for (int k = lane; k < d; k += 64) {
+        const float u = ue[k], p = pe[k], n = ne[k];
+        atomicAdd(gu + k, c * (p - n));
+        atomicAdd(gp + k, c * u);
+        atomicAdd(gn + k, -c * u);
+    }
+    if (lane == 0) atomicAdd(loss, -logf(gamma + sig) / (float)B);
+}
+
+// EmbLoss(norm=2, require_pow=True): reg = (|U0[user]|^2 + |I0[pos]|^2 + |I0[neg]|^2) / B / 2
+// d(reg_weight * reg)/d(row) = reg_weight / B * row   per occurrence
+__global__ __launch_bounds__(256) void emb_reg_grad_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
+                                                           int64_t n_users, const int64_t *__restrict__ user,
+                                                           const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                           int64_t B, int d, float reg_weight, float *__restrict__ grad_e0,
+                                                           float *__restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= 3 * B) return;
+    const int64_t b = w % B;
+    const int which = (int)(w / B);  // 0 user, 1 pos item, 2 neg item
+    const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
+    const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
+    float *g = grad_e0 + (which == 0 ? id : n_users + id) * d;
+    const float s = reg_weight / (float)B;
+    float sq = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float e = row[k];
+        sq = fmaf(e, e, sq);
+        atomicAdd(g + k, s * e);
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) atomicAdd(loss, reg_weight * sq / (float)B * 0.5f);
+}
+
+// torch.optim.Adam single step (foreach/fused semantics): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   Rows [0,n_users) of the [N,d] state live in the
+// user table, the rest in the item table.
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ user_emb, float *__restrict__ item_emb, int64_t n_users_d,
+                                                   const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                                   int64_t nd, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = grad[i];
+        const float mi = beta1 * m[i] + (1.0f - beta1) * g;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        float *p = i < n_users_d ? user_emb + i : item_emb + (i - n_users_d);
+        *p = *p - lr_over_bc1 * (mi / denom);
+    }
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, const int64_t *user, const int64_t *pos,
+                     const int64_t *neg, int64_t B, int d, float *grad_mean, float *loss, void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || B < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (!out_mean || !grad_mean || !loss || (B > 0 && (!user || !pos || !neg))) return fail(RBG_EINVAL, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    RBG_HIP(hipMemsetAsync(grad_mean, 0, sizeof(float) * (size_t)(n_users + n_items) * d, s));
+    RBG_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    if (B == 0) return RBG_OK;
+    hipLaunchKernelGGL(bpr_grad_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, out_mean, n_users, user, pos, neg, B, d,
+                       1e-10f, grad_mean, loss);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n_users, const int64_t *user,
+                         const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight, float *grad_e0,
+                         float *loss, void *stream) {
+    clear_error();
+    if (n_users < 0 || B < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (B == 0 || reg_weight == 0.f) return RBG_OK;
+    if (!user_emb || !item_emb || !user || !pos || !neg || !grad_e0 || !loss) return fail(RBG_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(emb_reg_grad_kernel, dim3((unsigned)((3 * B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, user_emb,
+                       item_emb, n_users, user, pos, neg, B, d, reg_weight, grad_e0, loss);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                      float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
+                      void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || d <= 0 || step < 1) return fail(RBG_ESHAPE, "bad shape or step < 1");
+    const int64_t nd = (n_users + n_items) * d;
+    if (nd == 0) return RBG_OK;
+    if (!grad || !exp_avg || !exp_avg_sq || (n_users && !user_emb) || (n_items && !item_emb)) return fail(RBG_EINVAL, "NULL pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const unsigned blocks = (unsigned)std::min<int64_t>((nd + 255) / 256, 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, user_emb, item_emb, n_users * d, grad,
+                       exp_avg, exp_avg_sq, nd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+}  // extern "C"

@@ -373,6 +373,47 @@ def test_fused_backward_vs_torch_autograd(rbg, cuda, golden, k_layers, per_layer
     close(iw.grad, iw_r.grad)
 
 
+def test_fused_training_step_matches_torch_adam(rbg, cuda, golden):
+    """FusedBPRAdam.step == calculate_loss + backward + torch.optim.Adam.step, checked against the same three steps
+    done by torch autograd on the CPU through the oracle's dense-branch propagation."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    uw = model.user_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    iw = model.item_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    ref_opt = torch.optim.Adam([uw, iw], lr=1e-2)
+    ei, ew = O.get_norm_adj_mat(g["uid"], g["iid"], nu, ni, enable_sparse=False)
+    fused = rbg.FusedBPRAdam(model, lr=1e-2)
+    rng = np.random.default_rng(4)
+    for step in range(3):
+        u = torch.from_numpy(rng.integers(1, nu, 64))   # duplicates inside the batch are likely and intended
+        p = torch.from_numpy(rng.integers(1, ni, 64))
+        q = torch.from_numpy(rng.integers(1, ni, 64))
+        loss = fused.step({"user_id": u.to(cuda), "item_id": p.to(cuda), "neg_item_id": q.to(cuda)})
+        ref_opt.zero_grad()
+        u_all, i_all = O.lightgcn_forward(uw, iw, lambda t: O.conv_dense(t, ei, ew), 3)
+        pos = (u_all[u] * i_all[p]).sum(1)
+        neg = (u_all[u] * i_all[q]).sum(1)
+        mf = -torch.log(1e-10 + torch.sigmoid(pos - neg)).mean()
+        reg = (uw[u].norm() ** 2 + iw[p].norm() ** 2 + iw[q].norm() ** 2) / 64 / 2
+        ref_loss = mf + 1e-2 * reg
+        ref_loss.backward()
+        ref_opt.step()
+        close(loss.reshape(()), ref_loss.detach().reshape(()))
+        close(model.user_embedding.weight, uw.detach(), tol=2e-5)
+        close(model.item_embedding.weight, iw.detach(), tol=2e-5)
+    # the torch-autograd path of the model and the fused step agree on the very same batch, too
+    model2, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    model3, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    batch = {"user_id": u.to(cuda), "item_id": p.to(cuda), "neg_item_id": q.to(cuda)}
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-2)
+    model2.calculate_loss(batch).backward()
+    opt2.step()
+    rbg.FusedBPRAdam(model3, lr=1e-2).step(batch)
+    close(model3.user_embedding.weight, model2.user_embedding.weight, tol=2e-5)
+    close(model3.item_embedding.weight, model2.item_embedding.weight, tol=2e-5)
+
+
 def test_sgl_model_views(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
