@@ -158,6 +158,37 @@ def main():
             del model, opt
         except Exception as ex:  # noqa: BLE001
             emit(kind="train_step", shape=name, error=str(ex)[:300])
+        # model-level numbers through the reference-shaped classes
+        try:
+            ds = rbg.InteractionDataset(uid, iid, nu, ni)
+            ngcf = rbg.NGCF({"device": "cuda:0", "enable_sparse": True, "embedding_size": 64, "hidden_size_list": [64, 64, 64]}, ds)
+            with torch.no_grad():
+                med, mn = time_us(lambda: ngcf.forward(), iters=30, warmup=3)
+            emit(kind="ngcf_forward", shape=name, us=med, note="3 BiGNN layers + LeakyReLU + L2-norm, fused inference path, [N,256] out")
+            users = torch.arange(1, 1 + 1024, device=dev) % nu
+            with torch.no_grad():
+                ngcf.full_sort_predict({"user_id": users})
+                med, mn = time_us(lambda: ngcf.full_sort_predict({"user_id": users}), iters=10, warmup=2)
+            emit(kind="ngcf_full_sort", shape=name, users=1024, us=med, users_per_s=1024 / (med * 1e-6))
+            del ngcf
+            lgc = rbg.LightGCN({"device": "cuda:0", "enable_sparse": True, "embedding_size": 64, "n_layers": 3}, ds)
+            with torch.no_grad():
+                lgc.full_sort_predict({"user_id": users})
+                med, mn = time_us(lambda: lgc.full_sort_predict({"user_id": users}), iters=10, warmup=2)
+            emit(kind="lightgcn_full_sort", shape=name, users=1024, us=med, users_per_s=1024 / (med * 1e-6))
+            del lgc
+            sgl = rbg.SGL({"device": "cuda:0", "enable_sparse": True, "embedding_size": 64, "n_layers": 3, "type": "ED"}, ds)
+            np.random.seed(0)
+            t0 = time.time()
+            sgl.train()
+            torch.cuda.synchronize()
+            emit(kind="sgl_graph_construction", shape=name, ms=(time.time() - t0) * 1e3, note="2 ED views: numpy sampling + device build")
+            with torch.no_grad():
+                med, mn = time_us(lambda: sgl.propagate_views(), iters=30, warmup=3)
+            emit(kind="sgl_three_propagations", shape=name, us=med)
+            del sgl
+        except Exception as ex:  # noqa: BLE001
+            emit(kind="models", shape=name, error=str(ex)[:300])
         # scoring GEMM
         for bsz in (1, 128, 4096):
             u = torch.randn(bsz, 64, device=dev)

@@ -145,24 +145,34 @@ def build_plans(uid, iid, n_users, n_items, world, owner=None, ranks=None):
 # ---- compute backends ----------------------------------------------------------------------------
 
 class HipBackend:
-    """The product backend: librbgnn.so kernels on this rank's GPU."""
+    """The product backend: librbgnn.so kernels on this rank's GPU.  The hot calls go straight to the C ABI (the
+    shapes were validated when the plan was built), so a layer costs a handful of ctypes calls on the host."""
 
     def __init__(self, device):
-        from . import ops
+        from . import _lib, ops
         from .graph import GraphHandle
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HipBackend needs a cuda device (no CPU path)")
-        self._ops, self._GraphHandle = ops, GraphHandle
+        self._ops, self._GraphHandle, self._lib = ops, GraphHandle, _lib
 
     def make_graph(self, csr, n_cols):
         return self._GraphHandle.from_csr(csr[0], csr[1], csr[2], n_cols, device=self.device)
 
     def spmm(self, graph, x, out, accumulate):
-        return self._ops.spmm_raw(graph, x, out=out, accumulate=accumulate)
+        lib, vp = self._lib.lib, self._lib.c_vp
+        self._lib.check(lib.rbg_spmm_f32(graph.ptr, vp(x.data_ptr()), vp(out.data_ptr()), x.shape[1], int(bool(accumulate)),
+                                         vp(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
 
-    def gather_rows(self, src, idx):
-        return self._ops.gather_rows(src, idx)
+    def gather_rows(self, src, idx, out=None):
+        if out is None:
+            return self._ops.gather_rows(src, idx)
+        lib, vp = self._lib.lib, self._lib.c_vp
+        self._lib.check(lib.rbg_gather_rows_f32(vp(src.data_ptr()), src.shape[1], vp(idx.data_ptr()), vp(out.data_ptr()),
+                                                idx.shape[0], src.shape[1],
+                                                vp(torch.cuda.current_stream(self.device).cuda_stream)))
+        return out
 
 
 # ---- the sharded propagation ---------------------------------------------------------------------
@@ -181,7 +191,21 @@ class ShardedPropagation:
         self.g_halo = backend.make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
-        self.bytes_received_per_layer = None
+        self._buf_d = None  # per-width buffers, allocated on first use: halo, send, two ping-pong outputs
+        self._recv_splits = [int(c) for c in plan.recv_counts]
+        self._send_splits = [int(c) for c in plan.send_counts]
+
+    def _buffers(self, x):
+        d = x.shape[1]
+        if self._buf_d != d:
+            plan = self.plan
+            f = dict(dtype=x.dtype, device=x.device)
+            self._halo = torch.empty((max(plan.n_halo, 1), d), **f)
+            self._send = torch.empty((max(len(plan.send_idx), 1), d), **f)
+            self._y = [torch.empty((plan.n_owned, d), **f) for _ in range(2)]
+            self._flip = 0
+            self._buf_d = d
+        return self._halo, self._send
 
     # -- halo exchange ---------------------------------------------------------------------------
     def _exchange_staged(self, x, halo):
@@ -204,19 +228,29 @@ class ShardedPropagation:
         halo.copy_(recv)
 
     def _exchange_nccl(self, x, halo):
-        plan = self.plan
-        send = self.backend.gather_rows(x, self.send_idx)
-        dist.all_to_all_single(halo, send, output_split_sizes=[int(c) for c in plan.recv_counts],
-                               input_split_sizes=[int(c) for c in plan.send_counts], group=self.group)
+        _, send = self._buffers(x)
+        n_send = len(self.plan.send_idx)
+        if n_send:
+            self.backend.gather_rows(x, self.send_idx, out=send[:n_send])
+        dist.all_to_all_single(halo, send[:n_send], output_split_sizes=self._recv_splits,
+                               input_split_sizes=self._send_splits, group=self.group)
 
     def spmm(self, x):
         """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows."""
         plan = self.plan
         d = x.shape[1]
-        y = torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
+        if x.device.type == "cuda":
+            halo, _ = self._buffers(x)
+            self._flip ^= 1
+            y = self._y[self._flip]  # ping-pong: x may be the other buffer (the previous layer's output)
+            if y.data_ptr() == x.data_ptr():
+                self._flip ^= 1
+                y = self._y[self._flip]
+        else:
+            y = torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
+            halo = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
         if plan.world == 1:
             return self.backend.spmm(self.g_int, x, y, False)
-        halo = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
         if self.transport == "nccl":
             # all_to_all_single is a collective: every rank takes part every layer, even one whose
             # own send and receive lists are empty.
