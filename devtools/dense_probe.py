@@ -29,3 +29,16 @@ t_layer = time_us(lambda: rbg.ops.bignn_conv_raw(g, x, w1, b1, w2, b2, out=yo, l
 y = torch.empty_like(x)
 t_spmm = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y))
 print(json.dumps(dict(kind="bignn_layer", us=t_layer, us_spmm=t_spmm, us_dense=t_layer - t_spmm)))
+# fused full-sort evaluation vs the unfused path (score matrix -> mask -> torch.topk)
+for B in (128, 1024, 4096):
+    users = torch.randint(1, nu, (B,), device=dev)
+    ua = torch.randn(nu, 64, device=dev)
+    hist_rows = torch.from_numpy(np.asarray(uid)).to(dev); hist_cols = torch.from_numpy(np.asarray(iid)).to(dev)
+    def unfused():
+        s = rbg.score(rbg.gather_rows(ua, users), it)
+        s[:, 0] = float("-inf")
+        return torch.topk(s, 10, dim=1)
+    t_unf = time_us(unfused, iters=10, warm=2)
+    t_fus = time_us(lambda: rbg.full_sort_topk(g, ua, it, users, 10), iters=10, warm=2)
+    print(json.dumps(dict(kind="full_sort_topk", B=B, k=10, us_fused=t_fus, us_score_plus_torch_topk_no_history_mask=t_unf,
+                          users_per_s=B / (t_fus * 1e-6))))

@@ -216,6 +216,18 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
                       float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                       void *stream);
 
+/* Full-sort evaluation of one batch without the [B, n_items] score matrix.
+ * Replaces full_sort_predict (lightgcn.py:123-133) + RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
+ *   scores = user_all[users] @ item_all.T;  scores[:, 0] = -inf;  scores[history_index] = -inf;  topk(scores, k)
+ * `history` is the TRAINING graph handle (a user's history = its graph row; NULL = no history mask).
+ * out_val [B, k] fp32 descending, out_idx [B, k] int64 item ids (-1 / -inf when fewer than k items remain).
+ * Ties are broken towards the smaller item id.  k <= 32, d <= 256.  `workspace`: device buffer of at least
+ * rbg_full_sort_topk_workspace(B, n_items, k) bytes. */
+int rbg_full_sort_topk_workspace(int64_t B, int64_t n_items, int k, int64_t *bytes);
+int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, const float *item_all, const int64_t *users,
+                           int64_t B, int64_t n_users, int64_t n_items, int d, int k, float *out_val, int64_t *out_idx,
+                           void *workspace, void *stream);
+
 /* Row gather: dst[i, :] = src[idx[i], :]  (restore_user_e[user], lightgcn.py:128; also packs the
  * halo send buffer of the node-range sharded path).  idx is a DEVICE int64 array. */
 int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,

@@ -1,0 +1,454 @@
+// topk.hip — full-sort evaluation without the [B, n_items] score matrix.
+//
+// Replaces, for one evaluation batch: LightGCN.full_sort_predict (lightgcn.py:123-133: u = restore_user_e[user];
+// scores = u @ restore_item_e.T) followed by RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
+//   scores[:, 0] = -inf; scores[history_index] = -inf; torch.topk(scores, k)
+// The history of a user is exactly its row of the training graph (the model was built from train_data.dataset,
+// quick_start.py:41), so the mask is read from the graph handle's CSR.
+//
+// Kernel 1 (score_topk_kernel): same MFMA tiling as score.hip (wave = 32 users x 32 items, exact fp32
+// v_mfma_f32_32x32x2_f32).  Each lane keeps, for its 16 accumulator rows, a threshold tau of that row's user.  After
+// a tile, a row whose ballot(score >= tau) is empty costs one compare; otherwise the passing lanes append
+// (score, item) to the user's LDS list (capacity 64, raw: no history lookups in the hot loop).  A full list is pruned
+// to its best k valid entries by a 64-lane bitonic sort, its history items dropped by ONE 64-lane-parallel binary
+// search in the user's graph row (a chain of dependent loads paid per batch, not per candidate); that raises tau.
+// A workgroup covers one 32-user tile x one chunk of item tiles; every wave hands its raw lists to a workspace.
+// Kernel 2 (topk_merge_kernel): one wavefront per user compacts all partial lists and folds them 32 at a time.
+// Two passes: a pre-pass over the first 2048 items yields tau0 = the k-th best VALID score among them, a lower bound
+// of the final k-th best, so the main pass starts selective (~k*n/2048 candidates per user instead of warm-up churn).
+// K <= 32.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "internal.h"
+
+namespace rbg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCap = 64;  // LDS list capacity per user (one wave-wide sort)
+constexpr float kNegInf = -__builtin_inff();
+
+constexpr int kListStride = 32;  // entries a wave hands over per user (workspace row)
+
+struct TopkParams {
+    const float *U;  // [n_users, d] all user embeddings (restore_user_e)
+    const float *I;  // [n_items, d]
+    const int64_t *users;  // [B] user ids of this batch
+    const int32_t *rowptr;  // training graph CSR (may be NULL: no history mask)
+    const int32_t *col;
+    int64_t n_users, n_items, B;
+    int d;
+    int k;               // entries kept by a prune (the pre-pass keeps 32 unmasked ones)
+    int filter_history;  // prunes drop history items (main pass); the pre-pass defers the mask to its merge
+    int tiles_per_chunk, n_chunks;
+    int64_t tile_lo, tile_hi;  // item tiles covered by this launch
+    const float *tau0;         // [B] lower bound of each user's k-th best valid score (NULL: -inf)
+    float *w_val;              // workspace [B][n_chunks*4][kListStride]
+    int32_t *w_idx;
+    int32_t *w_cnt;            // [B][n_chunks*4]
+};
+
+template <bool VEC>
+__device__ __forceinline__ void tk_load_run(const float *p, bool ok, int k0, int d, float (&r)[32]) {
+    if (VEC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
+            r[4 * q + 0] = v.x;
+            r[4 * q + 1] = v.y;
+            r[4 * q + 2] = v.z;
+            r[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) r[s] = (ok && k0 + s < d) ? p[k0 + s] : 0.f;
+    }
+}
+
+// (va, ia) "better than" (vb, ib): higher score first, lower item id on ties (a total order -> deterministic)
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+
+// 64-lane bitonic sort, best first.
+__device__ __forceinline__ void wave_sort_desc(float &v, int &idx, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const float ov = __shfl_xor(v, j);
+            const int oi = __shfl_xor(idx, j);
+            const bool up = (lane & k) == 0;        // this block sorts best-first
+            const bool lower = (lane & j) == 0;     // I hold the earlier position of the pair
+            const bool other_better = better(ov, oi, v, idx);
+            const bool take = (up == lower) ? other_better : !other_better;
+            if (take) {
+                v = ov;
+                idx = oi;
+            }
+        }
+    }
+}
+
+// Is `item` in the training history of `user` (= a column of the user's graph row)?  Binary search; called by
+// up to 64 lanes at once so the chain of dependent loads is paid once per batch, not once per candidate.
+__device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t *col, int64_t n_users, int64_t user, int item) {
+    if (!rowptr || user < 0 || item < 0) return false;
+    int lo = rowptr[user], hi = rowptr[user + 1];
+    const int target = (int)(item + n_users);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = col[mid];
+        if (c == target) return true;
+        if (c < target) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+// Prune one user's LDS list (<= 64 raw candidates) to its best k valid entries (sorted).  Returns the new
+// threshold: the k-th best (or -inf while fewer than k exist).
+__device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, float *lv, int *li, int *cnt, int lane) {
+    __builtin_amdgcn_wave_barrier();  // lists are handed between lanes of ONE wave through LDS: keep program order
+    const int n = *cnt;
+    float v = lane < n ? lv[lane] : kNegInf;
+    int idx = lane < n ? li[lane] : 0x7fffffff;
+    if (p.filter_history && lane < n && in_history(p.rowptr, p.col, p.n_users, user, idx)) {
+        v = kNegInf;
+        idx = 0x7fffffff;
+    }
+    wave_sort_desc(v, idx, lane);
+    const int valid = __popcll(__ballot(idx != 0x7fffffff));
+    if (lane < p.k) {
+        lv[lane] = v;
+        li[lane] = idx;
+    }
+    const int kept = valid < p.k ? valid : p.k;
+    if (lane == 0) *cnt = kept;
+    __builtin_amdgcn_wave_barrier();
+    return __shfl(v, p.k - 1);
+}
+
+// compile-time loop over the 16 accumulator rows: tau[] / row_ok[] / acc[] must be indexed statically or they
+// are demoted to scratch memory (measured: 144 B/lane of scratch and a 1.4 ms kernel)
+template <int R>
+struct RowLoop {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, R>{});
+        RowLoop<R + 1>::run(f);
+    }
+};
+template <>
+struct RowLoop<16> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+template <int NCHUNK, bool VEC>
+__global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
+    __shared__ float l_val[4][32][kCap];
+    __shared__ int l_idx[4][32][kCap];
+    __shared__ int l_cnt[4][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.y * 32;  // first batch slot of this user tile
+    if (lane < 32) l_cnt[wave][lane] = 0;
+    // A operand: the embedding row of batch slot b0 + i
+    const int64_t bi = b0 + i;
+    const int64_t my_user = bi < p.B ? p.users[bi] : -1;
+    float a[NCHUNK][32];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        tk_load_run<VEC>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+    // thresholds start at the pre-pass bound: an item scoring below the k-th best valid score of ANY item subset
+    // cannot be in the top k.  tau[r] belongs to the user of accumulator row (r&3) + 8*(r>>2) + 4h.
+    const float my_tau = (p.tau0 && bi < p.B) ? p.tau0[bi] : kNegInf;
+    float tau[16];
+    bool row_ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
+        tau[r] = __shfl(my_tau, src);
+        row_ok[r] = b0 + src < p.B;
+    }
+    const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
+    const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    float bfrag[32];
+    for (int64_t t = t_begin + wave; t < t_end; t += 4) {
+        const int64_t item = t * 32 + i;
+        f32x16 acc = zero;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+            tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, bfrag);
+#pragma unroll
+            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s], bfrag[s], acc, 0, 0, 0);
+        }
+        // filter the tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
+        const bool item_ok = item < p.n_items && item != 0;
+        RowLoop<0>::run([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const float s = acc[r];
+            const bool pass = s >= tau[r] && item_ok && row_ok[r];
+            const unsigned long long mask = __ballot(pass);
+            if (mask == 0ull) return;  // the common case once the thresholds have risen
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {  // the two lane halves hold two different users
+                const unsigned m = hh ? (unsigned)(mask >> 32) : (unsigned)mask;
+                if (m == 0u) continue;
+                const int lu = (r & 3) + 8 * (r >> 2) + 4 * hh;  // user slot inside the tile
+                float *lv = l_val[wave][lu];
+                int *li = l_idx[wave][lu];
+                int base = l_cnt[wave][lu];
+                const int add = __popc(m);
+                if (base + add > kCap) {  // full: prune to the best k valid ones (k <= 32, so 32 arrivals always fit)
+                    const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
+                    if (h == hh) tau[r] = fmaxf(tau[r], nt);
+                    base = l_cnt[wave][lu];
+                }
+                if (h == hh && pass) {
+                    const int slot = base + __popc(m & ((1u << i) - 1u));
+                    lv[slot] = s;
+                    li[slot] = (int)item;
+                }
+                if (lane == 0) l_cnt[wave][lu] = base + add;
+                __builtin_amdgcn_wave_barrier();
+            }
+        });
+    }
+    // hand the lists over: raw candidates (at most kListStride per user; longer lists are pruned first)
+    const int lists = p.n_chunks * 4;
+    const int my_list = (int)blockIdx.x * 4 + wave;
+    for (int lu = 0; lu < 32; ++lu) {
+        const int64_t b = b0 + lu;
+        if (b >= p.B) break;
+        __builtin_amdgcn_wave_barrier();
+        if (l_cnt[wave][lu] > kListStride) prune_list(p, __shfl(my_user, lu), l_val[wave][lu], l_idx[wave][lu], &l_cnt[wave][lu], lane);
+        const int n = l_cnt[wave][lu];
+        const int64_t off = (b * lists + my_list) * kListStride;
+        if (lane < n) {
+            p.w_val[off + lane] = l_val[wave][lu][lane];
+            p.w_idx[off + lane] = l_idx[wave][lu][lane];
+        }
+        if (lane == 0) p.w_cnt[b * lists + my_list] = n;
+    }
+}
+
+// One wavefront per batch user.  Stage A compacts the raw candidates of `lists` partial lists into LDS; stage B takes
+// them 32 at a time into the upper half-wave, masks history items (one 32-lane-parallel binary search per batch) and
+// bitonic-merges them into the running best 32 held by the lower half-wave.
+// tau_out != NULL (pre-pass): no mask while merging; afterwards the k-th VALID one of the 32 best becomes the bound.
+constexpr int kStage = 2048;
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ w_val, const int32_t *__restrict__ w_idx,
+                                                        const int32_t *__restrict__ w_cnt, const int64_t *__restrict__ users,
+                                                        const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        int64_t n_users, int64_t B, int lists, int k,
+                                                        float *__restrict__ out_val, int64_t *__restrict__ out_idx,
+                                                        float *__restrict__ tau_out) {
+    __shared__ float s_val[4][kStage];
+    __shared__ int s_idx[4][kStage];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int64_t user = users[b];
+    const bool mask_now = (tau_out == nullptr);
+    float v = kNegInf;  // lanes 0..31: best so far; lanes 32..63: incoming batch
+    int idx = 0x7fffffff;
+    int total = 0;
+    auto flush = [&]() {
+        for (int base = 0; base < total; base += 32) {
+            __builtin_amdgcn_wave_barrier();
+            if (lane >= 32) {
+                const int e = base + lane - 32;
+                v = e < total ? s_val[wave][e] : kNegInf;
+                idx = e < total ? s_idx[wave][e] : 0x7fffffff;
+                if (mask_now && e < total && in_history(rowptr, col, n_users, user, idx)) {
+                    v = kNegInf;
+                    idx = 0x7fffffff;
+                }
+            }
+            wave_sort_desc(v, idx, lane);
+            if (lane >= 32) {
+                v = kNegInf;
+                idx = 0x7fffffff;
+            }
+        }
+        total = 0;
+    };
+    for (int l0 = 0; l0 < lists; l0 += 32) {
+        // 32 lists per round: lane pair (2j, 2j+1) copies list l0 + j (entries e = lane&1, +2, ...)
+        const int l = l0 + (lane >> 1);
+        const int c = l < lists ? w_cnt[b * lists + l] : 0;
+        // exclusive prefix of the counts over the 32 lists (each list appears on two lanes: count it once)
+        int incl = (lane & 1) ? 0 : c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        const int round_total = __shfl(incl, 63);
+        const int my_off = __shfl(incl, lane | 1) - c;  // start of this list inside the round
+        if (total + round_total > kStage) flush();
+        const int64_t src = (b * lists + l) * kListStride;
+        for (int e = lane & 1; e < c; e += 2) {
+            s_val[wave][total + my_off + e] = w_val[src + e];
+            s_idx[wave][total + my_off + e] = w_idx[src + e];
+        }
+        total += round_total;
+    }
+    flush();
+    if (tau_out) {
+        // lanes 0..31 hold the 32 best UNMASKED sample scores; the k-th one that is not a history item bounds the
+        // user's k-th best valid score from below (-inf if the sample cannot tell)
+        const bool ok = lane < 32 && idx != 0x7fffffff && !in_history(rowptr, col, n_users, user, idx);
+        const unsigned long long m = __ballot(ok);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0 && __popcll(m) < k) tau_out[b] = kNegInf;
+        if (ok && rank == k - 1) tau_out[b] = v;
+        return;
+    }
+    if (lane < k) {
+        out_val[b * k + lane] = v;
+        out_idx[b * k + lane] = (idx == 0x7fffffff) ? -1 : (int64_t)idx;
+    }
+}
+
+constexpr int64_t kSampleTiles = 64;  // pre-pass over the first 2048 items
+
+static void topk_geometry(int64_t B, int64_t n_tiles, int64_t min_tiles_per_chunk, int &tiles_per_chunk, int &n_chunks) {
+    const int64_t user_tiles = (B + 31) / 32;
+    int64_t want = std::max<int64_t>(1, 2048 / std::max<int64_t>(user_tiles, 1));  // aim at ~2048 workgroups
+    want = std::min<int64_t>(want, std::max<int64_t>(1, n_tiles / min_tiles_per_chunk));
+    want = std::min<int64_t>(want, 64);
+    tiles_per_chunk = (int)((n_tiles + want - 1) / want);
+    n_chunks = (int)((n_tiles + tiles_per_chunk - 1) / std::max(tiles_per_chunk, 1));
+}
+
+template <int NCHUNK>
+static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    if (vec)
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false>), grid, dim3(256), 0, s, p);
+}
+
+static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    if (p.d <= 64) launch_topk<1>(p, vec, grid, s);
+    else if (p.d <= 128) launch_topk<2>(p, vec, grid, s);
+    else launch_topk<4>(p, vec, grid, s);
+}
+
+// workspace: main lists (val, idx: B*nc*4*32 each; cnt: B*nc*4), sample lists (same with nc_s), tau0 [B]
+struct TopkLayout {
+    int tpc, nc, tpc_s, nc_s;
+    int64_t n_tiles, sample_tiles, main_lists, sample_lists, bytes;
+};
+static TopkLayout topk_layout(int64_t B, int64_t n_items) {
+    TopkLayout L{};
+    L.n_tiles = (n_items + 31) / 32;
+    L.sample_tiles = std::min<int64_t>(kSampleTiles, L.n_tiles);
+    topk_geometry(B, L.n_tiles, 8, L.tpc, L.nc);
+    topk_geometry(B, L.sample_tiles, 8, L.tpc_s, L.nc_s);
+    L.main_lists = B * (int64_t)L.nc * 4;
+    L.sample_lists = B * (int64_t)L.nc_s * 4;
+    L.bytes = (L.main_lists + L.sample_lists) * (kListStride * 8 + 4) + B * 4 + 256;
+    return L;
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_full_sort_topk_workspace(int64_t B, int64_t n_items, int k, int64_t *bytes) {
+    if (!bytes || B < 0 || n_items < 0 || k < 1) return fail(RBG_EINVAL, "bad argument");
+    *bytes = topk_layout(B, n_items).bytes;
+    return RBG_OK;
+}
+
+int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, const float *item_all, const int64_t *users,
+                           int64_t B, int64_t n_users, int64_t n_items, int d, int k, float *out_val, int64_t *out_idx,
+                           void *workspace, void *stream) {
+    clear_error();
+    if (B < 0 || n_users < 0 || n_items < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (k < 1 || k > 32) return fail(RBG_EUNSUPPORTED, "k = %d (the fused top-k supports 1..32)", k);
+    if (d > 256) return fail(RBG_EUNSUPPORTED, "d = %d > 256", d);
+    if (B == 0) return RBG_OK;
+    if (!user_all || !item_all || !users || !out_val || !out_idx || !workspace) return fail(RBG_EINVAL, "NULL pointer");
+    if (history) {
+        if (history->device < 0) return fail(RBG_ENODEV, "history graph is a host graph");
+        if (history->n_rows != n_users + n_items) return fail(RBG_ESHAPE, "history graph has %lld nodes, expected %lld",
+                                                              (long long)history->n_rows, (long long)(n_users + n_items));
+        int rc = set_device_for(history->device);
+        if (rc) return rc;
+    }
+    const int64_t user_tiles = (B + 31) / 32;
+    if (user_tiles > 65535) return fail(RBG_EUNSUPPORTED, "B = %lld too large for one call", (long long)B);
+    const TopkLayout L = topk_layout(B, n_items);
+    char *w = reinterpret_cast<char *>(workspace);
+    float *main_val = reinterpret_cast<float *>(w);
+    int32_t *main_idx = reinterpret_cast<int32_t *>(main_val + L.main_lists * kListStride);
+    int32_t *main_cnt = main_idx + L.main_lists * kListStride;
+    float *samp_val = reinterpret_cast<float *>(main_cnt + L.main_lists);
+    int32_t *samp_idx = reinterpret_cast<int32_t *>(samp_val + L.sample_lists * kListStride);
+    int32_t *samp_cnt = samp_idx + L.sample_lists * kListStride;
+    float *tau0 = reinterpret_cast<float *>(samp_cnt + L.sample_lists);
+    const int32_t *rp = history ? history->d_rowptr : nullptr;
+    const int32_t *cl = history ? history->d_col : nullptr;
+    TopkParams p{};
+    p.U = user_all;
+    p.I = item_all;
+    p.users = users;
+    p.rowptr = rp;
+    p.col = cl;
+    p.n_users = n_users;
+    p.n_items = n_items;
+    p.B = B;
+    p.d = d;
+    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(user_all) | reinterpret_cast<uintptr_t>(item_all)) & 15u) == 0;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned merge_blocks = (unsigned)((B + 3) / 4);
+    const bool prepass = L.n_tiles > 2 * L.sample_tiles;  // small item sets: one pass
+    if (prepass) {
+        // pass 1: the first 2048 items, unmasked best 32 per user -> tau0[b] = its k-th valid score (a lower bound)
+        p.k = 32;
+        p.filter_history = 0;
+        p.tiles_per_chunk = L.tpc_s;
+        p.n_chunks = L.nc_s;
+        p.tile_lo = 0;
+        p.tile_hi = L.sample_tiles;
+        p.tau0 = nullptr;
+        p.w_val = samp_val;
+        p.w_idx = samp_idx;
+        p.w_cnt = samp_cnt;
+        launch_topk_d(p, vec, dim3((unsigned)L.nc_s, (unsigned)user_tiles), s);
+        RBG_HIP(hipGetLastError());
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(merge_blocks), dim3(256), 0, s, samp_val, samp_idx, samp_cnt, users, rp, cl,
+                           n_users, B, L.nc_s * 4, k, out_val, out_idx, tau0);
+        RBG_HIP(hipGetLastError());
+    }
+    // pass 2: every item, thresholds seeded with tau0
+    p.k = k;
+    p.filter_history = 1;
+    p.tiles_per_chunk = L.tpc;
+    p.n_chunks = L.nc;
+    p.tile_lo = 0;
+    p.tile_hi = L.n_tiles;
+    p.tau0 = prepass ? tau0 : nullptr;
+    p.w_val = main_val;
+    p.w_idx = main_idx;
+    p.w_cnt = main_cnt;
+    launch_topk_d(p, vec, dim3((unsigned)L.nc, (unsigned)user_tiles), s);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(merge_blocks), dim3(256), 0, s, main_val, main_idx, main_cnt, users, rp, cl, n_users,
+                       B, L.nc * 4, k, out_val, out_idx, (float *)nullptr);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+}  // extern "C"

@@ -173,6 +173,17 @@ class LightGCN(GeneralGraphRecommender):
         return scores.view(-1)
 
 
+def _full_sort_topk(model, interaction, k):
+    """Evaluation without the score matrix: cached propagation (as full_sort_predict) + fused scoring / masking / top-k."""
+    if model.restore_user_e is None or model.restore_item_e is None:
+        with torch.no_grad():
+            model.restore_user_e, model.restore_item_e = model.forward()
+    return ops.full_sort_topk(model.graph, model.restore_user_e, model.restore_item_e, interaction[model.USER_ID], k)
+
+
+LightGCN.full_sort_topk = _full_sort_topk
+
+
 class NGCF(GeneralGraphRecommender):
     """general_recommender/ngcf.py:36-149, at node_dropout = 0 (edge dropout, ngcf.py:74-90, is not
     part of the accelerated path).  ``message_dropout`` defaults to 0 here: the reference's
@@ -354,3 +365,7 @@ class SGL(GeneralGraphRecommender):
                 self.restore_user_e, self.restore_item_e = self.forward()
         user = ops.gather_rows(self.restore_user_e, interaction[self.USER_ID])
         return ops.score(user, self.restore_item_e)
+
+
+NGCF.full_sort_topk = _full_sort_topk
+SGL.full_sort_topk = _full_sort_topk

@@ -278,3 +278,27 @@ def gather_rows(src, idx):
                                       c_vp(idx.data_ptr()), c_vp(out.data_ptr()), idx.shape[0], src.shape[1],
                                       _stream(src)))
     return out
+
+
+def full_sort_topk(history, user_all, item_all, users, k):
+    """Top-k items per user of ``user_all[users] @ item_all.T`` with the PAD item and each user's training history
+    masked (full_sort_predict + RecBole's ``_full_sort_batch_eval`` masking + ``torch.topk``), without ever writing the
+    [B, n_items] score matrix.  ``history``: the training GraphHandle (or None).  Returns (values [B,k], item ids [B,k])."""
+    _check_dense(user_all, "user_all")
+    _check_dense(item_all, "item_all")
+    if history is not None:
+        _require_device_graph(history)
+    user_all, item_all = user_all.contiguous(), item_all.contiguous()
+    users = users.to(device=user_all.device, dtype=torch.int64).contiguous()
+    b, (n_users, d), n_items = users.shape[0], user_all.shape, item_all.shape[0]
+    nbytes = _lib.c_i64()
+    check(lib.rbg_full_sort_topk_workspace(b, n_items, k, ctypes.byref(nbytes)))
+    work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=user_all.device)
+    vals = torch.empty((b, k), dtype=torch.float32, device=user_all.device)
+    idx = torch.empty((b, k), dtype=torch.int64, device=user_all.device)
+    with torch.cuda.device(user_all.device):
+        check(lib.rbg_full_sort_topk_f32(history.ptr if history is not None else None, c_vp(user_all.data_ptr()),
+                                         c_vp(item_all.data_ptr()), c_vp(users.data_ptr()), b, n_users, n_items, d, k,
+                                         c_vp(vals.data_ptr()), c_vp(idx.data_ptr()), c_vp(work.data_ptr()),
+                                         _stream(user_all)))
+    return vals, idx

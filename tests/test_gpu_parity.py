@@ -548,6 +548,74 @@ def test_score_vs_fp64(rbg, cuda, shape):
     assert torch.equal(rbg.gather_rows(u, idx), u[idx])
 
 
+# ---- fused full-sort evaluation (score + mask + top-k) ---------------------------------------
+
+def reference_topk(user_all, item_all, users, k, uid, iid):
+    """RecBole's _full_sort_batch_eval on the oracle side: scores, scores[:,0] = -inf, history = -inf, topk."""
+    scores = user_all[users].double() @ item_all.double().T
+    scores[:, 0] = -np.inf
+    hist = {}
+    for u, i in zip(uid.tolist(), iid.tolist()):
+        hist.setdefault(u, []).append(i)
+    for r, u in enumerate(users.tolist()):
+        if u in hist:
+            scores[r, hist[u]] = -np.inf
+    return scores, torch.topk(scores, k, dim=1)
+
+
+@pytest.mark.parametrize("bk", [(1, 10), (3, 1), (64, 10), (200, 32), (33, 5)])
+@pytest.mark.parametrize("d", [64, 256, 20])
+def test_full_sort_topk(rbg, cuda, golden, bk, d):
+    g = golden
+    b, k = bk
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    user_all, item_all = randn((nu, d), 71, cuda), randn((ni, d), 72, cuda)
+    users = torch.from_numpy(np.random.default_rng(b).integers(0, nu, b))
+    vals, idx = rbg.full_sort_topk(h, user_all, item_all, users.to(cuda), k)
+    scores, (rv, ri) = reference_topk(user_all.cpu(), item_all.cpu(), users, k, g["uid"], g["iid"])
+    assert vals.shape == (b, k) and idx.shape == (b, k) and idx.dtype == torch.int64
+    close(vals, rv.float(), tol=1e-5 * max(1, d / 64))
+    vals_c, idx_c = vals.cpu(), idx.cpu()
+    for r in range(b):
+        assert len(set(idx_c[r].tolist())) == k            # no duplicates
+        assert 0 not in idx_c[r].tolist()                  # PAD item masked
+        got = scores[r, idx_c[r]]                          # every returned id carries the score we report ...
+        assert torch.all(torch.isfinite(got))              # ... and none of them is a history item
+        assert (got.float() - vals_c[r]).abs().max() <= 1e-4
+        assert torch.all(vals_c[r, :-1] >= vals_c[r, 1:])  # sorted, best first
+    # exact index agreement wherever the k-th and (k+1)-th reference scores are clearly apart
+    srt = torch.sort(scores, dim=1, descending=True).values
+    clear = (srt[:, k - 1] - srt[:, k]) > 1e-3 if ni > k else torch.ones(b, dtype=torch.bool)
+    for r in torch.nonzero(clear).flatten().tolist():
+        assert set(idx_c[r].tolist()) == set(ri[r].tolist())
+    # no history graph: only the PAD item is masked
+    v2, i2 = rbg.full_sort_topk(None, user_all, item_all, users.to(cuda), k)
+    s2 = user_all.cpu()[users].double() @ item_all.cpu().double().T
+    s2[:, 0] = -np.inf
+    close(v2, torch.topk(s2, k, dim=1).values.float(), tol=1e-5 * max(1, d / 64))
+
+
+def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True)
+    users = torch.tensor([1, 2, nu - 1], device=cuda)
+    vals, idx = model.full_sort_topk({"user_id": users}, 10)
+    flat = model.full_sort_predict({"user_id": users}).view(3, ni).cpu().double()
+    scores, (rv, ri) = reference_topk(model.restore_user_e.cpu(), model.restore_item_e.cpu(), users.cpu(), 10, g["uid"], g["iid"])
+    close(vals, rv.float())
+    assert (flat - (model.restore_user_e.cpu()[users.cpu()].double() @ model.restore_item_e.cpu().double().T)).abs().max() < 1e-5
+    # a user whose history covers everything but 3 items: the tail of the top-k is (-inf, -1)
+    nu2, ni2 = 3, 40
+    uid2 = np.concatenate([np.full(36, 1), [2]])
+    iid2 = np.concatenate([np.arange(4, 40), [5]])
+    h2 = rbg.GraphHandle.from_interactions(uid2, iid2, nu2, ni2, device=cuda)
+    ua, ia = randn((nu2, 64), 1, cuda), randn((ni2, 64), 2, cuda)
+    v, i = rbg.full_sort_topk(h2, ua, ia, torch.tensor([1], device=cuda), 8)
+    assert set(i[0, :3].tolist()) == {1, 2, 3} and torch.all(i[0, 3:] == -1) and torch.all(torch.isinf(v[0, 3:]))
+
+
 # ---- full-size properties (BASELINE.json config #2 shape) -----------------------------------
 
 @pytest.fixture(scope="module")
