@@ -15,7 +15,8 @@
  *     score buffer.  The library owns graph handles and their HBM arrays.
  *   - `stream` is a hipStream_t (0 = the null stream).  Kernels are enqueued and the call returns
  *     without synchronizing.  No allocation happens on a hot call.
- *   - a graph handle is immutable after creation: concurrent calls on different streams are safe.
+ *   - a graph handle is immutable after creation except for a small per-handle scratch used by rows longer
+ *     than `seg_len`: calls on ONE handle must be stream-ordered with each other; different handles are independent.
  */
 #ifndef RBGNN_H
 #define RBGNN_H
@@ -179,8 +180,8 @@ int rbg_lightgcn_backward_f32(const rbg_graph *const *graphs, int n_graphs, cons
  * W1, W2: [d_out, d_in] row-major (nn.Linear.weight), b1, b2: [d_out].
  * Y [N, d_out] is written with row stride ldy floats (ldy >= d_out) so the caller can place layer
  * outputs directly inside the concatenated [N, sum(d)] buffer (ngcf.py:100).
- * X [N, d_in] is read with row stride ldx floats.  P_save (optional, [N, d_in]) receives ÂX for the
- * autograd backward. */
+ * X [N, d_in] is read with row stride ldx floats.  P_save (required, caller-provided [N, d_in]) receives ÂX: it is the
+ * dense kernel's operand and what the autograd backward needs. */
 int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                        const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save,
                        int d_in, int d_out, uint32_t flags, float slope, void *stream);

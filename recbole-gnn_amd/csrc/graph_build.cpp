@@ -80,12 +80,8 @@ static void fill_side(int64_t n_inter, const int64_t *key, const int64_t *other,
     std::vector<int64_t> order((size_t)kept);
     for (int64_t e = 0; e < n_inter; ++e)
         if (!keep || keep[e]) order[(size_t)start[(size_t)other[e]]++] = e;
-    // cursors of the destination rows
-    std::vector<int32_t> cur;
-    {
-        // only the [key_offset, key_offset + n_key) rows are touched; copy their starts lazily
-        cur.assign(rowptr.begin(), rowptr.end() - 1);
-    }
+    // write cursors of the destination rows (only rows [key_offset, key_offset + n_key) are advanced)
+    std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
     for (int64_t k = 0; k < kept; ++k) {
         const int64_t e = order[(size_t)k];
         const int64_t r = key[e] + key_offset;

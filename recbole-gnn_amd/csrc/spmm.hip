@@ -10,7 +10,7 @@
 // (4 at d = 64) and every gathered neighbour row is one fully coalesced d*4-byte read.  Rows are
 // degree-binned at graph build (graph_build.cpp):
 //   short rows   (deg <= short_max): one row per lane-group, neighbours visited in column order
-//   wave rows    (deg <= wave_max) : the lane-groups of one wavefront split the row, DPP/bpermute reduce
+//   wave rows    (deg <= wave_max) : the lane-groups of one wavefront split the row, ds_bpermute butterfly
 //   block rows   (deg  > wave_max) : a 256-thread workgroup per row segment, LDS reduce; rows longer
 //                                    than seg_len are split into segments whose partial sums are added
 //                                    in fixed segment order by the last segment to finish
@@ -18,7 +18,7 @@
 // user rows (they gather item embeddings only), XCDs 4-7 item rows — each XCD's private 4 MB L2 then
 // caches one embedding table, not two (measured: the kernel is bound by L2 misses).
 // (col,val) are fetched lane-parallel (one coalesced non-temporal read per lane-group chunk) and
-// broadcast with ds_bpermute; U neighbour rows are in flight per lane-group before the FMAs.
+// broadcast with ds_bpermute; U (8) neighbour rows are in flight per lane-group before the FMAs.
 // No float atomics anywhere: the result is bit-stable run to run.
 // The layer-mean of LightGCN.forward is fused into the last layer's epilogue.
 
