@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--p-in", type=float, default=0.9, help="N>1: fraction of interactions inside a rank's block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) measurements at N = 1")
     ap.add_argument("--transport", choices=["nccl", "staged"], default="nccl",
                     help="N>1 halo transport: RCCL all_to_all (default) or host-staged gloo send/recv (self-test: lets "
                          "several ranks share one GPU)")
@@ -68,6 +69,48 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
     return {"value": reps / el, "unit": "propagations/s", "cores": coracle.num_threads(), "kind": "port",
             "sample": f"{reps} full propagations of the same workload in {el:.1f} s "
                       f"(oracle/rbg_oracle.c, OpenMP, {os.cpu_count()} logical cpus visible)"}
+
+
+def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
+    """Non-headline measurements on the same graph (each: median of 3 x 50 iterations, HIP events)."""
+    def time_us(fn, iters=50, warm=5):
+        for _ in range(warm):
+            fn()
+        out = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            out.append(a.elapsed_time(b) * 1e3 / iters)
+        return sorted(out)[1]
+
+    n = nu + ni
+    x, y = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev)
+    ex = {"spmm_single_layer_us": time_us(lambda: rbg.ops.spmm_raw(graph, x, out=y))}
+    b_layer, _ = rbg.synth.algorithmic_bytes(n, 2 * len(uid), d, k_layers)
+    ex["spmm_single_layer_roofline_frac"] = b_layer / (ex["spmm_single_layer_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    model = rbg.LightGCN({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers,
+                          "require_pow": True}, ds)
+    g = torch.Generator().manual_seed(1)
+    batch = {"user_id": torch.randint(1, nu, (2048,), generator=g).to(dev),
+             "item_id": torch.randint(1, ni, (2048,), generator=g).to(dev),
+             "neg_item_id": torch.randint(1, ni, (2048,), generator=g).to(dev)}
+    fused = rbg.FusedBPRAdam(model, lr=1e-3)
+    ex["train_step_fused_us(batch 2048, fwd + BPR + bwd + Adam)"] = time_us(lambda: fused.step(batch))
+    users = torch.randint(1, nu, (4096,), generator=g).to(dev)
+    with torch.no_grad():
+        model.full_sort_topk({"user_id": users}, 10)
+        ex["full_sort_topk_us(4096 users, k 10, history masked)"] = time_us(lambda: model.full_sort_topk({"user_id": users}, 10), iters=10, warm=2)
+    t0 = time.perf_counter()
+    rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+    torch.cuda.synchronize()
+    ex["graph_build_device_ms"] = (time.perf_counter() - t0) * 1e3
+    return ex
 
 
 def traffic_from_profiles(workload):
@@ -232,6 +275,8 @@ def main():
             "cpu_baseline": None,
         }
         result.update(extra)
+        if world == 1 and not args.no_extras:
+            result["extras"] = extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev)
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers, args.cpu_seconds)
         print(json.dumps(result))
