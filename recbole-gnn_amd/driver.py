@@ -1,0 +1,177 @@
+"""A minimal RecBole-free driver around the engine: just enough of what RecBole does
+around the path [recbole==1.1.1] to train and evaluate a model end to end — atomic ``.inter`` reader, token -> id
+remap (id 0 = [PAD]), per-user random split, uniform negative sampling, full-sort evaluation with the standard
+top-k metrics.  It is NOT a re-implementation of RecBole's config / dataloader / trainer stack (out of scope).
+
+Reference behaviour followed: ``tests/test_model.yaml`` (field names, RS split 0.8/0.1/0.1 grouped by user, full-sort
+mode, topk 10), ``Trainer._train_epoch`` / ``_full_sort_batch_eval`` (per-batch loop, history + PAD masking) and
+RecBole's metric definitions (Recall, MRR, NDCG, Hit, Precision @k).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .graph import InteractionDataset
+from .models import LightGCN
+from .train import FusedBPRAdam
+
+
+def load_inter(path, user_field="user_id", item_field="item_id", sep="\t"):
+    """Atomic file: first line ``name:type`` columns (tests/test_data/test/test.inter:1). Returns
+    (uid, iid, n_users, n_items, user_tokens, item_tokens); ids are dense, 0 = [PAD], in order of first appearance."""
+    with open(path) as f:
+        header = [h.split(":")[0] for h in f.readline().rstrip("\n").split(sep)]
+        ucol, icol = header.index(user_field), header.index(item_field)
+        users, items = [], []
+        for line in f:
+            parts = line.rstrip("\n").split(sep)
+            if len(parts) > max(ucol, icol):
+                users.append(parts[ucol])
+                items.append(parts[icol])
+    return remap_tokens(users, items)
+
+
+def remap_tokens(users, items):
+    def factorize(tokens):
+        table, ids = {}, np.empty(len(tokens), dtype=np.int64)
+        for n, t in enumerate(tokens):
+            ids[n] = table.setdefault(t, len(table) + 1)
+        return ids, ["[PAD]"] + list(table)
+
+    uid, utok = factorize(users)
+    iid, itok = factorize(items)
+    return uid, iid, len(utok), len(itok), utok, itok
+
+
+def split_by_user(uid, iid, ratios=(0.8, 0.1, 0.1), seed=2020):
+    """``eval_args: {split: {RS: [0.8,0.1,0.1]}, group_by: user, order: RO}``: each user's interactions are shuffled
+    and cut by the ratios (RecBole rounds the later parts down and gives the remainder to the first)."""
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(len(uid))
+    order = order[np.argsort(uid[order], kind="stable")]
+    parts = [[], [], []]
+    bounds = np.flatnonzero(np.diff(uid[order])) + 1
+    for grp in np.split(order, bounds):
+        n = len(grp)
+        n_valid, n_test = int(n * ratios[1]), int(n * ratios[2])
+        n_train = n - n_valid - n_test
+        parts[0].append(grp[:n_train])
+        parts[1].append(grp[n_train:n_train + n_valid])
+        parts[2].append(grp[n_train + n_valid:])
+    idx = [np.concatenate(p) if p else np.empty(0, dtype=np.int64) for p in parts]
+    return [(uid[i], iid[i]) for i in idx]
+
+
+class BPRSampler:
+    """Pair-wise training batches: every training interaction with one uniformly sampled item the user has not
+    interacted with in the training set (RecBole ``neg_sampling: {uniform: 1}``), reshuffled every epoch."""
+
+    def __init__(self, uid, iid, n_items, batch_size=2048, seed=2020):
+        self.uid, self.iid, self.n_items, self.batch_size = uid, iid, n_items, batch_size
+        self.rng = np.random.default_rng(seed)
+        self.pos_keys = np.unique(uid * n_items + iid)
+
+    def _negatives(self, users):
+        neg = self.rng.integers(1, self.n_items, len(users))
+        while True:
+            bad = np.isin(users * self.n_items + neg, self.pos_keys, assume_unique=False)
+            if not bad.any():
+                return neg
+            neg[bad] = self.rng.integers(1, self.n_items, int(bad.sum()))
+
+    def __iter__(self):
+        perm = self.rng.permutation(len(self.uid))
+        for s in range(0, len(perm), self.batch_size):
+            b = perm[s:s + self.batch_size]
+            yield {"user_id": torch.from_numpy(self.uid[b]), "item_id": torch.from_numpy(self.iid[b]),
+                   "neg_item_id": torch.from_numpy(self._negatives(self.uid[b]))}
+
+    def __len__(self):
+        return (len(self.uid) + self.batch_size - 1) // self.batch_size
+
+
+def topk_metrics(topk_idx, truth, k):
+    """RecBole's Recall / MRR / NDCG / Hit / Precision @k for one batch.  topk_idx: [B, k] item ids (best first);
+    truth: list of B sets of ground-truth items.  Returns per-user arrays."""
+    topk_idx = np.asarray(topk_idx)
+    b = topk_idx.shape[0]
+    hit = np.zeros((b, k), dtype=bool)
+    for r in range(b):
+        hit[r] = np.fromiter((int(i) in truth[r] for i in topk_idx[r]), dtype=bool, count=k)
+    n_truth = np.asarray([len(t) for t in truth], dtype=np.float64)
+    n_hit = hit.sum(1).astype(np.float64)
+    disc = 1.0 / np.log2(np.arange(2, k + 2))
+    dcg = (hit * disc).sum(1)
+    idcg = np.asarray([disc[:int(min(n, k))].sum() for n in n_truth])
+    first = np.where(hit.any(1), hit.argmax(1) + 1, 0)
+    return {
+        "recall": n_hit / np.maximum(n_truth, 1),
+        "precision": n_hit / k,
+        "hit": (n_hit > 0).astype(np.float64),
+        "ndcg": dcg / np.maximum(idcg, 1e-12),
+        "mrr": np.where(first > 0, 1.0 / np.maximum(first, 1), 0.0),
+    }
+
+
+@torch.no_grad()
+def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096):
+    """Full-sort evaluation (``mode: full``): every user with ground truth in (eval_uid, eval_iid) is ranked against all
+    items, PAD and training history masked, by the fused score/top-k kernel; metrics averaged over users."""
+    model.eval()
+    model.restore_user_e = model.restore_item_e = None
+    truth = {}
+    for u, i in zip(eval_uid.tolist(), eval_iid.tolist()):
+        truth.setdefault(u, set()).add(i)
+    users = np.asarray(sorted(truth), dtype=np.int64)
+    sums, count = {}, 0
+    for s in range(0, len(users), batch_users):
+        ub = users[s:s + batch_users]
+        _, idx = model.full_sort_topk({"user_id": torch.from_numpy(ub).to(model.device)}, k)
+        m = topk_metrics(idx.cpu().numpy(), [truth[u] for u in ub.tolist()], k)
+        for name, v in m.items():
+            sums[name] = sums.get(name, 0.0) + float(v.sum())
+        count += len(ub)
+    return {f"{name}@{k}": v / max(count, 1) for name, v in sums.items()}
+
+
+def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None):
+    """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  LightGCN with
+    ``require_pow`` uses the fused step (train.py); any other model goes through torch autograd + torch.optim.Adam."""
+    sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed)
+    if fused is None:
+        fused = isinstance(model, LightGCN) and model.require_pow
+    stepper = FusedBPRAdam(model, lr=lr) if fused else None
+    opt = None if fused else torch.optim.Adam(model.parameters(), lr=lr)
+    history = []
+    for epoch in range(epochs):
+        model.train()
+        total = torch.zeros((), device=model.device)
+        for batch in sampler:
+            batch = {k: v.to(model.device) for k, v in batch.items()}
+            if fused:
+                total += stepper.step(batch)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = model.calculate_loss(batch)
+                loss.backward()
+                opt.step()
+                total += loss.detach().reshape(())
+        history.append(float(total))
+        if log:
+            log(f"epoch {epoch}: train loss {history[-1]:.4f}")
+    return history
+
+
+def run(model_cls, uid, iid, n_users, n_items, config=None, epochs=1, seed=2020, k=10, log=None):
+    """quick_start.run_recbole_gnn in miniature (quick_start.py:9-63): split -> dataset from the TRAINING part ->
+    model -> fit -> evaluate on valid and test."""
+    (tr_u, tr_i), (va_u, va_i), (te_u, te_i) = split_by_user(uid, iid, seed=seed)
+    dataset = InteractionDataset(tr_u, tr_i, n_users, n_items)  # the model's graph is built from train_data.dataset
+    cfg = {"device": "cuda", "enable_sparse": True, "embedding_size": 64, "require_pow": True}
+    cfg.update(config or {})
+    torch.manual_seed(seed)
+    model = model_cls(cfg, dataset)
+    losses = fit(model, tr_u, tr_i, epochs=epochs, lr=cfg.get("learning_rate", 1e-3), seed=seed, log=log)
+    return {"model": model, "train_loss": losses, "valid": evaluate(model, va_u, va_i, k=k) if len(va_u) else {},
+            "test": evaluate(model, te_u, te_i, k=k) if len(te_u) else {}}

@@ -1,0 +1,84 @@
+"""The minimal RecBole-free driver: data pipeline and metrics on CPU; one-epoch runs (the reference's own test
+strategy, tests/test_model.py: train and do not crash) plus a learning check on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_load_inter_and_remap(rbg, tmp_path):
+    p = tmp_path / "toy.inter"
+    p.write_text("user_id:token\titem_id:token\trating:float\ttimestamp:float\n"
+                 "196\t242\t3\t881250949\n186\t302\t3\t891717742\n196\t377\t1\t878887116\n22\t242\t1\t1\n")
+    uid, iid, nu, ni, utok, itok = rbg.driver.load_inter(str(p))
+    assert uid.tolist() == [1, 2, 1, 3] and iid.tolist() == [1, 2, 3, 1]
+    assert (nu, ni) == (4, 4) and utok[0] == "[PAD]" and utok[1] == "196" and itok[2] == "302"
+
+
+def test_split_and_sampler(rbg, ref_inter):
+    uid, iid, nu, ni = ref_inter
+    (tr_u, tr_i), (va_u, va_i), (te_u, te_i) = rbg.driver.split_by_user(uid, iid, seed=1)
+    assert len(tr_u) + len(va_u) + len(te_u) == len(uid)
+    keys = lambda u, i: set((u * ni + i).tolist())  # noqa: E731
+    assert keys(tr_u, tr_i) | keys(va_u, va_i) | keys(te_u, te_i) == keys(uid, iid)
+    assert not (keys(tr_u, tr_i) & keys(te_u, te_i))
+    deg = np.bincount(uid, minlength=nu)
+    tr_deg = np.bincount(tr_u, minlength=nu)
+    assert np.all(tr_deg[deg > 0] >= 1)                       # every user keeps a training interaction
+    assert abs(len(tr_u) / len(uid) - 0.8) < 0.08
+    sampler = rbg.driver.BPRSampler(tr_u, tr_i, ni, batch_size=512, seed=3)
+    seen = 0
+    pos = keys(tr_u, tr_i)
+    for batch in sampler:
+        u, p, n = (batch[k].numpy() for k in ("user_id", "item_id", "neg_item_id"))
+        assert np.all(n >= 1) and not (keys(u, n) & pos)      # negatives are never training positives (nor PAD)
+        assert keys(u, p) <= pos
+        seen += len(u)
+    assert seen == len(tr_u) and len(sampler) == (len(tr_u) + 511) // 512
+
+
+def test_metrics_known_answers(rbg):
+    topk = np.array([[5, 7, 9, 2], [1, 2, 3, 4], [8, 1, 2, 3]])
+    truth = [{7, 2, 100}, {9}, {8}]
+    m = rbg.driver.topk_metrics(topk, truth, 4)
+    np.testing.assert_allclose(m["recall"], [2 / 3, 0, 1])
+    np.testing.assert_allclose(m["precision"], [0.5, 0, 0.25])
+    np.testing.assert_allclose(m["hit"], [1, 0, 1])
+    np.testing.assert_allclose(m["mrr"], [0.5, 0, 1])
+    d = 1 / np.log2(np.arange(2, 6))
+    np.testing.assert_allclose(m["ndcg"][0], (d[1] + d[3]) / (d[0] + d[1] + d[2]))
+    np.testing.assert_allclose(m["ndcg"][1], 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF"])
+def test_one_epoch_runs(rbg, cuda, ref_inter, name):
+    """tests/test_model.py:27-37 of the reference: build, train one epoch, evaluate — and the values are finite."""
+    uid, iid, nu, ni = ref_inter
+    cfg = {"device": str(cuda), "n_layers": 2, "reg_weight": 1e-5, "hidden_size_list": [64, 64]}
+    out = rbg.driver.run(getattr(rbg, name), uid, iid, nu, ni, config=cfg, epochs=1)
+    assert np.isfinite(out["train_loss"][0])
+    for split in ("valid", "test"):
+        assert set(out[split]) == {"recall@10", "precision@10", "hit@10", "ndcg@10", "mrr@10"}
+        assert all(0.0 <= v <= 1.0 for v in out[split].values())
+
+
+@pytest.mark.gpu
+def test_training_improves_ranking(rbg, cuda, ref_inter):
+    uid, iid, nu, ni = ref_inter
+    (tr_u, tr_i), (va_u, va_i), _ = rbg.driver.split_by_user(uid, iid, seed=2020)
+    ds = rbg.InteractionDataset(tr_u, tr_i, nu, ni)
+    torch.manual_seed(0)
+    model = rbg.LightGCN({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2,
+                          "require_pow": True, "reg_weight": 1e-5}, ds)
+    before = rbg.driver.evaluate(model, va_u, va_i, k=10)
+    losses = rbg.driver.fit(model, tr_u, tr_i, epochs=30, lr=5e-3, batch_size=1024)
+    after = rbg.driver.evaluate(model, va_u, va_i, k=10)
+    assert losses[-1] < losses[0]
+    assert after["recall@10"] > before["recall@10"] + 0.02 and after["ndcg@10"] > before["ndcg@10"]
+    # the torch-autograd training path reaches the same quality region as the fused one
+    torch.manual_seed(0)
+    model2 = rbg.LightGCN({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2,
+                           "require_pow": True, "reg_weight": 1e-5}, ds)
+    rbg.driver.fit(model2, tr_u, tr_i, epochs=30, lr=5e-3, batch_size=1024, fused=False)
+    after2 = rbg.driver.evaluate(model2, va_u, va_i, k=10)
+    assert abs(after2["recall@10"] - after["recall@10"]) < 0.03
