@@ -7,6 +7,7 @@ Everything here needs a GPU-resident graph: there is no CPU implementation.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -75,19 +76,26 @@ def spmm(graph, x):
     return _Spmm.apply(x, graph)
 
 
-# Graph handles for models that hold the reference's dense pair (edge_index, edge_weight).
-_coo_cache = {}
+# Graph handles for models that hold the reference's dense pair (edge_index, edge_weight).  The cache is keyed by the
+# identity of the two tensor OBJECTS (weak references + version counters), never by their device addresses: the
+# caching allocator hands the same address to a different graph's tensors as soon as the old ones are freed.
+_pair_cache = {}
 
 
 def graph_from_pair(edge_index, edge_weight, num_nodes, device):
-    key = (edge_index.data_ptr(), edge_weight.data_ptr(), edge_index.shape[1], int(num_nodes), str(device))
-    g = _coo_cache.get(key)
-    if g is None:
-        g = GraphHandle.from_edge_index(edge_index, edge_weight, num_nodes, device=device, symmetric=False)
-        if len(_coo_cache) > 64:
-            _coo_cache.clear()
-        _coo_cache[key] = g
-    return g
+    key = (id(edge_index), id(edge_weight))
+    hit = _pair_cache.get(key)
+    if hit is not None:
+        ref_i, ref_w, ver_i, ver_w, nodes, dev, graph = hit
+        if (ref_i() is edge_index and ref_w() is edge_weight and ver_i == edge_index._version
+                and ver_w == edge_weight._version and nodes == int(num_nodes) and dev == str(device)):
+            return graph
+    for k in [k for k, v in _pair_cache.items() if v[0]() is None or v[1]() is None]:
+        del _pair_cache[k]  # the tensors died: drop their handles
+    graph = GraphHandle.from_edge_index(edge_index, edge_weight, num_nodes, device=device, symmetric=False)
+    _pair_cache[key] = (weakref.ref(edge_index), weakref.ref(edge_weight), edge_index._version, edge_weight._version,
+                        int(num_nodes), str(device), graph)
+    return graph
 
 
 class LightGCNConv(nn.Module):

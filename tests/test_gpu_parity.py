@@ -218,6 +218,19 @@ def test_dense_pair_branch_runs_the_same_kernel(rbg, cuda, golden):
     close(y_pair, y_ref)
     h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
     close(conv(x, h, None), y_ref)
+    # the pair -> handle cache follows tensor identity: a different graph at a recycled device address, or an
+    # in-place edit of the weights, must not be served by a stale handle
+    ei_d, ew_d = ei.to(cuda), ew.to(cuda)
+    close(conv(x, ei_d, ew_d), y_ref)
+    ew_d.mul_(2.0)
+    close(conv(x, ei_d, ew_d), 2 * y_ref)
+    del ei_d, ew_d
+    half = len(g["uid"]) // 2
+    ei2, ew2 = rbg.norm_edges(g["uid"][:half], g["iid"][:half], nu, ni)
+    pad = torch.zeros(2, ei.shape[1] - ei2.shape[1], dtype=torch.int64)
+    ei2p = torch.cat([ei2, pad], dim=1).to(cuda)  # same shape (and very likely the same address) as the freed pair
+    ew2p = torch.cat([ew2, torch.zeros(ei.shape[1] - ei2.shape[1])]).to(cuda)
+    close(conv(x, ei2p, ew2p), O.conv_dense(x.cpu(), ei2, ew2))
 
 
 # ---- LightGCN forward -----------------------------------------------------------------------
