@@ -277,8 +277,8 @@ class NGCF(GeneralGraphRecommender):
 
 class SGL(GeneralGraphRecommender):
     """The propagation side of general_recommender/sgl.py: view construction (:73-126), ``forward``
-    with an optional per-layer graph list (:128-145) and ``full_sort_predict`` (:235-240).  The SSL /
-    BPR losses (:147-209) are a "next" row in SURVEY.md §8(f) and are not restated here."""
+    with an optional per-layer graph list (:128-145) and ``full_sort_predict`` (:235-240), and ``calculate_loss`` (:211-233) as plain
+    torch over the fused propagations (a fused InfoNCE kernel is a "next" row)."""
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -289,6 +289,10 @@ class SGL(GeneralGraphRecommender):
         self.n_layers = int(config["n_layers"] if config["n_layers"] is not None else 3)
         self.aug_type = config["type"] or "ED"
         self.drop_ratio = config["drop_ratio"] if config["drop_ratio"] is not None else 0.1
+        self.ssl_tau = config["ssl_tau"] if config["ssl_tau"] is not None else 0.5
+        self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
+        self.ssl_weight = config["ssl_weight"] if config["ssl_weight"] is not None else 0.05
+        self.reg_loss = EmbLoss()
         self.user_embedding = nn.Embedding(self.n_users, self.embed_dim)
         self.item_embedding = nn.Embedding(self.n_items, self.embed_dim)
         self.gcn_conv = ops.LightGCNConv(dim=self.embed_dim)
@@ -343,6 +347,30 @@ class SGL(GeneralGraphRecommender):
                 graphs = graphs[:1]
         mean = ops.lightgcn_forward(graphs, self.user_embedding.weight, self.item_embedding.weight, self.n_layers)
         return torch.split(mean, [self.n_users, self.n_items], dim=0)
+
+    @staticmethod
+    def _info_nce(anchor, positive, candidates, tau):
+        """-sum log( exp(<a,p>/tau) / sum_j exp(<a,c_j>/tau) ) over the batch, all vectors L2-normalised first
+        (one half of calc_ssl_loss, sgl.py:176-209)."""
+        a, p, c = F.normalize(anchor, dim=1), F.normalize(positive, dim=1), F.normalize(candidates, dim=1)
+        pos = torch.exp((a * p).sum(dim=1) / tau)
+        tot = torch.exp(a.matmul(c.T) / tau).sum(dim=1)
+        return -torch.log(pos / tot).sum()
+
+    def calculate_loss(self, interaction):
+        """sgl.py:211-233: BPR (sum-reduced logsigmoid form, :147-162) + reg on the ego embeddings + ssl_weight x
+        (user InfoNCE + item InfoNCE between the two augmented views).  Plain torch over three fused propagations."""
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        if self.sub_graph1 is None:
+            self.graph_construction()
+        user, pos, neg = interaction[self.USER_ID], interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]
+        (u_all, i_all), (u1, i1), (u2, i2) = self.propagate_views()
+        ue = u_all[user]
+        bpr = -F.logsigmoid((ue * i_all[pos]).sum(1) - (ue * i_all[neg]).sum(1)).sum()
+        reg = self.reg_loss(self.user_embedding(user), self.item_embedding(pos), self.item_embedding(neg))
+        ssl = self._info_nce(u1[user], u2[user], u2, self.ssl_tau) + self._info_nce(i1[pos], i2[pos], i2, self.ssl_tau)
+        return bpr + self.reg_weight * reg + self.ssl_weight * ssl
 
     def propagate_views(self):
         """The three propagations of one SGL training step (sgl.py:219-221): the full graph and the two

@@ -467,6 +467,46 @@ def test_sgl_model_views(rbg, cuda, golden):
         assert s.shape == (2, ni)  # SGL returns the un-flattened matrix (sgl.py:240)
 
 
+def test_sgl_training_loss_and_gradients(rbg, cuda, golden):
+    """SGL.calculate_loss (sgl.py:211-233) and its gradients against the same formulas on oracle-propagated
+    embeddings with torch autograd on the CPU (views replayed from the model's own keep masks)."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.SGL, cuda, golden, enable_sparse=True, type="ED", ssl_tau=0.5, ssl_weight=0.05,
+                          reg_weight=1e-4)
+    np.random.seed(5)
+    model.train()
+    batch = {"user_id": torch.tensor([1, 2, 3, 9, 2], device=cuda), "item_id": torch.tensor([1, 4, 3, 7, 8], device=cuda),
+             "neg_item_id": torch.tensor([5, 6, 2, 11, 30], device=cuda)}
+    loss = model.calculate_loss(batch)
+    loss.backward()
+    uw = model.user_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    iw = model.item_embedding.weight.detach().cpu().clone().requires_grad_(True)
+
+    def dense_conv(handle):
+        rp, c, v = handle.export_csr()
+        rows = torch.from_numpy(np.repeat(np.arange(len(rp) - 1), np.diff(rp)))
+        ei = torch.stack([torch.from_numpy(c.astype(np.int64)), rows])  # source = column, target = row
+        return lambda t: O.conv_dense(t, ei, torch.from_numpy(v))
+
+    props = []
+    for handle in (model.graph, model.sub_graph1[0][0], model.sub_graph2[0][0]):
+        props.append(O.lightgcn_forward(uw, iw, dense_conv(handle), 3))
+    (ua, ia), (u1, i1), (u2, i2) = props
+    u, p, q = (batch[k].cpu() for k in ("user_id", "item_id", "neg_item_id"))
+    nrm = torch.nn.functional.normalize
+    bpr = -torch.nn.functional.logsigmoid((ua[u] * ia[p]).sum(1) - (ua[u] * ia[q]).sum(1)).sum()
+    reg = (uw[u].norm() + iw[p].norm() + iw[q].norm()) / 5
+    def nce(a, b, allb):
+        a, b, allb = nrm(a, dim=1), nrm(b, dim=1), nrm(allb, dim=1)
+        return -torch.log(torch.exp((a * b).sum(1) / 0.5) / torch.exp(a @ allb.T / 0.5).sum(1)).sum()
+    ref = bpr + 1e-4 * reg + 0.05 * (nce(u1[u], u2[u], u2) + nce(i1[p], i2[p], i2))
+    ref.backward()
+    close(loss.reshape(()), ref.detach().reshape(()), tol=2e-5)
+    close(model.user_embedding.weight.grad, uw.grad, tol=2e-5)
+    close(model.item_embedding.weight.grad, iw.grad, tol=2e-5)
+
+
 # ---- NGCF -----------------------------------------------------------------------------------
 
 def test_bignn_conv_golden(rbg, cuda, golden):
