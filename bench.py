@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--workload", default="gowalla")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
-    ap.add_argument("--p-in", type=float, default=0.9, help="N>1: fraction of interactions inside a rank's block")
+    ap.add_argument("--p-in", type=float, default=0.95, help="N>1: fraction of interactions inside a rank's block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) measurements at N = 1")
