@@ -62,6 +62,21 @@ def main():
     emit(kind="copy_bw", gbps=2 * a.numel() * 4 / (mn * 1e-6) / 1e9, us=mn)
     del a, b
 
+    # locality lever: the same Gowalla-sized graph with 8 communities, default launch plan vs communities pinned to XCDs
+    nu, ni, e = rbg.synth.shape("gowalla")
+    for p_in, layout in ((0.99, "contiguous"), (0.95, "contiguous"), (0.8, "contiguous"), (0.5, "contiguous"), (0.95, "striped")):
+        uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=2020, n_blocks=8, p_in=p_in, layout=layout)
+        part = rbg.synth.partition_of(nu, ni, 8, layout=layout)
+        x = torch.randn(nu + ni, 64, device=dev)
+        y = torch.empty_like(x)
+        g0 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+        g1 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, xcd_part=part)
+        t0, _ = time_us(lambda: rbg.ops.spmm_raw(g0, x, out=y), iters=100, warmup=10)
+        t1, _ = time_us(lambda: rbg.ops.spmm_raw(g1, x, out=y), iters=100, warmup=10)
+        bl, _ = rbg.synth.algorithmic_bytes(nu + ni, 2 * e, 64, 3)
+        emit(kind="community_xcd", p_in=p_in, layout=layout, us_default_plan=t0, us_communities_on_xcds=t1, frac_default=bl / (t0 * 1e-6) / 8e12,
+             frac_pinned=bl / (t1 * 1e-6) / 8e12)
+        del g0, g1
     shapes = args.shapes.split(",") + (["g-1.3m"] if args.big else [])
     for name in shapes:
         t0 = time.time()

@@ -103,6 +103,16 @@ int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, i
                             const int64_t *uid, const int64_t *iid, const uint8_t *keep,
                             int device, uint32_t flags);
 
+/* rbg_graph_create_masked plus a node partition for L2 locality: part[node] in [0, n_parts) (HOST array over all
+ * n_users + n_items nodes; n_parts in {1,2,4,8}) names the community of every node, e.g. from a graph partitioner
+ * or the shard owner array.  The rows of part p are pinned to XCDs [p*8/n_parts, (p+1)*8/n_parts) (workgroup b runs
+ * on XCD b % 8), so an XCD's private 4 MB L2 only sees that community's embeddings plus the edge cut.  Results are
+ * identical to the unpartitioned graph (same CSR, same per-row arithmetic); only the launch plan changes.  Parts
+ * should carry similar nnz.  part == NULL or n_parts == 1: the default user-row / item-row XCD split. */
+int rbg_graph_create_partitioned(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
+                                 const int64_t *uid, const int64_t *iid, const uint8_t *keep, const int32_t *part,
+                                 int n_parts, int device, uint32_t flags);
+
 /* A pre-built (already weighted) CSR, possibly rectangular: rows = output nodes, cols = index
  * space of the dense operand.  Used for node-range shards ([local | halo] column space) and for
  * callers that hold the reference's SparseTensor storage (rowptr,col,value of adj_t;

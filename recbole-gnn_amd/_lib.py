@@ -30,6 +30,7 @@ SIGNATURES = {
     "rbg_get_option": (c_int, [ctypes.c_char_p, P(c_i64)]),
     "rbg_graph_create": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_int, c_u32]),
     "rbg_graph_create_masked": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),
+    "rbg_graph_create_partitioned": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_u32]),
     "rbg_graph_create_csr": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),
     "rbg_graph_create_coo": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_int, c_u32]),
     "rbg_norm_edges": (c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),

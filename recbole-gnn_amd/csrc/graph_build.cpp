@@ -147,20 +147,20 @@ int build_host_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_int
     return RBG_OK;
 }
 
-// Degree-bin the rows [r0, r1) of the CSR into one GroupPlan (appends to plan.desc / plan.tasks).
-static void plan_group(const rbg_graph *g, int64_t r0, int64_t r1, BinPlan &plan, GroupPlan &gp) {
+// Degree-bin the given rows (ascending ids) of the CSR into one GroupPlan (appends to plan.desc / plan.tasks).
+static void plan_group(const rbg_graph *g, const std::vector<int32_t> &rows, BinPlan &plan, GroupPlan &gp) {
     const int32_t *rp = g->h_rowptr.data();
     const Tuning tn = g->tuning;
-    const int64_t n = r1 - r0;
+    const int64_t n = (int64_t)rows.size();
     int32_t max_deg = 0;
-    for (int64_t r = r0; r < r1; ++r) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
+    for (int32_t r : rows) max_deg = std::max(max_deg, rp[r + 1] - rp[r]);
     plan.max_deg = std::max(plan.max_deg, max_deg);
     // counting sort by degree, descending; ties keep ascending row id
     std::vector<int32_t> order((size_t)n);
     std::vector<int64_t> start((size_t)max_deg + 2, 0);
-    for (int64_t r = r0; r < r1; ++r) start[(size_t)(max_deg - (rp[r + 1] - rp[r])) + 1]++;
+    for (int32_t r : rows) start[(size_t)(max_deg - (rp[r + 1] - rp[r])) + 1]++;
     for (int32_t k = 0; k <= max_deg; ++k) start[(size_t)k + 1] += start[(size_t)k];
-    for (int64_t r = r0; r < r1; ++r) order[(size_t)start[(size_t)(max_deg - (rp[r + 1] - rp[r]))]++] = (int32_t)r;
+    for (int32_t r : rows) order[(size_t)start[(size_t)(max_deg - (rp[r + 1] - rp[r]))]++] = r;
     gp = GroupPlan{};
     gp.task_base = (int32_t)plan.tasks.size();
     int64_t k = 0;
@@ -221,14 +221,40 @@ int plan_bins(const rbg_graph *g, BinPlan &plan) {
         plan.n_short = n;
         return RBG_OK;
     }
-    // XCD specialisation needs the user/item boundary (graphs built from interactions) and both classes
-    const bool split = opt_xcd_split() && g->n_users > 0 && g->n_users < n && g->n_rows == g->n_cols;
+    auto range = [](int64_t a, int64_t b) {
+        std::vector<int32_t> v((size_t)(b - a));
+        for (int64_t r = a; r < b; ++r) v[(size_t)(r - a)] = (int32_t)r;
+        return v;
+    };
+    if (!g->h_part.empty()) {
+        // caller-supplied communities: part p runs on XCDs [p*(8/P), (p+1)*(8/P))
+        const int P = g->n_parts, per = 8 / P;
+        plan.n_groups = P;
+        std::vector<std::vector<int32_t>> rows((size_t)P);
+        for (int64_t r = 0; r < n; ++r) rows[(size_t)g->h_part[(size_t)r]].push_back((int32_t)r);
+        for (int q = 0; q < P; ++q) plan_group(g, rows[(size_t)q], plan, plan.groups[q]);
+        for (int x = 0; x < 8; ++x) {
+            plan.xmap.grp[x] = (uint8_t)(x / per);
+            plan.xmap.idx[x] = (uint8_t)(x % per);
+            plan.xmap.cnt[x] = (uint8_t)per;
+        }
+        return RBG_OK;
+    }
+    // default XCD specialisation needs the user/item boundary (graphs built from interactions) and both classes
+    const int S = std::min(7, opt_xcd_split());
+    const bool split = S > 0 && g->n_users > 0 && g->n_users < n && g->n_rows == g->n_cols;
     if (split) {
         plan.n_groups = 2;
-        plan_group(g, 0, g->n_users, plan, plan.groups[0]);
-        plan_group(g, g->n_users, n, plan, plan.groups[1]);
+        plan_group(g, range(0, g->n_users), plan, plan.groups[0]);
+        plan_group(g, range(g->n_users, n), plan, plan.groups[1]);
+        for (int x = 0; x < 8; ++x) {
+            const bool second = x >= S;
+            plan.xmap.grp[x] = second ? 1 : 0;
+            plan.xmap.idx[x] = (uint8_t)(second ? x - S : x);
+            plan.xmap.cnt[x] = (uint8_t)(second ? 8 - S : S);
+        }
     } else {
-        plan_group(g, 0, n, plan, plan.groups[0]);
+        plan_group(g, range(0, n), plan, plan.groups[0]);
     }
     return RBG_OK;
 }
@@ -285,9 +311,9 @@ int upload_plan(rbg_graph *g) {
     }
     if (rc) return rc;
     g->n_groups = plan.n_groups;
-    g->xcd_split = std::min(7, std::max(1, opt_xcd_split()));
-    g->groups[0] = plan.groups[0];
-    g->groups[1] = plan.groups[1];
+    g->xmap = plan.xmap;
+    for (int q = 0; q < kMaxGroups; ++q) g->groups[q] = plan.groups[q];
+    std::vector<int8_t>().swap(g->h_part);
     g->n_block_rows = plan.n_block_rows;
     g->n_wave = plan.n_wave;
     g->n_short = plan.n_short;
@@ -416,15 +442,41 @@ int rbg_get_option(const char *key, int64_t *value) {
 int rbg_graph_create_masked(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
                             const int64_t *uid, const int64_t *iid, const uint8_t *keep, int device,
                             uint32_t flags) {
+    return rbg_graph_create_partitioned(out, n_users, n_items, n_inter, uid, iid, keep, nullptr, 0, device, flags);
+}
+
+int rbg_graph_create_partitioned(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t n_inter,
+                                 const int64_t *uid, const int64_t *iid, const uint8_t *keep, const int32_t *part,
+                                 int n_parts, int device, uint32_t flags) {
     clear_error();
     if (!out) return fail(RBG_EINVAL, "out is NULL");
     *out = nullptr;
     if (device < -1) return fail(RBG_EINVAL, "device %d", device);
+    if (part && n_parts != 1 && n_parts != 2 && n_parts != 4 && n_parts != 8)
+        return fail(RBG_EINVAL, "n_parts = %d (must be 1, 2, 4 or 8: parts are pinned to whole XCDs)", n_parts);
     rbg_graph *g = new (std::nothrow) rbg_graph();
     if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
     g->device = device;
     g->flags = flags | (device < 0 ? RBG_GRAPH_KEEP_HOST : 0u);
     g->tuning = current_tuning();
+    if (part && n_parts > 1 && n_users >= 0 && n_items >= 0) {
+        const int64_t n = n_users + n_items;
+        try {
+            g->h_part.resize((size_t)n);
+        } catch (const std::bad_alloc &) {
+            delete g;
+            return fail(RBG_ENOMEM, "host allocation failed");
+        }
+        for (int64_t r = 0; r < n; ++r) {
+            if (part[r] < 0 || part[r] >= n_parts) {
+                const int bad = part[r];
+                delete g;
+                return fail(RBG_EINVAL, "part[%lld] = %d out of [0,%d)", (long long)r, bad, n_parts);
+            }
+            g->h_part[(size_t)r] = (int8_t)part[r];
+        }
+        g->n_parts = n_parts;
+    }
     if (device >= 0 && !(flags & RBG_GRAPH_BUILD_ON_HOST)) {
         // device builder: sort / scan / weights in HBM, only rowptr returns for the launch plan
         int rc = build_device_csr(g, n_users, n_items, n_inter, uid, iid, keep);

@@ -35,6 +35,13 @@ int opt_xcd_split();
 int opt_nt_store();
 
 // One workgroup task: a row (or one segment of a split row).
+constexpr int kMaxGroups = 8;
+
+// XCD x runs row group grp[x]; it is XCD number idx[x] of the cnt[x] XCDs serving that group.
+struct XcdMap {
+    uint8_t grp[8], idx[8], cnt[8];
+};
+
 struct BlockTask {
     int32_t row;        // output row
     int32_t beg, end;   // CSR entry range of this segment
@@ -53,8 +60,9 @@ struct RowDesc {
 };
 static_assert(sizeof(RowDesc) == 16, "RowDesc must stay 16 bytes");
 
-// Launch plan of one row class.  With XCD specialisation there are two classes (user rows run on XCDs
-// 0-3, item rows on XCDs 4-7, so each XCD's L2 only ever holds ONE embedding table); otherwise one.
+// Launch plan of one row group.  Row groups are pinned to XCDs (workgroup b runs on XCD b % 8): by default two
+// classes (user rows on XCDs 0-3, item rows on XCDs 4-7, so each XCD's L2 only ever holds ONE embedding table);
+// with a caller-supplied node partition up to 8 groups (one community per XCD); or a single group.
 struct GroupPlan {
     int32_t n_tasks, task_base;  // workgroup tasks  [task_base, task_base + n_tasks)
     int32_t n_wave, pos_wave;    // wavefront rows   desc[pos_wave  .. +n_wave)
@@ -84,8 +92,10 @@ struct rbg_graph {
     // rows (expanded to d_tasks), wavefront rows and lane-group rows (both described by d_desc).
     rbg::Tuning tuning{};
     int n_groups = 1;
-    int xcd_split = 4;  // XCDs serving groups[0] when n_groups == 2
-    rbg::GroupPlan groups[2] = {};
+    rbg::XcdMap xmap{};
+    rbg::GroupPlan groups[rbg::kMaxGroups] = {};
+    std::vector<int8_t> h_part;  // optional node -> row group (community) supplied by the caller; consumed by the plan
+    int n_parts = 0;
     rbg::RowDesc *d_desc = nullptr;  // [n_wave + n_short over all groups]
     int64_t n_block_rows = 0, n_wave = 0, n_short = 0;
     rbg::BlockTask *d_tasks = nullptr;
@@ -104,8 +114,8 @@ struct BinPlan {
     std::vector<RowDesc> desc;
     std::vector<BlockTask> tasks;
     int n_groups = 1;
-    int xcd_split = 4;  // XCDs serving groups[0] when n_groups == 2
-    GroupPlan groups[2] = {};
+    XcdMap xmap{};
+    GroupPlan groups[kMaxGroups] = {};
     int64_t n_block_rows = 0, n_wave = 0, n_short = 0, n_split = 0, n_slots = 0;
     int32_t max_deg = 0;
 };

@@ -17,6 +17,8 @@
 // For graphs built from interactions the rows are additionally split by class: workgroups on XCDs 0-3 take
 // user rows (they gather item embeddings only), XCDs 4-7 item rows — each XCD's private 4 MB L2 then
 // caches one embedding table, not two (measured: the kernel is bound by L2 misses).
+// A caller-supplied node partition (communities; rbg_graph_create_partitioned) pins each community's rows to its
+// own XCD(s) instead, so an XCD's L2 only sees that community's embeddings plus the cut.
 // (col,val) are fetched lane-parallel (one coalesced non-temporal read per lane-group chunk) and
 // broadcast with ds_bpermute; U (8) neighbour rows are in flight per lane-group before the FMAs.
 // No float atomics anywhere: the result is bit-stable run to run.
@@ -52,8 +54,9 @@ struct SpmmParams {
     float *y;  // may be NULL in MODE_MEAN
     int64_t ldy;
     int32_t n_rows;
-    int32_t split_xcd;  // S > 0: workgroups on XCDs [0,S) run grp[0] (user rows), XCDs [S,8) grp[1] (item rows)
-    GroupPlan grp[2];
+    int32_t n_groups;  // > 1: workgroup b (XCD b & 7) runs row group xmap.grp[b & 7]
+    XcdMap xmap;
+    GroupPlan grp[kMaxGroups];
     int32_t mode;
     int32_t nt_store;
     // MODE_HORNER: y[row] = (addend[row] + acc) / denom   (one step of the backward chain)
@@ -192,10 +195,10 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     // XCDs 0-3 take class 0 (user rows, gather item embeddings), XCDs 4-7 class 1, so an XCD's 4 MB L2 is
     // shared by ONE embedding table instead of two.
     int grp = 0, vb = blockIdx.x;
-    if (p.split_xcd) {
-        const int x = blockIdx.x & 7, S = p.split_xcd;
-        grp = x >= S;
-        vb = grp ? (blockIdx.x >> 3) * (8 - S) + (x - S) : (blockIdx.x >> 3) * S + x;
+    if (p.n_groups > 1) {
+        const int x = blockIdx.x & 7;
+        grp = p.xmap.grp[x];
+        vb = (blockIdx.x >> 3) * p.xmap.cnt[x] + p.xmap.idx[x];
     }
     const GroupPlan gp = p.grp[grp];
     const int blocks_wave = (gp.n_wave + 3) >> 2;
@@ -374,9 +377,9 @@ static void fill_graph(const rbg_graph *g, SpmmParams &p) {
     p.partials = g->d_partials;
     p.counters = g->d_counters;
     p.n_rows = (int32_t)g->n_rows;
-    p.split_xcd = g->n_groups == 2 ? g->xcd_split : 0;
-    p.grp[0] = g->groups[0];
-    p.grp[1] = g->groups[1];
+    p.n_groups = g->n_groups;
+    p.xmap = g->xmap;
+    for (int q = 0; q < kMaxGroups; ++q) p.grp[q] = g->groups[q];
     p.nt_store = opt_nt_store();
 }
 
@@ -387,10 +390,12 @@ static int64_t group_blocks(const GroupPlan &gp, int subs) {
 template <int D>
 static int64_t grid_for(const rbg_graph *g) {
     constexpr int SUBS = 64 / (D / 4);
-    if (g->n_groups == 2) {
-        const int64_t S = g->xcd_split;
-        const int64_t m = std::max((group_blocks(g->groups[0], SUBS) + S - 1) / S,
-                                   (group_blocks(g->groups[1], SUBS) + (8 - S) - 1) / (8 - S));
+    if (g->n_groups > 1) {
+        int64_t m = 0;  // rounds of 8 workgroups: the slowest group decides
+        for (int x = 0; x < 8; ++x) {
+            const int64_t c = g->xmap.cnt[x];
+            m = std::max(m, (group_blocks(g->groups[g->xmap.grp[x]], SUBS) + c - 1) / c);
+        }
         return 8 * m;
     }
     return group_blocks(g->groups[0], SUBS);

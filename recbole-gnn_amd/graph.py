@@ -54,12 +54,24 @@ class GraphHandle:
 
     # ---- constructors -----------------------------------------------------------------------
     @classmethod
-    def from_interactions(cls, uid, iid, n_users, n_items, device=None, keep=None, flags=0):
-        """dataset.py:60-75 (keep=None) or one SGL view (sgl.py:107-126) when ``keep`` is a mask."""
+    def from_interactions(cls, uid, iid, n_users, n_items, device=None, keep=None, flags=0, xcd_part=None):
+        """dataset.py:60-75 (keep=None) or one SGL view (sgl.py:107-126) when ``keep`` is a mask.
+        ``xcd_part``: optional int array [n_users + n_items] with a community id per node (1, 2, 4 or 8 communities):
+        each community's rows are pinned to its own XCD(s) for L2 locality; results are unchanged."""
         uid, iid = _np_i64(uid), _np_i64(iid)
         if uid.shape != iid.shape or uid.ndim != 1:
             raise ValueError("uid and iid must be 1-D arrays of equal length")
         out = c_vp()
+        if xcd_part is not None:
+            part = np.ascontiguousarray(xcd_part, dtype=np.int32)
+            if part.shape != (n_users + n_items,):
+                raise ValueError("xcd_part must have one entry per node")
+            n_parts = int(part.max()) + 1 if part.size else 1
+            if keep is not None:
+                keep = np.ascontiguousarray(keep.detach().cpu().numpy() if isinstance(keep, torch.Tensor) else keep, dtype=np.uint8)
+            check(lib.rbg_graph_create_partitioned(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
+                                                   _ptr(keep), _ptr(part), n_parts, _device_index(device), flags))
+            return cls(out.value, symmetric=True, n_users=int(n_users))
         if keep is None:
             check(lib.rbg_graph_create(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
                                        _device_index(device), flags))

@@ -28,8 +28,25 @@ def _powerlaw_cdf(n, alpha=0.75, shift=10.0):
     return c / c[-1]
 
 
-def powerlaw_bipartite(n_users, n_items, n_inter, seed=2020, alpha=0.75, n_blocks=1, p_in=1.0):
-    """Returns (uid, iid) int64 arrays of exactly ``n_inter`` unique pairs, ids in [1, n)."""
+def contiguous_blocks(n, n_blocks):
+    """Relabelling striped -> contiguous communities: 0-based rank r (block r % P, position r // P) moves to
+    block * ceil(n / P) + position.  Returns (new_rank[r], block_of_new_rank[...])."""
+    r = np.arange(n)
+    per = (n + n_blocks - 1) // n_blocks
+    new = (r % n_blocks) * per + r // n_blocks
+    # compact (the last block may be shorter): rank of each new position among the used ones
+    order = np.argsort(new, kind="stable")
+    compact = np.empty(n, dtype=np.int64)
+    compact[order] = np.arange(n)
+    block = np.empty(n, dtype=np.int32)
+    block[compact] = (r % n_blocks).astype(np.int32)
+    return compact, block
+
+
+def powerlaw_bipartite(n_users, n_items, n_inter, seed=2020, alpha=0.75, n_blocks=1, p_in=1.0, layout="striped"):
+    """Returns (uid, iid) int64 arrays of exactly ``n_inter`` unique pairs, ids in [1, n).
+    ``layout="contiguous"`` relabels the nodes so that every community occupies one contiguous id range (what a
+    partitioner-driven relabelling produces); ``partition_of`` then gives the community of every node."""
     nu, ni = n_users - 1, n_items - 1  # real (non-PAD) ids
     if n_inter > nu * ni:
         raise ValueError("more interactions than user-item pairs")
@@ -55,7 +72,23 @@ def powerlaw_bipartite(n_users, n_items, n_inter, seed=2020, alpha=0.75, n_block
         keys = np.unique(np.concatenate([keys, u * ni + i]))
         need = n_inter - keys.shape[0]
     keys = rng.permutation(keys)[:n_inter]
-    return keys // ni + 1, keys % ni + 1
+    u, i = keys // ni, keys % ni
+    if n_blocks > 1 and layout == "contiguous":
+        u = contiguous_blocks(nu, n_blocks)[0][u]
+        i = contiguous_blocks(ni, n_blocks)[0][i]
+    return u + 1, i + 1
+
+
+def partition_of(n_users, n_items, n_blocks, layout="striped"):
+    """Community of every node (users then items; the PAD ids go to community 0) for the generator's layouts."""
+    out = []
+    for n in (n_users - 1, n_items - 1):
+        if layout == "contiguous":
+            blk = contiguous_blocks(n, n_blocks)[1]
+        else:
+            blk = (np.arange(n) % n_blocks).astype(np.int32)
+        out.append(np.concatenate([[0], blk]).astype(np.int32))
+    return np.concatenate(out)
 
 
 def shape(name):

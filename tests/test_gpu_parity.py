@@ -189,6 +189,33 @@ def test_hub_rows_at_scale(rbg, cuda):
     close(mean, acc / 4.0)
 
 
+@pytest.mark.parametrize("n_parts", [2, 4, 8])
+def test_community_partition_changes_only_the_launch_plan(rbg, cuda, n_parts):
+    """rbg_graph_create_partitioned: pinning communities to XCDs must give bit-identical results."""
+    nu, ni, e = 1201, 2401, 40_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=9, n_blocks=n_parts, p_in=0.9)
+    part = rbg.sharded.striped_partition(nu, ni, n_parts)
+    h0 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    h1 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, xcd_part=part)
+    for a, b in zip(h0.export_csr(), h1.export_csr()):
+        assert np.array_equal(a, b)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    for d in (64, 128):
+        x = randn((nu + ni, d), d, cuda)
+        y0, y1 = rbg.ops.spmm_raw(h0, x), rbg.ops.spmm_raw(h1, x)
+        assert torch.equal(y0, y1)
+        close(y1, C.spmm(rowptr, col, val, x.cpu().numpy()))
+    uw, iw = randn((nu, 64), 1, cuda), randn((ni, 64), 2, cuda)
+    m0, _ = rbg.ops.lightgcn_forward_raw(h0, uw, iw, 3)
+    m1, _ = rbg.ops.lightgcn_forward_raw(h1, uw, iw, 3)
+    assert torch.equal(m0, m1)
+    # an unbalanced / partly empty partition is still correct
+    lop = np.zeros(nu + ni, dtype=np.int32)
+    lop[: (nu + ni) // 10] = 1
+    h2 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, xcd_part=lop)
+    assert torch.equal(rbg.ops.spmm_raw(h2, x), y0)
+
+
 def test_spmm_empty_and_rectangular(rbg, cuda):
     h = rbg.GraphHandle.from_interactions([], [], 3, 4, device=cuda)
     y = rbg.ops.spmm_raw(h, randn((7, 64), 0, cuda))

@@ -113,3 +113,16 @@ def test_dataset_mirror(rbg, ref_inter):
     assert ei.shape == (2, 2 * len(uid)) and ew.dtype == torch.float32
     g, none = ds.get_norm_adj_mat(enable_sparse=True)    # host handle when no device is given
     assert none is None and isinstance(g, rbg.GraphHandle) and g.symmetric
+
+
+def test_partitioned_create_validates(rbg):
+    uid, iid, nu, ni = [1, 2, 1], [1, 2, 2], 3, 3
+    part = np.array([0, 0, 1, 0, 1, 1], dtype=np.int32)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, xcd_part=part)
+    ref = rbg.GraphHandle.from_interactions(uid, iid, nu, ni)
+    for a, b in zip(h.export_csr(), ref.export_csr()):
+        assert np.array_equal(a, b)                      # the partition never changes the matrix
+    with pytest.raises(rbg.RbgError):
+        rbg.GraphHandle.from_interactions(uid, iid, nu, ni, xcd_part=np.array([0, 0, 2, 0, 1, 1]))  # 3 parts
+    with pytest.raises(ValueError):
+        rbg.GraphHandle.from_interactions(uid, iid, nu, ni, xcd_part=np.array([0, 1]))
