@@ -12,5 +12,5 @@ if [ "${1:-}" != "notune" ]; then
   echo "== tune ==" ; timeout 1500 python devtools/tune_spmm.py --quick --big 2>&1 | tail -60 > gpurun_out/tune_tail.log
 fi
 echo "== rocprof ==" 
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 100 --warmup 10 --cpu-seconds 0 > "$OLDPWD/gpurun_out/rocprof_bench.log" 2>&1 )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o bench -- python "$OLDPWD/bench.py" --steps 100 --warmup 10 --cpu-seconds 0 --no-extras > "$OLDPWD/gpurun_out/rocprof_bench.log" 2>&1 )
 find gpurun_out/prof -name "*stats*" | head
