@@ -77,6 +77,25 @@ def main():
         emit(kind="community_xcd", p_in=p_in, layout=layout, us_default_plan=t0, us_communities_on_xcds=t1, frac_default=bl / (t0 * 1e-6) / 8e12,
              frac_pinned=bl / (t1 * 1e-6) / 8e12)
         del g0, g1
+    # ... and with the node ids scrambled, communities rediscovered by find_communities (xcd_part="auto")
+    for p_in in (0.99, 0.95, 0.8):
+        uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=2020, n_blocks=8, p_in=p_in, layout="contiguous")
+        rs = np.random.default_rng(1)
+        pu = np.concatenate([[0], rs.permutation(nu - 1) + 1])
+        pi = np.concatenate([[0], rs.permutation(ni - 1) + 1])
+        uid, iid = pu[uid], pi[iid]
+        t0 = time.time()
+        lab, cut, imb = rbg.find_communities(uid, iid, nu, ni)
+        t_lp = time.time() - t0
+        x = torch.randn(nu + ni, 64, device=dev)
+        y = torch.empty_like(x)
+        g0 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+        g1 = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, xcd_part=lab)
+        ta, _ = time_us(lambda: rbg.ops.spmm_raw(g0, x, out=y), iters=100, warmup=10)
+        tb, _ = time_us(lambda: rbg.ops.spmm_raw(g1, x, out=y), iters=100, warmup=10)
+        emit(kind="community_auto", p_in=p_in, found_cut=cut, imbalance=imb, label_propagation_s=t_lp, us_default_plan=ta,
+             us_found_communities_on_xcds=tb)
+        del g0, g1
     shapes = args.shapes.split(",") + (["g-1.3m"] if args.big else [])
     for name in shapes:
         t0 = time.time()

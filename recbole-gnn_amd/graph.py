@@ -38,6 +38,32 @@ def _device_index(device):
     return torch.cuda.current_device() if dev.index is None else dev.index
 
 
+def find_communities(uid, iid, n_users, n_items, n_parts=8, iters=12, seed=0):
+    """Balanced label propagation on the bipartite interaction graph (host, numpy): every node repeatedly adopts the
+    label most common among its neighbours, votes of over-loaded labels scaled down, half of the nodes moving per
+    round (a bipartite graph otherwise oscillates).  Returns (labels int32 [n_users + n_items], cut, imbalance) where
+    ``cut`` is the fraction of interactions whose two ends carry different labels and ``imbalance`` is the largest
+    label's share of the nnz over the mean.  Feeds ``rbg_graph_create_partitioned`` when the caller has no partition."""
+    uid, iid = _np_i64(uid), _np_i64(iid)
+    n = int(n_users) + int(n_items)
+    rng = np.random.default_rng(seed)
+    rows = np.concatenate([uid, iid + n_users])
+    cols = np.concatenate([iid + n_users, uid])
+    deg = np.bincount(rows, minlength=n).astype(np.float64)
+    label = rng.integers(0, n_parts, n)
+    target = max(deg.sum() / n_parts, 1.0)
+    for _ in range(iters):
+        votes = np.bincount(rows * n_parts + label[cols], minlength=n * n_parts).reshape(n, n_parts).astype(np.float64)
+        load = np.bincount(label, weights=deg, minlength=n_parts)
+        score = votes * (target / np.maximum(load, 1.0)) + rng.random(votes.shape) * 1e-3
+        new = score.argmax(1)
+        new[deg == 0] = label[deg == 0]
+        label = np.where(rng.random(n) < 0.5, new, label)
+    load = np.bincount(label, weights=deg, minlength=n_parts)
+    cut = float(np.mean(label[uid] != label[n_users + iid])) if len(uid) else 0.0
+    return label.astype(np.int32), cut, float(load.max() / max(load.mean(), 1.0))
+
+
 class GraphHandle:
     """Owns one ``rbg_graph*``.  Opaque to models, exactly like the reference's ``self.edge_index``
     (a torch_sparse SparseTensor when ``enable_sparse``; abstract_recommender.py:15-18)."""
@@ -62,6 +88,14 @@ class GraphHandle:
         if uid.shape != iid.shape or uid.ndim != 1:
             raise ValueError("uid and iid must be 1-D arrays of equal length")
         out = c_vp()
+        if isinstance(xcd_part, str):
+            if xcd_part != "auto":
+                raise ValueError("xcd_part must be an array or 'auto'")
+            # use discovered communities only if they are real (most interactions stay inside) and balanced;
+            # an unstructured graph keeps the default user-row / item-row XCD split
+            kept = np.flatnonzero(keep) if keep is not None else slice(None)
+            part, cut, imbalance = find_communities(uid[kept], iid[kept], n_users, n_items)
+            xcd_part = part if (cut < 0.15 and imbalance < 1.2) else None  # measured break-even, DESIGN.md §6.4
         if xcd_part is not None:
             part = np.ascontiguousarray(xcd_part, dtype=np.int32)
             if part.shape != (n_users + n_items,):

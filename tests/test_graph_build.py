@@ -126,3 +126,22 @@ def test_partitioned_create_validates(rbg):
         rbg.GraphHandle.from_interactions(uid, iid, nu, ni, xcd_part=np.array([0, 0, 2, 0, 1, 1]))  # 3 parts
     with pytest.raises(ValueError):
         rbg.GraphHandle.from_interactions(uid, iid, nu, ni, xcd_part=np.array([0, 1]))
+
+
+def test_find_communities_recovers_planted_structure(rbg):
+    nu, ni, e = 2001, 3001, 60_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=3, n_blocks=4, p_in=0.97, layout="contiguous")
+    rng = np.random.default_rng(5)  # scramble the ids: the structure is no longer visible in the numbering
+    pu = np.concatenate([[0], rng.permutation(nu - 1) + 1])
+    pi = np.concatenate([[0], rng.permutation(ni - 1) + 1])
+    lab, cut, imb = rbg.find_communities(pu[uid], pi[iid], nu, ni, n_parts=4)
+    assert lab.shape == (nu + ni,) and lab.min() >= 0 and lab.max() < 4
+    assert cut < 0.3 and imb < 1.3   # planted cut: 3 % x 3/4; a small sparse graph is recovered only roughly
+    # an unstructured graph: no partition worth using -> "auto" keeps the default plan (and never changes the matrix)
+    u2, i2 = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=4)
+    _, cut2, _ = rbg.find_communities(u2, i2, nu, ni, n_parts=8)
+    assert cut2 > 0.6
+    ha = rbg.GraphHandle.from_interactions(pu[uid], pi[iid], nu, ni, xcd_part="auto")
+    hd = rbg.GraphHandle.from_interactions(pu[uid], pi[iid], nu, ni)
+    for a, b in zip(ha.export_csr(), hd.export_csr()):
+        assert np.array_equal(a, b)
