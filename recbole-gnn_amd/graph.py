@@ -38,9 +38,9 @@ def _device_index(device):
     return torch.cuda.current_device() if dev.index is None else dev.index
 
 
-def find_communities(uid, iid, n_users, n_items, n_parts=8, iters=12, seed=0):
+def find_communities(uid, iid, n_users, n_items, n_parts=8, iters=24, seed=0):
     """Balanced label propagation on the bipartite interaction graph (host, numpy): every node repeatedly adopts the
-    label most common among its neighbours, votes of over-loaded labels scaled down, half of the nodes moving per
+    label most common among its neighbours, votes scaled by (target load / label load)^2, half of the nodes moving per
     round (a bipartite graph otherwise oscillates).  Returns (labels int32 [n_users + n_items], cut, imbalance) where
     ``cut`` is the fraction of interactions whose two ends carry different labels and ``imbalance`` is the largest
     label's share of the nnz over the mean.  Feeds ``rbg_graph_create_partitioned`` when the caller has no partition."""
@@ -55,7 +55,7 @@ def find_communities(uid, iid, n_users, n_items, n_parts=8, iters=12, seed=0):
     for _ in range(iters):
         votes = np.bincount(rows * n_parts + label[cols], minlength=n * n_parts).reshape(n, n_parts).astype(np.float64)
         load = np.bincount(label, weights=deg, minlength=n_parts)
-        score = votes * (target / np.maximum(load, 1.0)) + rng.random(votes.shape) * 1e-3
+        score = votes * (target / np.maximum(load, 1.0)) ** 2 + rng.random(votes.shape) * 1e-3
         new = score.argmax(1)
         new[deg == 0] = label[deg == 0]
         label = np.where(rng.random(n) < 0.5, new, label)
@@ -95,7 +95,7 @@ class GraphHandle:
             # an unstructured graph keeps the default user-row / item-row XCD split
             kept = np.flatnonzero(keep) if keep is not None else slice(None)
             part, cut, imbalance = find_communities(uid[kept], iid[kept], n_users, n_items)
-            xcd_part = part if (cut < 0.15 and imbalance < 1.2) else None  # measured break-even, DESIGN.md §6.4
+            xcd_part = part if (cut < 0.3 and imbalance < 1.1) else None  # measured to pay up to a ~20 % cut, DESIGN.md §6.4
         if xcd_part is not None:
             part = np.ascontiguousarray(xcd_part, dtype=np.int32)
             if part.shape != (n_users + n_items,):
