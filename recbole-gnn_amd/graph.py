@@ -267,9 +267,11 @@ class InteractionDataset:
     def num(self, field):
         return self.user_num if field == "user_id" else self.item_num
 
-    def get_norm_adj_mat(self, enable_sparse=False, device=None):
+    def get_norm_adj_mat(self, enable_sparse=False, device=None, xcd_part=None):
         """dataset.py:49-79.  enable_sparse truthy -> (GraphHandle, None) [the SparseTensor branch];
-        falsy (None / False, the reference default) -> (edge_index, edge_weight) CPU tensors."""
+        falsy (None / False, the reference default) -> (edge_index, edge_weight) CPU tensors.
+        ``xcd_part`` (engine extension): community array or "auto", see GraphHandle.from_interactions."""
         if enable_sparse:
-            return GraphHandle.from_interactions(self.uid, self.iid, self.user_num, self.item_num, device=device), None
+            return GraphHandle.from_interactions(self.uid, self.iid, self.user_num, self.item_num, device=device,
+                                                 xcd_part=xcd_part), None
         return norm_edges(self.uid, self.iid, self.user_num, self.item_num)

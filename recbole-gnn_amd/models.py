@@ -93,14 +93,16 @@ class GeneralGraphRecommender(nn.Module):
         self.n_items = dataset.num(self.ITEM_ID)
         self.dataset = dataset
         self.use_sparse = bool(config["enable_sparse"] and dataset.is_sparse)
+        xcd_part = config["xcd_partition"]  # engine extension: None | "auto" | node -> community array
         if self.use_sparse:
-            self.edge_index, self.edge_weight = dataset.get_norm_adj_mat(enable_sparse=True, device=self.device)
+            self.edge_index, self.edge_weight = dataset.get_norm_adj_mat(enable_sparse=True, device=self.device,
+                                                                         xcd_part=xcd_part)
             self.graph = self.edge_index
         else:
             ei, ew = dataset.get_norm_adj_mat(enable_sparse=config["enable_sparse"])
             self.edge_index, self.edge_weight = ei.to(self.device), ew.to(self.device)
             self.graph = GraphHandle.from_interactions(dataset.uid, dataset.iid, self.n_users, self.n_items,
-                                                       device=self.device)
+                                                       device=self.device, xcd_part=xcd_part)
 
 
 class LightGCN(GeneralGraphRecommender):

@@ -209,6 +209,19 @@ def test_community_partition_changes_only_the_launch_plan(rbg, cuda, n_parts):
     m0, _ = rbg.ops.lightgcn_forward_raw(h0, uw, iw, 3)
     m1, _ = rbg.ops.lightgcn_forward_raw(h1, uw, iw, 3)
     assert torch.equal(m0, m1)
+    # communities rediscovered under scrambled ids ("auto") and passed through the model config
+    if n_parts == 8:
+        rs = np.random.default_rng(2)
+        pu = np.concatenate([[0], rs.permutation(nu - 1) + 1])
+        pi = np.concatenate([[0], rs.permutation(ni - 1) + 1])
+        su, si = pu[uid], pi[iid]
+        ds = rbg.InteractionDataset(su, si, nu, ni)
+        torch.manual_seed(1)
+        ma = rbg.LightGCN({"device": str(cuda), "enable_sparse": True, "xcd_partition": "auto", "n_layers": 2}, ds)
+        torch.manual_seed(1)
+        mb = rbg.LightGCN({"device": str(cuda), "enable_sparse": True, "n_layers": 2}, ds)
+        with torch.no_grad():
+            assert all(torch.equal(a, b) for a, b in zip(ma.forward(), mb.forward()))
     # an unbalanced / partly empty partition is still correct
     lop = np.zeros(nu + ni, dtype=np.int32)
     lop[: (nu + ni) // 10] = 1
