@@ -709,6 +709,28 @@ def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
     assert set(i[0, :3].tolist()) == {1, 2, 3} and torch.all(i[0, 3:] == -1) and torch.all(torch.isinf(v[0, 3:]))
 
 
+def test_no_device_memory_leak(rbg, cuda, golden):
+    """Graph handles (both builders, views, partitioned, transposes) free everything they allocate."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    x = randn((nu + ni, 64), 3, cuda)
+
+    def cycle(n):
+        for i in range(n):
+            flags = rbg._lib.GRAPH_BUILD_ON_HOST if i % 2 else 0
+            h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, flags=flags,
+                                                  keep=g["sgl_keep"] if i % 3 == 0 else None)
+            rbg.ops.spmm_raw(h, x)
+            h.destroy()
+        torch.cuda.synchronize()
+
+    cycle(5)
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(60)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"leaked {(free0 - free1) >> 20} MiB over 60 create/destroy cycles"
+
+
 # ---- full-size properties (BASELINE.json config #2 shape) -----------------------------------
 
 @pytest.fixture(scope="module")
