@@ -142,8 +142,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.transport == "nccl":
             dist.init_process_group("nccl", device_id=dev)
+            gloo_group = dist.new_group(backend="gloo")  # control plane + fallback transport
         else:
             dist.init_process_group("gloo")
+            gloo_group = None
 
     import recbole_gnn_amd as rbg
     from recbole_gnn_amd import sharded as sh
@@ -186,8 +188,24 @@ def main():
                                                 p_in=args.p_in)
         owner = sh.striped_partition(nu_g, ni_g, world)
         plan = sh.build_plans(uid, iid, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
-        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport=args.transport)
+        transport = args.transport
+        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport=transport)
         e0 = xavier(plan.n_owned, d, gen).to(dev)
+        if transport == "nccl":
+            # rehearse one exchange; if RCCL cannot run it on this node, every rank falls back to the host-staged
+            # gloo transport (slow, but the run still reports a labelled number instead of crashing)
+            ok = torch.ones(1, device=dev)
+            try:
+                prop.forward(e0, 1)
+                torch.cuda.synchronize()
+            except Exception as ex:  # noqa: BLE001
+                ok.zero_()
+                extra["nccl_error"] = str(ex)[:300]
+            votes = [torch.zeros(1) for _ in range(world)]
+            dist.all_gather(votes, ok.cpu(), group=gloo_group)
+            if min(float(v) for v in votes) == 0.0:
+                transport = "staged"
+                prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), group=gloo_group, transport="staged")
 
         def step():
             prop.forward(e0, k_layers)
@@ -203,7 +221,7 @@ def main():
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=gloo_group)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -213,13 +231,13 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=gloo_group)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=dev if args.transport == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo_group)
         elapsed, ev_ms = float(t[0]), float(t[1])
 
     if world > 1:
@@ -229,7 +247,7 @@ def main():
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
-            dist.barrier()
+            dist.barrier(group=gloo_group)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(iters):
@@ -242,7 +260,7 @@ def main():
         y_buf = torch.empty((plan.n_owned, d), device=dev)
         extra["phase_us"] = {
             "halo_exchange(pack + all_to_all)": phase_us(
-                lambda: (prop._exchange_nccl if args.transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
+                lambda: (prop._exchange_nccl if transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
             "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
             "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
         }
@@ -265,7 +283,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "embedding_dim": d, "n_layers": k_layers,
                        "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
-                       "sharding": "none" if world == 1 else f"node-range x{world}, transport={args.transport}"},
+                       "sharding": "none" if world == 1 else f"node-range x{world}, transport={transport}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
                          "kernel": "spmm_binned_kernel<64,8,true>", "avg_launch_us": launch_us,
