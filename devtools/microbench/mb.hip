@@ -127,3 +127,14 @@ extern "C" int mb_gather_nt(const float* tab, const int* idx, int64_t m, float* 
     }
     return (int)hipGetLastError();
 }
+
+// XCD census: which XCC does workgroup b land on?  (the SpMM pins row classes to XCDs by blockIdx % 8)
+__global__ void xcc_census_kernel(int* out) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 0xf);
+}
+extern "C" int mb_xcc_census(int* out, int blocks, void* stream) {
+    hipLaunchKernelGGL(xcc_census_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out);
+    return (int)hipGetLastError();
+}
