@@ -321,6 +321,38 @@ def test_sgl_per_layer_graphs(rbg, cuda, golden):
     close(mean, torch.cat([u_ref, i_ref]))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_graphs_widths_and_depths(rbg, cuda, seed):
+    """Randomised sweep: small graphs with duplicated interactions, masked views and isolated nodes; widths that hit
+    the binned kernels (32/64/128/256) and the generic one; depths 0..5; forward, kept layers and backward."""
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(8):
+        nu, ni = int(rng.integers(1, 50)), int(rng.integers(1, 80))
+        e = int(rng.integers(0, 600))
+        uid, iid = rng.integers(0, nu, e), rng.integers(0, ni, e)
+        keep = (rng.random(e) < 0.8).astype(np.uint8) if rng.random() < 0.5 else None
+        d = int(rng.choice([1, 3, 8, 32, 64, 100, 128, 256]))
+        k_layers = int(rng.integers(0, 6))
+        h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, keep=keep,
+                                              flags=rbg._lib.GRAPH_BUILD_ON_HOST if rng.random() < 0.3 else 0)
+        rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni, keep=keep)
+        got = h.export_csr()
+        assert all(np.array_equal(a, b) for a, b in zip(got, (rowptr, col, val)))
+        uw = randn((nu, d), seed, cuda).requires_grad_(True)
+        iw = randn((ni, d), seed + 1, cuda).requires_grad_(True)
+        ref, ref_layers = C.lightgcn_forward(rowptr, col, val, uw.detach().cpu().numpy(), iw.detach().cpu().numpy(),
+                                             k_layers, return_layers=True)
+        mean, layers = rbg.ops.lightgcn_forward_raw(h, uw.detach(), iw.detach(), k_layers, keep_layers=True)
+        close(mean, ref)
+        for k in range(k_layers):
+            close(layers[k], ref_layers[k + 1])
+        # backward: d(sum(out * w))/dE0 = mean_k(A^k) w  (A symmetric) -> the same oracle applied to w
+        w = randn((nu + ni, d), seed + 2, cuda)
+        (rbg.lightgcn_forward(h, uw, iw, k_layers) * w).sum().backward()
+        gref = C.lightgcn_forward(rowptr, col, val, w[:nu].cpu().numpy(), w[nu:].cpu().numpy(), k_layers)
+        close(torch.cat([uw.grad, iw.grad]), gref)
+
+
 # ---- models: the reference's interface ------------------------------------------------------
 
 def make_model(rbg, cls, cuda, golden, **cfg):
