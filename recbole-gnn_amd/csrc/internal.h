@@ -33,6 +33,7 @@ Tuning current_tuning();
 int spmm_unroll();
 int opt_xcd_split();
 int opt_nt_store();
+int opt_topk_sample();  // items the fused top-k pre-pass looks at
 
 // One workgroup task: a row (or one segment of a split row).
 constexpr int kMaxGroups = 8;

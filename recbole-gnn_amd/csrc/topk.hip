@@ -14,8 +14,9 @@
 // search in the user's graph row (a chain of dependent loads paid per batch, not per candidate); that raises tau.
 // A workgroup covers one 32-user tile x one chunk of item tiles; every wave hands its raw lists to a workspace.
 // Kernel 2 (topk_merge_kernel): one wavefront per user compacts all partial lists and folds them 32 at a time.
-// Two passes: a pre-pass over the first 2048 items yields tau0 = the k-th best VALID score among them, a lower bound
-// of the final k-th best, so the main pass starts selective (~k*n/2048 candidates per user instead of warm-up churn).
+// Two passes: a pre-pass over the first 8192 items (topk_prepass_kernel: per-lane running maxima, no lists) yields tau0,
+// a lower bound of the final k-th best valid score, so the main pass starts selective (~k*n/8192 candidates per user
+// instead of warm-up churn).
 // K <= 32.
 
 #include <hip/hip_runtime.h>
@@ -178,17 +179,8 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    float bfrag[32];
-    for (int64_t t = t_begin + wave; t < t_end; t += 4) {
-        const int64_t item = t * 32 + i;
-        f32x16 acc = zero;
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-            tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, bfrag);
-#pragma unroll
-            for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s], bfrag[s], acc, 0, 0, 0);
-        }
-        // filter the tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
+    // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
+    auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
         const bool item_ok = item < p.n_items && item != 0;
         RowLoop<0>::run([&](auto rc) {
             constexpr int r = decltype(rc)::value;
@@ -219,6 +211,42 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
                 __builtin_amdgcn_wave_barrier();
             }
         });
+    };
+    // The item fragment of the NEXT (tile, chunk) is in flight while the current one feeds the matrix core (two register
+    // buffers, statically chosen), as in score.hip.
+    auto load_b = [&](float (&buf)[32], const int64_t t, const int c) __attribute__((always_inline)) {
+        const int64_t item = t * 32 + i;
+        tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, buf);
+    };
+    auto mfma32 = [&](const float (&av)[32], const float (&bv)[32], f32x16 acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+        return acc;
+    };
+    float bq0[32], bq1[32];
+    const int64_t t_first = t_begin + wave;
+    if (t_first < t_end) load_b(bq0, t_first, 0);
+    if constexpr (NCHUNK == 1) {
+        for (int64_t t = t_first; t < t_end; t += 8) {  // two tiles per trip
+            const int64_t t1 = t + 4, t2 = t + 8;
+            if (t1 < t_end) load_b(bq1, t1, 0);
+            filter_tile(mfma32(a[0], bq0, zero), t * 32 + i);
+            if (t2 < t_end) load_b(bq0, t2, 0);
+            if (t1 < t_end) filter_tile(mfma32(a[0], bq1, zero), t1 * 32 + i);
+        }
+    } else {
+        for (int64_t t = t_first; t < t_end; t += 4) {
+            f32x16 acc = zero;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; c += 2) {
+                load_b(bq1, t, c + 1);
+                acc = mfma32(a[c], bq0, acc);
+                if (c + 2 < NCHUNK) load_b(bq0, t, c + 2);
+                else if (t + 4 < t_end) load_b(bq0, t + 4, 0);
+                acc = mfma32(a[c + 1], bq1, acc);
+            }
+            filter_tile(acc, t * 32 + i);
+        }
     }
     // hand the lists over: raw candidates (at most kListStride per user; longer lists are pruned first)
     const int lists = p.n_chunks * 4;
@@ -236,6 +264,144 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
         }
         if (lane == 0) p.w_cnt[b * lists + my_list] = n;
     }
+}
+
+// Pre-pass: a lower bound tau0 of every user's k-th best VALID score from the first `tile_hi` item tiles, with no
+// lists at all.  Each lane keeps, per accumulator row, the running maximum (and its item) over the tiles it sees:
+// for one user that is 32 "group maxima" (group = items sharing a lane index), all distinct items.  The k-th largest
+// group maximum that is neither PAD nor a history item is <= the k-th best valid score overall, and with k << 32 it is
+// nearly as tight as the exact k-th best of the sample.  A workgroup covers one 32-user tile x one split of the sample;
+// its 8 waves share the tiles and combine through LDS; topk_tau_kernel folds the splits and selects.
+constexpr int kPreWaves = 8;
+template <int NCHUNK, bool VEC>
+__global__ __launch_bounds__(64 * kPreWaves) void topk_prepass_kernel(const TopkParams p, float *__restrict__ g_val,
+                                                                       int32_t *__restrict__ g_idx) {
+    __shared__ float s_v[kPreWaves][16][64];
+    __shared__ int s_i[kPreWaves][16][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.y * 32;
+    const int64_t bi = b0 + i;
+    const int64_t my_user = bi < p.B ? p.users[bi] : -1;
+    float a[NCHUNK][32];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+        tk_load_run<VEC>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+    float best_v[16];
+    int best_i[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        best_v[r] = kNegInf;
+        best_i[r] = 0x7fffffff;
+    }
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto keep_max = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
+        const bool item_ok = item < p.n_items && item != 0;
+        RowLoop<0>::run([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            const float sc = acc[r];
+            if (item_ok && sc > best_v[r]) {
+                best_v[r] = sc;
+                best_i[r] = (int)item;
+            }
+        });
+    };
+    auto load_b = [&](float (&buf)[32], const int64_t t, const int c) __attribute__((always_inline)) {
+        const int64_t item = t * 32 + i;
+        tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, buf);
+    };
+    auto mfma32 = [&](const float (&av)[32], const float (&bv)[32], f32x16 acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+        return acc;
+    };
+    float bq0[32], bq1[32];
+    const int64_t t_lo = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
+    const int64_t t_end = (t_lo + p.tiles_per_chunk < p.tile_hi) ? t_lo + p.tiles_per_chunk : p.tile_hi;
+    const int64_t t_first = t_lo + wave;
+    constexpr int W = kPreWaves;
+    if (t_first < t_end) load_b(bq0, t_first, 0);
+    if constexpr (NCHUNK == 1) {
+        for (int64_t t = t_first; t < t_end; t += 2 * W) {
+            const int64_t t1 = t + W, t2 = t + 2 * W;
+            if (t1 < t_end) load_b(bq1, t1, 0);
+            keep_max(mfma32(a[0], bq0, zero), t * 32 + i);
+            if (t2 < t_end) load_b(bq0, t2, 0);
+            if (t1 < t_end) keep_max(mfma32(a[0], bq1, zero), t1 * 32 + i);
+        }
+    } else {
+        for (int64_t t = t_first; t < t_end; t += W) {
+            f32x16 acc = zero;
+#pragma unroll
+            for (int c = 0; c < NCHUNK; c += 2) {
+                load_b(bq1, t, c + 1);
+                acc = mfma32(a[c], bq0, acc);
+                if (c + 2 < NCHUNK) load_b(bq0, t, c + 2);
+                else if (t + W < t_end) load_b(bq0, t + W, 0);
+                acc = mfma32(a[c + 1], bq1, acc);
+            }
+            keep_max(acc, t * 32 + i);
+        }
+    }
+    RowLoop<0>::run([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        s_v[wave][r][lane] = best_v[r];
+        s_i[wave][r][lane] = best_i[r];
+    });
+    __syncthreads();
+    // each wave combines 32 / kPreWaves users; user slot lu lives in accumulator row r = (lu&3) + 4(lu>>3), half (lu>>2)&1
+    constexpr int kPer = 32 / kPreWaves;
+    for (int q = 0; q < kPer; ++q) {
+        const int lu = wave * kPer + q;
+        const int64_t b = b0 + lu;
+        if (b >= p.B) break;
+        const int r = (lu & 3) + 4 * (lu >> 3), hh = (lu >> 2) & 1;
+        if (lane < 32) {
+            float v = kNegInf;
+            int idx = 0x7fffffff;
+            for (int wv = 0; wv < kPreWaves; ++wv) {
+                const float ov = s_v[wv][r][hh * 32 + lane];
+                const int oi = s_i[wv][r][hh * 32 + lane];
+                if (better(ov, oi, v, idx)) {
+                    v = ov;
+                    idx = oi;
+                }
+            }
+            const int64_t off = (b * p.n_chunks + blockIdx.x) * 32 + lane;
+            g_val[off] = v;
+            g_idx[off] = idx;
+        }
+    }
+}
+
+// tau0[b] = the k-th largest group maximum of user b that is not a history item (-inf if fewer than k).  The maxima of
+// the same lane slot in different splits are different items, but only the slot maximum is needed for a valid bound
+// with 32 candidates; one wavefront per user.
+__global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__ g_val, const int32_t *__restrict__ g_idx,
+                                                       const int64_t *__restrict__ users, const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col, int64_t n_users, int64_t B, int splits,
+                                                       int k, float *__restrict__ tau_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float v = kNegInf;
+    int idx = 0x7fffffff;
+    if (lane < 32) {
+        for (int sp = 0; sp < splits; ++sp) {
+            const float ov = g_val[(b * splits + sp) * 32 + lane];
+            const int oi = g_idx[(b * splits + sp) * 32 + lane];
+            if (better(ov, oi, v, idx)) {
+                v = ov;
+                idx = oi;
+            }
+        }
+    }
+    wave_sort_desc(v, idx, lane);
+    const bool ok = lane < 32 && idx != 0x7fffffff && !in_history(rowptr, col, n_users, users[b], idx);
+    const unsigned long long m = __ballot(ok);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0 && __popcll(m) < k) tau_out[b] = kNegInf;
+    if (ok && rank == k - 1) tau_out[b] = v;
 }
 
 // One wavefront per batch user.  Stage A compacts the raw candidates of `lists` partial lists into LDS; stage B takes
@@ -317,8 +483,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
-constexpr int64_t kSampleTiles = 64;  // pre-pass over the first 2048 items
-
 static void topk_geometry(int64_t B, int64_t n_tiles, int64_t min_tiles_per_chunk, int &tiles_per_chunk, int &n_chunks) {
     const int64_t user_tiles = (B + 31) / 32;
     int64_t want = std::max<int64_t>(1, 2048 / std::max<int64_t>(user_tiles, 1));  // aim at ~2048 workgroups
@@ -336,26 +500,45 @@ static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s)
         hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false>), grid, dim3(256), 0, s, p);
 }
 
+template <int NCHUNK>
+static void launch_prepass(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
+    if (vec)
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true>), grid, dim3(64 * kPreWaves), 0, s, p, gv, gi);
+    else
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false>), grid, dim3(64 * kPreWaves), 0, s, p, gv, gi);
+}
+
+static void launch_prepass_d(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
+    if (p.d <= 64) launch_prepass<1>(p, vec, grid, gv, gi, s);
+    else if (p.d <= 128) launch_prepass<2>(p, vec, grid, gv, gi, s);
+    else launch_prepass<4>(p, vec, grid, gv, gi, s);
+}
+
 static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
     if (p.d <= 64) launch_topk<1>(p, vec, grid, s);
     else if (p.d <= 128) launch_topk<2>(p, vec, grid, s);
     else launch_topk<4>(p, vec, grid, s);
 }
 
-// workspace: main lists (val, idx: B*nc*4*32 each; cnt: B*nc*4), sample lists (same with nc_s), tau0 [B]
+// workspace: main lists (val, idx: B*nc*4*32 each; cnt: B*nc*4), pre-pass group maxima (val, idx: B*max_splits*32 each),
+// tau0 [B].  Independent of the "topk_sample" option.
 struct TopkLayout {
-    int tpc, nc, tpc_s, nc_s;
-    int64_t n_tiles, sample_tiles, main_lists, sample_lists, bytes;
+    int tpc, nc, max_splits, splits, tpc_s;
+    int64_t n_tiles, sample_tiles, main_lists, bytes;
 };
 static TopkLayout topk_layout(int64_t B, int64_t n_items) {
     TopkLayout L{};
     L.n_tiles = (n_items + 31) / 32;
-    L.sample_tiles = std::min<int64_t>(kSampleTiles, L.n_tiles);
+    L.sample_tiles = std::min<int64_t>(opt_topk_sample() / 32, L.n_tiles);
     topk_geometry(B, L.n_tiles, 8, L.tpc, L.nc);
-    topk_geometry(B, L.sample_tiles, 8, L.tpc_s, L.nc_s);
     L.main_lists = B * (int64_t)L.nc * 4;
-    L.sample_lists = B * (int64_t)L.nc_s * 4;
-    L.bytes = (L.main_lists + L.sample_lists) * (kListStride * 8 + 4) + B * 4 + 256;
+    // the pre-pass splits its sample over up to 16 workgroups per user tile (aim: ~512 workgroups, >= one tile per wave)
+    const int64_t user_tiles = (B + 31) / 32;
+    L.max_splits = (int)std::min<int64_t>(16, std::max<int64_t>(1, 512 / std::max<int64_t>(user_tiles, 1)));
+    const int64_t want = std::min<int64_t>(L.max_splits, std::max<int64_t>(1, L.sample_tiles / kPreWaves));
+    L.tpc_s = (int)((L.sample_tiles + want - 1) / want);
+    L.splits = (int)((L.sample_tiles + L.tpc_s - 1) / std::max(L.tpc_s, 1));
+    L.bytes = L.main_lists * (kListStride * 8 + 4) + B * (int64_t)L.max_splits * 32 * 8 + B * 4 + 256;
     return L;
 }
 
@@ -394,10 +577,9 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     float *main_val = reinterpret_cast<float *>(w);
     int32_t *main_idx = reinterpret_cast<int32_t *>(main_val + L.main_lists * kListStride);
     int32_t *main_cnt = main_idx + L.main_lists * kListStride;
-    float *samp_val = reinterpret_cast<float *>(main_cnt + L.main_lists);
-    int32_t *samp_idx = reinterpret_cast<int32_t *>(samp_val + L.sample_lists * kListStride);
-    int32_t *samp_cnt = samp_idx + L.sample_lists * kListStride;
-    float *tau0 = reinterpret_cast<float *>(samp_cnt + L.sample_lists);
+    float *pre_val = reinterpret_cast<float *>(main_cnt + L.main_lists);
+    int32_t *pre_idx = reinterpret_cast<int32_t *>(pre_val + B * (int64_t)L.max_splits * 32);
+    float *tau0 = reinterpret_cast<float *>(pre_idx + B * (int64_t)L.max_splits * 32);
     const int32_t *rp = history ? history->d_rowptr : nullptr;
     const int32_t *cl = history ? history->d_col : nullptr;
     TopkParams p{};
@@ -415,21 +597,17 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     const unsigned merge_blocks = (unsigned)((B + 3) / 4);
     const bool prepass = L.n_tiles > 2 * L.sample_tiles;  // small item sets: one pass
     if (prepass) {
-        // pass 1: the first 2048 items, unmasked best 32 per user -> tau0[b] = its k-th valid score (a lower bound)
-        p.k = 32;
-        p.filter_history = 0;
-        p.tiles_per_chunk = L.tpc_s;
-        p.n_chunks = L.nc_s;
+        // pass 1: group maxima over the first "topk_sample" (default 8192) items -> tau0[b], a lower bound of the user's k-th best valid score
+        p.k = k;
+        p.filter_history = 1;
         p.tile_lo = 0;
         p.tile_hi = L.sample_tiles;
-        p.tau0 = nullptr;
-        p.w_val = samp_val;
-        p.w_idx = samp_idx;
-        p.w_cnt = samp_cnt;
-        launch_topk_d(p, vec, dim3((unsigned)L.nc_s, (unsigned)user_tiles), s);
+        p.tiles_per_chunk = L.tpc_s;
+        p.n_chunks = L.splits;
+        launch_prepass_d(p, vec, dim3((unsigned)L.splits, (unsigned)user_tiles), pre_val, pre_idx, s);
         RBG_HIP(hipGetLastError());
-        hipLaunchKernelGGL(topk_merge_kernel, dim3(merge_blocks), dim3(256), 0, s, samp_val, samp_idx, samp_cnt, users, rp, cl,
-                           n_users, B, L.nc_s * 4, k, out_val, out_idx, tau0);
+        hipLaunchKernelGGL(topk_tau_kernel, dim3(merge_blocks), dim3(256), 0, s, pre_val, pre_idx, users, rp, cl, n_users, B,
+                           L.splits, k, tau0);
         RBG_HIP(hipGetLastError());
     }
     // pass 2: every item, thresholds seeded with tau0
