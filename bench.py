@@ -93,6 +93,32 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     ex = {"spmm_single_layer_us": time_us(lambda: rbg.ops.spmm_raw(graph, x, out=y))}
     b_layer, _ = rbg.synth.algorithmic_bytes(n, 2 * len(uid), d, k_layers)
     ex["spmm_single_layer_roofline_frac"] = b_layer / (ex["spmm_single_layer_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    # the headline loop re-uses one buffer set (~110 MB: it lives in the 256 MB Infinity Cache).  Rotating
+    # over enough independent sets (own graph handle, E0, layer and output buffers) that the footprint exceeds the cache
+    # gives the HBM-resident figure.
+    set_mb = (4 * (n + 1) + 8 * graph.nnz + 16 * n + (k_layers + 3) * n * d * 4) / 1e6  # CSR + row descriptors + E0, layers, out
+    n_sets = max(2, int(np.ceil(320.0 / set_mb)))
+    sets = []
+    for _ in range(n_sets):
+        sets.append((rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev), torch.randn(nu, d, device=dev) * 0.1,
+                     torch.randn(ni, d, device=dev) * 0.1, torch.empty(n, d, device=dev),
+                     torch.empty(max(k_layers, 1), n, d, device=dev)))
+    turn = [0]
+
+    def rotated():
+        gq, uq, iq, oq, lq = sets[turn[0] % n_sets]
+        turn[0] += 1
+        rbg.ops.lightgcn_forward_raw(gq, uq, iq, k_layers, out=oq, layers=lq)
+
+    def hot():
+        gq, uq, iq, oq, lq = sets[0]
+        rbg.ops.lightgcn_forward_raw(gq, uq, iq, k_layers, out=oq, layers=lq)
+
+    ex["propagation_hot_us"] = time_us(hot, iters=100)
+    ex["propagation_rotated_us"] = time_us(rotated, iters=100)
+    ex["propagation_rotated_sets"] = n_sets
+    ex["propagation_rotated_footprint_MB"] = round(n_sets * set_mb, 1)
+    del sets
     ds = rbg.InteractionDataset(uid, iid, nu, ni)
     model = rbg.LightGCN({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers,
                           "require_pow": True}, ds)
