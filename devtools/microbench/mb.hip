@@ -138,3 +138,38 @@ extern "C" int mb_xcc_census(int* out, int blocks, void* stream) {
     hipLaunchKernelGGL(xcc_census_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out);
     return (int)hipGetLastError();
 }
+
+// fp32 matrix-core issue rate: every wave runs `iters` x 32 v_mfma_f32_32x32x2_f32 on CHAINS independent accumulators
+// (CHAINS = 1: each MFMA depends on the previous one, as in a k-ordered dot-product tile).
+typedef float mb_f32x16 __attribute__((ext_vector_type(16)));
+template <int CHAINS>
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float* out, int iters, float seed) {
+    mb_f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float a = seed + threadIdx.x * 1e-3f, b = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 32 / CHAINS; ++s)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+        a += 1e-6f;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[c][r];
+    if (t == 12345.678f) out[0] = t;
+}
+extern "C" int mb_mfma_rate(float* out, int blocks, int threads, int iters, int chains, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (chains) {
+        case 1: hipLaunchKernelGGL((mfma_rate_kernel<1>), dim3(blocks), dim3(threads), 0, s, out, iters, 1.0f); break;
+        case 2: hipLaunchKernelGGL((mfma_rate_kernel<2>), dim3(blocks), dim3(threads), 0, s, out, iters, 1.0f); break;
+        default: hipLaunchKernelGGL((mfma_rate_kernel<4>), dim3(blocks), dim3(threads), 0, s, out, iters, 1.0f); break;
+    }
+    return (int)hipGetLastError();
+}

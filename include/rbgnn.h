@@ -228,6 +228,27 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
                       float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                       void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * contrastive (InfoNCE) denominator without the [B, n] matrix
+ * ------------------------------------------------------------------------------------------- */
+
+/* lse[b] = log sum_{j<n} exp(scale * <Q[b,:], C[j,:]>),  computed as log sum exp(scale*x - shift) + shift.
+ * Replaces sgl.py:195-198 / :204-207:  v2 = u_emd1.matmul(all_user2.T); v2 = sum(exp(v2 / ssl_tau), dim=1)
+ * with Q = the normalised batch rows, C = the normalised table, scale = 1 / ssl_tau; the reference takes no shift
+ * (shift = 0 reproduces it exactly, incl. overflow at tiny tau); for unit rows shift = scale keeps every term <= 1.
+ * Exact-fp32 MFMA; the matrix is never written.  d <= 128.  `workspace`: rbg_lse_rows_workspace(B, n, d) bytes. */
+int rbg_lse_rows_workspace(int64_t B, int64_t n, int d, int64_t *bytes);
+int rbg_lse_rows_f32(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale,
+                     float shift, float *lse, void *workspace, void *stream);
+
+/* Autograd of the above (what torch derives for sgl.py:195-198): with P[b][j] = exp(scale*x[b][j] - lse[b]),
+ *   grad_Q[b,:] = grad_lse[b] * scale * sum_j P[b][j] C[j,:]      [B, d] contiguous (may be NULL)
+ *   grad_C[j,:] = scale * sum_b grad_lse[b] P[b][j] Q[b,:]        [n, d] contiguous (may be NULL)
+ * Tiles are recomputed; partial sums are combined in a fixed order (no atomics: bit-reproducible). */
+int rbg_lse_rows_backward_f32(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d,
+                              float scale, float shift, const float *lse, const float *grad_lse, float *grad_Q,
+                              float *grad_C, void *workspace, void *stream);
+
 /* Full-sort evaluation of one batch without the [B, n_items] score matrix.
  * Replaces full_sort_predict (lightgcn.py:123-133) + RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
  *   scores = user_all[users] @ item_all.T;  scores[:, 0] = -inf;  scores[history_index] = -inf;  topk(scores, k)

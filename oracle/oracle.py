@@ -222,6 +222,27 @@ def ngcf_forward(user_w, item_w, conv, layer_params, slope=0.2):
     return torch.split(cat, [user_w.shape[0], item_w.shape[0]])
 
 
+def calc_ssl_loss(user_list, pos_item_list, user_sub1, user_sub2, item_sub1, item_sub2, ssl_tau, ssl_weight):
+    """SGL.calc_ssl_loss — recbole_gnn/model/general_recommender/sgl.py:176-209, statement by statement
+    (normalize; v1 = exp(<a,p>/tau); v2 = sum_j exp(<a,c_j>/tau); -sum log(v1/v2); users then items)."""
+    nrm = torch.nn.functional.normalize
+    u1, u2, all_u2 = nrm(user_sub1[user_list], dim=1), nrm(user_sub2[user_list], dim=1), nrm(user_sub2, dim=1)
+    v1 = torch.exp(torch.sum(u1 * u2, dim=1) / ssl_tau)
+    v2 = torch.sum(torch.exp(u1.matmul(all_u2.T) / ssl_tau), dim=1)
+    ssl_user = -torch.sum(torch.log(v1 / v2))
+    i1, i2, all_i2 = nrm(item_sub1[pos_item_list], dim=1), nrm(item_sub2[pos_item_list], dim=1), nrm(item_sub2, dim=1)
+    v3 = torch.exp(torch.sum(i1 * i2, dim=1) / ssl_tau)
+    v4 = torch.sum(torch.exp(i1.matmul(all_i2.T) / ssl_tau), dim=1)
+    ssl_item = -torch.sum(torch.log(v3 / v4))
+    return (ssl_item + ssl_user) * ssl_weight
+
+
+def lse_rows(q, c, scale):
+    """log of the InfoNCE denominator (sgl.py:195-198): log sum_j exp(scale * <q_b, c_j>), float64."""
+    x = torch.as_tensor(q, dtype=torch.float64) @ torch.as_tensor(c, dtype=torch.float64).T * scale
+    return torch.log(torch.exp(x).sum(dim=1))
+
+
 # --------------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md §8(d)) — mirrored by the product's own generator; kept here so the
 # oracle side of a test never imports product code to make its inputs.

@@ -1,0 +1,420 @@
+// lse.hip — row-wise log-sum-exp of a scaled dot-product matrix that is never written:
+//   lse[b] = log sum_j exp(scale * <Q_b, C_j>)          and its backward (dQ, dC).
+//
+// Replaces the contrastive denominator of SGL's InfoNCE:
+//   v2 = u_emd1.matmul(all_user2.T);  v2 = torch.sum(torch.exp(v2 / self.ssl_tau), dim=1)
+//   recbole_gnn/model/general_recommender/sgl.py:195-198 (users), :204-207 (items)
+// which materialises [B, n] three times forward (matmul, /tau, exp) and again in autograd — 336 MB each at
+// B = 2048 x 40 982 items, 82 GB at BASELINE config #5 (10 M users).  Here a 32x32 tile of the product lives only in
+// the accumulator registers of one wavefront (exact-fp32 v_mfma_f32_32x32x2_f32, as score.hip).
+//
+// One kernel serves the forward and both gradients.  A wave OWNS 32 rows of one operand ("own", in the MFMA B slot, so
+// the tile's column = lane&31 = own row) and LOOPS over 32-row tiles of the other ("oth", A slot, tile row =
+// rowmap(reg, lane>>5)):
+//   forward : own = Q, oth = C chunked over blockIdx.x;  z[b] += sum_tile exp2(x*s2 - shift2)      -> partial sums
+//   dQ      : own = Q, oth = C;   dQ[b]  = sum_j W[b][j] C[j]      W = exp2(..) * coef[b],  coef = g*scale*exp(shift-lse)
+//   dC      : own = C, oth = Q;   dC[j]  = sum_b W[b][j] Q[b]
+// For the gradients the weight tile is consumed where it is: lane (own = l&31, h) holds W for 16 oth rows rowmap(s,h),
+// which is exactly the A-slot layout of a second 32x32x2 MFMA whose k index runs over oth rows; its B slot (oth rows x
+// 32 feature columns) is read from a wave-private LDS copy of the oth tile (row stride d+1: conflict-free both ways).
+// Nothing is accumulated with atomics: chunk partials are summed in a fixed order by small reduce kernels.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "internal.h"
+
+namespace rbg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct LseParams {
+    const float *own;
+    int64_t ld_own, n_own;
+    const float *oth;
+    int64_t ld_oth, n_oth;
+    int d;
+    float s2, shift2;       // weight = exp2(x * s2 - shift2)
+    const float *coef_own;  // [n_own] or NULL (gradients)
+    const float *coef_oth;  // [n_oth] or NULL
+    float *out;             // forward: [n_chunks][n_own]; gradients: [n_chunks][n_own][d]
+    int tiles_per_chunk, n_chunks;
+    int64_t own_blocks, total_blocks, blocks_per_xcd;  // workgroup j = chunk * own_blocks + own_block, j < total_blocks
+};
+
+template <int R>
+struct LseRows {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, R>{});
+        LseRows<R + 1>::run(f);
+    }
+};
+template <>
+struct LseRows<16> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+// 32 floats of a row starting at k0 (zero past d / for an out-of-range row)
+template <bool VEC>
+__device__ __forceinline__ void lse_load_run(const float *p, bool ok, int k0, int d, float (&r)[32]) {
+    if (VEC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
+            r[4 * q + 0] = v.x;
+            r[4 * q + 1] = v.y;
+            r[4 * q + 2] = v.z;
+            r[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) r[s] = (ok && k0 + s < d) ? p[k0 + s] : 0.f;
+    }
+}
+
+constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// NC = ceil(d / 64) in {1, 2}.  GRAD = false: forward partial sums; true: gradient of the own side.
+// A workgroup owns 128 own rows (32 per wave, in registers as the MFMA B fragments) and walks the oth tiles of one
+// chunk; every oth tile is fetched ONCE per workgroup into a double-buffered LDS tile (row stride 64 NC + 4 floats:
+// 16-byte aligned rows, full-rate b128 reads of the A fragments, conflict-free b32 reads of the second product's B
+// fragments).  Workgroups are numbered so that the ones an XCD runs back to back share a chunk: the chunk's oth rows
+// stay in that XCD's L2 and cross the fabric once.
+template <int NC, bool GRAD, bool VEC>
+__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? 3 : 1) : (NC == 1 ? 4 : 2))) void lse_tile_kernel(const LseParams p) {
+    constexpr int LD = NC * 64 + 4;
+    __shared__ __attribute__((aligned(16))) float s_oth[2][32][LD];
+    __shared__ float s_coef[2][32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t j = (int64_t)(blockIdx.x & 7) * p.blocks_per_xcd + (blockIdx.x >> 3);
+    if (j >= p.total_blocks) return;  // whole workgroup
+    const int64_t chunk = j / p.own_blocks, ob = j - chunk * p.own_blocks;
+    const int64_t own0 = (ob * 4 + wave) * 32;
+    const bool wave_live = own0 < p.n_own;  // an idle wave still takes part in the tile loads and barriers
+    const int64_t own_row = own0 + i;
+    const bool own_ok = own_row < p.n_own;
+    float bo[NC][32];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lse_load_run<VEC>(p.own + own_row * p.ld_own, own_ok, c * 64 + h * 32, p.d, bo[c]);
+    const float c_own = (GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float zsum = 0.f;
+    f32x16 g[GRAD ? NC * 2 : 1];
+#pragma unroll
+    for (int q = 0; q < (GRAD ? NC * 2 : 1); ++q) g[q] = zero;
+
+    const int64_t n_tiles = (p.n_oth + 31) / 32;
+    const int64_t t0 = chunk * p.tiles_per_chunk;
+    const int64_t t1 = (t0 + p.tiles_per_chunk < n_tiles) ? t0 + p.tiles_per_chunk : n_tiles;
+
+    // cooperative tile fetch: 32 rows x NC*16 float4 slots, NC*2 slots per thread
+    float4 stage[NC * 2];
+    float stage_coef = 0.f;
+    auto fetch = [&](const int64_t t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NC * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NC * 16), c4 = (f % (NC * 16)) * 4;
+            const int64_t r = t * 32 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < p.n_oth) {
+                const float *src = p.oth + r * p.ld_oth + c4;
+                if (VEC) {
+                    if (c4 < p.d) v = *reinterpret_cast<const float4 *>(src);
+                } else {
+                    if (c4 + 0 < p.d) v.x = src[0];
+                    if (c4 + 1 < p.d) v.y = src[1];
+                    if (c4 + 2 < p.d) v.z = src[2];
+                    if (c4 + 3 < p.d) v.w = src[3];
+                }
+            }
+            stage[k] = v;
+        }
+        if (GRAD && p.coef_oth && tid < 32) stage_coef = (t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] : 0.f;
+    };
+    auto publish = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NC * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NC * 16), c4 = (f % (NC * 16)) * 4;
+            *reinterpret_cast<float4 *>(&s_oth[buf][row][c4]) = stage[k];
+        }
+        if (GRAD && p.coef_oth && tid < 32) s_coef[buf][tid] = stage_coef;
+    };
+    auto compute = [&](const int buf, const int64_t t) __attribute__((always_inline)) {
+        f32x16 x = zero;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {  // lane (i, h) walks k = 64c + 32h + s of oth row i, as the own fragment does
+                const float4 a = *reinterpret_cast<const float4 *>(&s_oth[buf][i][c * 64 + h * 32 + s4 * 4]);
+                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bo[c][s4 * 4 + 0], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bo[c][s4 * 4 + 1], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bo[c][s4 * 4 + 2], x, 0, 0, 0);
+                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bo[c][s4 * 4 + 3], x, 0, 0, 0);
+            }
+        // x[r] = <oth row t*32 + rowmap(r,h), own row own0 + i>
+        const int64_t left = p.n_oth - t * 32;  // oth rows of this tile that exist
+        if constexpr (!GRAD) {
+            LseRows<0>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float e = __builtin_amdgcn_exp2f(x[r] * p.s2 - p.shift2);
+                zsum += (lse_rowmap(r, h) < left) ? e : 0.f;
+            });
+        } else {
+            float w[16];
+            LseRows<0>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int o = lse_rowmap(r, h);
+                float e = __builtin_amdgcn_exp2f(x[r] * p.s2 - p.shift2) * c_own;
+                if (p.coef_oth) e *= s_coef[buf][o];
+                w[r] = (o < left) ? e : 0.f;
+            });
+#pragma unroll
+            for (int q = 0; q < NC * 2; ++q) {
+                LseRows<0>::run([&](auto rc) {
+                    constexpr int s = decltype(rc)::value;
+                    const float bv = s_oth[buf][lse_rowmap(s, h)][q * 32 + i];
+                    g[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], bv, g[q], 0, 0, 0);
+                });
+            }
+        }
+    };
+    if (t0 < t1) {
+        fetch(t0);
+        publish(0);
+    }
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const int buf = (int)(t - t0) & 1;
+        if (t + 1 < t1) fetch(t + 1);  // in flight while this tile feeds the matrix core
+        if (wave_live) compute(buf, t);
+        if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    if (!wave_live) return;
+    if constexpr (!GRAD) {
+        zsum += __shfl_xor(zsum, 32);
+        if (h == 0 && own_ok) p.out[chunk * p.n_own + own_row] = zsum;
+    } else {
+        // g[q][r]: own row own0 + rowmap(r,h), feature column q*32 + i
+        float *base = p.out + chunk * p.n_own * p.d;
+#pragma unroll
+        for (int q = 0; q < NC * 2; ++q) {
+            const int col = q * 32 + i;
+            LseRows<0>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int64_t row = own0 + lse_rowmap(r, h);
+                if (row < p.n_own && col < p.d) base[row * p.d + col] = g[q][r];
+            });
+        }
+    }
+}
+
+// lse[b] = log(sum_c part[c][b]) + shift
+__global__ void lse_finish_kernel(const float *__restrict__ part, int n_chunks, int64_t B, float shift, float *__restrict__ lse) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float z = 0.f;
+    for (int c = 0; c < n_chunks; ++c) z += part[(int64_t)c * B + b];
+    lse[b] = logf(z) + shift;
+}
+
+// coef[b] = g[b] * scale * exp(shift - lse[b])
+__global__ void lse_coef_kernel(const float *__restrict__ g, const float *__restrict__ lse, int64_t B, float scale, float shift,
+                                float *__restrict__ coef) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) coef[b] = g[b] * scale * expf(shift - lse[b]);
+}
+
+// out[x] = sum_c part[c * len + x], fixed order
+__global__ void lse_reduce_kernel(const float *__restrict__ part, int n_chunks, int64_t len, float *__restrict__ out) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= len) return;
+    float a = 0.f;
+    for (int c = 0; c < n_chunks; ++c) a += part[(int64_t)c * len + x];
+    out[x] = a;
+}
+
+// Chunking.  Measured (per-workgroup clock trace, r01): the kernel is matrix-core bound per CU, all workgroups start at
+// once and the dispatcher spreads them evenly, so the launch lasts as long as the fullest CU: ceil(blocks / 256)
+// workgroups x tiles per chunk.  832 workgroups (3.25 per CU) ran 130 us where 768 run 89 us.  Pick the chunk count
+// minimising that product, discounted when fewer than 3 waves per SIMD are left to hide the LDS/exp phases, plus the
+// cost of one partial array per chunk (`chunk_cost`, in tile units).
+static void lse_geometry(int64_t n_own, int64_t n_oth, int resident, double chunk_cost, int &tiles_per_chunk, int &n_chunks) {
+    const int64_t own_blocks = std::max<int64_t>(1, (n_own + 127) / 128), oth_tiles = std::max<int64_t>(1, (n_oth + 31) / 32);
+    const int64_t max_chunks = std::max<int64_t>(1, std::min<int64_t>(oth_tiles / 4, 64));
+    int64_t best = 1;
+    double best_cost = 1e300;
+    for (int64_t c = 1; c <= max_chunks; ++c) {
+        const int64_t per_cu = (own_blocks * c + 255) / 256, tiles = (oth_tiles + c - 1) / c;
+        const int64_t conc = std::min<int64_t>(per_cu, resident);
+        double eff = conc >= 3 ? 1.0 : (conc == 2 ? 0.85 : 0.6);
+        if (per_cu > resident && per_cu < 3 * resident) eff *= 0.8;  // a short second round runs with idle SIMDs
+        const double cost = (double)(per_cu * tiles) / eff + chunk_cost * (double)c;
+        if (cost < best_cost - 1e-9) {
+            best = c;
+            best_cost = cost;
+        }
+    }
+    tiles_per_chunk = (int)((oth_tiles + best - 1) / best);
+    n_chunks = (int)((oth_tiles + tiles_per_chunk - 1) / tiles_per_chunk);
+}
+
+struct LseLayout {
+    int tpc_f, nc_f;  // forward (own = Q)
+    int tpc_q, nc_q;  // dQ (own = Q)
+    int tpc_c, nc_c;  // dC (own = C)
+    int64_t off_coef, off_q, off_c, bytes;
+};
+static LseLayout lse_layout(int64_t B, int64_t n, int d) {
+    LseLayout L{};
+    const int res_f = d <= 64 ? 4 : 2, res_g = d <= 64 ? 3 : 1;  // resident workgroups per CU (register-limited)
+    // one partial array per chunk: own rows x d x 8 bytes (write + read) at ~5 TB/s, in units of a ~1.2 us tile
+    auto partial_cost = [&](int64_t rows) { return (double)rows * d * 8.0 / 5e6 / 1.2; };
+    lse_geometry(B, n, res_f, 0.02, L.tpc_f, L.nc_f);
+    lse_geometry(B, n, res_g, partial_cost(B), L.tpc_q, L.nc_q);
+    lse_geometry(n, B, res_g, partial_cost(n), L.tpc_c, L.nc_c);
+    auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+    L.off_coef = 0;
+    L.off_q = up(B * 4);  // forward partial sums [nc_q][B] live here too (before the gradients need the space)
+    const int64_t q_bytes = std::max<int64_t>((int64_t)L.nc_q * B * d * 4, (int64_t)L.nc_f * B * 4);
+    L.off_c = L.off_q + up(q_bytes);
+    const int64_t c_bytes = L.nc_c > 1 ? (int64_t)L.nc_c * n * d * 4 : 0;
+    L.bytes = L.off_c + up(c_bytes) + 256;
+    return L;
+}
+
+template <int NC, bool GRAD>
+static void lse_launch(LseParams p, bool vec, hipStream_t s) {
+    p.own_blocks = (p.n_own + 127) / 128;
+    p.total_blocks = p.own_blocks * p.n_chunks;
+    p.blocks_per_xcd = (p.total_blocks + 7) / 8;
+    dim3 grid((unsigned)(p.blocks_per_xcd * 8));
+    if (vec)
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, false>), grid, dim3(256), 0, s, p);
+}
+
+template <bool GRAD>
+static void lse_launch_d(const LseParams &p, bool vec, hipStream_t s) {
+    if (p.d <= 64) lse_launch<1, GRAD>(p, vec, s);
+    else lse_launch<2, GRAD>(p, vec, s);
+}
+
+static int lse_check(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d) {
+    if (B < 0 || n < 0 || d <= 0) return fail(RBG_ESHAPE, "B = %lld, n = %lld, d = %d", (long long)B, (long long)n, d);
+    if (d > 128) return fail(RBG_EUNSUPPORTED, "lse_rows: d = %d > 128", d);
+    if (ldq < d || ldc < d) return fail(RBG_ESHAPE, "row stride smaller than d");
+    if ((B && !Q) || (n && !C)) return fail(RBG_EINVAL, "NULL pointer");
+    return RBG_OK;
+}
+
+static bool lse_vec(const float *Q, int64_t ldq, const float *C, int64_t ldc, int d) {
+    return (d % 4 == 0) && (ldq % 4 == 0) && (ldc % 4 == 0) &&
+           ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(C)) & 15u) == 0;
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_lse_rows_workspace(int64_t B, int64_t n, int d, int64_t *bytes) {
+    if (!bytes || B < 0 || n < 0 || d <= 0) return fail(RBG_EINVAL, "bad argument");
+    *bytes = lse_layout(B, n, d).bytes;
+    return RBG_OK;
+}
+
+int rbg_lse_rows_f32(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale,
+                     float shift, float *lse, void *workspace, void *stream) {
+    clear_error();
+    int rc = lse_check(Q, ldq, B, C, ldc, n, d);
+    if (rc) return rc;
+    if (B == 0) return RBG_OK;
+    if (!lse || !workspace) return fail(RBG_EINVAL, "NULL pointer");
+    if (n == 0) return fail(RBG_ESHAPE, "lse_rows over an empty candidate set");
+    const LseLayout L = lse_layout(B, n, d);
+    hipStream_t s = (hipStream_t)stream;
+    float *part = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + L.off_q);
+    LseParams p{};
+    p.own = Q, p.ld_own = ldq, p.n_own = B;
+    p.oth = C, p.ld_oth = ldc, p.n_oth = n;
+    p.d = d;
+    p.s2 = scale * kLog2e;
+    p.shift2 = shift * kLog2e;
+    p.out = part;
+    p.tiles_per_chunk = L.tpc_f;
+    p.n_chunks = L.nc_f;
+    lse_launch_d<false>(p, lse_vec(Q, ldq, C, ldc, d), s);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lse_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, part, L.nc_f, B, shift, lse);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_lse_rows_backward_f32(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d,
+                              float scale, float shift, const float *lse, const float *grad_lse, float *grad_Q,
+                              float *grad_C, void *workspace, void *stream) {
+    clear_error();
+    int rc = lse_check(Q, ldq, B, C, ldc, n, d);
+    if (rc) return rc;
+    if (!workspace || (B && (!lse || !grad_lse))) return fail(RBG_EINVAL, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0 || n == 0) {
+        if (grad_Q && B) RBG_HIP(hipMemsetAsync(grad_Q, 0, (size_t)B * d * 4, s));
+        if (grad_C && n) RBG_HIP(hipMemsetAsync(grad_C, 0, (size_t)n * d * 4, s));
+        return RBG_OK;
+    }
+    const LseLayout L = lse_layout(B, n, d);
+    char *w = reinterpret_cast<char *>(workspace);
+    float *coef = reinterpret_cast<float *>(w + L.off_coef);
+    float *part_q = reinterpret_cast<float *>(w + L.off_q);
+    float *part_c = reinterpret_cast<float *>(w + L.off_c);
+    const bool vec = lse_vec(Q, ldq, C, ldc, d);
+    hipLaunchKernelGGL(lse_coef_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, grad_lse, lse, B, scale, shift, coef);
+    RBG_HIP(hipGetLastError());
+    LseParams p{};
+    p.d = d;
+    p.s2 = scale * kLog2e;
+    p.shift2 = shift * kLog2e;
+    if (grad_Q) {
+        p.own = Q, p.ld_own = ldq, p.n_own = B;
+        p.oth = C, p.ld_oth = ldc, p.n_oth = n;
+        p.coef_own = coef, p.coef_oth = nullptr;
+        p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
+        p.out = L.nc_q > 1 ? part_q : grad_Q;
+        lse_launch_d<true>(p, vec, s);
+        RBG_HIP(hipGetLastError());
+        if (L.nc_q > 1) {
+            const int64_t len = B * d;
+            hipLaunchKernelGGL(lse_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_q, L.nc_q, len, grad_Q);
+            RBG_HIP(hipGetLastError());
+        }
+    }
+    if (grad_C) {
+        p.own = C, p.ld_own = ldc, p.n_own = n;
+        p.oth = Q, p.ld_oth = ldq, p.n_oth = B;
+        p.coef_own = nullptr, p.coef_oth = coef;
+        p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
+        p.out = L.nc_c > 1 ? part_c : grad_C;
+        lse_launch_d<true>(p, vec, s);
+        RBG_HIP(hipGetLastError());
+        if (L.nc_c > 1) {
+            const int64_t len = n * d;
+            hipLaunchKernelGGL(lse_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_c, L.nc_c, len, grad_C);
+            RBG_HIP(hipGetLastError());
+        }
+    }
+    return RBG_OK;
+}
+
+}  // extern "C"

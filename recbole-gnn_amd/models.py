@@ -355,13 +355,17 @@ class SGL(GeneralGraphRecommender):
         """-sum log( exp(<a,p>/tau) / sum_j exp(<a,c_j>/tau) ) over the batch, all vectors L2-normalised first
         (one half of calc_ssl_loss, sgl.py:176-209)."""
         a, p, c = F.normalize(anchor, dim=1), F.normalize(positive, dim=1), F.normalize(candidates, dim=1)
-        pos = torch.exp((a * p).sum(dim=1) / tau)
-        tot = torch.exp(a.matmul(c.T) / tau).sum(dim=1)
-        return -torch.log(pos / tot).sum()
+        if a.shape[1] > 128:  # the fused denominator covers d <= 128; wider rows take the reference's own formula
+            pos = torch.exp((a * p).sum(dim=1) / tau)
+            tot = torch.exp(a.matmul(c.T) / tau).sum(dim=1)
+            return -torch.log(pos / tot).sum()
+        # -log(exp(s) / sum exp) = lse - s; the [B, n] matrix of sgl.py:195-198 is never written (unit rows: shift = 1/tau)
+        return (ops.lse_rows(a, c, 1.0 / tau, 1.0 / tau) - (a * p).sum(dim=1) / tau).sum()
 
     def calculate_loss(self, interaction):
         """sgl.py:211-233: BPR (sum-reduced logsigmoid form, :147-162) + reg on the ego embeddings + ssl_weight x
-        (user InfoNCE + item InfoNCE between the two augmented views).  Plain torch over three fused propagations."""
+        (user InfoNCE + item InfoNCE between the two augmented views): three fused propagations, the InfoNCE
+        denominators through ``ops.lse_rows`` (rbg_lse_rows_f32 and its backward)."""
         if self.restore_user_e is not None or self.restore_item_e is not None:
             self.restore_user_e, self.restore_item_e = None, None
         if self.sub_graph1 is None:

@@ -310,3 +310,60 @@ def full_sort_topk(history, user_all, item_all, users, k):
                                          c_vp(vals.data_ptr()), c_vp(idx.data_ptr()), c_vp(work.data_ptr()),
                                          _stream(user_all)))
     return vals, idx
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# InfoNCE denominator (sgl.py:195-198, :204-207) without the [B, n] matrix
+# ---------------------------------------------------------------------------------------------------------------------
+def _lse_workspace(b, n, d, device):
+    nbytes = _lib.c_i64()
+    check(lib.rbg_lse_rows_workspace(b, n, d, ctypes.byref(nbytes)))
+    return torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=device)
+
+
+def lse_rows_raw(q, c, scale, shift=0.0):
+    """lse[b] = log sum_j exp(scale * <q[b], c[j]>) (no autograd)."""
+    _check_dense(q, "q")
+    _check_dense(c, "c")
+    if q.shape[1] != c.shape[1]:
+        raise ValueError(f"q is [*, {q.shape[1]}] but c is [*, {c.shape[1]}]")
+    q, c = q.contiguous(), c.contiguous()
+    b, d = q.shape
+    out = torch.empty(b, dtype=torch.float32, device=q.device)
+    work = _lse_workspace(b, c.shape[0], d, q.device)
+    with torch.cuda.device(q.device):
+        check(lib.rbg_lse_rows_f32(c_vp(q.data_ptr()), d, b, c_vp(c.data_ptr()), d, c.shape[0], d, float(scale),
+                                   float(shift), c_vp(out.data_ptr()), c_vp(work.data_ptr()), _stream(q)))
+    return out
+
+
+class _LseRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, c, scale, shift):
+        q, c = q.contiguous(), c.contiguous()
+        lse = lse_rows_raw(q, c, scale, shift)
+        ctx.save_for_backward(q, c, lse)
+        ctx.scale, ctx.shift = float(scale), float(shift)
+        return lse
+
+    @staticmethod
+    def backward(ctx, grad_lse):
+        q, c, lse = ctx.saved_tensors
+        b, d = q.shape
+        n = c.shape[0]
+        grad_lse = grad_lse.contiguous().to(torch.float32)
+        gq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        work = _lse_workspace(b, n, d, q.device)
+        with torch.cuda.device(q.device):
+            check(lib.rbg_lse_rows_backward_f32(c_vp(q.data_ptr()), d, b, c_vp(c.data_ptr()), d, n, d, ctx.scale, ctx.shift,
+                                                c_vp(lse.data_ptr()), c_vp(grad_lse.data_ptr()),
+                                                c_vp(gq.data_ptr()) if gq is not None else None,
+                                                c_vp(gc.data_ptr()) if gc is not None else None,
+                                                c_vp(work.data_ptr()), _stream(q)))
+        return gq, gc, None, None
+
+
+def lse_rows(q, c, scale, shift=0.0):
+    """Differentiable ``torch.logsumexp(scale * q @ c.T, dim=1)`` that never writes the [B, n] matrix."""
+    return _LseRows.apply(q, c, float(scale), float(shift))

@@ -579,6 +579,66 @@ def test_sgl_training_loss_and_gradients(rbg, cuda, golden):
     close(model.item_embedding.weight.grad, iw.grad, tol=2e-5)
 
 
+# ---- InfoNCE denominator (sgl.py:195-198) ------------------------------------------------------
+
+@pytest.mark.parametrize("b,n,d", [(1, 1, 4), (5, 7, 8), (33, 65, 16), (64, 1000, 64), (100, 333, 100), (257, 2049, 128),
+                                   (40, 31, 3)])
+def test_lse_rows_forward_backward(rbg, cuda, b, n, d):
+    """rbg_lse_rows_f32 / _backward_f32 against float64 autograd of the reference expression
+    log(sum(exp(q @ c.T / tau), dim=1)) — ragged B, n and d (tile edges), unit and non-unit rows."""
+    gen = torch.Generator().manual_seed(b * 1000 + n + d)
+    q = torch.nn.functional.normalize(torch.randn(b, d, generator=gen), dim=1)
+    c = torch.nn.functional.normalize(torch.randn(n, d, generator=gen), dim=1)
+    w = torch.randn(b, generator=gen)
+    for scale, shift in ((5.0, 5.0), (5.0, 0.0), (2.0, 1.0)):
+        q64, c64 = q.double().requires_grad_(True), c.double().requires_grad_(True)
+        ref = O.lse_rows(q64, c64, scale)
+        (ref * w.double()).sum().backward()
+        qg, cg = q.to(cuda).requires_grad_(True), c.to(cuda).requires_grad_(True)
+        out = rbg.ops.lse_rows(qg, cg, scale, shift)
+        (out * w.to(cuda)).sum().backward()
+        close(out, ref.detach().float(), tol=1e-5)
+        close(qg.grad, q64.grad.float(), tol=1e-5)
+        close(cg.grad, c64.grad.float(), tol=1e-5)
+
+
+def test_lse_rows_batch_shape_and_determinism(rbg, cuda):
+    """SGL's training shape (B = 2048 against the Gowalla-sized item table): value and both gradients against torch's
+    own matmul/exp/sum on the GPU, and bit-identical across calls (no atomics in the reductions)."""
+    gen = torch.Generator().manual_seed(3)
+    q = torch.nn.functional.normalize(torch.randn(2048, 64, generator=gen), dim=1).to(cuda)
+    c = torch.nn.functional.normalize(torch.randn(40982, 64, generator=gen), dim=1).to(cuda)
+    tau = 0.2
+    outs = []
+    for _ in range(2):
+        qg, cg = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        out = rbg.ops.lse_rows(qg, cg, 1 / tau, 1 / tau)
+        out.sum().backward()
+        outs.append((out.detach(), qg.grad, cg.grad))
+    for a, b2 in zip(*outs):
+        assert torch.equal(a, b2)
+    qr, cr = q.double().requires_grad_(True), c.double().requires_grad_(True)
+    ref = torch.log(torch.exp(qr @ cr.T / tau).sum(1))
+    ref.sum().backward()
+    close(outs[0][0], ref.detach().float(), tol=1e-5)
+    close(outs[0][1], qr.grad.float(), tol=1e-5)
+    close(outs[0][2], cr.grad.float(), tol=1e-5)
+
+
+def test_sgl_ssl_loss_matches_reference_formula(rbg, cuda):
+    """SGL._info_nce x 2 == calc_ssl_loss (sgl.py:176-209) on random view embeddings."""
+    gen = torch.Generator().manual_seed(11)
+    nu, ni, d, tau = 300, 500, 32, 0.3
+    u1, u2 = torch.randn(nu, d, generator=gen), torch.randn(nu, d, generator=gen)
+    i1, i2 = torch.randn(ni, d, generator=gen), torch.randn(ni, d, generator=gen)
+    users, pos = torch.randint(1, nu, (70,), generator=gen), torch.randint(1, ni, (70,), generator=gen)
+    ref = O.calc_ssl_loss(users, pos, u1.double(), u2.double(), i1.double(), i2.double(), tau, 1.0)
+    U1, U2, I1, I2 = (t.to(cuda) for t in (u1, u2, i1, i2))
+    got = rbg.SGL._info_nce(U1[users.to(cuda)], U2[users.to(cuda)], U2, tau) + \
+        rbg.SGL._info_nce(I1[pos.to(cuda)], I2[pos.to(cuda)], I2, tau)
+    assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+
+
 # ---- NGCF -----------------------------------------------------------------------------------
 
 def test_bignn_conv_golden(rbg, cuda, golden):
