@@ -173,3 +173,31 @@ extern "C" int mb_mfma_rate(float* out, int blocks, int threads, int iters, int 
     }
     return (int)hipGetLastError();
 }
+
+// Store-only twin of score_kernel: same grid, same 32x32 tile store pattern (lane = item column, 16 user rows per lane),
+// no loads, no MFMA.  ld = row stride of S in floats (n, or n rounded up to 32 for line-aligned rows).
+__global__ __launch_bounds__(256) void store_tiles_kernel(float* __restrict__ S, int64_t B, int64_t n, int64_t ld, int tiles_per_wave) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t user0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
+    if (user0 >= B) return;
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wave;
+    const int64_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t item = t * 32 + i;
+        if (item < n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t u = user0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (u < B) S[u * ld + item] = (float)(r + lane);
+            }
+        }
+    }
+}
+extern "C" int mb_store_tiles(float* S, int64_t B, int64_t n, int64_t ld, int tiles_per_wave, void* stream) {
+    const int64_t n_tiles = (n + 31) / 32;
+    dim3 grid((unsigned)((n_tiles + tiles_per_wave - 1) / tiles_per_wave), (unsigned)((B + 127) / 128));
+    hipLaunchKernelGGL(store_tiles_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, B, n, ld, tiles_per_wave);
+    return (int)hipGetLastError();
+}

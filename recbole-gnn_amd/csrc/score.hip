@@ -25,7 +25,6 @@ namespace rbg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTilesPerWave = 8;  // item tiles walked by one workgroup
 
 // 32 floats of row `row` starting at k0 (zero beyond d or when the row is out of range).
 template <bool VEC>
@@ -48,6 +47,26 @@ __device__ __forceinline__ void load_run(const float *base, int64_t ld, int64_t 
     }
 }
 
+// Branch-free variant for the hot loop: `p` points at an in-range row (callers clamp the row index; the columns or rows
+// computed from a clamped operand are never stored).  With FULLD (d == 64 * NCHUNK, 16-byte aligned rows) the eight loads
+// are unconditional, which keeps the whole tile loop one basic block — see the note on vmcnt at score_kernel.
+template <bool FAST>
+__device__ __forceinline__ void load_run_rowptr(const float *p, int k0, int d, float (&r)[32]) {
+    if (FAST) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
+            r[4 * q + 0] = v.x;
+            r[4 * q + 1] = v.y;
+            r[4 * q + 2] = v.z;
+            r[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 32; ++s) r[s] = (k0 + s < d) ? p[k0 + s] : 0.f;
+    }
+}
+
 // One 64-wide k chunk of one 32x32 tile: 32 exact-fp32 MFMAs.
 __device__ __forceinline__ f32x16 mfma_chunk(const float (&a)[32], const float (&b)[32], f32x16 acc) {
 #pragma unroll
@@ -67,87 +86,253 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, int64_t n, int
     }
 }
 
-// NCHUNK > 0: d <= 64*NCHUNK and the user fragment stays in registers across item tiles; the item
-// fragment of the NEXT (tile, chunk) is fetched into the other buffer BEFORE the current tile's stores are
-// issued.  gfx950's vmcnt counts stores too, so an un-pipelined loop would drain every tile's 16 stores
-// (HBM write latency) before its next operand load could complete — measured MFMA busy 30 %.
-// NCHUNK == 0: any d, un-pipelined (user fragment re-read per tile).
-template <int NCHUNK, bool VEC>
-__global__ __launch_bounds__(256) void score_kernel(const float *__restrict__ U, int64_t ldu,
-                                                    const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
-                                                    int64_t B, int64_t n, int d) {
+// Line-aligned stores for the reference's contiguous [B, n] output (lightgcn.py:131 returns scores.view(-1)): a row of
+// S starts at byte 4*u*n, so unless n % 32 == 0 the 128-byte piece a tile contributes to a row straddles two cache
+// lines and every store instruction costs two L2 write requests (store-only twin of this kernel, r01: 226 us vs 125 us
+// with aligned rows, profiles/r01_microbench.md).  A wave walks consecutive item tiles, so it can shift each row's data
+// by that row's phase instead: line k of a row = the last 32-s columns of tile k-1 + the first s columns of tile k,
+// assembled with one cross-lane read per row.  Only the head of the first tile and the tail of the last one remain
+// partial.  `sh[r]` = columns of the first tile that precede the row's first line boundary.
+// Everything but `prev` is wave-uniform (scalar registers): addresses are a uniform 64-bit base + a 32-bit lane offset,
+// and a row's phase is recomputed from (c0, n mod 32) instead of being kept per row.
+// Stores go through an explicit global (address space 1) pointer: carried through this struct the pointer is otherwise
+// treated as generic, the stores become flat_store, and a pending FLAT access forces every later wait to vmcnt(0).
+typedef __attribute__((address_space(1))) float gfloat;
+
+struct AlignedRows {
+    float prev[16];
+    gfloat *row0;      // &S[user0][0]
+    unsigned n;        // row stride (n <= 2^26 so 32 rows of offsets fit 32 bits)
+    unsigned c0, nm;   // (address of S[user0][first_col] / 4) mod 32, n mod 32
+    int rows_left;     // B - user0, clamped to 32
+};
+
+__device__ __forceinline__ void aligned_init(AlignedRows &a, float *S, int64_t n, int64_t B, int64_t user0, int64_t first_col) {
+    a.row0 = (gfloat *)(S + user0 * n);
+    a.n = (unsigned)n;
+    a.c0 = (unsigned)(((reinterpret_cast<uintptr_t>(a.row0) >> 2) + (uint64_t)first_col) & 31u);
+    a.nm = (unsigned)(n & 31);
+    a.rows_left = (int)((B - user0 < 32) ? B - user0 : 32);
+}
+
+// Hand tile `t` (acc: col = lane&31, row = rowmap(reg, h)) to the shifted store stream.
+__device__ __forceinline__ void aligned_emit(AlignedRows &a, int64_t n, int64_t t, bool first, int i, int h, const f32x16 &acc) {
+    gfloat *base = a.row0 + (first ? t : t - 1) * 32;                      // uniform
+    const int64_t left64 = n - (first ? t : t - 1) * 32;
+    const int cols_left = (int)(left64 < 64 ? left64 : 64);                // uniform; a line never reaches past +63
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;                      // row inside the tile
+        const int s = (int)((32u - ((a.c0 + (unsigned)m * a.nm) & 31u)) & 31u);
+        const unsigned row_off = (unsigned)m * a.n;
+        if (first) {  // head: the columns before the row's first line boundary
+            if (i < s && i < cols_left && m < a.rows_left) base[row_off + (unsigned)i] = acc[r];
+        } else {
+            const float x = (i >= s) ? a.prev[r] : acc[r];  // what source lane i contributes to the line
+            const float v = __shfl(x, ((i + s) & 31) + 32 * h);
+            if (s + i < cols_left && m < a.rows_left) base[row_off + (unsigned)(s + i)] = v;
+        }
+        a.prev[r] = acc[r];
+    }
+}
+
+// Interior tile (not the first of the walk, line (t-1)*32 + s .. + 31 inside the row for every s, all 32 rows valid):
+// 16 cross-lane reads + 16 unconditional whole-line stores, no branches.
+__device__ __forceinline__ void aligned_emit_interior(AlignedRows &a, int64_t t, int i, int h, const f32x16 &acc) {
+    gfloat *base = a.row0 + (t - 1) * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int s = (int)((32u - ((a.c0 + (unsigned)m * a.nm) & 31u)) & 31u);
+        const float x = (i >= s) ? a.prev[r] : acc[r];
+        base[(unsigned)m * a.n + (unsigned)(s + i)] = __shfl(x, ((i + s) & 31) + 32 * h);
+        a.prev[r] = acc[r];
+    }
+}
+
+// After the last tile `t`: the columns from the last line boundary on.
+__device__ __forceinline__ void aligned_flush(const AlignedRows &a, int64_t n, int64_t t, int i, int h) {
+    gfloat *base = a.row0 + t * 32;
+    const int64_t left64 = n - t * 32;
+    const int cols_left = (int)(left64 < 32 ? left64 : 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int s = (int)((32u - ((a.c0 + (unsigned)m * a.nm) & 31u)) & 31u);
+        const float v = __shfl(a.prev[r], ((i + s) & 31) + 32 * h);
+        if (s + i < cols_left && m < a.rows_left) base[(unsigned)m * a.n + (unsigned)(s + i)] = v;
+    }
+}
+
+// Any d, no LDS, un-pipelined (user fragment re-read per tile): d > 256 or n > 2^26.
+template <bool VEC>
+__global__ __launch_bounds__(256) void score_generic_kernel(const float *__restrict__ U, int64_t ldu,
+                                                            const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
+                                                            int64_t B, int64_t n, int d, int tiles_per_wave) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t user_tile = (int64_t)blockIdx.y * 4 + wave;
     const int64_t ur = user_tile * 32 + i;
-    if (user_tile * 32 >= B) return;  // whole wave out of range (no barriers below)
+    if (user_tile * 32 >= B) return;
     const bool u_ok = ur < B;
     const int64_t n_tiles = (n + 31) / 32;
-    const int64_t t0 = (int64_t)blockIdx.x * kTilesPerWave;
-    const int64_t t1 = (t0 + kTilesPerWave < n_tiles) ? t0 + kTilesPerWave : n_tiles;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wave;
+    const int64_t t1 = (t0 + tiles_per_wave < n_tiles) ? t0 + tiles_per_wave : n_tiles;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int nchunk = (d + 63) / 64;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t jr = t * 32 + i;
+        f32x16 acc = zero;
+        for (int c = 0; c < nchunk; ++c) {
+            float a[32], b[32];
+            load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a);
+            load_run<VEC>(I, ldi, jr, jr < n, c * 64 + h * 32, d, b);
+            acc = mfma_chunk(a, b, acc);
+        }
+        store_tile(S, n, B, user_tile * 32, jr, h, acc);
+    }
+}
+
+// d <= 64 NCHUNK <= 256.  A workgroup = 4 waves = 128 users whose A fragments stay in registers; it walks
+// `tiles_per_wave` item tiles.  What the earlier versions of this kernel taught (r01, SQ counters + ISA):
+//  * operand loads must be COALESCED: "each lane reads its own 128-byte run" is 8 dwordx4 instructions that each touch
+//    64 different cache lines — 512 tag lookups per tile and wave, as many cycles as the 32 MFMAs (matrix core busy
+//    38 %).  Here the 256 threads fetch an item tile as consecutive float4s (8 lines per instruction) into a
+//    double-buffered LDS tile (row stride 64 NCHUNK + 4 floats) and every wave reads its B fragments with b128 LDS loads.
+//  * `vmcnt` counts stores, so the fetch of tile t+1 is issued before tile t's stores and consumed (written to LDS)
+//    before them as well; stores must be global_store (a pointer that decays to a generic one makes them flat_store and
+//    every wait becomes vmcnt(0)) — see AlignedRows.
+//  * output rows are not line-aligned (row stride n) — aligned_emit.
+template <int NCHUNK, bool VEC, bool FAST>
+__global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) void score_kernel(const float *__restrict__ U, int64_t ldu,
+                                                    const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
+                                                    int64_t B, int64_t n, int d, int tiles_per_wave) {
+    constexpr int LD = NCHUNK * 64 + 4;
+    __shared__ __attribute__((aligned(16))) float s_it[2][32][LD];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t user_tile = (int64_t)blockIdx.y * 4 + wave;
+    const int64_t ur = user_tile * 32 + i;
+    const bool wave_live = user_tile * 32 < B;  // an idle wave still fetches and meets the barriers
+    const int64_t n_tiles = (n + 31) / 32;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wave;
+    const int64_t t1 = (t0 + tiles_per_wave < n_tiles) ? t0 + tiles_per_wave : n_tiles;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (NCHUNK == 0) {
-        const int nchunk = (d + 63) / 64;
-        for (int64_t t = t0; t < t1; ++t) {
-            const int64_t jr = t * 32 + i;
-            f32x16 acc = zero;
-            for (int c = 0; c < nchunk; ++c) {
-                float a[32], b[32];
-                load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a);
-                load_run<VEC>(I, ldi, jr, jr < n, c * 64 + h * 32, d, b);
-                acc = mfma_chunk(a, b, acc);
-            }
-            store_tile(S, n, B, user_tile * 32, jr, h, acc);
-        }
-    } else {
-        float a[NCHUNK][32];
+    // clamped rows: a user row >= B / an item row >= n computes values that are never stored
+    const float *urow = U + (ur < B ? ur : B - 1) * ldu;
+    float a[NCHUNK][32];
 #pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a[c]);
-        float b0[32], b1[32];
-        load_run<VEC>(I, ldi, t0 * 32 + i, t0 * 32 + i < n, h * 32, d, b0);
-        if constexpr (NCHUNK == 1) {
-            for (int64_t t = t0; t < t1; t += 2) {  // two tiles per trip so the buffer choice is static
-                const int64_t j0 = t * 32 + i, j1 = j0 + 32, j2 = j0 + 64;
-                if (t + 1 < t1) load_run<VEC>(I, ldi, j1, j1 < n, h * 32, d, b1);
-                f32x16 acc = mfma_chunk(a[0], b0, zero);
-                store_tile(S, n, B, user_tile * 32, j0, h, acc);
-                if (t + 2 < t1) load_run<VEC>(I, ldi, j2, j2 < n, h * 32, d, b0);
-                if (t + 1 < t1) {
-                    acc = mfma_chunk(a[0], b1, zero);
-                    store_tile(S, n, B, user_tile * 32, j1, h, acc);
-                }
-            }
-        } else {  // NCHUNK even: chunk c uses buffer c & 1; the next tile's chunk 0 lands in b0 during the last chunk
-            for (int64_t t = t0; t < t1; ++t) {
-                const int64_t jr = t * 32 + i, jn = jr + 32;
-                f32x16 acc = zero;
+    for (int c = 0; c < NCHUNK; ++c) load_run_rowptr<FAST>(urow, c * 64 + h * 32, d, a[c]);
+
+    float4 stage[NCHUNK * 2];
+    auto fetch = [&](const int64_t t) __attribute__((always_inline)) {
 #pragma unroll
-                for (int c = 0; c < NCHUNK; c += 2) {
-                    load_run<VEC>(I, ldi, jr, jr < n, (c + 1) * 64 + h * 32, d, b1);
-                    acc = mfma_chunk(a[c], b0, acc);
-                    if (c + 2 < NCHUNK) load_run<VEC>(I, ldi, jr, jr < n, (c + 2) * 64 + h * 32, d, b0);
-                    else if (t + 1 < t1) load_run<VEC>(I, ldi, jn, jn < n, h * 32, d, b0);
-                    acc = mfma_chunk(a[c + 1], b1, acc);
-                }
-                store_tile(S, n, B, user_tile * 32, jr, h, acc);
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            const int64_t r = t * 32 + row;
+            const float *src = I + (r < n ? r : n - 1) * ldi + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FAST) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else if (VEC) {
+                if (c4 < d) v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                if (c4 + 0 < d) v.x = src[0];
+                if (c4 + 1 < d) v.y = src[1];
+                if (c4 + 2 < d) v.z = src[2];
+                if (c4 + 3 < d) v.w = src[3];
             }
+            stage[k] = v;
         }
+    };
+    auto publish = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            *reinterpret_cast<float4 *>(&s_it[buf][row][c4]) = stage[k];
+        }
+    };
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
+        f32x16 acc = zero;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {  // lane (i, h) walks k = 64c + 32h + s of item row i, as its user fragment does
+                const float4 b = *reinterpret_cast<const float4 *>(&s_it[buf][i][c * 64 + h * 32 + s4 * 4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 0], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 3], b.w, acc, 0, 0, 0);
+            }
+        return acc;
+    };
+    AlignedRows al;
+    aligned_init(al, S, n, B, user_tile * 32, t0 * 32);
+    // tiles whose shifted line lies inside the row for every phase, in a wave with 32 valid rows: unconditional stores
+    const int64_t t_int_end = (wave_live && al.rows_left >= 32 && n >= 64) ? (n - 64) / 32 + 2 : t0;
+    // Pipeline (vmcnt retires in order, stores included): iteration t runs
+    //   product(t) from LDS | publish(t+1) LDS <- stage | fetch(t+2) -> stage | stores(t) | barrier
+    // so the fetch consumed by publish() was issued one whole iteration earlier and only YOUNGER stores are outstanding
+    // when it is awaited (vmcnt(16)); with fetch(t+1) at the top of iteration t the wait also drained tile t-1's stores,
+    // whose write acknowledge takes longer than one tile of MFMAs (matrix core busy 59 % -> see DESIGN.md 6.3).
+    if (t0 < t1) {
+        fetch(t0);
+        publish(0);
+        if (t0 + 1 < t1) fetch(t0 + 1);
     }
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const int buf = (int)(t - t0) & 1;
+        f32x16 acc = zero;
+        if (wave_live) acc = tile_product(buf);
+        if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        if (t + 2 < t1) fetch(t + 2);
+        if (wave_live) {
+            if (t > t0 && t < t_int_end) aligned_emit_interior(al, t, i, h, acc);
+            else aligned_emit(al, n, t, t == t0, i, h, acc);
+        }
+        __syncthreads();
+    }
+    if (wave_live && t1 > t0) aligned_flush(al, n, t1 - 1, i, h);
 }
 
 template <int NCHUNK>
 static int launch_score(const float *U, int64_t ldu, const float *I, int64_t ldi, float *S, int64_t B, int64_t n, int d,
                         bool vec, hipStream_t s) {
+    // Walk length: equal-sized workgroups should fill whole rounds of the resident ones (3 / 2 / 1 per CU for
+    // NCHUNK 1 / 2 / 4; lse.hip's block trace), and a walk should be long enough to amortise its masked first tile.
+    // Smallest round count that keeps a walk <= 56 tiles (sweep r01: 250 us at exactly one round of 54-tile walks vs
+    // 262-294 us otherwise, B = 4096 x 40 982).
     const int64_t n_tiles = (n + 31) / 32;
-    const int64_t gx = (n_tiles + kTilesPerWave - 1) / kTilesPerWave;
     const int64_t gy = (B + 127) / 128;
+    const int64_t slots = 256 * (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1));
+    int64_t tiles_per_wave = n_tiles;
+    for (int64_t rounds = 1; rounds <= 64; ++rounds) {
+        const int64_t gx_want = std::max<int64_t>(1, rounds * slots / gy);
+        tiles_per_wave = (n_tiles + gx_want - 1) / gx_want;
+        if (tiles_per_wave <= 56) break;
+    }
+    tiles_per_wave = std::max<int64_t>(tiles_per_wave, std::min<int64_t>(4, n_tiles));
+    if (opt_score_tiles() > 0) tiles_per_wave = std::min<int64_t>(opt_score_tiles(), n_tiles);
+    const int64_t gx = (n_tiles + tiles_per_wave - 1) / tiles_per_wave;
     if (gx > INT32_MAX || gy > 65535) return fail(RBG_EUNSUPPORTED, "score grid too large (B = %lld)", (long long)B);
     dim3 grid((unsigned)gx, (unsigned)gy);
-    if (vec)
-        hipLaunchKernelGGL((score_kernel<NCHUNK, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d);
-    else
-        hipLaunchKernelGGL((score_kernel<NCHUNK, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d);
+    if constexpr (NCHUNK == 0) {
+        if (vec)
+            hipLaunchKernelGGL((score_generic_kernel<true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+        else
+            hipLaunchKernelGGL((score_generic_kernel<false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+    } else {
+        const bool fast = vec && d == 64 * NCHUNK;
+        if (fast)
+            hipLaunchKernelGGL((score_kernel<NCHUNK, true, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+        else if (vec)
+            hipLaunchKernelGGL((score_kernel<NCHUNK, true, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+        else
+            hipLaunchKernelGGL((score_kernel<NCHUNK, false, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -166,6 +351,7 @@ extern "C" int rbg_score_f32(const float *U, int64_t ldu, const float *I, int64_
     const bool vec = (d % 4 == 0) && (ldu % 4 == 0) && (ldi % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(I)) & 15u) == 0;
     hipStream_t s = (hipStream_t)stream;
+    if (n > (int64_t(1) << 26)) return launch_score<0>(U, ldu, I, ldi, S, B, n, d, vec, s);  // 32-bit row offsets in the aligned store stream
     if (d <= 64) return launch_score<1>(U, ldu, I, ldi, S, B, n, d, vec, s);
     if (d <= 128) return launch_score<2>(U, ldu, I, ldi, S, B, n, d, vec, s);
     if (d <= 256) return launch_score<4>(U, ldu, I, ldi, S, B, n, d, vec, s);
