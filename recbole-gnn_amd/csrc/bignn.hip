@@ -11,10 +11,15 @@
 // The dense part is ONE GEMM with the two linears concatenated along k:
 //     Y = [P+X | P⊙X] (N x 2d_in) · [W1^T ; W2^T] (2d_in x d_out) + (b1 + b2)
 // run on v_mfma_f32_32x32x2_f32 (exact fp32).  A wavefront owns 32 rows and all d_out columns, so the
-// row L2 norm is a 32-lane butterfly inside the wave.  The A operand is built in registers straight
+// row L2 norm is a 32-lane reduction inside the wave (DPP).  The A operand is built in registers straight
 // from the lane's contiguous 128-byte runs of P and X (same k-walk trick as score.hip); the
-// concatenated weight matrix is staged once per workgroup in LDS in the MFMA's k order, so a B
-// operand is one conflict-free ds_read_b32.
+// concatenated weight matrix is staged once per workgroup in LDS as Wl[part][j][k] (coalesced loads, row stride
+// d_in + 4) and read back as b128 B fragments.
+// Per-wave clock trace (r01, Gowalla shape, one 32-row tile per wave, all 2 216 waves resident at once): the kernel
+// runs as three lock-stepped phases — staging + barrier ~10 us, MFMA ~5 us, epilogue + stores ~8 us — so the matrix
+// core is a minor term.  The staging phase is dominated by the row loads themselves (each lane's own 128-byte run =
+// 64 cache lines per instruction); fetching rows coalesced and transposing them through LDS cut that phase to 6.8 us
+// but cost 4.5 us of LDS passes and a resident workgroup (measured, not kept).
 
 #include <hip/hip_runtime.h>
 
@@ -57,14 +62,23 @@ __device__ __forceinline__ void load_run32(const float *p, int k0, int d, float 
     }
 }
 
+// Sum over the 32 lanes of a wave half, result in every lane: four DPP adds (xor 1, xor 2 as quad permutes, then
+// half-mirror and mirror inside the 16-lane row) and ONE cross-row exchange, instead of five dependent ds_bpermute.
+__device__ __forceinline__ float row32_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));  // row_mirror
+    return x + __shfl_xor(x, 16);
+}
+
 // NT = number of 32-column output tiles held by a wave (d_out <= 32*NT).
 // FAST = d_in is a multiple of 64 and P / X / W rows are 16-byte aligned (the NGCF configuration).
-// LDS holds W as Wl[kk][h][j], kk = chunk*32 + s walking k = 64*(chunk % nch) + 32*h + s of
-// part (chunk / nch) (0: W1 against P+X, 1: W2 against P⊙X); width DP = 32*NT.
+// LDS holds W as Wl[part][j][k] (part 0: W1 against P+X, 1: W2 against P⊙X), DP = 32*NT rows of KP = 64 nch + 4 floats.
 // (A variant that feeds B straight from global memory with no LDS and no barrier measured slower:
 //  42.8 vs 34.3 us at the Gowalla shape.)
 template <int NT, bool FAST>
-__global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void bignn_dense_kernel(const BignnParams p) {
+__global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(const BignnParams p) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     constexpr int DP = 32 * NT;
     const int nch = (p.d_in + 63) / 64;  // k chunks per part
@@ -80,46 +94,42 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void bignn_dense_kernel(con
         load_run32<FAST>(p.P + r * p.d_in, 32 * h, p.d_in, a1);
         load_run32<FAST>(p.X + r * p.ldx, 32 * h, p.d_in, a2);
     }
-    // Stage [W1^T ; W2^T] into LDS in MFMA k-order: thread -> (j = t % DP, k-group q = t / DP, stepping
-    // 256/DP) — consecutive lanes write consecutive LDS banks, and 4 k-groups are fetched per trip so their
-    // load latencies overlap.
+    // Stage [W1 ; W2] as Wl[part][j][k] (row stride KP = 64 nch + 4 floats, zero-padded to DP rows and 64 nch columns).
+    // Coalesced: consecutive threads fetch consecutive float4s of a weight row, and a whole batch of loads is in flight
+    // before the first LDS write (the first version took two dependent round trips of lane-strided loads).
     {
-        const int j = threadIdx.x % DP;
-        constexpr int QS = 256 / DP;
-        const int kq = 16 * nch;  // float4 groups per (padded) weight row
-#pragma unroll 1
-        for (int part = 0; part < 2; ++part) {
-            const float *W = (part ? p.W2 : p.W1) + (int64_t)j * p.d_in;
-            for (int q0 = threadIdx.x / DP; q0 < kq; q0 += 4 * QS) {
-                float4 w[4];
+        const int KP = nch * 64 + 4;
+        const int slots_per_row = nch * 16, per_part = DP * slots_per_row, total = 2 * per_part;
+        constexpr int BATCH = 8;
+        for (int f0 = threadIdx.x; f0 < total; f0 += 256 * BATCH) {
+            float4 w[BATCH];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int q = q0 + t * QS;
-                    w[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (q < kq && j < p.d_out) {
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + 256 * u;
+                w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < total) {
+                    const int part = f >= per_part, g = f - part * per_part;
+                    const int j = g / slots_per_row, k = 4 * (g % slots_per_row);
+                    if (j < p.d_out) {
+                        const float *src = (part ? p.W2 : p.W1) + (int64_t)j * p.d_in + k;
                         if (FAST) {
-                            w[t] = *reinterpret_cast<const float4 *>(W + 4 * q);
+                            w[u] = *reinterpret_cast<const float4 *>(src);
                         } else {
-                            if (4 * q + 0 < p.d_in) w[t].x = W[4 * q + 0];
-                            if (4 * q + 1 < p.d_in) w[t].y = W[4 * q + 1];
-                            if (4 * q + 2 < p.d_in) w[t].z = W[4 * q + 2];
-                            if (4 * q + 3 < p.d_in) w[t].w = W[4 * q + 3];
+                            if (k + 0 < p.d_in) w[u].x = src[0];
+                            if (k + 1 < p.d_in) w[u].y = src[1];
+                            if (k + 2 < p.d_in) w[u].z = src[2];
+                            if (k + 3 < p.d_in) w[u].w = src[3];
                         }
                     }
                 }
+            }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int q = q0 + t * QS;
-                    if (q < kq) {
-                        // k = 4q .. 4q+3 share chunk and half; s = (4q & 31) + e
-                        const int k = 4 * q;
-                        const int chunk = part * nch + (k >> 6), hh = (k >> 5) & 1, s0 = k & 31;
-                        float *dst = Wl + ((chunk * 32 + s0) * 2 + hh) * DP + j;
-                        dst[0 * 2 * DP] = w[t].x;
-                        dst[1 * 2 * DP] = w[t].y;
-                        dst[2 * 2 * DP] = w[t].z;
-                        dst[3 * 2 * DP] = w[t].w;
-                    }
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + 256 * u;
+                if (f < total) {
+                    const int part = f >= per_part, g = f - part * per_part;
+                    const int j = g / slots_per_row, k = 4 * (g % slots_per_row);
+                    *reinterpret_cast<float4 *>(Wl + (part * DP + j) * KP + k) = w[u];
                 }
             }
         }
@@ -149,19 +159,30 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void bignn_dense_kernel(con
                 a1[s] = pv + xv;  // lin1 operand (layers.py:56)
                 a2[s] = pv * xv;  // lin2 operand (layers.py:57)
             }
-            const float *w1 = Wl + ((c * 32) * 2 + h) * DP + i;
-            const float *w2 = Wl + (((nch + c) * 32) * 2 + h) * DP + i;
+            const int KP = nch * 64 + 4;
+            const float *w1 = Wl + (0 * DP + i) * KP + c * 64 + 32 * h;
+            const float *w2 = Wl + (1 * DP + i) * KP + c * 64 + 32 * h;
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int q = 0; q < 8; ++q) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], w1[s * 2 * DP + t * 32], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w = *reinterpret_cast<const float4 *>(w1 + t * 32 * KP + 4 * q);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * q + 0], w.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * q + 1], w.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * q + 2], w.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[4 * q + 3], w.w, acc[t], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
+            for (int q = 0; q < 8; ++q) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s], w2[s * 2 * DP + t * 32], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const float4 w = *reinterpret_cast<const float4 *>(w2 + t * 32 * KP + 4 * q);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], w.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], w.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], w.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], w.w, acc[t], 0, 0, 0);
+                }
             }
         }
         // epilogue on the C layout: col = 32t + (lane&31), row = (reg&3) + 8*(reg>>2) + 4*h
@@ -177,8 +198,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void bignn_dense_kernel(con
                 ss = fmaf(x, x, ss);  // padded columns hold exact zeros
             }
             if (p.leaky_norm) {
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) ss += __shfl_xor(ss, off);
+                ss = row32_sum(ss);
                 const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] *= inv;
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 2 : 1)) void bignn_dense_kernel(con
 template <int NT>
 static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
     const int nch = (p.d_in + 63) / 64;
-    const size_t lds = (size_t)2 * nch * 32 * 2 * 32 * NT * sizeof(float);
+    const size_t lds = (size_t)2 * 32 * NT * (nch * 64 + 4) * sizeof(float);
     if (lds > 160 * 1024) return fail(RBG_EUNSUPPORTED, "BiGNNConv %d x %d needs %zu bytes of LDS", p.d_in, p.d_out, lds);
     if (lds > 64 * 1024) {
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dense_kernel<NT, true>),
