@@ -282,14 +282,19 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) * 1e3 / iters
 
-        halo_buf = torch.empty((max(plan.n_halo, 1), d), device=dev)
-        y_buf = torch.empty((plan.n_owned, d), device=dev)
-        extra["phase_us"] = {
-            "halo_exchange(pack + all_to_all)": phase_us(
-                lambda: (prop._exchange_nccl if transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
-            "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
-            "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
-        }
+        # diagnostic only: a failure here must not cost the measurement above its JSON line.  Every rank decides
+        # together (the phases contain collectives), so one rank's exception cannot leave the others waiting.
+        try:
+            halo_buf = torch.empty((max(plan.n_halo, 1), d), device=dev)
+            y_buf = torch.empty((plan.n_owned, d), device=dev)
+            extra["phase_us"] = {
+                "halo_exchange(pack + all_to_all)": phase_us(
+                    lambda: (prop._exchange_nccl if transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
+                "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
+                "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
+            }
+        except Exception as ex:  # noqa: BLE001
+            extra["phase_us_error"] = str(ex)[:200]
 
     if rank == 0:
         launch_us = ev_ms * 1e3 / (args.steps * launches_per_step)
