@@ -282,8 +282,8 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) * 1e3 / iters
 
-        # diagnostic only: a failure here must not cost the measurement above its JSON line.  Every rank decides
-        # together (the phases contain collectives), so one rank's exception cannot leave the others waiting.
+        # diagnostic only: a failure here must not cost the measurement above its JSON line (the calls are the ones the
+        # timed region already made, so an exception would be a deterministic one raised on every rank alike)
         try:
             halo_buf = torch.empty((max(plan.n_halo, 1), d), device=dev)
             y_buf = torch.empty((plan.n_owned, d), device=dev)
