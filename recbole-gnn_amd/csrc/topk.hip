@@ -9,10 +9,11 @@
 // Kernel 1 (score_topk_kernel): same MFMA tiling as score.hip (wave = 32 users x 32 items, exact fp32
 // v_mfma_f32_32x32x2_f32).  Each lane keeps, for its 16 accumulator rows, a threshold tau of that row's user.  After
 // a tile, a row whose ballot(score >= tau) is empty costs one compare; otherwise the passing lanes append
-// (score, item) to the user's LDS list (capacity 64, raw: no history lookups in the hot loop).  A full list is pruned
-// to its best k valid entries by a 64-lane bitonic sort, its history items dropped by ONE 64-lane-parallel binary
+// (score, item) to the user's LDS list (capacity 48 or 64, raw: no history lookups in the hot loop).  A full list is
+// pruned to its best k valid entries by a 64-lane bitonic sort, its history items dropped by ONE 64-lane-parallel binary
 // search in the user's graph row (a chain of dependent loads paid per batch, not per candidate); that raises tau.
-// A workgroup covers one 32-user tile x one chunk of item tiles; every wave hands its raw lists to a workspace.
+// A workgroup covers four 32-user tiles (one per wave) x one chunk of item tiles, which it fetches once, coalesced,
+// into LDS (ItemTiles); every wave hands its raw lists to a workspace.
 // Kernel 2 (topk_merge_kernel): one wavefront per user compacts all partial lists and folds them 32 at a time.
 // Two passes: a pre-pass over the first 8192 items (topk_prepass_kernel: per-lane running maxima, no lists) yields tau0,
 // a lower bound of the final k-th best valid score, so the main pass starts selective (~k*n/8192 candidates per user
@@ -30,7 +31,6 @@ namespace rbg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kCap = 64;  // LDS list capacity per user (one wave-wide sort)
 constexpr float kNegInf = -__builtin_inff();
 
 constexpr int kListStride = 32;  // entries a wave hands over per user (workspace row)
@@ -148,14 +148,68 @@ struct RowLoop<16> {
     static __device__ __forceinline__ void run(F &&) {}
 };
 
+// Shared by both passes.  A workgroup = 4 waves = 4 tiles of 32 batch users (A fragments in registers); all four walk
+// the SAME item tiles, each fetched once per workgroup with coalesced float4 loads into a double-buffered LDS tile and
+// read back as b128 B fragments (score.hip: "every lane reads its own 128-byte run" costs 64 cache lines per load
+// instruction and as many L1-tag cycles as the MFMAs).
 template <int NCHUNK, bool VEC>
+struct ItemTiles {
+    static constexpr int LD = NCHUNK * 64 + 4;
+    float4 stage[NCHUNK * 2];
+    __device__ __forceinline__ void fetch(const TopkParams &p, const int64_t t, const int tid) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            const int64_t r = t * 32 + row;
+            const float *src = p.I + (r < p.n_items ? r : p.n_items - 1) * (int64_t)p.d + c4;  // clamped: never scored
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (VEC) {
+                if (c4 < p.d) v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                if (c4 + 0 < p.d) v.x = src[0];
+                if (c4 + 1 < p.d) v.y = src[1];
+                if (c4 + 2 < p.d) v.z = src[2];
+                if (c4 + 3 < p.d) v.w = src[3];
+            }
+            stage[k] = v;
+        }
+    }
+    __device__ __forceinline__ void publish(float (*tile)[LD], const int tid) const {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            *reinterpret_cast<float4 *>(&tile[row][c4]) = stage[k];
+        }
+    }
+    static __device__ __forceinline__ f32x16 product(const float (*tile)[LD], const float (&a)[NCHUNK][32], const int i, const int h) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float4 b = *reinterpret_cast<const float4 *>(&tile[i][c * 64 + h * 32 + s4 * 4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 0], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 3], b.w, acc, 0, 0, 0);
+            }
+        return acc;
+    }
+};
+
+// CAP = list capacity per user: a prune leaves <= k entries and one tile adds <= 32, so CAP >= k + 32 (48 for k <= 16,
+// which lets two workgroups share a CU's LDS; 64 otherwise).
+template <int NCHUNK, bool VEC, int CAP>
 __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
-    __shared__ float l_val[4][32][kCap];
-    __shared__ int l_idx[4][32][kCap];
+    using Tiles = ItemTiles<NCHUNK, VEC>;
+    __shared__ __attribute__((aligned(16))) float s_it[2][32][Tiles::LD];
+    __shared__ float l_val[4][32][CAP];
+    __shared__ int l_idx[4][32][CAP];
     __shared__ int l_cnt[4][32];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t b0 = (int64_t)blockIdx.y * 32;  // first batch slot of this user tile
+    const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;  // first batch slot of this wave's user tile
+    const bool wave_live = b0 < p.B;                            // an idle wave still fetches and meets the barriers
     if (lane < 32) l_cnt[wave][lane] = 0;
     // A operand: the embedding row of batch slot b0 + i
     const int64_t bi = b0 + i;
@@ -177,7 +231,6 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     }
     const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
     auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
@@ -197,7 +250,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
                 int *li = l_idx[wave][lu];
                 int base = l_cnt[wave][lu];
                 const int add = __popc(m);
-                if (base + add > kCap) {  // full: prune to the best k valid ones (k <= 32, so 32 arrivals always fit)
+                if (base + add > CAP) {  // full: prune to the best k valid ones (CAP >= k + 32, so 32 arrivals then fit)
                     const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
                     if (h == hh) tau[r] = fmaxf(tau[r], nt);
                     base = l_cnt[wave][lu];
@@ -212,45 +265,23 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
             }
         });
     };
-    // The item fragment of the NEXT (tile, chunk) is in flight while the current one feeds the matrix core (two register
-    // buffers, statically chosen), as in score.hip.
-    auto load_b = [&](float (&buf)[32], const int64_t t, const int c) __attribute__((always_inline)) {
-        const int64_t item = t * 32 + i;
-        tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, buf);
-    };
-    auto mfma32 = [&](const float (&av)[32], const float (&bv)[32], f32x16 acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-        return acc;
-    };
-    float bq0[32], bq1[32];
-    const int64_t t_first = t_begin + wave;
-    if (t_first < t_end) load_b(bq0, t_first, 0);
-    if constexpr (NCHUNK == 1) {
-        for (int64_t t = t_first; t < t_end; t += 8) {  // two tiles per trip
-            const int64_t t1 = t + 4, t2 = t + 8;
-            if (t1 < t_end) load_b(bq1, t1, 0);
-            filter_tile(mfma32(a[0], bq0, zero), t * 32 + i);
-            if (t2 < t_end) load_b(bq0, t2, 0);
-            if (t1 < t_end) filter_tile(mfma32(a[0], bq1, zero), t1 * 32 + i);
-        }
-    } else {
-        for (int64_t t = t_first; t < t_end; t += 4) {
-            f32x16 acc = zero;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; c += 2) {
-                load_b(bq1, t, c + 1);
-                acc = mfma32(a[c], bq0, acc);
-                if (c + 2 < NCHUNK) load_b(bq0, t, c + 2);
-                else if (t + 4 < t_end) load_b(bq0, t + 4, 0);
-                acc = mfma32(a[c + 1], bq1, acc);
-            }
-            filter_tile(acc, t * 32 + i);
-        }
+    Tiles tiles;
+    if (t_begin < t_end) {
+        tiles.fetch(p, t_begin, tid);
+        tiles.publish(s_it[0], tid);
     }
+    __syncthreads();
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int buf = (int)(t - t_begin) & 1;
+        if (t + 1 < t_end) tiles.fetch(p, t + 1, tid);  // in flight while this tile feeds the matrix core
+        if (wave_live) filter_tile(Tiles::product(s_it[buf], a, i, h), t * 32 + i);
+        if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    if (!wave_live) return;
     // hand the lists over: raw candidates (at most kListStride per user; longer lists are pruned first)
-    const int lists = p.n_chunks * 4;
-    const int my_list = (int)blockIdx.x * 4 + wave;
+    const int lists = p.n_chunks;
+    const int my_list = (int)blockIdx.x;
     for (int lu = 0; lu < 32; ++lu) {
         const int64_t b = b0 + lu;
         if (b >= p.B) break;
@@ -270,17 +301,17 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
 // lists at all.  Each lane keeps, per accumulator row, the running maximum (and its item) over the tiles it sees:
 // for one user that is 32 "group maxima" (group = items sharing a lane index), all distinct items.  The k-th largest
 // group maximum that is neither PAD nor a history item is <= the k-th best valid score overall, and with k << 32 it is
-// nearly as tight as the exact k-th best of the sample.  A workgroup covers one 32-user tile x one split of the sample;
-// its 8 waves share the tiles and combine through LDS; topk_tau_kernel folds the splits and selects.
-constexpr int kPreWaves = 8;
+// nearly as tight as the exact k-th best of the sample.  Same workgroup shape as the main pass (4 user tiles sharing the
+// item tiles of one split of the sample); topk_tau_kernel folds the splits and selects.
 template <int NCHUNK, bool VEC>
-__global__ __launch_bounds__(64 * kPreWaves) void topk_prepass_kernel(const TopkParams p, float *__restrict__ g_val,
-                                                                       int32_t *__restrict__ g_idx) {
-    __shared__ float s_v[kPreWaves][16][64];
-    __shared__ int s_i[kPreWaves][16][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, float *__restrict__ g_val,
+                                                           int32_t *__restrict__ g_idx) {
+    using Tiles = ItemTiles<NCHUNK, VEC>;
+    __shared__ __attribute__((aligned(16))) float s_it[2][32][Tiles::LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t b0 = (int64_t)blockIdx.y * 32;
+    const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
+    const bool wave_live = b0 < p.B;
     const int64_t bi = b0 + i;
     const int64_t my_user = bi < p.B ? p.users[bi] : -1;
     float a[NCHUNK][32];
@@ -294,84 +325,44 @@ __global__ __launch_bounds__(64 * kPreWaves) void topk_prepass_kernel(const Topk
         best_v[r] = kNegInf;
         best_i[r] = 0x7fffffff;
     }
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto keep_max = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
-        const bool item_ok = item < p.n_items && item != 0;
-        RowLoop<0>::run([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            const float sc = acc[r];
-            if (item_ok && sc > best_v[r]) {
-                best_v[r] = sc;
-                best_i[r] = (int)item;
-            }
-        });
-    };
-    auto load_b = [&](float (&buf)[32], const int64_t t, const int c) __attribute__((always_inline)) {
-        const int64_t item = t * 32 + i;
-        tk_load_run<VEC>(p.I + item * (int64_t)p.d, item < p.n_items, c * 64 + h * 32, p.d, buf);
-    };
-    auto mfma32 = [&](const float (&av)[32], const float (&bv)[32], f32x16 acc) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-        return acc;
-    };
-    float bq0[32], bq1[32];
-    const int64_t t_lo = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
-    const int64_t t_end = (t_lo + p.tiles_per_chunk < p.tile_hi) ? t_lo + p.tiles_per_chunk : p.tile_hi;
-    const int64_t t_first = t_lo + wave;
-    constexpr int W = kPreWaves;
-    if (t_first < t_end) load_b(bq0, t_first, 0);
-    if constexpr (NCHUNK == 1) {
-        for (int64_t t = t_first; t < t_end; t += 2 * W) {
-            const int64_t t1 = t + W, t2 = t + 2 * W;
-            if (t1 < t_end) load_b(bq1, t1, 0);
-            keep_max(mfma32(a[0], bq0, zero), t * 32 + i);
-            if (t2 < t_end) load_b(bq0, t2, 0);
-            if (t1 < t_end) keep_max(mfma32(a[0], bq1, zero), t1 * 32 + i);
-        }
-    } else {
-        for (int64_t t = t_first; t < t_end; t += W) {
-            f32x16 acc = zero;
-#pragma unroll
-            for (int c = 0; c < NCHUNK; c += 2) {
-                load_b(bq1, t, c + 1);
-                acc = mfma32(a[c], bq0, acc);
-                if (c + 2 < NCHUNK) load_b(bq0, t, c + 2);
-                else if (t + W < t_end) load_b(bq0, t + W, 0);
-                acc = mfma32(a[c + 1], bq1, acc);
-            }
-            keep_max(acc, t * 32 + i);
-        }
+    const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
+    const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
+    Tiles tiles;
+    if (t_begin < t_end) {
+        tiles.fetch(p, t_begin, tid);
+        tiles.publish(s_it[0], tid);
     }
+    __syncthreads();
+    for (int64_t t = t_begin; t < t_end; ++t) {
+        const int buf = (int)(t - t_begin) & 1;
+        if (t + 1 < t_end) tiles.fetch(p, t + 1, tid);
+        if (wave_live) {
+            const f32x16 acc = Tiles::product(s_it[buf], a, i, h);
+            const int64_t item = t * 32 + i;
+            const bool item_ok = item < p.n_items && item != 0;
+            RowLoop<0>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float sc = acc[r];
+                if (item_ok && sc > best_v[r]) {
+                    best_v[r] = sc;
+                    best_i[r] = (int)item;
+                }
+            });
+        }
+        if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);
+        __syncthreads();
+    }
+    if (!wave_live) return;
+    // lane (i, h) holds group i of user slot (r&3) + 8(r>>2) + 4h for r = 0..15
     RowLoop<0>::run([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        s_v[wave][r][lane] = best_v[r];
-        s_i[wave][r][lane] = best_i[r];
-    });
-    __syncthreads();
-    // each wave combines 32 / kPreWaves users; user slot lu lives in accumulator row r = (lu&3) + 4(lu>>3), half (lu>>2)&1
-    constexpr int kPer = 32 / kPreWaves;
-    for (int q = 0; q < kPer; ++q) {
-        const int lu = wave * kPer + q;
-        const int64_t b = b0 + lu;
-        if (b >= p.B) break;
-        const int r = (lu & 3) + 4 * (lu >> 3), hh = (lu >> 2) & 1;
-        if (lane < 32) {
-            float v = kNegInf;
-            int idx = 0x7fffffff;
-            for (int wv = 0; wv < kPreWaves; ++wv) {
-                const float ov = s_v[wv][r][hh * 32 + lane];
-                const int oi = s_i[wv][r][hh * 32 + lane];
-                if (better(ov, oi, v, idx)) {
-                    v = ov;
-                    idx = oi;
-                }
-            }
-            const int64_t off = (b * p.n_chunks + blockIdx.x) * 32 + lane;
-            g_val[off] = v;
-            g_idx[off] = idx;
+        const int64_t b = b0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (b < p.B) {
+            const int64_t off = (b * p.n_chunks + blockIdx.x) * 32 + i;
+            g_val[off] = best_v[r];
+            g_idx[off] = best_i[r];
         }
-    }
+    });
 }
 
 // tau0[b] = the k-th largest group maximum of user b that is not a history item (-inf if fewer than k).  The maxima of
@@ -483,29 +474,32 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
-static void topk_geometry(int64_t B, int64_t n_tiles, int64_t min_tiles_per_chunk, int &tiles_per_chunk, int &n_chunks) {
-    const int64_t user_tiles = (B + 31) / 32;
-    int64_t want = std::max<int64_t>(1, 2048 / std::max<int64_t>(user_tiles, 1));  // aim at ~2048 workgroups
-    want = std::min<int64_t>(want, std::max<int64_t>(1, n_tiles / min_tiles_per_chunk));
-    want = std::min<int64_t>(want, 64);
+// Chunk the item tiles so that a launch has about `want_blocks` workgroups (two resident per CU), at least
+// `min_tiles` tiles per chunk and at most `max_chunks` chunks (= partial lists per user).
+static void topk_geometry(int64_t B, int64_t n_tiles, int64_t want_blocks, int64_t min_tiles, int64_t max_chunks,
+                          int &tiles_per_chunk, int &n_chunks) {
+    const int64_t user_blocks = std::max<int64_t>(1, (B + 127) / 128);
+    int64_t want = std::max<int64_t>(1, want_blocks / user_blocks);
+    want = std::min<int64_t>(want, std::max<int64_t>(1, n_tiles / min_tiles));
+    want = std::min<int64_t>(want, max_chunks);
     tiles_per_chunk = (int)((n_tiles + want - 1) / want);
     n_chunks = (int)((n_tiles + tiles_per_chunk - 1) / std::max(tiles_per_chunk, 1));
 }
 
-template <int NCHUNK>
+template <int NCHUNK, int CAP>
 static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
     if (vec)
-        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false, CAP>), grid, dim3(256), 0, s, p);
 }
 
 template <int NCHUNK>
 static void launch_prepass(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
     if (vec)
-        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true>), grid, dim3(64 * kPreWaves), 0, s, p, gv, gi);
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true>), grid, dim3(256), 0, s, p, gv, gi);
     else
-        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false>), grid, dim3(64 * kPreWaves), 0, s, p, gv, gi);
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false>), grid, dim3(256), 0, s, p, gv, gi);
 }
 
 static void launch_prepass_d(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
@@ -514,13 +508,19 @@ static void launch_prepass_d(const TopkParams &p, bool vec, dim3 grid, float *gv
     else launch_prepass<4>(p, vec, grid, gv, gi, s);
 }
 
-static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
-    if (p.d <= 64) launch_topk<1>(p, vec, grid, s);
-    else if (p.d <= 128) launch_topk<2>(p, vec, grid, s);
-    else launch_topk<4>(p, vec, grid, s);
+template <int CAP>
+static void launch_topk_c(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    if (p.d <= 64) launch_topk<1, CAP>(p, vec, grid, s);
+    else if (p.d <= 128) launch_topk<2, CAP>(p, vec, grid, s);
+    else launch_topk<4, CAP>(p, vec, grid, s);
 }
 
-// workspace: main lists (val, idx: B*nc*4*32 each; cnt: B*nc*4), pre-pass group maxima (val, idx: B*max_splits*32 each),
+static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    if (p.k <= 16) launch_topk_c<48>(p, vec, grid, s);
+    else launch_topk_c<64>(p, vec, grid, s);
+}
+
+// workspace: main lists (val, idx: B*nc*32 each; cnt: B*nc), pre-pass group maxima (val, idx: B*max_splits*32 each),
 // tau0 [B].  Independent of the "topk_sample" option.
 struct TopkLayout {
     int tpc, nc, max_splits, splits, tpc_s;
@@ -530,14 +530,15 @@ static TopkLayout topk_layout(int64_t B, int64_t n_items) {
     TopkLayout L{};
     L.n_tiles = (n_items + 31) / 32;
     L.sample_tiles = std::min<int64_t>(opt_topk_sample() / 32, L.n_tiles);
-    topk_geometry(B, L.n_tiles, 8, L.tpc, L.nc);
-    L.main_lists = B * (int64_t)L.nc * 4;
-    // the pre-pass splits its sample over up to 16 workgroups per user tile (aim: ~512 workgroups, >= one tile per wave)
-    const int64_t user_tiles = (B + 31) / 32;
-    L.max_splits = (int)std::min<int64_t>(16, std::max<int64_t>(1, 512 / std::max<int64_t>(user_tiles, 1)));
-    const int64_t want = std::min<int64_t>(L.max_splits, std::max<int64_t>(1, L.sample_tiles / kPreWaves));
-    L.tpc_s = (int)((L.sample_tiles + want - 1) / want);
-    L.splits = (int)((L.sample_tiles + L.tpc_s - 1) / std::max(L.tpc_s, 1));
+    topk_geometry(B, L.n_tiles, 512, 8, 128, L.tpc, L.nc);
+    L.main_lists = B * (int64_t)L.nc;
+    // the pre-pass splits its sample over up to 64 workgroups per 128 users (aim: ~512 workgroups, >= 2 tiles each)
+    const int64_t user_blocks = std::max<int64_t>(1, (B + 127) / 128);
+    L.max_splits = (int)std::min<int64_t>(64, std::max<int64_t>(1, 512 / user_blocks));
+    int tpc_s = 1, splits = 1;
+    topk_geometry(B, std::max<int64_t>(L.sample_tiles, 1), 512, 2, L.max_splits, tpc_s, splits);
+    L.tpc_s = tpc_s;
+    L.splits = splits;
     L.bytes = L.main_lists * (kListStride * 8 + 4) + B * (int64_t)L.max_splits * 32 * 8 + B * 4 + 256;
     return L;
 }
@@ -570,7 +571,7 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
         int rc = set_device_for(history->device);
         if (rc) return rc;
     }
-    const int64_t user_tiles = (B + 31) / 32;
+    const int64_t user_tiles = (B + 127) / 128;  // workgroups along the batch
     if (user_tiles > 65535) return fail(RBG_EUNSUPPORTED, "B = %lld too large for one call", (long long)B);
     const TopkLayout L = topk_layout(B, n_items);
     char *w = reinterpret_cast<char *>(workspace);
@@ -624,7 +625,7 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     launch_topk_d(p, vec, dim3((unsigned)L.nc, (unsigned)user_tiles), s);
     RBG_HIP(hipGetLastError());
     hipLaunchKernelGGL(topk_merge_kernel, dim3(merge_blocks), dim3(256), 0, s, main_val, main_idx, main_cnt, users, rp, cl, n_users,
-                       B, L.nc * 4, k, out_val, out_idx, (float *)nullptr);
+                       B, L.nc, k, out_val, out_idx, (float *)nullptr);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
