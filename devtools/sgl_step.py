@@ -37,7 +37,7 @@ def timed(fn, iters=20):
 
 
 out = {"kind": "sgl_train_step", "us_step": round(timed(step), 1)}
-fused = rbg.SGL._info_nce
+fused = rbg.ops.info_nce
 
 
 def torch_nce(a, p, c, tau):
@@ -46,7 +46,7 @@ def torch_nce(a, p, c, tau):
     return -torch.log(torch.exp((a * p).sum(1) / tau) / torch.exp(a.matmul(c.T) / tau).sum(1)).sum()
 
 
-rbg.SGL._info_nce = staticmethod(torch_nce)
+rbg.ops.info_nce = lambda t1, t2, idx, tau: torch_nce(t1[idx], t2[idx], t2, tau)  # the reference formula in torch
 out["us_step_torch_ssl"] = round(timed(step), 1)
-rbg.SGL._info_nce = fused
+rbg.ops.info_nce = fused
 print(json.dumps(out))

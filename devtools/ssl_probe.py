@@ -37,6 +37,10 @@ for name, n, d, B in (("gowalla users", 29859, 64, 2048), ("gowalla items", 4098
 
     us_t = time_us(lambda: run(torch_nce))
     us_f = time_us(lambda: run(rbg.SGL._info_nce))
+    def run2():
+        t1.grad = t2.grad = None
+        rbg.ops.info_nce(t1, t2, idx, 0.2).backward()
+    us_f2 = time_us(run2)
     torch.cuda.reset_peak_memory_stats()
     run(torch_nce)
     mem_t = torch.cuda.max_memory_allocated() / 1e6
@@ -47,6 +51,6 @@ for name, n, d, B in (("gowalla users", 29859, 64, 2048), ("gowalla items", 4098
     c = F.normalize(t2.detach(), dim=1)
     us_fwd = time_us(lambda: rbg.ops.lse_rows_raw(q, c, 5.0, 5.0))
     print(json.dumps({"kind": "info_nce_fwd_bwd", "case": name, "B": B, "n": n, "d": d, "us_torch": round(us_t, 1),
-                      "us_fused": round(us_f, 1), "peak_MB_torch": round(mem_t), "peak_MB_fused": round(mem_f),
+                      "us_fused_denominator": round(us_f, 1), "us_fused_all": round(us_f2, 1), "peak_MB_torch": round(mem_t), "peak_MB_fused": round(mem_f),
                       "us_lse_forward_only": round(us_fwd, 1),
                       "fwd_TFLOPs": round(2.0 * B * n * d / us_fwd / 1e6, 1)}), flush=True)

@@ -250,6 +250,16 @@ int rbg_lse_rows_backward_f32(const float *Q, int64_t ldq, int64_t B, const floa
                               float scale, float shift, const float *lse, const float *grad_lse, float *grad_Q,
                               float *grad_C, void *workspace, void *stream);
 
+/* One half of SGL.calc_ssl_loss (sgl.py:191-199 users, :201-208 items), value AND gradients in one call:
+ *   a = normalize(T1[idx]); p = normalize(T2[idx]); c = normalize(T2)                       (F.normalize, eps 1e-12)
+ *   *loss += weight * sum_b ( log sum_j exp(<a_b, c_j> / tau)  -  <a_b, p_b> / tau )        (= -sum log(v1 / v2))
+ *   grad_T1 [n, d] += d/dT1,  grad_T2 [n, d] += d/dT2 of that term (either may be NULL; both NULL = value only).
+ * T1, T2: the two views of one table, [n, d] contiguous; idx [B] int64 rows (repeats allowed: float atomics on the
+ * scattered rows, like torch's GPU index_add).  d <= 128.  `workspace`: rbg_infonce_workspace(B, n, d) bytes. */
+int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes);
+int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau,
+                    float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream);
+
 /* Full-sort evaluation of one batch without the [B, n_items] score matrix.
  * Replaces full_sort_predict (lightgcn.py:123-133) + RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
  *   scores = user_all[users] @ item_all.T;  scores[:, 0] = -inf;  scores[history_index] = -inf;  topk(scores, k)

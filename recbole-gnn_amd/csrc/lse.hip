@@ -418,3 +418,190 @@ int rbg_lse_rows_backward_f32(const float *Q, int64_t ldq, int64_t B, const floa
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// InfoNCE between two views of one embedding table (one half of SGL.calc_ssl_loss, sgl.py:191-199 / :201-208), value
+// and gradients in one call: everything around the lse kernels — F.normalize of the table and of the batch rows, the
+// gathers, the positive term, the backward of the normalisations and the row scatters — is a handful of row kernels
+// here instead of ~75 elementwise / reduction / index launches of 4-5 us each in torch autograd.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace rbg {
+
+constexpr float kNormEps = 1e-12f;  // F.normalize default eps
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// C[j] = T[j] / max(||T[j]||, eps), inv[j] = 1 / max(||T[j]||, eps).  One wave per row.
+__global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__restrict__ T, int64_t n, int d, float *__restrict__ C,
+                                                             float *__restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const float *row = T + j * d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) ss = fmaf(row[c], row[c], ss);
+    ss = wave_sum(ss);
+    const float iv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+    for (int c = lane; c < d; c += 64) C[j * d + c] = row[c] * iv;
+    if (lane == 0) inv[j] = iv;
+}
+
+// A[b] = normalize(T1[idx[b]]), inv1[b], pos[b] = <A[b], C[idx[b]]>.  One wave per batch row.
+__global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__restrict__ T1, const float *__restrict__ C,
+                                                             const int64_t *__restrict__ idx, int64_t B, int d,
+                                                             float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t r = idx[b];
+    const float *row = T1 + r * d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) ss = fmaf(row[c], row[c], ss);
+    ss = wave_sum(ss);
+    const float iv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float a = row[c] * iv;
+        A[b * d + c] = a;
+        dot = fmaf(a, C[r * d + c], dot);
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) {
+        inv1[b] = iv;
+        pos[b] = dot;
+    }
+}
+
+// *loss += weight * sum_b (lse[b] - scale * pos[b]);  gl[b] = weight (the upstream gradient of every lse[b]).  One block.
+__global__ __launch_bounds__(256) void nce_loss_kernel(const float *__restrict__ lse, const float *__restrict__ pos, int64_t B,
+                                                       float scale, float weight, float *__restrict__ loss, float *__restrict__ gl) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 256) {  // fixed order per thread, fixed tree below: reproducible
+        acc += lse[b] - scale * pos[b];
+        gl[b] = weight;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss += weight * (((part[0] + part[1]) + part[2]) + part[3]);
+}
+
+// Batch rows, backward: gA = dA[b] - weight*scale*C[r]  (lse term + positive term), pushed through normalize into
+// grad_T1[r]; the positive term's gradient on the table side, -weight*scale*A[b], is added to dC[r].  r = idx[b] may
+// repeat inside a batch: float atomics, like torch's GPU index_add.
+__global__ __launch_bounds__(256) void nce_batch_back_kernel(const float *__restrict__ dA, const float *__restrict__ A,
+                                                             const float *__restrict__ C, const float *__restrict__ inv1,
+                                                             const float *__restrict__ T1, const int64_t *__restrict__ idx, int64_t B,
+                                                             int d, float ws, float *__restrict__ dC, float *__restrict__ grad_T1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t r = idx[b];
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dA[b * d + c] - ws * C[r * d + c];
+        dot = fmaf(g, A[b * d + c], dot);
+    }
+    dot = wave_sum(dot);
+    const float iv = inv1[b];
+    const bool clamped = iv >= 1.0f / kNormEps;  // ||x|| < eps: normalize is x / eps, a plain scaling
+    for (int c = lane; c < d; c += 64) {
+        const float a = A[b * d + c];
+        const float g = dA[b * d + c] - ws * C[r * d + c];
+        if (grad_T1) atomicAdd(grad_T1 + r * d + c, (clamped ? g : g - a * dot) * iv);
+        atomicAdd(dC + r * d + c, -ws * a);
+    }
+}
+
+// Table rows, backward of C = normalize(T2): grad_T2[j] += (g - C[j] <g, C[j]>) * inv[j],  g = dC[j].
+__global__ __launch_bounds__(256) void nce_table_back_kernel(const float *__restrict__ dC, const float *__restrict__ C,
+                                                             const float *__restrict__ inv, int64_t n, int d,
+                                                             float *__restrict__ grad_T2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    float dot = 0.f;
+    for (int c = lane; c < d; c += 64) dot = fmaf(dC[j * d + c], C[j * d + c], dot);
+    dot = wave_sum(dot);
+    const float iv = inv[j];
+    const bool clamped = iv >= 1.0f / kNormEps;
+    for (int c = lane; c < d; c += 64) {
+        const float g = dC[j * d + c];
+        grad_T2[j * d + c] += (clamped ? g : g - C[j * d + c] * dot) * iv;
+    }
+}
+
+struct NceLayout {
+    int64_t off_C, off_inv2, off_A, off_inv1, off_pos, off_lse, off_gl, off_dA, off_dC, off_lse_ws, bytes;
+};
+static NceLayout nce_layout(int64_t B, int64_t n, int d) {
+    auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+    NceLayout L{};
+    int64_t o = 0;
+    L.off_C = o, o += up(n * d * 4);
+    L.off_inv2 = o, o += up(n * 4);
+    L.off_A = o, o += up(B * d * 4);
+    L.off_inv1 = o, o += up(B * 4);
+    L.off_pos = o, o += up(B * 4);
+    L.off_lse = o, o += up(B * 4);
+    L.off_gl = o, o += up(B * 4);
+    L.off_dA = o, o += up(B * d * 4);
+    L.off_dC = o, o += up(n * d * 4);
+    L.off_lse_ws = o, o += lse_layout(B, n, d).bytes;
+    L.bytes = o + 256;
+    return L;
+}
+
+}  // namespace rbg
+
+extern "C" {
+
+int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes) {
+    if (!bytes || B < 0 || n < 0 || d <= 0) return fail(RBG_EINVAL, "bad argument");
+    *bytes = nce_layout(B, n, d).bytes;
+    return RBG_OK;
+}
+
+int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau,
+                    float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
+    clear_error();
+    if (B < 0 || n <= 0 || d <= 0) return fail(RBG_ESHAPE, "B = %lld, n = %lld, d = %d", (long long)B, (long long)n, d);
+    if (d > 128) return fail(RBG_EUNSUPPORTED, "infonce: d = %d > 128", d);
+    if (!(tau > 0.f)) return fail(RBG_EINVAL, "tau must be positive");
+    if (B == 0) return RBG_OK;
+    if (!T1 || !T2 || !idx || !loss || !workspace) return fail(RBG_EINVAL, "NULL pointer");
+    const NceLayout L = nce_layout(B, n, d);
+    char *w = reinterpret_cast<char *>(workspace);
+    auto f = [&](int64_t off) { return reinterpret_cast<float *>(w + off); };
+    float *C = f(L.off_C), *inv2 = f(L.off_inv2), *A = f(L.off_A), *inv1 = f(L.off_inv1), *pos = f(L.off_pos);
+    float *lse = f(L.off_lse), *gl = f(L.off_gl), *dA = f(L.off_dA), *dC = f(L.off_dC);
+    void *lse_ws = w + L.off_lse_ws;
+    hipStream_t s = (hipStream_t)stream;
+    const float scale = 1.0f / tau;
+    const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
+    hipLaunchKernelGGL(nce_norm_table_kernel, dim3(nb), dim3(256), 0, s, T2, n, d, C, inv2);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos);
+    RBG_HIP(hipGetLastError());
+    int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
+    RBG_HIP(hipGetLastError());
+    if (!grad_T1 && !grad_T2) return RBG_OK;
+    rc = rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(nce_batch_back_kernel, dim3(bb), dim3(256), 0, s, dA, A, C, inv1, T1, idx, B, d, weight * scale, dC, grad_T1);
+    RBG_HIP(hipGetLastError());
+    if (grad_T2) {
+        hipLaunchKernelGGL(nce_table_back_kernel, dim3(nb), dim3(256), 0, s, dC, C, inv2, n, d, grad_T2);
+        RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+}  // extern "C"

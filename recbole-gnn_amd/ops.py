@@ -367,3 +367,45 @@ class _LseRows(torch.autograd.Function):
 def lse_rows(q, c, scale, shift=0.0):
     """Differentiable ``torch.logsumexp(scale * q @ c.T, dim=1)`` that never writes the [B, n] matrix."""
     return _LseRows.apply(q, c, float(scale), float(shift))
+
+
+class _InfoNCE(torch.autograd.Function):
+    """Loss and both table gradients come out of ONE library call; backward only scales them."""
+
+    @staticmethod
+    def forward(ctx, t1, t2, idx, tau):
+        t1, t2 = t1.contiguous(), t2.contiguous()
+        idx = idx.to(device=t1.device, dtype=torch.int64).contiguous()
+        n, d = t2.shape
+        b = idx.shape[0]
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.zeros_like(t1) if need1 else None
+        g2 = torch.zeros_like(t2) if need2 else None
+        loss = torch.zeros(1, dtype=torch.float32, device=t1.device)
+        nbytes = _lib.c_i64()
+        check(lib.rbg_infonce_workspace(b, n, d, ctypes.byref(nbytes)))
+        work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=t1.device)
+        with torch.cuda.device(t1.device):
+            check(lib.rbg_infonce_f32(c_vp(t1.data_ptr()), c_vp(t2.data_ptr()), n, d, c_vp(idx.data_ptr()), b, float(tau), 1.0,
+                                      c_vp(loss.data_ptr()), c_vp(g1.data_ptr()) if need1 else None,
+                                      c_vp(g2.data_ptr()) if need2 else None, c_vp(work.data_ptr()), _stream(t1)))
+        ctx.save_for_backward(*(g for g in (g1, g2) if g is not None))
+        ctx.have = (need1, need2)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = list(ctx.saved_tensors)
+        g1 = saved.pop(0) * grad_out if ctx.have[0] else None
+        g2 = saved.pop(0) * grad_out if ctx.have[1] else None
+        return g1, g2, None, None
+
+
+def info_nce(t1, t2, idx, tau):
+    """-sum_b log( exp(<a_b,p_b>/tau) / sum_j exp(<a_b,c_j>/tau) ) with a = normalize(t1[idx]), p = normalize(t2[idx]),
+    c = normalize(t2): one half of SGL.calc_ssl_loss (sgl.py:191-208) — rbg_infonce_f32."""
+    _check_dense(t1, "t1")
+    _check_dense(t2, "t2")
+    if t1.shape != t2.shape:
+        raise ValueError(f"the two views differ in shape: {tuple(t1.shape)} vs {tuple(t2.shape)}")
+    return _InfoNCE.apply(t1, t2, idx, float(tau))

@@ -639,6 +639,54 @@ def test_sgl_ssl_loss_matches_reference_formula(rbg, cuda):
     assert abs(float(got) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
 
 
+@pytest.mark.parametrize("n,d,b,tau", [(40, 8, 7, 0.5), (300, 32, 70, 0.2), (1000, 64, 257, 0.2), (500, 100, 64, 0.3), (65, 128, 33, 1.0)])
+def test_info_nce_value_and_gradients(rbg, cuda, n, d, b, tau):
+    """rbg_infonce_f32 == one half of calc_ssl_loss (sgl.py:191-199) in float64 autograd: loss, d/dT1, d/dT2; the batch
+    repeats rows (scatter with duplicates) and contains the PAD row."""
+    gen = torch.Generator().manual_seed(n + d + b)
+    t1, t2 = torch.randn(n, d, generator=gen), torch.randn(n, d, generator=gen)
+    idx = torch.randint(0, n, (b,), generator=gen)
+    idx[: min(4, b)] = idx[0]  # duplicates
+    w = 0.37
+    a64, b64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+    nrm = torch.nn.functional.normalize
+    u1, u2, allu = nrm(a64[idx], dim=1), nrm(b64[idx], dim=1), nrm(b64, dim=1)
+    ref = -torch.sum(torch.log(torch.exp(torch.sum(u1 * u2, dim=1) / tau) / torch.sum(torch.exp(u1.matmul(allu.T) / tau), dim=1)))
+    (ref * w).backward()
+    g1, g2 = t1.to(cuda).requires_grad_(True), t2.to(cuda).requires_grad_(True)
+    out = rbg.ops.info_nce(g1, g2, idx.to(cuda), tau)
+    (out * w).backward()
+    assert abs(float(out.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    close(g1.grad, a64.grad.float(), tol=1e-5)
+    close(g2.grad, b64.grad.float(), tol=1e-5)
+    # value-only call (no gradient requested) and a table that does not require grad
+    with torch.no_grad():
+        assert abs(float(rbg.ops.info_nce(t1.to(cuda), t2.to(cuda), idx.to(cuda), tau)) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    h1 = t1.to(cuda).requires_grad_(True)
+    rbg.ops.info_nce(h1, t2.to(cuda), idx.to(cuda), tau).backward()
+    close(h1.grad, a64.grad.float() / w, tol=1e-5)
+
+
+def test_info_nce_zero_row(rbg, cuda):
+    """A zero row takes F.normalize's clamp branch (x / eps): finite loss, gradients equal to float64 autograd."""
+    gen = torch.Generator().manual_seed(2)
+    t1, t2 = torch.randn(50, 16, generator=gen), torch.randn(50, 16, generator=gen)
+    t1[3] = 0
+    t2[5] = 0
+    idx = torch.tensor([3, 5, 7, 3])
+    a64, b64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+    ref = O.calc_ssl_loss(idx, idx, a64, b64, a64, b64, 0.5, 1.0) / 2  # both halves identical -> one half
+    ref.backward()
+    g1, g2 = t1.to(cuda).requires_grad_(True), t2.to(cuda).requires_grad_(True)
+    out = rbg.ops.info_nce(g1, g2, idx.to(cuda), 0.5)
+    out.backward()
+    assert torch.isfinite(out.detach())
+    assert abs(float(out.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    # calc_ssl_loss used (a64, b64) for both halves: each table's gradient there is twice one half's... divided by 2 above
+    close(g1.grad, a64.grad.float(), tol=2e-5)
+    close(g2.grad, b64.grad.float(), tol=2e-5)
+
+
 # ---- NGCF -----------------------------------------------------------------------------------
 
 def test_bignn_conv_golden(rbg, cuda, golden):
