@@ -781,6 +781,40 @@ def test_score_vs_fp64(rbg, cuda, shape):
     assert torch.equal(rbg.gather_rows(u, idx), u[idx])
 
 
+def test_score_edges_alignment_and_canaries(rbg, cuda):
+    """The shifted line-aligned store stream of score.hip at its edges: item counts around the 32 / 64 boundaries, user
+    counts around a tile, output bases at every kind of 128-byte phase, forced walk lengths of 1-3 tiles and auto; the
+    result is checked against float64 and the floats just before / after the [B, n] block must stay untouched."""
+    import ctypes
+    lib, c_vp = rbg._lib.lib, ctypes.c_void_p
+    gen = torch.Generator().manual_seed(77)
+    pad = 64
+    try:
+        for tiles in (0, 1, 2, 3):
+            rbg.set_option("score_tiles", tiles)
+            for d in (64, 20, 128):
+                for b in (1, 31, 33, 130):
+                    for n in (1, 31, 32, 33, 63, 64, 65, 97, 129, 1000):
+                        if tiles and (b, d) not in ((33, 64), (130, 20), (1, 128)):
+                            continue  # the walk-length sweep runs on a subset
+                        u = torch.randn(b, d, generator=gen).to(cuda)
+                        it = torch.randn(n, d, generator=gen).to(cuda)
+                        ref = (u.cpu().double() @ it.cpu().double().T).float()
+                        for off in (0, 1, 13, 31):
+                            buf = torch.full((pad + off + b * n + pad,), -777.0, device=cuda)
+                            out = buf[pad + off: pad + off + b * n]
+                            rc = lib.rbg_score_f32(c_vp(u.data_ptr()), d, c_vp(it.data_ptr()), d, c_vp(out.data_ptr()), b, n, d,
+                                                   c_vp(torch.cuda.current_stream().cuda_stream))
+                            assert rc == 0, rbg._lib.lib.rbg_last_error()
+                            got = out.view(b, n).cpu()
+                            err = float((got - ref).abs().max())
+                            assert err <= 2e-5 * max(1, d / 64), (tiles, d, b, n, off, err)
+                            assert bool((buf[: pad + off] == -777.0).all()) and bool((buf[pad + off + b * n:] == -777.0).all()), \
+                                (tiles, d, b, n, off, "wrote outside the output")
+    finally:
+        rbg.set_option("score_tiles", 0)
+
+
 # ---- fused full-sort evaluation (score + mask + top-k) ---------------------------------------
 
 def reference_topk(user_all, item_all, users, k, uid, iid):
