@@ -49,4 +49,6 @@ def torch_nce(a, p, c, tau):
 rbg.ops.info_nce = lambda t1, t2, idx, tau: torch_nce(t1[idx], t2[idx], t2, tau)  # the reference formula in torch
 out["us_step_torch_ssl"] = round(timed(step), 1)
 rbg.ops.info_nce = fused
+gs = rbg.GraphedStep(model, batch, lr=1e-3)
+out["us_step_graphed"] = round(timed(lambda: gs.step(batch)), 1)
 print(json.dumps(out))

@@ -205,6 +205,15 @@ int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const fl
 int rbg_score_f32(const float *U, int64_t ldu, const float *I, int64_t ldi, float *S, int64_t B,
                   int64_t n, int d, void *stream);
 
+/* Weight gradients of BiGNNConv (autograd of layers.py:54-58) with G = dL/dY [N, d_out] (row stride ldg), P = ÂX
+ * [N, d_in] contiguous (the P_save of rbg_bignn_conv_f32) and X [N, d_in] (row stride ldx):
+ *   dW1 = G^T (P + X)   dW2 = G^T (P ⊙ X)   [d_out, d_in] each;   db = sum_rows G  [d_out] (= db1 = db2; may be NULL)
+ * One pass over G, P, X; split over row ranges, partials summed in a fixed order (no atomics).  d_in, d_out <= 128.
+ * `workspace`: rbg_bignn_wgrad_workspace(n_rows, d_in, d_out) bytes. */
+int rbg_bignn_wgrad_workspace(int64_t n_rows, int d_in, int d_out, int64_t *bytes);
+int rbg_bignn_wgrad_f32(const float *G, int64_t ldg, const float *P, const float *X, int64_t ldx, int64_t n_rows, int d_in,
+                        int d_out, float *dW1, float *dW2, float *db, void *workspace, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * fused mini-batch training step.  All pointers are DEVICE pointers; `loss` is a
  * device scalar.  Row scatters use float atomics like torch's GPU index backward.

@@ -14,7 +14,7 @@ import torch
 
 from .graph import InteractionDataset
 from .models import LightGCN
-from .train import FusedBPRAdam
+from .train import FusedBPRAdam, GraphedStep
 
 
 def load_inter(path, user_field="user_id", item_field="item_id", sep="\t"):
@@ -135,14 +135,17 @@ def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096):
     return {f"{name}@{k}": v / max(count, 1) for name, v in sums.items()}
 
 
-def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None):
+def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None, graphed=True):
     """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  LightGCN with
-    ``require_pow`` uses the fused step (train.py); any other model goes through torch autograd + torch.optim.Adam."""
+    ``require_pow`` uses the fused step (train.py); any other model goes through torch autograd + torch.optim.Adam, the
+    whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly)."""
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed)
     if fused is None:
         fused = isinstance(model, LightGCN) and model.require_pow
     stepper = FusedBPRAdam(model, lr=lr) if fused else None
-    opt = None if fused else torch.optim.Adam(model.parameters(), lr=lr)
+    graphed = graphed and not fused and next(model.parameters()).is_cuda
+    opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr)
+    gstep = None
     history = []
     for epoch in range(epochs):
         model.train()
@@ -151,6 +154,16 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
             batch = {k: v.to(model.device) for k, v in batch.items()}
             if fused:
                 total += stepper.step(batch)
+            elif graphed:
+                if gstep is None and len(batch["user_id"]) == min(batch_size, len(train_uid)):
+                    gstep = GraphedStep(model, batch, lr=lr)
+                if gstep is not None and len(batch["user_id"]) == len(gstep.static["user_id"]):
+                    total += gstep.step(batch).detach().reshape(())
+                elif gstep is not None:
+                    total += gstep.eager_step(batch).reshape(())
+                else:  # a first batch that is not full-sized: nothing captured yet
+                    gstep = GraphedStep(model, batch, lr=lr)
+                    total += gstep.step(batch).detach().reshape(())
             else:
                 opt.zero_grad(set_to_none=True)
                 loss = model.calculate_loss(batch)

@@ -214,6 +214,28 @@ def bignn_conv_raw(graph, x, w1, b1, w2, b2, out=None, leaky_norm=False, slope=0
     return out, p
 
 
+def bignn_wgrad_raw(g, p, x):
+    """(G^T (P + X), G^T (P * X), sum_rows G): the weight / bias gradients of BiGNNConv (layers.py:54-58)."""
+    for t, name in ((g, "g"), (p, "p"), (x, "x")):
+        _check_dense(t, name)
+    g = g if g.stride(1) == 1 else g.contiguous()
+    x = x if x.stride(1) == 1 else x.contiguous()
+    p = p.contiguous()
+    n, d_out = g.shape
+    d_in = x.shape[1]
+    gw1 = torch.empty((d_out, d_in), dtype=torch.float32, device=g.device)
+    gw2 = torch.empty_like(gw1)
+    gb = torch.empty(d_out, dtype=torch.float32, device=g.device)
+    nbytes = _lib.c_i64()
+    check(lib.rbg_bignn_wgrad_workspace(n, d_in, d_out, ctypes.byref(nbytes)))
+    work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        check(lib.rbg_bignn_wgrad_f32(c_vp(g.data_ptr()), g.stride(0) if n > 1 else d_out, c_vp(p.data_ptr()), c_vp(x.data_ptr()),
+                                      x.stride(0) if n > 1 else d_in, n, d_in, d_out, c_vp(gw1.data_ptr()), c_vp(gw2.data_ptr()),
+                                      c_vp(gb.data_ptr()), c_vp(work.data_ptr()), _stream(g)))
+    return gw1, gw2, gb
+
+
 class _BiGNNConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, graph):
@@ -230,9 +252,12 @@ class _BiGNNConv(torch.autograd.Function):
         gi = g @ w2            # d/d(P*X)
         gp = gt + gi * x
         gx = gt + gi * p + spmm_raw(ctx.graph.transpose(), gp.contiguous())
-        gw1 = g.t() @ (p + x)
-        gw2 = g.t() @ (p * x)
-        gb = g.sum(dim=0)
+        if x.shape[1] <= 128 and g.shape[1] <= 128:
+            gw1, gw2, gb = bignn_wgrad_raw(g, p, x)  # one pass over G, P, X instead of two 64 x 64 x N rocBLAS GEMMs
+        else:
+            gw1 = g.t() @ (p + x)
+            gw2 = g.t() @ (p * x)
+            gb = g.sum(dim=0)
         return gx, gw1, gb, gw2, gb, None
 
 

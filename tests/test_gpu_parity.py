@@ -764,6 +764,83 @@ def test_ngcf_model(rbg, cuda, golden):
     close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
 
 
+@pytest.mark.parametrize("n,d_in,d_out", [(1, 4, 4), (31, 16, 8), (33, 64, 64), (1000, 64, 64), (70841, 64, 64), (257, 20, 50),
+                                           (500, 128, 96), (100, 64, 128), (64, 7, 5)])
+def test_bignn_wgrad(rbg, cuda, n, d_in, d_out):
+    """rbg_bignn_wgrad_f32: G^T (P + X), G^T (P * X), column sums of G against float64; strided G and X (views into wider
+    buffers, as NGCF's concat buffer gives them); bit-identical across calls (fixed-order split-K)."""
+    gen = torch.Generator().manual_seed(n + d_in * 7 + d_out)
+    gbuf = torch.randn(n, d_out + 8, generator=gen).to(cuda)
+    xbuf = torch.randn(n, d_in + 12, generator=gen).to(cuda)
+    g, x = gbuf[:, 4:4 + d_out], xbuf[:, 8:8 + d_in]
+    p = torch.randn(n, d_in, generator=gen).to(cuda)
+    w1, w2, b = rbg.ops.bignn_wgrad_raw(g, p, x)
+    g64, x64, p64 = g.double().cpu(), x.double().cpu(), p.double().cpu()
+    scale = max(1.0, float(n) ** 0.5)
+    close(w1, (g64.T @ (p64 + x64)).float(), tol=2e-6 * scale)
+    close(w2, (g64.T @ (p64 * x64)).float(), tol=2e-6 * scale)
+    close(b, g64.sum(0).float(), tol=2e-6 * scale)
+    w1b, w2b, bb = rbg.ops.bignn_wgrad_raw(g, p, x)
+    assert torch.equal(w1, w1b) and torch.equal(w2, w2b) and torch.equal(b, bb)
+
+
+# ---- whole training step as a HIP graph --------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL"])
+def test_graphed_step_matches_eager(rbg, cuda, golden, name):
+    """train.GraphedStep (zero_grad + calculate_loss + backward + Adam captured once, replayed per batch) takes the same
+    optimisation steps as the eager loop: losses and parameters after three different batches agree, and the warm-up
+    inside the constructor leaves parameters and optimiser state untouched."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    cfg = dict(enable_sparse=True, reg_weight=1e-4, require_pow=False)
+    if name == "SGL":
+        cfg.update(type="ED", drop_ratio=0.1, ssl_tau=0.5, ssl_weight=0.05)
+    np.random.seed(3)
+    model, _ = make_model(rbg, getattr(rbg, name), cuda, golden, **cfg)
+    twin, _ = make_model(rbg, getattr(rbg, name), cuda, golden, **cfg)
+    twin.load_state_dict(model.state_dict())
+    model.train()
+    twin.train()  # SGL.train() samples the augmented views (sgl.py:94-98) ...
+    if name == "SGL":  # ... and both models must train on the very same ones
+        twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2
+    gen = torch.Generator().manual_seed(9)
+    batches = [{"user_id": torch.randint(1, nu, (64,), generator=gen).to(cuda), "item_id": torch.randint(1, ni, (64,), generator=gen).to(cuda),
+                "neg_item_id": torch.randint(1, ni, (64,), generator=gen).to(cuda)} for _ in range(3)]
+    before = [p.detach().clone() for p in model.parameters()]
+    stepper = rbg.GraphedStep(model, batches[0], lr=1e-3)
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), b)  # the warm-up left no trace
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    for step_no, batch in enumerate(batches):
+        lg = float(stepper.step(batch).detach())
+        opt.zero_grad(set_to_none=True)
+        le = twin.calculate_loss(batch)
+        le.backward()
+        opt.step()
+        # same parameters in the first step; afterwards the Adam noise described below feeds back into the loss
+        assert abs(lg - float(le.detach())) <= (2e-5 if step_no == 0 else 2e-4) * max(1.0, abs(float(le.detach())))
+    # Adam divides by |g|: where a gradient is ~0 the order of the float atomics in the row scatters decides the sign of a
+    # step of size lr, so parameters are compared at a fraction of 3 lr, the losses above at 2e-5
+    for pg, pe in zip(model.parameters(), twin.parameters()):
+        close(pg, pe.detach(), tol=1e-4)
+    with pytest.raises(ValueError):
+        stepper.step({k: v[:10] for k, v in batches[0].items()})
+    stepper.eager_step({k: v[:10] for k, v in batches[0].items()})  # odd-sized batch: eager path
+    if name == "SGL":  # a new epoch samples new views: the step must re-capture, not replay the old handles
+        old = stepper.graph
+        model.train()
+        twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2
+        twin.load_state_dict(model.state_dict())
+        lg = float(stepper.step(batches[1]).detach())
+        assert stepper.graph is not old
+        with torch.no_grad():
+            pass
+        le = float(twin.calculate_loss(batches[1]).detach())
+        # the graphed loss was computed BEFORE its Adam update, on the parameters twin holds now
+        assert abs(lg - le) <= 2e-4 * max(1.0, abs(le))
+
+
 # ---- scoring GEMM ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("shape", [(1, 1125, 64), (3, 1125, 64), (130, 1000, 64), (33, 70, 256), (5, 40, 128),
