@@ -33,6 +33,7 @@ Tuning current_tuning();
 int spmm_unroll();
 int opt_xcd_split();
 int opt_nt_store();
+int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)
 int opt_topk_sample();  // items the fused top-k pre-pass looks at
 

@@ -100,8 +100,9 @@ __device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
 
 // Sum of val[e] * X[col[e], 4*sl .. 4*sl+3] over the chunks of [beg,end) owned by lane-group g of G.
 // A chunk is LPR consecutive entries; lane sl of the group fetches entry sl of the chunk.
-template <int D, int U, bool CONTIG>
-__device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl) {
+// XS = compile-time row stride of a contiguous source (D, or 2 D in column-half mode); coff = first column of the slice.
+template <int D, int U, bool CONTIG, int XS = D>
+__device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl, int coff = 0) {
     constexpr int LPR = D / 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = beg + g * LPR; e < end; e += G * LPR) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int
             for (int u = 0; u < U; ++u) {
                 const int cj = __shfl(c, j + u, LPR);
                 vv[u] = __shfl(v, j + u, LPR);
-                xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
+                xv[u] = ld4((CONTIG ? src_row_c<XS>(p.x, cj) : src_row(p.x, cj)) + coff + sl * 4);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc = fma4(vv[u], xv[u], acc);
@@ -137,7 +138,7 @@ __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int
                 const bool on = (j + u) < cnt;
                 vv[u] = on ? vj : 0.f;
                 xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (on) xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
+                if (on) xv[u] = ld4((CONTIG ? src_row_c<XS>(p.x, cj) : src_row(p.x, cj)) + coff + sl * 4);
             }
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) acc = fma4(vv[u], xv[u], acc);
@@ -161,20 +162,22 @@ __device__ __forceinline__ float4 reduce_groups(float4 a) {
 }
 
 // Row epilogue, executed by the LPR lanes that hold the finished row.
-__device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D) {
+// D = width of the contiguous [N, D] side arrays (prev, mean_out, addend); c0 = first column of this lane's float4.
+__device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D, int coff = 0) {
+    const int c0 = coff + sl * 4;
     if (p.mode == MODE_MEAN) {
-        float4 s = ld4(src_row(p.e0, row) + sl * 4);
-        for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + sl * 4));
+        float4 s = ld4(src_row(p.e0, row) + c0);
+        for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + c0));
         s = add4(s, acc);
         s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
-        st4_stream(p.mean_out + (int64_t)row * D + sl * 4, s, p.nt_store);
-        if (p.y) st4_stream(p.y + (int64_t)row * p.ldy + sl * 4, acc, p.nt_store);
+        st4_stream(p.mean_out + (int64_t)row * D + c0, s, p.nt_store);
+        if (p.y) st4_stream(p.y + (int64_t)row * p.ldy + c0, acc, p.nt_store);
     } else if (p.mode == MODE_HORNER) {
-        float4 s = add4(ld4(p.addend + (int64_t)row * D + sl * 4), acc);
+        float4 s = add4(ld4(p.addend + (int64_t)row * D + c0), acc);
         s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
-        st4_stream(p.y + (int64_t)row * p.ldy + sl * 4, s, p.nt_store);
+        st4_stream(p.y + (int64_t)row * p.ldy + c0, s, p.nt_store);
     } else {
-        float *dst = p.y + (int64_t)row * p.ldy + sl * 4;
+        float *dst = p.y + (int64_t)row * p.ldy + c0;
         if (p.mode == MODE_ACCUM) {
             st4(dst, add4(acc, ld4(dst)));
         } else {
@@ -183,10 +186,15 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
     }
 }
 
-template <int D, int U, bool CONTIG>
+// HALF (column-half mode, "col_split" option): the launch covers rows of width W = 2 D; workgroups on even XCDs own
+// columns [0, D), on odd XCDs [D, 2 D), so an XCD's L2 holds half-width rows of one table (the per-XCD working set of
+// the gather halves; the CSR is read twice).  Only for graphs without split rows (the host checks).
+template <int D, int U, bool CONTIG, bool HALF = false>
 __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     constexpr int LPR = D / 4;
     constexpr int SUBS = 64 / LPR;
+    constexpr int W = HALF ? 2 * D : D;
+    const int coff = HALF ? (int)(blockIdx.x & 1) * D : 0;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         const int4 t1 = *(reinterpret_cast<const int4 *>(&p.tasks[gp.task_base + vb]) + 1);
         const int row = t0.x, beg = t0.y, end = t0.z, seg = t0.w;
         const int nseg = t1.x, part_base = t1.y, ctr = t1.z;
-        float4 acc = gather_range<D, U, CONTIG>(p, beg, end, wave * SUBS + sub, 4 * SUBS, sl);
+        float4 acc = gather_range<D, U, CONTIG, W>(p, beg, end, wave * SUBS + sub, 4 * SUBS, sl, coff);
         acc = reduce_groups<D>(acc);
         if (sub == 0) st4(&red[wave][sl * 4], acc);
         __syncthreads();
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
             acc = add4(add4(ld4(&red[0][sl * 4]), ld4(&red[1][sl * 4])),
                        add4(ld4(&red[2][sl * 4]), ld4(&red[3][sl * 4])));
         if (nseg == 1) {
-            if (owner) finish_row(p, row, acc, sl, D);
+            if (owner) finish_row(p, row, acc, sl, W, coff);
             return;
         }
         // Split row.  Publish this segment's partial sum WRITE-THROUGH (agent-scope relaxed stores = sc1, no
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
                 q.w = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s = add4(s, q);
             }
-            finish_row(p, row, s, sl, D);
+            finish_row(p, row, s, sl, W, coff);
         }
         return;
     }
@@ -265,9 +273,9 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         const int slot = (vb - gp.n_tasks) * 4 + wave;
         if (slot >= gp.n_wave) return;
         const int4 dsc = *reinterpret_cast<const int4 *>(&p.desc[gp.pos_wave + slot]);
-        float4 acc = gather_range<D, U, CONTIG>(p, dsc.y, dsc.z, sub, SUBS, sl);
+        float4 acc = gather_range<D, U, CONTIG, W>(p, dsc.y, dsc.z, sub, SUBS, sl, coff);
         acc = reduce_groups<D>(acc);
-        if (sub == 0) finish_row(p, dsc.x, acc, sl, D);
+        if (sub == 0) finish_row(p, dsc.x, acc, sl, W, coff);
         return;
     }
 
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     const int slot = ((vb - gp.n_tasks - blocks_wave) * 4 + wave) * SUBS + sub;
     if (slot >= gp.n_short) return;
     const int4 dsc = *reinterpret_cast<const int4 *>(&p.desc[gp.pos_short + slot]);
-    const float4 acc = gather_range<D, U, CONTIG>(p, dsc.y, dsc.z, 0, 1, sl);
-    finish_row(p, dsc.x, acc, sl, D);
+    const float4 acc = gather_range<D, U, CONTIG, W>(p, dsc.y, dsc.z, 0, 1, sl, coff);
+    finish_row(p, dsc.x, acc, sl, W, coff);
 }
 
 // Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
@@ -401,8 +409,38 @@ static int64_t grid_for(const rbg_graph *g) {
     return group_blocks(g->groups[0], SUBS);
 }
 
+// Column-half launch of a width-2H problem: XCD x serves group x / 4, column half x & 1, as XCD (x % 4) / 2 of 2.
+template <int H>
+static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
+    constexpr int SUBS = 64 / (H / 4);
+    int64_t m = 0;
+    for (int x = 0; x < 8; ++x) {
+        p.xmap.grp[x] = (uint8_t)(x / 4);
+        p.xmap.idx[x] = (uint8_t)((x % 4) / 2);
+        p.xmap.cnt[x] = 2;
+        m = std::max(m, (group_blocks(g->groups[x / 4], SUBS) + 1) / 2);
+    }
+    const int64_t grid = 8 * m;
+    if (grid == 0) return RBG_OK;
+    if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
+    const dim3 gr((unsigned)grid), bl(256);
+    if (spmm_unroll() == 8) hipLaunchKernelGGL((spmm_binned_kernel<H, 8, true, true>), gr, bl, 0, s, p);
+    else hipLaunchKernelGGL((spmm_binned_kernel<H, 4, true, true>), gr, bl, 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
 template <int D>
 static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
+    if constexpr (D == 64 || D == 128) {
+        // default class split (users on XCDs 0-3, items on 4-7), contiguous rows, no split rows: eligible for column halves
+        // auto: only at d = 128 (measured r01, Gowalla shape: 86.4 -> 77.8 us; at d = 64 the doubled CSR / index work costs
+        // more than the better L2 hit rate returns: 42.0 -> 49.8 us)
+        const int cs = opt_col_split();
+        if ((cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && g->n_split_rows == 0 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
+            g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1)
+            return launch_binned_half<D / 2>(g, p, s);
+    }
     const int64_t grid = grid_for<D>(g);
     if (grid == 0) return RBG_OK;
     if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");

@@ -189,9 +189,64 @@ def test_hub_rows_at_scale(rbg, cuda):
     close(mean, acc / 4.0)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_spmm_column_half_mode(rbg, cuda, d):
+    """"col_split": even / odd XCDs own the lower / upper half of the columns (auto at d = 128).  Same result as the
+    full-width mode up to the summation grouping (both against float64), through every epilogue (plain, accumulate,
+    fused layer mean, backward chain); a graph with split rows must silently keep the full-width mode."""
+    nu, ni, e = 3001, 2201, 60_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=5)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    assert h.bins(d)["n_split_rows"] == 0
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    n = nu + ni
+    x = randn((n, d), 3, cuda)
+    truth = O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rowptr, col, val)
+    res = {}
+    try:
+        for mode in (0, 1):
+            rbg.set_option("col_split", mode)
+            y = rbg.ops.spmm_raw(h, x)
+            close(y, truth)
+            acc = torch.ones(n, d, device=cuda)
+            rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
+            close(acc, truth + 1.0)
+            uw, iw = x[:nu].contiguous(), x[nu:].contiguous()
+            mean, layers = rbg.ops.lightgcn_forward_raw(h, uw, iw, 3, keep_layers=True)
+            xg = x.clone().requires_grad_(True)
+            out = rbg.ops._LightGCNForward.apply(xg[:nu], xg[nu:], 3, h)
+            out.backward(torch.ones_like(out))
+            res[mode] = (y, mean, layers.clone(), xg.grad.clone())
+        for a, b in zip(res[0], res[1]):
+            close(a, b, tol=2e-6)
+        # hub row longer than seg_len -> split rows -> the launch falls back to full width: bit-identical either way
+        hub_u = np.concatenate([uid, np.full(5000, 1, dtype=np.int64)])
+        hub_i = np.concatenate([iid, (np.arange(5000) % (ni - 1) + 1).astype(np.int64)])
+        rbg.set_tuning(64, 256, 1024)
+        hh = rbg.GraphHandle.from_interactions(hub_u, hub_i, nu, ni, device=cuda)
+        assert hh.bins(d)["n_split_rows"] > 0
+        rbg.set_option("col_split", 1)
+        y_on = rbg.ops.spmm_raw(hh, x)
+        rbg.set_option("col_split", 0)
+        assert torch.equal(y_on, rbg.ops.spmm_raw(hh, x))
+    finally:
+        rbg.set_option("col_split", -1)
+        rbg.set_tuning(64, 256, 4096)
+
+
 @pytest.mark.parametrize("n_parts", [2, 4, 8])
 def test_community_partition_changes_only_the_launch_plan(rbg, cuda, n_parts):
     """rbg_graph_create_partitioned: pinning communities to XCDs must give bit-identical results."""
+    # the column-half mode (auto at d = 128) groups a wave row's entries differently: bit-identity across launch plans
+    # is a property within one summation scheme, so it is pinned off here (test_spmm_column_half_mode covers it)
+    rbg.set_option("col_split", 0)
+    try:
+        _community_partition_body(rbg, cuda, n_parts)
+    finally:
+        rbg.set_option("col_split", -1)
+
+
+def _community_partition_body(rbg, cuda, n_parts):
     nu, ni, e = 1201, 2401, 40_000
     uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=9, n_blocks=n_parts, p_in=0.9)
     part = rbg.sharded.striped_partition(nu, ni, n_parts)
