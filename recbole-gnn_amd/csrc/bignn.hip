@@ -42,6 +42,7 @@ struct BignnParams {
     int d_in, d_out;
     int leaky_norm;
     float slope;
+    float *inv_norm;  // optional [N]: 1 / max(||LeakyReLU(z)||, eps) per row, what the tail's backward needs
 };
 
 // 32 floats of a row starting at k0.  FAST: the run is fully inside the row and 16-byte aligned.
@@ -202,6 +203,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(con
                 const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] *= inv;
+                const int64_t nrow = tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (p.inv_norm && i == 0 && nrow < p.n_rows) p.inv_norm[nrow] = inv;
             }
             const int64_t row = tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (row < p.n_rows) {
@@ -241,9 +244,9 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
 
 using namespace rbg;
 
-extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
-                                  const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, int d_in,
-                                  int d_out, uint32_t flags, float slope, void *stream) {
+static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
+                           const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm, int d_in, int d_out,
+                           uint32_t flags, float slope, void *stream) {
     clear_error();
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
@@ -273,6 +276,7 @@ extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ld
     p.d_out = d_out;
     p.leaky_norm = (flags & RBG_BIGNN_LEAKY_NORM) ? 1 : 0;
     p.slope = slope;
+    p.inv_norm = p.leaky_norm ? inv_norm : nullptr;
     const int fast = (d_in % 64 == 0) && (ldx % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P_save) | reinterpret_cast<uintptr_t>(W1) |
                        reinterpret_cast<uintptr_t>(W2)) & 15u) == 0;
@@ -280,4 +284,17 @@ extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ld
     if (d_out <= 64) return launch_dense<2>(p, fast, s);
     if (d_out <= 128) return launch_dense<4>(p, fast, s);
     return launch_dense<8>(p, fast, s);
+}
+
+extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
+                                  const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, int d_in,
+                                  int d_out, uint32_t flags, float slope, void *stream) {
+    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, nullptr, d_in, d_out, flags, slope, stream);
+}
+
+extern "C" int rbg_bignn_layer_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
+                                   const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm,
+                                   int d_in, int d_out, float slope, void *stream) {
+    if (!inv_norm) return fail(RBG_EINVAL, "inv_norm is NULL: the caller provides the [N] buffer the backward needs");
+    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, inv_norm, d_in, d_out, RBG_BIGNN_LEAKY_NORM, slope, stream);
 }

@@ -217,6 +217,220 @@ static int launch_wgrad_o(const WgradParams &p, bool fast, int64_t grid, hipStre
     return launch_wgrad<TO, 4>(p, fast, grid, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input-side gradients of one NGCF layer (autograd of layers.py:54-58 followed by ngcf.py:96,98), per 32-row tile:
+//   G  = dL/dz:  tail backward of y = normalize(LeakyReLU(z)) from the saved output y and 1/||a|| (or G = dL/dy)
+//   gt = G W1,  gi = G W2                               (MFMA, k = d_out)
+//   GP = gt + gi ⊙ X   (to be propagated: dX += Â^T GP),   GX = gt + gi ⊙ P   (the direct part of dX)
+// G is also written out: it is the operand of the weight-gradient kernel above.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DgradParams {
+    const float *GY;
+    int64_t ldgy;
+    const float *Y;  // saved layer output (tail only)
+    int64_t ldy;
+    const float *inv_norm;  // [N] or NULL (no tail)
+    const float *X;
+    int64_t ldx;
+    const float *P;          // [N, d_in]
+    const float *Wt1, *Wt2;  // TRANSPOSED weights [d_in, d_out] (wt_transpose_kernel)
+    float *G;                // [N, d_out] out
+    float *GP, *GX;          // [N, d_in] out
+    int64_t n_rows;
+    int d_in, d_out;
+    float slope;
+};
+
+// Wt[c][j] = W[j][c]
+__global__ void wt_transpose_kernel(const float *__restrict__ W1, const float *__restrict__ W2, int d_out, int d_in,
+                                    float *__restrict__ Wt1, float *__restrict__ Wt2) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= d_out * d_in) return;
+    const int c = x / d_out, j = x % d_out;
+    Wt1[x] = W1[j * d_in + c];
+    Wt2[x] = W2[j * d_in + c];
+}
+
+// TI = 32-column tiles of d_in held by a wave; NCO = 64-wide k chunks of d_out.  FAST: d_out a multiple of 64, 16-byte
+// aligned rows.  LDS: Wl[2][32 TI][KP], KP = 64 NCO + 4 (rows = input column c, k = output feature j).
+template <int TI, int NCO, bool FAST>
+__global__ __launch_bounds__(256, (TI <= 2 && NCO == 1 ? 2 : 1)) void bignn_dgrad_kernel(const DgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float Wl[];
+    constexpr int DP = 32 * TI, KP = 64 * NCO + 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (p.n_rows + 31) / 32;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = tile < n_tiles;
+    const int64_t row_i = live ? min(tile * 32 + i, p.n_rows - 1) : 0;  // clamped: rows past the end are masked at the stores
+
+    // this lane's runs of dL/dy and y go out first (their latency hides under the weight staging)
+    float gy[NCO][32], yv[NCO][32];
+    auto load_run = [&](const float *row, const int k0, float (&r)[32]) __attribute__((always_inline)) {
+        if (FAST) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(row + k0 + 4 * q);
+                r[4 * q + 0] = v.x, r[4 * q + 1] = v.y, r[4 * q + 2] = v.z, r[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 32; ++s) r[s] = (k0 + s < p.d_out) ? row[k0 + s] : 0.f;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        load_run(p.GY + row_i * p.ldgy, 64 * c + 32 * h, gy[c]);
+        if (p.inv_norm) load_run(p.Y + row_i * p.ldy, 64 * c + 32 * h, yv[c]);
+    }
+    // stage the transposed weights, coalesced, a batch of loads in flight at a time (zero-padded)
+    {
+        const int slots_per_row = NCO * 16, per_part = DP * slots_per_row, total = 2 * per_part;
+        constexpr int BATCH = 8;
+        for (int f0 = threadIdx.x; f0 < total; f0 += 256 * BATCH) {
+            float4 w[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + 256 * u;
+                w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < total) {
+                    const int part = f >= per_part, g = f - part * per_part;
+                    const int c = g / slots_per_row, k = 4 * (g % slots_per_row);
+                    if (c < p.d_in) {
+                        const float *src = (part ? p.Wt2 : p.Wt1) + (int64_t)c * p.d_out + k;
+                        if (FAST) {
+                            w[u] = *reinterpret_cast<const float4 *>(src);
+                        } else {
+                            if (k + 0 < p.d_out) w[u].x = src[0];
+                            if (k + 1 < p.d_out) w[u].y = src[1];
+                            if (k + 2 < p.d_out) w[u].z = src[2];
+                            if (k + 3 < p.d_out) w[u].w = src[3];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int f = f0 + 256 * u;
+                if (f < total) {
+                    const int part = f >= per_part, g = f - part * per_part;
+                    *reinterpret_cast<float4 *>(Wl + (part * DP + g / slots_per_row) * KP + 4 * (g % slots_per_row)) = w[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    // G = dL/dz in the fragment layout (lane = row, registers = a 32-wide k run)
+    if (p.inv_norm) {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) dot = fmaf(gy[c][s], yv[c][s], dot);
+        dot += __shfl_xor(dot, 32);  // the other half of the row
+        const float inv = p.inv_norm[row_i];
+        const bool clamped = inv >= 1e12f;  // ||a|| < eps: normalize is a / eps, a plain scaling
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                const float y = yv[c][s];
+                const float da = (clamped ? gy[c][s] : gy[c][s] - y * dot) * inv;
+                gy[c][s] = y > 0.f ? da : da * p.slope;  // sign(z) = sign(y); LeakyReLU'(0) = slope as in torch
+            }
+    }
+    if (tile * 32 + i < p.n_rows) {
+        float *grow = p.G + (tile * 32 + i) * (int64_t)p.d_out;
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+            const int k0 = 64 * c + 32 * h;
+            if (FAST) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<float4 *>(grow + k0 + 4 * q) =
+                        make_float4(gy[c][4 * q + 0], gy[c][4 * q + 1], gy[c][4 * q + 2], gy[c][4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 32; ++s)
+                    if (k0 + s < p.d_out) grow[k0 + s] = gy[c][s];
+            }
+        }
+    }
+    f32x16 at[TI], ai[TI];
+#pragma unroll
+    for (int t = 0; t < TI; ++t) {
+        at[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ai[t] = at[t];
+    }
+#pragma unroll
+    for (int c = 0; c < NCO; ++c) {
+        const float *w1 = Wl + (0 * DP + i) * KP + c * 64 + 32 * h;
+        const float *w2 = Wl + (1 * DP + i) * KP + c * 64 + 32 * h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const float4 a = *reinterpret_cast<const float4 *>(w1 + t * 32 * KP + 4 * q);
+                const float4 b = *reinterpret_cast<const float4 *>(w2 + t * 32 * KP + 4 * q);
+                at[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 0], a.x, at[t], 0, 0, 0);
+                ai[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 0], b.x, ai[t], 0, 0, 0);
+                at[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 1], a.y, at[t], 0, 0, 0);
+                ai[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 1], b.y, ai[t], 0, 0, 0);
+                at[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 2], a.z, at[t], 0, 0, 0);
+                ai[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 2], b.z, ai[t], 0, 0, 0);
+                at[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 3], a.w, at[t], 0, 0, 0);
+                ai[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(gy[c][4 * q + 3], b.w, ai[t], 0, 0, 0);
+            }
+        }
+    }
+    // C layout: col = 32 t + (lane & 31) = input column, row = (reg & 3) + 8 (reg >> 2) + 4 h
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int64_t row = tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row < p.n_rows) {
+#pragma unroll
+            for (int t = 0; t < TI; ++t) {
+                const int c = t * 32 + i;
+                if (c < p.d_in) {
+                    const float gt = at[t][reg], gi = ai[t][reg];
+                    const float x = p.X[row * p.ldx + c], pv = p.P[row * (int64_t)p.d_in + c];
+                    p.GP[row * (int64_t)p.d_in + c] = fmaf(gi, x, gt);   // d/dP
+                    p.GX[row * (int64_t)p.d_in + c] = fmaf(gi, pv, gt);  // direct d/dX
+                }
+            }
+        }
+    }
+}
+
+template <int TI, int NCO>
+static int launch_dgrad(const DgradParams &p, bool fast, hipStream_t s) {
+    const size_t lds = (size_t)2 * 32 * TI * (64 * NCO + 4) * sizeof(float);
+    if (lds > 64 * 1024) {
+        RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dgrad_kernel<TI, NCO, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dgrad_kernel<TI, NCO, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    const int64_t grid = std::max<int64_t>(1, ((p.n_rows + 31) / 32 + 3) / 4);
+    if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
+    if (fast)
+        hipLaunchKernelGGL((bignn_dgrad_kernel<TI, NCO, true>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL((bignn_dgrad_kernel<TI, NCO, false>), dim3((unsigned)grid), dim3(256), lds, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+template <int TI>
+static int launch_dgrad_i(const DgradParams &p, bool fast, hipStream_t s) {
+    if (p.d_out <= 64) return launch_dgrad<TI, 1>(p, fast, s);
+    return launch_dgrad<TI, 2>(p, fast, s);
+}
+
+static int64_t up256(int64_t x) { return (x + 255) / 256 * 256; }
+
 }  // namespace rbg
 
 using namespace rbg;
@@ -262,6 +476,56 @@ int rbg_bignn_wgrad_f32(const float *G, int64_t ldg, const float *P, const float
                        dW1, dW2, db);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+int rbg_bignn_backward_workspace(int64_t n_rows, int d_in, int d_out, int64_t *bytes) {
+    if (!bytes || n_rows < 0 || d_in <= 0 || d_out <= 0) return fail(RBG_EINVAL, "bad argument");
+    int64_t wg = 0;
+    rbg_bignn_wgrad_workspace(n_rows, d_in, d_out, &wg);
+    *bytes = up256(2 * (int64_t)d_in * d_out * 4) + up256(n_rows * d_out * 4) + up256(n_rows * d_in * 4) + wg + 256;
+    return RBG_OK;
+}
+
+int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, const float *Y, int64_t ldy,
+                           const float *inv_norm, const float *X, int64_t ldx, const float *P, const float *W1,
+                           const float *W2, int d_in, int d_out, float slope, float *GX, float *dW1, float *dW2, float *db,
+                           void *workspace, void *stream) {
+    clear_error();
+    if (!g_t) return fail(RBG_EINVAL, "graph is NULL");
+    if (g_t->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
+    if (g_t->n_rows != g_t->n_cols) return fail(RBG_ESHAPE, "graph is not square");
+    const int64_t n = g_t->n_rows;
+    if (d_in <= 0 || d_out <= 0 || ldgy < d_out || ldx < d_in || (inv_norm && ldy < d_out))
+        return fail(RBG_ESHAPE, "d_in = %d, d_out = %d, ldgy = %lld, ldy = %lld, ldx = %lld", d_in, d_out, (long long)ldgy,
+                    (long long)ldy, (long long)ldx);
+    if (d_in > 128 || d_out > 128) return fail(RBG_EUNSUPPORTED, "bignn_backward: d_in = %d, d_out = %d (both <= 128)", d_in, d_out);
+    if (n == 0) return RBG_OK;
+    if (!GY || !X || !P || !W1 || !W2 || !GX || !dW1 || !dW2 || !workspace || (inv_norm && !Y))
+        return fail(RBG_EINVAL, "NULL pointer");
+    int rc = set_device_for(g_t->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    char *w = reinterpret_cast<char *>(workspace);
+    float *Wt1 = reinterpret_cast<float *>(w), *Wt2 = Wt1 + (int64_t)d_in * d_out;
+    w += up256(2 * (int64_t)d_in * d_out * 4);
+    float *G = reinterpret_cast<float *>(w);
+    w += up256(n * d_out * 4);
+    float *GP = reinterpret_cast<float *>(w);
+    w += up256(n * d_in * 4);
+    const int wn = d_in * d_out;
+    hipLaunchKernelGGL(wt_transpose_kernel, dim3((unsigned)((wn + 255) / 256)), dim3(256), 0, s, W1, W2, d_out, d_in, Wt1, Wt2);
+    RBG_HIP(hipGetLastError());
+    DgradParams p{};
+    p.GY = GY, p.ldgy = ldgy, p.Y = Y, p.ldy = ldy, p.inv_norm = inv_norm, p.X = X, p.ldx = ldx, p.P = P;
+    p.Wt1 = Wt1, p.Wt2 = Wt2, p.G = G, p.GP = GP, p.GX = GX, p.n_rows = n, p.d_in = d_in, p.d_out = d_out, p.slope = slope;
+    const bool fast = (d_out % 64 == 0) && (ldgy % 4 == 0) && (!inv_norm || ldy % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(GY) | reinterpret_cast<uintptr_t>(Y)) & 15u) == 0;
+    if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
+    else if (d_in <= 64) rc = launch_dgrad_i<2>(p, fast, s);
+    else rc = launch_dgrad_i<4>(p, fast, s);
+    if (rc) return rc;
+    if ((rc = rbg_bignn_wgrad_f32(G, d_out, P, X, ldx, n, d_in, d_out, dW1, dW2, db, w, stream))) return rc;
+    return spmm_strided(g_t, GP, d_in, GX, d_in, d_in, 1, s);  // dX = GX + Â^T GP
 }
 
 }  // extern "C"

@@ -206,6 +206,7 @@ class NGCF(GeneralGraphRecommender):
         self.node_dropout = config["node_dropout"] or 0.0
         self.message_dropout = config["message_dropout"] or 0.0
         self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
+        self.fused = config["fused_forward"] if config["fused_forward"] is not None else True  # False: op-by-op like ngcf.py
         if self.node_dropout != 0:
             raise NotImplementedError("node_dropout > 0 (ngcf.py:74-90) is outside the accelerated path")
         self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)
@@ -228,6 +229,15 @@ class NGCF(GeneralGraphRecommender):
             return self._forward_fused()
         all_embeddings = self.get_ego_embeddings()
         embeddings_list = [all_embeddings]
+        if (self.fused and self.message_dropout == 0 and isinstance(self.graph, ops.GraphHandle)
+                and max(self.hidden_size_list) <= 128):
+            # training: each layer with its LeakyReLU + normalize tail is one forward and one backward library call
+            for gnn in self.GNNlayers:
+                all_embeddings = ops.bignn_layer(all_embeddings, gnn.lin1.weight, gnn.lin1.bias, gnn.lin2.weight, gnn.lin2.bias,
+                                                 self.graph, 0.2)
+                embeddings_list += [all_embeddings]
+            ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
+            return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])
         for gnn in self.GNNlayers:
             all_embeddings = gnn(all_embeddings, self.graph, None)
             all_embeddings = F.leaky_relu(all_embeddings, negative_slope=0.2)

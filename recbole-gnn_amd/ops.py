@@ -261,6 +261,56 @@ class _BiGNNConv(torch.autograd.Function):
         return gx, gw1, gb, gw2, gb, None
 
 
+class _BiGNNLayer(torch.autograd.Function):
+    """One NGCF layer with its tail — BiGNNConv -> LeakyReLU(slope) -> F.normalize (layers.py:54-58, ngcf.py:96,98) — as
+    one forward call (rbg_bignn_layer_f32) and one backward call (rbg_bignn_backward_f32: tail backward, the two
+    G·W products, the weight / bias gradients and the propagated input gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, graph, slope):
+        _require_device_graph(graph)
+        _check_dense(x, "x", graph)
+        x = x if x.stride(1) == 1 else x.contiguous()
+        w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        n, d_in = x.shape
+        d_out = w1.shape[0]
+        y = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+        p = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
+        inv = torch.empty(n, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.rbg_bignn_layer_f32(graph.ptr, c_vp(x.data_ptr()), x.stride(0) if n > 1 else d_in, c_vp(w1.data_ptr()),
+                                          c_vp(b1.data_ptr()), c_vp(w2.data_ptr()), c_vp(b2.data_ptr()), c_vp(y.data_ptr()), d_out,
+                                          c_vp(p.data_ptr()), c_vp(inv.data_ptr()), d_in, d_out, float(slope), _stream(x)))
+        ctx.graph, ctx.slope = graph, float(slope)
+        ctx.save_for_backward(x, p, y, inv, w1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, p, y, inv, w1, w2 = ctx.saved_tensors
+        gy = gy if gy.stride(1) == 1 else gy.contiguous()
+        n, d_in = x.shape
+        d_out = w1.shape[0]
+        gx = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        gb = torch.empty(d_out, dtype=torch.float32, device=x.device)
+        nbytes = _lib.c_i64()
+        check(lib.rbg_bignn_backward_workspace(n, d_in, d_out, ctypes.byref(nbytes)))
+        work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.rbg_bignn_backward_f32(ctx.graph.transpose().ptr, c_vp(gy.data_ptr()), gy.stride(0) if n > 1 else d_out,
+                                             c_vp(y.data_ptr()), d_out, c_vp(inv.data_ptr()), c_vp(x.data_ptr()),
+                                             x.stride(0) if n > 1 else d_in, c_vp(p.data_ptr()), c_vp(w1.data_ptr()),
+                                             c_vp(w2.data_ptr()), d_in, d_out, ctx.slope, c_vp(gx.data_ptr()), c_vp(gw1.data_ptr()),
+                                             c_vp(gw2.data_ptr()), c_vp(gb.data_ptr()), c_vp(work.data_ptr()), _stream(x)))
+        return gx, gw1, gb, gw2, gb, None, None
+
+
+def bignn_layer(x, w1, b1, w2, b2, graph, slope=0.2):
+    """normalize(LeakyReLU(BiGNNConv(x))) with fused forward and backward; d_in, d_out <= 128."""
+    return _BiGNNLayer.apply(x, w1, b1, w2, b2, graph, float(slope))
+
+
 class BiGNNConv(nn.Module):
     """recbole_gnn/model/layers.py:41-67: lin1(ÂX + X) + lin2(ÂX ⊙ X)."""
 

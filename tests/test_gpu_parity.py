@@ -896,6 +896,61 @@ def test_graphed_step_matches_eager(rbg, cuda, golden, name):
         assert abs(lg - le) <= 2e-4 * max(1.0, abs(le))
 
 
+@pytest.mark.parametrize("n,d_in,d_out", [(1, 8, 8), (33, 16, 24), (500, 64, 64), (257, 20, 50), (300, 128, 64), (129, 64, 128)])
+def test_bignn_layer_forward_backward(rbg, cuda, n, d_in, d_out):
+    """ops.bignn_layer = normalize(LeakyReLU(BiGNNConv(x))) (layers.py:54-58, ngcf.py:96,98): value and all five gradients
+    against float64 autograd of the same expression on the oracle's dense operator."""
+    rng = np.random.default_rng(n + d_in)
+    nu = max(1, n // 2)
+    ni = n - nu + 1 if n > 1 else 1
+    nu = n - ni if n > 1 else 0
+    if n == 1:
+        uid, iid, nu, ni = np.empty(0, dtype=np.int64), np.empty(0, dtype=np.int64), 0, 1
+    else:
+        e = 6 * n
+        uid, iid = rng.integers(0, nu, e), rng.integers(0, ni, e)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    rp, c, v = h.export_csr()
+    dense = torch.zeros(n, n, dtype=torch.float64)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    dense.index_put_((torch.from_numpy(rows), torch.from_numpy(c.astype(np.int64))), torch.from_numpy(v.astype(np.float64)), accumulate=True)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, d_in, generator=gen)
+    w1, w2 = torch.randn(d_out, d_in, generator=gen) * 0.3, torch.randn(d_out, d_in, generator=gen) * 0.3
+    b1, b2 = torch.randn(d_out, generator=gen) * 0.1, torch.randn(d_out, generator=gen) * 0.1
+    up = torch.randn(n, d_out, generator=gen)
+    ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xr, w1r, b1r, w2r, b2r = ref_in
+    pr = dense @ xr
+    zr = (pr + xr) @ w1r.T + b1r + (pr * xr) @ w2r.T + b2r
+    yr = torch.nn.functional.normalize(torch.nn.functional.leaky_relu(zr, 0.2), p=2, dim=1)
+    (yr * up.double()).sum().backward()
+    got_in = [t.to(cuda).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = rbg.ops.bignn_layer(*got_in, h, 0.2)
+    (y * up.to(cuda)).sum().backward()
+    close(y, yr.detach().float(), tol=2e-5)
+    for got, ref, name in zip(got_in, ref_in, ("x", "w1", "b1", "w2", "b2")):
+        scale = max(1.0, float(ref.grad.abs().max()))
+        err = float((got.grad.cpu().double() - ref.grad).abs().max())
+        assert err <= 3e-5 * scale, (name, err, scale)
+
+
+def test_ngcf_fused_training_path_matches_op_by_op(rbg, cuda, golden):
+    """NGCF.calculate_loss through the fused layers (default) and through the op-by-op structure of ngcf.py:92-104
+    (fused_forward=False): same loss, same gradients."""
+    ma, _ = make_model(rbg, rbg.NGCF, cuda, golden, enable_sparse=True, reg_weight=1e-4)
+    mb, _ = make_model(rbg, rbg.NGCF, cuda, golden, enable_sparse=True, reg_weight=1e-4, fused_forward=False)
+    mb.load_state_dict(ma.state_dict())
+    ma.train(), mb.train()
+    batch = {"user_id": torch.tensor([1, 2, 3, 9, 2], device=cuda), "item_id": torch.tensor([1, 4, 3, 7, 8], device=cuda),
+             "neg_item_id": torch.tensor([5, 6, 2, 11, 30], device=cuda)}
+    la, lb = ma.calculate_loss(batch), mb.calculate_loss(batch)
+    la.backward(), lb.backward()
+    close(la.detach().reshape(()), lb.detach().reshape(()), tol=1e-5)
+    for (na, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        close(pa.grad, pb.grad, tol=2e-5)
+
+
 # ---- scoring GEMM ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("shape", [(1, 1125, 64), (3, 1125, 64), (130, 1000, 64), (33, 70, 256), (5, 40, 128),
