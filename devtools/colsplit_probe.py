@@ -10,7 +10,7 @@ def timed(fn, iters=200):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) * 1e3 / iters
-for shape, d in (("gowalla", 64), ("yelp2018", 64), ("amazon-book", 64), ("gowalla", 128)):
+for shape, d in (("gowalla", 64), ("yelp2018", 64), ("amazon-book", 64), ("gowalla", 128), ("yelp2018", 128), ("amazon-book", 128)):
     uid, iid, nu, ni = rbg.synth.make(shape)
     g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     n = nu + ni

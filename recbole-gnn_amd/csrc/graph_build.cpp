@@ -329,7 +329,8 @@ int upload_plan(rbg_graph *g) {
     const size_t pb = std::max<size_t>((size_t)plan.n_slots, 1) * kPartialSlotFloats * sizeof(float);
     hipError_t e = hipMalloc((void **)&g->d_partials, pb);
     if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", pb, hipGetErrorString(e));
-    const size_t cb = std::max<size_t>((size_t)plan.n_split, 1) * sizeof(uint32_t);
+    // two arrival counters per split row: the column-half SpMM mode finishes each half of a row on its own
+    const size_t cb = 2 * std::max<size_t>((size_t)plan.n_split, 1) * sizeof(uint32_t);
     e = hipMalloc((void **)&g->d_counters, cb);
     if (e != hipSuccess) return fail(RBG_ENOMEM, "hipMalloc(%zu bytes) failed: %s", cb, hipGetErrorString(e));
     RBG_HIP(hipMemset(g->d_counters, 0, cb));

@@ -49,7 +49,8 @@ struct SpmmParams {
     const RowDesc *desc;
     const BlockTask *tasks;
     float *partials;
-    uint32_t *counters;
+    uint32_t *counters;   // [2][n_split]: second set for the upper column half in column-half mode
+    int32_t n_split;
     RowSrc x;
     float *y;  // may be NULL in MODE_MEAN
     int64_t ldy;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         // to arrive re-reads all partials with agent-scope loads (served past L1) and adds them in segment
         // order, so the result does not depend on arrival order (MI355X guide §6 G16, form R1).
         if (owner) {
-            float *dst = p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + sl * 4;
+            float *dst = p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + coff + sl * 4;
             __hip_atomic_store(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -245,17 +246,18 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(p.counters + ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t *arrivals = p.counters + ctr + (coff ? p.n_split : 0);
+            const unsigned old = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (old == (unsigned)(nseg - 1));
             if (last)  // self-cleaning: the next (stream-ordered) launch finds the counter at zero
-                __hip_atomic_store(p.counters + ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_flag = last;
         }
         __syncthreads();
         if (last_flag && owner) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int i = 0; i < nseg; ++i) {
-                const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + sl * 4;
+                const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + coff + sl * 4;
                 float4 q;
                 q.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -384,6 +386,7 @@ static void fill_graph(const rbg_graph *g, SpmmParams &p) {
     p.tasks = g->d_tasks;
     p.partials = g->d_partials;
     p.counters = g->d_counters;
+    p.n_split = (int32_t)g->n_split_rows;
     p.n_rows = (int32_t)g->n_rows;
     p.n_groups = g->n_groups;
     p.xmap = g->xmap;
@@ -433,11 +436,11 @@ static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s) 
 template <int D>
 static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     if constexpr (D == 64 || D == 128) {
-        // default class split (users on XCDs 0-3, items on 4-7), contiguous rows, no split rows: eligible for column halves
+        // default class split (users on XCDs 0-3, items on 4-7), contiguous rows: eligible for column halves
         // auto: only at d = 128 (measured r01, Gowalla shape: 86.4 -> 77.8 us; at d = 64 the doubled CSR / index work costs
         // more than the better L2 hit rate returns: 42.0 -> 49.8 us)
         const int cs = opt_col_split();
-        if ((cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && g->n_split_rows == 0 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
+        if ((cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
             g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1)
             return launch_binned_half<D / 2>(g, p, s);
     }

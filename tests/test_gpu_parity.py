@@ -193,7 +193,7 @@ def test_hub_rows_at_scale(rbg, cuda):
 def test_spmm_column_half_mode(rbg, cuda, d):
     """"col_split": even / odd XCDs own the lower / upper half of the columns (auto at d = 128).  Same result as the
     full-width mode up to the summation grouping (both against float64), through every epilogue (plain, accumulate,
-    fused layer mean, backward chain); a graph with split rows must silently keep the full-width mode."""
+    fused layer mean, backward chain), including rows split into segments."""
     nu, ni, e = 3001, 2201, 60_000
     uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=5)
     h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
@@ -219,16 +219,18 @@ def test_spmm_column_half_mode(rbg, cuda, d):
             res[mode] = (y, mean, layers.clone(), xg.grad.clone())
         for a, b in zip(res[0], res[1]):
             close(a, b, tol=2e-6)
-        # hub row longer than seg_len -> split rows -> the launch falls back to full width: bit-identical either way
-        hub_u = np.concatenate([uid, np.full(5000, 1, dtype=np.int64)])
-        hub_i = np.concatenate([iid, (np.arange(5000) % (ni - 1) + 1).astype(np.int64)])
+        # hub rows longer than seg_len -> split rows: each column half collects its own partial sums and arrivals
+        hub_u = np.concatenate([uid, np.full(5000, 1, dtype=np.int64), np.full(3000, 7, dtype=np.int64)])
+        hub_i = np.concatenate([iid, (np.arange(5000) % (ni - 1) + 1).astype(np.int64), (np.arange(3000) * 3 % (ni - 1) + 1).astype(np.int64)])
         rbg.set_tuning(64, 256, 1024)
         hh = rbg.GraphHandle.from_interactions(hub_u, hub_i, nu, ni, device=cuda)
         assert hh.bins(d)["n_split_rows"] > 0
-        rbg.set_option("col_split", 1)
-        y_on = rbg.ops.spmm_raw(hh, x)
-        rbg.set_option("col_split", 0)
-        assert torch.equal(y_on, rbg.ops.spmm_raw(hh, x))
+        hr, hc, hv = C.build_norm_csr(hub_u, hub_i, nu, ni)
+        hub_truth = O.conv_csr_f64(x.cpu().numpy().astype(np.float64), hr, hc, hv)
+        for mode in (1, 0, 1):
+            rbg.set_option("col_split", mode)
+            for _ in range(3):  # counters are self-cleaning: repeated launches stay correct
+                close(rbg.ops.spmm_raw(hh, x), hub_truth)
     finally:
         rbg.set_option("col_split", -1)
         rbg.set_tuning(64, 256, 4096)
