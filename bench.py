@@ -317,7 +317,7 @@ def main():
                        "sharding": "none" if world == 1 else f"node-range x{world}, transport={transport}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
-                         "kernel": "spmm_binned_kernel<64,8,true>", "avg_launch_us": launch_us,
+                         "kernel": "spmm_binned_kernel<64, 8, true, false>", "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "
                                  "time of the timed region / launches, so inter-kernel gaps and (N>1) halo waits count"},
