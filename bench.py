@@ -132,10 +132,44 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     with torch.no_grad():
         model.full_sort_topk({"user_id": users}, 10)
         ex["full_sort_topk_us(4096 users, k 10, history masked)"] = time_us(lambda: model.full_sort_topk({"user_id": users}, 10), iters=10, warm=2)
+        iw_all = model.restore_item_e if model.restore_item_e is not None else model.forward()[1]
+        uq = torch.randn(4096, d, device=dev)
+        ex["score_gemm_us(4096 users x all items)"] = time_us(lambda: rbg.score(uq, iw_all), iters=20, warm=3)
     t0 = time.perf_counter()
     rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     torch.cuda.synchronize()
     ex["graph_build_device_ms"] = (time.perf_counter() - t0) * 1e3
+    # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
+    try:
+        cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-5,
+               "hidden_size_list": [d] * 3}
+        ngcf = rbg.NGCF(cfg, ds)
+        ngcf.train()
+        opt = torch.optim.Adam(ngcf.parameters(), lr=1e-3)
+
+        def ngcf_step():
+            opt.zero_grad(set_to_none=True)
+            ngcf.calculate_loss(batch).backward()
+            opt.step()
+
+        ex["ngcf_train_step_us(3 BiGNN layers, batch 2048)"] = time_us(ngcf_step, iters=20, warm=3)
+        with torch.no_grad():
+            ex["ngcf_forward_us"] = time_us(lambda: ngcf.forward(), iters=20, warm=3)
+        del ngcf, opt
+        np.random.seed(0)
+        sgl = rbg.SGL({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "type": "ED",
+                       "drop_ratio": 0.1, "ssl_tau": 0.2, "ssl_weight": 0.05, "reg_weight": 1e-4}, ds)
+        sgl.train()
+        opt = torch.optim.Adam(sgl.parameters(), lr=1e-3)
+
+        def sgl_step():
+            opt.zero_grad(set_to_none=True)
+            sgl.calculate_loss(batch).backward()
+            opt.step()
+
+        ex["sgl_train_step_us(ED views, InfoNCE, batch 2048)"] = time_us(sgl_step, iters=10, warm=2)
+    except Exception as e:  # noqa: BLE001  (diagnostics only: never cost the headline its JSON line)
+        ex["model_steps_error"] = str(e)[:200]
     return ex
 
 
