@@ -162,6 +162,11 @@ void rbg_graph_destroy(rbg_graph *g);
  * (Â symmetric):  dL/dX = Â · dL/dY. */
 int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, void *stream);
 
+/* One perturbed layer of SimGCL / XSimGCL (simgcl.py:29-34, xsimgcl.py:34-38):
+ *   Y = Â X;   Y += sign(Y) * F.normalize(noise, dim=-1) * eps        (noise [N, d]: the caller's torch.rand_like draw)
+ * as the SpMM's epilogue.  sign() has zero gradient, so the backward of this op is the plain Â^T product. */
+int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float *noise, int d, float eps, void *stream);
+
 /* Replaces LightGCN.get_ego_embeddings + LightGCN.forward
  *   recbole_gnn/model/general_recommender/lightgcn.py:60-68,70-81  (and SGL.forward,
  *   sgl.py:128-145, where layer k may use its own graph).

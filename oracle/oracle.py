@@ -222,6 +222,38 @@ def ngcf_forward(user_w, item_w, conv, layer_params, slope=0.2):
     return torch.split(cat, [user_w.shape[0], item_w.shape[0]])
 
 
+def simgcl_forward(user_w, item_w, conv, n_layers, noises=None, eps=0.0, layer_cl=None):
+    """SimGCL.forward / XSimGCL.forward — recbole_gnn/model/general_recommender/simgcl.py:24-38, xsimgcl.py:28-48.
+    Layers 1..K only (embeddings_list starts empty); perturbed (noises = the K torch.rand_like draws, in order):
+    e = e + sign(e) * F.normalize(noise, dim=-1) * eps after every product.  layer_cl (XSimGCL): also return the
+    embedding after layer `layer_cl` (the ego embedding if it is outside 1..K)."""
+    all_embs = torch.cat([user_w, item_w], dim=0)
+    all_embs_cl = all_embs
+    embs = []
+    for layer_idx in range(n_layers):
+        all_embs = conv(all_embs)
+        all_embs = all_embs if isinstance(all_embs, torch.Tensor) else torch.from_numpy(np.asarray(all_embs))
+        if noises is not None:
+            all_embs = all_embs + torch.sign(all_embs) * torch.nn.functional.normalize(noises[layer_idx], dim=-1) * eps
+        embs.append(all_embs)
+        if layer_cl is not None and layer_idx == layer_cl - 1:
+            all_embs_cl = all_embs
+    mean = torch.mean(torch.stack(embs, dim=1), dim=1)
+    out = torch.split(mean, [user_w.shape[0], item_w.shape[0]])
+    if layer_cl is not None:
+        return out + torch.split(all_embs_cl, [user_w.shape[0], item_w.shape[0]])
+    return out
+
+
+def simgcl_cl_loss(x1, x2, temperature, reduce="sum"):
+    """calculate_cl_loss — simgcl.py:40-46 (sum) / xsimgcl.py:48-54 (mean)."""
+    x1, x2 = torch.nn.functional.normalize(x1, dim=-1), torch.nn.functional.normalize(x2, dim=-1)
+    pos = torch.exp((x1 * x2).sum(dim=-1) / temperature)
+    ttl = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / temperature).sum(dim=1)
+    v = -torch.log(pos / ttl)
+    return v.sum() if reduce == "sum" else v.mean()
+
+
 def calc_ssl_loss(user_list, pos_item_list, user_sub1, user_sub2, item_sub1, item_sub2, ssl_tau, ssl_weight):
     """SGL.calc_ssl_loss — recbole_gnn/model/general_recommender/sgl.py:176-209, statement by statement
     (normalize; v1 = exp(<a,p>/tau); v2 = sum_j exp(<a,c_j>/tau); -sum log(v1/v2); users then items)."""

@@ -9,7 +9,7 @@ from . import _lib, driver, graph, models, ops, sharded, synth, train  # noqa: F
 from ._lib import LIB_PATH, RbgError  # noqa: F401
 from .graph import (GraphHandle, InteractionDataset, device_count, find_communities, get_option, get_tuning, norm_edges,  # noqa: F401
                     set_option, set_tuning)
-from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN  # noqa: F401
+from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN, SimGCL, XSimGCL  # noqa: F401
 from .ops import BiGNNConv, LightGCNConv, full_sort_topk, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
 
 from .train import FusedBPRAdam, GraphedStep  # noqa: F401,E402

@@ -40,7 +40,7 @@ struct RowSrc {  // where dense rows live: row r is p0 + r*ld (r < split) or p1 
     int64_t ld;
 };
 
-enum { MODE_STORE = 0, MODE_ACCUM = 1, MODE_MEAN = 2, MODE_HORNER = 3 };
+enum { MODE_STORE = 0, MODE_ACCUM = 1, MODE_MEAN = 2, MODE_HORNER = 3, MODE_NOISE = 4 };
 
 struct SpmmParams {
     const int32_t *rowptr;
@@ -61,6 +61,7 @@ struct SpmmParams {
     int32_t mode;
     int32_t nt_store;
     // MODE_HORNER: y[row] = (addend[row] + acc) / denom   (one step of the backward chain)
+    // MODE_NOISE:  y[row] = acc + sign(acc) * addend[row] / max(||addend[row]||, 1e-12) * denom   (addend = noise, denom = eps)
     const float *addend;
     // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom
     float *mean_out;
@@ -164,8 +165,20 @@ __device__ __forceinline__ float4 reduce_groups(float4 a) {
 
 // Row epilogue, executed by the LPR lanes that hold the finished row.
 // D = width of the contiguous [N, D] side arrays (prev, mean_out, addend); c0 = first column of this lane's float4.
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
+
 __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D, int coff = 0) {
     const int c0 = coff + sl * 4;
+    if (p.mode == MODE_NOISE) {  // simgcl.py:32-33: all_embs + sign(all_embs) * F.normalize(random_noise, dim=-1) * eps
+        const float4 nz = ld4(p.addend + (int64_t)row * D + c0);
+        float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
+        for (int off = 1; off < D / 4; off <<= 1) ss += __shfl_xor(ss, off);  // the D/4 lanes holding this row
+        const float sc = p.denom / fmaxf(sqrtf(ss), 1e-12f);
+        const float4 y = make_float4(fmaf(sgn(acc.x) * nz.x, sc, acc.x), fmaf(sgn(acc.y) * nz.y, sc, acc.y),
+                                     fmaf(sgn(acc.z) * nz.z, sc, acc.z), fmaf(sgn(acc.w) * nz.w, sc, acc.w));
+        st4_stream(p.y + (int64_t)row * p.ldy + c0, y, p.nt_store);
+        return;
+    }
     if (p.mode == MODE_MEAN) {
         float4 s = ld4(src_row(p.e0, row) + c0);
         for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + c0));
@@ -295,6 +308,13 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, i
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.n_rows) return;
     const int beg = p.rowptr[row], end = p.rowptr[row + 1];
+    float noise_scale = 0.f;
+    if (p.mode == MODE_NOISE) {
+        float ss = 0.f;
+        for (int k = lane; k < d; k += 64) ss = fmaf(p.addend[(int64_t)row * d + k], p.addend[(int64_t)row * d + k], ss);
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+        noise_scale = p.denom / fmaxf(sqrtf(ss), 1e-12f);
+    }
     for (int k0 = 0; k0 < d; k0 += 64) {
         const int k = k0 + lane;
         float acc = 0.f;
@@ -320,6 +340,8 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, i
                 s += acc;
                 p.mean_out[(int64_t)row * d + k] = s / p.denom;
                 if (p.y) p.y[(int64_t)row * p.ldy + k] = acc;
+            } else if (p.mode == MODE_NOISE) {
+                p.y[(int64_t)row * p.ldy + k] = fmaf(sgn(acc) * p.addend[(int64_t)row * d + k], noise_scale, acc);
             } else if (p.mode == MODE_HORNER) {
                 p.y[(int64_t)row * p.ldy + k] = (p.addend[(int64_t)row * d + k] + acc) / p.denom;
             } else {
@@ -440,7 +462,7 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
         // auto: only at d = 128 (measured r01, Gowalla shape: 86.4 -> 77.8 us; at d = 64 the doubled CSR / index work costs
         // more than the better L2 hit rate returns: 42.0 -> 49.8 us)
         const int cs = opt_col_split();
-        if ((cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
+        if (p.mode != MODE_NOISE /* the noise row norm spans both halves */ && (cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
             g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1)
             return launch_binned_half<D / 2>(g, p, s);
     }
@@ -465,7 +487,7 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     fill_graph(g, p);
     if (g->n_rows == 0) return RBG_OK;
     bool vec = (d % 4 == 0) && vec_ok(p.x) && (p.ldy % 4 == 0) && (!p.y || aligned16(p.y));
-    if (p.mode == MODE_HORNER) vec = vec && aligned16(p.addend);
+    if (p.mode == MODE_HORNER || p.mode == MODE_NOISE) vec = vec && aligned16(p.addend);
     if (p.mode == MODE_MEAN) {
         vec = vec && vec_ok(p.e0) && aligned16(p.mean_out);
         for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
@@ -538,6 +560,25 @@ int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumu
     if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
     if ((rc = set_device_for(g->device))) return rc;
     return spmm_strided(g, X, d, Y, d, d, accumulate, (hipStream_t)stream);
+}
+
+int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float *noise, int d, float eps, void *stream) {
+    clear_error();
+    int rc = check_device_graph(g);
+    if (rc) return rc;
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    if (g->n_rows == 0) return RBG_OK;
+    if (!X || !Y || !noise) return fail(RBG_EINVAL, "NULL pointer");
+    if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
+    if ((rc = set_device_for(g->device))) return rc;
+    SpmmParams p{};
+    p.x = make_src(X, X, 0, d);
+    p.y = Y;
+    p.ldy = d;
+    p.mode = MODE_NOISE;
+    p.addend = noise;
+    p.denom = eps;
+    return launch_spmm(g, p, d, (hipStream_t)stream);
 }
 
 int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64_t n_users, const float *user_emb,

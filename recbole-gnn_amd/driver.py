@@ -167,6 +167,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
             else:
                 opt.zero_grad(set_to_none=True)
                 loss = model.calculate_loss(batch)
+                loss = sum(loss) if isinstance(loss, tuple) else loss  # RecBole's trainer sums tuple losses
                 loss.backward()
                 opt.step()
                 total += loss.detach().reshape(())

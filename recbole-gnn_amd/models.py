@@ -422,5 +422,98 @@ class SGL(GeneralGraphRecommender):
         return ops.score(user, self.restore_item_e)
 
 
+class SimGCL(LightGCN):
+    """general_recommender/simgcl.py:15-61.  forward() averages layers 1..K (no E_0, simgcl.py:25-36); the perturbed pass
+    adds sign(e) * normalize(U(0,1) noise) * eps after every layer — the noise is drawn with ``torch.rand_like`` in the
+    reference's order, the add is the SpMM's epilogue (``ops.spmm_noise``)."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self.cl_rate = config["lambda"] if config["lambda"] is not None else 0.5
+        self.eps = config["eps"] if config["eps"] is not None else 0.1
+        self.temperature = config["temperature"] if config["temperature"] is not None else 0.2
+
+    def _layers(self, perturbed):
+        all_embs = self.get_ego_embeddings()
+        graph = self.graph if isinstance(self.graph, ops.GraphHandle) else ops.graph_from_pair(
+            self.edge_index, self.edge_weight, all_embs.shape[0], all_embs.device)
+        out = []
+        for _ in range(self.n_layers):
+            if perturbed:
+                buf = torch.empty_like(all_embs)
+                random_noise = torch.rand_like(buf)  # simgcl.py:31, drawn before the product here: same RNG stream
+                all_embs = ops.spmm_noise(graph, all_embs, random_noise, self.eps)
+            else:
+                all_embs = ops.spmm(graph, all_embs)
+            out.append(all_embs)
+        return out
+
+    def forward(self, perturbed=False):
+        embeddings_list = self._layers(perturbed)
+        mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+        return torch.split(mean, [self.n_users, self.n_items])
+
+    def calculate_cl_loss(self, x1, x2):
+        x1, x2 = F.normalize(x1, dim=-1), F.normalize(x2, dim=-1)
+        pos_score = torch.exp((x1 * x2).sum(dim=-1) / self.temperature)
+        ttl_score = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature).sum(dim=1)
+        return -torch.log(pos_score / ttl_score).sum()
+
+    def calculate_loss(self, interaction):
+        loss = super().calculate_loss(interaction)
+        user = torch.unique(interaction[self.USER_ID])
+        pos_item = torch.unique(interaction[self.ITEM_ID])
+        u1, i1 = self.forward(perturbed=True)
+        u2, i2 = self.forward(perturbed=True)
+        user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user))
+        item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item))
+        return loss + self.cl_rate * (user_cl_loss + item_cl_loss)
+
+
+class XSimGCL(SimGCL):
+    """general_recommender/xsimgcl.py:18-90: ONE perturbed pass serves the recommendation loss and the contrast between
+    the final embedding and the one after layer ``layer_cl``; the CL loss is a mean (xsimgcl.py:54)."""
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self.cl_rate = config["lambda"] if config["lambda"] is not None else 0.1
+        self.eps = config["eps"] if config["eps"] is not None else 0.2
+        self.layer_cl = config["layer_cl"] if config["layer_cl"] is not None else 1
+
+    def forward(self, perturbed=False):
+        all_embs_cl = self.get_ego_embeddings()
+        embeddings_list = self._layers(perturbed)
+        if 1 <= self.layer_cl <= self.n_layers:
+            all_embs_cl = embeddings_list[self.layer_cl - 1]
+        mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+        user_all, item_all = torch.split(mean, [self.n_users, self.n_items])
+        if perturbed:
+            user_cl, item_cl = torch.split(all_embs_cl, [self.n_users, self.n_items])
+            return user_all, item_all, user_cl, item_cl
+        return user_all, item_all
+
+    def calculate_cl_loss(self, x1, x2):
+        x1, x2 = F.normalize(x1, dim=-1), F.normalize(x2, dim=-1)
+        pos_score = torch.exp((x1 * x2).sum(dim=-1) / self.temperature)
+        ttl_score = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature).sum(dim=1)
+        return -torch.log(pos_score / ttl_score).mean()
+
+    def calculate_loss(self, interaction):
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        user, pos_item, neg_item = interaction[self.USER_ID], interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]
+        user_all, item_all, user_cl, item_cl = self.forward(perturbed=True)
+        u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
+        mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
+        reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
+                                 _rows(self.item_embedding.weight, neg_item), require_pow=self.require_pow)
+        user_u, item_u = torch.unique(user), torch.unique(pos_item)
+        user_cl_loss = self.calculate_cl_loss(_rows(user_all, user_u), _rows(user_cl, user_u))
+        item_cl_loss = self.calculate_cl_loss(_rows(item_all, item_u), _rows(item_cl, item_u))
+        return mf_loss, self.reg_weight * reg_loss, self.cl_rate * (user_cl_loss + item_cl_loss)
+
+
 NGCF.full_sort_topk = _full_sort_topk
 SGL.full_sort_topk = _full_sort_topk

@@ -76,6 +76,39 @@ def spmm(graph, x):
     return _Spmm.apply(x, graph)
 
 
+def spmm_noise_raw(graph, x, noise, eps, out=None):
+    """Y = Â·X;  Y += sign(Y) * normalize(noise, dim=-1) * eps  (simgcl.py:29-34), no autograd."""
+    _require_device_graph(graph)
+    _check_dense(x, "x", graph)
+    _check_dense(noise, "noise", graph)
+    if x.dim() != 2 or x.shape[0] != graph.n_cols or tuple(noise.shape) != (graph.n_rows, x.shape[1]):
+        raise ValueError(f"x must be [{graph.n_cols}, d] and noise [{graph.n_rows}, d]")
+    x, noise = x.contiguous(), noise.contiguous()
+    if out is None:
+        out = torch.empty((graph.n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.rbg_spmm_noise_f32(graph.ptr, c_vp(x.data_ptr()), c_vp(out.data_ptr()), c_vp(noise.data_ptr()), x.shape[1],
+                                     float(eps), _stream(x)))
+    return out
+
+
+class _SpmmNoise(torch.autograd.Function):
+    """The perturbation sign(y) * const has zero gradient (as in torch autograd of simgcl.py:33): backward = Â^T·dY."""
+
+    @staticmethod
+    def forward(ctx, x, noise, graph, eps):
+        ctx.graph = graph
+        return spmm_noise_raw(graph, x, noise, eps)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return spmm_raw(ctx.graph.transpose(), grad_out.contiguous()), None, None, None
+
+
+def spmm_noise(graph, x, noise, eps):
+    return _SpmmNoise.apply(x, noise, graph, float(eps))
+
+
 # Graph handles for models that hold the reference's dense pair (edge_index, edge_weight).  The cache is keyed by the
 # identity of the two tensor OBJECTS (weak references + version counters), never by their device addresses: the
 # caching allocator hands the same address to a different graph's tensors as soon as the old ones are freed.

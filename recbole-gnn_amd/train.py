@@ -68,6 +68,11 @@ class FusedBPRAdam:
         return self.loss
 
 
+def _total(loss):
+    """RecBole's trainer sums a tuple of loss terms (XSimGCL returns mf, reg, cl separately, xsimgcl.py:90)."""
+    return sum(loss) if isinstance(loss, tuple) else loss
+
+
 class GraphedStep:
     """One whole training step — ``zero_grad; calculate_loss; backward; Adam.step`` (RecBole ``Trainer._train_epoch``
     [recbole==1.1.1]) — captured ONCE into a HIP graph and replayed per batch.
@@ -121,13 +126,13 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.loss = self.model.calculate_loss(self.static)
+            self.loss = _total(self.model.calculate_loss(self.static))
             self.loss.backward()
             self.opt.step()
 
     def _eager(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = self.model.calculate_loss(self.static)
+        loss = _total(self.model.calculate_loss(self.static))
         loss.backward()
         self.opt.step()
         return loss
@@ -146,7 +151,7 @@ class GraphedStep:
     def eager_step(self, batch):
         """The same step without the graph (odd-sized batches).  Gradients left by the graph's buffers are dropped first."""
         self.opt.zero_grad(set_to_none=True)
-        loss = self.model.calculate_loss(batch)
+        loss = _total(self.model.calculate_loss(batch))
         loss.backward()
         self.opt.step()
         return loss.detach()

@@ -50,7 +50,7 @@ def test_metrics_known_answers(rbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL"])
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL"])
 def test_one_epoch_runs(rbg, cuda, ref_inter, name):
     """tests/test_model.py:27-37 of the reference: build, train one epoch, evaluate — and the values are finite."""
     uid, iid, nu, ni = ref_inter

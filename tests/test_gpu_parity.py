@@ -636,6 +636,97 @@ def test_sgl_training_loss_and_gradients(rbg, cuda, golden):
     close(model.item_embedding.weight.grad, iw.grad, tol=2e-5)
 
 
+# ---- SimGCL / XSimGCL: noise-perturbed propagation (simgcl.py:24-38, xsimgcl.py:28-48) ---------------
+
+@pytest.mark.parametrize("d", [64, 128, 20, 256])
+def test_spmm_noise_epilogue(rbg, cuda, golden, d):
+    """rbg_spmm_noise_f32: Y = AX + sign(AX) * normalize(noise) * eps against the torch expression in float64; zero rows
+    (PAD) keep sign 0; the backward is the plain transposed product."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    n = nu + ni
+    x = randn((n, d), 5, cuda)
+    noise = torch.rand(n, d, generator=torch.Generator().manual_seed(6)).to(cuda)
+    y = rbg.ops.spmm_noise_raw(h, x, noise, 0.1)
+    ax = torch.from_numpy(O.conv_csr_f64(x.cpu().numpy().astype(np.float64), g["rowptr"], g["col"].astype(np.int64), g["val"]))
+    ref = ax + torch.sign(ax) * torch.nn.functional.normalize(noise.cpu().double(), dim=-1) * 0.1
+    # sign() flips where AX is within rounding of zero: compare where |AX| is clearly non-zero, and PAD rows exactly
+    mask = ax.abs() > 1e-6
+    assert float((y.cpu().double() - ref)[mask].abs().max()) <= 1e-5
+    assert torch.all(y[0] == 0) and torch.all(y[nu] == 0)
+    xg = x.clone().requires_grad_(True)
+    up = randn((n, d), 7, cuda)
+    (rbg.ops.spmm_noise(h, xg, noise, 0.1) * up).sum().backward()
+    close(xg.grad, rbg.ops.spmm_raw(h, up))
+
+
+@pytest.mark.parametrize("name", ["SimGCL", "XSimGCL"])
+def test_simgcl_models(rbg, cuda, golden, name):
+    """Model mirrors: clean forward = mean of layers 1..K (no E0); perturbed forward reproduces the reference's expression
+    on the same torch.rand_like draws; calculate_loss and its gradients equal the reference formulas (oracle) evaluated
+    with torch autograd on the same noise."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    extra = {"layer_cl": 1, "require_pow": True} if name == "XSimGCL" else {}
+    model, _ = make_model(rbg, getattr(rbg, name), cuda, golden, enable_sparse=True, n_layers=2, eps=0.1, temperature=0.2,
+                          reg_weight=1e-4, **{"lambda": 0.5}, **extra)
+    model.train()
+    uw = model.user_embedding.weight.detach().cpu().double()
+    iw = model.item_embedding.weight.detach().cpu().double()
+    rp, col, val = g["rowptr"], g["col"].astype(np.int64), g["val"]
+    conv64 = lambda t: torch.from_numpy(O.conv_csr_f64(t.detach().numpy(), rp, col, val))
+    with torch.no_grad():
+        got = model.forward()
+    ref = O.simgcl_forward(uw, iw, conv64, 2)
+    close(torch.cat(got), torch.cat(ref).float())
+    # perturbed forward on the same random draws
+    n, d = nu + ni, 64
+    torch.manual_seed(123)
+    with torch.no_grad():
+        pert = model.forward(perturbed=True)
+    torch.manual_seed(123)
+    noises = [torch.rand(n, d, device=cuda).cpu().double() for _ in range(2)]
+    refp = O.simgcl_forward(uw, iw, conv64, 2, noises=noises, eps=0.1, layer_cl=1 if name == "XSimGCL" else None)
+    for a, b in zip(pert, refp):
+        assert float((a.cpu().double() - b).abs().max()) <= 2e-5  # (sign flips need |AX| ~ 1e-7: not on these embeddings)
+    # loss + gradients against the oracle formulas with autograd (dense operator), same noise stream
+    batch = {"user_id": torch.tensor([1, 2, 3, 9, 2], device=cuda), "item_id": torch.tensor([1, 4, 3, 7, 8], device=cuda),
+             "neg_item_id": torch.tensor([5, 6, 2, 11, 30], device=cuda)}
+    torch.manual_seed(321)
+    loss = model.calculate_loss(batch)
+    loss = sum(loss) if isinstance(loss, tuple) else loss
+    loss.backward()
+    torch.manual_seed(321)
+    n_draws = 2 if name == "XSimGCL" else 4
+    draws = [torch.rand(n, d, device=cuda).cpu().double() for _ in range(n_draws)]
+    uwr, iwr = uw.clone().requires_grad_(True), iw.clone().requires_grad_(True)
+    dense = torch.zeros(n, n, dtype=torch.float64)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    dense.index_put_((torch.from_numpy(rows), torch.from_numpy(col)), torch.from_numpy(val.astype(np.float64)), accumulate=True)
+    convd = lambda t: dense @ t
+    u, p, q = (batch[k].cpu() for k in ("user_id", "item_id", "neg_item_id"))
+    uu, pu = torch.unique(u), torch.unique(p)
+    if name == "SimGCL":
+        ua, ia = O.simgcl_forward(uwr, iwr, convd, 2)
+        bpr = -torch.log(1e-10 + torch.sigmoid((ua[u] * ia[p]).sum(1) - (ua[u] * ia[q]).sum(1))).mean()
+        reg = (uwr[u].norm() + iwr[p].norm() + iwr[q].norm()) / 5
+        u1, i1 = O.simgcl_forward(uwr, iwr, convd, 2, noises=draws[0:2], eps=0.1)
+        u2, i2 = O.simgcl_forward(uwr, iwr, convd, 2, noises=draws[2:4], eps=0.1)
+        cl = O.simgcl_cl_loss(u1[uu], u2[uu], 0.2) + O.simgcl_cl_loss(i1[pu], i2[pu], 0.2)
+        ref_loss = bpr + 1e-4 * reg + 0.5 * cl
+    else:
+        ua, ia, uc, ic = O.simgcl_forward(uwr, iwr, convd, 2, noises=draws, eps=0.1, layer_cl=1)
+        bpr = -torch.log(1e-10 + torch.sigmoid((ua[u] * ia[p]).sum(1) - (ua[u] * ia[q]).sum(1))).mean()
+        reg = (uwr[u].pow(2).sum() + iwr[p].pow(2).sum() + iwr[q].pow(2).sum()) / 2 / 5  # EmbLoss(require_pow=True)
+        cl = O.simgcl_cl_loss(ua[uu], uc[uu], 0.2, "mean") + O.simgcl_cl_loss(ia[pu], ic[pu], 0.2, "mean")
+        ref_loss = bpr + 1e-4 * reg + 0.5 * cl
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-5 * max(1.0, abs(float(ref_loss.detach())))
+    close(model.user_embedding.weight.grad, uwr.grad.float(), tol=2e-5)
+    close(model.item_embedding.weight.grad, iwr.grad.float(), tol=2e-5)
+
+
 # ---- InfoNCE denominator (sgl.py:195-198) ------------------------------------------------------
 
 @pytest.mark.parametrize("b,n,d", [(1, 1, 4), (5, 7, 8), (33, 65, 16), (64, 1000, 64), (100, 333, 100), (257, 2049, 128),
