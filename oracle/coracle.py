@@ -84,7 +84,9 @@ def spmm(rowptr, col, val, x):
     return out
 
 
-def lightgcn_forward(rowptr, col, val, user_w, item_w, n_layers, return_layers=False):
+def lightgcn_forward(rowptr, col, val, user_w, item_w, n_layers, return_layers=False, buffers=None):
+    """buffers: optional (layers [K+1, N, d], out [N, d]) float32 arrays to reuse (a timing loop should not pay for
+    72 MB of fresh pages per call)."""
     user_w = np.ascontiguousarray(user_w, dtype=np.float32)
     item_w = np.ascontiguousarray(item_w, dtype=np.float32)
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
@@ -92,8 +94,12 @@ def lightgcn_forward(rowptr, col, val, user_w, item_w, n_layers, return_layers=F
     val = np.ascontiguousarray(val, dtype=np.float32)
     nu, ni, d = user_w.shape[0], item_w.shape[0], user_w.shape[1]
     n = nu + ni
-    layers = np.empty((n_layers + 1, n, d), dtype=np.float32)
-    out = np.empty((n, d), dtype=np.float32)
+    if buffers is not None:
+        layers, out = buffers
+        assert layers.shape == (n_layers + 1, n, d) and out.shape == (n, d) and layers.dtype == out.dtype == np.float32
+    else:
+        layers = np.empty((n_layers + 1, n, d), dtype=np.float32)
+        out = np.empty((n, d), dtype=np.float32)
     lib().ora_lightgcn_forward_f32(nu, ni, d, n_layers, _p(rowptr, _i64p), _p(col, _i64p), _p(val, _f32p),
                                    _p(user_w, _f32p), _p(item_w, _f32p), _p(layers, _f32p), _p(out, _f32p))
     if return_layers:

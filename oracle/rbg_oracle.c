@@ -91,18 +91,21 @@ int64_t ora_build_norm_csr(int64_t n_users, int64_t n_items, int64_t n_inter, co
 }
 
 /* out[m,:] = sum_e val[e] * mat[col[e],:]   (spmm_cpu loop order) */
-void ora_spmm_csr_f32(int64_t M, int64_t K, const int64_t *rowptr, const int64_t *col, const float *val,
-                      const float *mat, float *out) {
+/* target_clones: an AVX2 body is picked at load time where the host has it (the k loop vectorises across k, which does
+ * not change any element's operation order: results are bit-identical to the scalar clone). */
+__attribute__((target_clones("avx2", "default")))
+void ora_spmm_csr_f32(int64_t M, int64_t K, const int64_t *restrict rowptr, const int64_t *restrict col,
+                      const float *restrict val, const float *restrict mat, float *restrict out) {
 #pragma omp parallel
     {
-        float *vals = (float *)malloc(sizeof(float) * (size_t)(K ? K : 1));
+        float *restrict vals = (float *)malloc(sizeof(float) * (size_t)(K ? K : 1));
 #pragma omp for schedule(dynamic, 64)
         for (int64_t m = 0; m < M; ++m) {
             for (int64_t k = 0; k < K; ++k) vals[k] = 0.0f;
             for (int64_t e = rowptr[m]; e < rowptr[m + 1]; ++e) {
                 const int64_t c = col[e];
                 const float v = val[e];
-                const float *src = mat + c * K;
+                const float *restrict src = mat + c * K;
                 for (int64_t k = 0; k < K; ++k) vals[k] += v * src[k];
             }
             memcpy(out + m * K, vals, sizeof(float) * (size_t)K);
