@@ -93,17 +93,25 @@ class BPRSampler:
 
 def topk_metrics(topk_idx, truth, k):
     """RecBole's Recall / MRR / NDCG / Hit / Precision @k for one batch.  topk_idx: [B, k] item ids (best first);
-    truth: list of B sets of ground-truth items.  Returns per-user arrays."""
-    topk_idx = np.asarray(topk_idx)
+    truth: list of B sets (or arrays) of ground-truth items.  Returns per-user arrays.  Vectorised: (row, item) pairs
+    are compared as sorted 64-bit keys."""
+    topk_idx = np.asarray(topk_idx, dtype=np.int64)
     b = topk_idx.shape[0]
-    hit = np.zeros((b, k), dtype=bool)
-    for r in range(b):
-        hit[r] = np.fromiter((int(i) in truth[r] for i in topk_idx[r]), dtype=bool, count=k)
-    n_truth = np.asarray([len(t) for t in truth], dtype=np.float64)
+    n_truth = np.fromiter((len(t) for t in truth), dtype=np.int64, count=b)
+    stride = int(max(topk_idx.max(initial=0), max((max(t) for t in truth if len(t)), default=0))) + 2
+    rows = np.repeat(np.arange(b, dtype=np.int64), n_truth)
+    items = np.fromiter((i for t in truth for i in t), dtype=np.int64, count=int(n_truth.sum()))
+    truth_keys = np.sort(rows * stride + items)
+    cand = np.arange(b, dtype=np.int64)[:, None] * stride + topk_idx
+    pos = np.searchsorted(truth_keys, cand.ravel())
+    pos[pos >= len(truth_keys)] = max(len(truth_keys) - 1, 0)
+    hit = (truth_keys[pos] == cand.ravel()).reshape(b, k) if len(truth_keys) else np.zeros((b, k), dtype=bool)
+    hit &= topk_idx >= 0  # -1 = fewer than k items were rankable
+    n_truth = n_truth.astype(np.float64)
     n_hit = hit.sum(1).astype(np.float64)
     disc = 1.0 / np.log2(np.arange(2, k + 2))
     dcg = (hit * disc).sum(1)
-    idcg = np.asarray([disc[:int(min(n, k))].sum() for n in n_truth])
+    idcg = np.concatenate([[0.0], np.cumsum(disc)])[np.minimum(n_truth, k).astype(np.int64)]
     first = np.where(hit.any(1), hit.argmax(1) + 1, 0)
     return {
         "recall": n_hit / np.maximum(n_truth, 1),
