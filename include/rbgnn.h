@@ -311,6 +311,23 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
 int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,
                         int d, void *stream);
 
+/* One layer of the node-range sharded propagation with the host side in two calls; the caller's
+ * collective (e.g. RCCL all_to_all of send_buf -> halo on the comm stream) goes in between.
+ *   begin: comm stream waits for the main stream (X ready), packs send_buf[i] = X[send_idx[i]];  main: Y = A_int X
+ *   end  : main stream waits for the comm stream (halo filled);  main: Y += A_halo halo   (g_halo may be NULL)
+ * A context owns the two events used for the cross-stream ordering. */
+typedef struct rbg_shard_ctx rbg_shard_ctx;
+int rbg_shard_ctx_create(rbg_shard_ctx **out, int device);
+void rbg_shard_ctx_destroy(rbg_shard_ctx *ctx);
+int rbg_shard_layer_begin(rbg_shard_ctx *ctx, const rbg_graph *g_int, const float *X, float *Y, const int64_t *send_idx,
+                          int64_t n_send, float *send_buf, int d, void *main_stream, void *comm_stream);
+int rbg_shard_layer_end(rbg_shard_ctx *ctx, const rbg_graph *g_halo, const float *halo, float *Y, int d, void *main_stream,
+                        void *comm_stream);
+
+/* out[t] = scale * (srcs[0][t] + srcs[1][t] + ...), added left to right: the layer mean of lightgcn.py:80-81 over
+ * separately held layer outputs (the sharded propagation) in one launch.  n_srcs <= RBG_MAX_FUSED_LAYERS + 1. */
+int rbg_mean_f32(const float *const *srcs, int n_srcs, int64_t n_floats, float scale, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

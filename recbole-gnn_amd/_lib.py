@@ -50,6 +50,11 @@ SIGNATURES = {
     "rbg_score_f32": (c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp]),
     "rbg_full_sort_topk_workspace": (c_int, [c_i64, c_i64, c_int, P(c_i64)]),
     "rbg_full_sort_topk_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "rbg_shard_ctx_create": (c_int, [P(c_vp), c_int]),
+    "rbg_shard_ctx_destroy": (None, [c_vp]),
+    "rbg_shard_layer_begin": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp]),
+    "rbg_shard_layer_end": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "rbg_mean_f32": (c_int, [c_vp, c_int, c_i64, c_f32, c_vp, c_vp]),
     "rbg_gather_rows_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp]),
     "rbg_bignn_layer_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
     "rbg_bignn_backward_workspace": (c_int, [c_i64, c_int, c_int, P(c_i64)]),

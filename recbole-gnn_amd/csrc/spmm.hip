@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <new>
 
 #include "internal.h"
 
@@ -363,6 +364,29 @@ __global__ void layer_mean_kernel(RowSrc e0, const float *layers, int64_t n_rows
     }
 }
 
+// out = scale * (s[0] + s[1] + ... ), left to right (the layer mean of the sharded propagation: one launch instead of
+// clone + K adds + one divide)
+struct MeanSrcs {
+    const float *s[RBG_MAX_FUSED_LAYERS + 1];
+    int n;
+};
+__global__ void mean_kernel(const MeanSrcs m, int64_t len, float scale, float *__restrict__ out, int vec) {
+    if (vec) {
+        const int64_t q = len / 4;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < q; t += (int64_t)gridDim.x * blockDim.x) {
+            float4 a = ld4(m.s[0] + 4 * t);
+            for (int i = 1; i < m.n; ++i) a = add4(a, ld4(m.s[i] + 4 * t));
+            st4(out + 4 * t, make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale));
+        }
+    } else {
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < len; t += (int64_t)gridDim.x * blockDim.x) {
+            float a = m.s[0][t];
+            for (int i = 1; i < m.n; ++i) a += m.s[i][t];
+            out[t] = a * scale;
+        }
+    }
+}
+
 __global__ void gather_rows_kernel(const float *src, int64_t lds, const int64_t *idx, float *dst, int64_t n_idx,
                                    int d, int vec) {
     if (vec) {
@@ -562,6 +586,26 @@ int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumu
     return spmm_strided(g, X, d, Y, d, d, accumulate, (hipStream_t)stream);
 }
 
+int rbg_mean_f32(const float *const *srcs, int n_srcs, int64_t n_floats, float scale, float *out, void *stream) {
+    clear_error();
+    if (!srcs || !out || n_srcs < 1 || n_srcs > RBG_MAX_FUSED_LAYERS + 1 || n_floats < 0)
+        return fail(RBG_EINVAL, "rbg_mean_f32: 1 <= n_srcs <= %d", RBG_MAX_FUSED_LAYERS + 1);
+    if (n_floats == 0) return RBG_OK;
+    MeanSrcs m{};
+    m.n = n_srcs;
+    bool vec = (n_floats % 4 == 0) && aligned16(out);
+    for (int i = 0; i < n_srcs; ++i) {
+        if (!srcs[i]) return fail(RBG_EINVAL, "srcs[%d] is NULL", i);
+        m.s[i] = srcs[i];
+        vec = vec && aligned16(srcs[i]);
+    }
+    const int64_t work = vec ? n_floats / 4 : n_floats;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((work + 255) / 256, 1 << 16));
+    hipLaunchKernelGGL(mean_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, m, n_floats, scale, out, vec ? 1 : 0);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
 int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float *noise, int d, float eps, void *stream) {
     clear_error();
     int rc = check_device_graph(g);
@@ -707,6 +751,81 @@ int rbg_gather_rows_f32(const float *src, int64_t lds, const int64_t *idx, float
                        n_idx, d, vec);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+// ---- one layer of the node-range sharded propagation, host side in two calls ------------------------------------------
+// The N > 1 path is host-bound (a propagation is ~190 us of GPU work but cost ~320 us of Python: every layer made ~10
+// torch / ctypes calls, r01 world-size-1 RCCL probe).  begin() and end() take BOTH raw stream handles and do the
+// cross-stream ordering with two events of their own, so that a layer is: begin, the caller's all_to_all on the comm
+// stream, end.
+struct rbg_shard_ctx {
+    int device;
+    hipEvent_t x_ready, halo_ready;
+};
+
+int rbg_shard_ctx_create(rbg_shard_ctx **out, int device) {
+    clear_error();
+    if (!out) return fail(RBG_EINVAL, "out is NULL");
+    int rc = set_device_for(device);
+    if (rc) return rc;
+    rbg_shard_ctx *c = new (std::nothrow) rbg_shard_ctx{device, nullptr, nullptr};
+    if (!c) return fail(RBG_ENOMEM, "out of host memory");
+    if (hipEventCreateWithFlags(&c->x_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->halo_ready, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return fail(RBG_EHIP, "hipEventCreate failed");
+    }
+    *out = c;
+    return RBG_OK;
+}
+
+void rbg_shard_ctx_destroy(rbg_shard_ctx *c) {
+    if (!c) return;
+    (void)hipEventDestroy(c->x_ready);
+    (void)hipEventDestroy(c->halo_ready);
+    delete c;
+}
+
+// comm stream: wait until X is ready on the main stream, then pack send_buf[i] = X[send_idx[i]]  (n_send may be 0);
+// main stream: Y = A_interior X.  The caller then enqueues its collective on the comm stream.
+int rbg_shard_layer_begin(rbg_shard_ctx *c, const rbg_graph *g_int, const float *X, float *Y, const int64_t *send_idx,
+                          int64_t n_send, float *send_buf, int d, void *main_stream, void *comm_stream) {
+    clear_error();
+    if (!c) return fail(RBG_EINVAL, "ctx is NULL");
+    int rc = check_device_graph(g_int);
+    if (rc) return rc;
+    if (d <= 0 || n_send < 0) return fail(RBG_ESHAPE, "d = %d, n_send = %lld", d, (long long)n_send);
+    if (!X || !Y || (n_send && (!send_idx || !send_buf))) return fail(RBG_EINVAL, "NULL pointer");
+    if ((rc = set_device_for(g_int->device))) return rc;
+    hipStream_t ms = (hipStream_t)main_stream, cs = (hipStream_t)comm_stream;
+    RBG_HIP(hipEventRecord(c->x_ready, ms));
+    RBG_HIP(hipStreamWaitEvent(cs, c->x_ready, 0));
+    if (n_send) {
+        const int vec = (d % 4 == 0) && aligned16(X) && aligned16(send_buf);
+        const int64_t work = n_send * (vec ? d / 4 : d);
+        const int64_t grid = std::min<int64_t>((work + 255) / 256, 4096);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)grid), dim3(256), 0, cs, X, (int64_t)d, send_idx, send_buf, n_send, d, vec);
+        RBG_HIP(hipGetLastError());
+    }
+    if (g_int->n_rows == 0) return RBG_OK;
+    return spmm_strided(g_int, X, d, Y, d, d, 0, ms);
+}
+
+// main stream: wait for the comm stream (the collective filled `halo`), then Y += A_halo halo  (g_halo may be NULL).
+int rbg_shard_layer_end(rbg_shard_ctx *c, const rbg_graph *g_halo, const float *halo, float *Y, int d, void *main_stream,
+                        void *comm_stream) {
+    clear_error();
+    if (!c) return fail(RBG_EINVAL, "ctx is NULL");
+    hipStream_t ms = (hipStream_t)main_stream, cs = (hipStream_t)comm_stream;
+    RBG_HIP(hipEventRecord(c->halo_ready, cs));
+    RBG_HIP(hipStreamWaitEvent(ms, c->halo_ready, 0));
+    if (!g_halo) return RBG_OK;
+    int rc = check_device_graph(g_halo);
+    if (rc) return rc;
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    if (!halo || !Y) return fail(RBG_EINVAL, "NULL pointer");
+    if (g_halo->n_rows == 0) return RBG_OK;
+    return spmm_strided(g_halo, halo, d, Y, d, d, 1, ms);
 }
 
 }  // extern "C"

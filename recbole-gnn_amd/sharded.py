@@ -159,19 +159,57 @@ class HipBackend:
     def make_graph(self, csr, n_cols):
         return self._GraphHandle.from_csr(csr[0], csr[1], csr[2], n_cols, device=self.device)
 
-    def spmm(self, graph, x, out, accumulate):
+    def layer_ctx(self):
+        """Context (two events) for layer_begin / layer_end; freed with the backend object."""
+        import ctypes
+        ctx = self._lib.c_vp()
+        self._lib.check(self._lib.lib.rbg_shard_ctx_create(ctypes.byref(ctx), self.device.index or 0))
+        self._ctxs = getattr(self, "_ctxs", []) + [ctx]
+        return ctx
+
+    def __del__(self):
+        for ctx in getattr(self, "_ctxs", []):
+            try:
+                self._lib.lib.rbg_shard_ctx_destroy(ctx)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def layer_begin(self, ctx, g_int, x, y, send_idx, n_send, send_buf, main_h, comm_h):
+        """comm stream: wait for x, pack the send rows; main stream: y = A_int x  (one call, rbg_shard_layer_begin)."""
+        lib, vp = self._lib.lib, self._lib.c_vp
+        self._lib.check(lib.rbg_shard_layer_begin(ctx, g_int.ptr, vp(x.data_ptr()), vp(y.data_ptr()), vp(send_idx.data_ptr()),
+                                                  n_send, vp(send_buf.data_ptr()), x.shape[1], vp(main_h), vp(comm_h)))
+
+    def layer_end(self, ctx, g_halo, halo, y, main_h, comm_h):
+        """main stream: wait for the comm stream, y += A_halo halo  (rbg_shard_layer_end)."""
+        lib, vp = self._lib.lib, self._lib.c_vp
+        self._lib.check(lib.rbg_shard_layer_end(ctx, g_halo.ptr if g_halo is not None else None, vp(halo.data_ptr()),
+                                                vp(y.data_ptr()), y.shape[1], vp(main_h), vp(comm_h)))
+
+    # `stream`: raw HIP stream handle (int) to launch on; None = torch's current stream.  The sharded propagation passes
+    # handles it looked up once per call: torch.cuda.current_stream() costs ~5 us, and a layer would make five of them.
+    def _stream(self, stream):
+        return self._lib.c_vp(torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream)
+
+    def spmm(self, graph, x, out, accumulate, stream=None):
         lib, vp = self._lib.lib, self._lib.c_vp
         self._lib.check(lib.rbg_spmm_f32(graph.ptr, vp(x.data_ptr()), vp(out.data_ptr()), x.shape[1], int(bool(accumulate)),
-                                         vp(torch.cuda.current_stream(self.device).cuda_stream)))
+                                         self._stream(stream)))
         return out
 
-    def gather_rows(self, src, idx, out=None):
+    def mean(self, srcs, out, stream=None):
+        """out = (srcs[0] + srcs[1] + ...) / len(srcs), one launch (rbg_mean_f32)."""
+        lib, vp = self._lib.lib, self._lib.c_vp
+        arr = (vp * len(srcs))(*[t.data_ptr() for t in srcs])
+        self._lib.check(lib.rbg_mean_f32(arr, len(srcs), out.numel(), 1.0 / len(srcs), vp(out.data_ptr()), self._stream(stream)))
+        return out
+
+    def gather_rows(self, src, idx, out=None, stream=None):
         if out is None:
             return self._ops.gather_rows(src, idx)
         lib, vp = self._lib.lib, self._lib.c_vp
         self._lib.check(lib.rbg_gather_rows_f32(vp(src.data_ptr()), src.shape[1], vp(idx.data_ptr()), vp(out.data_ptr()),
-                                                idx.shape[0], src.shape[1],
-                                                vp(torch.cuda.current_stream(self.device).cuda_stream)))
+                                                idx.shape[0], src.shape[1], self._stream(stream)))
         return out
 
 
@@ -183,14 +221,24 @@ class ShardedPropagation:
     the host and exchanged with point-to-point send/recv; works with gloo — used by tests and when two
     ranks must share one GPU)."""
 
-    def __init__(self, plan, backend, group=None, transport="nccl"):
+    def __init__(self, plan, backend, group=None, transport="nccl", overlap=False):
+        """overlap: run pack + all_to_all on a second (high-priority) stream beside the interior SpMM.  Off by default:
+        measured with a world-size-1 RCCL group on MI355X (devtools/nccl1_probe.py, r01) a layer is gather 5 us, RCCL
+        kernel 8 us, interior SpMM 47 us, halo SpMM 12 us, and the second stream added ~35 us of cross-stream event
+        latency per layer while the kernels did not overlap (default-priority streams shared one hardware queue; a
+        high-priority comm stream overlapped but still paid the event hops): 325 us two streams, 297 us with a
+        high-priority comm stream, 259 us on one stream per propagation."""
         self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
+        self.overlap = bool(overlap)
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev
         self.g_int = backend.make_graph(plan.int_csr, plan.n_owned)
         self.g_halo = backend.make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
-        self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.comm_stream = torch.cuda.Stream(device=dev, priority=-1) if (dev.type == "cuda" and self.overlap) else None
+        self._comm_h = self.comm_stream.cuda_stream if self.comm_stream is not None else None
+        self._ctx = backend.layer_ctx() if (transport == "nccl" and self.overlap and hasattr(backend, "layer_ctx")) else None
+        self._n_send = len(plan.send_idx)
         self._buf_d = None  # per-width buffers, allocated on first use: halo, send, two ping-pong outputs
         self._recv_splits = [int(c) for c in plan.recv_counts]
         self._send_splits = [int(c) for c in plan.send_counts]
@@ -203,6 +251,8 @@ class ShardedPropagation:
             self._halo = torch.empty((max(plan.n_halo, 1), d), **f)
             self._send = torch.empty((max(len(plan.send_idx), 1), d), **f)
             self._y = [torch.empty((plan.n_owned, d), **f) for _ in range(2)]
+            self._mean = torch.empty((plan.n_owned, d), **f)
+            self._halo_view = self._halo[: plan.n_halo]
             self._flip = 0
             self._buf_d = d
         return self._halo, self._send
@@ -227,25 +277,31 @@ class ShardedPropagation:
                 w.wait()
         halo.copy_(recv)
 
-    def _exchange_nccl(self, x, halo):
+    def _exchange_nccl(self, x, halo, stream=None):
+        """Pack + all_to_all_single on torch's current stream (the collective is enqueued there); `stream` = that
+        stream's raw handle, to spare the pack launch a lookup."""
         _, send = self._buffers(x)
         n_send = len(self.plan.send_idx)
         if n_send:
-            self.backend.gather_rows(x, self.send_idx, out=send[:n_send])
+            self.backend.gather_rows(x, self.send_idx, out=send[:n_send], stream=stream)
         dist.all_to_all_single(halo, send[:n_send], output_split_sizes=self._recv_splits,
                                input_split_sizes=self._send_splits, group=self.group)
 
-    def spmm(self, x):
-        """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows."""
+    def spmm(self, x, out=None, main=None):
+        """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows.  `main`: the torch stream the caller runs on
+        (looked up once per propagation by forward())."""
         plan = self.plan
         d = x.shape[1]
         if x.device.type == "cuda":
             halo, _ = self._buffers(x)
-            self._flip ^= 1
-            y = self._y[self._flip]  # ping-pong: x may be the other buffer (the previous layer's output)
-            if y.data_ptr() == x.data_ptr():
+            if out is not None:
+                y = out
+            else:
                 self._flip ^= 1
-                y = self._y[self._flip]
+                y = self._y[self._flip]  # ping-pong: x may be the other buffer (the previous layer's output)
+                if y.data_ptr() == x.data_ptr():
+                    self._flip ^= 1
+                    y = self._y[self._flip]
         else:
             y = torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
             halo = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
@@ -254,21 +310,58 @@ class ShardedPropagation:
         if self.transport == "nccl":
             # all_to_all_single is a collective: every rank takes part every layer, even one whose
             # own send and receive lists are empty.
-            main = torch.cuda.current_stream(x.device)
+            if main is None:
+                main = torch.cuda.current_stream(x.device)
+            main_h = main.cuda_stream
+            if not self.overlap:  # one stream: pack, exchange, interior, halo — no cross-stream events
+                if self._n_send:
+                    self.backend.gather_rows(x, self.send_idx, out=self._send[: self._n_send], stream=main_h)
+                dist.all_to_all_single(self._halo_view, self._send[: self._n_send], output_split_sizes=self._recv_splits,
+                                       input_split_sizes=self._send_splits, group=self.group)
+                self.backend.spmm(self.g_int, x, y, False, stream=main_h)
+                if self.g_halo is not None:
+                    self.backend.spmm(self.g_halo, halo, y, True, stream=main_h)
+                return y
+            if self._ctx is not None:
+                # begin: comm waits for x and packs, main runs the interior SpMM; the collective goes on the comm stream;
+                # end: main waits for the comm stream and adds the halo product.  Three host calls per layer.
+                self.backend.layer_begin(self._ctx, self.g_int, x, y, self.send_idx, self._n_send, self._send, main_h, self._comm_h)
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_to_all_single(self._halo_view, self._send[: self._n_send], output_split_sizes=self._recv_splits,
+                                           input_split_sizes=self._send_splits, group=self.group)
+                self.backend.layer_end(self._ctx, self.g_halo, halo, y, main_h, self._comm_h)
+                return y
             self.comm_stream.wait_stream(main)            # x is ready
             with torch.cuda.stream(self.comm_stream):
-                self._exchange_nccl(x, halo[: plan.n_halo])
-            self.backend.spmm(self.g_int, x, y, False)    # overlaps with the exchange
+                self._exchange_nccl(x, self._halo_view, stream=self._comm_h)
+            self.backend.spmm(self.g_int, x, y, False, stream=main_h)    # overlaps with the exchange
             main.wait_stream(self.comm_stream)
-        else:
-            self.backend.spmm(self.g_int, x, y, False)
-            self._exchange_staged(x, halo[: plan.n_halo])  # point-to-point: only non-empty pairs talk
+            if self.g_halo is not None:
+                self.backend.spmm(self.g_halo, halo, y, True, stream=main_h)
+            return y
+        self.backend.spmm(self.g_int, x, y, False)
+        self._exchange_staged(x, halo[: plan.n_halo])  # point-to-point: only non-empty pairs talk
         if self.g_halo is not None:
             self.backend.spmm(self.g_halo, halo, y, True)
         return y
 
+    # (Capturing the whole propagation in a HIP graph was tried on a world-size-1 RCCL group, devtools/nccl1_probe.py: a
+    # lone all_to_all_single captures and replays, but the capture of this method — the collective on a second stream
+    # forked from the capturing one — segfaults inside torch.cuda.graph on torch 2.10 / ROCm 7.2, so the N > 1 path stays
+    # eager: a crash cannot be caught and voted on the way an exception is.)
     def forward(self, e0, n_layers):
         """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users."""
+        if hasattr(self.backend, "mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
+            # keep the K layer outputs and take the mean in one launch (instead of clone + K adds + a divide)
+            self._buffers(e0)
+            while len(self._y) < n_layers:
+                self._y.append(torch.empty_like(self._y[0]))
+            main = torch.cuda.current_stream(e0.device)
+            srcs, x = [e0], e0
+            for k in range(n_layers):
+                x = self.spmm(x, out=self._y[k], main=main)
+                srcs.append(x)
+            return self.backend.mean(srcs, self._mean, stream=main.cuda_stream)
         acc = e0.clone()
         x = e0
         for _ in range(n_layers):
