@@ -10,7 +10,8 @@ uid, iid, nu, ni = rbg.synth.make("gowalla")
 ds = rbg.InteractionDataset(uid, iid, nu, ni)
 torch.manual_seed(0)
 cfg = {"device": "cuda:0", "enable_sparse": True, "embedding_size": 64, "n_layers": 3, "reg_weight": 1e-5, "require_pow": False,
-       "hidden_size_list": [64, 64, 64], "node_dropout": 0.0, "message_dropout": 0.0}
+       "hidden_size_list": [64, 64, 64], "node_dropout": 0.0, "message_dropout": float(os.environ.get("MSG_DROPOUT", "0.0")),
+       "fused_forward": os.environ.get("FUSED", "1") == "1"}
 model = (rbg.NGCF if which == "ngcf" else rbg.LightGCN)(cfg, ds)
 model.train()
 g = torch.Generator().manual_seed(1)

@@ -222,22 +222,25 @@ int rbg_bignn_wgrad_f32(const float *G, int64_t ldg, const float *P, const float
                         int d_out, float *dW1, float *dW2, float *db, void *workspace, void *stream);
 
 /* Training forward of one NGCF layer: rbg_bignn_conv_f32 with RBG_BIGNN_LEAKY_NORM that additionally writes
- * inv_norm [N] = 1 / max(||LeakyReLU(z)||, eps) per row — with the output Y all the tail's backward needs. */
+ * inv_norm [N] = 1 / max(||a||, eps) per row — with the output Y all the tail's backward needs — and applies the
+ * message dropout of ngcf.py:97 when drop_mask != NULL: a = LeakyReLU(z) ⊙ drop_mask, drop_mask [N, d_out] contiguous
+ * holding 0 or 1/(1-p) (the caller draws it with its own RNG, as the reference's nn.Dropout does). */
 int rbg_bignn_layer_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                         const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm,
-                        int d_in, int d_out, float slope, void *stream);
+                        const float *drop_mask, int d_in, int d_out, float slope, void *stream);
 
 /* Backward of that layer (autograd of layers.py:54-58 [+ ngcf.py:96,98 when inv_norm != NULL]) from GY = dL/dY:
- *   G = dL/dz (normalize + LeakyReLU backward from the saved Y, inv_norm; G = GY without the tail)
+ *   G = dL/dz (normalize [+ dropout with the forward's drop_mask] + LeakyReLU backward from the saved Y, inv_norm;
+ *       G = GY without the tail)
  *   GX [N, d_in] = G W1 + (G W2) ⊙ P + Â^T (G W1 + (G W2) ⊙ X)        (the gradient of the layer input X)
  *   dW1 = G^T (P + X),  dW2 = G^T (P ⊙ X),  db = sum_rows G            (db may be NULL)
  * g_t: handle of Â^T (for the symmetric graphs of this path, the forward handle).  d_in, d_out <= 128.
  * `workspace`: rbg_bignn_backward_workspace(n_rows, d_in, d_out) bytes. */
 int rbg_bignn_backward_workspace(int64_t n_rows, int d_in, int d_out, int64_t *bytes);
 int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, const float *Y, int64_t ldy,
-                           const float *inv_norm, const float *X, int64_t ldx, const float *P, const float *W1,
-                           const float *W2, int d_in, int d_out, float slope, float *GX, float *dW1, float *dW2, float *db,
-                           void *workspace, void *stream);
+                           const float *inv_norm, const float *drop_mask, const float *X, int64_t ldx, const float *P,
+                           const float *W1, const float *W2, int d_in, int d_out, float slope, float *GX, float *dW1,
+                           float *dW2, float *db, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * fused mini-batch training step.  All pointers are DEVICE pointers; `loss` is a

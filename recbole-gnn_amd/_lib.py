@@ -56,9 +56,9 @@ SIGNATURES = {
     "rbg_shard_layer_end": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "rbg_mean_f32": (c_int, [c_vp, c_int, c_i64, c_f32, c_vp, c_vp]),
     "rbg_gather_rows_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp]),
-    "rbg_bignn_layer_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
+    "rbg_bignn_layer_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),
     "rbg_bignn_backward_workspace": (c_int, [c_i64, c_int, c_int, P(c_i64)]),
-    "rbg_bignn_backward_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_f32,
+    "rbg_bignn_backward_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_f32,
                                        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rbg_bignn_wgrad_workspace": (c_int, [c_i64, c_int, c_int, P(c_i64)]),
     "rbg_bignn_wgrad_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -43,6 +43,7 @@ struct BignnParams {
     int leaky_norm;
     float slope;
     float *inv_norm;  // optional [N]: 1 / max(||LeakyReLU(z)||, eps) per row, what the tail's backward needs
+    const float *drop_mask;  // optional [N, d_out] contiguous: 0 or 1/(1-p), applied between LeakyReLU and normalize (ngcf.py:97)
 };
 
 // 32 floats of a row starting at k0.  FAST: the run is fully inside the row and 16-byte aligned.
@@ -195,6 +196,11 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(con
             for (int t = 0; t < NT; ++t) {
                 float x = acc[t][reg] + bias[t];
                 if (p.leaky_norm) x = x > 0.f ? x : x * p.slope;
+                if (p.drop_mask) {
+                    const int64_t mrow = tile * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    const int mc = t * 32 + i;
+                    x *= (mrow < p.n_rows && mc < p.d_out) ? p.drop_mask[mrow * p.d_out + mc] : 0.f;
+                }
                 v[t] = x;
                 ss = fmaf(x, x, ss);  // padded columns hold exact zeros
             }
@@ -245,8 +251,8 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
 using namespace rbg;
 
 static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
-                           const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm, int d_in, int d_out,
-                           uint32_t flags, float slope, void *stream) {
+                           const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm, const float *drop_mask,
+                           int d_in, int d_out, uint32_t flags, float slope, void *stream) {
     clear_error();
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
@@ -277,6 +283,7 @@ static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, cons
     p.leaky_norm = (flags & RBG_BIGNN_LEAKY_NORM) ? 1 : 0;
     p.slope = slope;
     p.inv_norm = p.leaky_norm ? inv_norm : nullptr;
+    p.drop_mask = p.leaky_norm ? drop_mask : nullptr;
     const int fast = (d_in % 64 == 0) && (ldx % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P_save) | reinterpret_cast<uintptr_t>(W1) |
                        reinterpret_cast<uintptr_t>(W2)) & 15u) == 0;
@@ -289,12 +296,13 @@ static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, cons
 extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                                   const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, int d_in,
                                   int d_out, uint32_t flags, float slope, void *stream) {
-    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, nullptr, d_in, d_out, flags, slope, stream);
+    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, nullptr, nullptr, d_in, d_out, flags, slope, stream);
 }
 
 extern "C" int rbg_bignn_layer_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                                    const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm,
-                                   int d_in, int d_out, float slope, void *stream) {
+                                   const float *drop_mask, int d_in, int d_out, float slope, void *stream) {
     if (!inv_norm) return fail(RBG_EINVAL, "inv_norm is NULL: the caller provides the [N] buffer the backward needs");
-    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, inv_norm, d_in, d_out, RBG_BIGNN_LEAKY_NORM, slope, stream);
+    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, inv_norm, drop_mask, d_in, d_out, RBG_BIGNN_LEAKY_NORM, slope,
+                           stream);
 }

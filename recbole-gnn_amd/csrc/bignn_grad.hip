@@ -230,6 +230,7 @@ struct DgradParams {
     const float *Y;  // saved layer output (tail only)
     int64_t ldy;
     const float *inv_norm;  // [N] or NULL (no tail)
+    const float *drop_mask;  // [N, d_out] or NULL: the forward's scaled dropout mask (tail only)
     const float *X;
     int64_t ldx;
     const float *P;          // [N, d_in]
@@ -333,13 +334,19 @@ __global__ __launch_bounds__(256, (TI <= 2 && NCO == 1 ? 2 : 1)) void bignn_dgra
         const float inv = p.inv_norm[row_i];
         const bool clamped = inv >= 1e12f;  // ||a|| < eps: normalize is a / eps, a plain scaling
 #pragma unroll
-        for (int c = 0; c < NCO; ++c)
+        for (int c = 0; c < NCO; ++c) {
+            float mk[32];
+            if (p.drop_mask) {
+                load_run(p.drop_mask + row_i * (int64_t)p.d_out, 64 * c + 32 * h, mk);
+            }
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
                 const float y = yv[c][s];
-                const float da = (clamped ? gy[c][s] : gy[c][s] - y * dot) * inv;
-                gy[c][s] = y > 0.f ? da : da * p.slope;  // sign(z) = sign(y); LeakyReLU'(0) = slope as in torch
+                float da = (clamped ? gy[c][s] : gy[c][s] - y * dot) * inv;
+                if (p.drop_mask) da *= mk[s];            // dropout sits between LeakyReLU and normalize (ngcf.py:96-98)
+                gy[c][s] = y > 0.f ? da : da * p.slope;  // sign(z) = sign(y) where kept; LeakyReLU'(0) = slope as in torch
             }
+        }
     }
     if (tile * 32 + i < p.n_rows) {
         float *grow = p.G + (tile * 32 + i) * (int64_t)p.d_out;
@@ -487,9 +494,9 @@ int rbg_bignn_backward_workspace(int64_t n_rows, int d_in, int d_out, int64_t *b
 }
 
 int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, const float *Y, int64_t ldy,
-                           const float *inv_norm, const float *X, int64_t ldx, const float *P, const float *W1,
-                           const float *W2, int d_in, int d_out, float slope, float *GX, float *dW1, float *dW2, float *db,
-                           void *workspace, void *stream) {
+                           const float *inv_norm, const float *drop_mask, const float *X, int64_t ldx, const float *P,
+                           const float *W1, const float *W2, int d_in, int d_out, float slope, float *GX, float *dW1,
+                           float *dW2, float *db, void *workspace, void *stream) {
     clear_error();
     if (!g_t) return fail(RBG_EINVAL, "graph is NULL");
     if (g_t->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
@@ -517,9 +524,10 @@ int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, 
     RBG_HIP(hipGetLastError());
     DgradParams p{};
     p.GY = GY, p.ldgy = ldgy, p.Y = Y, p.ldy = ldy, p.inv_norm = inv_norm, p.X = X, p.ldx = ldx, p.P = P;
+    p.drop_mask = inv_norm ? drop_mask : nullptr;
     p.Wt1 = Wt1, p.Wt2 = Wt2, p.G = G, p.GP = GP, p.GX = GX, p.n_rows = n, p.d_in = d_in, p.d_out = d_out, p.slope = slope;
     const bool fast = (d_out % 64 == 0) && (ldgy % 4 == 0) && (!inv_norm || ldy % 4 == 0) &&
-                      ((reinterpret_cast<uintptr_t>(GY) | reinterpret_cast<uintptr_t>(Y)) & 15u) == 0;
+                      ((reinterpret_cast<uintptr_t>(GY) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(drop_mask)) & 15u) == 0;
     if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
     else if (d_in <= 64) rc = launch_dgrad_i<2>(p, fast, s);
     else rc = launch_dgrad_i<4>(p, fast, s);

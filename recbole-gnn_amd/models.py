@@ -225,16 +225,17 @@ class NGCF(GeneralGraphRecommender):
         return torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
 
     def forward(self):
-        if not torch.is_grad_enabled() and self.message_dropout == 0:
+        if not torch.is_grad_enabled() and self.message_dropout == 0 and self.fused:
             return self._forward_fused()
         all_embeddings = self.get_ego_embeddings()
         embeddings_list = [all_embeddings]
-        if (self.fused and self.message_dropout == 0 and isinstance(self.graph, ops.GraphHandle)
-                and max(self.hidden_size_list) <= 128):
-            # training: each layer with its LeakyReLU + normalize tail is one forward and one backward library call
+        if self.fused and isinstance(self.graph, ops.GraphHandle) and max(self.hidden_size_list) <= 128:
+            # each layer with its LeakyReLU -> dropout -> normalize tail is one forward and one backward library call.
+            # The dropout mask is drawn on EVERY forward, training or not, like the reference's fresh
+            # nn.Dropout(p)(x) (ngcf.py:97); NGCF.yaml ships message_dropout = 0.1.
             for gnn in self.GNNlayers:
                 all_embeddings = ops.bignn_layer(all_embeddings, gnn.lin1.weight, gnn.lin1.bias, gnn.lin2.weight, gnn.lin2.bias,
-                                                 self.graph, 0.2)
+                                                 self.graph, 0.2, p_drop=self.message_dropout)
                 embeddings_list += [all_embeddings]
             ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
             return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])

@@ -300,7 +300,7 @@ class _BiGNNLayer(torch.autograd.Function):
     G·W products, the weight / bias gradients and the propagated input gradient)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, graph, slope):
+    def forward(ctx, x, w1, b1, w2, b2, graph, slope, mask):
         _require_device_graph(graph)
         _check_dense(x, "x", graph)
         x = x if x.stride(1) == 1 else x.contiguous()
@@ -310,17 +310,24 @@ class _BiGNNLayer(torch.autograd.Function):
         y = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
         p = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
         inv = torch.empty(n, dtype=torch.float32, device=x.device)
+        if mask is not None:
+            _check_dense(mask, "mask", graph)
+            if tuple(mask.shape) != (n, d_out):
+                raise ValueError(f"mask must be [{n}, {d_out}]")
+            mask = mask.contiguous()
         with torch.cuda.device(x.device):
             check(lib.rbg_bignn_layer_f32(graph.ptr, c_vp(x.data_ptr()), x.stride(0) if n > 1 else d_in, c_vp(w1.data_ptr()),
                                           c_vp(b1.data_ptr()), c_vp(w2.data_ptr()), c_vp(b2.data_ptr()), c_vp(y.data_ptr()), d_out,
-                                          c_vp(p.data_ptr()), c_vp(inv.data_ptr()), d_in, d_out, float(slope), _stream(x)))
-        ctx.graph, ctx.slope = graph, float(slope)
-        ctx.save_for_backward(x, p, y, inv, w1, w2)
+                                          c_vp(p.data_ptr()), c_vp(inv.data_ptr()), c_vp(mask.data_ptr()) if mask is not None else None,
+                                          d_in, d_out, float(slope), _stream(x)))
+        ctx.graph, ctx.slope, ctx.has_mask = graph, float(slope), mask is not None
+        ctx.save_for_backward(x, p, y, inv, w1, w2, *([mask] if mask is not None else []))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, p, y, inv, w1, w2 = ctx.saved_tensors
+        x, p, y, inv, w1, w2 = ctx.saved_tensors[:6]
+        mask = ctx.saved_tensors[6] if ctx.has_mask else None
         gy = gy if gy.stride(1) == 1 else gy.contiguous()
         n, d_in = x.shape
         d_out = w1.shape[0]
@@ -332,16 +339,21 @@ class _BiGNNLayer(torch.autograd.Function):
         work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=x.device)
         with torch.cuda.device(x.device):
             check(lib.rbg_bignn_backward_f32(ctx.graph.transpose().ptr, c_vp(gy.data_ptr()), gy.stride(0) if n > 1 else d_out,
-                                             c_vp(y.data_ptr()), d_out, c_vp(inv.data_ptr()), c_vp(x.data_ptr()),
+                                             c_vp(y.data_ptr()), d_out, c_vp(inv.data_ptr()),
+                                             c_vp(mask.data_ptr()) if mask is not None else None, c_vp(x.data_ptr()),
                                              x.stride(0) if n > 1 else d_in, c_vp(p.data_ptr()), c_vp(w1.data_ptr()),
                                              c_vp(w2.data_ptr()), d_in, d_out, ctx.slope, c_vp(gx.data_ptr()), c_vp(gw1.data_ptr()),
                                              c_vp(gw2.data_ptr()), c_vp(gb.data_ptr()), c_vp(work.data_ptr()), _stream(x)))
-        return gx, gw1, gb, gw2, gb, None, None
+        return gx, gw1, gb, gw2, gb, None, None, None
 
 
-def bignn_layer(x, w1, b1, w2, b2, graph, slope=0.2):
-    """normalize(LeakyReLU(BiGNNConv(x))) with fused forward and backward; d_in, d_out <= 128."""
-    return _BiGNNLayer.apply(x, w1, b1, w2, b2, graph, float(slope))
+def bignn_layer(x, w1, b1, w2, b2, graph, slope=0.2, p_drop=0.0, mask=None):
+    """normalize(dropout(LeakyReLU(BiGNNConv(x)))) — one NGCF layer (ngcf.py:94-98) with fused forward and backward;
+    d_in, d_out <= 128.  ``p_drop`` > 0 draws the scaled keep mask (0 or 1/(1-p)) with torch's RNG; ``mask`` supplies one."""
+    if mask is None and p_drop > 0:
+        keep = torch.rand((x.shape[0], w1.shape[0]), device=x.device) >= p_drop
+        mask = keep.to(torch.float32) / (1.0 - p_drop)
+    return _BiGNNLayer.apply(x, w1, b1, w2, b2, graph, float(slope), mask)
 
 
 class BiGNNConv(nn.Module):

@@ -1012,20 +1012,30 @@ def test_bignn_layer_forward_backward(rbg, cuda, n, d_in, d_out):
     w1, w2 = torch.randn(d_out, d_in, generator=gen) * 0.3, torch.randn(d_out, d_in, generator=gen) * 0.3
     b1, b2 = torch.randn(d_out, generator=gen) * 0.1, torch.randn(d_out, generator=gen) * 0.1
     up = torch.randn(n, d_out, generator=gen)
-    ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-    xr, w1r, b1r, w2r, b2r = ref_in
-    pr = dense @ xr
-    zr = (pr + xr) @ w1r.T + b1r + (pr * xr) @ w2r.T + b2r
-    yr = torch.nn.functional.normalize(torch.nn.functional.leaky_relu(zr, 0.2), p=2, dim=1)
-    (yr * up.double()).sum().backward()
-    got_in = [t.to(cuda).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
-    y = rbg.ops.bignn_layer(*got_in, h, 0.2)
-    (y * up.to(cuda)).sum().backward()
-    close(y, yr.detach().float(), tol=2e-5)
-    for got, ref, name in zip(got_in, ref_in, ("x", "w1", "b1", "w2", "b2")):
-        scale = max(1.0, float(ref.grad.abs().max()))
-        err = float((got.grad.cpu().double() - ref.grad).abs().max())
-        assert err <= 3e-5 * scale, (name, err, scale)
+    for p_drop in (0.0, 0.3):  # ngcf.py:96-98: LeakyReLU -> Dropout -> normalize, here with an explicit scaled keep mask
+        mask = None if p_drop == 0 else (torch.rand(n, d_out, generator=gen) >= p_drop).float() / (1 - p_drop)
+        ref_in = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        xr, w1r, b1r, w2r, b2r = ref_in
+        pr = dense @ xr
+        zr = (pr + xr) @ w1r.T + b1r + (pr * xr) @ w2r.T + b2r
+        ar = torch.nn.functional.leaky_relu(zr, 0.2)
+        if mask is not None:
+            ar = ar * mask.double()
+        yr = torch.nn.functional.normalize(ar, p=2, dim=1)
+        (yr * up.double()).sum().backward()
+        got_in = [t.to(cuda).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = rbg.ops.bignn_layer(*got_in, h, 0.2, mask=mask.to(cuda) if mask is not None else None)
+        (y * up.to(cuda)).sum().backward()
+        close(y, yr.detach().float(), tol=2e-5)
+        for got, ref, name in zip(got_in, ref_in, ("x", "w1", "b1", "w2", "b2")):
+            scale = max(1.0, float(ref.grad.abs().max()))
+            err = float((got.grad.cpu().double() - ref.grad).abs().max())
+            assert err <= 3e-5 * scale, (name, p_drop, err, scale)
+    # p_drop draws its own mask: about that fraction of the layer output is exactly zero
+    with torch.no_grad():
+        yd = rbg.ops.bignn_layer(*[t.to(cuda) for t in (x, w1, b1, w2, b2)], h, 0.2, p_drop=0.25)
+    if n * d_out >= 4000:
+        assert abs(float((yd == 0).float().mean()) - 0.25) < 0.05
 
 
 def test_ngcf_fused_training_path_matches_op_by_op(rbg, cuda, golden):
