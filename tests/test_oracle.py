@@ -145,3 +145,51 @@ def test_ngcf_oracle_golden(golden):
     # every propagated block is row-normalized (or an all-zero row)
     nrm = np.linalg.norm(out[:, 16:32], axis=1)
     assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm < 1e-12))
+
+
+# ---- restatements added with the "next" rows (SGL InfoNCE, SimGCL / XSimGCL) -------------------------------------------
+
+def test_ssl_loss_known_answers():
+    """calc_ssl_loss (sgl.py:176-209): with identical views and one-hot rows the loss has a closed form."""
+    n, tau = 4, 0.5
+    eye = torch.eye(n, dtype=torch.float64)
+    users = torch.tensor([0, 2])
+    items = torch.tensor([1])
+    # a = p = e_u, candidates = all e_j: v1 = exp(1/tau), v2 = exp(1/tau) + (n-1) exp(0)
+    per_row = -np.log(np.exp(1 / tau) / (np.exp(1 / tau) + (n - 1)))
+    got = O.calc_ssl_loss(users, items, eye, eye, eye, eye, tau, 0.3)
+    assert abs(float(got) - 0.3 * 3 * per_row) < 1e-12
+    # scale invariance of the normalised rows, and lse_rows == torch.logsumexp
+    q = torch.randn(5, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    c = torch.randn(9, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    a = O.calc_ssl_loss(torch.arange(5), torch.arange(5), q, q * 3.0, q, q * 3.0, tau, 1.0)
+    b = O.calc_ssl_loss(torch.arange(5), torch.arange(5), q * 0.5, q, q * 0.5, q, tau, 1.0)
+    assert abs(float(a) - float(b)) < 1e-9
+    assert torch.allclose(O.lse_rows(q, c, 2.0), torch.logsumexp(2.0 * q @ c.T, dim=1))
+
+
+def test_simgcl_forward_restatement(ref_inter):
+    """simgcl.py:24-38 / xsimgcl.py:28-48: no E0 in the mean; zero-eps noise changes nothing; the noise term has norm eps
+    per row and the sign of the clean embedding; layer_cl picks the right layer."""
+    uid, iid, nu, ni = ref_inter
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    conv = lambda t: torch.from_numpy(O.conv_csr_f64(t.numpy(), rowptr, col, val))
+    gen = torch.Generator().manual_seed(3)
+    uw, iw = torch.randn(nu, 8, dtype=torch.float64, generator=gen), torch.randn(ni, 8, dtype=torch.float64, generator=gen)
+    e0 = torch.cat([uw, iw])
+    e1 = conv(e0)
+    e2 = conv(e1)
+    u, i = O.simgcl_forward(uw, iw, conv, 2)
+    assert torch.allclose(torch.cat([u, i]), (e1 + e2) / 2)
+    noises = [torch.rand(nu + ni, 8, dtype=torch.float64, generator=gen) for _ in range(2)]
+    u0, i0 = O.simgcl_forward(uw, iw, conv, 2, noises=noises, eps=0.0)
+    assert torch.allclose(torch.cat([u0, i0]), (e1 + e2) / 2)
+    out = O.simgcl_forward(uw, iw, conv, 2, noises=noises, eps=0.1, layer_cl=1)
+    p1 = torch.cat(out[2:])  # the perturbed layer-1 embedding
+    delta = p1 - e1
+    rows = e1.abs().sum(1) > 0
+    assert torch.allclose(delta[rows].norm(dim=1) ** 2, (0.01 * (torch.nn.functional.normalize(noises[0], dim=-1)[rows] ** 2)
+                                                          * (e1[rows] != 0)).sum(1))
+    assert torch.all(torch.sign(delta[rows]) * torch.sign(e1[rows]) >= 0)
+    assert torch.all(delta[~rows] == 0)  # PAD rows: sign(0) = 0
+    assert abs(float(O.simgcl_cl_loss(e1[:6], e1[:6], 0.2, "mean")) - float(O.simgcl_cl_loss(e1[:6], e1[:6], 0.2)) / 6) < 1e-12
