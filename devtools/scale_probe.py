@@ -21,6 +21,7 @@ def time_ms(fn, iters=3):
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.time() - t) / iters * 1e3
 t_spmm = time_ms(lambda: rbg.ops.spmm_raw(g, x, out=y))
+rbg.set_option("col_split", 0); t_spmm_full = time_ms(lambda: rbg.ops.spmm_raw(g, x, out=y)); rbg.set_option("col_split", -1); rbg.ops.spmm_raw(g, x, out=y)
 uw, iw = x[:nu], x[nu:]
 out = torch.empty(n, d, device=dev); layers = torch.empty(3, n, d, device=dev)
 t_prop = time_ms(lambda: rbg.ops.lightgcn_forward_raw(g, uw, iw, 3, out=out, layers=layers))
@@ -41,5 +42,5 @@ for r in rows.tolist():
     err = max(err, float(np.abs(ref.sum(0) - got).max()))
 bl, bp = rbg.synth.algorithmic_bytes(n, 2 * e, d, 3)
 print(json.dumps(dict(kind="scale_probe", frac=a.frac, n=n, nnz=2 * e, d=d, gen_s=round(t_gen, 1), build_s=round(t_build, 2), max_deg=int(deg.max()),
-                      bins=g.bins(d), spmm_ms=round(t_spmm, 2), propagation_ms=round(t_prop, 2), prop_per_s=round(1e3 / t_prop, 2),
+                      bins=g.bins(d), spmm_ms=round(t_spmm, 2), spmm_ms_full_width=round(t_spmm_full, 2), propagation_ms=round(t_prop, 2), prop_per_s=round(1e3 / t_prop, 2),
                       frac_roofline=round(bl / (t_spmm * 1e-3) / 8e12, 4), spot_max_abs_err_vs_f64=err)))

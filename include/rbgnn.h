@@ -78,7 +78,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   read at graph creation; default 4), 0 = one row class on all XCDs
  *   "nt_store"    : 1 = non-temporal output stores
  *   "col_split"   : SpMM column-half mode (even / odd XCDs own the lower / upper half of the columns of one row class,
- *                   halving the per-XCD gather working set): -1 = auto (d = 128 only), 0 = off, 1 = on where eligible
+ *                   halving the per-XCD gather working set): -1 = auto (d = 128 and a table <= 512 MB), 0 = off, 1 = on where eligible
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192) */
 int rbg_set_option(const char *key, int64_t value);

@@ -484,9 +484,12 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     if constexpr (D == 64 || D == 128) {
         // default class split (users on XCDs 0-3, items on 4-7), contiguous rows: eligible for column halves
         // auto: only at d = 128 (measured r01, Gowalla shape: 86.4 -> 77.8 us; at d = 64 the doubled CSR / index work costs
-        // more than the better L2 hit rate returns: 42.0 -> 49.8 us)
+        // more than the better L2 hit rate returns: 42.0 -> 49.8 us) and only while the table is cache-scale (<= 512 MB):
+        // at the config-#5 shape (15 M rows, 7.7 GB) L2 residency is out of reach and reading the CSR twice loses 5 %
+        // (31.9 -> 33.7 ms)
         const int cs = opt_col_split();
-        if (p.mode != MODE_NOISE /* the noise row norm spans both halves */ && (cs == 1 || (cs < 0 && D == 128)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
+        const bool cache_scale = (int64_t)g->n_rows * D * 4 <= ((int64_t)512 << 20);
+        if (p.mode != MODE_NOISE /* the noise row norm spans both halves */ && (cs == 1 || (cs < 0 && D == 128 && cache_scale)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
             g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1)
             return launch_binned_half<D / 2>(g, p, s);
     }
