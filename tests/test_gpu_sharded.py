@@ -69,3 +69,56 @@ def test_world_size_one_is_the_plain_path(rbg, cuda, ref_inter):
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
     ref = C.lightgcn_forward(rowptr, col, val, e0[:nu].numpy(), e0[nu:].numpy(), 3)
     assert np.abs(got.cpu().numpy() - ref).max() <= 1e-5
+
+
+def test_shard_layer_begin_end_and_mean(rbg, cuda, ref_inter):
+    """rbg_shard_layer_begin / _end (the two-stream layer of the sharded path) and rbg_mean_f32, without a process group:
+    rank 0's plan of a 2-rank split, its halo rows filled by a stream-ordered copy on the comm stream where the
+    all_to_all would be.  The layer must equal the rows of the global product, three layers + mean the global forward."""
+    uid, iid, nu, ni = ref_inter
+    sh = rbg.sharded
+    d, k_layers = 64, 3
+    plans = sh.build_plans(uid, iid, nu, ni, 2)
+    plan = plans[0]
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    e0 = np.random.default_rng(2).standard_normal((nu + ni, d)).astype(np.float32)
+    layers_ref = [e0]
+    for _ in range(k_layers):
+        layers_ref.append(C.spmm(rowptr, col, val, layers_ref[-1]))
+    be = sh.HipBackend(cuda)
+    g_int = be.make_graph(plan.int_csr, plan.n_owned)
+    g_halo = be.make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
+    ctx = be.layer_ctx()
+    comm = torch.cuda.Stream(device=cuda, priority=-1)
+    main = torch.cuda.current_stream(cuda)
+    send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=cuda)
+    n_send = len(plan.send_idx)
+    send = torch.empty((max(n_send, 1), d), device=cuda)
+    halo = torch.empty((max(plan.n_halo, 1), d), device=cuda)
+    halo_ids = torch.as_tensor(np.asarray(plan.halo_ids), dtype=torch.int64, device=cuda)
+    ys = []
+    x = torch.from_numpy(e0[plan.owned]).to(cuda)
+    for k in range(k_layers):
+        y = torch.empty((plan.n_owned, d), device=cuda)
+        full_prev = torch.from_numpy(layers_ref[k]).to(cuda)  # what the peer would send: rows of the previous global layer
+        be.layer_begin(ctx, g_int, x, y, send_idx, n_send, send, main.cuda_stream, comm.cuda_stream)
+        with torch.cuda.stream(comm):  # stands in for the collective: fills the halo slots, ordered after the pack
+            if plan.n_halo:
+                halo[: plan.n_halo].copy_(full_prev[halo_ids])
+        be.layer_end(ctx, g_halo, halo, y, main.cuda_stream, comm.cuda_stream)
+        torch.cuda.synchronize()
+        if n_send:  # the pack kernel gathered this rank's rows for its peer
+            assert torch.equal(send[:n_send], x[send_idx])
+        err = float(np.abs(y.cpu().numpy() - layers_ref[k + 1][plan.owned]).max())
+        assert err <= 1e-5, (k, err)
+        ys.append(y)
+        x = y
+    e0_owned = torch.from_numpy(e0[plan.owned]).to(cuda)
+    mean = be.mean([e0_owned] + ys, torch.empty_like(ys[0]))
+    ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)[plan.owned]
+    assert float(np.abs(mean.cpu().numpy() - ref).max()) <= 1e-5
+    # rbg_mean_f32 on a length that is not a multiple of 4 (scalar path) and a single source
+    a = [torch.randn(1237, device=cuda) for _ in range(3)]
+    out = be.mean(a, torch.empty(1237, device=cuda))
+    assert torch.allclose(out, ((a[0] + a[1]) + a[2]) * (1.0 / 3.0), rtol=0, atol=1e-7)
+    assert torch.equal(be.mean([a[0]], torch.empty(1237, device=cuda)), a[0])
