@@ -1,7 +1,8 @@
 """The sharded path with the PRODUCT backend (HIP kernels) on the single GPU of the test box: two gloo
 processes share cuda:0 and exchange halos through the host ("staged" transport).  This covers every kernel
-the multi-GPU path launches (interior / halo CSR blocks, accumulate epilogue, send-list gather); only the
-RCCL all_to_all call itself is left to the multi-GPU driver run."""
+the multi-GPU path launches (interior / halo CSR blocks, accumulate epilogue, send-list gather).  The RCCL transport
+itself (pack, all_to_all_single, both stream structures) runs on a world-size-1 group whose plan exchanges a third of
+the rank's rows with itself; only exchanges between DIFFERENT GPUs are left to the multi-GPU driver run."""
 import os
 
 import numpy as np
@@ -122,3 +123,67 @@ def test_shard_layer_begin_end_and_mean(rbg, cuda, ref_inter):
     out = be.mean(a, torch.empty(1237, device=cuda))
     assert torch.allclose(out, ((a[0] + a[1]) + a[2]) * (1.0 / 3.0), rtol=0, atol=1e-7)
     assert torch.equal(be.mean([a[0]], torch.empty(1237, device=cuda)), a[0])
+
+
+def _nccl_world1_worker(port, uid, iid, nu, ni, k_layers, d, out_q):
+    """The RCCL transport on one GPU: a world-size-1 group, where all_to_all_single is a self-exchange.  The 1-rank plan is
+    rewritten so that every third node is a *halo* column: its rows are packed, sent (to the rank itself) and consumed by
+    the halo SpMM, exactly the calls of the N > 1 path; the result must be the global forward."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        plan = sh.build_plans(uid, iid, nu, ni, 1)[0]
+        rp, col, val = (np.asarray(a) for a in plan.int_csr)
+        n = plan.n_owned
+        halo_nodes = np.arange(0, n, 3)
+        slot = -np.ones(n, dtype=np.int64)
+        slot[halo_nodes] = np.arange(len(halo_nodes))
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        is_halo = slot[col] >= 0
+
+        def csr(mask, cols):
+            r = rows[mask]
+            ptr = np.zeros(n + 1, dtype=np.int64)
+            np.add.at(ptr, r + 1, 1)
+            return np.cumsum(ptr), cols.astype(np.int32), val[mask].astype(np.float32)
+
+        plan.int_csr = csr(~is_halo, col[~is_halo])
+        plan.halo_csr = csr(is_halo, slot[col[is_halo]])
+        plan.halo_ids = halo_nodes
+        plan.send_idx = halo_nodes.copy()
+        plan.send_counts = np.array([len(halo_nodes)])
+        plan.recv_counts = np.array([len(halo_nodes)])
+        plan.world = 2  # take the exchange branch; the split lists keep the length of the 1-rank group
+        e0 = np.random.default_rng(4).standard_normal((n, d)).astype(np.float32)
+        rowptr, c2, v2 = C.build_norm_csr(uid, iid, nu, ni)
+        ref = C.lightgcn_forward(rowptr, c2, v2, e0[:nu], e0[nu:], k_layers)
+        errs = {}
+        for overlap in (False, True):
+            prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="nccl", overlap=overlap)
+            for _ in range(2):  # buffers are reused: a second call must give the same result
+                got = prop.forward(torch.from_numpy(e0).to(dev), k_layers)
+            torch.cuda.synchronize()
+            errs[overlap] = float(np.abs(got.cpu().numpy() - ref).max())
+        out_q.put(errs)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nccl_transport_on_a_world_size_one_group(ref_inter):
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000)
+    p = ctx.Process(target=_nccl_world1_worker, args=(port, uid, iid, nu, ni, 3, 64, q))
+    p.start()
+    errs = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert errs[False] <= 1e-5 and errs[True] <= 1e-5, errs
