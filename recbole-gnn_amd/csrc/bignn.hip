@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "internal.h"
 
@@ -229,7 +230,11 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
     const int nch = (p.d_in + 63) / 64;
     const size_t lds = (size_t)2 * 32 * NT * (nch * 64 + 4) * sizeof(float);
     if (lds > 160 * 1024) return fail(RBG_EUNSUPPORTED, "BiGNNConv %d x %d needs %zu bytes of LDS", p.d_in, p.d_out, lds);
-    if (lds > 64 * 1024) {
+    static std::atomic<int> lds_attr_device{-2};  // per template instantiation: set once per device, not per launch
+    int cur_dev = -1;
+    (void)hipGetDevice(&cur_dev);
+    if (lds > 64 * 1024 && lds_attr_device.load() != cur_dev) {
+        lds_attr_device = cur_dev;
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dense_kernel<NT, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dense_kernel<NT, false>),

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "internal.h"
 
@@ -196,7 +197,11 @@ template <int TO, int TI>
 static int launch_wgrad(const WgradParams &p, bool fast, int64_t grid, hipStream_t s) {
     const size_t lds = std::max<size_t>((size_t)2 * 32 * (32 * TO + 2 * 32 * TI) * sizeof(float),
                                         (size_t)((32 * 32 * TO / 4 + 255) / 256) * 256 * sizeof(float4));
-    if (lds > 64 * 1024) {
+    static std::atomic<int> lds_attr_device{-2};  // per template instantiation: set once per device, not per launch
+    int cur_dev = -1;
+    (void)hipGetDevice(&cur_dev);
+    if (lds > 64 * 1024 && lds_attr_device.load() != cur_dev) {
+        lds_attr_device = cur_dev;
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_wgrad_kernel<TO, TI, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_wgrad_kernel<TO, TI, false>),
@@ -414,7 +419,11 @@ __global__ __launch_bounds__(256, (TI <= 2 && NCO == 1 ? 2 : 1)) void bignn_dgra
 template <int TI, int NCO>
 static int launch_dgrad(const DgradParams &p, bool fast, hipStream_t s) {
     const size_t lds = (size_t)2 * 32 * TI * (64 * NCO + 4) * sizeof(float);
-    if (lds > 64 * 1024) {
+    static std::atomic<int> lds_attr_device{-2};  // per template instantiation: set once per device, not per launch
+    int cur_dev = -1;
+    (void)hipGetDevice(&cur_dev);
+    if (lds > 64 * 1024 && lds_attr_device.load() != cur_dev) {
+        lds_attr_device = cur_dev;
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dgrad_kernel<TI, NCO, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&bignn_dgrad_kernel<TI, NCO, false>),
