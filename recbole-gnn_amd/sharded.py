@@ -347,8 +347,9 @@ class ShardedPropagation:
 
     # (Capturing the whole propagation in a HIP graph was tried on a world-size-1 RCCL group, devtools/nccl1_probe.py: a
     # lone all_to_all_single captures and replays, but the capture of this method — the collective on a second stream
-    # forked from the capturing one — segfaults inside torch.cuda.graph on torch 2.10 / ROCm 7.2, so the N > 1 path stays
-    # eager: a crash cannot be caught and voted on the way an exception is.)
+    # forked from the capturing one — segfaults inside torch.cuda.graph on torch 2.10 / ROCm 7.2; with the single-stream
+    # layer the capture works (236 vs 260 us) but the process hung in process-group teardown.  The N > 1 path stays
+    # eager: a crash or hang cannot be caught and voted on the way an exception is.)
     def forward(self, e0, n_layers):
         """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users."""
         if hasattr(self.backend, "mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
