@@ -27,10 +27,10 @@
 #include <atomic>
 
 #include "internal.h"
+#include "mfma_common.h"
 
 namespace rbg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct BignnParams {
     const float *P;  // [N, d_in] contiguous
@@ -46,24 +46,6 @@ struct BignnParams {
     float *inv_norm;  // optional [N]: 1 / max(||LeakyReLU(z)||, eps) per row, what the tail's backward needs
     const float *drop_mask;  // optional [N, d_out] contiguous: 0 or 1/(1-p), applied between LeakyReLU and normalize (ngcf.py:97)
 };
-
-// 32 floats of a row starting at k0.  FAST: the run is fully inside the row and 16-byte aligned.
-template <bool FAST>
-__device__ __forceinline__ void load_run32(const float *p, int k0, int d, float (&r)[32]) {
-    if (FAST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
-            r[4 * q + 0] = v.x;
-            r[4 * q + 1] = v.y;
-            r[4 * q + 2] = v.z;
-            r[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) r[s] = (k0 + s < d) ? p[k0 + s] : 0.f;
-    }
-}
 
 // Sum over the 32 lanes of a wave half, result in every lane: four DPP adds (xor 1, xor 2 as quad permutes, then
 // half-mirror and mirror inside the 16-lane row) and ONE cross-row exchange, instead of five dependent ds_bpermute.
@@ -94,8 +76,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(con
     float a1[32], a2[32];
     {
         const int64_t r = min(tile_first * 32 + i, p.n_rows - 1);
-        load_run32<FAST>(p.P + r * p.d_in, 32 * h, p.d_in, a1);
-        load_run32<FAST>(p.X + r * p.ldx, 32 * h, p.d_in, a2);
+        load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(p.P + r * p.d_in, true, 32 * h, p.d_in, a1);
+        load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(p.X + r * p.ldx, true, 32 * h, p.d_in, a2);
     }
     // Stage [W1 ; W2] as Wl[part][j][k] (row stride KP = 64 nch + 4 floats, zero-padded to DP rows and 64 nch columns).
     // Coalesced: consecutive threads fetch consecutive float4s of a weight row, and a whole batch of loads is in flight
@@ -153,8 +135,8 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(con
             acc[t] = (f32x16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < nch; ++c) {
             if (c > 0 || tile != tile_first) {  // (chunk 0 of the first tile was fetched before the staging)
-                load_run32<FAST>(p.P + r * p.d_in, 64 * c + 32 * h, p.d_in, a1);
-                load_run32<FAST>(p.X + r * p.ldx, 64 * c + 32 * h, p.d_in, a2);
+                load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(p.P + r * p.d_in, true, 64 * c + 32 * h, p.d_in, a1);
+                load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(p.X + r * p.ldx, true, 64 * c + 32 * h, p.d_in, a2);
             }
 #pragma unroll
             for (int s = 0; s < 32; ++s) {

@@ -15,10 +15,10 @@
 #include <atomic>
 
 #include "internal.h"
+#include "mfma_common.h"
 
 namespace rbg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct WgradParams {
     const float *G;

@@ -25,10 +25,10 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "mfma_common.h"
 
 namespace rbg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct LseParams {
     const float *own;
@@ -58,25 +58,6 @@ struct LseRows<16> {
     static __device__ __forceinline__ void run(F &&) {}
 };
 
-// 32 floats of a row starting at k0 (zero past d / for an out-of-range row)
-template <bool VEC>
-__device__ __forceinline__ void lse_load_run(const float *p, bool ok, int k0, int d, float (&r)[32]) {
-    if (VEC) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
-            r[4 * q + 0] = v.x;
-            r[4 * q + 1] = v.y;
-            r[4 * q + 2] = v.z;
-            r[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) r[s] = (ok && k0 + s < d) ? p[k0 + s] : 0.f;
-    }
-}
-
 constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // NC = ceil(d / 64) in {1, 2}.  GRAD = false: forward partial sums; true: gradient of the own side.
@@ -101,7 +82,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? 3 : 1) : (NC == 1 ? 4 : 2))
     const bool own_ok = own_row < p.n_own;
     float bo[NC][32];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) lse_load_run<VEC>(p.own + own_row * p.ld_own, own_ok, c * 64 + h * 32, p.d, bo[c]);
+    for (int c = 0; c < NC; ++c) load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.own + own_row * p.ld_own, own_ok, c * 64 + h * 32, p.d, bo[c]);
     const float c_own = (GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zsum = 0.f;

@@ -20,52 +20,11 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "mfma_common.h"
 
 namespace rbg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-
-// 32 floats of row `row` starting at k0 (zero beyond d or when the row is out of range).
-template <bool VEC>
-__device__ __forceinline__ void load_run(const float *base, int64_t ld, int64_t row, bool row_ok, int k0, int d,
-                                         float (&r)[32]) {
-    const float *p = base + row * ld + k0;
-    if (VEC) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + 4 * q);
-            r[4 * q + 0] = v.x;
-            r[4 * q + 1] = v.y;
-            r[4 * q + 2] = v.z;
-            r[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) r[s] = (row_ok && k0 + s < d) ? p[s] : 0.f;
-    }
-}
-
-// Branch-free variant for the hot loop: `p` points at an in-range row (callers clamp the row index; the columns or rows
-// computed from a clamped operand are never stored).  With FULLD (d == 64 * NCHUNK, 16-byte aligned rows) the eight loads
-// are unconditional, which keeps the whole tile loop one basic block — see the note on vmcnt at score_kernel.
-template <bool FAST>
-__device__ __forceinline__ void load_run_rowptr(const float *p, int k0, int d, float (&r)[32]) {
-    if (FAST) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
-            r[4 * q + 0] = v.x;
-            r[4 * q + 1] = v.y;
-            r[4 * q + 2] = v.z;
-            r[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) r[s] = (k0 + s < d) ? p[k0 + s] : 0.f;
-    }
-}
 
 // One 64-wide k chunk of one 32x32 tile: 32 exact-fp32 MFMAs.
 __device__ __forceinline__ f32x16 mfma_chunk(const float (&a)[32], const float (&b)[32], f32x16 acc) {
@@ -185,8 +144,8 @@ __global__ __launch_bounds__(256) void score_generic_kernel(const float *__restr
         f32x16 acc = zero;
         for (int c = 0; c < nchunk; ++c) {
             float a[32], b[32];
-            load_run<VEC>(U, ldu, ur, u_ok, c * 64 + h * 32, d, a);
-            load_run<VEC>(I, ldi, jr, jr < n, c * 64 + h * 32, d, b);
+            load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(U + ur * ldu, u_ok, c * 64 + h * 32, d, a);
+            load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(I + jr * ldi, jr < n, c * 64 + h * 32, d, b);
             acc = mfma_chunk(a, b, acc);
         }
         store_tile(S, n, B, user_tile * 32, jr, h, acc);
@@ -224,7 +183,7 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
     const float *urow = U + (ur < B ? ur : B - 1) * ldu;
     float a[NCHUNK][32];
 #pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) load_run_rowptr<FAST>(urow, c * 64 + h * 32, d, a[c]);
+    for (int c = 0; c < NCHUNK; ++c) load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(urow, true, c * 64 + h * 32, d, a[c]);
 
     float4 stage[NCHUNK * 2];
     auto fetch = [&](const int64_t t) __attribute__((always_inline)) {

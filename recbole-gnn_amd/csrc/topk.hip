@@ -26,10 +26,10 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "mfma_common.h"
 
 namespace rbg {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr float kNegInf = -__builtin_inff();
 
@@ -52,24 +52,6 @@ struct TopkParams {
     int32_t *w_idx;
     int32_t *w_cnt;            // [B][n_chunks*4]
 };
-
-template <bool VEC>
-__device__ __forceinline__ void tk_load_run(const float *p, bool ok, int k0, int d, float (&r)[32]) {
-    if (VEC) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && k0 + 4 * q < d) v = *reinterpret_cast<const float4 *>(p + k0 + 4 * q);
-            r[4 * q + 0] = v.x;
-            r[4 * q + 1] = v.y;
-            r[4 * q + 2] = v.z;
-            r[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < 32; ++s) r[s] = (ok && k0 + s < d) ? p[k0 + s] : 0.f;
-    }
-}
 
 // (va, ia) "better than" (vb, ib): higher score first, lower item id on ties (a total order -> deterministic)
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -217,7 +199,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     float a[NCHUNK][32];
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
-        tk_load_run<VEC>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+        load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
     // thresholds start at the pre-pass bound: an item scoring below the k-th best valid score of ANY item subset
     // cannot be in the top k.  tau[r] belongs to the user of accumulator row (r&3) + 8*(r>>2) + 4h.
     const float my_tau = (p.tau0 && bi < p.B) ? p.tau0[bi] : kNegInf;
@@ -317,7 +299,7 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
     float a[NCHUNK][32];
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
-        tk_load_run<VEC>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+        load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
     float best_v[16];
     int best_i[16];
 #pragma unroll
