@@ -46,4 +46,58 @@ __device__ __forceinline__ void load_run32f(const float *p, bool ok, int k0, int
     }
 }
 
+// A 32-row x 64 NCHUNK operand tile staged through LDS: the 256 threads of a workgroup fetch it with coalesced float4
+// loads (consecutive threads = consecutive 16 bytes; "every lane reads its own 128-byte run" would touch 64 cache lines
+// per instruction), publish it with row stride LD = 64 NCHUNK + 4 floats (16-byte aligned rows: full-rate b128 reads of
+// the fragments), and every wave multiplies it against its register-resident A fragments.  Rows >= n_rows are clamped
+// to the last row: callers never use what they produce.
+template <int NCHUNK, int MODE>
+struct RowTile {
+    static constexpr int LD = NCHUNK * 64 + 4;
+    float4 stage[NCHUNK * 2];
+
+    __device__ __forceinline__ void fetch(const float *base, int64_t ld, int64_t n_rows, int d, int64_t tile, int tid) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            const int64_t r = tile * 32 + row;
+            const float *src = base + (r < n_rows ? r : n_rows - 1) * ld + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == RUN_FAST) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else if (MODE == RUN_VEC) {
+                if (c4 < d) v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                if (c4 + 0 < d) v.x = src[0];
+                if (c4 + 1 < d) v.y = src[1];
+                if (c4 + 2 < d) v.z = src[2];
+                if (c4 + 3 < d) v.w = src[3];
+            }
+            stage[k] = v;
+        }
+    }
+    __device__ __forceinline__ void publish(float (*tile)[LD], int tid) const {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            *reinterpret_cast<float4 *>(&tile[row][c4]) = stage[k];
+        }
+    }
+    // acc[i = A row][j = tile row]: lane (i, h) walks k = 64c + 32h + s of tile row i, as its A fragment does
+    static __device__ __forceinline__ f32x16 product(const float (*tile)[LD], const float (&a)[NCHUNK][32], int i, int h) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float4 b = *reinterpret_cast<const float4 *>(&tile[i][c * 64 + h * 32 + s4 * 4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 0], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 3], b.w, acc, 0, 0, 0);
+            }
+        return acc;
+    }
+};
+
 }  // namespace rbg

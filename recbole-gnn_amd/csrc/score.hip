@@ -185,48 +185,11 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(urow, true, c * 64 + h * 32, d, a[c]);
 
-    float4 stage[NCHUNK * 2];
-    auto fetch = [&](const int64_t t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            const int64_t r = t * 32 + row;
-            const float *src = I + (r < n ? r : n - 1) * ldi + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (FAST) {
-                v = *reinterpret_cast<const float4 *>(src);
-            } else if (VEC) {
-                if (c4 < d) v = *reinterpret_cast<const float4 *>(src);
-            } else {
-                if (c4 + 0 < d) v.x = src[0];
-                if (c4 + 1 < d) v.y = src[1];
-                if (c4 + 2 < d) v.z = src[2];
-                if (c4 + 3 < d) v.w = src[3];
-            }
-            stage[k] = v;
-        }
-    };
-    auto publish = [&](const int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            *reinterpret_cast<float4 *>(&s_it[buf][row][c4]) = stage[k];
-        }
-    };
-    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
-        f32x16 acc = zero;
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {  // lane (i, h) walks k = 64c + 32h + s of item row i, as its user fragment does
-                const float4 b = *reinterpret_cast<const float4 *>(&s_it[buf][i][c * 64 + h * 32 + s4 * 4]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 0], b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 1], b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 2], b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 3], b.w, acc, 0, 0, 0);
-            }
-        return acc;
-    };
+    using Tile = RowTile<NCHUNK, (FAST ? RUN_FAST : (VEC ? RUN_VEC : RUN_ANY))>;
+    Tile tile;
+    auto fetch = [&](const int64_t t) __attribute__((always_inline)) { tile.fetch(I, ldi, n, d, t, tid); };
+    auto publish = [&](const int buf) __attribute__((always_inline)) { tile.publish(s_it[buf], tid); };
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) { return Tile::product(s_it[buf], a, i, h); };
     AlignedRows al;
     aligned_init(al, S, n, B, user_tile * 32, t0 * 32);
     // tiles whose shifted line lies inside the row for every phase, in a wave with 32 valid rows: unconditional stores

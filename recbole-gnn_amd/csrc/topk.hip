@@ -131,53 +131,9 @@ struct RowLoop<16> {
 };
 
 // Shared by both passes.  A workgroup = 4 waves = 4 tiles of 32 batch users (A fragments in registers); all four walk
-// the SAME item tiles, each fetched once per workgroup with coalesced float4 loads into a double-buffered LDS tile and
-// read back as b128 B fragments (score.hip: "every lane reads its own 128-byte run" costs 64 cache lines per load
-// instruction and as many L1-tag cycles as the MFMAs).
+// the SAME item tiles, each fetched once per workgroup into a double-buffered LDS tile (mfma_common.h::RowTile).
 template <int NCHUNK, bool VEC>
-struct ItemTiles {
-    static constexpr int LD = NCHUNK * 64 + 4;
-    float4 stage[NCHUNK * 2];
-    __device__ __forceinline__ void fetch(const TopkParams &p, const int64_t t, const int tid) {
-#pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            const int64_t r = t * 32 + row;
-            const float *src = p.I + (r < p.n_items ? r : p.n_items - 1) * (int64_t)p.d + c4;  // clamped: never scored
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (VEC) {
-                if (c4 < p.d) v = *reinterpret_cast<const float4 *>(src);
-            } else {
-                if (c4 + 0 < p.d) v.x = src[0];
-                if (c4 + 1 < p.d) v.y = src[1];
-                if (c4 + 2 < p.d) v.z = src[2];
-                if (c4 + 3 < p.d) v.w = src[3];
-            }
-            stage[k] = v;
-        }
-    }
-    __device__ __forceinline__ void publish(float (*tile)[LD], const int tid) const {
-#pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            *reinterpret_cast<float4 *>(&tile[row][c4]) = stage[k];
-        }
-    }
-    static __device__ __forceinline__ f32x16 product(const float (*tile)[LD], const float (&a)[NCHUNK][32], const int i, const int h) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-#pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {
-                const float4 b = *reinterpret_cast<const float4 *>(&tile[i][c * 64 + h * 32 + s4 * 4]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 0], b.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 1], b.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 2], b.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][s4 * 4 + 3], b.w, acc, 0, 0, 0);
-            }
-        return acc;
-    }
-};
+using ItemTiles = RowTile<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>;
 
 // CAP = list capacity per user: a prune leaves <= k entries and one tile adds <= 32, so CAP >= k + 32 (48 for k <= 16,
 // which lets two workgroups share a CU's LDS; 64 otherwise).
@@ -249,13 +205,13 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     };
     Tiles tiles;
     if (t_begin < t_end) {
-        tiles.fetch(p, t_begin, tid);
+        tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
         tiles.publish(s_it[0], tid);
     }
     __syncthreads();
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
-        if (t + 1 < t_end) tiles.fetch(p, t + 1, tid);  // in flight while this tile feeds the matrix core
+        if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
         if (wave_live) filter_tile(Tiles::product(s_it[buf], a, i, h), t * 32 + i);
         if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         __syncthreads();
@@ -311,13 +267,13 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     Tiles tiles;
     if (t_begin < t_end) {
-        tiles.fetch(p, t_begin, tid);
+        tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
         tiles.publish(s_it[0], tid);
     }
     __syncthreads();
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
-        if (t + 1 < t_end) tiles.fetch(p, t + 1, tid);
+        if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
         if (wave_live) {
             const f32x16 acc = Tiles::product(s_it[buf], a, i, h);
             const int64_t item = t * 32 + i;
