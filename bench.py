@@ -162,7 +162,7 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
     try:
         cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-5,
-               "hidden_size_list": [d] * 3}
+               "hidden_size_list": [d] * 3, "message_dropout": 0.0}
         ngcf = rbg.NGCF(cfg, ds)
         ngcf.train()
         opt = torch.optim.Adam(ngcf.parameters(), lr=1e-3)

@@ -79,6 +79,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "nt_store"    : 1 = non-temporal output stores
  *   "col_split"   : SpMM column-half mode (even / odd XCDs own the lower / upper half of the columns of one row class,
  *                   halving the per-XCD gather working set): -1 = auto (d = 128 and a table <= 512 MB), 0 = off, 1 = on where eligible
+ *   "sweep"       : 1 = SpMM launches use the column-sweep plan attached to the graph for that width (if any), 0 = binned kernel
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192) */
 int rbg_set_option(const char *key, int64_t value);
@@ -147,6 +148,26 @@ int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave,
 /* Copy the CSR out to HOST buffers: rowptr int64 [n_rows+1], col int32 [nnz], val fp32 [nnz].
  * Any pointer may be NULL.  Works for host and device graphs (D2H copy + sync for the latter). */
 int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val);
+
+/* Column-sweep launch plan of rbg_spmm_f32 and every operator built on it (engine extension, no reference counterpart:
+ * the reference's torch_sparse kernel has no launch plan).  The plan re-cuts the SAME CSR (every entry exactly once,
+ * values unchanged) into per-lane-group streams of pieces ordered by column range, so that all rows of an XCD sweep
+ * the gathered table range by range while their partial sums stay in LDS.  Arrays are HOST
+ * pointers and are validated (bounds, every row finished exactly once) before they are copied to the device:
+ *   lg_ptr      [n_wg * lgs + 1]  piece range of every lane-group, lgs = threads / (d / 4)
+ *   pieces      [n_pieces][2]     {first entry, slot | cnt << 16 | flags << 24}; flags: 1 = first piece of its slot
+ *                                 (store instead of add), 2 = columns index the workgroup's hot tile
+ *   ent         [n_ent][2]        {column, bit pattern of the fp32 value}
+ *   wg_row_ptr  [n_wg + 1], rows [n_desc][4] = {row, first slot, slots, 0}: the rows a workgroup finishes (sum of the
+ *                                 slots in order; 0 slots = an empty row, written as zeros)
+ *   wg_hot [n_wg][2] = {first, count} into hot_rows [n_hot] (or both NULL): rows of X copied to LDS at hot_base.
+ * One plan per width d in {32, 64, 128}; attaching replaces the previous plan of that width.  Not to be called
+ * concurrently with launches on the same handle.  The "sweep" option (default 1) selects the plan when present. */
+int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_floats, const int32_t *lg_ptr,
+                           const uint32_t *pieces, int64_t n_pieces, const int32_t *ent, int64_t n_ent,
+                           const int32_t *wg_row_ptr, const int32_t *rows, int64_t n_desc, const int32_t *wg_hot,
+                           const int32_t *hot_rows, int64_t n_hot, int hot_base);
+int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
 void rbg_graph_destroy(rbg_graph *g);
 

@@ -38,6 +38,9 @@ SIGNATURES = {
     "rbg_graph_bins": (c_int, [c_vp, c_int, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
     "rbg_graph_export_csr": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_destroy": (None, [c_vp]),
+    "rbg_graph_attach_sweep": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                       c_i64, c_int]),
+    "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
     "rbg_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "rbg_spmm_noise_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "rbg_lightgcn_forward_f32": (c_int, [P(c_vp), c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_u32, c_vp]),

@@ -38,13 +38,14 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
 int opt_xcd_split() { return g_xcd_split.load(); }
 int opt_nt_store() { return g_nt_store.load(); }
 int opt_topk_sample() { return g_topk_sample.load(); }
 int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
+int opt_sweep() { return g_sweep.load(); }
 
 Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
 
@@ -262,11 +263,25 @@ int plan_bins(const rbg_graph *g, BinPlan &plan) {
     return RBG_OK;
 }
 
+static void free_sweep(SweepDev *sw) {
+    if (!sw) return;
+    (void)hipFree(sw->lg_ptr);
+    (void)hipFree(sw->pieces);
+    (void)hipFree(sw->ent);
+    (void)hipFree(sw->wg_row_ptr);
+    (void)hipFree(sw->rows);
+    (void)hipFree(sw->wg_hot);
+    (void)hipFree(sw->hot_rows);
+    delete sw;
+}
+
 static void free_device(rbg_graph *g) {
     if (g->device < 0) return;
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return;
     if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
+    for (SweepDev *sw : g->sweeps) free_sweep(sw);
+    g->sweeps.clear();
     (void)hipFree(g->d_rowptr);
     (void)hipFree(g->d_col);
     (void)hipFree(g->d_val);
@@ -428,6 +443,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_col_split = (int)value;
         return RBG_OK;
     }
+    if (!strcmp(key, "sweep")) {
+        g_sweep = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "score_tiles")) {
         if (value < 0 || value > 4096) return fail(RBG_EINVAL, "score_tiles must be 0 (auto) or 1..4096");
         g_score_tiles = (int)value;
@@ -457,6 +476,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "col_split")) {
         *value = g_col_split.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sweep")) {
+        *value = g_sweep.load();
         return RBG_OK;
     }
     if (!strcmp(key, "score_tiles")) {
@@ -655,6 +678,132 @@ int rbg_norm_edges(int64_t n_users, int64_t n_items, int64_t n_inter, const int6
         deg[(size_t)r] = isinf(s) ? 0.0f : s;
     }
     for (int64_t e = 0; e < m; ++e) edge_weight[e] = (deg[(size_t)src[e]] * 1.0f) * deg[(size_t)dst[e]];
+    return RBG_OK;
+}
+
+int rbg_graph_detach_sweep(rbg_graph *g, int d) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return RBG_OK;
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    RBG_HIP(hipDeviceSynchronize());
+    for (size_t i = 0; i < g->sweeps.size();) {
+        if (g->sweeps[i] && (d <= 0 || g->sweeps[i]->d == d)) {
+            free_sweep(g->sweeps[i]);
+            g->sweeps.erase(g->sweeps.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+    return RBG_OK;
+}
+
+int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_floats, const int32_t *lg_ptr,
+                           const uint32_t *pieces, int64_t n_pieces, const int32_t *ent, int64_t n_ent,
+                           const int32_t *wg_row_ptr, const int32_t *rows, int64_t n_desc, const int32_t *wg_hot,
+                           const int32_t *hot_rows, int64_t n_hot, int hot_base) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "sweep plans attach to device graphs");
+    if (d != 32 && d != 64 && d != 128) return fail(RBG_EUNSUPPORTED, "sweep plans exist for d in {32, 64, 128}, got %d", d);
+    if (threads != 256 && threads != 512 && threads != 1024) return fail(RBG_EINVAL, "threads = %d", threads);
+    if (n_wg <= 0 || n_pieces < 0 || n_ent < 0 || n_desc < 0 || n_hot < 0) return fail(RBG_EINVAL, "negative size");
+    if (lds_floats <= 0 || (size_t)lds_floats * 4 > 160 * 1024) return fail(RBG_EINVAL, "lds_floats = %d (at most 160 KiB)", lds_floats);
+    if (!lg_ptr || !wg_row_ptr || (n_pieces && (!pieces || !ent)) || (n_desc && !rows)) return fail(RBG_EINVAL, "NULL plan array");
+    if ((wg_hot != nullptr) != (hot_rows != nullptr)) return fail(RBG_EINVAL, "wg_hot and hot_rows come together");
+    const int lpr = d / 4, lgs = threads / lpr, pm = lpr < 16 ? lpr : 16;
+    const int64_t n_lg = (int64_t)n_wg * lgs;
+    // the plan is executed as given, so everything the kernel dereferences is bounds-checked here
+    const int n_slots_max = (wg_hot ? hot_base : lds_floats) / d;
+    if (wg_hot && (hot_base < 0 || hot_base % 4 || hot_base > lds_floats)) return fail(RBG_EINVAL, "hot_base = %d", hot_base);
+    const int hot_cap = wg_hot ? (lds_floats - hot_base) / d : 0;
+    if (lg_ptr[0] != 0 || lg_ptr[n_lg] != n_pieces) return fail(RBG_EINVAL, "lg_ptr does not span the pieces");
+    std::vector<int32_t> hot_of_wg;
+    if (wg_hot) {
+        for (int w = 0; w < n_wg; ++w) {
+            const int32_t hb = wg_hot[2 * w], hn = wg_hot[2 * w + 1];
+            if (hb < 0 || hn < 0 || hn > hot_cap || (int64_t)hb + hn > n_hot) return fail(RBG_EINVAL, "wg_hot[%d] out of range", w);
+        }
+        for (int64_t h = 0; h < n_hot; ++h)
+            if (hot_rows[h] < 0 || hot_rows[h] >= g->n_cols) return fail(RBG_EINVAL, "hot_rows[%lld] out of range", (long long)h);
+    }
+    for (int64_t l = 0; l < n_lg; ++l) {
+        if (lg_ptr[l + 1] < lg_ptr[l]) return fail(RBG_EINVAL, "lg_ptr not monotone at %lld", (long long)l);
+        const int w = (int)(l / lgs);
+        int64_t pos = lg_ptr[l] < lg_ptr[l + 1] ? (int64_t)pieces[2 * (int64_t)lg_ptr[l]] : 0;
+        for (int64_t q = lg_ptr[l]; q < lg_ptr[l + 1]; ++q) {
+            const uint32_t beg = pieces[2 * q], meta = pieces[2 * q + 1];
+            const int cnt = (int)((meta >> 16) & 0xffu), slot = (int)(meta & 0xffffu), flags = (int)(meta >> 24);
+            if ((int64_t)beg != pos) return fail(RBG_EINVAL, "piece %lld does not continue its lane-group's stream", (long long)q);
+            if (cnt < 1 || cnt > pm || (int64_t)beg + cnt > n_ent) return fail(RBG_EINVAL, "piece %lld: cnt = %d", (long long)q, cnt);
+            if (slot >= n_slots_max) return fail(RBG_EINVAL, "piece %lld: slot %d beyond the LDS accumulators", (long long)q, slot);
+            const bool hot = (flags & 2) != 0;
+            if (hot && !wg_hot) return fail(RBG_EINVAL, "piece %lld is HOT but the plan has no hot tile", (long long)q);
+            for (int j = 0; j < cnt; ++j) {
+                const int32_t c = ent[2 * ((int64_t)beg + j)];
+                if (hot ? (c < 0 || c >= wg_hot[2 * w + 1]) : (c < 0 || c >= g->n_cols))
+                    return fail(RBG_EINVAL, "piece %lld entry %d: column %d out of range", (long long)q, j, c);
+            }
+            pos += cnt;
+        }
+    }
+    if (wg_row_ptr[0] != 0 || wg_row_ptr[n_wg] != n_desc) return fail(RBG_EINVAL, "wg_row_ptr does not span the row descriptors");
+    std::vector<uint8_t> seen;
+    try {
+        seen.assign((size_t)g->n_rows, 0);
+    } catch (const std::bad_alloc &) {
+        return fail(RBG_ENOMEM, "host allocation failed");
+    }
+    for (int w = 0; w < n_wg; ++w) {
+        if (wg_row_ptr[w + 1] < wg_row_ptr[w]) return fail(RBG_EINVAL, "wg_row_ptr not monotone at %d", w);
+        for (int64_t r = wg_row_ptr[w]; r < wg_row_ptr[w + 1]; ++r) {
+            const int32_t row = rows[4 * r], s0 = rows[4 * r + 1], ns = rows[4 * r + 2];
+            if (row < 0 || row >= g->n_rows || seen[(size_t)row]) return fail(RBG_EINVAL, "row descriptor %lld: row %d invalid or repeated", (long long)r, row);
+            seen[(size_t)row] = 1;
+            if (s0 < 0 || ns < 0 || s0 + ns > n_slots_max) return fail(RBG_EINVAL, "row descriptor %lld: slots out of range", (long long)r);
+        }
+    }
+    for (int64_t r = 0; r < g->n_rows; ++r)
+        if (!seen[(size_t)r]) return fail(RBG_EINVAL, "row %lld is finished by no workgroup", (long long)r);
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    if ((rc = rbg_graph_detach_sweep(g, d))) return rc;
+    SweepDev *sw = new (std::nothrow) SweepDev();
+    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
+    sw->d = d;
+    sw->threads = threads;
+    sw->n_wg = n_wg;
+    sw->lds_floats = lds_floats;
+    sw->hot_base = hot_base;
+    sw->n_pieces = n_pieces;
+    sw->n_ent = n_ent;
+    sw->n_desc = n_desc;
+    std::vector<int32_t> ent_pad;
+    try {
+        ent_pad.assign((size_t)(n_ent + 16) * 2, 0);
+    } catch (const std::bad_alloc &) {
+        delete sw;
+        return fail(RBG_ENOMEM, "host allocation failed");
+    }
+    if (n_ent) memcpy(ent_pad.data(), ent, sizeof(int32_t) * 2 * (size_t)n_ent);
+    rc = to_device(&sw->lg_ptr, lg_ptr, (size_t)n_lg + 1);
+    if (!rc) rc = to_device(&sw->pieces, pieces, (size_t)n_pieces * 2);
+    if (!rc) rc = to_device(&sw->ent, ent_pad.data(), ent_pad.size());
+    if (!rc) rc = to_device(&sw->wg_row_ptr, wg_row_ptr, (size_t)n_wg + 1);
+    if (!rc) rc = to_device(&sw->rows, rows, (size_t)n_desc * 4);
+    if (!rc && wg_hot) rc = to_device(&sw->wg_hot, wg_hot, (size_t)n_wg * 2);
+    if (!rc && wg_hot) rc = to_device(&sw->hot_rows, hot_rows, (size_t)n_hot);
+    if (rc) {
+        free_sweep(sw);
+        return rc;
+    }
+    try {
+        g->sweeps.push_back(sw);
+    } catch (const std::bad_alloc &) {
+        free_sweep(sw);
+        return fail(RBG_ENOMEM, "out of host memory");
+    }
     return RBG_OK;
 }
 

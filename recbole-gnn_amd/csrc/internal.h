@@ -33,6 +33,7 @@ Tuning current_tuning();
 int spmm_unroll();
 int opt_xcd_split();
 int opt_nt_store();
+int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the binned kernel (0)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)
 int opt_topk_sample();  // items the fused top-k pre-pass looks at
@@ -72,6 +73,25 @@ struct GroupPlan {
     int32_t n_short, pos_short;  // lane-group rows  desc[pos_short .. +n_short)
 };
 
+// Column-sweep launch plan (spmm.hip, "sweep" kernel): a persistent grid in which every lane-group walks its own stream
+// of pieces (<= 16 CSR entries of one row, all inside one column range) in column-range order, adding each piece's
+// partial sum into an LDS accumulator slot; rows are finished from their slots after a workgroup barrier.  All device.
+struct SweepDev {
+    int d = 0;            // embedding width the plan was cut for (lane-groups per workgroup = threads / (d/4))
+    int threads = 0;      // workgroup size
+    int n_wg = 0;         // grid
+    int lds_floats = 0;   // dynamic LDS per workgroup: accumulator slots [+ hot rows]
+    int32_t *lg_ptr = nullptr;      // [n_wg * lgs + 1] piece range of every lane-group
+    uint32_t *pieces = nullptr;     // [n_pieces][2]: {first entry, slot | cnt << 16 | flags << 24}
+    int32_t *ent = nullptr;         // [n_ent + 16][2]: {col, bits of val}
+    int32_t *wg_row_ptr = nullptr;  // [n_wg + 1]
+    int32_t *rows = nullptr;        // [n_desc][4]: {row, first slot, slots, 0}
+    int32_t *wg_hot = nullptr;      // [n_wg][2]: {first hot row, hot rows} or NULL
+    int32_t *hot_rows = nullptr;    // source row of every hot-tile row
+    int hot_base = 0;               // float offset of the hot tile inside the workgroup's LDS
+    int64_t n_pieces = 0, n_ent = 0, n_desc = 0;
+};
+
 }  // namespace rbg
 
 // The graph handle.  Arrays named d_* live in HBM (device >= 0); h_* on the host.
@@ -106,6 +126,7 @@ struct rbg_graph {
     float *d_partials = nullptr;    // [n_partial_slots][kPartialSlotFloats]
     uint32_t *d_counters = nullptr;  // [n_split_rows], zero between launches
     int32_t max_degree = 0;
+    std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
 };
 
 namespace rbg {

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <new>
 
 #include "internal.h"
@@ -303,6 +304,125 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     finish_row(p, dsc.x, acc, sl, W, coff);
 }
 
+// ---- column-sweep kernel ("sweep" plan, rbg_graph_attach_sweep) --------------------------------------------------------
+// The binned kernel above is bound by L2 misses: an XCD's 4 MB L2 cannot hold the table its rows gather from, and rows
+// are dispatched in degree order, so a cold row of X crosses the fabric once per reference (r01: 4.8x the algorithmic
+// bytes).  Here ALL rows of an XCD are in flight at once (persistent grid, accumulators in LDS) and every lane-group
+// walks its rows' entries column range by column range — the plan stores them in that order — so at any moment the
+// whole XCD gathers from one L2-sized range of X, which is then fetched from the fabric once per XCD and launch.
+// A piece = up to 16 entries of one row inside one column range; its partial sum is added to the row's LDS slot by the
+// one lane-group that owns the slot (rows longer than a lane-group's share are cut over several lane-groups, one slot
+// each), so the summation order is fixed by the plan: results are bit-stable, no atomics.
+// Optional hot tile: the plan may name rows of X that every workgroup of a class copies into its LDS first; pieces
+// flagged HOT index that copy instead of global memory (the north_star's "LDS staging of embedding tiles").
+struct SweepArgs {
+    const int32_t *lg_ptr;
+    const uint2 *pieces;
+    const int2 *ent;
+    const int32_t *wg_row_ptr;
+    const int4 *rows;
+    const int2 *wg_hot;
+    const int32_t *hot_rows;
+    int hot_base;
+};
+
+enum { PIECE_FIRST = 1, PIECE_HOT = 2 };
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int2 ld_ent(const int2 *p) {  // streamed once: non-temporal
+    const v2i w = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(p));
+    return make_int2(w.x, w.y);
+}
+
+template <int D, int U, int THREADS, bool CONTIG>
+__global__ __launch_bounds__(THREADS) void spmm_sweep_kernel(const SpmmParams p, const SweepArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    constexpr int LPR = D / 4;
+    constexpr int LGS = THREADS / LPR;
+    constexpr int PM = LPR < 16 ? LPR : 16;  // entries per piece (the plan is cut for this width)
+    const int lg = threadIdx.x / LPR, sl = threadIdx.x % LPR;
+    const int wg = blockIdx.x;
+    if (a.wg_hot) {
+        const int2 hw = a.wg_hot[wg];
+        for (int h = lg; h < hw.y; h += LGS) {
+            const int r = a.hot_rows[hw.x + h];
+            st4(lds + a.hot_base + h * D + sl * 4, ld4((CONTIG ? src_row_c<D>(p.x, r) : src_row(p.x, r)) + sl * 4));
+        }
+        __syncthreads();
+    }
+    const int q0 = a.lg_ptr[wg * LGS + lg], q1 = a.lg_ptr[wg * LGS + lg + 1];
+    if (q0 < q1) {
+        uint2 pc = a.pieces[q0];
+        int pos = (int)pc.x;
+        int2 e = make_int2(0, 0);
+        if (sl < PM) e = ld_ent(a.ent + pos + sl);
+        for (int q = q0; q < q1; ++q) {
+            const int cnt = (int)((pc.y >> 16) & 0xffu), slot = (int)(pc.y & 0xffffu), flags = (int)(pc.y >> 24);
+            // the next piece's descriptor and entries are requested before this piece's gathers (the entry array is
+            // padded, so the read past the lane-group's last piece stays in bounds)
+            pos += cnt;
+            uint2 pc_n = pc;
+            int2 e_n = e;
+            if (q + 1 < q1) {
+                pc_n = a.pieces[q + 1];
+                if (sl < PM) e_n = ld_ent(a.ent + pos + sl);
+            }
+            const int c = e.x;
+            const float v = __int_as_float(e.y);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (flags & PIECE_HOT) {
+                for (int j = 0; j < cnt; ++j) {
+                    const int cj = __shfl(c, j, LPR);
+                    const float vj = __shfl(v, j, LPR);
+                    acc = fma4(vj, ld4(lds + a.hot_base + cj * D + sl * 4), acc);
+                }
+            } else {
+                int j = 0;
+                for (; j + U <= cnt; j += U) {
+                    float4 xv[U];
+                    float vv[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int cj = __shfl(c, j + u, LPR);
+                        vv[u] = __shfl(v, j + u, LPR);
+                        xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc = fma4(vv[u], xv[u], acc);
+                }
+                if (j < cnt) {
+                    float4 xv[U - 1];
+                    float vv[U - 1];
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) {
+                        const int src = min(j + u, LPR - 1);
+                        const int cj = __shfl(c, src, LPR);
+                        const float vj = __shfl(v, src, LPR);
+                        const bool on = (j + u) < cnt;
+                        vv[u] = on ? vj : 0.f;
+                        xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (on) xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U - 1; ++u) acc = fma4(vv[u], xv[u], acc);
+                }
+            }
+            float *dst = lds + slot * D + sl * 4;
+            if (!(flags & PIECE_FIRST)) acc = add4(ld4(dst), acc);
+            st4(dst, acc);
+            pc = pc_n;
+            e = e_n;
+        }
+    }
+    __syncthreads();
+    for (int r = a.wg_row_ptr[wg] + lg; r < a.wg_row_ptr[wg + 1]; r += LGS) {
+        const int4 rd = a.rows[r];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < rd.z; ++i) s = add4(s, ld4(lds + (rd.y + i) * D + sl * 4));
+        finish_row(p, rd.x, s, sl, D);
+    }
+}
+
 // Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
 __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, int d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -509,6 +629,49 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     return RBG_OK;
 }
 
+// ---- sweep launch ----------------------------------------------------------------------------------------------------
+static const SweepDev *find_sweep(const rbg_graph *g, int d) {
+    for (const SweepDev *sw : g->sweeps)
+        if (sw && sw->d == d) return sw;
+    return nullptr;
+}
+
+template <int D, int THREADS, bool CONTIG>
+static int launch_sweep_inst(const SweepDev *sw, const SpmmParams &p, const SweepArgs &a, hipStream_t s) {
+    auto kern = spmm_sweep_kernel<D, 8, THREADS, CONTIG>;
+    const size_t lds_bytes = (size_t)sw->lds_floats * sizeof(float);
+    static std::atomic<size_t> configured[16] = {};  // per device: the largest dynamic-LDS size set for this instantiation
+    int dev = 0;
+    RBG_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && configured[dev].load() < lds_bytes) {
+        RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        configured[dev].store(lds_bytes);
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)sw->n_wg), dim3(THREADS), lds_bytes, s, p, a);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+template <int D>
+static int launch_sweep(const SweepDev *sw, const SpmmParams &p, hipStream_t s) {
+    SweepArgs a{};
+    a.lg_ptr = sw->lg_ptr;
+    a.pieces = reinterpret_cast<const uint2 *>(sw->pieces);
+    a.ent = reinterpret_cast<const int2 *>(sw->ent);
+    a.wg_row_ptr = sw->wg_row_ptr;
+    a.rows = reinterpret_cast<const int4 *>(sw->rows);
+    a.wg_hot = reinterpret_cast<const int2 *>(sw->wg_hot);
+    a.hot_rows = sw->hot_rows;
+    a.hot_base = sw->hot_base;
+    const bool contig = (p.x.ld == D);
+    switch (sw->threads) {
+        case 256: return contig ? launch_sweep_inst<D, 256, true>(sw, p, a, s) : launch_sweep_inst<D, 256, false>(sw, p, a, s);
+        case 512: return contig ? launch_sweep_inst<D, 512, true>(sw, p, a, s) : launch_sweep_inst<D, 512, false>(sw, p, a, s);
+        case 1024: return contig ? launch_sweep_inst<D, 1024, true>(sw, p, a, s) : launch_sweep_inst<D, 1024, false>(sw, p, a, s);
+        default: return fail(RBG_EINVAL, "sweep plan with %d threads per workgroup", sw->threads);
+    }
+}
+
 // One SpMM launch with the epilogue described by p (graph fields are filled here).
 static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) {
     fill_graph(g, p);
@@ -518,6 +681,16 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     if (p.mode == MODE_MEAN) {
         vec = vec && vec_ok(p.e0) && aligned16(p.mean_out);
         for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
+    }
+    if (vec && opt_sweep()) {
+        if (const SweepDev *sw = find_sweep(g, d)) {
+            switch (d) {
+                case 32: return launch_sweep<32>(sw, p, s);
+                case 64: return launch_sweep<64>(sw, p, s);
+                case 128: return launch_sweep<128>(sw, p, s);
+                default: break;
+            }
+        }
     }
     if (vec) {
         switch (d) {

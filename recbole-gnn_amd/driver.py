@@ -14,7 +14,8 @@ import torch
 
 from .graph import InteractionDataset
 from .models import LightGCN
-from .train import FusedBPRAdam, GraphedStep
+from .graph import GraphHandle
+from .train import FusedBPRAdam, GraphedStep, fused_step_applies
 
 
 def load_inter(path, user_field="user_id", item_field="item_id", sep="\t"):
@@ -123,9 +124,11 @@ def topk_metrics(topk_idx, truth, k):
 
 
 @torch.no_grad()
-def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096):
+def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096, history=None):
     """Full-sort evaluation (``mode: full``): every user with ground truth in (eval_uid, eval_iid) is ranked against all
-    items, PAD and training history masked, by the fused score/top-k kernel; metrics averaged over users."""
+    items, PAD and history masked, by the fused score/top-k kernel; metrics averaged over users.
+    ``history``: GraphHandle whose user rows are the interactions to mask (RecBole's sampler ``used_ids``: the training
+    set for the valid phase, training + valid for the test phase); None = the model's training graph."""
     model.eval()
     model.restore_user_e = model.restore_item_e = None
     truth = {}
@@ -135,7 +138,7 @@ def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096):
     sums, count = {}, 0
     for s in range(0, len(users), batch_users):
         ub = users[s:s + batch_users]
-        _, idx = model.full_sort_topk({"user_id": torch.from_numpy(ub).to(model.device)}, k)
+        _, idx = model.full_sort_topk({"user_id": torch.from_numpy(ub).to(model.device)}, k, history=history)
         m = topk_metrics(idx.cpu().numpy(), [truth[u] for u in ub.tolist()], k)
         for name, v in m.items():
             sums[name] = sums.get(name, 0.0) + float(v.sum())
@@ -146,12 +149,13 @@ def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096):
 def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None, graphed=True):
     """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  LightGCN with
     ``require_pow`` uses the fused step (train.py); any other model goes through torch autograd + torch.optim.Adam, the
-    whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly)."""
+    whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly;
+    models whose loss has data-dependent shapes — SimGCL, XSimGCL — always run eagerly)."""
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed)
-    if fused is None:
-        fused = isinstance(model, LightGCN) and model.require_pow
+    if fused is None:  # only the plain LightGCN objective: SimGCL / XSimGCL subclass it with different losses
+        fused = fused_step_applies(model) and model.require_pow
     stepper = FusedBPRAdam(model, lr=lr) if fused else None
-    graphed = graphed and not fused and next(model.parameters()).is_cuda
+    graphed = graphed and not fused and next(model.parameters()).is_cuda and getattr(model, "graph_capturable", True)
     opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr)
     gstep = None
     history = []
@@ -195,5 +199,8 @@ def run(model_cls, uid, iid, n_users, n_items, config=None, epochs=1, seed=2020,
     torch.manual_seed(seed)
     model = model_cls(cfg, dataset)
     losses = fit(model, tr_u, tr_i, epochs=epochs, lr=cfg.get("learning_rate", 1e-3), seed=seed, log=log)
+    # the test phase masks training AND validation positives (RecBole's test sampler used_ids), the valid phase training only
+    seen = GraphHandle.from_interactions(np.concatenate([tr_u, va_u]), np.concatenate([tr_i, va_i]), n_users, n_items,
+                                         device=model.device) if len(va_u) else None
     return {"model": model, "train_loss": losses, "valid": evaluate(model, va_u, va_i, k=k) if len(va_u) else {},
-            "test": evaluate(model, te_u, te_i, k=k) if len(te_u) else {}}
+            "test": evaluate(model, te_u, te_i, k=k, history=seen) if len(te_u) else {}}

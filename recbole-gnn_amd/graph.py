@@ -103,6 +103,8 @@ class GraphHandle:
             n_parts = int(part.max()) + 1 if part.size else 1
             if keep is not None:
                 keep = np.ascontiguousarray(keep.detach().cpu().numpy() if isinstance(keep, torch.Tensor) else keep, dtype=np.uint8)
+                if keep.shape != uid.shape:  # the C side reads keep[e] for every interaction
+                    raise ValueError("keep mask must have one entry per interaction")
             check(lib.rbg_graph_create_partitioned(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
                                                    _ptr(keep), _ptr(part), n_parts, _device_index(device), flags))
             return cls(out.value, symmetric=True, n_users=int(n_users))

@@ -182,21 +182,24 @@ class LightGCN(GeneralGraphRecommender):
         return scores.view(-1)
 
 
-def _full_sort_topk(model, interaction, k):
-    """Evaluation without the score matrix: cached propagation (as full_sort_predict) + fused scoring / masking / top-k."""
+def _full_sort_topk(model, interaction, k, history=None):
+    """Evaluation without the score matrix: cached propagation (as full_sort_predict) + fused scoring / masking / top-k.
+    ``history``: graph whose user rows are masked (default: the training graph)."""
     if model.restore_user_e is None or model.restore_item_e is None:
         with torch.no_grad():
-            model.restore_user_e, model.restore_item_e = model.forward()
-    return ops.full_sort_topk(model.graph, model.restore_user_e, model.restore_item_e, interaction[model.USER_ID], k)
+            out = model.forward()
+            model.restore_user_e, model.restore_item_e = out[0], out[1]
+    return ops.full_sort_topk(history if history is not None else model.graph, model.restore_user_e, model.restore_item_e,
+                              interaction[model.USER_ID], k)
 
 
 LightGCN.full_sort_topk = _full_sort_topk
 
 
 class NGCF(GeneralGraphRecommender):
-    """general_recommender/ngcf.py:36-149, at node_dropout = 0 (edge dropout, ngcf.py:74-90, is not
-    part of the accelerated path).  ``message_dropout`` defaults to 0 here: the reference's
-    ``nn.Dropout(p)(x)`` (ngcf.py:97) is active even in eval, so parity is defined at 0."""
+    """general_recommender/ngcf.py:36-149.  Defaults are NGCF.yaml's (``message_dropout`` 0.1, ``node_dropout`` 0.0).
+    The reference's ``nn.Dropout(p)(x)`` (ngcf.py:97) is a fresh module, hence active even under ``model.eval()``
+    (SURVEY.md Q3): value parity is defined at ``message_dropout = 0`` (the parity tests pass it explicitly)."""
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -204,7 +207,7 @@ class NGCF(GeneralGraphRecommender):
         self.embedding_size = config["embedding_size"] or 64
         self.hidden_size_list = [self.embedding_size] + list(config["hidden_size_list"] or [64, 64, 64])
         self.node_dropout = config["node_dropout"] or 0.0
-        self.message_dropout = config["message_dropout"] or 0.0
+        self.message_dropout = config["message_dropout"] if config["message_dropout"] is not None else 0.1  # NGCF.yaml
         self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
         self.fused = config["fused_forward"] if config["fused_forward"] is not None else True  # False: op-by-op like ngcf.py
         if self.node_dropout != 0:
@@ -428,9 +431,13 @@ class SimGCL(LightGCN):
     adds sign(e) * normalize(U(0,1) noise) * eps after every layer — the noise is drawn with ``torch.rand_like`` in the
     reference's order, the add is the SpMM's epilogue (``ops.spmm_noise``)."""
 
+    graph_capturable = False  # calculate_loss calls torch.unique (simgcl.py:52-53): data-dependent shapes
+
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
         config = self.config
+        if config["reg_weight"] is None:
+            self.reg_weight = 1e-4  # SimGCL.yaml / XSimGCL.yaml (LightGCN.yaml ships 1e-5)
         self.cl_rate = config["lambda"] if config["lambda"] is not None else 0.5
         self.eps = config["eps"] if config["eps"] is not None else 0.1
         self.temperature = config["temperature"] if config["temperature"] is not None else 0.2

@@ -408,6 +408,16 @@ def gather_rows(src, idx):
     return out
 
 
+def _history_csr(graph):
+    """(rowptr, col) of a graph handle as device tensors (cached on the handle): user u's history = its row."""
+    hit = getattr(graph, "_hist_csr", None)
+    if hit is None:
+        rowptr, col, _ = graph.export_csr()
+        hit = (torch.from_numpy(rowptr).to(graph.device), torch.from_numpy(col.astype("int64")).to(graph.device))
+        graph._hist_csr = hit
+    return hit
+
+
 def full_sort_topk(history, user_all, item_all, users, k):
     """Top-k items per user of ``user_all[users] @ item_all.T`` with the PAD item and each user's training history
     masked (full_sort_predict + RecBole's ``_full_sort_batch_eval`` masking + ``torch.topk``), without ever writing the
@@ -419,6 +429,25 @@ def full_sort_topk(history, user_all, item_all, users, k):
     user_all, item_all = user_all.contiguous(), item_all.contiguous()
     users = users.to(device=user_all.device, dtype=torch.int64).contiguous()
     b, (n_users, d), n_items = users.shape[0], user_all.shape, item_all.shape[0]
+    if k > 32 or d > 256:
+        # beyond the fused kernel's list capacity (e.g. RecBole configs with topk: [50]): the reference's own sequence —
+        # score matrix, PAD and history to -inf, torch.topk (Trainer._full_sort_batch_eval [recbole==1.1.1])
+        scores = score(gather_rows(user_all, users), item_all)
+        scores[:, 0] = float("-inf")
+        if history is not None:
+            rowptr, col = _history_csr(history)
+            cnt = rowptr[users + 1] - rowptr[users]
+            rows = torch.repeat_interleave(torch.arange(b, device=users.device), cnt)
+            start = torch.repeat_interleave(rowptr[users] - (torch.cumsum(cnt, 0) - cnt), cnt)
+            items = col[start + torch.arange(rows.shape[0], device=users.device)] - n_users
+            scores[rows, items] = float("-inf")
+        kk = min(k, n_items)
+        vals, idx = torch.topk(scores, kk, dim=1)
+        idx = torch.where(torch.isinf(vals) & (vals < 0), torch.full_like(idx, -1), idx)
+        if kk < k:
+            vals = torch.cat([vals, vals.new_full((b, k - kk), float("-inf"))], 1)
+            idx = torch.cat([idx, idx.new_full((b, k - kk), -1)], 1)
+        return vals, idx
     nbytes = _lib.c_i64()
     check(lib.rbg_full_sort_topk_workspace(b, n_items, k, ctypes.byref(nbytes)))
     work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=user_all.device)

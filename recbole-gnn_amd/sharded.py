@@ -350,8 +350,10 @@ class ShardedPropagation:
     # forked from the capturing one — segfaults inside torch.cuda.graph on torch 2.10 / ROCm 7.2; with the single-stream
     # layer the capture works (236 vs 260 us) but the process hung in process-group teardown.  The N > 1 path stays
     # eager: a crash or hang cannot be caught and voted on the way an exception is.)
-    def forward(self, e0, n_layers):
-        """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users."""
+    def forward(self, e0, n_layers, out=None):
+        """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users.
+        The result lives in a buffer this object re-uses: it is valid until the next forward() / spmm() call on this
+        object (propagating two views back to back: pass ``out=`` or clone the first result)."""
         if hasattr(self.backend, "mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
             # keep the K layer outputs and take the mean in one launch (instead of clone + K adds + a divide)
             self._buffers(e0)
@@ -362,11 +364,14 @@ class ShardedPropagation:
             for k in range(n_layers):
                 x = self.spmm(x, out=self._y[k], main=main)
                 srcs.append(x)
-            return self.backend.mean(srcs, self._mean, stream=main.cuda_stream)
+            return self.backend.mean(srcs, self._mean if out is None else out, stream=main.cuda_stream)
         acc = e0.clone()
         x = e0
         for _ in range(n_layers):
             x = self.spmm(x)
             acc += x
         acc /= float(n_layers + 1)
+        if out is not None:
+            out.copy_(acc)
+            return out
         return acc

@@ -15,10 +15,18 @@ from ._lib import c_vp, check, lib
 from .models import LightGCN
 
 
+def fused_step_applies(model):
+    """True when the model's training objective is exactly lightgcn.py:83-110 (what the fused step implements)."""
+    return (isinstance(model, LightGCN) and type(model).calculate_loss is LightGCN.calculate_loss
+            and type(model).forward is LightGCN.forward)
+
+
 class FusedBPRAdam:
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        if not isinstance(model, LightGCN):
-            raise TypeError("FusedBPRAdam drives a LightGCN model")
+        # exactly LightGCN: subclasses (SimGCL, XSimGCL) override forward / calculate_loss — contrastive terms, perturbed
+        # passes, a layer mean without E0 — none of which this hard-wired BPR + reg step computes
+        if not fused_step_applies(model):
+            raise TypeError("FusedBPRAdam drives a plain LightGCN model (its forward and calculate_loss, not a subclass's)")
         if not model.require_pow:
             raise NotImplementedError("the fused regulariser implements EmbLoss(require_pow=True) (LightGCN.yaml default)")
         self.model, self.lr, self.betas, self.eps = model, float(lr), betas, float(eps)
@@ -80,7 +88,10 @@ class GraphedStep:
     The autograd path of NGCF / SGL issues ~300 kernels per step from Python; on MI355X those kernels add up to less than
     half of the step's wall time (NGCF, Gowalla shape: 1.5 ms of kernels in a 3.5 ms step, r01) — the rest is launch
     latency.  A graph replay submits the same kernels, in the same order on the same buffers, with one call.  Works for
-    any model of this package (all device work is enqueued on torch's current stream and nothing synchronises).
+    every model of this package whose loss has static shapes (all device work is enqueued on torch's current stream and
+    nothing synchronises): LightGCN, NGCF, SGL.  SimGCL / XSimGCL call ``torch.unique`` on the batch (simgcl.py:52-53):
+    a data-dependent shape needs a device-to-host sync, which stream capture forbids, and a replay would bake in the
+    first batch's unique count — those models declare ``graph_capturable = False`` and are refused here.
 
     ``step(batch)`` copies the batch's index tensors into the captured input buffers and replays; batches must have the
     size of ``example_batch`` (RecBole's last, shorter batch of an epoch goes through ``eager_step``)."""
@@ -88,6 +99,9 @@ class GraphedStep:
     def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, warmup=2):
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("GraphedStep needs the model on a GPU")
+        if not getattr(model, "graph_capturable", True):
+            raise RuntimeError(f"{type(model).__name__}.calculate_loss has data-dependent shapes (torch.unique) and cannot be "
+                               "captured into a HIP graph; train it eagerly")
         self.model = model
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True)
         self.static = {k: v.detach().clone() for k, v in example_batch.items()}
