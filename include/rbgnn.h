@@ -125,6 +125,13 @@ int rbg_graph_create_partitioned(rbg_graph **out, int64_t n_users, int64_t n_ite
 int rbg_graph_create_csr(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
                          const int32_t *col, const float *val, int device, uint32_t flags);
 
+/* The same, with the caller declaring two row classes: rows [0, n_class0_rows) and the rest reference disjoint sets of
+ * columns (a shard's user rows gather item embeddings only, its item rows user embeddings only), so the launch plan pins
+ * the classes to different XCDs exactly as it does for graphs built from interactions (each XCD's L2 then serves one
+ * table).  n_class0_rows < 0: one class (= rbg_graph_create_csr).  Results do not depend on it. */
+int rbg_graph_create_csr_classes(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                                 const int32_t *col, const float *val, int64_t n_class0_rows, int device, uint32_t flags);
+
 /* The (edge_index, edge_weight) form, i.e. get_norm_adj_mat(enable_sparse=False|None)
  *   recbole_gnn/data/dataset.py:60-66,77-79.
  * Writes edge_index as int64 [2][2*n_inter] (row 0 = source, row 1 = target; first all u->i,
@@ -148,6 +155,17 @@ int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave,
 /* Copy the CSR out to HOST buffers: rowptr int64 [n_rows+1], col int32 [nnz], val fp32 [nnz].
  * Any pointer may be NULL.  Works for host and device graphs (D2H copy + sync for the latter). */
 int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val);
+
+/* Edge re-weighting without a rebuild — NGCF's per-forward edge dropout (ngcf.py:74-90: dropout_adj [PyG] filters the
+ * directed edges with a Bernoulli mask, weights unchanged, no re-normalisation, then re-builds and re-sorts a
+ * SparseTensor on every forward).  A view shares src's sparsity structure and launch plan and reads its values from the
+ * caller's DEVICE array vals [nnz] (the handle's CSR entry order) at launch time: the caller rewrites that array between
+ * stream-ordered launches (vals[e] = weight[e] * keep[e]); a dropped edge is a zero weight.  src must outlive the view.
+ * rbg_graph_transpose_map fills map [nnz] (DEVICE int32) with the position of every entry's transposed partner, so the
+ * values of the transposed view (the autograd backward of a NON-symmetric dropout mask) are vals_t[e] = vals[map[e]].
+ * It synchronises the stream (called once per graph) and fails if the structure is not symmetric. */
+int rbg_graph_create_reweighted(rbg_graph **out, const rbg_graph *src, const float *vals);
+int rbg_graph_transpose_map(const rbg_graph *g, int32_t *map, void *stream);
 
 /* Column-sweep launch plan of rbg_spmm_f32 and every operator built on it (engine extension, no reference counterpart:
  * the reference's torch_sparse kernel has no launch plan).  The plan re-cuts the SAME CSR (every entry exactly once,

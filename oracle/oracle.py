@@ -126,6 +126,15 @@ def sgl_random_graph_augment(uid, iid, n_users, n_items, aug_type, drop_ratio, r
     return keep_mask, graph
 
 
+def dropout_adj(edge_index, edge_weight, keep_mask):
+    """PyG ``dropout_adj(edge_index, edge_attr, p, training=True)`` as called at
+    recbole_gnn/model/general_recommender/ngcf.py:81-82,89-90, with the Bernoulli draw
+    ``mask = torch.rand(E) >= p`` replaced by an explicit ``keep_mask``: the surviving directed edges keep their
+    weights — no rescale by 1/(1-p), no re-normalisation, the two directions of an interaction are independent."""
+    keep = torch.as_tensor(keep_mask, dtype=torch.bool)
+    return edge_index[:, keep], edge_weight[keep]
+
+
 # --------------------------------------------------------------------------------------------
 # operators
 # --------------------------------------------------------------------------------------------

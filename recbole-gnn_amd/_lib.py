@@ -32,12 +32,15 @@ SIGNATURES = {
     "rbg_graph_create_masked": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),
     "rbg_graph_create_partitioned": (c_int, [P(c_vp), c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_u32]),
     "rbg_graph_create_csr": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_vp, c_int, c_u32]),
+    "rbg_graph_create_csr_classes": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_u32]),
     "rbg_graph_create_coo": (c_int, [P(c_vp), c_i64, c_i64, c_vp, c_vp, c_int, c_u32]),
     "rbg_norm_edges": (c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_info": (c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_int)]),
     "rbg_graph_bins": (c_int, [c_vp, c_int, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
     "rbg_graph_export_csr": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_destroy": (None, [c_vp]),
+    "rbg_graph_create_reweighted": (c_int, [P(c_vp), c_vp, c_vp]),
+    "rbg_graph_transpose_map": (c_int, [c_vp, c_vp, c_vp]),
     "rbg_graph_attach_sweep": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
                                        c_i64, c_int]),
     "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),

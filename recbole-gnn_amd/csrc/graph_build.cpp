@@ -245,12 +245,15 @@ int plan_bins(const rbg_graph *g, BinPlan &plan) {
         return RBG_OK;
     }
     // default XCD specialisation needs the user/item boundary (graphs built from interactions) and both classes
+    // (or, for a CSR-built block such as a shard's interior / halo part, the caller-declared row_split: the two row
+    // classes reference disjoint column sets there too)
     const int S = std::min(7, opt_xcd_split());
-    const bool split = S > 0 && g->n_users > 0 && g->n_users < n && g->n_rows == g->n_cols;
+    const int64_t cut = g->row_split >= 0 ? g->row_split : ((g->n_rows == g->n_cols) ? g->n_users : -1);
+    const bool split = S > 0 && cut > 0 && cut < n;
     if (split) {
         plan.n_groups = 2;
-        plan_group(g, range(0, g->n_users), plan, plan.groups[0]);
-        plan_group(g, range(g->n_users, n), plan, plan.groups[1]);
+        plan_group(g, range(0, cut), plan, plan.groups[0]);
+        plan_group(g, range(cut, n), plan, plan.groups[1]);
         for (int x = 0; x < 8; ++x) {
             const bool second = x >= S;
             plan.xmap.grp[x] = second ? 1 : 0;
@@ -282,6 +285,14 @@ static void free_device(rbg_graph *g) {
     if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
     for (SweepDev *sw : g->sweeps) free_sweep(sw);
     g->sweeps.clear();
+    if (g->base) {  // a view owns only its split-row scratch
+        (void)hipFree(g->d_partials);
+        (void)hipFree(g->d_counters);
+        g->d_partials = nullptr;
+        g->d_counters = nullptr;
+        if (cur != g->device) (void)hipSetDevice(cur);
+        return;
+    }
     (void)hipFree(g->d_rowptr);
     (void)hipFree(g->d_col);
     (void)hipFree(g->d_val);
@@ -562,10 +573,16 @@ int rbg_graph_create(rbg_graph **out, int64_t n_users, int64_t n_items, int64_t 
 
 int rbg_graph_create_csr(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
                          const int32_t *col, const float *val, int device, uint32_t flags) {
+    return rbg_graph_create_csr_classes(out, n_rows, n_cols, rowptr, col, val, -1, device, flags);
+}
+
+int rbg_graph_create_csr_classes(rbg_graph **out, int64_t n_rows, int64_t n_cols, const int64_t *rowptr,
+                                 const int32_t *col, const float *val, int64_t n_class0_rows, int device, uint32_t flags) {
     clear_error();
     if (!out) return fail(RBG_EINVAL, "out is NULL");
     *out = nullptr;
     if (n_rows < 0 || n_cols < 0 || !rowptr) return fail(RBG_EINVAL, "bad shape or NULL rowptr");
+    if (n_class0_rows > n_rows) return fail(RBG_EINVAL, "n_class0_rows = %lld > n_rows", (long long)n_class0_rows);
     if (device < -1) return fail(RBG_EINVAL, "device %d", device);
     if (n_rows >= (int64_t)INT32_MAX || n_cols >= (int64_t)INT32_MAX)
         return fail(RBG_EUNSUPPORTED, "dimension >= 2^31");
@@ -586,6 +603,7 @@ int rbg_graph_create_csr(rbg_graph **out, int64_t n_rows, int64_t n_cols, const 
     g->n_rows = n_rows;
     g->n_cols = n_cols;
     g->nnz = nnz;
+    g->row_split = n_class0_rows < 0 ? -1 : n_class0_rows;
     int rc = RBG_OK;
     try {
         g->h_rowptr.resize((size_t)n_rows + 1);
@@ -804,6 +822,57 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
         free_sweep(sw);
         return fail(RBG_ENOMEM, "out of host memory");
     }
+    return RBG_OK;
+}
+
+int rbg_graph_create_reweighted(rbg_graph **out, const rbg_graph *src, const float *vals) {
+    clear_error();
+    if (!out) return fail(RBG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!src) return fail(RBG_EINVAL, "src is NULL");
+    if (src->device < 0) return fail(RBG_ENODEV, "re-weighted views exist for device graphs");
+    if (src->nnz > 0 && !vals) return fail(RBG_EINVAL, "vals is NULL");
+    int rc = set_device_for(src->device);
+    if (rc) return rc;
+    rbg_graph *g = new (std::nothrow) rbg_graph();
+    if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
+    const rbg_graph *root = src->base ? src->base : src;
+    g->n_rows = root->n_rows;
+    g->n_cols = root->n_cols;
+    g->nnz = root->nnz;
+    g->n_users = root->n_users;
+    g->row_split = root->row_split;
+    g->device = root->device;
+    g->flags = root->flags & ~RBG_GRAPH_KEEP_HOST;
+    g->d_rowptr = root->d_rowptr;
+    g->d_col = root->d_col;
+    g->d_val = const_cast<float *>(vals);
+    g->tuning = root->tuning;
+    g->n_groups = root->n_groups;
+    g->xmap = root->xmap;
+    for (int q = 0; q < kMaxGroups; ++q) g->groups[q] = root->groups[q];
+    g->d_desc = root->d_desc;
+    g->n_block_rows = root->n_block_rows;
+    g->n_wave = root->n_wave;
+    g->n_short = root->n_short;
+    g->d_tasks = root->d_tasks;
+    g->n_tasks = root->n_tasks;
+    g->n_split_rows = root->n_split_rows;
+    g->n_partial_slots = root->n_partial_slots;
+    g->max_degree = root->max_degree;
+    g->base = root;
+    // split rows publish partial sums through per-handle scratch: a view gets its own, so launches on the view and on
+    // its base may run concurrently
+    const size_t pb = std::max<size_t>((size_t)g->n_partial_slots, 1) * kPartialSlotFloats * sizeof(float);
+    const size_t cb = 2 * std::max<size_t>((size_t)g->n_split_rows, 1) * sizeof(uint32_t);
+    if (hipMalloc((void **)&g->d_partials, pb) != hipSuccess || hipMalloc((void **)&g->d_counters, cb) != hipSuccess ||
+        hipMemset(g->d_counters, 0, cb) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(g->d_partials);
+        (void)hipFree(g->d_counters);
+        delete g;
+        return fail(RBG_ENOMEM, "device allocation of the view's scratch failed");
+    }
+    *out = g;
     return RBG_OK;
 }
 

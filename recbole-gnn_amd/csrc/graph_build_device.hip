@@ -154,4 +154,61 @@ int build_device_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_i
     return RBG_OK;
 }
 
+// map[e] = position of the transposed entry of CSR entry e = (r, c): the k-th entry (r, c) of row r pairs with the k-th
+// entry (c, r) of row c (rows are column-sorted; duplicated interactions stay separate entries).  *bad counts entries
+// whose transpose is missing (the structure is not symmetric).
+__global__ void transpose_map_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int64_t n_rows,
+                                     int64_t nnz, int32_t *__restrict__ map, int *bad) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        // row of entry e: upper bound of e in rowptr
+        int64_t lo = 0, hi = n_rows;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rowptr[mid + 1] <= e) lo = mid + 1; else hi = mid;
+        }
+        const int32_t r = (int32_t)lo, c = col[e];
+        auto lower = [&](int32_t row, int32_t key) {
+            int32_t a = rowptr[row], b = rowptr[row + 1];
+            while (a < b) {
+                const int32_t m = (a + b) >> 1;
+                if (col[m] < key) a = m + 1; else b = m;
+            }
+            return a;
+        };
+        const int32_t k = (int32_t)e - lower(r, c);
+        int32_t t = -1;
+        if (c < n_rows) {
+            t = lower(c, r) + k;
+            if (t >= rowptr[c + 1] || col[t] != r) t = -1;
+        }
+        if (t < 0) atomicAdd(bad, 1);
+        map[e] = t < 0 ? 0 : t;
+    }
+}
+
 }  // namespace rbg
+
+extern "C" int rbg_graph_transpose_map(const rbg_graph *g, int32_t *map, void *stream) {
+    using namespace rbg;
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "rbg_graph_transpose_map needs a device graph");
+    if (g->n_rows != g->n_cols) return fail(RBG_ESHAPE, "graph is not square");
+    if (g->nnz == 0) return RBG_OK;
+    if (!map) return fail(RBG_EINVAL, "map is NULL");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    int *bad = nullptr;
+    RBG_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    hipError_t e1 = hipMemsetAsync(bad, 0, sizeof(int), s);
+    const unsigned blocks = (unsigned)std::min<int64_t>((g->nnz + 255) / 256, 16384);
+    hipLaunchKernelGGL(transpose_map_kernel, dim3(blocks), dim3(256), 0, s, g->d_rowptr, g->d_col, g->n_rows, g->nnz, map, bad);
+    int h_bad = 0;
+    hipError_t e2 = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s);
+    hipError_t e3 = hipStreamSynchronize(s);
+    (void)hipFree(bad);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(RBG_EHIP, "transpose map failed: %s", hipGetErrorString(e3 != hipSuccess ? e3 : (e2 != hipSuccess ? e2 : e1)));
+    if (h_bad) return fail(RBG_EINVAL, "%d entries have no transposed partner: the graph's structure is not symmetric", h_bad);
+    return RBG_OK;
+}

@@ -98,6 +98,7 @@ struct SweepDev {
 struct rbg_graph {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     int64_t n_users = -1;  // -1 when built from CSR/COO (unknown split)
+    int64_t row_split = -1;  // rows [0, row_split) / [row_split, n_rows) are the two row classes of the XCD split (-1: n_users)
     int device = -1;
     uint32_t flags = 0;
 
@@ -126,6 +127,8 @@ struct rbg_graph {
     float *d_partials = nullptr;    // [n_partial_slots][kPartialSlotFloats]
     uint32_t *d_counters = nullptr;  // [n_split_rows], zero between launches
     int32_t max_degree = 0;
+    const rbg_graph *base = nullptr;  // a re-weighted view (rbg_graph_create_reweighted): structure + plan borrowed from base,
+                                      // d_val borrowed from the caller; only partials / counters are its own
     std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
 };
 

@@ -122,13 +122,16 @@ class GraphHandle:
         return cls(out.value, symmetric=True, n_users=int(n_users))
 
     @classmethod
-    def from_csr(cls, rowptr, col, val, n_cols, device=None, symmetric=False, flags=0):
+    def from_csr(cls, rowptr, col, val, n_cols, device=None, symmetric=False, flags=0, n_class0_rows=None):
+        """``n_class0_rows``: rows [0, n_class0_rows) and the rest reference disjoint column sets (a shard's user / item
+        rows): the two classes are pinned to different XCDs like a graph built from interactions."""
         rowptr = _np_i64(rowptr)
         col = np.ascontiguousarray(col, dtype=np.int32)
         val = np.ascontiguousarray(val, dtype=np.float32)
         out = c_vp()
-        check(lib.rbg_graph_create_csr(ctypes.byref(out), rowptr.shape[0] - 1, n_cols, _ptr(rowptr), _ptr(col),
-                                       _ptr(val), _device_index(device), flags))
+        check(lib.rbg_graph_create_csr_classes(ctypes.byref(out), rowptr.shape[0] - 1, n_cols, _ptr(rowptr), _ptr(col),
+                                               _ptr(val), -1 if n_class0_rows is None else int(n_class0_rows),
+                                               _device_index(device), flags))
         return cls(out.value, symmetric=symmetric)
 
     @classmethod
@@ -189,6 +192,30 @@ class GraphHandle:
                                                    device=self.device if self.is_device else None)
             self._transpose._transpose = self
         return self._transpose
+
+    def values(self):
+        """The fp32 edge weights in CSR entry order as a tensor on the graph's device (a copy)."""
+        _, _, val = self.export_csr()
+        return torch.from_numpy(val).to(self.device)
+
+    def transpose_map(self):
+        """int32 device tensor [nnz]: position of every entry's transposed partner (structure must be symmetric)."""
+        m = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.rbg_graph_transpose_map(self.ptr, c_vp(m.data_ptr()), c_vp(torch.cuda.current_stream(self.device).cuda_stream)))
+        return m[: self.nnz]
+
+    def reweighted(self, vals, symmetric=False):
+        """A view with this graph's structure and launch plan whose edge weights are read from ``vals`` (fp32 device
+        tensor [nnz], CSR entry order) at launch time — rewrite ``vals`` in place between launches (NGCF edge dropout,
+        ngcf.py:74-90, without rebuilding a sparse matrix).  The view keeps this handle and ``vals`` alive."""
+        if not (vals.is_cuda and vals.dtype == torch.float32 and vals.is_contiguous() and vals.numel() == self.nnz):
+            raise ValueError("vals must be a contiguous fp32 device tensor with one entry per edge")
+        out = c_vp()
+        check(lib.rbg_graph_create_reweighted(ctypes.byref(out), self.ptr, c_vp(vals.data_ptr())))
+        view = GraphHandle(out.value, symmetric=symmetric, n_users=self.n_users)
+        view._keep_alive = (self, vals)
+        return view
 
     def to(self, device):
         """Mirror of ``SparseTensor.to(device)`` (abstract_recommender.py:18)."""

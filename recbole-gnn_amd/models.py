@@ -210,8 +210,7 @@ class NGCF(GeneralGraphRecommender):
         self.message_dropout = config["message_dropout"] if config["message_dropout"] is not None else 0.1  # NGCF.yaml
         self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
         self.fused = config["fused_forward"] if config["fused_forward"] is not None else True  # False: op-by-op like ngcf.py
-        if self.node_dropout != 0:
-            raise NotImplementedError("node_dropout > 0 (ngcf.py:74-90) is outside the accelerated path")
+        self._drop = None  # lazily built state of the edge-dropout path (node_dropout > 0)
         self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)
         self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
         self.GNNlayers = nn.ModuleList(
@@ -227,23 +226,50 @@ class NGCF(GeneralGraphRecommender):
     def get_ego_embeddings(self):
         return torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
 
+    def _draw_edge_keep(self, n_edges):
+        """dropout_adj's mask over the directed edges (PyG: ``torch.rand(E) >= p``; ngcf.py:81,89)."""
+        return torch.rand(n_edges, device=self.device) >= self.node_dropout
+
+    def _dropout_graph(self):
+        """ngcf.py:74-90 with node_dropout > 0 in training mode: every forward drops each DIRECTED edge independently with
+        probability p and keeps the surviving weights as they are (PyG ``dropout_adj``: no rescale, no re-normalisation,
+        the two directions of an interaction fall independently — SURVEY A.4), the reference by rebuilding and
+        re-sorting a SparseTensor per forward.  Here the sparsity structure and launch plan stay: a dropped edge is a
+        zero weight in a re-weighted view of the graph (``GraphHandle.reweighted``); the matrix is no longer symmetric,
+        so the backward runs on the transposed view, whose weights are the same mask read through the transpose map."""
+        if self._drop is None:
+            base = self.graph
+            val = base.values()
+            buf, buf_t = torch.empty_like(val), torch.empty_like(val)
+            fwd, bwd = base.reweighted(buf), base.reweighted(buf_t)
+            fwd._transpose, bwd._transpose = bwd, fwd
+            self._drop = dict(val=val, tmap=base.transpose_map().long(), buf=buf, buf_t=buf_t, graph=fwd)
+        st = self._drop
+        keep = self._draw_edge_keep(st["val"].shape[0]).to(torch.float32)
+        torch.mul(st["val"], keep, out=st["buf"])
+        torch.mul(st["val"], keep.index_select(0, st["tmap"]), out=st["buf_t"])  # A^T[r,c] = A[c,r]; the weights are symmetric
+        return st["graph"]
+
     def forward(self):
-        if not torch.is_grad_enabled() and self.message_dropout == 0 and self.fused:
+        graph = self.graph
+        if self.node_dropout != 0 and self.training:
+            graph = self._dropout_graph()
+        elif not torch.is_grad_enabled() and self.message_dropout == 0 and self.fused:
             return self._forward_fused()
         all_embeddings = self.get_ego_embeddings()
         embeddings_list = [all_embeddings]
-        if self.fused and isinstance(self.graph, ops.GraphHandle) and max(self.hidden_size_list) <= 128:
+        if self.fused and isinstance(graph, ops.GraphHandle) and max(self.hidden_size_list) <= 128:
             # each layer with its LeakyReLU -> dropout -> normalize tail is one forward and one backward library call.
             # The dropout mask is drawn on EVERY forward, training or not, like the reference's fresh
             # nn.Dropout(p)(x) (ngcf.py:97, SURVEY Q3); NGCF.yaml ships message_dropout = 0.1.
             for gnn in self.GNNlayers:
                 all_embeddings = ops.bignn_layer(all_embeddings, gnn.lin1.weight, gnn.lin1.bias, gnn.lin2.weight, gnn.lin2.bias,
-                                                 self.graph, 0.2, p_drop=self.message_dropout)
+                                                 graph, 0.2, p_drop=self.message_dropout)
                 embeddings_list += [all_embeddings]
             ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
             return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])
         for gnn in self.GNNlayers:
-            all_embeddings = gnn(all_embeddings, self.graph, None)
+            all_embeddings = gnn(all_embeddings, graph, None)
             all_embeddings = F.leaky_relu(all_embeddings, negative_slope=0.2)
             all_embeddings = nn.Dropout(self.message_dropout)(all_embeddings)
             all_embeddings = F.normalize(all_embeddings, p=2, dim=1)

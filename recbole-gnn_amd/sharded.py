@@ -156,8 +156,10 @@ class HipBackend:
             raise RuntimeError("HipBackend needs a cuda device (no CPU path)")
         self._ops, self._GraphHandle, self._lib = ops, GraphHandle, _lib
 
-    def make_graph(self, csr, n_cols):
-        return self._GraphHandle.from_csr(csr[0], csr[1], csr[2], n_cols, device=self.device)
+    def make_graph(self, csr, n_cols, n_user_rows=None):
+        """``n_user_rows``: the shard's leading user rows — they gather item rows only, the rest user rows only, so the
+        launch plan pins the two classes to different XCDs (as for a single-GPU graph)."""
+        return self._GraphHandle.from_csr(csr[0], csr[1], csr[2], n_cols, device=self.device, n_class0_rows=n_user_rows)
 
     def layer_ctx(self):
         """Context (two events) for layer_begin / layer_end; freed with the backend object."""
@@ -232,8 +234,8 @@ class ShardedPropagation:
         self.overlap = bool(overlap)
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev
-        self.g_int = backend.make_graph(plan.int_csr, plan.n_owned)
-        self.g_halo = backend.make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
+        self.g_int = self._make_graph(plan.int_csr, plan.n_owned)
+        self.g_halo = self._make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev, priority=-1) if (dev.type == "cuda" and self.overlap) else None
         self._comm_h = self.comm_stream.cuda_stream if self.comm_stream is not None else None
@@ -242,6 +244,9 @@ class ShardedPropagation:
         self._buf_d = None  # per-width buffers, allocated on first use: halo, send, two ping-pong outputs
         self._recv_splits = [int(c) for c in plan.recv_counts]
         self._send_splits = [int(c) for c in plan.send_counts]
+
+    def _make_graph(self, csr, n_cols):
+        return self.backend.make_graph(csr, n_cols, n_user_rows=self.plan.n_users_owned)
 
     def _buffers(self, x):
         d = x.shape[1]

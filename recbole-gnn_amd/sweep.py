@@ -95,6 +95,7 @@ def build_plan(rowptr, col, val, n_users, d, *, n_wg=768, threads=512, range_byt
     hot_rows_all, wg_hot = [], np.zeros((n_wg, 2), dtype=np.int32)
     n_phases = 0
     col_deg = np.bincount(col, minlength=n) if nnz else np.zeros(n, dtype=np.int64)
+    row_chunks = np.zeros(n, dtype=np.int64)
 
     for cls, (r0, r1, c0, c1) in enumerate(classes):
         wgs = np.flatnonzero(wg_class == cls)
@@ -118,6 +119,9 @@ def build_plan(rowptr, col, val, n_users, d, *, n_wg=768, threads=512, range_byt
             wg_hot[wgs, 1] = len(top)
         phase[sel] = ph
         n_phases = max(n_phases, int(ph.max(initial=0)) + 1)
+        # chunks (<= pm entries of one row inside one phase) per row: a row is cut over at most that many lane-groups
+        gkey, gcnt = np.unique(e_row[sel] * (int(ph.max(initial=0)) + 2) + ph, return_counts=True)
+        np.add.at(row_chunks, gkey // (int(ph.max(initial=0)) + 2), (gcnt + pm - 1) // pm)
         t_est = max(1, (c1 - c0 + range_rows - 1) // range_rows)
         rows = np.arange(r0, r1)
         order = rows[np.argsort(-deg[rows], kind="stable")]
@@ -135,7 +139,7 @@ def build_plan(rowptr, col, val, n_users, d, *, n_wg=768, threads=512, range_byt
             heap = [(0.0, l) for l in range(lgs)]
             slot = 0
             for r, c in zip(mine.tolist(), c_m.tolist()):
-                k = 1 if deg[r] == 0 else int(min(lgs, max(1, np.ceil(c / (part_frac * target)))))
+                k = 1 if deg[r] == 0 else int(min(lgs, row_chunks[r], max(1, np.ceil(c / (part_frac * target)))))
                 got = [heapq.heappop(heap) for _ in range(k)]
                 for load, l in got:
                     heapq.heappush(heap, (load + c / k, l))

@@ -837,6 +837,72 @@ def test_info_nce_zero_row(rbg, cuda):
     close(g2.grad, b64.grad.float(), tol=2e-5)
 
 
+# ---- column-sweep launch plan (rbg_graph_attach_sweep) --------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", [dict(d=64, threads=256, n_wg=16), dict(d=64, threads=512, n_wg=16, range_bytes=16 * 1024),
+                                 dict(d=32, threads=256, n_wg=16), dict(d=128, threads=512, n_wg=24),
+                                 dict(d=64, threads=256, n_wg=16, hot_rows_per_class=40),
+                                 dict(d=64, threads=1024, n_wg=24, hot_rows_per_class=64, range_bytes=32 * 1024)])
+def test_sweep_kernel(rbg, cuda, golden, cfg):
+    """The sweep kernel executes an attached plan: same operator as the binned kernel (1e-5 vs the oracle), bit-stable,
+    every epilogue (store, accumulate, the fused layer mean of lightgcn_forward, the backward chain), and the
+    "sweep" option switches back to the binned kernel."""
+    from recbole_gnn_amd import sweep
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    n = nu + ni
+    cfg = dict(cfg)
+    d = cfg.pop("d")
+    cfg.setdefault("range_bytes", 64 * 1024)
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    plan = sweep.build_plan(g["rowptr"], g["col"], g["val"], nu, d, lds_bytes=64 * 1024, **cfg)
+    sweep.attach(h, plan)
+    x = randn((n, d), 3, cuda)
+    ref = C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], x.cpu().numpy())
+    y = rbg.ops.spmm_raw(h, x)
+    close(y, ref)
+    assert torch.equal(y, rbg.ops.spmm_raw(h, x))  # fixed summation order
+    acc = torch.ones_like(y)
+    rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
+    close(acc, ref + 1.0)
+    rbg.set_option("sweep", 0)
+    try:
+        y_binned = rbg.ops.spmm_raw(h, x)
+    finally:
+        rbg.set_option("sweep", 1)
+    close(y_binned, ref)
+    uw, iw = x[:nu].clone().requires_grad_(True), x[nu:].clone().requires_grad_(True)
+    mean = rbg.lightgcn_forward(h, uw, iw, 3)
+    close(mean, C.lightgcn_forward(g["rowptr"], g["col"].astype(np.int64), g["val"], x[:nu].cpu().numpy(), x[nu:].cpu().numpy(), 3))
+    mean.square().sum().backward()
+    sweep.detach(h, d)
+    uw2, iw2 = x[:nu].clone().requires_grad_(True), x[nu:].clone().requires_grad_(True)
+    rbg.lightgcn_forward(h, uw2, iw2, 3).square().sum().backward()
+    close(uw.grad, uw2.grad)
+    close(iw.grad, iw2.grad)
+
+
+def test_sweep_plan_is_validated(rbg, cuda, golden):
+    """rbg_graph_attach_sweep executes caller-built arrays, so it refuses plans that would read or write out of bounds or
+    that leave a row unfinished."""
+    from recbole_gnn_amd import sweep
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    good = sweep.build_plan(g["rowptr"], g["col"], g["val"], nu, 64, n_wg=16, threads=256, range_bytes=64 * 1024, lds_bytes=64 * 1024)
+    import copy
+    for field, edit in [("ent", lambda a: a.__setitem__((0, 0), nu + ni + 5)), ("rows", lambda a: a.__setitem__((1, 0), int(a[0, 0]))),
+                        ("pieces", lambda a: a.__setitem__((0, 1), int(a[0, 1]) | 0xFFFF)), ("lg_ptr", lambda a: a.__setitem__(-1, int(a[-1]) - 1))]:
+        bad = copy.deepcopy(good)
+        edit(getattr(bad, field))
+        with pytest.raises(rbg.RbgError):
+            sweep.attach(h, bad)
+    sweep.attach(h, good)
+    host = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=None)
+    with pytest.raises(rbg.RbgError):
+        sweep.attach(host, good)
+
+
 # ---- NGCF -----------------------------------------------------------------------------------
 
 def test_bignn_conv_golden(rbg, cuda, golden):
@@ -912,6 +978,87 @@ def test_ngcf_model(rbg, cuda, golden):
     close(x.grad, xr.grad, tol=2e-5)
     close(layer.lin1.weight.grad, w1.grad, tol=2e-5)
     close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
+
+
+def test_ngcf_node_dropout(rbg, cuda, golden):
+    """NGCF with node_dropout > 0 (ngcf.py:74-90): per-forward Bernoulli drop of DIRECTED edges, surviving weights kept
+    (PyG dropout_adj).  With the mask fixed, the training forward, the loss and every gradient — the backward runs on the
+    transposed (non-symmetric) view — match torch autograd through the restated formulas; eval mode uses the full graph."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.NGCF, cuda, golden, enable_sparse=True, node_dropout=0.3, reg_weight=1e-4)
+    rowptr, col, val = model.graph.export_csr()
+    nnz = len(col)
+    keep = torch.rand(nnz, generator=torch.Generator().manual_seed(11)) >= 0.3
+    model._draw_edge_keep = lambda n_edges: keep.to(cuda)
+    rows = np.repeat(np.arange(nu + ni), np.diff(rowptr))
+    ei = torch.from_numpy(np.stack([col.astype(np.int64), rows]))  # source = column, target = row of adj_t
+    ei_k, ew_k = O.dropout_adj(ei, torch.from_numpy(val), keep)
+    params = [tuple(t.detach().cpu().clone().requires_grad_(True) for t in (l.lin1.weight, l.lin1.bias, l.lin2.weight, l.lin2.bias))
+              for l in model.GNNlayers]
+    uw = model.user_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    iw = model.item_embedding.weight.detach().cpu().clone().requires_grad_(True)
+    batch = {"user_id": torch.tensor([1, 2, 3, 9, 2]), "item_id": torch.tensor([1, 4, 3, 7, 8]), "neg_item_id": torch.tensor([5, 6, 2, 11, 30])}
+    ur, ir = O.ngcf_forward(uw, iw, lambda t: O.conv_dense(t, ei_k, ew_k), params)
+    ue, pe, ne = ur[batch["user_id"]], ir[batch["item_id"]], ir[batch["neg_item_id"]]
+    ref_loss = (-torch.log(1e-10 + torch.sigmoid((ue * pe).sum(1) - (ue * ne).sum(1))).mean()
+                + 1e-4 * (ue.norm(p=2) + pe.norm(p=2) + ne.norm(p=2)) / 5)
+    ref_loss.backward()
+    for fused in (True, False):
+        model.fused = fused
+        model.zero_grad(set_to_none=True)
+        model.train()
+        u, i = model.forward()
+        close(torch.cat([u, i]), torch.cat([ur, ir]).detach())
+        loss = model.calculate_loss({k: v.to(cuda) for k, v in batch.items()})
+        loss.backward()
+        close(loss.detach().reshape(()), ref_loss.detach().reshape(()))
+        close(model.user_embedding.weight.grad, uw.grad, tol=2e-5)
+        close(model.item_embedding.weight.grad, iw.grad, tol=2e-5)
+        for layer, (w1, b1, w2, b2) in zip(model.GNNlayers, params):
+            close(layer.lin1.weight.grad, w1.grad, tol=2e-5)
+            close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
+    # the drawn mask has the requested rate and differs between forwards
+    del model._draw_edge_keep
+    m1, m2 = model._draw_edge_keep(nnz), model._draw_edge_keep(nnz)
+    assert abs(float(m1.float().mean()) - 0.7) < 0.03 and not torch.equal(m1, m2)
+    # eval: dropout_adj(training=False) is the identity
+    model.eval()
+    conv = lambda t: torch.from_numpy(C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], t.numpy()))  # noqa: E731
+    p0 = [tuple(t.detach() for t in p) for p in params]
+    u_ref, i_ref = O.ngcf_forward(uw.detach(), iw.detach(), conv, p0)
+    with torch.no_grad():
+        u, i = model.forward()
+    close(torch.cat([u, i]), torch.cat([u_ref, i_ref]))
+
+
+def test_reweighted_view_and_transpose_map(rbg, cuda, golden):
+    """GraphHandle.reweighted / transpose_map (rbg_graph_create_reweighted, rbg_graph_transpose_map): a view's product
+    uses the caller's values at launch time; the transpose map pairs (r, c) with (c, r), duplicates included."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    rowptr, col, val = h.export_csr()
+    tmap = h.transpose_map().cpu().numpy()
+    rows = np.repeat(np.arange(nu + ni), np.diff(rowptr))
+    assert np.array_equal(col[tmap], rows) and np.array_equal(rows[tmap], col) and np.array_equal(np.sort(tmap), np.arange(len(col)))
+    w = torch.rand(len(col), generator=torch.Generator().manual_seed(3)).to(cuda)
+    view = h.reweighted(w)
+    x = randn((nu + ni, 64), 5, cuda)
+    ref = C.spmm(rowptr, col.astype(np.int64), w.cpu().numpy(), x.cpu().numpy())
+    close(rbg.ops.spmm_raw(view, x), ref)
+    w.mul_(0.5)  # the view reads the values at launch time
+    close(rbg.ops.spmm_raw(view, x), 0.5 * ref)
+    close(rbg.ops.spmm_raw(h, x), C.spmm(rowptr, col.astype(np.int64), val, x.cpu().numpy()))  # the base is untouched
+    # a duplicated interaction and a non-symmetric structure
+    hd = rbg.GraphHandle.from_interactions([1, 1, 1, 2], [1, 1, 2, 1], 3, 3, device=cuda)
+    rp, cc, _ = hd.export_csr()
+    tm = hd.transpose_map().cpu().numpy()
+    rr = np.repeat(np.arange(6), np.diff(rp))
+    assert np.array_equal(cc[tm], rr) and np.array_equal(np.sort(tm), np.arange(len(cc)))
+    bad = rbg.GraphHandle.from_csr(np.array([0, 1, 1]), np.array([1], dtype=np.int32), np.array([1.0], dtype=np.float32), 2, device=cuda)
+    with pytest.raises(rbg.RbgError):
+        bad.transpose_map()
 
 
 @pytest.mark.parametrize("n,d_in,d_out", [(1, 4, 4), (31, 16, 8), (33, 64, 64), (1000, 64, 64), (70841, 64, 64), (257, 20, 50),

@@ -193,3 +193,15 @@ def test_simgcl_forward_restatement(ref_inter):
     assert torch.all(torch.sign(delta[rows]) * torch.sign(e1[rows]) >= 0)
     assert torch.all(delta[~rows] == 0)  # PAD rows: sign(0) = 0
     assert abs(float(O.simgcl_cl_loss(e1[:6], e1[:6], 0.2, "mean")) - float(O.simgcl_cl_loss(e1[:6], e1[:6], 0.2)) / 6) < 1e-12
+
+
+def test_dropout_adj_keeps_weights_and_directions():
+    """ngcf.py:81-82 / PyG dropout_adj: a filter — no rescale, no re-normalisation, directions independent."""
+    ei, ew = O.get_norm_adj_mat(np.array([1, 1, 2]), np.array([1, 2, 1]), 3, 3, enable_sparse=False)
+    keep = torch.tensor([True, False, True, True, True, False])
+    ei2, ew2 = O.dropout_adj(ei, ew, keep)
+    assert torch.equal(ei2, ei[:, keep]) and torch.equal(ew2, ew[keep]) and ei2.shape[1] == 4
+    x = torch.eye(6)
+    full, part = O.conv_dense(x, ei, ew), O.conv_dense(x, ei2, ew2)
+    dropped = full - part  # exactly the two dropped directed edges, at their original weights
+    assert int((dropped != 0).sum()) == 2 and not torch.equal(part, part.T)

@@ -17,7 +17,7 @@ class CpuBackend:
     """Test double for sharded.HipBackend: same three calls, computed by the CPU oracle."""
     device = torch.device("cpu")
 
-    def make_graph(self, csr, n_cols):
+    def make_graph(self, csr, n_cols, n_user_rows=None):
         return (np.asarray(csr[0]), np.asarray(csr[1], dtype=np.int64), np.asarray(csr[2]), n_cols)
 
     def spmm(self, graph, x, out, accumulate):
