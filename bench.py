@@ -91,6 +91,36 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
                       f"(oracle/rbg_oracle.c, gcc -O3 + AVX2 clone, OpenMP dynamic rows, buffers reused; {os.cpu_count()} logical cpus visible)"}
 
 
+def cpu_baseline_torch_sparse(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
+    """Second stand-in for the reference's CPU path: ``torch.sparse`` CSR ``A @ X`` per
+    layer + the stack/mean of lightgcn.py:77-78, torch's own intra-op threads (torch_sparse itself is not installable)."""
+    from oracle import coracle
+    rowptr, col, val = coracle.build_norm_csr(uid, iid, nu, ni)
+    n = nu + ni
+    a = torch.sparse_csr_tensor(torch.from_numpy(np.asarray(rowptr, dtype=np.int64)), torch.from_numpy(np.asarray(col, dtype=np.int64)),
+                                torch.from_numpy(np.asarray(val, dtype=np.float32)), size=(n, n))
+    e0 = torch.cat([torch.from_numpy(uw), torch.from_numpy(iw)])
+
+    def prop():
+        x, layers = e0, [e0]
+        for _ in range(k_layers):
+            x = a @ x
+            layers.append(x)
+        return torch.mean(torch.stack(layers, dim=1), dim=1)
+
+    prop()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        prop()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 200:
+            break
+    return {"value": reps / el, "unit": "propagations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} full propagations in {el:.1f} s: torch.sparse CSR A @ X x {k_layers} + stack/mean, "
+                      f"torch {torch.__version__} CPU, {torch.get_num_threads()} intra-op threads"}
+
+
 def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     """Non-headline measurements on the same graph (each: median of 3 x 50 iterations, HIP events)."""
     def time_us(fn, iters=50, warm=5):
@@ -159,6 +189,19 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     torch.cuda.synchronize()
     ex["graph_build_device_ms"] = (time.perf_counter() - t0) * 1e3
+    # the scale the north_star names ("~1.3 M nodes"): X = 333 MB no longer fits any cache level
+    try:
+        gu, gi, gnu, gni = rbg.synth.make("g-1.3m")
+        gg = rbg.GraphHandle.from_interactions(gu, gi, gnu, gni, device=dev)
+        gn = gnu + gni
+        gx, gy = torch.randn(gn, d, device=dev), torch.empty(gn, d, device=dev)
+        us = time_us(lambda: rbg.ops.spmm_raw(gg, gx, out=gy), iters=10, warm=2)
+        gb, _ = rbg.synth.algorithmic_bytes(gn, gg.nnz, d, k_layers)
+        ex["g-1.3m"] = {"nodes": gn, "nnz": gg.nnz, "spmm_us": us, "roofline_frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                        "kernel": gg.spmm_kernel_name(d)}
+        del gg, gx, gy
+    except Exception as e:  # noqa: BLE001
+        ex["g-1.3m_error"] = str(e)[:200]
     # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
     try:
         cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-5,
@@ -193,11 +236,17 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     return ex
 
 
-def traffic_from_profiles(workload):
+def traffic_from_profiles(workload, d, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json; the counters need
+    their own rocprofv3 runs, so they cannot be collected inside this process).  None when no pass exists for this
+    workload / width / kernel."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get(workload)
+            table = json.load(open(path))
+            rec = table.get(f"{workload}:d{d}:{kernel}")
+            if rec is not None:
+                return rec
         except Exception:
             return None
     return None
@@ -258,6 +307,7 @@ def main():
         if not err <= 1e-5:
             raise SystemExit(f"parity gate failed: max|E_hip - E_oracle| = {err:.3e} > 1e-5")
         extra.update(max_abs_err_vs_oracle=err, bins=graph.bins(d), tuning=rbg.get_tuning())
+        kernel_name = graph.spmm_kernel_name(d)
         launches_per_step = k_layers
         units_per_step = 1
         workload = (f"{args.workload}-shape synthetic power-law bipartite graph: {nu} users / {ni} items / "
@@ -292,6 +342,7 @@ def main():
 
         launches_per_step = k_layers
         units_per_step = world
+        kernel_name = prop.g_int.spmm_kernel_name(d)
         extra.update(p_in=args.p_in, halo_rows_rank0=int(plan.n_halo), owned_rows_rank0=int(plan.n_owned),
                      halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4)
         workload = (f"{world} x {args.workload}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
@@ -370,8 +421,11 @@ def main():
                        "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
                        "sharding": "none" if world == 1 else f"node-range x{world}, transport={transport}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic_from_profiles(args.workload) if world == 1 else None,
-                         "kernel": "spmm_binned_kernel<64, 8, true, false>", "avg_launch_us": launch_us,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic_from_profiles(args.workload, d, kernel_name) if world == 1 else None,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
+                                           "this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per the gfx950 correction)",
+                         "kernel": kernel_name, "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "
                                  "time of the timed region / launches, so inter-kernel gaps and (N>1) halo waits count"},
@@ -382,6 +436,8 @@ def main():
             result["extras"] = extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev)
         if world == 1 and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers, args.cpu_seconds)
+            result["cpu_baseline_torch_sparse"] = cpu_baseline_torch_sparse(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers,
+                                                                            min(args.cpu_seconds, 6.0))
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

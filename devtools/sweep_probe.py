@@ -144,8 +144,12 @@ def main():
 
     rbg.set_option("sweep", 0)
     run("binned")
+    for key, value, default in (("col_split", 1, -1), ("spmm_unroll", 4, 8), ("nt_store", 0, 1)):
+        rbg.set_option(key, value)  # launch-time options of the binned kernel, one at a time
+        run(f"binned_{key}={value}")
+        rbg.set_option(key, default)
     rbg.set_option("sweep", 1)
-    for name, kw in parse_variants(args.variants):
+    for name, kw in (parse_variants(args.variants) if args.variants != "none" else []):
         t0 = time.time()
         try:
             lds = 150 * 1024 if kw["threads"] == 1024 else (72 * 1024 if kw["threads"] == 512 else 36 * 1024)

@@ -152,6 +152,10 @@ int rbg_graph_info(const rbg_graph *g, int64_t *n_rows, int64_t *n_cols, int64_t
 int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
                    int64_t *n_split_rows, int64_t *grid_blocks);
 
+/* Name (as rocprofv3 prints it, without the namespace) of the kernel rbg_spmm_f32 launches for width d on this handle
+ * under the current options — so that a benchmark can label its roofline line and find the kernel in a trace. */
+int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len);
+
 /* Copy the CSR out to HOST buffers: rowptr int64 [n_rows+1], col int32 [nnz], val fp32 [nnz].
  * Any pointer may be NULL.  Works for host and device graphs (D2H copy + sync for the latter). */
 int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val);
@@ -200,6 +204,14 @@ void rbg_graph_destroy(rbg_graph *g);
  * X and Y must not alias.  Rows of Â with no entries produce zeros.  Also the autograd backward
  * (Â symmetric):  dL/dX = Â · dL/dY. */
 int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, void *stream);
+
+/* The last layer of a propagation with the layer mean in its epilogue (lightgcn.py:75-78 for one layer):
+ *   out_mean = (srcs[0] + ... + srcs[n_srcs-1] + (partial + Â X)) / (n_srcs + 1)
+ * srcs = E_0 and the earlier layer outputs ([n_rows, d] each, n_srcs <= RBG_MAX_FUSED_LAYERS + 1); partial ([n_rows, d] or
+ * NULL) is a product already formed for the same rows — the node-range sharded path passes the interior product and
+ * runs this call on the halo block, so its K-th layer needs no separate accumulate and mean passes. */
+int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs,
+                      float *out_mean, int d, void *stream);
 
 /* One perturbed layer of SimGCL / XSimGCL (simgcl.py:29-34, xsimgcl.py:34-38):
  *   Y = Â X;   Y += sign(Y) * F.normalize(noise, dim=-1) * eps        (noise [N, d]: the caller's torch.rand_like draw)

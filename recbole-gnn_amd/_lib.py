@@ -37,6 +37,7 @@ SIGNATURES = {
     "rbg_norm_edges": (c_int, [c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_info": (c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_int)]),
     "rbg_graph_bins": (c_int, [c_vp, c_int, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
+    "rbg_spmm_kernel_name": (c_int, [c_vp, c_int, ctypes.c_char_p, c_int]),
     "rbg_graph_export_csr": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_destroy": (None, [c_vp]),
     "rbg_graph_create_reweighted": (c_int, [P(c_vp), c_vp, c_vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
                                        c_i64, c_int]),
     "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
     "rbg_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "rbg_spmm_mean_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "rbg_spmm_noise_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "rbg_lightgcn_forward_f32": (c_int, [P(c_vp), c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_u32, c_vp]),
     "rbg_lightgcn_backward_f32": (c_int, [P(c_vp), c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),

@@ -25,6 +25,7 @@
 // The layer-mean of LightGCN.forward is fused into the last layer's epilogue.
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 
 #include <algorithm>
 #include <atomic>
@@ -65,8 +66,10 @@ struct SpmmParams {
     // MODE_HORNER: y[row] = (addend[row] + acc) / denom   (one step of the backward chain)
     // MODE_NOISE:  y[row] = acc + sign(acc) * addend[row] / max(||addend[row]||, 1e-12) * denom   (addend = noise, denom = eps)
     const float *addend;
-    // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom
+    // MODE_MEAN: mean_out[row] = (e0[row] + sum_i prev[i][row] + acc) / denom, acc += partial[row] first when partial != NULL
+    // (the sharded last layer: partial = the interior product, this launch = the halo product)
     float *mean_out;
+    const float *partial;
     RowSrc e0;
     const float *prev[RBG_MAX_FUSED_LAYERS];
     int32_t n_prev;
@@ -182,6 +185,7 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
         return;
     }
     if (p.mode == MODE_MEAN) {
+        if (p.partial) acc = add4(acc, ld4(p.partial + (int64_t)row * D + c0));  // same order as the accumulate epilogue
         float4 s = ld4(src_row(p.e0, row) + c0);
         for (int i = 0; i < p.n_prev; ++i) s = add4(s, ld4(p.prev[i] + (int64_t)row * D + c0));
         s = add4(s, acc);
@@ -456,6 +460,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, i
         }
         if (k < d) {
             if (p.mode == MODE_MEAN) {
+                if (p.partial) acc += p.partial[(int64_t)row * d + k];
                 float s = src_row(p.e0, row)[k];
                 for (int i = 0; i < p.n_prev; ++i) s += p.prev[i][(int64_t)row * d + k];
                 s += acc;
@@ -599,6 +604,16 @@ static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s) 
     return RBG_OK;
 }
 
+// column-half eligibility of a launch of width D on this graph (see launch_binned)
+static bool use_col_half(const rbg_graph *g, int D, int mode, int64_t ldx) {
+    if (D != 64 && D != 128) return false;
+    const int cs = opt_col_split();
+    const bool cache_scale = (int64_t)g->n_rows * D * 4 <= ((int64_t)512 << 20);
+    return mode != MODE_NOISE && (cs == 1 || (cs < 0 && D == 128 && cache_scale)) && g->n_groups == 2 && ldx == D &&
+           g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 && g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 &&
+           g->xmap.grp[7] == 1;
+}
+
 template <int D>
 static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     if constexpr (D == 64 || D == 128) {
@@ -607,11 +622,8 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
         // more than the better L2 hit rate returns: 42.0 -> 49.8 us) and only while the table is cache-scale (<= 512 MB):
         // at the config-#5 shape (15 M rows, 7.7 GB) L2 residency is out of reach and reading the CSR twice loses 5 %
         // (31.9 -> 33.7 ms)
-        const int cs = opt_col_split();
-        const bool cache_scale = (int64_t)g->n_rows * D * 4 <= ((int64_t)512 << 20);
-        if (p.mode != MODE_NOISE /* the noise row norm spans both halves */ && (cs == 1 || (cs < 0 && D == 128 && cache_scale)) && g->n_groups == 2 && p.x.ld == D && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 &&
-            g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 && g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1)
-            return launch_binned_half<D / 2>(g, p, s);
+        // (MODE_NOISE is excluded: the noise row norm spans both halves)
+        if (use_col_half(g, D, p.mode, p.x.ld)) return launch_binned_half<D / 2>(g, p, s);
     }
     const int64_t grid = grid_for<D>(g);
     if (grid == 0) return RBG_OK;
@@ -679,7 +691,7 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     bool vec = (d % 4 == 0) && vec_ok(p.x) && (p.ldy % 4 == 0) && (!p.y || aligned16(p.y));
     if (p.mode == MODE_HORNER || p.mode == MODE_NOISE) vec = vec && aligned16(p.addend);
     if (p.mode == MODE_MEAN) {
-        vec = vec && vec_ok(p.e0) && aligned16(p.mean_out);
+        vec = vec && vec_ok(p.e0) && aligned16(p.mean_out) && (!p.partial || aligned16(p.partial));
         for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
     }
     if (vec && opt_sweep()) {
@@ -728,6 +740,25 @@ static int check_device_graph(const rbg_graph *g) {
 using namespace rbg;
 
 extern "C" {
+
+int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
+    clear_error();
+    if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
+    // mirrors launch_spmm for contiguous, 16-byte aligned fp32 operands in store mode
+    if (d != 32 && d != 64 && d != 128 && d != 256) {
+        snprintf(buf, (size_t)len, "spmm_generic_kernel");
+        return RBG_OK;
+    }
+    if (opt_sweep() && d <= 128) {
+        if (const SweepDev *sw = find_sweep(g, d)) {
+            snprintf(buf, (size_t)len, "spmm_sweep_kernel<%d, 8, %d, true>", d, sw->threads);
+            return RBG_OK;
+        }
+    }
+    const bool half = use_col_half(g, d, MODE_STORE, d);
+    snprintf(buf, (size_t)len, "spmm_binned_kernel<%d, %d, true, %s>", half ? d / 2 : d, spmm_unroll(), half ? "true" : "false");
+    return RBG_OK;
+}
 
 int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
                    int64_t *n_split_rows, int64_t *grid_blocks) {
@@ -780,6 +811,33 @@ int rbg_mean_f32(const float *const *srcs, int n_srcs, int64_t n_floats, float s
     hipLaunchKernelGGL(mean_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, m, n_floats, scale, out, vec ? 1 : 0);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs,
+                      float *out_mean, int d, void *stream) {
+    clear_error();
+    int rc = check_device_graph(g);
+    if (rc) return rc;
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    if (n_srcs < 1 || n_srcs > RBG_MAX_FUSED_LAYERS + 1) return fail(RBG_EINVAL, "1 <= n_srcs <= %d", RBG_MAX_FUSED_LAYERS + 1);
+    if (g->n_rows == 0) return RBG_OK;
+    if (!X || !srcs || !out_mean) return fail(RBG_EINVAL, "NULL pointer");
+    for (int i = 0; i < n_srcs; ++i)
+        if (!srcs[i]) return fail(RBG_EINVAL, "srcs[%d] is NULL", i);
+    if (out_mean == X || out_mean == partial) return fail(RBG_EINVAL, "out_mean aliases an input");
+    if ((rc = set_device_for(g->device))) return rc;
+    SpmmParams p{};
+    p.x = make_src(X, X, 0, d);
+    p.y = nullptr;
+    p.ldy = d;
+    p.mode = MODE_MEAN;
+    p.mean_out = out_mean;
+    p.partial = partial;
+    p.e0 = make_src(srcs[0], srcs[0], 0, d);
+    p.n_prev = n_srcs - 1;
+    for (int i = 1; i < n_srcs; ++i) p.prev[i - 1] = srcs[i];
+    p.denom = (float)(n_srcs + 1);
+    return launch_spmm(g, p, d, (hipStream_t)stream);
 }
 
 int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float *noise, int d, float eps, void *stream) {

@@ -177,6 +177,12 @@ class GraphHandle:
         keys = ("n_short", "n_wave", "n_block_tasks", "n_split_rows", "grid_blocks")
         return dict(zip(keys, (v.value for v in vals)))
 
+    def spmm_kernel_name(self, d):
+        """The kernel an SpMM of width d launches on this handle under the current options (as rocprofv3 prints it)."""
+        buf = ctypes.create_string_buffer(128)
+        check(lib.rbg_spmm_kernel_name(self.ptr, d, buf, 128))
+        return buf.value.decode()
+
     def transpose(self):
         """Handle of Â^T (needed for the backward of a non-symmetric graph)."""
         if self.symmetric:
