@@ -191,6 +191,11 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
                            const int32_t *hot_rows, int64_t n_hot, int hot_base);
 int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
+/* The handle's CSR arrays in HBM, read-only and valid while the handle lives: rowptr int32 [n_rows + 1], col int32 [nnz],
+ * val fp32 [nnz] (any pointer argument may be NULL).  For device-side consumers of the normalized adjacency (the shard
+ * planner cuts a rank's blocks out of it without a host round trip). */
+int rbg_graph_device_arrays(const rbg_graph *g, const int32_t **rowptr, const int32_t **col, const float **val);
+
 void rbg_graph_destroy(rbg_graph *g);
 
 /* ---------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rbg_graph_info": (c_int, [c_vp, P(c_i64), P(c_i64), P(c_i64), P(c_int)]),
     "rbg_graph_bins": (c_int, [c_vp, c_int, P(c_i64), P(c_i64), P(c_i64), P(c_i64), P(c_i64)]),
     "rbg_spmm_kernel_name": (c_int, [c_vp, c_int, ctypes.c_char_p, c_int]),
+    "rbg_graph_device_arrays": (c_int, [c_vp, P(c_vp), P(c_vp), P(c_vp)]),
     "rbg_graph_export_csr": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_destroy": (None, [c_vp]),
     "rbg_graph_create_reweighted": (c_int, [P(c_vp), c_vp, c_vp]),

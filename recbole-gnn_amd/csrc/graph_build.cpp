@@ -885,6 +885,16 @@ int rbg_graph_info(const rbg_graph *g, int64_t *n_rows, int64_t *n_cols, int64_t
     return RBG_OK;
 }
 
+int rbg_graph_device_arrays(const rbg_graph *g, const int32_t **rowptr, const int32_t **col, const float **val) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "host graph: no device arrays");
+    if (rowptr) *rowptr = g->d_rowptr;
+    if (col) *col = g->d_col;
+    if (val) *val = g->d_val;
+    return RBG_OK;
+}
+
 int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, float *val) {
     clear_error();
     if (!g) return fail(RBG_EINVAL, "graph is NULL");

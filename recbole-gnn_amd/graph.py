@@ -199,6 +199,24 @@ class GraphHandle:
             self._transpose._transpose = self
         return self._transpose
 
+    def device_csr(self):
+        """(rowptr int32 [n_rows+1], col int32 [nnz], val fp32 [nnz]) as torch tensors that ALIAS the handle's HBM arrays
+        (no copy; read-only by contract; they keep this handle alive)."""
+        ptrs = [c_vp(), c_vp(), c_vp()]
+        check(lib.rbg_graph_device_arrays(self.ptr, *[ctypes.byref(q) for q in ptrs]))
+        handle = self
+
+        class _View:  # the CUDA array interface: torch wraps the memory without copying it
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr or 0, True), "version": 2}
+                self._owner = handle
+
+        out = []
+        for q, n, ts in zip(ptrs, (self.n_rows + 1, self.nnz, self.nnz), ("<i4", "<i4", "<f4")):
+            out.append(torch.as_tensor(_View(q.value, n, ts), device=self.device) if n and q.value else
+                       torch.empty(0, dtype=torch.int32 if ts == "<i4" else torch.float32, device=self.device))
+        return tuple(out)
+
     def values(self):
         """The fp32 edge weights in CSR entry order as a tensor on the graph's device (a copy)."""
         _, _, val = self.export_csr()

@@ -85,14 +85,22 @@ def _csr_from_sorted(rows_local, cols, vals, n_rows):
     return np.cumsum(rowptr), cols.astype(np.int32), vals.astype(np.float32)
 
 
-def build_plans(uid, iid, n_users, n_items, world, owner=None, ranks=None):
+def build_plans(uid, iid, n_users, n_items, world, owner=None, ranks=None, keep=None):
     """Plans for `ranks` (default: all).  Deterministic and communication-free: every rank holds the
-    interaction list (as in the reference, where the dataset is replicated on the host)."""
+    interaction list (as in the reference, where the dataset is replicated on the host).
+    ``keep`` (one flag per interaction): an SGL edge-drop view (sgl.py:107-126) — the kept sub-graph, normalized on its
+    OWN global degrees (sgl.py:119-124); the partition is still the full graph's unless ``owner`` says otherwise.
+    (numpy reference implementation; ``plan_from_csr`` cuts the same plan out of a built CSR with device-side sorts.)"""
     uid = np.ascontiguousarray(uid, dtype=np.int64)
     iid = np.ascontiguousarray(iid, dtype=np.int64)
     n = n_users + n_items
     if owner is None:
         owner = default_partition(uid, iid, n_users, n_items, world)
+    if keep is not None:
+        keep = np.asarray(keep).astype(bool)
+        if keep.shape != uid.shape:
+            raise ValueError("keep mask must have one entry per interaction")
+        uid, iid = uid[keep], iid[keep]
     owner = np.asarray(owner, dtype=np.int32)
     assert owner.shape == (n,) and owner.min(initial=0) >= 0 and owner.max(initial=0) < world
     # directed edges of the symmetric graph: target row <- source col  (dataset.py:60-64)
@@ -140,6 +148,52 @@ def build_plans(uid, iid, n_users, n_items, world, owner=None, ranks=None):
         plans[p] = ShardPlan(p, world, owned, int(np.count_nonzero(owned < n_users)), int_csr, halo_csr, halo_ids,
                              recv_counts, send_idx, send_counts)
     return plans
+
+
+def plan_from_csr(rowptr, col, val, n_users, owner, rank, world):
+    """Rank `rank`'s ShardPlan cut out of the GLOBAL normalized CSR (torch tensors on any device — e.g.
+    ``GraphHandle.device_csr()`` of a graph the device builder made, so that nothing of size nnz is sorted on the host:
+    at BASELINE config #5 that is 4e8 directed edges per rank for the numpy planner).  The matrix must be structurally
+    symmetric (it is: dataset.py:62-64): what a peer q needs from this rank — the rows of mine that q's rows reference — is
+    then exactly the set of my rows with a neighbour owned by q, so a rank plans from its own rows alone.  Equal to
+    ``build_plans(...)[rank]`` (tested)."""
+    dev = col.device
+    rowptr = rowptr.to(torch.int64)
+    n = rowptr.numel() - 1
+    owner_t = torch.as_tensor(np.asarray(owner), device=dev).to(torch.int64)
+    owned = torch.nonzero(owner_t == rank).flatten()
+    n_owned = int(owned.numel())
+    beg = rowptr[owned]
+    cnt = rowptr[owned + 1] - beg
+    total = int(cnt.sum())
+    r_local = torch.repeat_interleave(torch.arange(n_owned, device=dev), cnt)
+    first = torch.cumsum(cnt, 0) - cnt
+    idx = torch.repeat_interleave(beg - first, cnt) + torch.arange(total, device=dev)
+    c = col[idx].to(torch.int64)
+    v = val[idx]
+    co = owner_t[c]
+    interior = co == rank
+    local_index = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    local_index[owned] = torch.arange(n_owned, device=dev)
+
+    def block(mask, cols):
+        ptr = torch.zeros(n_owned + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(torch.bincount(r_local[mask], minlength=n_owned), 0)
+        return ptr.cpu().numpy(), cols.to(torch.int32).cpu().numpy(), v[mask].cpu().numpy()
+
+    int_csr = block(interior, local_index[c[interior]])
+    remote = ~interior
+    key = co[remote] * n + c[remote]                      # (owner, global id): the halo order
+    ukey = torch.unique(key)
+    halo_ids = (ukey % n).cpu().numpy()
+    recv_counts = torch.bincount(ukey // n, minlength=world).cpu().numpy().astype(np.int64)
+    halo_csr = block(remote, torch.searchsorted(ukey, key))
+    skey = torch.unique(co[remote] * max(n_owned, 1) + r_local[remote])   # (destination, my row): what each peer needs of mine
+    send_idx = (skey % max(n_owned, 1)).cpu().numpy()
+    send_counts = torch.bincount(skey // max(n_owned, 1), minlength=world).cpu().numpy().astype(np.int64)
+    owned_np = owned.cpu().numpy()
+    return ShardPlan(rank, world, owned_np, int(np.count_nonzero(owned_np < n_users)), int_csr, halo_csr, halo_ids, recv_counts,
+                     send_idx, send_counts)
 
 
 # ---- compute backends ----------------------------------------------------------------------------
@@ -206,6 +260,15 @@ class HipBackend:
         self._lib.check(lib.rbg_mean_f32(arr, len(srcs), out.numel(), 1.0 / len(srcs), vp(out.data_ptr()), self._stream(stream)))
         return out
 
+    def spmm_mean(self, graph, x, partial, srcs, out, stream=None):
+        """out = (srcs[0] + ... + (partial + A x)) / (len(srcs) + 1): the last layer with the layer mean in its epilogue
+        (rbg_spmm_mean_f32); partial may be None."""
+        lib, vp = self._lib.lib, self._lib.c_vp
+        arr = (vp * len(srcs))(*[t.data_ptr() for t in srcs])
+        self._lib.check(lib.rbg_spmm_mean_f32(graph.ptr, vp(x.data_ptr()), vp(partial.data_ptr()) if partial is not None else None,
+                                              arr, len(srcs), vp(out.data_ptr()), x.shape[1], self._stream(stream)))
+        return out
+
     def gather_rows(self, src, idx, out=None, stream=None):
         if out is None:
             return self._ops.gather_rows(src, idx)
@@ -219,31 +282,38 @@ class HipBackend:
 
 class ShardedPropagation:
     """K-layer LightGCN propagation over a ShardPlan.  ``transport``: "nccl" (device buffers straight
-    into RCCL all_to_all_single, exchange on a second HIP stream) or "staged" (buffers staged through
-    the host and exchanged with point-to-point send/recv; works with gloo — used by tests and when two
-    ranks must share one GPU)."""
+    into RCCL all_to_all_single) or "staged" (buffers staged through the host and exchanged with
+    point-to-point send/recv; works with gloo — used by tests and when several ranks must share one GPU).
+
+    ``overlap`` (nccl transport): False = one stream per layer (pack, exchange, interior product, halo product), True =
+    pack + collective on a second, high-priority stream beside the interior product (rbg_shard_layer_begin/end).
+    Which is faster depends on the machine: on one GPU with a world-size-1 RCCL group (r01, devtools/nccl1_probe.py) the
+    second stream cost ~35 us of cross-stream event latency per layer and hid nothing (there was no link time to hide:
+    325 vs 259 us per propagation); with real peers the single-stream layer exposes the whole collective.  ``autotune``
+    measures both on the actual group and keeps the faster."""
 
     def __init__(self, plan, backend, group=None, transport="nccl", overlap=False):
-        """overlap: run pack + all_to_all on a second (high-priority) stream beside the interior SpMM.  Off by default:
-        measured with a world-size-1 RCCL group on MI355X (devtools/nccl1_probe.py, r01) a layer is gather 5 us, RCCL
-        kernel 8 us, interior SpMM 47 us, halo SpMM 12 us, and the second stream added ~35 us of cross-stream event
-        latency per layer while the kernels did not overlap (default-priority streams shared one hardware queue; a
-        high-priority comm stream overlapped but still paid the event hops): 325 us two streams, 297 us with a
-        high-priority comm stream, 259 us on one stream per propagation."""
         self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
-        self.overlap = bool(overlap)
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev
         self.g_int = self._make_graph(plan.int_csr, plan.n_owned)
         self.g_halo = self._make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
-        self.comm_stream = torch.cuda.Stream(device=dev, priority=-1) if (dev.type == "cuda" and self.overlap) else None
-        self._comm_h = self.comm_stream.cuda_stream if self.comm_stream is not None else None
-        self._ctx = backend.layer_ctx() if (transport == "nccl" and self.overlap and hasattr(backend, "layer_ctx")) else None
+        self.comm_stream, self._comm_h, self._ctx = None, None, None
+        self.overlap = False
+        self.set_overlap(overlap)
         self._n_send = len(plan.send_idx)
-        self._buf_d = None  # per-width buffers, allocated on first use: halo, send, two ping-pong outputs
+        self._buf_d = None  # per-width buffers, allocated on first use: halo, send, ping-pong outputs
         self._recv_splits = [int(c) for c in plan.recv_counts]
         self._send_splits = [int(c) for c in plan.send_counts]
+        self.tuned = None  # filled by autotune(): {"single_stream_us", "overlap_us", "chosen"}
+
+    def set_overlap(self, overlap):
+        self.overlap = bool(overlap) and self.transport == "nccl" and self.device.type == "cuda"
+        if self.overlap and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            self._comm_h = self.comm_stream.cuda_stream
+            self._ctx = self.backend.layer_ctx() if hasattr(self.backend, "layer_ctx") else None
 
     def _make_graph(self, csr, n_cols):
         return self.backend.make_graph(csr, n_cols, n_user_rows=self.plan.n_users_owned)
@@ -292,9 +362,23 @@ class ShardedPropagation:
         dist.all_to_all_single(halo, send[:n_send], output_split_sizes=self._recv_splits,
                                input_split_sizes=self._send_splits, group=self.group)
 
-    def spmm(self, x, out=None, main=None):
+    def _halo_product(self, halo, y, finish, main_h=None):
+        """The second half of a layer: Y += A_halo·halo — or, on the last layer (finish = (srcs, out)), the same product
+        with the layer mean in its epilogue: out = (srcs... + (Y + A_halo·halo)) / (len(srcs) + 1)."""
+        kw = {} if main_h is None else {"stream": main_h}
+        if finish is None:
+            if self.g_halo is not None:
+                self.backend.spmm(self.g_halo, halo, y, True, **kw)
+            return y
+        srcs, out = finish
+        if self.g_halo is not None:
+            return self.backend.spmm_mean(self.g_halo, halo, y, srcs, out, **kw)
+        return self.backend.mean(list(srcs) + [y], out, **kw)  # no halo on this rank: plain mean of the kept layers
+
+    def spmm(self, x, out=None, main=None, finish=None):
         """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows.  `main`: the torch stream the caller runs on
-        (looked up once per propagation by forward())."""
+        (looked up once per propagation by forward()).  `finish` = (srcs, out_mean): this is the last layer of a
+        propagation — returns out_mean = (sum(srcs) + Y) / (len(srcs) + 1) instead of Y (HIP backend only)."""
         plan = self.plan
         d = x.shape[1]
         if x.device.type == "cuda":
@@ -311,6 +395,8 @@ class ShardedPropagation:
             y = torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
             halo = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
         if plan.world == 1:
+            if finish is not None:
+                return self.backend.spmm_mean(self.g_int, x, None, finish[0], finish[1])
             return self.backend.spmm(self.g_int, x, y, False)
         if self.transport == "nccl":
             # all_to_all_single is a collective: every rank takes part every layer, even one whose
@@ -324,31 +410,25 @@ class ShardedPropagation:
                 dist.all_to_all_single(self._halo_view, self._send[: self._n_send], output_split_sizes=self._recv_splits,
                                        input_split_sizes=self._send_splits, group=self.group)
                 self.backend.spmm(self.g_int, x, y, False, stream=main_h)
-                if self.g_halo is not None:
-                    self.backend.spmm(self.g_halo, halo, y, True, stream=main_h)
-                return y
+                return self._halo_product(halo, y, finish, main_h)
             if self._ctx is not None:
                 # begin: comm waits for x and packs, main runs the interior SpMM; the collective goes on the comm stream;
-                # end: main waits for the comm stream and adds the halo product.  Three host calls per layer.
+                # end: main waits for the comm stream; the halo product follows on main.
                 self.backend.layer_begin(self._ctx, self.g_int, x, y, self.send_idx, self._n_send, self._send, main_h, self._comm_h)
                 with torch.cuda.stream(self.comm_stream):
                     dist.all_to_all_single(self._halo_view, self._send[: self._n_send], output_split_sizes=self._recv_splits,
                                            input_split_sizes=self._send_splits, group=self.group)
-                self.backend.layer_end(self._ctx, self.g_halo, halo, y, main_h, self._comm_h)
-                return y
+                self.backend.layer_end(self._ctx, None, halo, y, main_h, self._comm_h)  # the wait only
+                return self._halo_product(halo, y, finish, main_h)
             self.comm_stream.wait_stream(main)            # x is ready
             with torch.cuda.stream(self.comm_stream):
                 self._exchange_nccl(x, self._halo_view, stream=self._comm_h)
             self.backend.spmm(self.g_int, x, y, False, stream=main_h)    # overlaps with the exchange
             main.wait_stream(self.comm_stream)
-            if self.g_halo is not None:
-                self.backend.spmm(self.g_halo, halo, y, True, stream=main_h)
-            return y
+            return self._halo_product(halo, y, finish, main_h)
         self.backend.spmm(self.g_int, x, y, False)
         self._exchange_staged(x, halo[: plan.n_halo])  # point-to-point: only non-empty pairs talk
-        if self.g_halo is not None:
-            self.backend.spmm(self.g_halo, halo, y, True)
-        return y
+        return self._halo_product(halo, y, finish)
 
     # (Capturing the whole propagation in a HIP graph was tried on a world-size-1 RCCL group, devtools/nccl1_probe.py: a
     # lone all_to_all_single captures and replays, but the capture of this method — the collective on a second stream
@@ -359,17 +439,17 @@ class ShardedPropagation:
         """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users.
         The result lives in a buffer this object re-uses: it is valid until the next forward() / spmm() call on this
         object (propagating two views back to back: pass ``out=`` or clone the first result)."""
-        if hasattr(self.backend, "mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
-            # keep the K layer outputs and take the mean in one launch (instead of clone + K adds + a divide)
+        if hasattr(self.backend, "spmm_mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
+            # keep the K - 1 first layer outputs; the K-th product carries the layer mean in its epilogue
             self._buffers(e0)
             while len(self._y) < n_layers:
                 self._y.append(torch.empty_like(self._y[0]))
-            main = torch.cuda.current_stream(e0.device)
+            main = torch.cuda.current_stream(e0.device) if e0.device.type == "cuda" else None
             srcs, x = [e0], e0
-            for k in range(n_layers):
+            for k in range(n_layers - 1):
                 x = self.spmm(x, out=self._y[k], main=main)
                 srcs.append(x)
-            return self.backend.mean(srcs, self._mean if out is None else out, stream=main.cuda_stream)
+            return self.spmm(x, out=self._y[n_layers - 1], main=main, finish=(srcs, self._mean if out is None else out))
         acc = e0.clone()
         x = e0
         for _ in range(n_layers):
@@ -380,3 +460,97 @@ class ShardedPropagation:
             out.copy_(acc)
             return out
         return acc
+
+    def backward(self, grad_out, n_layers):
+        """dL/dE0 for the owned rows given dL/d(mean) for the owned rows.  The propagation is linear and the GLOBAL matrix
+        is symmetric (dataset.py:62-64 builds both directions), so  (Â^T g)[owned] = (Â g)[owned]: the backward of the
+        sharded product is the same sharded product — same plan, same halo exchange, applied to the gradient:
+            dE0 = (g + Â(g + Â(... + Â g))) / (K + 1)        (Horner form, K exchanges)."""
+        g = grad_out.contiguous()
+        x = g
+        for i in range(n_layers):
+            x = self.spmm(x)
+            x = x + g  # a fresh tensor: the ping-pong buffer is free again
+        return x / float(n_layers + 1)
+
+    def autotune(self, e0, n_layers, iters=10):
+        """nccl transport, N > 1: time a few propagations with each stream structure on the real group, take the MAX over
+        ranks, keep the faster one on every rank.  Returns the record it also stores in ``self.tuned``."""
+        if not (self.transport == "nccl" and self.plan.world > 1 and e0.device.type == "cuda"):
+            return None
+        res = {}
+        for ov in (False, True):
+            self.set_overlap(ov)
+            for _ in range(3):
+                self.forward(e0, n_layers)
+            torch.cuda.synchronize(e0.device)
+            dist.barrier(group=self.group)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                self.forward(e0, n_layers)
+            b.record()
+            torch.cuda.synchronize(e0.device)
+            t = torch.tensor([a.elapsed_time(b) * 1e3 / iters], device=e0.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            res[ov] = float(t[0])
+        choice = res[True] < res[False]
+        self.set_overlap(choice)
+        self.tuned = {"single_stream_us": res[False], "overlap_us": res[True], "chosen": "overlap" if choice else "single_stream"}
+        return self.tuned
+
+    # -- full-sort scoring over a sharded table (lightgcn.py:123-133: scores = u @ item_all.T) -------------------------------
+    def gather_item_table(self, mean_local, n_users, n_items):
+        """All-gather the item rows of the propagated embeddings once per evaluation: every rank ends with the
+        full [n_items, d] table in global item order; the user rows stay sharded."""
+        plan = self.plan
+        d = mean_local.shape[1]
+        items_local = mean_local[plan.n_users_owned:]
+        ids_local = torch.as_tensor(plan.owned[plan.n_users_owned:] - n_users, dtype=torch.int64)
+        table = torch.empty((n_items, d), dtype=mean_local.dtype, device=mean_local.device)
+        if plan.world == 1:
+            table[ids_local.to(table.device)] = items_local
+            return table
+        counts = [None] * plan.world
+        dist.all_gather_object(counts, int(items_local.shape[0]), group=self.group if self.transport != "nccl" else None)
+        cap = max(counts)
+        staged = self.transport != "nccl"
+        pad = torch.zeros((cap, d), dtype=mean_local.dtype, device="cpu" if staged else mean_local.device)
+        pad[: items_local.shape[0]] = items_local.cpu() if staged else items_local
+        pid = torch.full((cap,), -1, dtype=torch.int64, device=pad.device)
+        pid[: ids_local.shape[0]] = ids_local.to(pad.device)
+        rows = [torch.empty_like(pad) for _ in range(plan.world)]
+        ids = [torch.empty_like(pid) for _ in range(plan.world)]
+        dist.all_gather(rows, pad, group=self.group)
+        dist.all_gather(ids, pid, group=self.group)
+        for r, i, c in zip(rows, ids, counts):
+            table[i[:c].to(table.device)] = r[:c].to(table.device)
+        return table
+
+    def full_sort_scores(self, mean_local, local_users, n_users, n_items, item_table=None):
+        """scores [B, n_items] of this rank's users (indices into its owned user rows) against ALL items."""
+        if item_table is None:
+            item_table = self.gather_item_table(mean_local, n_users, n_items)
+        u = mean_local[: self.plan.n_users_owned].index_select(0, local_users.to(mean_local.device))
+        if mean_local.device.type == "cuda":
+            from . import ops
+            return ops.score(u.contiguous(), item_table)
+        return u @ item_table.T
+
+
+class _ShardedLightGCN(torch.autograd.Function):
+    """Autograd over ShardedPropagation.forward (fused mean) / .backward (Horner chain of the same sharded product)."""
+
+    @staticmethod
+    def forward(ctx, e0, prop, n_layers):
+        ctx.prop, ctx.n_layers = prop, n_layers
+        return prop.forward(e0, n_layers).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.prop.backward(grad_out, ctx.n_layers), None, None
+
+
+def sharded_lightgcn_forward(prop, e0, n_layers):
+    """Differentiable mean(E_0..E_K) of this rank's rows; e0 = the rank's rows of the embedding tables (users first)."""
+    return _ShardedLightGCN.apply(e0, prop, n_layers)

@@ -187,3 +187,93 @@ def test_nccl_transport_on_a_world_size_one_group(ref_inter):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert errs[False] <= 1e-5 and errs[True] <= 1e-5, errs
+
+
+def _worker_round2(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
+    """HIP backend, two ranks on cuda:0: the plan cut on the device out of the device-built CSR (full graph and an edge-drop
+    view), the fused-mean forward, the sharded backward, and full-sort scoring over the all-gathered item table."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        dev = torch.device("cuda:0")
+        n = nu + ni
+        rng = np.random.default_rng(1)
+        e0 = rng.standard_normal((n, d)).astype(np.float32)
+        w = rng.standard_normal((n, d)).astype(np.float32)
+        keep = np.zeros(len(uid), dtype=np.uint8)
+        keep[np.random.default_rng(5).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+        owner = sh.default_partition(uid, iid, nu, ni, world)
+        out = {}
+        for name, mask in (("full", None), ("view", keep)):
+            g_global = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, keep=mask)
+            rowptr, col, val = g_global.device_csr()  # aliases the handle's HBM arrays
+            plan = sh.plan_from_csr(rowptr, col, val, nu, owner, rank, world)
+            ref_plan = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=mask)[rank]
+            same = all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(
+                plan.int_csr + plan.halo_csr + (plan.halo_ids, plan.send_idx, plan.send_counts, plan.recv_counts, plan.owned),
+                ref_plan.int_csr + ref_plan.halo_csr + (ref_plan.halo_ids, ref_plan.send_idx, ref_plan.send_counts,
+                                                        ref_plan.recv_counts, ref_plan.owned)))
+            prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="staged")
+            x = torch.from_numpy(e0[plan.owned]).to(dev).requires_grad_(True)
+            mean = sh.sharded_lightgcn_forward(prop, x, k_layers)
+            (mean * torch.from_numpy(w[plan.owned]).to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            rp, cc, vv = C.build_norm_csr(uid, iid, nu, ni, keep=mask)
+            ref = C.lightgcn_forward(rp, cc, vv, e0[:nu], e0[nu:], k_layers)
+            gref = C.lightgcn_forward(rp, cc, vv, w[:nu], w[nu:], k_layers)  # M is symmetric: d<w, M e0>/d e0 = M w
+            out[name] = (same, float(np.abs(mean.detach().cpu().numpy() - ref[plan.owned]).max()),
+                         float(np.abs(x.grad.cpu().numpy() - gref[plan.owned]).max()))
+            if name == "full":
+                m = mean.detach()
+                table = prop.gather_item_table(m, nu, ni)
+                users = torch.arange(min(7, plan.n_users_owned))
+                sc = prop.full_sort_scores(m, users, nu, ni, item_table=table)
+                s_ref = ref[plan.owned[users.numpy()]] @ ref[nu:].T
+                out["score"] = (float(np.abs(table.cpu().numpy() - ref[nu:]).max()), float(np.abs(sc.cpu().numpy() - s_ref).max()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, out))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_device_planner_backward_view_scoring(ref_inter):
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_round2, args=(r, 2, port, uid, iid, nu, ni, 3, 64, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for name in ("full", "view"):
+            same, err, gerr = out[name]
+            assert same and err <= 1e-5 and gerr <= 1e-5, (rank, name, out[name])
+        assert out["score"][0] <= 1e-5 and out["score"][1] <= 1e-5, (rank, out["score"])
+
+
+def test_spmm_mean_epilogue(rbg, cuda, ref_inter):
+    """rbg_spmm_mean_f32: (srcs... + (partial + A x)) / (n + 1) against the separate product / accumulate / mean calls."""
+    uid, iid, nu, ni = ref_inter
+    be = rbg.sharded.HipBackend(cuda)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    n = nu + ni
+    for d in (64, 20):
+        gen = torch.Generator().manual_seed(d)
+        x, part, e0, y1 = (torch.randn(n, d, generator=gen).to(cuda) for _ in range(4))
+        ax = rbg.ops.spmm_raw(h, x)
+        got = be.spmm_mean(h, x, part, [e0, y1], torch.empty_like(x))
+        ref = (e0 + y1 + (ax + part)) / 3.0
+        assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+        got = be.spmm_mean(h, x, None, [e0], torch.empty_like(x))
+        assert float((got - (e0 + ax) / 2.0).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))

@@ -140,3 +140,116 @@ def test_two_process_gloo_exchange(ref_inter, layout):
     for rank, err, n_halo, n_send in res:
         assert err <= 1e-5, (rank, err)
         assert n_halo > 0 and n_send > 0  # the exchange path really ran
+
+
+# ---- round 2: plan_from_csr, edge-drop views, backward, sharded scoring ------------------------------------------------------
+
+def _plans_equal(a, b):
+    assert a.rank == b.rank and a.world == b.world and a.n_users_owned == b.n_users_owned
+    assert np.array_equal(a.owned, b.owned) and np.array_equal(a.halo_ids, b.halo_ids)
+    assert np.array_equal(a.recv_counts, b.recv_counts) and np.array_equal(a.send_counts, b.send_counts)
+    assert np.array_equal(a.send_idx, b.send_idx)
+    for x, y in ((a.int_csr, b.int_csr), (a.halo_csr, b.halo_csr)):
+        assert np.array_equal(np.asarray(x[0]), np.asarray(y[0])) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("layout", ["ranges", "striped"])
+def test_plan_from_csr_equals_numpy_planner(rbg, ref_inter, world, layout):
+    """The planner that cuts a rank's blocks out of the built global CSR (torch ops; on a GPU box they run in HBM) gives
+    exactly the numpy planner's plan: same blocks bit for bit, same halo / send lists."""
+    uid, iid, nu, ni = ref_inter
+    sh = rbg.sharded
+    owner = sh.default_partition(uid, iid, nu, ni, world) if layout == "ranges" else sh.striped_partition(nu, ni, world)
+    ref = sh.build_plans(uid, iid, nu, ni, world, owner=owner)
+    g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=None)  # host builder; on the GPU box: device_csr()
+    rowptr, col, val = (torch.from_numpy(a) for a in g.export_csr())
+    for r in range(world):
+        _plans_equal(sh.plan_from_csr(rowptr, col, val, nu, owner, r, world), ref[r])
+
+
+def test_edge_drop_view_plans_match_the_single_device_view(rbg, ref_inter):
+    """build_plans(keep=mask): an SGL ED view (sgl.py:107-126) sharded — the blocks of all ranks together are the masked
+    single-device graph bit for bit (weights from the view's own GLOBAL degrees, sgl.py:119-124)."""
+    uid, iid, nu, ni = ref_inter
+    sh = rbg.sharded
+    keep = np.zeros(len(uid), dtype=np.uint8)
+    keep[np.random.default_rng(5).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+    world = 2
+    owner = sh.default_partition(uid, iid, nu, ni, world)  # the FULL graph's partition: the views share the embedding shards
+    plans = sh.build_plans(uid, iid, nu, ni, world, owner=owner, keep=keep)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni, keep=keep)
+    for p, plan in plans.items():
+        assert np.array_equal(plan.owned, np.flatnonzero(owner == p))
+        for r_local in range(0, plan.n_owned, 7):
+            g_row = plan.owned[r_local]
+            ent = {}
+            for csr, ids in ((plan.int_csr, plan.owned), (plan.halo_csr, plan.halo_ids)):
+                for c, v in zip(csr[1][csr[0][r_local]:csr[0][r_local + 1]], csr[2][csr[0][r_local]:csr[0][r_local + 1]]):
+                    ent[int(ids[c])] = v
+            gb, ge = rowptr[g_row], rowptr[g_row + 1]
+            assert sorted(ent) == col[gb:ge].tolist() and all(ent[int(c)] == v for c, v in zip(col[gb:ge], val[gb:ge]))
+
+
+def _worker2(rank, world, port, uid, iid, nu, ni, k_layers, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        n, d = nu + ni, 16
+        rng = np.random.default_rng(1)
+        e0 = rng.standard_normal((n, d)).astype(np.float32)
+        w = rng.standard_normal((n, d)).astype(np.float32)
+        keep = np.zeros(len(uid), dtype=np.uint8)
+        keep[np.random.default_rng(5).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+        owner = sh.default_partition(uid, iid, nu, ni, world)
+        out = {}
+        for name, mask in (("full", None), ("view", keep)):
+            plan = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=mask)[rank]
+            prop = sh.ShardedPropagation(plan, CpuBackend(), transport="staged")
+            x = torch.from_numpy(e0[plan.owned]).requires_grad_(True)
+            mean = sh.sharded_lightgcn_forward(prop, x, k_layers)
+            (mean * torch.from_numpy(w[plan.owned])).sum().backward()
+            rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni, keep=mask)
+            ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)
+            # the propagation operator M = (I + A + ... + A^K) / (K + 1) is symmetric: d<w, M e0>/d e0 = M w
+            gref = C.lightgcn_forward(rowptr, col, val, w[:nu], w[nu:], k_layers)
+            out[name] = (float(np.abs(mean.detach().numpy() - ref[plan.owned]).max()),
+                         float(np.abs(x.grad.numpy() - gref[plan.owned]).max()))
+            if name == "full":  # sharded full-sort scoring: local users against the all-gathered item table
+                m = mean.detach()
+                table = prop.gather_item_table(m, nu, ni)
+                users = torch.arange(min(5, plan.n_users_owned))
+                s = prop.full_sort_scores(m, users, nu, ni, item_table=table)
+                s_ref = ref[plan.owned[users.numpy()]] @ ref[nu:].T
+                out["score"] = (float(np.abs(table.numpy() - ref[nu:]).max()), float(np.abs(s.numpy() - s_ref).max()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, out))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_backward_views_and_scoring(ref_inter):
+    """World size 2 over gloo: sharded gradients (the backward is the same sharded product, by symmetry of the global
+    matrix), an edge-drop view propagated over its own plan, and full-sort scoring over the all-gathered item table."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 23
+    procs = [ctx.Process(target=_worker2, args=(r, 2, port, uid, iid, nu, ni, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for name in ("full", "view"):
+            assert out[name][0] <= 1e-5 and out[name][1] <= 1e-5, (rank, name, out[name])
+        assert out["score"][0] <= 1e-5 and out["score"][1] <= 1e-4, (rank, out["score"])
