@@ -6,11 +6,15 @@ the layer mean, 64-d fp32, inputs resident in HBM before the timed region.
 
 N = 1: BASELINE.json configs[1] — the Gowalla-shaped synthetic power-law graph (29,859 users / 40,982
        items / 1,027,370 interactions incl. the two PAD rows).
-N > 1: the node-range sharded path (recbole-gnn_amd/sharded.py): every rank owns one Gowalla-shaped
-       block of a P-times larger graph (weak scaling); a fraction p_in of each user's interactions stays
-       inside the rank's block, the rest references other ranks and is served by a per-layer halo
-       exchange (RCCL all_to_all over xGMI, overlapped with the interior SpMM on a second stream).
-       value counts shard-propagations: one global forward over P shards = P propagations.
+N > 1: the node-range sharded path (recbole-gnn_amd/sharded.py), trimmed halo exchange per layer (RCCL all_to_all over
+       xGMI; single-stream or overlapped on a second stream — both are timed on the real group, the faster is kept).
+       --scaling weak (default): every rank owns one Gowalla-shaped block of a P-times larger graph with PLANTED
+         locality: a fraction p_in (printed) of each user's interactions stays inside the rank's block.  value counts
+         shard-propagations: one global forward over P shards = P propagations.
+       --scaling strong: ONE fixed graph (Amazon-Book shape at N <= 4, the 1.3 M-node shape above) cut into nnz-balanced
+         node ranges, no planted locality; value = global forwards/s.  N = 1 extras carry the single-GPU
+         propagations/s of the same graphs ("strong_scaling_reference").
+       Whichever mode is not the headline is measured too and reported under "other_scaling_mode".
 
 Also reported: "roofline" (algorithmic bytes of one SpMM launch / its average duration from HIP events on
 the launch stream, against the 8 TB/s HBM peak) and "cpu_baseline" (the oracle's C restatement of the
@@ -43,6 +47,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) measurements at N = 1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N>1 headline: weak = one workload-shaped block per rank with planted locality p_in (value counts "
+                         "shard-propagations); strong = ONE fixed graph (amazon-book at N <= 4, g-1.3m above) cut into nnz-balanced "
+                         "node ranges, no planted locality (value = global forwards/s).  The other one is reported alongside.")
+    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the other scaling mode's measurement")
     ap.add_argument("--transport", choices=["nccl", "staged"], default="nccl",
                     help="N>1 halo transport: RCCL all_to_all (default) or host-staged gloo send/recv (self-test: lets "
                          "several ranks share one GPU)")
@@ -199,7 +208,17 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         gb, _ = rbg.synth.algorithmic_bytes(gn, gg.nnz, d, k_layers)
         ex["g-1.3m"] = {"nodes": gn, "nnz": gg.nnz, "spmm_us": us, "roofline_frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                         "kernel": gg.spmm_kernel_name(d)}
-        del gg, gx, gy
+        ref = {}
+        go, gl = torch.empty(gn, d, device=dev), torch.empty(max(k_layers, 1), gn, d, device=dev)
+        ref["g-1.3m"] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl), iters=5, warm=1)
+        del gg, gx, gy, go, gl
+        au, ai, anu, ani = rbg.synth.make("amazon-book")
+        ag = rbg.GraphHandle.from_interactions(au, ai, anu, ani, device=dev)
+        ax = torch.randn(anu + ani, d, device=dev)
+        ao, al = torch.empty(anu + ani, d, device=dev), torch.empty(max(k_layers, 1), anu + ani, d, device=dev)
+        ref["amazon-book"] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(ag, ax[:anu], ax[anu:], k_layers, out=ao, layers=al), iters=20, warm=3)
+        ex["strong_scaling_reference(single-GPU propagations/s of the --scaling strong graphs)"] = ref
+        del ag, ax, ao, al
     except Exception as e:  # noqa: BLE001
         ex["g-1.3m_error"] = str(e)[:200]
     # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
@@ -234,6 +253,52 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     except Exception as e:  # noqa: BLE001  (diagnostics only: never cost the headline its JSON line)
         ex["model_steps_error"] = str(e)[:200]
     return ex
+
+
+def timed_loop(step, steps, warmup, world, gloo_group):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; (wall s, event ms), MAX over ranks."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(group=gloo_group)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()  # torch's current stream == the stream every kernel is launched on
+    for _ in range(steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(group=gloo_group)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo_group)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+    return elapsed, ev_ms
+
+
+def strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, overlap):
+    """Strong scaling: ONE fixed graph, default_partition (users and items each cut into `world` nnz-balanced node ranges),
+    no planted locality.  The global normalized CSR is built on the device and the rank's blocks are cut out of it there
+    (plan_from_csr) — nothing of size nnz is sorted on the host."""
+    name = "amazon-book" if world <= 4 else "g-1.3m"
+    uid, iid, nu, ni = rbg.synth.make(name)
+    owner = sh.default_partition(uid, iid, nu, ni, world)
+    g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+    plan = sh.plan_from_csr(*g.device_csr(), nu, owner, rank, world)
+    del g
+    prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), group=gloo_group if transport == "staged" else None,
+                                 transport=transport, overlap=overlap)
+    e0 = xavier(plan.n_owned, d, gen).to(dev)
+    desc = (f"{name}-shape graph ({nu} users / {ni} items / {len(uid)} interactions) cut into {world} nnz-balanced node ranges "
+            f"per side, no planted locality, trimmed halo all_to_all per layer")
+    return prop, e0, plan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * len(uid), d, 3)
 
 
 def traffic_from_profiles(workload, d, kernel):
@@ -313,14 +378,24 @@ def main():
         workload = (f"{args.workload}-shape synthetic power-law bipartite graph: {nu} users / {ni} items / "
                     f"{n_inter} interactions (PAD rows included), nnz(A_hat) = {2 * n_inter}")
     else:
-        nu_g, ni_g = (nu - 1) * world + 1, (ni - 1) * world + 1
-        uid, iid = rbg.synth.powerlaw_bipartite(nu_g, ni_g, n_inter * world, seed=args.seed, n_blocks=world,
-                                                p_in=args.p_in)
-        owner = sh.striped_partition(nu_g, ni_g, world)
-        plan = sh.build_plans(uid, iid, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
         transport = args.transport
-        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport=transport)
-        e0 = xavier(plan.n_owned, d, gen).to(dev)
+
+        def weak_setup():
+            nu_g, ni_g = (nu - 1) * world + 1, (ni - 1) * world + 1
+            wu, wi = rbg.synth.powerlaw_bipartite(nu_g, ni_g, n_inter * world, seed=args.seed, n_blocks=world, p_in=args.p_in)
+            owner = sh.striped_partition(nu_g, ni_g, world)
+            wplan = sh.build_plans(wu, wi, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
+            wprop = sh.ShardedPropagation(wplan, sh.HipBackend(dev), group=gloo_group if transport == "staged" else None,
+                                          transport=transport)
+            desc = (f"{world} x {args.workload}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
+                    f"{n_inter * world} interactions, PLANTED locality p_in = {args.p_in} (striped communities = the partition), "
+                    f"trimmed halo all_to_all per layer")
+            return wprop, xavier(wplan.n_owned, d, gen).to(dev), wplan, desc
+
+        if args.scaling == "weak":
+            prop, e0, plan, workload = weak_setup()
+        else:
+            prop, e0, plan, workload, (b_layer, b_prop) = strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, False)
         if transport == "nccl":
             # rehearse one exchange; if RCCL cannot run it on this node, every rank falls back to the host-staged
             # gloo transport (slow, but the run still reports a labelled number instead of crashing)
@@ -336,40 +411,40 @@ def main():
             if min(float(v) for v in votes) == 0.0:
                 transport = "staged"
                 prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), group=gloo_group, transport="staged")
+        if transport == "nccl":  # pick the stream structure on the real group: both are timed, the faster is kept
+            extra["overlap_autotune"] = prop.autotune(e0, k_layers)
 
         def step():
             prop.forward(e0, k_layers)
 
         launches_per_step = k_layers
-        units_per_step = world
+        units_per_step = world if args.scaling == "weak" else 1
         kernel_name = prop.g_int.spmm_kernel_name(d)
-        extra.update(p_in=args.p_in, halo_rows_rank0=int(plan.n_halo), owned_rows_rank0=int(plan.n_owned),
-                     halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4)
-        workload = (f"{world} x {args.workload}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
-                    f"{n_inter * world} interactions, p_in = {args.p_in}, trimmed halo all_to_all per layer")
+        extra.update(p_in=args.p_in if args.scaling == "weak" else None, halo_rows_rank0=int(plan.n_halo),
+                     owned_rows_rank0=int(plan.n_owned), halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4,
+                     overlap=bool(prop.overlap))
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier(group=gloo_group)
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # torch's current stream == the stream every kernel is launched on
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier(group=gloo_group)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo_group)
-        elapsed, ev_ms = float(t[0]), float(t[1])
+    elapsed, ev_ms = timed_loop(step, args.steps, args.warmup, world, gloo_group if world > 1 else None)
+
+    if world > 1 and not args.no_secondary:
+        # the other scaling mode, same process group, bounded: its own short timed loop
+        try:
+            if args.scaling == "weak":
+                p2, e2, plan2, desc2, _ = strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, prop.overlap)
+                units2, label2 = 1, "strong"
+            else:
+                p2, e2, plan2, desc2 = weak_setup()
+                p2.set_overlap(prop.overlap)
+                units2, label2 = world, "weak"
+            steps2 = max(10, min(args.steps, 100))
+            el2, _ = timed_loop(lambda: p2.forward(e2, k_layers), steps2, max(3, min(args.warmup, 10)), world, gloo_group)
+            secondary = {"scaling": label2, "value": units2 * steps2 / el2, "unit": "propagations/s", "ms_per_step": el2 * 1e3 / steps2,
+                         "steps": steps2, "workload": desc2, "halo_rows_rank0": int(plan2.n_halo), "owned_rows_rank0": int(plan2.n_owned),
+                         "p_in": args.p_in if label2 == "weak" else None}
+            del p2, e2
+        except Exception as ex:  # noqa: BLE001  (a deterministic failure is raised on every rank alike)
+            secondary = {"error": str(ex)[:300]}
+        extra["other_scaling_mode"] = secondary
 
     if world > 1:
         # phase breakdown of one sharded layer (each phase alone, back to back; rank-0 view) so the scaling
@@ -413,13 +488,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "embedding_dim": d, "n_layers": k_layers,
                        "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
-                       "sharding": "none" if world == 1 else f"node-range x{world}, transport={transport}"},
+                       "sharding": "none" if world == 1 else
+                       f"node-range x{world}, transport={transport}, {'exchange overlapped on a second stream' if prop.overlap else 'single-stream layers'}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic_from_profiles(args.workload, d, kernel_name) if world == 1 else None,
