@@ -43,6 +43,9 @@ extern "C" {
 #define RBG_GRAPH_KEEP_HOST      1u  /* keep the host CSR next to the device copy (export without D2H) */
 #define RBG_GRAPH_BUILD_ON_HOST  2u  /* force the host (C++) builder even for a device graph */
 #define RBG_GRAPH_NATURAL_ORDER  4u  /* do not degree-bin rows; rows are processed in id order */
+#define RBG_GRAPH_INPUTS_ON_DEVICE 8u /* uid / iid / keep are DEVICE pointers on the graph's GPU (device builder only; work
+                                         that produced them must be complete or ordered before the null stream): an SGL view
+                                         sampled on the device is built without the interactions crossing PCIe again */
 
 /* rbg_lightgcn_forward_f32 flags */
 #define RBG_FWD_DEFAULT          0u

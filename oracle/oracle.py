@@ -293,3 +293,64 @@ def xavier_uniform(rows, d, gen):
     """recbole xavier_uniform_initialization on nn.Embedding (lightgcn.py:57): U(+-sqrt(6/(rows+d)))."""
     bound = float(np.sqrt(6.0 / (rows + d)))
     return (torch.rand(rows, d, generator=gen, dtype=torch.float32) * 2 - 1) * bound
+
+
+# --------------------------------------------------------------------------------------------
+# NCL (recbole_gnn/model/general_recommender/ncl.py)
+# --------------------------------------------------------------------------------------------
+
+def ncl_forward(user_w, item_w, conv, n_layers, hyper_layers):
+    """ncl.py:93-104: max(n_layers, 2 * hyper_layers) propagations, every layer kept; the recommendation embedding is the
+    mean of layers 0..n_layers."""
+    x = torch.cat([user_w, item_w], dim=0)
+    embs = [x]
+    for _ in range(max(n_layers, hyper_layers * 2)):
+        x = conv(x)
+        embs.append(x)
+    mean = torch.mean(torch.stack(embs[: n_layers + 1], dim=1), dim=1)
+    return mean[: user_w.shape[0]], mean[user_w.shape[0]:], embs
+
+
+def ncl_proto_nce_loss(node_embedding, n_users, user, item, user_centroids, user_2cluster, item_centroids, item_2cluster,
+                       ssl_temp, proto_reg):
+    """ncl.py:106-135, statement by statement."""
+    import torch.nn.functional as F
+    ua, ia = node_embedding[:n_users], node_embedding[n_users:]
+    out = 0.0
+    for table, idx, cents, n2c in ((ua, user, user_centroids, user_2cluster), (ia, item, item_centroids, item_2cluster)):
+        norm = F.normalize(table[idx])
+        pos = torch.exp((norm * cents[n2c[idx]]).sum(dim=1) / ssl_temp)
+        ttl = torch.exp(norm.matmul(cents.T) / ssl_temp).sum(dim=1)
+        out = out + (-torch.log(pos / ttl).sum())
+    return proto_reg * out
+
+
+def ncl_ssl_layer_loss(current, previous, n_users, user, item, ssl_temp, ssl_reg, alpha):
+    """ncl.py:137-165, statement by statement."""
+    import torch.nn.functional as F
+    losses = []
+    for cur, prev, idx in ((current[:n_users], previous[:n_users], user), (current[n_users:], previous[n_users:], item)):
+        e1, e2, e_all = F.normalize(cur[idx]), F.normalize(prev[idx]), F.normalize(prev)
+        pos = torch.exp((e1 * e2).sum(dim=1) / ssl_temp)
+        ttl = torch.exp(e1.matmul(e_all.T) / ssl_temp).sum(dim=1)
+        losses.append(-torch.log(pos / ttl).sum())
+    return ssl_reg * (losses[0] + alpha * losses[1])
+
+
+def kmeans_lloyd(x, init, niter=25):
+    """Lloyd's algorithm in float64 from given starting centroids — the published algorithm behind ``faiss.Kmeans.train``
+    (ncl.py:69-71; faiss is third-party, un-pinned, absent here).  Returns (centroids, assignment, objective per round).
+    Empty clusters keep their centroid (the callers' test data has none; faiss would split a populated cluster)."""
+    x = np.asarray(x, dtype=np.float64)
+    c = np.asarray(init, dtype=np.float64).copy()
+    obj = []
+    for _ in range(niter):
+        d2 = (x * x).sum(1)[:, None] - 2.0 * x @ c.T + (c * c).sum(1)[None, :]
+        a = d2.argmin(1)
+        obj.append(float(d2[np.arange(len(x)), a].sum()))
+        for j in range(len(c)):
+            m = a == j
+            if m.any():
+                c[j] = x[m].mean(0)
+    d2 = (x * x).sum(1)[:, None] - 2.0 * x @ c.T + (c * c).sum(1)[None, :]
+    return c, d2.argmin(1), obj

@@ -5,11 +5,11 @@ The package directory name carries a hyphen; import it as ``recbole_gnn_amd`` (t
 the repository root) or with ``importlib.import_module("recbole-gnn_amd")``.
 Importing fails loudly if librbgnn.so (the HIP extension) has not been built; there is no CPU path.
 """
-from . import _lib, driver, graph, models, ops, sharded, synth, train  # noqa: F401
+from . import _lib, driver, graph, models, ops, sharded, sweep, synth, train  # noqa: F401
 from ._lib import LIB_PATH, RbgError  # noqa: F401
 from .graph import (GraphHandle, InteractionDataset, device_count, find_communities, get_option, get_tuning, norm_edges,  # noqa: F401
                     set_option, set_tuning)
-from .models import NGCF, SGL, GeneralGraphRecommender, LightGCN, SimGCL, XSimGCL  # noqa: F401
+from .models import NCL, NGCF, SGL, GeneralGraphRecommender, LightGCN, SimGCL, XSimGCL  # noqa: F401
 from .ops import BiGNNConv, LightGCNConv, full_sort_topk, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
 
 from .train import FusedBPRAdam, GraphedStep  # noqa: F401,E402

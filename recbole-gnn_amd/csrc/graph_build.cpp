@@ -519,6 +519,8 @@ int rbg_graph_create_partitioned(rbg_graph **out, int64_t n_users, int64_t n_ite
     if (device < -1) return fail(RBG_EINVAL, "device %d", device);
     if (part && n_parts != 1 && n_parts != 2 && n_parts != 4 && n_parts != 8)
         return fail(RBG_EINVAL, "n_parts = %d (must be 1, 2, 4 or 8: parts are pinned to whole XCDs)", n_parts);
+    if ((flags & RBG_GRAPH_INPUTS_ON_DEVICE) && (device < 0 || (flags & RBG_GRAPH_BUILD_ON_HOST)))
+        return fail(RBG_EINVAL, "RBG_GRAPH_INPUTS_ON_DEVICE needs a device graph and the device builder");
     rbg_graph *g = new (std::nothrow) rbg_graph();
     if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
     g->device = device;

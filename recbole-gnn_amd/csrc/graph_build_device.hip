@@ -100,9 +100,9 @@ int build_device_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_i
         return rc;
     if (keep && (rc = d_keep.alloc(e))) return rc;
     if (e) {
-        RBG_HIP(hipMemcpyAsync(d_uid.p, uid, e * 8, hipMemcpyHostToDevice, s));
-        RBG_HIP(hipMemcpyAsync(d_iid.p, iid, e * 8, hipMemcpyHostToDevice, s));
-        if (keep) RBG_HIP(hipMemcpyAsync(d_keep.p, keep, e, hipMemcpyHostToDevice, s));
+        RBG_HIP(hipMemcpyAsync(d_uid.p, uid, e * 8, hipMemcpyDefault, s));
+        RBG_HIP(hipMemcpyAsync(d_iid.p, iid, e * 8, hipMemcpyDefault, s));
+        if (keep) RBG_HIP(hipMemcpyAsync(d_keep.p, keep, e, hipMemcpyDefault, s));
     }
     RBG_HIP(hipMemsetAsync(d_deg.p, 0, ((size_t)n + 1) * 4, s));
     RBG_HIP(hipMemsetAsync(d_bad.p, 0, 4, s));

@@ -159,7 +159,10 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
     opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr)
     gstep = None
     history = []
-    for epoch in range(epochs):
+    warm_up = getattr(model, "warm_up_step", None)  # NCLTrainer._train_epoch (trainer.py:130-133): the last loss term
+    for epoch in range(epochs):                       # (the prototype contrast) joins after warm_up_step epochs
+        if hasattr(model, "e_step") and epoch % max(int(getattr(model, "m_step", 1) or 1), 1) == 0:
+            model.e_step()  # NCLTrainer.fit (trainer.py:38-40)
         model.train()
         total = torch.zeros((), device=model.device)
         for batch in sampler:
@@ -179,7 +182,8 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
             else:
                 opt.zero_grad(set_to_none=True)
                 loss = model.calculate_loss(batch)
-                loss = sum(loss) if isinstance(loss, tuple) else loss  # RecBole's trainer sums tuple losses
+                if isinstance(loss, tuple):  # RecBole's trainer sums tuple losses
+                    loss = sum(loss[:-1] if (warm_up is not None and epoch < warm_up) else loss)
                 loss.backward()
                 opt.step()
                 total += loss.detach().reshape(())

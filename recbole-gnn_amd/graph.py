@@ -84,6 +84,8 @@ class GraphHandle:
         """dataset.py:60-75 (keep=None) or one SGL view (sgl.py:107-126) when ``keep`` is a mask.
         ``xcd_part``: optional int array [n_users + n_items] with a community id per node (1, 2, 4 or 8 communities):
         each community's rows are pinned to its own XCD(s) for L2 locality; results are unchanged."""
+        if isinstance(uid, torch.Tensor) and uid.is_cuda:
+            return cls._from_device_interactions(uid, iid, n_users, n_items, device, keep, flags, xcd_part)
         uid, iid = _np_i64(uid), _np_i64(iid)
         if uid.shape != iid.shape or uid.ndim != 1:
             raise ValueError("uid and iid must be 1-D arrays of equal length")
@@ -119,6 +121,31 @@ class GraphHandle:
                 raise ValueError("keep mask must have one entry per interaction")
             check(lib.rbg_graph_create_masked(ctypes.byref(out), n_users, n_items, uid.shape[0], _ptr(uid), _ptr(iid),
                                               _ptr(keep), _device_index(device), flags))
+        return cls(out.value, symmetric=True, n_users=int(n_users))
+
+    @classmethod
+    def _from_device_interactions(cls, uid, iid, n_users, n_items, device, keep, flags, xcd_part):
+        """uid / iid (int64) and keep (uint8 / bool) already live on the graph's GPU: the device builder reads them in
+        place (RBG_GRAPH_INPUTS_ON_DEVICE) — the path of SGL views sampled on the device."""
+        if xcd_part is not None:
+            raise ValueError("xcd_part needs host interactions")
+        idx = _device_index(device if device is not None else uid.device)
+        if not (iid.is_cuda and uid.device == iid.device and uid.device.index == idx):
+            raise ValueError("uid, iid and the graph must be on the same GPU")
+        uid, iid = uid.to(torch.int64).contiguous(), iid.to(torch.int64).contiguous()
+        if uid.shape != iid.shape or uid.dim() != 1:
+            raise ValueError("uid and iid must be 1-D tensors of equal length")
+        kp = None
+        if keep is not None:
+            keep = torch.as_tensor(keep, device=uid.device).to(torch.uint8).contiguous()
+            if keep.shape != uid.shape:
+                raise ValueError("keep mask must have one entry per interaction")
+            kp = c_vp(keep.data_ptr())
+        torch.cuda.current_stream(uid.device).synchronize()  # the builder runs on the null stream
+        out = c_vp()
+        with torch.cuda.device(uid.device):
+            check(lib.rbg_graph_create_masked(ctypes.byref(out), n_users, n_items, uid.shape[0], c_vp(uid.data_ptr()),
+                                              c_vp(iid.data_ptr()), kp, idx, flags | _lib.GRAPH_INPUTS_ON_DEVICE))
         return cls(out.value, symmetric=True, n_users=int(n_users))
 
     @classmethod

@@ -341,6 +341,11 @@ class SGL(GeneralGraphRecommender):
         self.ssl_tau = config["ssl_tau"] if config["ssl_tau"] is not None else 0.5
         self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-5
         self.ssl_weight = config["ssl_weight"] if config["ssl_weight"] is not None else 0.05
+        # engine extension: sample the augmentation masks on the GPU (torch's device RNG) and build the views from
+        # device-resident interactions.  False = the reference's numpy calls on the host (np.random's global stream:
+        # what RNG-parity tests need; 51 of the 51 ms of graph_construction at the Gowalla shape, r01).
+        self.device_sampling = config["device_sampling"] if config["device_sampling"] is not None else True
+        self._inter_dev = None
         self.reg_loss = EmbLoss()
         self.user_embedding = nn.Embedding(self.n_users, self.embed_dim)
         self.item_embedding = nn.Embedding(self.n_items, self.embed_dim)
@@ -369,6 +374,9 @@ class SGL(GeneralGraphRecommender):
     def random_graph_augment(self):
         """sgl.py:93-126: sample with numpy's global RNG exactly as the reference does, then rebuild
         and re-normalize the view (native builder, keep-mask form)."""
+        if self.device_sampling:
+            return self._random_graph_augment_device()
+
         def rand_sample(high, size=None, replace=True):
             return np.random.choice(np.arange(high), size=size, replace=replace)
 
@@ -385,6 +393,26 @@ class SGL(GeneralGraphRecommender):
             keep_mask[keep] = 1
         graph = GraphHandle.from_interactions(self._user, self._item, self.n_users, self.n_items, device=self.device,
                                               keep=keep_mask)
+        return graph, None
+
+    def _random_graph_augment_device(self):
+        """The same three augmentations with the draw on the GPU: a uniform sample WITHOUT replacement of exactly the
+        reference's size (sgl.py:97-110) — ``torch.randperm(n, device)[:k]`` instead of ``np.random.choice(arange(n), k,
+        replace=False)`` — and the view built by the device builder from interactions that stay in HBM."""
+        if self._inter_dev is None:
+            self._inter_dev = (self._user.to(self.device), self._item.to(self.device))
+        u, i = self._inter_dev
+        n_inter = u.shape[0]
+        if self.aug_type == "ND":
+            du = torch.zeros(self.n_users, dtype=torch.bool, device=self.device)
+            di = torch.zeros(self.n_items, dtype=torch.bool, device=self.device)
+            du[torch.randperm(self.n_users, device=self.device)[: int(self.n_users * self.drop_ratio)]] = True
+            di[torch.randperm(self.n_items, device=self.device)[: int(self.n_items * self.drop_ratio)]] = True
+            keep = ~(du[u] | di[i])
+        else:  # ED / RW
+            keep = torch.zeros(n_inter, dtype=torch.bool, device=self.device)
+            keep[torch.randperm(n_inter, device=self.device)[: int(n_inter * (1 - self.drop_ratio))]] = True
+        graph = GraphHandle.from_interactions(u, i, self.n_users, self.n_items, device=self.device, keep=keep)
         return graph, None
 
     def forward(self, graph=None):
@@ -549,5 +577,119 @@ class XSimGCL(SimGCL):
         return mf_loss, self.reg_weight * reg_loss, self.cl_rate * (user_cl_loss + item_cl_loss)
 
 
+class NCL(GeneralGraphRecommender):
+    """general_recommender/ncl.py:20-219.  Propagation = LightGCN's with every layer kept (:93-104); the structure
+    contrast (:137-165) is SGL's InfoNCE form on two layers of the same propagation, one ``ops.info_nce`` call per side;
+    the prototype contrast (:106-135) takes its denominators from the fused logsumexp-GEMM (``ops.lse_rows``); the
+    prototypes come from k-means on the device (``ops.kmeans``) where the reference calls faiss (:66-81).
+    ``calculate_loss`` returns the reference's 3-tuple (BPR + reg, ssl, proto): NCLTrainer sums it, without the last
+    term during the first ``warm_up_step`` epochs, and calls ``e_step`` every ``m_step`` epochs (trainer.py:35-40,130-133)."""
+
+    graph_capturable = False  # e_step swaps the centroid tensors between epochs; the loss tuple is summed by the trainer
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        config = self.config
+        self.latent_dim = config["embedding_size"] or 64
+        self.n_layers = config["n_layers"] if config["n_layers"] is not None else 3
+        self.reg_weight = config["reg_weight"] if config["reg_weight"] is not None else 1e-4
+        self.ssl_temp = config["ssl_temp"] if config["ssl_temp"] is not None else 0.1
+        self.ssl_reg = config["ssl_reg"] if config["ssl_reg"] is not None else 1e-7
+        self.hyper_layers = config["hyper_layers"] if config["hyper_layers"] is not None else 1
+        self.alpha = config["alpha"] if config["alpha"] is not None else 1
+        self.proto_reg = config["proto_reg"] if config["proto_reg"] is not None else 8e-8
+        self.k = config["num_clusters"] if config["num_clusters"] is not None else 1000
+        self.m_step = config["m_step"] if config["m_step"] is not None else 1
+        self.warm_up_step = config["warm_up_step"] if config["warm_up_step"] is not None else 20
+        self.user_embedding = nn.Embedding(self.n_users, self.latent_dim)
+        self.item_embedding = nn.Embedding(self.n_items, self.latent_dim)
+        self.gcn_conv = ops.LightGCNConv(dim=self.latent_dim)
+        self.mf_loss = BPRLoss()
+        self.reg_loss = EmbLoss()
+        self.restore_user_e = None
+        self.restore_item_e = None
+        self.apply(xavier_uniform_initialization)
+        self.other_parameter_name = ["restore_user_e", "restore_item_e"]
+        self.user_centroids = self.user_2cluster = self.item_centroids = self.item_2cluster = None
+        self.to(self.device)
+
+    def e_step(self):
+        self.user_centroids, self.user_2cluster = self.run_kmeans(self.user_embedding.weight.detach())
+        self.item_centroids, self.item_2cluster = self.run_kmeans(self.item_embedding.weight.detach())
+
+    def run_kmeans(self, x):
+        """ncl.py:66-81: k clusters of the rows of x; centroids L2-normalized, node -> cluster as int64."""
+        cent, assign = ops.kmeans(x.contiguous(), self.k)
+        return F.normalize(cent, p=2, dim=1), assign
+
+    def get_ego_embeddings(self):
+        return torch.cat([self.user_embedding.weight, self.item_embedding.weight], dim=0)
+
+    def forward(self):
+        all_embeddings = self.get_ego_embeddings()
+        embeddings_list = [all_embeddings]
+        for _ in range(max(self.n_layers, self.hyper_layers * 2)):
+            all_embeddings = self.gcn_conv(all_embeddings, self.graph, None)
+            embeddings_list.append(all_embeddings)
+        mean = torch.mean(torch.stack(embeddings_list[: self.n_layers + 1], dim=1), dim=1)
+        user_all, item_all = torch.split(mean, [self.n_users, self.n_items])
+        return user_all, item_all, embeddings_list
+
+    def _proto_side(self, table, idx, centroids, node2cluster):
+        a = F.normalize(_rows(table, idx))
+        pos = (a * centroids[node2cluster[idx]]).sum(dim=1) / self.ssl_temp
+        if a.shape[1] <= 128:  # log sum_j exp(<a, c_j> / T) without the [B, k] matrix; unit rows: shift = 1 / T
+            lse = ops.lse_rows(a, centroids, 1.0 / self.ssl_temp, 1.0 / self.ssl_temp)
+        else:
+            lse = torch.logsumexp(a.matmul(centroids.T) / self.ssl_temp, dim=1)
+        return (lse - pos).sum()  # = -sum log(exp(pos) / sum_j exp(.))
+
+    def ProtoNCE_loss(self, node_embedding, user, item):
+        if self.user_centroids is None:
+            raise RuntimeError("NCL.e_step() has not run: no prototypes yet (NCLTrainer calls it before the first epoch)")
+        user_all, item_all = torch.split(node_embedding, [self.n_users, self.n_items])
+        loss_u = self._proto_side(user_all, user, self.user_centroids, self.user_2cluster)
+        loss_i = self._proto_side(item_all, item, self.item_centroids, self.item_2cluster)
+        return self.proto_reg * (loss_u + loss_i)
+
+    def ssl_layer_loss(self, current_embedding, previous_embedding, user, item):
+        cu, ci = torch.split(current_embedding, [self.n_users, self.n_items])
+        pu, pi = torch.split(previous_embedding, [self.n_users, self.n_items])
+        if cu.shape[1] <= 128:  # normalize, positives, denominators over ALL previous rows, and the gradients: one call per side
+            loss_u = ops.info_nce(cu, pu, user, self.ssl_temp)
+            loss_i = ops.info_nce(ci, pi, item, self.ssl_temp)
+        else:
+            loss_u = SGL._info_nce(cu[user], pu[user], pu, self.ssl_temp)
+            loss_i = SGL._info_nce(ci[item], pi[item], pi, self.ssl_temp)
+        return self.ssl_reg * (loss_u + self.alpha * loss_i)
+
+    def calculate_loss(self, interaction):
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        user, pos_item, neg_item = interaction[self.USER_ID], interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]
+        user_all, item_all, embeddings_list = self.forward()
+        center_embedding = embeddings_list[0]
+        context_embedding = embeddings_list[self.hyper_layers * 2]
+        ssl_loss = self.ssl_layer_loss(context_embedding, center_embedding, user, pos_item)
+        proto_loss = self.ProtoNCE_loss(center_embedding, user, pos_item)
+        u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
+        mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
+        reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
+                                 _rows(self.item_embedding.weight, neg_item))
+        return mf_loss + self.reg_weight * reg_loss, ssl_loss, proto_loss
+
+    def predict(self, interaction):
+        user_all, item_all, _ = self.forward()
+        return torch.mul(user_all[interaction[self.USER_ID]], item_all[interaction[self.ITEM_ID]]).sum(dim=1)
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID]
+        if self.restore_user_e is None or self.restore_item_e is None:
+            with torch.no_grad():
+                self.restore_user_e, self.restore_item_e, _ = self.forward()
+        return ops.score(ops.gather_rows(self.restore_user_e, user), self.restore_item_e).view(-1)
+
+
 NGCF.full_sort_topk = _full_sort_topk
 SGL.full_sort_topk = _full_sort_topk
+NCL.full_sort_topk = _full_sort_topk

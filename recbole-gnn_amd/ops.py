@@ -558,3 +558,71 @@ def info_nce(t1, t2, idx, tau):
     if t1.shape != t2.shape:
         raise ValueError(f"the two views differ in shape: {tuple(t1.shape)} vs {tuple(t2.shape)}")
     return _InfoNCE.apply(t1, t2, idx, float(tau))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# k-means on the device (NCL's prototypes, ncl.py:60-81: faiss.Kmeans(d, k, gpu=True).train(x) + index.search(x, 1))
+# ---------------------------------------------------------------------------------------------------------------------
+def nearest_centroid(x, centroids):
+    """argmin_j ||x_i - c_j||^2 for every row of x, without the [n, k] distance matrix: it is argmax_j of
+    <x_i, c_j> - ||c_j||^2 / 2, i.e. the fused scoring + top-1 kernel (rbg_full_sort_topk_f32, exact-fp32 MFMA) on operands
+    widened by one column; slot 0 of the item side is that kernel's masked [PAD] item, so the centroids sit at 1..k."""
+    _check_dense(x, "x")
+    _check_dense(centroids, "centroids")
+    n, d = x.shape
+    k = centroids.shape[0]
+    dp = (d + 4) // 4 * 4
+    xa = torch.zeros((n, dp), dtype=torch.float32, device=x.device)
+    xa[:, :d] = x
+    xa[:, d] = 1.0
+    ca = torch.zeros((k + 1, dp), dtype=torch.float32, device=x.device)
+    ca[1:, :d] = centroids
+    ca[1:, d] = -0.5 * (centroids * centroids).sum(dim=1)
+    out = torch.empty(n, dtype=torch.int64, device=x.device)
+    step = 1 << 20
+    for s0 in range(0, n, step):
+        users = torch.arange(s0, min(n, s0 + step), device=x.device)
+        _, idx = full_sort_topk(None, xa, ca, users, 1)
+        out[s0:s0 + users.shape[0]] = idx[:, 0] - 1
+    return out
+
+
+def kmeans(x, k, niter=25, seed=1234, max_points_per_centroid=256, init=None):
+    """Lloyd's k-means as faiss.Kmeans runs it [faiss: third-party, un-pinned, not under the reference tree]: centroids
+    start as k distinct random training points (seed 1234), ``niter`` = 25 rounds of {assign every point to its nearest
+    centroid (L2); centroid = mean of its points}, an empty cluster is re-seeded by splitting a populated one (its
+    centroid copied with a +-1/1024 relative perturbation, faiss ``split_clusters``), and at most
+    ``max_points_per_centroid * k`` randomly chosen points train.  Returns (centroids [k, d], assignment [n] of ALL points).
+    The assignment step runs on the fused MFMA scoring + top-1 kernel; sums / counts are index_add_ / bincount."""
+    _check_dense(x, "x")
+    n, d = x.shape
+    if n < k:
+        raise ValueError(f"k-means needs at least as many points ({n}) as clusters ({k})")
+    gen = torch.Generator(device=x.device).manual_seed(int(seed))
+    train = x
+    if n > max_points_per_centroid * k:
+        train = x.index_select(0, torch.randperm(n, generator=gen, device=x.device)[: max_points_per_centroid * k])
+    m = train.shape[0]
+    if init is not None:  # caller-supplied starting centroids (tests: the same start as the CPU restatement)
+        cent = init.to(device=x.device, dtype=torch.float32).clone()
+    else:
+        cent = train.index_select(0, torch.randperm(m, generator=gen, device=x.device)[:k]).clone()
+    gen_cpu = torch.Generator().manual_seed(int(seed))
+    eps = 1.0 / 1024.0
+    sign = torch.where(torch.arange(d, device=x.device) % 2 == 0, 1.0 + eps, 1.0 - eps)
+    for _ in range(niter):
+        assign = nearest_centroid(train, cent)
+        cnt = torch.bincount(assign, minlength=k).to(torch.float32)
+        sums = torch.zeros((k, d), dtype=torch.float32, device=x.device).index_add_(0, assign, train)
+        cent = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1.0)[:, None], cent)
+        empty = torch.nonzero(cnt == 0).flatten()
+        if empty.numel():  # rare: handled on the host like faiss does (data-dependent control flow)
+            cnt_h = cnt.cpu().clone()
+            for ci in empty.tolist():
+                p = (cnt_h - 1.0).clamp(min=0.0)
+                cj = int(torch.multinomial(p / p.sum(), 1, generator=gen_cpu)) if float(p.sum()) > 0 else int(cnt_h.argmax())
+                cent[ci] = cent[cj] * sign
+                cent[cj] = cent[cj] * (2.0 - sign)
+                cnt_h[ci] = cnt_h[cj] / 2
+                cnt_h[cj] -= cnt_h[ci]
+    return cent, nearest_centroid(x, cent)

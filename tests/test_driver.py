@@ -50,11 +50,15 @@ def test_metrics_known_answers(rbg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL"])
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL", "NCL"])
 def test_one_epoch_runs(rbg, cuda, ref_inter, name):
     """tests/test_model.py:27-37 of the reference: build, train one epoch, evaluate — and the values are finite."""
     uid, iid, nu, ni = ref_inter
     cfg = {"device": str(cuda), "n_layers": 2, "reg_weight": 1e-5, "hidden_size_list": [64, 64]}
+    if name == "NCL":  # the shipped 1000 clusters exceed this dataset's node counts; no warm-up so the prototype term trains
+        cfg.update(num_clusters=8, warm_up_step=0, m_step=1)
+    if name == "NGCF":
+        cfg.update(node_dropout=0.1)  # the edge-dropout path (ngcf.py:74-90) trains too
     out = rbg.driver.run(getattr(rbg, name), uid, iid, nu, ni, config=cfg, epochs=1)
     assert np.isfinite(out["train_loss"][0])
     for split in ("valid", "test"):
@@ -82,3 +86,39 @@ def test_training_improves_ranking(rbg, cuda, ref_inter):
     rbg.driver.fit(model2, tr_u, tr_i, epochs=30, lr=5e-3, batch_size=1024, fused=False)
     after2 = rbg.driver.evaluate(model2, va_u, va_i, k=10)
     assert abs(after2["recall@10"] - after["recall@10"]) < 0.03
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["SimGCL", "XSimGCL"])
+def test_fit_trains_the_subclass_objective(rbg, cuda, ref_inter, name):
+    """driver.fit on a LightGCN SUBCLASS (SimGCL / XSimGCL: contrastive terms, perturbed passes, a layer mean without E0)
+    must train that model's own calculate_loss — not LightGCN's fused BPR step, and not through a HIP-graph capture (their
+    loss calls torch.unique).  One epoch through fit() equals the eager zero_grad / calculate_loss / backward / Adam loop
+    on a twin model with the same seeds."""
+    uid, iid, nu, ni = ref_inter
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    cfg = {"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2, "require_pow": True}
+    torch.manual_seed(1)
+    a = getattr(rbg, name)(cfg, ds)
+    torch.manual_seed(1)
+    b = getattr(rbg, name)(cfg, ds)
+    assert not rbg.train.fused_step_applies(a) and not a.graph_capturable
+    with pytest.raises(TypeError):
+        rbg.FusedBPRAdam(a)
+    torch.manual_seed(77)
+    la = rbg.driver.fit(a, uid, iid, epochs=1, lr=1e-3, batch_size=512, seed=5)
+    torch.manual_seed(77)
+    opt = torch.optim.Adam(b.parameters(), lr=1e-3)
+    b.train()
+    total = 0.0
+    for batch in rbg.driver.BPRSampler(uid, iid, ni, batch_size=512, seed=5):
+        batch = {k: v.to(cuda) for k, v in batch.items()}
+        opt.zero_grad(set_to_none=True)
+        loss = b.calculate_loss(batch)
+        loss = sum(loss) if isinstance(loss, tuple) else loss
+        loss.backward()
+        opt.step()
+        total += float(loss)
+    assert abs(la[0] - total) <= 1e-4 * max(1.0, abs(total))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert float((pa - pb).abs().max()) <= 1e-6

@@ -419,6 +419,8 @@ def make_model(rbg, cls, cuda, golden, **cfg):
     config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3}
     if cls.__name__ == "NGCF":  # the mirror defaults to NGCF.yaml's 0.1; value parity is defined at 0
         config["message_dropout"] = 0.0
+    if cls.__name__ == "SGL":  # the reference's numpy sampling calls: the views are then reproducible from np.random.seed
+        config["device_sampling"] = False
     config.update(cfg)
     return cls(config, ds), ds
 
@@ -596,6 +598,12 @@ def test_sgl_model_views(rbg, cuda, golden):
         close(torch.cat(outs[1]), torch.cat([u_ref, i_ref]))
         s = model.full_sort_predict({"user_id": torch.tensor([1, 5], device=cuda)})
         assert s.shape == (2, ni)  # SGL returns the un-flattened matrix (sgl.py:240)
+        # ... whose values are the FULL graph's propagation (sgl.py:236-237: self.forward() without a view) scored as :240
+        full = lambda t: torch.from_numpy(C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], t.numpy()))  # noqa: E731
+        uf, itf = O.lightgcn_forward(uw, iw, full, 3)
+        close(s, O.full_sort_predict(uf, itf, [1, 5]).view(2, ni))
+        close(model.predict({"user_id": torch.tensor([1, 5], device=cuda), "item_id": torch.tensor([2, 7], device=cuda)}),
+              (uf[[1, 5]] * itf[[2, 7]]).sum(1))
 
 
 def test_sgl_training_loss_and_gradients(rbg, cuda, golden):
@@ -835,6 +843,121 @@ def test_info_nce_zero_row(rbg, cuda):
     # calc_ssl_loss used (a64, b64) for both halves: each table's gradient there is twice one half's... divided by 2 above
     close(g1.grad, a64.grad.float(), tol=2e-5)
     close(g2.grad, b64.grad.float(), tol=2e-5)
+
+
+def test_sgl_device_sampling(rbg, cuda, golden):
+    """SGL views sampled on the GPU (device_sampling, the default): a view built from device-resident interactions and a
+    device mask equals the host-built view of the same mask bit for bit; ED keeps exactly int(E (1 - ratio)) interactions
+    (sgl.py:107-109), ND drops whole nodes (sgl.py:97-106), successive draws differ."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    uid, iid = g["uid"], g["iid"]
+    e = len(uid)
+    u_dev, i_dev = torch.from_numpy(uid.astype(np.int64)).to(cuda), torch.from_numpy(iid.astype(np.int64)).to(cuda)
+    keep = torch.rand(e, generator=torch.Generator().manual_seed(2)) < 0.8
+    a = rbg.GraphHandle.from_interactions(u_dev, i_dev, nu, ni, device=cuda, keep=keep.to(cuda))
+    b = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda, keep=keep.numpy())
+    for x, y in zip(a.export_csr(), b.export_csr()):
+        assert np.array_equal(x, y)
+    full = rbg.GraphHandle.from_interactions(u_dev, i_dev, nu, ni, device=cuda)
+    for x, y in zip(full.export_csr(), (g["rowptr"], g["col"], g["val"])):
+        assert np.array_equal(x, y)
+    model, _ = make_model(rbg, rbg.SGL, cuda, golden, enable_sparse=True, type="ED", drop_ratio=0.1, device_sampling=True)
+    v1, _ = model.random_graph_augment()
+    v2, _ = model.random_graph_augment()
+    assert v1.nnz == v2.nnz == 2 * int(e * (1 - 0.1))
+    c1, c2 = v1.export_csr(), v2.export_csr()
+    assert not (np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1]))
+    rp, col, val = c1
+    rows = np.repeat(np.arange(nu + ni), np.diff(rp))
+    deg = np.diff(rp).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        dis = np.where(deg > 0, np.float32(1.0) / np.sqrt(deg), np.float32(0.0)).astype(np.float32)
+    assert np.array_equal(val, (dis[rows] * np.float32(1.0)) * dis[col])  # re-normalized on the view's own degrees
+    full_pairs = set(zip(g["col"].tolist(), np.repeat(np.arange(nu + ni), np.diff(g["rowptr"])).tolist()))
+    assert set(zip(col.tolist(), rows.tolist())) <= full_pairs
+    model_nd, _ = make_model(rbg, rbg.SGL, cuda, golden, enable_sparse=True, type="ND", drop_ratio=0.2, device_sampling=True)
+    vn, _ = model_nd.random_graph_augment()
+    d_nd = np.diff(vn.export_csr()[0])
+    d_full = np.diff(g["rowptr"])
+    dropped_u = int(((d_nd[:nu] == 0) & (d_full[:nu] > 0)).sum())
+    assert dropped_u >= int(nu * 0.2) * 0.5  # the sampled users (those with interactions) lost every edge
+    model.train()  # sgl.py:82-91: train() re-samples both views
+    u1, i1 = model.forward(model.sub_graph1)
+    assert torch.isfinite(u1).all() and u1.shape == (nu, 64)
+
+
+# ---- NCL (ncl.py) -------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,d,k", [(1472, 64, 40), (5000, 64, 100), (700, 16, 7), (3000, 128, 33)])
+def test_device_kmeans(rbg, cuda, n, d, k):
+    """ops.nearest_centroid (fused MFMA scoring + top-1, no [n, k] matrix) against the float64 distance matrix, and
+    ops.kmeans against Lloyd's algorithm in float64 from the same start (the algorithm faiss.Kmeans runs, ncl.py:69-74)."""
+    gen = torch.Generator().manual_seed(n + k)
+    centers = torch.randn(k, d, generator=gen) * 3.0  # clustered data: a clear optimum, few near-ties
+    x = (centers[torch.randint(0, k, (n,), generator=gen)] + torch.randn(n, d, generator=gen)).to(cuda)
+    c0 = x[torch.randperm(n, generator=gen)[:k].to(cuda)].clone()
+    a = rbg.ops.nearest_centroid(x, c0).cpu().numpy()
+    x64, c64 = x.double().cpu().numpy(), c0.double().cpu().numpy()
+    d2 = (x64 * x64).sum(1)[:, None] - 2 * x64 @ c64.T + (c64 * c64).sum(1)[None, :]
+    best = d2.min(1)
+    assert np.all(d2[np.arange(n), a] <= best + 1e-4 * np.maximum(1.0, np.abs(best)))  # nearest up to fp32 near-ties
+    assert np.mean(a == d2.argmin(1)) > 0.999
+    cent, assign = rbg.ops.kmeans(x, k, init=c0)
+    c_ref, a_ref, obj = O.kmeans_lloyd(x64, c64)
+    assert all(b <= a_ + 1e-6 * a_ for a_, b in zip(obj, obj[1:]))  # Lloyd's objective never increases
+    assert np.mean(assign.cpu().numpy() == a_ref) > 0.995
+    close(cent, c_ref.astype(np.float32), tol=5e-3)
+    cent2, assign2 = rbg.ops.kmeans(x, k)  # random start (seed 1234): deterministic, every point assigned to its nearest centroid
+    cent3, assign3 = rbg.ops.kmeans(x, k)
+    assert torch.equal(cent2, cent3) and torch.equal(assign2, assign3)
+    assert int(assign2.min()) >= 0 and int(assign2.max()) < k
+    with pytest.raises(ValueError):
+        rbg.ops.kmeans(x[: k - 1], k)
+
+
+def test_ncl_model(rbg, cuda, golden):
+    """NCL (ncl.py:93-184): forward with every layer kept, the 3-term loss (BPR + reg, structure contrast, prototype
+    contrast) and its gradients against torch autograd through the restated formulas, with the model's own prototypes."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    model, _ = make_model(rbg, rbg.NCL, cuda, golden, enable_sparse=True, num_clusters=16, ssl_reg=1e-3, proto_reg=1e-3, hyper_layers=1)
+    conv = lambda t: torch.from_numpy(C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], t.detach().numpy()))  # noqa: E731
+    uw, iw = model.user_embedding.weight.detach().cpu(), model.item_embedding.weight.detach().cpu()
+    u_ref, i_ref, embs = O.ncl_forward(uw, iw, conv, 3, 1)
+    with torch.no_grad():
+        u, i, lst = model.forward()
+    assert len(lst) == 4
+    close(torch.cat([u, i]), torch.cat([u_ref, i_ref]))
+    close(lst[2], embs[2])
+    with pytest.raises(RuntimeError):
+        model.calculate_loss({"user_id": torch.tensor([1], device=cuda), "item_id": torch.tensor([1], device=cuda),
+                              "neg_item_id": torch.tensor([2], device=cuda)})
+    model.e_step()
+    assert model.user_centroids.shape == (16, 64) and model.item_2cluster.shape == (ni,)
+    close(model.user_centroids.norm(dim=1), torch.ones(16))
+    batch = {"user_id": torch.tensor([1, 2, 3, 9, 2]), "item_id": torch.tensor([1, 4, 3, 7, 8]), "neg_item_id": torch.tensor([5, 6, 2, 11, 30])}
+    model.train()
+    losses = model.calculate_loss({k_: v.to(cuda) for k_, v in batch.items()})
+    assert isinstance(losses, tuple) and len(losses) == 3
+    sum(losses).backward()
+    ei, ew = O.get_norm_adj_mat(g["uid"], g["iid"], nu, ni, enable_sparse=False)
+    ul, il = uw.clone().requires_grad_(True), iw.clone().requires_grad_(True)
+    ur, ir, er = O.ncl_forward(ul, il, lambda t: O.conv_dense(t, ei, ew), 3, 1)
+    ue, pe, ne = ur[batch["user_id"]], ir[batch["item_id"]], ir[batch["neg_item_id"]]
+    mf = -torch.log(1e-10 + torch.sigmoid((ue * pe).sum(1) - (ue * ne).sum(1))).mean()
+    reg = (ul[batch["user_id"]].norm(p=2) + il[batch["item_id"]].norm(p=2) + il[batch["neg_item_id"]].norm(p=2)) / 5
+    ssl = O.ncl_ssl_layer_loss(er[2], er[0], nu, batch["user_id"], batch["item_id"], model.ssl_temp, model.ssl_reg, model.alpha)
+    proto = O.ncl_proto_nce_loss(er[0], nu, batch["user_id"], batch["item_id"], model.user_centroids.cpu(), model.user_2cluster.cpu(),
+                                 model.item_centroids.cpu(), model.item_2cluster.cpu(), model.ssl_temp, model.proto_reg)
+    ref = (mf + model.reg_weight * reg, ssl, proto)
+    for got, want in zip(losses, ref):
+        close(got.detach().reshape(()), want.detach().reshape(()), tol=2e-5)
+    sum(ref).backward()
+    close(model.user_embedding.weight.grad, ul.grad, tol=2e-5)
+    close(model.item_embedding.weight.grad, il.grad, tol=2e-5)
+    scores = model.full_sort_predict({"user_id": torch.tensor([3, 4], device=cuda)})
+    close(scores, O.full_sort_predict(u_ref, i_ref, [3, 4]))
 
 
 # ---- column-sweep launch plan (rbg_graph_attach_sweep) --------------------------------------------------------------------

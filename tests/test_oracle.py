@@ -205,3 +205,35 @@ def test_dropout_adj_keeps_weights_and_directions():
     full, part = O.conv_dense(x, ei, ew), O.conv_dense(x, ei2, ew2)
     dropped = full - part  # exactly the two dropped directed edges, at their original weights
     assert int((dropped != 0).sum()) == 2 and not torch.equal(part, part.T)
+
+
+def test_ncl_restatements_known_answers():
+    """ncl.py:93-104,106-165 restated: the forward keeps every layer; the structure contrast of identical views reduces to
+    -sum log softmax diag; Lloyd's objective never increases and converges on separated clusters."""
+    g = torch.Generator().manual_seed(0)
+    uw, iw = torch.randn(4, 8, generator=g), torch.randn(5, 8, generator=g)
+    ident = lambda t: t  # noqa: E731
+    u, i, embs = O.ncl_forward(uw, iw, ident, 3, 2)
+    assert len(embs) == 5 and torch.allclose(torch.cat([u, i]), torch.cat([uw, iw]))  # max(3, 2*2) propagations, mean of 0..3
+    x = torch.cat([uw, iw])
+    user, item = torch.tensor([0, 2]), torch.tensor([1, 3])
+    loss = O.ncl_ssl_layer_loss(x, x, 4, user, item, 0.5, 1.0, 2.0)
+    xn = torch.nn.functional.normalize(x[:4])
+    want_u = -(torch.log_softmax(xn[user] @ xn.T / 0.5, dim=1)[torch.arange(2), user]).sum()
+    xi = torch.nn.functional.normalize(x[4:])
+    want_i = -(torch.log_softmax(xi[item] @ xi.T / 0.5, dim=1)[torch.arange(2), item]).sum()
+    assert torch.allclose(loss, want_u + 2.0 * want_i, atol=1e-5)
+    cents = torch.nn.functional.normalize(torch.randn(3, 8, generator=g))
+    n2c_u, n2c_i = torch.tensor([0, 1, 2, 0]), torch.tensor([2, 2, 1, 0, 1])
+    proto = O.ncl_proto_nce_loss(x, 4, user, item, cents, n2c_u, cents, n2c_i, 0.5, 1.0)
+    want = -(torch.log_softmax(xn[user] @ cents.T / 0.5, dim=1)[torch.arange(2), n2c_u[user]]).sum() \
+        - (torch.log_softmax(xi[item] @ cents.T / 0.5, dim=1)[torch.arange(2), n2c_i[item]]).sum()
+    assert torch.allclose(proto, want, atol=1e-5)
+    rng = np.random.default_rng(0)
+    centers = rng.standard_normal((4, 6)) * 10
+    pts = centers[rng.integers(0, 4, 200)] + rng.standard_normal((200, 6)) * 0.1
+    c, a, obj = O.kmeans_lloyd(pts, pts[[0, 50, 100, 150]] + 0.0, niter=10)
+    assert all(b <= a_ + 1e-9 for a_, b in zip(obj, obj[1:]))
+    for j in range(4):
+        if (a == j).any():
+            assert np.allclose(c[j], pts[a == j].mean(0))
