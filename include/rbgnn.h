@@ -386,6 +386,42 @@ int rbg_shard_layer_begin(rbg_shard_ctx *ctx, const rbg_graph *g_int, const floa
 int rbg_shard_layer_end(rbg_shard_ctx *ctx, const rbg_graph *g_halo, const float *halo, float *Y, int d, void *main_stream,
                         void *comm_stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * multi-GPU: node-range shards with a per-layer halo exchange over RCCL (SURVEY.md §8(b),(e)).  One process (or thread)
+ * per GPU.  The reference has no distributed path; what is distributed is LightGCNConv (layers.py:13-20) and
+ * LightGCN.forward (lightgcn.py:70-81).  RCCL is bound at run time; without it these calls return RBG_EUNSUPPORTED.
+ * ------------------------------------------------------------------------------------------- */
+#define RBG_COMM_ID_BYTES 128
+typedef struct rbg_comm rbg_comm;
+typedef struct rbg_shard rbg_shard;
+
+/* Rank 0 draws the communicator id (ncclGetUniqueId) and hands the RBG_COMM_ID_BYTES bytes to every rank by any channel the
+ * host program has (MPI, torch.distributed, a file); then every rank calls rbg_comm_create (collective: ncclCommInitRank). */
+int rbg_comm_unique_id(void *id);
+int rbg_comm_create(rbg_comm **out, int nranks, int rank, const void *id, int device);
+void rbg_comm_destroy(rbg_comm *comm);
+
+/* This rank's shard from its plan (HOST arrays; sharded.py::plan_from_csr / build_plans produce them): the interior block
+ * [n_owned x n_owned] (columns = local row indices) and the halo block [n_owned x n_halo] (columns = halo slots, grouped by
+ * owner rank, ascending global id inside a rank) of the rows it owns — rows [0, n_users_owned) are users — plus the local
+ * rows it packs for every peer (send_idx grouped by destination, send_counts [nranks]) and what it receives
+ * (recv_counts [nranks], summing to n_halo).  d_max sizes the exchange buffers. */
+int rbg_graph_create_sharded(rbg_shard **out, rbg_comm *comm, int64_t n_owned, int64_t n_users_owned, const int64_t *int_rowptr,
+                             const int32_t *int_col, const float *int_val, int64_t n_halo, const int64_t *halo_rowptr,
+                             const int32_t *halo_col, const float *halo_val, const int64_t *send_idx, const int64_t *send_counts,
+                             const int64_t *recv_counts, int d_max);
+void rbg_shard_destroy(rbg_shard *shard);
+
+/* One sharded layer, collective over the communicator: Y[owned] = Â[owned, :] X with X = this rank's owned rows [n_owned, d].
+ * The halo rows are packed and exchanged (grouped ncclSend / ncclRecv) on the shard's own high-priority stream while the
+ * interior product runs on `stream`; then Y += Â_halo X_halo.  Also the backward of itself (the global Â is symmetric). */
+int rbg_spmm_sharded_f32(rbg_shard *shard, const float *X, float *Y, int d, void *stream);
+
+/* lightgcn.py:70-81 over the shard: out_mean [n_owned, d] = mean(E_0 .. E_K) of the owned rows, K exchanges; the layer
+ * mean rides in the last halo product's epilogue.  layers: [K][n_owned][d] (E_1 .. E_{K-1} are kept there; the last slice
+ * is scratch).  1 <= K <= RBG_MAX_FUSED_LAYERS + 1. */
+int rbg_lightgcn_forward_sharded_f32(rbg_shard *shard, const float *E0, float *out_mean, float *layers, int d, int K, void *stream);
+
 /* out[t] = scale * (srcs[0][t] + srcs[1][t] + ...), added left to right: the layer mean of lightgcn.py:80-81 over
  * separately held layer outputs (the sharded propagation) in one launch.  n_srcs <= RBG_MAX_FUSED_LAYERS + 1. */
 int rbg_mean_f32(const float *const *srcs, int n_srcs, int64_t n_floats, float scale, float *out, void *stream);

@@ -63,6 +63,13 @@ SIGNATURES = {
     "rbg_shard_ctx_destroy": (None, [c_vp]),
     "rbg_shard_layer_begin": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_vp, c_vp]),
     "rbg_shard_layer_end": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "rbg_comm_unique_id": (c_int, [c_vp]),
+    "rbg_comm_create": (c_int, [P(c_vp), c_int, c_int, c_vp, c_int]),
+    "rbg_comm_destroy": (None, [c_vp]),
+    "rbg_graph_create_sharded": (c_int, [P(c_vp), c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
+    "rbg_shard_destroy": (None, [c_vp]),
+    "rbg_spmm_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    "rbg_lightgcn_forward_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "rbg_mean_f32": (c_int, [c_vp, c_int, c_i64, c_f32, c_vp, c_vp]),
     "rbg_gather_rows_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp]),
     "rbg_bignn_layer_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),

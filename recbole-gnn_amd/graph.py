@@ -228,14 +228,15 @@ class GraphHandle:
 
     def device_csr(self):
         """(rowptr int32 [n_rows+1], col int32 [nnz], val fp32 [nnz]) as torch tensors that ALIAS the handle's HBM arrays
-        (no copy; read-only by contract; they keep this handle alive)."""
+        (no copy; read-only BY CONTRACT — torch has no read-only tensors, so nothing stops a caller from breaking the graph by
+        writing to them; they keep this handle alive)."""
         ptrs = [c_vp(), c_vp(), c_vp()]
         check(lib.rbg_graph_device_arrays(self.ptr, *[ctypes.byref(q) for q in ptrs]))
         handle = self
 
         class _View:  # the CUDA array interface: torch wraps the memory without copying it
             def __init__(self, ptr, n, typestr):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr or 0, True), "version": 2}
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr or 0, False), "version": 2}
                 self._owner = handle
 
         out = []

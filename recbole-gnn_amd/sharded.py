@@ -554,3 +554,72 @@ class _ShardedLightGCN(torch.autograd.Function):
 def sharded_lightgcn_forward(prop, e0, n_layers):
     """Differentiable mean(E_0..E_K) of this rank's rows; e0 = the rank's rows of the embedding tables (users first)."""
     return _ShardedLightGCN.apply(e0, prop, n_layers)
+
+
+# ---- the same path behind the C ABI (no torch.distributed): rbg_comm_* / rbg_graph_create_sharded / rbg_*_sharded_f32 ------------
+
+def comm_unique_id():
+    """128 bytes rank 0 draws (ncclGetUniqueId inside the library) and passes to every rank by whatever channel the host
+    program has; RCCL is bound at run time by librbgnn.so."""
+    import ctypes
+    from . import _lib
+    buf = ctypes.create_string_buffer(128)
+    _lib.check(_lib.lib.rbg_comm_unique_id(buf))
+    return buf.raw
+
+
+class RcclShard:
+    """A rank's shard driven entirely through the C ABI: the library owns the RCCL communicator, the exchange buffers, the
+    comm stream and the interior / halo graph handles; a layer is ONE host call (rbg_spmm_sharded_f32), a propagation ONE
+    (rbg_lightgcn_forward_sharded_f32) — what a host program without torch.distributed binds."""
+
+    def __init__(self, plan, comm_id, device, nranks=None, rank=None, d_max=128):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        lib, vp = _lib.lib, _lib.c_vp
+        self.plan = plan
+        self.device = torch.device(device)
+        nranks = plan.world if nranks is None else nranks
+        rank = plan.rank if rank is None else rank
+        self._comm, self._shard = vp(), vp()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.rbg_comm_create(ctypes.byref(self._comm), nranks, rank, comm_id, self.device.index or 0))
+            a = lambda x, dt: np.ascontiguousarray(x, dtype=dt)  # noqa: E731
+            ir, ic, iv = a(plan.int_csr[0], np.int64), a(plan.int_csr[1], np.int32), a(plan.int_csr[2], np.float32)
+            hr, hc, hv = a(plan.halo_csr[0], np.int64), a(plan.halo_csr[1], np.int32), a(plan.halo_csr[2], np.float32)
+            si, sc, rc = a(plan.send_idx, np.int64), a(plan.send_counts, np.int64), a(plan.recv_counts, np.int64)
+            p = lambda x: vp(x.ctypes.data)  # noqa: E731
+            _lib.check(lib.rbg_graph_create_sharded(ctypes.byref(self._shard), self._comm, plan.n_owned, plan.n_users_owned, p(ir), p(ic),
+                                                    p(iv), plan.n_halo, p(hr), p(hc), p(hv), p(si), p(sc), p(rc), int(d_max)))
+
+    def _stream(self):
+        return self._lib.c_vp(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def spmm(self, x, out=None):
+        out = torch.empty_like(x) if out is None else out
+        self._lib.check(self._lib.lib.rbg_spmm_sharded_f32(self._shard, self._lib.c_vp(x.data_ptr()), self._lib.c_vp(out.data_ptr()),
+                                                           x.shape[1], self._stream()))
+        return out
+
+    def forward(self, e0, n_layers, out=None):
+        out = torch.empty_like(e0) if out is None else out
+        layers = torch.empty((n_layers,) + tuple(e0.shape), dtype=e0.dtype, device=e0.device)
+        self._lib.check(self._lib.lib.rbg_lightgcn_forward_sharded_f32(self._shard, self._lib.c_vp(e0.data_ptr()), self._lib.c_vp(out.data_ptr()),
+                                                                       self._lib.c_vp(layers.data_ptr()), e0.shape[1], n_layers,
+                                                                       self._stream()))
+        self._layers = layers  # stream-ordered use: keep the buffer alive until the next call
+        return out
+
+    def close(self):
+        if getattr(self, "_shard", None):
+            torch.cuda.synchronize(self.device)
+            self._lib.lib.rbg_shard_destroy(self._shard)
+            self._lib.lib.rbg_comm_destroy(self._comm)
+            self._shard = self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -903,11 +903,20 @@ def test_device_kmeans(rbg, cuda, n, d, k):
     best = d2.min(1)
     assert np.all(d2[np.arange(n), a] <= best + 1e-4 * np.maximum(1.0, np.abs(best)))  # nearest up to fp32 near-ties
     assert np.mean(a == d2.argmin(1)) > 0.999
+    # one round from the same start is the same round (up to fp32 near-ties in the assignment)
+    cent1, _ = rbg.ops.kmeans(x, k, init=c0, niter=1)
+    c_ref1, _, _ = O.kmeans_lloyd(x64, c64, niter=1)
+    close(cent1, c_ref1.astype(np.float32), tol=2e-3)
+    # 25 rounds: trajectories may part at a near-tie, so the runs are compared by what k-means optimises
     cent, assign = rbg.ops.kmeans(x, k, init=c0)
     c_ref, a_ref, obj = O.kmeans_lloyd(x64, c64)
     assert all(b <= a_ + 1e-6 * a_ for a_, b in zip(obj, obj[1:]))  # Lloyd's objective never increases
-    assert np.mean(assign.cpu().numpy() == a_ref) > 0.995
-    close(cent, c_ref.astype(np.float32), tol=5e-3)
+    cd, ad = cent.double().cpu().numpy(), assign.cpu().numpy()
+    obj_dev = float(((x64 - cd[ad]) ** 2).sum())
+    obj_ref = float(((x64 - c_ref[a_ref]) ** 2).sum())
+    assert obj_dev <= obj[0] and abs(obj_dev - obj_ref) <= 0.05 * obj_ref, (obj_dev, obj_ref, obj[0])
+    d2f = (x64 * x64).sum(1)[:, None] - 2 * x64 @ cd.T + (cd * cd).sum(1)[None, :]
+    assert np.mean(ad == d2f.argmin(1)) > 0.999  # the returned assignment is the nearest-centroid assignment
     cent2, assign2 = rbg.ops.kmeans(x, k)  # random start (seed 1234): deterministic, every point assigned to its nearest centroid
     cent3, assign3 = rbg.ops.kmeans(x, k)
     assert torch.equal(cent2, cent3) and torch.equal(assign2, assign3)

@@ -277,3 +277,67 @@ def test_spmm_mean_epilogue(rbg, cuda, ref_inter):
         assert float((got - ref).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
         got = be.spmm_mean(h, x, None, [e0], torch.empty_like(x))
         assert float((got - (e0 + ax) / 2.0).abs().max()) <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
+def _cabi_world1_worker(uid, iid, nu, ni, k_layers, d, out_q):
+    """The C-ABI multi-GPU path (rbg_comm_create / rbg_graph_create_sharded / rbg_spmm_sharded_f32 /
+    rbg_lightgcn_forward_sharded_f32) on one GPU: a 1-rank communicator whose plan exchanges every third row with itself
+    (grouped ncclSend / ncclRecv to the own rank), so pack, exchange on the comm stream, interior and halo products and the
+    fused mean all run; the result must be the global forward.  In its own process: the communicator is process state."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import recbole_gnn_amd as rbg
+    sh = rbg.sharded
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    plan = sh.build_plans(uid, iid, nu, ni, 1)[0]
+    rp, col, val = (np.asarray(a) for a in plan.int_csr)
+    n = plan.n_owned
+    halo_nodes = np.arange(0, n, 3)
+    slot = -np.ones(n, dtype=np.int64)
+    slot[halo_nodes] = np.arange(len(halo_nodes))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    is_halo = slot[col] >= 0
+
+    def csr(mask, cols):
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, rows[mask] + 1, 1)
+        return np.cumsum(ptr), cols.astype(np.int32), val[mask].astype(np.float32)
+
+    plan.int_csr = csr(~is_halo, col[~is_halo])
+    plan.halo_csr = csr(is_halo, slot[col[is_halo]])
+    plan.halo_ids = halo_nodes
+    plan.send_idx = halo_nodes.copy()
+    plan.send_counts = np.array([len(halo_nodes)])
+    plan.recv_counts = np.array([len(halo_nodes)])
+    e0 = np.random.default_rng(4).standard_normal((n, d)).astype(np.float32)
+    rowptr, c2, v2 = C.build_norm_csr(uid, iid, nu, ni)
+    ref_layer = C.spmm(rowptr, c2, v2, e0)
+    ref = C.lightgcn_forward(rowptr, c2, v2, e0[:nu], e0[nu:], k_layers)
+    shard = sh.RcclShard(plan, sh.comm_unique_id(), dev, nranks=1, rank=0, d_max=d)
+    x = torch.from_numpy(e0).to(dev)
+    y = shard.spmm(x)
+    torch.cuda.synchronize()
+    err_layer = float(np.abs(y.cpu().numpy() - ref_layer).max())
+    errs = []
+    for _ in range(2):
+        got = shard.forward(x, k_layers)
+        torch.cuda.synchronize()
+        errs.append(float(np.abs(got.cpu().numpy() - ref).max()))
+    one = shard.forward(x, 1)
+    torch.cuda.synchronize()
+    err1 = float(np.abs(one.cpu().numpy() - (e0 + ref_layer) / 2).max())
+    shard.close()
+    out_q.put((err_layer, errs, err1))
+
+
+def test_c_abi_sharded_path_on_a_one_rank_communicator(ref_inter):
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_cabi_world1_worker, args=(uid, iid, nu, ni, 3, 64, q))
+    p.start()
+    err_layer, errs, err1 = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert err_layer <= 1e-5 and max(errs) <= 1e-5 and err1 <= 1e-5, (err_layer, errs, err1)
