@@ -914,12 +914,17 @@ def test_device_kmeans(rbg, cuda, n, d, k):
     cd, ad = cent.double().cpu().numpy(), assign.cpu().numpy()
     obj_dev = float(((x64 - cd[ad]) ** 2).sum())
     obj_ref = float(((x64 - c_ref[a_ref]) ** 2).sum())
-    assert obj_dev <= obj[0] and abs(obj_dev - obj_ref) <= 0.05 * obj_ref, (obj_dev, obj_ref, obj[0])
+    # not worse than the float64 run by more than 5 % (it may be better: an emptied cluster is re-seeded here, kept dead there)
+    assert obj_dev <= obj[0] and obj_dev <= 1.05 * obj_ref, (obj_dev, obj_ref, obj[0])
     d2f = (x64 * x64).sum(1)[:, None] - 2 * x64 @ cd.T + (cd * cd).sum(1)[None, :]
     assert np.mean(ad == d2f.argmin(1)) > 0.999  # the returned assignment is the nearest-centroid assignment
-    cent2, assign2 = rbg.ops.kmeans(x, k)  # random start (seed 1234): deterministic, every point assigned to its nearest centroid
+    # random start from the fixed seed 1234 (faiss's default): the same start every call; the centroid sums are float
+    # atomics (index_add_), so two runs agree to rounding, not bit for bit
+    cent2, assign2 = rbg.ops.kmeans(x, k)
     cent3, assign3 = rbg.ops.kmeans(x, k)
-    assert torch.equal(cent2, cent3) and torch.equal(assign2, assign3)
+    o2 = float(((x64 - cent2.double().cpu().numpy()[assign2.cpu().numpy()]) ** 2).sum())
+    o3 = float(((x64 - cent3.double().cpu().numpy()[assign3.cpu().numpy()]) ** 2).sum())
+    assert abs(o2 - o3) <= 0.02 * o2 and o2 <= obj[0]
     assert int(assign2.min()) >= 0 and int(assign2.max()) < k
     with pytest.raises(ValueError):
         rbg.ops.kmeans(x[: k - 1], k)
