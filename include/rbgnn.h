@@ -264,6 +264,12 @@ int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const fl
                        const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save,
                        int d_in, int d_out, uint32_t flags, float slope, void *stream);
 
+/* The dense half of that layer from a product P = ÂX [n_rows, d_in] (contiguous) the caller already holds — the sharded path
+ * forms P with rbg_spmm_sharded_f32 and finishes BiGNNConv (layers.py:55-57) [+ the NGCF tail] on its own rows. */
+int rbg_bignn_dense_f32(const float *P, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
+                        const float *b2, float *Y, int64_t ldy, int64_t n_rows, int d_in, int d_out, uint32_t flags, float slope,
+                        void *stream);
+
 /* Replaces the scoring GEMM of full_sort_predict
  *   recbole_gnn/model/general_recommender/lightgcn.py:131 (ngcf.py:147, sgl.py:240):
  *   scores = u_embeddings @ restore_item_e.T

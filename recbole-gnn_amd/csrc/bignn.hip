@@ -237,23 +237,29 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
 
 using namespace rbg;
 
-static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
+// g != NULL: P_save = ÂX first (n_rows from the graph); g == NULL: P_save already holds the product for n_rows rows.
+static int bignn_conv_impl(const rbg_graph *g, int64_t n_rows, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
                            const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm, const float *drop_mask,
                            int d_in, int d_out, uint32_t flags, float slope, void *stream) {
     clear_error();
-    if (!g) return fail(RBG_EINVAL, "graph is NULL");
-    if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
-    if (g->n_rows != g->n_cols) return fail(RBG_ESHAPE, "graph is not square");
+    if (g) {
+        if (g->device < 0) return fail(RBG_ENODEV, "operator called on a host graph (create it with device >= 0)");
+        if (g->n_rows != g->n_cols) return fail(RBG_ESHAPE, "graph is not square");
+        n_rows = g->n_rows;
+    }
+    if (n_rows < 0) return fail(RBG_ESHAPE, "n_rows = %lld", (long long)n_rows);
     if (d_in <= 0 || d_out <= 0 || ldx < d_in || ldy < d_out)
         return fail(RBG_ESHAPE, "d_in = %d, d_out = %d, ldx = %lld, ldy = %lld", d_in, d_out, (long long)ldx, (long long)ldy);
     if (d_out > 256) return fail(RBG_EUNSUPPORTED, "d_out = %d > 256", d_out);
-    if (g->n_rows == 0) return RBG_OK;
+    if (n_rows == 0) return RBG_OK;
     if (!X || !W1 || !b1 || !W2 || !b2 || !Y) return fail(RBG_EINVAL, "NULL pointer");
-    if (!P_save) return fail(RBG_EINVAL, "P_save is NULL: the caller provides the [N, d_in] buffer that receives ÂX");
-    int rc = set_device_for(g->device);
-    if (rc) return rc;
+    if (!P_save) return fail(RBG_EINVAL, "P_save is NULL: the caller provides the [N, d_in] buffer that receives / holds ÂX");
+    int rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = spmm_strided(g, X, ldx, P_save, d_in, d_in, 0, s))) return rc;
+    if (g) {
+        if ((rc = set_device_for(g->device))) return rc;
+        if ((rc = spmm_strided(g, X, ldx, P_save, d_in, d_in, 0, s))) return rc;
+    }
     BignnParams p{};
     p.P = P_save;
     p.X = X;
@@ -264,7 +270,7 @@ static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, cons
     p.b2 = b2;
     p.Y = Y;
     p.ldy = ldy;
-    p.n_rows = g->n_rows;
+    p.n_rows = n_rows;
     p.d_in = d_in;
     p.d_out = d_out;
     p.leaky_norm = (flags & RBG_BIGNN_LEAKY_NORM) ? 1 : 0;
@@ -283,13 +289,25 @@ static int bignn_conv_impl(const rbg_graph *g, const float *X, int64_t ldx, cons
 extern "C" int rbg_bignn_conv_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                                   const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, int d_in,
                                   int d_out, uint32_t flags, float slope, void *stream) {
-    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, nullptr, nullptr, d_in, d_out, flags, slope, stream);
+    if (!g) return (clear_error(), fail(RBG_EINVAL, "graph is NULL"));
+    return bignn_conv_impl(g, 0, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, nullptr, nullptr, d_in, d_out, flags, slope, stream);
 }
 
 extern "C" int rbg_bignn_layer_f32(const rbg_graph *g, const float *X, int64_t ldx, const float *W1, const float *b1,
                                    const float *W2, const float *b2, float *Y, int64_t ldy, float *P_save, float *inv_norm,
                                    const float *drop_mask, int d_in, int d_out, float slope, void *stream) {
     if (!inv_norm) return fail(RBG_EINVAL, "inv_norm is NULL: the caller provides the [N] buffer the backward needs");
-    return bignn_conv_impl(g, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, inv_norm, drop_mask, d_in, d_out, RBG_BIGNN_LEAKY_NORM, slope,
+    if (!g) return (clear_error(), fail(RBG_EINVAL, "graph is NULL"));
+    return bignn_conv_impl(g, 0, X, ldx, W1, b1, W2, b2, Y, ldy, P_save, inv_norm, drop_mask, d_in, d_out, RBG_BIGNN_LEAKY_NORM, slope,
                            stream);
+}
+
+// The dense half of the layer alone — lin1(P + X) + lin2(P ⊙ X) [+ LeakyReLU + L2-normalize] from a product P = ÂX the
+// caller already holds (layers.py:55-57 after :55's propagate): the node-range sharded path forms P with
+// rbg_spmm_sharded_f32 (halo exchange) and finishes the layer on its own rows here.
+extern "C" int rbg_bignn_dense_f32(const float *P, const float *X, int64_t ldx, const float *W1, const float *b1, const float *W2,
+                                   const float *b2, float *Y, int64_t ldy, int64_t n_rows, int d_in, int d_out, uint32_t flags,
+                                   float slope, void *stream) {
+    return bignn_conv_impl(nullptr, n_rows, X, ldx, W1, b1, W2, b2, Y, ldy, const_cast<float *>(P), nullptr, nullptr, d_in, d_out, flags,
+                           slope, stream);
 }

@@ -269,6 +269,18 @@ class HipBackend:
                                               arr, len(srcs), vp(out.data_ptr()), x.shape[1], self._stream(stream)))
         return out
 
+    def bignn_dense(self, p, x, w1, b1, w2, b2, out, leaky_norm=True, slope=0.2, stream=None):
+        """lin1(P + X) + lin2(P * X) [+ LeakyReLU + L2-normalize] on this rank's rows from its product P (rbg_bignn_dense_f32);
+        x / out may be column slices of wider row-major buffers."""
+        lib, vp = self._lib.lib, self._lib.c_vp
+        n, d_in = x.shape
+        self._lib.check(lib.rbg_bignn_dense_f32(vp(p.data_ptr()), vp(x.data_ptr()), x.stride(0) if n > 1 else d_in, vp(w1.data_ptr()),
+                                                vp(b1.data_ptr()), vp(w2.data_ptr()), vp(b2.data_ptr()), vp(out.data_ptr()),
+                                                out.stride(0) if n > 1 else out.shape[1], n, d_in, out.shape[1],
+                                                self._lib.BIGNN_LEAKY_NORM if leaky_norm else self._lib.BIGNN_CONV_ONLY, float(slope),
+                                                self._stream(stream)))
+        return out
+
     def gather_rows(self, src, idx, out=None, stream=None):
         if out is None:
             return self._ops.gather_rows(src, idx)
@@ -460,6 +472,26 @@ class ShardedPropagation:
             out.copy_(acc)
             return out
         return acc
+
+    def ngcf_forward(self, e0, layer_params, slope=0.2):
+        """NGCF.forward (ngcf.py:92-104, message_dropout = node_dropout = 0) for the owned rows: per layer the sharded
+        product P = (Â X)[owned] (one halo exchange), then BiGNNConv's dense half + LeakyReLU + L2-normalize on the rank's
+        own rows, written into its column block of the [n_owned, sum(d)] concat buffer.  layer_params: [(W1, b1, W2, b2)]."""
+        widths = [e0.shape[1]] + [w1.shape[0] for w1, _, _, _ in layer_params]
+        out = torch.empty((self.plan.n_owned, sum(widths)), dtype=e0.dtype, device=e0.device)
+        out[:, : widths[0]] = e0
+        off = 0
+        for (w1, b1, w2, b2), d_in, d_out in zip(layer_params, widths[:-1], widths[1:]):
+            x = out[:, off: off + d_in]
+            p = self.spmm(x.contiguous())
+            y = out[:, off + d_in: off + d_in + d_out]
+            if hasattr(self.backend, "bignn_dense"):
+                self.backend.bignn_dense(p, x, w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), y, True, slope)
+            else:  # injected CPU backend (tests)
+                z = (p + x) @ w1.T + b1 + (p * x) @ w2.T + b2
+                y.copy_(torch.nn.functional.normalize(torch.nn.functional.leaky_relu(z, slope), p=2, dim=1))
+            off += d_in
+        return out
 
     def backward(self, grad_out, n_layers):
         """dL/dE0 for the owned rows given dL/d(mean) for the owned rows.  The propagation is linear and the GLOBAL matrix

@@ -228,7 +228,15 @@ def _worker_round2(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
             gref = C.lightgcn_forward(rp, cc, vv, w[:nu], w[nu:], k_layers)  # M is symmetric: d<w, M e0>/d e0 = M w
             out[name] = (same, float(np.abs(mean.detach().cpu().numpy() - ref[plan.owned]).max()),
                          float(np.abs(x.grad.cpu().numpy() - gref[plan.owned]).max()))
-            if name == "full":
+            if name == "full":  # NGCF forward over the shard: sharded product + rbg_bignn_dense_f32 on the rank's rows
+                from oracle import oracle as O
+                g2 = torch.Generator().manual_seed(3)
+                params = [(torch.randn(d, d, generator=g2) * 0.2, torch.randn(d, generator=g2) * 0.1,
+                           torch.randn(d, d, generator=g2) * 0.2, torch.randn(d, generator=g2) * 0.1) for _ in range(2)]
+                conv = lambda t: torch.from_numpy(C.spmm(rp, cc, vv, t.numpy()))  # noqa: E731
+                u_ref, i_ref = O.ngcf_forward(torch.from_numpy(e0[:nu]), torch.from_numpy(e0[nu:]), conv, params)
+                got = prop.ngcf_forward(torch.from_numpy(e0[plan.owned]).to(dev), [tuple(t.to(dev) for t in p) for p in params])
+                out["ngcf"] = float((got.cpu() - torch.cat([u_ref, i_ref])[plan.owned]).abs().max())
                 m = mean.detach()
                 table = prop.gather_item_table(m, nu, ni)
                 users = torch.arange(min(7, plan.n_users_owned))
@@ -260,6 +268,7 @@ def test_two_ranks_device_planner_backward_view_scoring(ref_inter):
             same, err, gerr = out[name]
             assert same and err <= 1e-5 and gerr <= 1e-5, (rank, name, out[name])
         assert out["score"][0] <= 1e-5 and out["score"][1] <= 1e-5, (rank, out["score"])
+        assert out["ngcf"] <= 1e-5, (rank, out["ngcf"])
 
 
 def test_spmm_mean_epilogue(rbg, cuda, ref_inter):

@@ -220,6 +220,15 @@ def _worker2(rank, world, port, uid, iid, nu, ni, k_layers, out_q):
             gref = C.lightgcn_forward(rowptr, col, val, w[:nu], w[nu:], k_layers)
             out[name] = (float(np.abs(mean.detach().numpy() - ref[plan.owned]).max()),
                          float(np.abs(x.grad.numpy() - gref[plan.owned]).max()))
+            if name == "full":  # NGCF forward over the shard (ngcf.py:92-104): sharded product + local dense half per layer
+                from oracle import oracle as O
+                g2 = torch.Generator().manual_seed(3)
+                params = [(torch.randn(16, 16, generator=g2) * 0.3, torch.randn(16, generator=g2) * 0.1,
+                           torch.randn(16, 16, generator=g2) * 0.3, torch.randn(16, generator=g2) * 0.1) for _ in range(2)]
+                conv = lambda t: torch.from_numpy(C.spmm(rowptr, col, val, t.numpy()))  # noqa: E731
+                u_ref, i_ref = O.ngcf_forward(torch.from_numpy(e0[:nu]), torch.from_numpy(e0[nu:]), conv, params)
+                got = prop.ngcf_forward(torch.from_numpy(e0[plan.owned]), params)
+                out["ngcf"] = float((got - torch.cat([u_ref, i_ref])[plan.owned]).abs().max())
             if name == "full":  # sharded full-sort scoring: local users against the all-gathered item table
                 m = mean.detach()
                 table = prop.gather_item_table(m, nu, ni)
@@ -253,3 +262,4 @@ def test_two_process_gloo_backward_views_and_scoring(ref_inter):
         for name in ("full", "view"):
             assert out[name][0] <= 1e-5 and out[name][1] <= 1e-5, (rank, name, out[name])
         assert out["score"][0] <= 1e-5 and out["score"][1] <= 1e-4, (rank, out["score"])
+        assert out["ngcf"] <= 1e-5, (rank, out["ngcf"])
