@@ -325,6 +325,13 @@ int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n
                          const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight, float *grad_e0,
                          float *loss, void *stream);
 
+/* The same with require_pow = False (RecBole's EmbLoss default; lightgcn.py:103-108 passes self.require_pow):
+ * reg_weight * (||U0[user]||_F + ||I0[pos]||_F + ||I0[neg]||_F) / B — the 2-norm of each gathered [B, d] block.
+ * `workspace`: 3 floats of device scratch. */
+int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int64_t n_users, const int64_t *user,
+                               const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight, float *grad_e0,
+                               float *loss, float *workspace, void *stream);
+
 /* Replaces optimizer.step() of torch.optim.Adam (RecBole's default learner; no weight decay, no amsgrad) for the
  * two embedding tables in one pass.  grad / exp_avg / exp_avg_sq are [N,d]; step counts from 1. */
 int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,

@@ -109,6 +109,63 @@ __global__ __launch_bounds__(256) void emb_reg_grad_kernel(const float *__restri
     block_add_loss(loss_part, loss);
 }
 
+// EmbLoss(norm=2, require_pow=False): reg = (||U0[user]||_F + ||I0[pos]||_F + ||I0[neg]||_F) / B — torch.norm of each
+// gathered [B, d] block (RecBole's default; LightGCN.yaml switches to the squared form).  Pass 1: the three sums of squares.
+__global__ __launch_bounds__(256) void emb_sumsq_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
+                                                        const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
+                                                        const int64_t *__restrict__ neg, int64_t B, int d, float *__restrict__ sums) {
+    __shared__ float red[4][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int e = 0; e < kElemsPerWave; ++e) {
+        const int64_t w = ((int64_t)blockIdx.x * 4 + wave) * kElemsPerWave + e;
+        if (w >= 3 * B) break;
+        const int64_t b = w % B;
+        const int which = (int)(w / B);
+        const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
+        const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
+        float sq = 0.f;
+        for (int k = lane; k < d; k += 64) sq = fmaf(row[k], row[k], sq);
+        sq = wave_sum(sq);
+        part[0] += which == 0 ? sq : 0.f;
+        part[1] += which == 1 ? sq : 0.f;
+        part[2] += which == 2 ? sq : 0.f;
+    }
+    if (lane == 0) {
+        red[wave][0] = part[0];
+        red[wave][1] = part[1];
+        red[wave][2] = part[2];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
+    }
+}
+
+// Pass 2: d(reg_weight * ||E||_F / B)/d(row) = reg_weight / B * row / ||E||_F per occurrence (torch: zero at ||E|| = 0).
+__global__ __launch_bounds__(256) void emb_reg_grad_nopow_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
+                                                                 int64_t n_users, const int64_t *__restrict__ user,
+                                                                 const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                                 int64_t B, int d, float reg_weight, const float *__restrict__ sums,
+                                                                 float *__restrict__ grad_e0, float *__restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const float nrm[3] = {sqrtf(sums[0]), sqrtf(sums[1]), sqrtf(sums[2])};
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss, reg_weight * ((nrm[0] + nrm[1]) + nrm[2]) / (float)B);
+    for (int e = 0; e < kElemsPerWave; ++e) {
+        const int64_t w = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
+        if (w >= 3 * B) break;
+        const int64_t b = w % B;
+        const int which = (int)(w / B);
+        const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
+        const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
+        float *g = grad_e0 + (which == 0 ? id : n_users + id) * d;
+        const float nw = which == 0 ? nrm[0] : (which == 1 ? nrm[1] : nrm[2]);
+        const float s = nw > 0.f ? reg_weight / (float)B / nw : 0.f;
+        for (int k = lane; k < d; k += 64) atomicAdd(g + k, s * row[k]);
+    }
+}
+
 // torch.optim.Adam single step (foreach/fused semantics): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   Rows [0,n_users) of the [N,d] state live in the
 // user table, the rest in the item table.
@@ -158,6 +215,23 @@ int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n
     hipLaunchKernelGGL(emb_reg_grad_kernel, dim3((unsigned)((3 * B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0,
                        (hipStream_t)stream, user_emb,
                        item_emb, n_users, user, pos, neg, B, d, reg_weight, grad_e0, loss);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int64_t n_users, const int64_t *user,
+                               const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight, float *grad_e0,
+                               float *loss, float *workspace, void *stream) {
+    clear_error();
+    if (n_users < 0 || B < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (B == 0 || reg_weight == 0.f) return RBG_OK;
+    if (!user_emb || !item_emb || !user || !pos || !neg || !grad_e0 || !loss || !workspace) return fail(RBG_EINVAL, "NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    RBG_HIP(hipMemsetAsync(workspace, 0, 3 * sizeof(float), s));
+    const dim3 grid((unsigned)((3 * B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave)));
+    hipLaunchKernelGGL(emb_sumsq_kernel, grid, dim3(256), 0, s, user_emb, item_emb, user, pos, neg, B, d, workspace);
+    hipLaunchKernelGGL(emb_reg_grad_nopow_kernel, grid, dim3(256), 0, s, user_emb, item_emb, n_users, user, pos, neg, B, d, reg_weight,
+                       workspace, grad_e0, loss);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

@@ -153,7 +153,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
     models whose loss has data-dependent shapes — SimGCL, XSimGCL — always run eagerly)."""
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed)
     if fused is None:  # only the plain LightGCN objective: SimGCL / XSimGCL subclass it with different losses
-        fused = fused_step_applies(model) and model.require_pow
+        fused = fused_step_applies(model)
     stepper = FusedBPRAdam(model, lr=lr) if fused else None
     graphed = graphed and not fused and next(model.parameters()).is_cuda and getattr(model, "graph_capturable", True)
     opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr)

@@ -27,8 +27,6 @@ class FusedBPRAdam:
         # passes, a layer mean without E0 — none of which this hard-wired BPR + reg step computes
         if not fused_step_applies(model):
             raise TypeError("FusedBPRAdam drives a plain LightGCN model (its forward and calculate_loss, not a subclass's)")
-        if not model.require_pow:
-            raise NotImplementedError("the fused regulariser implements EmbLoss(require_pow=True) (LightGCN.yaml default)")
         self.model, self.lr, self.betas, self.eps = model, float(lr), betas, float(eps)
         self.step_count = 0
         dev = model.device
@@ -42,6 +40,7 @@ class FusedBPRAdam:
         self.exp_avg = torch.zeros((n, d), **f)
         self.exp_avg_sq = torch.zeros((n, d), **f)
         self.loss = torch.zeros((), **f)
+        self.reg_ws = torch.zeros(3, **f)  # the three block norms of EmbLoss(require_pow=False)
 
     @torch.no_grad()
     def step(self, interaction):
@@ -65,9 +64,15 @@ class FusedBPRAdam:
             arr = (c_vp * 1)(g.transpose().ptr)
             check(lib.rbg_lightgcn_backward_f32(arr, 1, c_vp(self.grad_mean.data_ptr()), c_vp(self.grad_e0.data_ptr()),
                                                 c_vp(self.work.data_ptr()), d, k_layers, st))
-            check(lib.rbg_emb_reg_grad_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, c_vp(user.data_ptr()),
-                                           c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, d, float(m.reg_weight),
-                                           c_vp(self.grad_e0.data_ptr()), c_vp(self.loss.data_ptr()), st))
+            if m.require_pow:  # LightGCN.yaml: squared form
+                check(lib.rbg_emb_reg_grad_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, c_vp(user.data_ptr()),
+                                               c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, d, float(m.reg_weight),
+                                               c_vp(self.grad_e0.data_ptr()), c_vp(self.loss.data_ptr()), st))
+            else:              # EmbLoss's default: the 2-norm of each gathered block
+                check(lib.rbg_emb_reg_grad_nopow_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, c_vp(user.data_ptr()),
+                                                     c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, d, float(m.reg_weight),
+                                                     c_vp(self.grad_e0.data_ptr()), c_vp(self.loss.data_ptr()),
+                                                     c_vp(self.reg_ws.data_ptr()), st))
             self.step_count += 1
             check(lib.rbg_adam_step_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, d,
                                         c_vp(self.grad_e0.data_ptr()), c_vp(self.exp_avg.data_ptr()),

@@ -519,12 +519,14 @@ def test_fused_backward_vs_torch_autograd(rbg, cuda, golden, k_layers, per_layer
     close(iw.grad, iw_r.grad)
 
 
-def test_fused_training_step_matches_torch_adam(rbg, cuda, golden):
+@pytest.mark.parametrize("require_pow", [True, False])
+def test_fused_training_step_matches_torch_adam(rbg, cuda, golden, require_pow):
     """FusedBPRAdam.step == calculate_loss + backward + torch.optim.Adam.step, checked against the same three steps
-    done by torch autograd on the CPU through the oracle's dense-branch propagation."""
+    done by torch autograd on the CPU through the oracle's dense-branch propagation; both forms of EmbLoss
+    (require_pow = True: LightGCN.yaml; False: RecBole's default, the 2-norm of each gathered block)."""
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
-    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    model, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=require_pow, reg_weight=1e-2)
     uw = model.user_embedding.weight.detach().cpu().clone().requires_grad_(True)
     iw = model.item_embedding.weight.detach().cpu().clone().requires_grad_(True)
     ref_opt = torch.optim.Adam([uw, iw], lr=1e-2)
@@ -541,7 +543,10 @@ def test_fused_training_step_matches_torch_adam(rbg, cuda, golden):
         pos = (u_all[u] * i_all[p]).sum(1)
         neg = (u_all[u] * i_all[q]).sum(1)
         mf = -torch.log(1e-10 + torch.sigmoid(pos - neg)).mean()
-        reg = (uw[u].norm() ** 2 + iw[p].norm() ** 2 + iw[q].norm() ** 2) / 64 / 2
+        if require_pow:
+            reg = (uw[u].norm() ** 2 + iw[p].norm() ** 2 + iw[q].norm() ** 2) / 64 / 2
+        else:
+            reg = (uw[u].norm() + iw[p].norm() + iw[q].norm()) / 64
         ref_loss = mf + 1e-2 * reg
         ref_loss.backward()
         ref_opt.step()
@@ -549,8 +554,8 @@ def test_fused_training_step_matches_torch_adam(rbg, cuda, golden):
         close(model.user_embedding.weight, uw.detach(), tol=2e-5)
         close(model.item_embedding.weight, iw.detach(), tol=2e-5)
     # the torch-autograd path of the model and the fused step agree on the very same batch, too
-    model2, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
-    model3, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    model2, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=require_pow, reg_weight=1e-2)
+    model3, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=require_pow, reg_weight=1e-2)
     batch = {"user_id": u.to(cuda), "item_id": p.to(cuda), "neg_item_id": q.to(cuda)}
     opt2 = torch.optim.Adam(model2.parameters(), lr=1e-2)
     model2.calculate_loss(batch).backward()
