@@ -100,4 +100,114 @@ struct RowTile {
     }
 };
 
+// ---- split-precision operands: fp32 = hi + mid + lo in bf16 -------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (1/16 of the bf16 matrix rate).  Splitting every fp32 operand into
+// three bf16 terms (round-to-nearest residuals: x = h + m + l up to 2^-24 |x|) and forming the SIX products whose order is
+// >= 2^-16 (h h, h m, m h, h l, l h, m m — the dropped ones are <= 2^-23 relative) on v_mfma_f32_32x32x16_bf16 gives
+// the same accuracy as the exact-fp32 chain (measured: 2.1e-7 vs 2.3e-7 relative to float64 at d = 64, 5.8e-7 vs 6.3e-7
+// at d = 256, profiles/r02_bf16x3_probe.jsonl) at 2.3x its throughput (6 x 32 instead of 8 x 64 cycles per 16 k).
+// The k-sum is order-free, so lane-half h keeps its contiguous run k = 64c + 32h + [0, 32): MFMA (c, m) consumes elements
+// [8m, 8m + 8) of that run from both halves, for A and B alike.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2_bf16(float x0, float x1, bf16x2 &h, bf16x2 &m, bf16x2 &l) {
+    const f32x2v v = {x0, x1};
+    h = __builtin_convertvector(v, bf16x2);                       // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2v r1 = v - __builtin_convertvector(h, f32x2v);    // exact
+    m = __builtin_convertvector(r1, bf16x2);
+    const f32x2v r2 = r1 - __builtin_convertvector(m, f32x2v);
+    l = __builtin_convertvector(r2, bf16x2);
+}
+
+template <int NCHUNK>
+struct AFrag3 {  // a lane's A operand: NCHUNK runs of 32 floats, split; 48 NCHUNK registers
+    bf16x8 h[NCHUNK * 4], m[NCHUNK * 4], l[NCHUNK * 4];
+};
+
+template <int NCHUNK>
+__device__ __forceinline__ void split_a(const float (&a)[NCHUNK][32], AFrag3<NCHUNK> &f) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x2 h, m, l;
+                split2_bf16(a[c][8 * q + 2 * j], a[c][8 * q + 2 * j + 1], h, m, l);
+                f.h[c * 4 + q][2 * j] = h[0];
+                f.h[c * 4 + q][2 * j + 1] = h[1];
+                f.m[c * 4 + q][2 * j] = m[0];
+                f.m[c * 4 + q][2 * j + 1] = m[1];
+                f.l[c * 4 + q][2 * j] = l[0];
+                f.l[c * 4 + q][2 * j + 1] = l[1];
+            }
+}
+
+// RowTile with the tile published as three bf16 planes (row stride 64 NCHUNK + 8 elements = 128 NCHUNK + 16 bytes:
+// 16-byte aligned rows, conflict-free b128 fragment reads).  Same fetch as RowTile; 3 x 32 x (64 NCHUNK + 8) x 2 bytes of LDS.
+template <int NCHUNK, int MODE>
+struct RowTile3 {
+    static constexpr int LDH = NCHUNK * 64 + 8;
+    typedef __bf16 Planes[3][32][LDH];
+    float4 stage[NCHUNK * 2];
+
+    __device__ __forceinline__ void fetch(const float *base, int64_t ld, int64_t n_rows, int d, int64_t tile, int tid) {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            const int64_t r = tile * 32 + row;
+            const float *src = base + (r < n_rows ? r : n_rows - 1) * ld + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == RUN_FAST) {
+                v = *reinterpret_cast<const float4 *>(src);
+            } else if (MODE == RUN_VEC) {
+                if (c4 < d) v = *reinterpret_cast<const float4 *>(src);
+            } else {
+                if (c4 + 0 < d) v.x = src[0];
+                if (c4 + 1 < d) v.y = src[1];
+                if (c4 + 2 < d) v.z = src[2];
+                if (c4 + 3 < d) v.w = src[3];
+            }
+            stage[k] = v;
+        }
+    }
+    __device__ __forceinline__ void publish(Planes &tile, int tid) const {
+#pragma unroll
+        for (int k = 0; k < NCHUNK * 2; ++k) {
+            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+            bf16x2 h0, m0, l0, h1, m1, l1;
+            split2_bf16(stage[k].x, stage[k].y, h0, m0, l0);
+            split2_bf16(stage[k].z, stage[k].w, h1, m1, l1);
+            const bf16x4 hv = {h0[0], h0[1], h1[0], h1[1]}, mv = {m0[0], m0[1], m1[0], m1[1]}, lv = {l0[0], l0[1], l1[0], l1[1]};
+            *reinterpret_cast<bf16x4 *>(&tile[0][row][c4]) = hv;
+            *reinterpret_cast<bf16x4 *>(&tile[1][row][c4]) = mv;
+            *reinterpret_cast<bf16x4 *>(&tile[2][row][c4]) = lv;
+        }
+    }
+    // acc[i = A row][j = tile row]; small terms first
+    static __device__ __forceinline__ f32x16 product(const Planes &tile, const AFrag3<NCHUNK> &a, int i, int h) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int off = c * 64 + h * 32 + q * 8;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(&tile[0][i][off]);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(&tile[1][i][off]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(&tile[2][i][off]);
+                const int s = c * 4 + q;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s], bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s], bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s], bh, acc, 0, 0, 0);
+            }
+        return acc;
+    }
+};
+
 }  // namespace rbg

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "internal.h"
 #include "mfma_common.h"
@@ -162,12 +163,16 @@ __global__ __launch_bounds__(256) void score_generic_kernel(const float *__restr
 //    before them as well; stores must be global_store (a pointer that decays to a generic one makes them flat_store and
 //    every wait becomes vmcnt(0)) — see AlignedRows.
 //  * output rows are not line-aligned (row stride n) — aligned_emit.
-template <int NCHUNK, bool VEC, bool FAST>
+//  * SPLIT (default, option "mfma_split"): both operands are split into three bf16 terms and the six products of order
+//    >= 2^-16 run on v_mfma_f32_32x32x16_bf16 — the accuracy of the fp32 chain at 2.3x its rate (mfma_common.h).
+template <int NCHUNK, bool VEC, bool FAST, bool SPLIT>
 __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) void score_kernel(const float *__restrict__ U, int64_t ldu,
                                                     const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
                                                     int64_t B, int64_t n, int d, int tiles_per_wave) {
-    constexpr int LD = NCHUNK * 64 + 4;
-    __shared__ __attribute__((aligned(16))) float s_it[2][32][LD];
+    constexpr int MODE = FAST ? RUN_FAST : (VEC ? RUN_VEC : RUN_ANY);
+    using Tile = std::conditional_t<SPLIT, RowTile3<NCHUNK, MODE>, RowTile<NCHUNK, MODE>>;
+    using TileMem = std::conditional_t<SPLIT, typename RowTile3<NCHUNK, MODE>::Planes, float[32][NCHUNK * 64 + 4]>;
+    __shared__ __attribute__((aligned(16))) TileMem s_it[2];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform
     const int i = lane & 31, h = lane >> 5;
@@ -185,11 +190,15 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c) load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(urow, true, c * 64 + h * 32, d, a[c]);
 
-    using Tile = RowTile<NCHUNK, (FAST ? RUN_FAST : (VEC ? RUN_VEC : RUN_ANY))>;
+    std::conditional_t<SPLIT, AFrag3<NCHUNK>, int> a3;
+    if constexpr (SPLIT) split_a(a, a3);  // the fp32 runs are dead after this
     Tile tile;
     auto fetch = [&](const int64_t t) __attribute__((always_inline)) { tile.fetch(I, ldi, n, d, t, tid); };
     auto publish = [&](const int buf) __attribute__((always_inline)) { tile.publish(s_it[buf], tid); };
-    auto tile_product = [&](const int buf) __attribute__((always_inline)) { return Tile::product(s_it[buf], a, i, h); };
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
+        if constexpr (SPLIT) return Tile::product(s_it[buf], a3, i, h);
+        else return Tile::product(s_it[buf], a, i, h);
+    };
     AlignedRows al;
     aligned_init(al, S, n, B, user_tile * 32, t0 * 32);
     // tiles whose shifted line lies inside the row for every phase, in a wave with 32 valid rows: unconditional stores
@@ -248,12 +257,19 @@ static int launch_score(const float *U, int64_t ldu, const float *I, int64_t ldi
             hipLaunchKernelGGL((score_generic_kernel<false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
     } else {
         const bool fast = vec && d == 64 * NCHUNK;
-        if (fast)
-            hipLaunchKernelGGL((score_kernel<NCHUNK, true, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+        if (opt_mfma_split()) {
+            if (fast)
+                hipLaunchKernelGGL((score_kernel<NCHUNK, true, true, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+            else if (vec)
+                hipLaunchKernelGGL((score_kernel<NCHUNK, true, false, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+            else
+                hipLaunchKernelGGL((score_kernel<NCHUNK, false, false, true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+        } else if (fast)
+            hipLaunchKernelGGL((score_kernel<NCHUNK, true, true, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
         else if (vec)
-            hipLaunchKernelGGL((score_kernel<NCHUNK, true, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+            hipLaunchKernelGGL((score_kernel<NCHUNK, true, false, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
         else
-            hipLaunchKernelGGL((score_kernel<NCHUNK, false, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
+            hipLaunchKernelGGL((score_kernel<NCHUNK, false, false, false>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);
     }
     RBG_HIP(hipGetLastError());
     return RBG_OK;

@@ -132,15 +132,19 @@ struct RowLoop<16> {
 
 // Shared by both passes.  A workgroup = 4 waves = 4 tiles of 32 batch users (A fragments in registers); all four walk
 // the SAME item tiles, each fetched once per workgroup into a double-buffered LDS tile (mfma_common.h::RowTile).
-template <int NCHUNK, bool VEC>
-using ItemTiles = RowTile<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>;
+// SPLIT: the tile is published as three bf16 planes and the product runs on the bf16 matrix cores (mfma_common.h: fp32
+// accuracy at 2.3x the rate of the exact-fp32 MFMA); both passes use the same product, so a pair scores identically in both.
+template <int NCHUNK, bool VEC, bool SPLIT>
+using ItemTiles = std::conditional_t<SPLIT, RowTile3<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>, RowTile<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>>;
+template <int NCHUNK, bool VEC, bool SPLIT>
+using ItemTileMem = std::conditional_t<SPLIT, typename RowTile3<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>::Planes, float[32][NCHUNK * 64 + 4]>;
 
 // CAP = list capacity per user: a prune leaves <= k entries and one tile adds <= 32, so CAP >= k + 32 (48 for k <= 16,
 // which lets two workgroups share a CU's LDS; 64 otherwise).
-template <int NCHUNK, bool VEC, int CAP>
+template <int NCHUNK, bool VEC, int CAP, bool SPLIT>
 __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
-    using Tiles = ItemTiles<NCHUNK, VEC>;
-    __shared__ __attribute__((aligned(16))) float s_it[2][32][Tiles::LD];
+    using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
+    __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     __shared__ float l_val[4][32][CAP];
     __shared__ int l_idx[4][32][CAP];
     __shared__ int l_cnt[4][32];
@@ -156,6 +160,12 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
         load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+    std::conditional_t<SPLIT, AFrag3<NCHUNK>, int> a3;
+    if constexpr (SPLIT) split_a(a, a3);
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
+        if constexpr (SPLIT) return Tiles::product(s_it[buf], a3, i, h);
+        else return Tiles::product(s_it[buf], a, i, h);
+    };
     // thresholds start at the pre-pass bound: an item scoring below the k-th best valid score of ANY item subset
     // cannot be in the top k.  tau[r] belongs to the user of accumulator row (r&3) + 8*(r>>2) + 4h.
     const float my_tau = (p.tau0 && bi < p.B) ? p.tau0[bi] : kNegInf;
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
         if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
-        if (wave_live) filter_tile(Tiles::product(s_it[buf], a, i, h), t * 32 + i);
+        if (wave_live) filter_tile(tile_product(buf), t * 32 + i);
         if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         __syncthreads();
     }
@@ -241,11 +251,11 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
 // group maximum that is neither PAD nor a history item is <= the k-th best valid score overall, and with k << 32 it is
 // nearly as tight as the exact k-th best of the sample.  Same workgroup shape as the main pass (4 user tiles sharing the
 // item tiles of one split of the sample); topk_tau_kernel folds the splits and selects.
-template <int NCHUNK, bool VEC>
+template <int NCHUNK, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, float *__restrict__ g_val,
                                                            int32_t *__restrict__ g_idx) {
-    using Tiles = ItemTiles<NCHUNK, VEC>;
-    __shared__ __attribute__((aligned(16))) float s_it[2][32][Tiles::LD];
+    using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
+    __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
@@ -256,6 +266,12 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
 #pragma unroll
     for (int c = 0; c < NCHUNK; ++c)
         load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.U + (my_user < 0 ? 0 : my_user) * (int64_t)p.d, my_user >= 0, c * 64 + h * 32, p.d, a[c]);
+    std::conditional_t<SPLIT, AFrag3<NCHUNK>, int> a3;
+    if constexpr (SPLIT) split_a(a, a3);
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
+        if constexpr (SPLIT) return Tiles::product(s_it[buf], a3, i, h);
+        else return Tiles::product(s_it[buf], a, i, h);
+    };
     float best_v[16];
     int best_i[16];
 #pragma unroll
@@ -275,7 +291,7 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
         const int buf = (int)(t - t_begin) & 1;
         if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
         if (wave_live) {
-            const f32x16 acc = Tiles::product(s_it[buf], a, i, h);
+            const f32x16 acc = tile_product(buf);
             const int64_t item = t * 32 + i;
             const bool item_ok = item < p.n_items && item != 0;
             RowLoop<0>::run([&](auto rc) {
@@ -426,18 +442,37 @@ static void topk_geometry(int64_t B, int64_t n_tiles, int64_t want_blocks, int64
 
 template <int NCHUNK, int CAP>
 static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    // three bf16 planes of a d = 256 tile (2 x 50.7 KB) plus 64-entry lists (64 KB) exceed the 160 KB of LDS: that one
+    // combination (k > 16 at d > 128) stays on the exact-fp32 MFMA; the pre-pass uses the same product as its main pass
+    constexpr bool kSplitFits = !(NCHUNK == 4 && CAP > 48);
+    const bool split = kSplitFits && opt_mfma_split() != 0;
+    if constexpr (kSplitFits) {
+        if (vec && split) {
+            hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+        if (split) {
+            hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false, CAP, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+    }
     if (vec)
-        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP, false>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false, CAP>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((score_topk_kernel<NCHUNK, false, CAP, false>), grid, dim3(256), 0, s, p);
 }
 
 template <int NCHUNK>
 static void launch_prepass(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
-    if (vec)
-        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true>), grid, dim3(256), 0, s, p, gv, gi);
+    const bool split = opt_mfma_split() != 0 && !(NCHUNK == 4 && p.k > 16);  // the same product as the main pass (launch_topk)
+    if (vec && split)
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true, true>), grid, dim3(256), 0, s, p, gv, gi);
+    else if (vec)
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true, false>), grid, dim3(256), 0, s, p, gv, gi);
+    else if (split)
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false, true>), grid, dim3(256), 0, s, p, gv, gi);
     else
-        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false>), grid, dim3(256), 0, s, p, gv, gi);
+        hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, false, false>), grid, dim3(256), 0, s, p, gv, gi);
 }
 
 static void launch_prepass_d(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
