@@ -148,16 +148,17 @@ __device__ __forceinline__ void split_a(const float (&a)[NCHUNK][32], AFrag3<NCH
 
 // RowTile with the tile published as three bf16 planes (row stride 64 NCHUNK + 8 elements = 128 NCHUNK + 16 bytes:
 // 16-byte aligned rows, conflict-free b128 fragment reads).  Same fetch as RowTile; 3 x 32 x (64 NCHUNK + 8) x 2 bytes of LDS.
-template <int NCHUNK, int MODE>
+template <int NCHUNK, int MODE, int THREADS = 256>
 struct RowTile3 {
     static constexpr int LDH = NCHUNK * 64 + 8;
+    static constexpr int NSTAGE = NCHUNK * 512 / THREADS;  // float4s a thread fetches per tile (THREADS threads share it)
     typedef __bf16 Planes[3][32][LDH];
-    float4 stage[NCHUNK * 2];
+    float4 stage[NSTAGE];
 
     __device__ __forceinline__ void fetch(const float *base, int64_t ld, int64_t n_rows, int d, int64_t tile, int tid) {
 #pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int f = tid + THREADS * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
             const int64_t r = tile * 32 + row;
             const float *src = base + (r < n_rows ? r : n_rows - 1) * ld + c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -176,8 +177,8 @@ struct RowTile3 {
     }
     __device__ __forceinline__ void publish(Planes &tile, int tid) const {
 #pragma unroll
-        for (int k = 0; k < NCHUNK * 2; ++k) {
-            const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
+        for (int k = 0; k < NSTAGE; ++k) {
+            const int f = tid + THREADS * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
             bf16x2 h0, m0, l0, h1, m1, l1;
             split2_bf16(stage[k].x, stage[k].y, h0, m0, l0);
             split2_bf16(stage[k].z, stage[k].w, h1, m1, l1);

@@ -229,6 +229,11 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
     if (wave_live && t1 > t0) aligned_flush(al, n, t1 - 1, i, h);
 }
 
+// (Tried, r02: a role-specialised variant — one loader wave publishing the tiles, four compute waves that only multiply
+// and store, so that no wave ever waits on `vmcnt` behind its own stores.  Correct, but slower: 237 vs 216 us at d = 64,
+// 359 vs 308 us at d = 128 (B = 4096 x 40 982, interleaved timing, profiles/r02_split_probe.jsonl): with 5-wave
+// workgroups only 8 instead of 12 compute waves fit a CU, and the store stream, not the operand wait, sets the pace.)
+
 template <int NCHUNK>
 static int launch_score(const float *U, int64_t ldu, const float *I, int64_t ldi, float *S, int64_t B, int64_t n, int d,
                         bool vec, hipStream_t s) {
