@@ -250,6 +250,17 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             opt.step()
 
         ex["sgl_train_step_us(ED views, InfoNCE, batch 2048)"] = time_us(sgl_step, iters=10, warm=2)
+        gc = {}
+        for mode, flag in (("device_sampling", True), ("numpy_sampling(reference calls)", False)):
+            sgl.device_sampling = flag
+            sgl.graph_construction()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                sgl.graph_construction()
+            torch.cuda.synchronize()
+            gc[mode] = (time.perf_counter() - t0) / 3 * 1e3
+        ex["sgl_graph_construction_ms(two ED views)"] = gc
     except Exception as e:  # noqa: BLE001  (diagnostics only: never cost the headline its JSON line)
         ex["model_steps_error"] = str(e)[:200]
     return ex
