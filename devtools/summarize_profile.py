@@ -29,4 +29,16 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     traffic = (2 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024
     out["traffic_bytes_per_launch"] = traffic
     print("traffic bytes per spmm launch (2*FETCH + WRITE)*1024 =", traffic)
+    # the table bench.py reads: workload : width : kernel -> bytes per launch, averaged over the launches of the bench
+    # command (two plain layers + the layer that carries the fused mean)
+    tpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        table = json.load(open(tpath))
+    except Exception:
+        table = {}
+    key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:spmm_binned_kernel<64, 8, true, false>"
+    table[key] = traffic
+    table["_bench_command_note"] = ("the key above is refreshed by devtools/profile_session.sh from PMC passes of `python bench.py --steps 100 "
+                                    "--warmup 10 --cpu-seconds 0 --no-extras`: mean over all SpMM launches of that command")
+    json.dump(table, open(tpath, "w"), indent=1)
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
