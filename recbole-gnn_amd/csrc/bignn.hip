@@ -224,7 +224,8 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
     }
     const int64_t n_tiles = (p.n_rows + 31) / 32;
     // one 32-row tile per wavefront (the grid-stride loop in the kernel only matters beyond 2^20 tiles)
-    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 1 << 18));
+    int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 1 << 18));
+    if (opt_bignn_grid() > 0) grid = std::min<int64_t>(grid, opt_bignn_grid());  // fewer, longer-lived workgroups: the weights are staged once per workgroup
     if (fast)
         hipLaunchKernelGGL((bignn_dense_kernel<NT, true>), dim3((unsigned)grid), dim3(256), lds, s, p);
     else
