@@ -86,7 +86,6 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "mfma_split"  : 1 (default) = rbg_score_f32 / rbg_full_sort_topk_f32 split both fp32 operands into three bf16 terms and
  *                   form the six products of order >= 2^-16 on the bf16 matrix cores (fp32-MFMA accuracy at 2.3x its
  *                   rate); 0 = the exact-fp32 MFMA chain
- *   "bignn_grid"  : cap on the workgroups of the BiGNN dense kernel (0 = auto: one 32-row tile per wavefront)
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192) */
 int rbg_set_option(const char *key, int64_t value);

@@ -224,8 +224,9 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
     }
     const int64_t n_tiles = (p.n_rows + 31) / 32;
     // one 32-row tile per wavefront (the grid-stride loop in the kernel only matters beyond 2^20 tiles)
-    int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 1 << 18));
-    if (opt_bignn_grid() > 0) grid = std::min<int64_t>(grid, opt_bignn_grid());  // fewer, longer-lived workgroups: the weights are staged once per workgroup
+    // (capping the grid so that a workgroup stages the weights once for several tiles changes nothing: 28.7 us at every cap
+    //  from 768 workgroups up, slower below — r02, Gowalla shape; the kernel is bound by its row loads, not by the staging)
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, 1 << 18));
     if (fast)
         hipLaunchKernelGGL((bignn_dense_kernel<NT, true>), dim3((unsigned)grid), dim3(256), lds, s, p);
     else

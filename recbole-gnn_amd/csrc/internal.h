@@ -36,7 +36,6 @@ int opt_nt_store();
 int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the binned kernel (0)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
-int opt_bignn_grid();   // BiGNN dense kernel: cap on workgroups (0 = one 32-row tile per wavefront)
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)
 int opt_topk_sample();  // items the fused top-k pre-pass looks at
 
