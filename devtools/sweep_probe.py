@@ -32,8 +32,14 @@ def parse_variants(text):
     out = []
     for item in text.split(","):
         name, spec = item.split("=")
-        threads, n_wg, rk, hot = (int(x) for x in spec.split(":"))
-        out.append((name, dict(threads=threads, n_wg=n_wg, range_bytes=(rk * 1024 if rk else 1 << 40), hot_rows_per_class=hot)))
+        f = spec.split(":")
+        threads, n_wg, rk, hot = (int(x) for x in f[:4])
+        kw = dict(threads=threads, n_wg=n_wg, range_bytes=(rk * 1024 if rk else 1 << 40), hot_rows_per_class=hot)
+        if len(f) > 4:
+            kw["piece_cost"] = float(f[4])
+        if len(f) > 5:
+            kw["part_frac"] = float(f[5])
+        out.append((name, kw))
     return out
 
 
@@ -161,6 +167,10 @@ def main():
         st = plan.stats()
         st["plan_s"] = round(time.time() - t0, 2)
         run(name, st)
+        if d == 64 and os.environ.get("SWEEP_PLAIN_TOO"):
+            rbg.set_option("sweep_lean", 0)
+            run(name + "_plain", st)
+            rbg.set_option("sweep_lean", 1)
     sweep.detach(graph)
     if args.pmc_run:
         mf = args.manifest or os.path.join(ROOT, "gpurun_out", "manifest.json")

@@ -38,7 +38,7 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1}, g_mfma_split{1};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1}, g_mfma_split{1}, g_sweep_lean{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
 int opt_xcd_split() { return g_xcd_split.load(); }
 int opt_nt_store() { return g_nt_store.load(); }
@@ -46,6 +46,7 @@ int opt_topk_sample() { return g_topk_sample.load(); }
 int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
 int opt_sweep() { return g_sweep.load(); }
+int opt_sweep_lean() { return g_sweep_lean.load(); }
 int opt_mfma_split() { return g_mfma_split.load(); }
 
 Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
@@ -459,6 +460,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sweep = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sweep_lean")) {
+        g_sweep_lean = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "mfma_split")) {
         g_mfma_split = value ? 1 : 0;
         return RBG_OK;
@@ -496,6 +501,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sweep")) {
         *value = g_sweep.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sweep_lean")) {
+        *value = g_sweep_lean.load();
         return RBG_OK;
     }
     if (!strcmp(key, "mfma_split")) {
@@ -808,6 +817,19 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
     sw->n_pieces = n_pieces;
     sw->n_ent = n_ent;
     sw->n_desc = n_desc;
+    sw->n_cols = g->n_cols;
+    // two row classes = no workgroup finishes rows on both sides of the user / item boundary (then all its gathers go to
+    // the other side's table, and the lean gather may address that table alone)
+    sw->class_split = 0;
+    if (g->n_users > 0 && g->n_users < g->n_rows) {
+        bool pure = true;
+        for (int w = 0; w < n_wg && pure; ++w) {
+            bool lo = false, hi = false;
+            for (int64_t r = wg_row_ptr[w]; r < wg_row_ptr[w + 1]; ++r) (rows[4 * r] < g->n_users ? lo : hi) = true;
+            pure = !(lo && hi);
+        }
+        if (pure) sw->class_split = g->n_users;
+    }
     std::vector<int32_t> ent_pad;
     try {
         ent_pad.assign((size_t)(n_ent + 16) * 2, 0);

@@ -34,6 +34,7 @@ int spmm_unroll();
 int opt_xcd_split();
 int opt_nt_store();
 int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the binned kernel (0)
+int opt_sweep_lean();   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)
@@ -90,6 +91,8 @@ struct SweepDev {
     int32_t *wg_hot = nullptr;      // [n_wg][2]: {first hot row, hot rows} or NULL
     int32_t *hot_rows = nullptr;    // source row of every hot-tile row
     int hot_base = 0;               // float offset of the hot tile inside the workgroup's LDS
+    int64_t n_cols = 0;             // rows of the gathered operand
+    int64_t class_split = 0;        // > 0: rows [0, class_split) / the rest are separate workgroups' classes (two-table sources)
     int64_t n_pieces = 0, n_ent = 0, n_desc = 0;
 };
 
