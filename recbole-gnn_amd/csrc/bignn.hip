@@ -235,6 +235,257 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
     return RBG_OK;
 }
 
+
+// ---- the NGCF configuration (d_in = 64, d_out <= 64): rows arrive by LDS-DMA, the weights live in registers ----------
+//
+// The kernel above spends most of its time fetching rows: a lane needs ITS row's contiguous k-run (the MFMA operand
+// layout ties lanes to rows), so every load instruction touches 64 cache lines for 16 bytes each, the lines are revisited by
+// the next seven instructions, and with 12 waves per CU their 196 KB of in-flight rows do not survive in the 32 KB L1.
+// Here a wave fetches a 16-row tile of P and of X as 8 fully coalesced 1 KiB `global_load_lds_dwordx4` requests straight
+// into its private 8 KB of LDS (no VGPR round trip, nothing for the L1 to keep), and then reads its k-runs back with
+// 8 conflict-free ds_read_b128: LDS-DMA writes lane-linear, so the 16-byte chunk c of tile row r is SOURCED into slot
+// c ^ r and read from slot c ^ r (same involution on both sides).
+// Matrix-core shape: v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand and the data rows as B, i.e. the tile of
+// Y^T: lane (n = lane & 15, g = lane >> 4) then holds output columns 16 t + 4 g .. + 3 of data row n — a float4 store per
+// column tile, one row norm per lane (in-lane sum + two cross-group shuffles), one rsqrt per tile instead of 16.
+// The concatenated weights are 128 registers per lane (W1 / W2 rows 16 t + n, k-run 16 g .. + 15), filled once per
+// persistent wave from a per-workgroup LDS copy (itself one DMA pass): the MFMA loop reads registers only.
+// Pipeline per wave (8 waves per CU, 2 per SIMD so one wave's epilogue runs under the other's MFMAs):
+//   MFMA(tile i) -> vmcnt(0) [tile i+1 landed long ago] -> ds_read tile i+1 -> lgkmcnt(0) -> DMA(tile i+2) -> epilogue(i)
+// so the stores of tile i are never waited on and a DMA has a whole tile of MFMAs to land.  (With a dropout mask the DMA
+// goes out after the epilogue: the mask loads are ordinary loads, and the wait hipcc places for them would drain it.)
+__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {  // lds_dst: wave-uniform LDS byte address
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// Per-wave clock trace (devtools/microbench/bignn_trace.hip builds this file with RBG_BIGNN_TRACE; the product does not):
+// slot k of wave w receives s_memtime at stamp k.
+#ifdef RBG_BIGNN_TRACE
+__device__ unsigned long long *g_bignn_trace = nullptr;
+#define RBG_STAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (g_bignn_trace && lane == 0 && (k) < 32) g_bignn_trace[((int64_t)blockIdx.x * 8 + wave) * 32 + (k)] = clock64(); \
+    } while (0)
+#else
+#define RBG_STAMP(k) ((void)0)
+#endif
+
+__device__ __forceinline__ void pin8(float *a) {  // the compiler must have these eight registers' loads complete here
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+}
+
+// NT = 16-column output tiles held by a wave (d_out <= 16 NT); MASK = a dropout mask is applied (its own instantiation:
+// the wait hipcc places for the mask loads must not exist in the kernel that overlaps the DMA with the epilogue)
+template <int NT, bool MASK>
+__global__ __launch_bounds__(512) void bignn_dense_dma_kernel(const BignnParams p) {
+    constexpr int WAVES = 8;
+    __shared__ __attribute__((aligned(1024))) float tiles[WAVES * 2048];  // per wave: P tile [16][64], X tile [16][64]
+    __shared__ __attribute__((aligned(1024))) float wstage[2 * 64 * 64];   // W1, W2 [64][64], chunk-swizzled like the tiles
+    __shared__ __attribute__((aligned(1024))) float bstage[256];           // b1 [64], b2 [64] (+ the rest of the DMA's 1 KiB)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t n_tiles = (p.n_rows + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t tile = blockIdx.x + (int64_t)gridDim.x * wave;  // consecutive tiles go to different CUs
+    float *buf = tiles + wave * 2048;
+    const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)buf);
+
+    auto issue = [&](int64_t t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rr = 4 * j + g;  // this lane's destination is slot n of tile row rr; it sources chunk n ^ rr
+            const int64_t r = min(t * 16 + rr, p.n_rows - 1);
+            lds_dma16(p.P + r * 64 + 4 * (n ^ rr), buf_lds + j * 1024);
+            lds_dma16(p.X + r * p.ldx + 4 * (n ^ rr), buf_lds + 4096 + j * 1024);
+        }
+    };
+    auto fetch = [&](float(&pv)[16], float(&xv)[16]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = (4 * g + q) ^ n;
+            const float4 a = *reinterpret_cast<const float4 *>(buf + n * 64 + slot * 4);
+            const float4 b = *reinterpret_cast<const float4 *>(buf + 1024 + n * 64 + slot * 4);
+            pv[4 * q + 0] = a.x, pv[4 * q + 1] = a.y, pv[4 * q + 2] = a.z, pv[4 * q + 3] = a.w;
+            xv[4 * q + 0] = b.x, xv[4 * q + 1] = b.y, xv[4 * q + 2] = b.z, xv[4 * q + 3] = b.w;
+        }
+    };
+
+    RBG_STAMP(0);
+    // Two waves share a SIMD (w and w + 4).  Started together they would run their MFMA phases together and their epilogues
+    // together, leaving the matrix core idle through every epilogue; the older four get issue priority, so their MFMAs run
+    // at full rate first and from then on one wave's epilogue sits under the other's MFMAs.
+    if (wave < 4) __builtin_amdgcn_s_setprio(2);
+    const bool has_tile = tile < n_tiles;  // (wave-uniform) a wave without work still stages its share of the weights
+    // Weights and biases: staged ONCE per workgroup by DMA (each wave brings 8 rows of W1 / W2, coalesced; wave 0 also the
+    // two bias vectors), then every lane reads its A operands — rows 16 t + n of W1 / W2, k-run 16 g .. 16 g + 15 — into
+    // registers.  (Per-lane global loads of the same runs cost 64 cache lines per instruction and 32 KB per WAVE out of
+    // 256 L2 lines the whole grid shares: ~15 us.)  They go out BEFORE the first tile so that vmcnt(8) — requests retire
+    // in order — means "weights landed" while the tile is still in flight, and no load is visible to hipcc, whose waits
+    // would otherwise drain the DMA queue.
+    {
+        const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)wstage);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * wave + u, part = i >> 4, rr = 4 * (i & 15) + g;  // destination: slot n of weight row rr
+            const float *w = part ? p.W2 : p.W1;
+            lds_dma16(w + min(rr, p.d_out - 1) * 64 + 4 * (n ^ (rr & 15)), w_lds + i * 1024);
+        }
+        if (wave == 0) {  // lanes 0-15: b1[4 n ..], lanes 16-31: b2[4 n ..] (clamped inside the vectors; padded columns are zeroed below)
+            const float *b = (g & 1) ? p.b2 : p.b1;
+            lds_dma16(b + min(4 * n, p.d_out - 4), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)bstage));
+        }
+    }
+    if (has_tile) {
+        issue(tile);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RBG_STAMP(1);
+    __syncthreads();  // every wave's share of the weights is in LDS (the only barrier of the kernel)
+    RBG_STAMP(2);
+    if (!has_tile) return;
+    float w1[NT][16], w2[NT][16], bias[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = 16 * t + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int slot = (4 * g + q) ^ n;
+            const float4 a = *reinterpret_cast<const float4 *>(wstage + j * 64 + slot * 4);
+            const float4 b = *reinterpret_cast<const float4 *>(wstage + 4096 + j * 64 + slot * 4);
+            w1[t][4 * q + 0] = a.x, w1[t][4 * q + 1] = a.y, w1[t][4 * q + 2] = a.z, w1[t][4 * q + 3] = a.w;
+            w2[t][4 * q + 0] = b.x, w2[t][4 * q + 1] = b.y, w2[t][4 * q + 2] = b.z, w2[t][4 * q + 3] = b.w;
+        }
+        const int c = 16 * t + 4 * g;  // this lane's four output columns of tile t (d_out is a multiple of 4)
+        const int cc = min(c, p.d_out - 4);
+        const float4 ba = *reinterpret_cast<const float4 *>(bstage + cc), bb = *reinterpret_cast<const float4 *>(bstage + 64 + cc);
+        const bool in = c < p.d_out;
+        bias[t][0] = in ? ba.x + bb.x : 0.f, bias[t][1] = in ? ba.y + bb.y : 0.f, bias[t][2] = in ? ba.z + bb.z : 0.f,
+        bias[t][3] = in ? ba.w + bb.w : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {  // weight rows past d_out (the DMA clamped them to the last row) are zero
+        if (16 * t + n >= p.d_out) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) w1[t][s] = 0.f, w2[t][s] = 0.f;
+        }
+    }
+    float pv[16], xv[16];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fetch(pv, xv);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next DMA overwrites the tile
+    if (tile + stride < n_tiles) issue(tile + stride);
+    RBG_STAMP(3);
+    int stamp = 4;
+    (void)stamp;
+
+    for (;;) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a1 = pv[s] + xv[s];  // lin1 operand (layers.py:56)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], a1, acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float a2 = pv[s] * xv[s];  // lin2 operand (layers.py:57)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][s], a2, acc[t], 0, 0, 0);
+        }
+        const int64_t next = tile + stride;
+        const bool more = next < n_tiles;
+        RBG_STAMP(stamp);  // (the last MFMA is issued, not necessarily complete)
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile `next` (issued a whole tile ago) is in LDS
+            RBG_STAMP(stamp + 1);
+            fetch(pv, xv);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // with a dropout mask the epilogue has compiler-visible loads, whose wait must not see a DMA behind them
+            if (!MASK && next + stride < n_tiles) issue(next + stride);
+        }
+        RBG_STAMP(stamp + 2);
+        // epilogue: lane (n, g) holds columns 16 t + 4 g + r of data row n
+        const int64_t row = tile * 16 + n;
+        const bool live = row < p.n_rows;
+        float v[NT][4];
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c = 16 * t + 4 * g;
+            float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+            if constexpr (MASK)
+                if (live && c < p.d_out) m = *reinterpret_cast<const float4 *>(p.drop_mask + row * p.d_out + c);
+            const float mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[t][r] + bias[t][r];
+                if (p.leaky_norm) x = x > 0.f ? x : x * p.slope;
+                if constexpr (MASK) x *= mm[r];
+                v[t][r] = x;
+                ss = fmaf(x, x, ss);  // padded columns hold exact zeros
+            }
+        }
+        if (p.leaky_norm) {
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[t][r] *= inv;
+            if (p.inv_norm && g == 0 && live) p.inv_norm[row] = inv;
+        }
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = 16 * t + 4 * g;
+                if (c < p.d_out) *reinterpret_cast<float4 *>(p.Y + row * p.ldy + c) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+            }
+        }
+        RBG_STAMP(stamp + 3);
+        stamp += 4;
+        if (!more) break;
+        if (MASK && next + stride < n_tiles) issue(next + stride);
+        tile = next;
+    }
+}
+
+static int device_cu_count() {
+    static std::atomic<int> cached{0};
+    int v = cached.load();
+    if (v > 0) return v;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+        v = 256;
+    cached = v;
+    return v;
+}
+
+template <int NT>
+static int launch_dense_dma(const BignnParams &p, hipStream_t s) {
+    const int64_t n_tiles = (p.n_rows + 15) / 16;
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, device_cu_count()));
+    if (p.drop_mask)
+        hipLaunchKernelGGL((bignn_dense_dma_kernel<NT, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    else
+        hipLaunchKernelGGL((bignn_dense_dma_kernel<NT, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
 }  // namespace rbg
 
 using namespace rbg;
@@ -282,6 +533,12 @@ static int bignn_conv_impl(const rbg_graph *g, int64_t n_rows, const float *X, i
     const int fast = (d_in % 64 == 0) && (ldx % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P_save) | reinterpret_cast<uintptr_t>(W1) |
                        reinterpret_cast<uintptr_t>(W2)) & 15u) == 0;
+    // the NGCF configuration takes the LDS-DMA kernel ("bignn_dma" option, default on)
+    const bool vec_out = d_out % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 &&
+                         (!p.drop_mask || (reinterpret_cast<uintptr_t>(p.drop_mask) & 15u) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2)) & 15u) == 0;
+    if (fast && d_in == 64 && d_out <= 64 && vec_out && opt_bignn_dma())
+        return d_out <= 32 ? launch_dense_dma<2>(p, s) : launch_dense_dma<4>(p, s);
     if (d_out <= 32) return launch_dense<1>(p, fast, s);
     if (d_out <= 64) return launch_dense<2>(p, fast, s);
     if (d_out <= 128) return launch_dense<4>(p, fast, s);

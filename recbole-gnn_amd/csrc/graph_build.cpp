@@ -38,7 +38,7 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1}, g_mfma_split{1}, g_sweep_lean{1};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1}, g_mfma_split{1}, g_sweep_lean{1}, g_bignn_dma{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
 int opt_xcd_split() { return g_xcd_split.load(); }
 int opt_nt_store() { return g_nt_store.load(); }
@@ -47,6 +47,7 @@ int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
 int opt_sweep() { return g_sweep.load(); }
 int opt_sweep_lean() { return g_sweep_lean.load(); }
+int opt_bignn_dma() { return g_bignn_dma.load(); }
 int opt_mfma_split() { return g_mfma_split.load(); }
 
 Tuning current_tuning() { return Tuning{g_short_max.load(), g_wave_max.load(), g_seg_len.load()}; }
@@ -464,6 +465,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "bignn_dma")) {
+        g_bignn_dma = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "mfma_split")) {
         g_mfma_split = value ? 1 : 0;
         return RBG_OK;
@@ -505,6 +510,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sweep_lean")) {
         *value = g_sweep_lean.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "bignn_dma")) {
+        *value = g_bignn_dma.load();
         return RBG_OK;
     }
     if (!strcmp(key, "mfma_split")) {

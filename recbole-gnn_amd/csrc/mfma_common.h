@@ -10,6 +10,7 @@
 namespace rbg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // row of the 32x32 accumulator tile held by register `reg` of lane-half `h`
 __host__ __device__ constexpr int mfma_rowmap(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

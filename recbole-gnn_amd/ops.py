@@ -247,6 +247,30 @@ def bignn_conv_raw(graph, x, w1, b1, w2, b2, out=None, leaky_norm=False, slope=0
     return out, p
 
 
+def bignn_dense_raw(p, x, w1, b1, w2, b2, out=None, leaky_norm=False, slope=0.2):
+    """The dense half of BiGNNConv.forward from a product P = Â·x the caller holds (layers.py:56-58) [+ LeakyReLU +
+    L2-normalize]: rbg_bignn_dense_f32.  x / out may be column slices of wider row-major buffers."""
+    for t, nm in ((p, "P"), (x, "x"), (w1, "W1"), (b1, "b1"), (w2, "W2"), (b2, "b2")):
+        _check_dense(t, nm)
+    if x.dim() != 2 or x.stride(1) != 1 or not p.is_contiguous() or tuple(p.shape) != tuple(x.shape):
+        raise ValueError("x must be 2-D with unit column stride and P a contiguous tensor of the same shape")
+    n, d_in = x.shape
+    d_out = w1.shape[0]
+    if tuple(w1.shape) != (d_out, d_in) or tuple(w2.shape) != (d_out, d_in):
+        raise ValueError("W1/W2 must be [d_out, d_in]")
+    if out is None:
+        out = torch.empty((n, d_out), dtype=torch.float32, device=x.device)
+    elif out.stride(1) != 1 or tuple(out.shape) != (n, d_out):
+        raise ValueError("out must be [N, d_out] with unit column stride")
+    flags = _lib.BIGNN_LEAKY_NORM if leaky_norm else _lib.BIGNN_CONV_ONLY
+    with torch.cuda.device(x.device):
+        check(lib.rbg_bignn_dense_f32(c_vp(p.data_ptr()), c_vp(x.data_ptr()), x.stride(0) if n > 1 else d_in,
+                                      c_vp(w1.contiguous().data_ptr()), c_vp(b1.contiguous().data_ptr()),
+                                      c_vp(w2.contiguous().data_ptr()), c_vp(b2.contiguous().data_ptr()), c_vp(out.data_ptr()),
+                                      out.stride(0) if n > 1 else d_out, n, d_in, d_out, flags, float(slope), _stream(x)))
+    return out
+
+
 def bignn_wgrad_raw(g, p, x):
     """(G^T (P + X), G^T (P * X), sum_rows G): the weight / bias gradients of BiGNNConv (layers.py:54-58)."""
     for t, name in ((g, "g"), (p, "p"), (x, "x")):

@@ -1280,6 +1280,38 @@ def test_graphed_step_matches_eager(rbg, cuda, golden, name):
         assert abs(lg - le) <= 2e-4 * max(1.0, abs(le))
 
 
+@pytest.mark.parametrize("n,d_out", [(1, 64), (15, 64), (16, 32), (17, 48), (1000, 64), (4099, 4), (70841, 64), (200003, 64), (33000, 20)])
+def test_bignn_dense_dma_kernel(rbg, cuda, n, d_out):
+    """rbg_bignn_dense_f32 at the NGCF width (d_in = 64, d_out <= 64): the LDS-DMA kernel (rows by global_load_lds, weights in
+    registers, 16x16x4 MFMA on Y^T; `bignn_dma` option) against float64 of layers.py:56-58 [+ ngcf.py:96,98] and against the
+    general kernel, plain and fused-tail, with x / out as column slices of wider buffers (NGCF's concat buffer) and every
+    pipeline depth (1 tile per wave up to several, ragged last tile).  d_out = 20 / 48 / 4: partly padded 16-column tiles
+    (a d_out that is not a multiple of 4 takes the general kernel)."""
+    gen = torch.Generator().manual_seed(n * 7 + d_out)
+    xbuf = torch.randn(n, 64 + 8, generator=gen).to(cuda)
+    x = xbuf[:, 4:68]
+    p = torch.randn(n, 64, generator=gen).to(cuda)
+    w1, w2 = (torch.randn(d_out, 64, generator=gen) * 0.2).to(cuda), (torch.randn(d_out, 64, generator=gen) * 0.2).to(cuda)
+    b1, b2 = (torch.randn(d_out, generator=gen) * 0.1).to(cuda), (torch.randn(d_out, generator=gen) * 0.1).to(cuda)
+    p64, x64 = p.double().cpu(), x.double().cpu()
+    z = (p64 + x64) @ w1.double().cpu().T + b1.double().cpu() + (p64 * x64) @ w2.double().cpu().T + b2.double().cpu()
+    zn = torch.nn.functional.normalize(torch.nn.functional.leaky_relu(z, 0.2), p=2, dim=1)
+    assert rbg.get_option("bignn_dma") == 1
+    try:
+        for leaky, ref in ((False, z), (True, zn)):
+            ybuf = torch.full((n, d_out + 8), 7.0, device=cuda)
+            y = ybuf[:, 4:4 + d_out]
+            rbg.set_option("bignn_dma", 1)
+            rbg.ops.bignn_dense_raw(p, x, w1, b1, w2, b2, out=y, leaky_norm=leaky)
+            close(y, ref.float())
+            assert torch.all(ybuf[:, :4] == 7.0) and torch.all(ybuf[:, 4 + d_out:] == 7.0)  # nothing outside the slice
+            rbg.set_option("bignn_dma", 0)
+            y0 = rbg.ops.bignn_dense_raw(p, x, w1, b1, w2, b2, leaky_norm=leaky)
+            close(y, y0.cpu(), tol=5e-6)
+    finally:
+        rbg.set_option("bignn_dma", 1)
+
+
 @pytest.mark.parametrize("n,d_in,d_out", [(1, 8, 8), (33, 16, 24), (500, 64, 64), (257, 20, 50), (300, 128, 64), (129, 64, 128)])
 def test_bignn_layer_forward_backward(rbg, cuda, n, d_in, d_out):
     """ops.bignn_layer = normalize(LeakyReLU(BiGNNConv(x))) (layers.py:54-58, ngcf.py:96,98): value and all five gradients
