@@ -25,7 +25,7 @@ t0 = np.stack([t[x::8, :, 0].min() for x in range(8)])
 rel = t - t0[np.arange(256) % 8][:, None, None]
 rel[t == 0] = np.nan
 rel = rel.reshape(2048, 32)
-names = ["start", "w+tile0 landed", "barrier", "first fetch done"] + [f"t{i}:{nm}" for i in range(7) for nm in ("mfma issued", "next landed", "fetched+dma", "epilogue")]
+names = ["start", "w+tile0 landed", "barrier", "first fetch done"] + [f"t{i}:{nm}" for i in range(7) for nm in ("96 mfma + prev epilogue issued", "next tile fetched", "32 mfma + dma issued", "-")]
 prev = None
 for k in range(32):
     col = rel[:, k]

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "internal.h"
 #include "mfma_common.h"
@@ -236,24 +237,21 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
 }
 
 
-// ---- the NGCF configuration (d_in = 64, d_out <= 64): rows arrive by LDS-DMA, the weights live in registers ----------
+// ---- the NGCF configuration (d_in = 64, d_out in {16, 32, 48, 64}): rows by LDS-DMA, weights in registers ------------
 //
 // The kernel above spends most of its time fetching rows: a lane needs ITS row's contiguous k-run (the MFMA operand
 // layout ties lanes to rows), so every load instruction touches 64 cache lines for 16 bytes each, the lines are revisited by
 // the next seven instructions, and with 12 waves per CU their 196 KB of in-flight rows do not survive in the 32 KB L1.
-// Here a wave fetches a 16-row tile of P and of X as 8 fully coalesced 1 KiB `global_load_lds_dwordx4` requests straight
-// into its private 8 KB of LDS (no VGPR round trip, nothing for the L1 to keep), and then reads its k-runs back with
-// 8 conflict-free ds_read_b128: LDS-DMA writes lane-linear, so the 16-byte chunk c of tile row r is SOURCED into slot
-// c ^ r and read from slot c ^ r (same involution on both sides).
+// bignn_dense_pipe_kernel instead has a wave fetch a 16-row tile of P and of X as 8 fully coalesced 1 KiB
+// `global_load_lds_dwordx4` requests straight into LDS (no VGPR round trip, nothing for the L1 to keep) and read its k-runs
+// back with 8 conflict-free ds_read_b128: LDS-DMA writes lane-linear, so the 16-byte chunk c of tile row r is SOURCED into
+// slot c ^ r and read from slot c ^ r (same involution on both sides).
 // Matrix-core shape: v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand and the data rows as B, i.e. the tile of
 // Y^T: lane (n = lane & 15, g = lane >> 4) then holds output columns 16 t + 4 g .. + 3 of data row n — a float4 store per
 // column tile, one row norm per lane (in-lane sum + two cross-group shuffles), one rsqrt per tile instead of 16.
 // The concatenated weights are 128 registers per lane (W1 / W2 rows 16 t + n, k-run 16 g .. + 15), filled once per
-// persistent wave from a per-workgroup LDS copy (itself one DMA pass): the MFMA loop reads registers only.
-// Pipeline per wave (8 waves per CU, 2 per SIMD so one wave's epilogue runs under the other's MFMAs):
-//   MFMA(tile i) -> vmcnt(0) [tile i+1 landed long ago] -> ds_read tile i+1 -> lgkmcnt(0) -> DMA(tile i+2) -> epilogue(i)
-// so the stores of tile i are never waited on and a DMA has a whole tile of MFMAs to land.  (With a dropout mask the DMA
-// goes out after the epilogue: the mask loads are ordinary loads, and the wait hipcc places for them would drain it.)
+// persistent wave from a per-workgroup LDS copy (itself one DMA pass, biases included): the MFMA loop reads registers
+// only, and no load is visible to hipcc, whose own vmcnt waits would otherwise drain the DMA queue it does not count.
 __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {  // lds_dst: wave-uniform LDS byte address
     unsigned keep;
     asm volatile(
@@ -279,79 +277,81 @@ __device__ unsigned long long *g_bignn_trace = nullptr;
 #define RBG_STAMP(k) ((void)0)
 #endif
 
-__device__ __forceinline__ void pin8(float *a) {  // the compiler must have these eight registers' loads complete here
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-}
-
-// NT = 16-column output tiles held by a wave (d_out <= 16 NT); MASK = a dropout mask is applied (its own instantiation:
-// the wait hipcc places for the mask loads must not exist in the kernel that overlaps the DMA with the epilogue)
-template <int NT, bool MASK>
-__global__ __launch_bounds__(512) void bignn_dense_dma_kernel(const BignnParams p) {
-    constexpr int WAVES = 8;
-    __shared__ __attribute__((aligned(1024))) float tiles[WAVES * 2048];  // per wave: P tile [16][64], X tile [16][64]
-    __shared__ __attribute__((aligned(1024))) float wstage[2 * 64 * 64];   // W1, W2 [64][64], chunk-swizzled like the tiles
-    __shared__ __attribute__((aligned(1024))) float bstage[256];           // b1 [64], b2 [64] (+ the rest of the DMA's 1 KiB)
+// ONE wave per SIMD runs a rotated loop (a first version with two waves per SIMD and the epilogue after the MFMAs ran
+// 17.7 us at the Gowalla shape against 16.8 us: its clock trace showed a wave's own chain per tile — MFMA 4.1 k cycles,
+// wait / fetch / DMA issue 1-2 k, epilogue 2.5-3.5 k — and the three-tile waves setting the kernel time with the matrix
+// core 40 % busy):
+//     iteration k:  MFMA(tile k), first 3/4, with epilogue(tile k-1) in the same basic block (sched_group_barrier pattern)
+//                   counted vmcnt wait (tile k+1 was issued a tile ago), ds_read it
+//                   MFMA(tile k), last 1/4, with the DMA of tile k+2 spread between the k-steps
+// so the in-order instruction stream never waits on anything that is not long done.  Tiles are double-buffered in LDS
+// (the DMA for k+2 overwrites the buffer tile k was read from an iteration ago).  Rows past the end are CLAMPED copies of
+// the last row at the loads and at the stores (identical inputs give identical outputs, so the duplicate stores are
+// benign): no predicated store, no branch in the epilogue.
+// Steady state is 2.06 us per tile round against 1.73 us of pure MFMA time (devtools/microbench/mfma_rate.hip:
+// 13.5 ns per 16x16x4 instruction); the rest of the 16.8 us at the Gowalla shape is fixed: weights + first tiles ~3.8 us,
+// the fifth round that only a third of the waves have (4 428 tiles on 1 024 waves) 1.4 us, launch and drain.
+// TAIL = LeakyReLU + L2-normalize fused, INV = the row's 1 / norm is stored too, MASK = dropout mask between the two: compile
+// time, so that the epilogue is straight-line code the scheduler can spread between the MFMAs.
+template <int NT, bool MASK, bool TAIL, bool INV>
+__global__ __launch_bounds__(256) void bignn_dense_pipe_kernel(const BignnParams p) {
+    constexpr int WAVES = 4;
+    __shared__ __attribute__((aligned(1024))) float tiles[WAVES * 4096];  // per wave: 2 x {P tile [16][64], X tile [16][64]}
+    __shared__ __attribute__((aligned(1024))) float wstage[2 * 64 * 64];
+    __shared__ __attribute__((aligned(1024))) float bstage[256];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n = lane & 15, g = lane >> 4;
     const int64_t n_tiles = (p.n_rows + 15) >> 4;
     const int64_t stride = (int64_t)gridDim.x * WAVES;
-    int64_t tile = blockIdx.x + (int64_t)gridDim.x * wave;  // consecutive tiles go to different CUs
-    float *buf = tiles + wave * 2048;
+    int64_t tile = blockIdx.x + (int64_t)gridDim.x * wave;
+    float *buf = tiles + wave * 4096;
     const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)buf);
 
-    auto issue = [&](int64_t t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = 4 * j + g;  // this lane's destination is slot n of tile row rr; it sources chunk n ^ rr
-            const int64_t r = min(t * 16 + rr, p.n_rows - 1);
-            lds_dma16(p.P + r * 64 + 4 * (n ^ rr), buf_lds + j * 1024);
-            lds_dma16(p.X + r * p.ldx + 4 * (n ^ rr), buf_lds + 4096 + j * 1024);
-        }
+    auto issue_row = [&](int64_t t, int par, int j) __attribute__((always_inline)) {  // rows 4 j .. 4 j + 3 of tile t
+        const int rr = 4 * j + g;
+        const int64_t r = min(t * 16 + rr, p.n_rows - 1);
+        lds_dma16(p.P + r * 64 + 4 * (n ^ rr), buf_lds + par * 8192 + j * 1024);
+        lds_dma16(p.X + r * p.ldx + 4 * (n ^ rr), buf_lds + par * 8192 + 4096 + j * 1024);
     };
-    auto fetch = [&](float(&pv)[16], float(&xv)[16]) __attribute__((always_inline)) {
+    auto issue = [&](int64_t t, int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_row(t, par, j);
+    };
+    auto fetch = [&](int par, float(&pv)[16], float(&xv)[16]) __attribute__((always_inline)) {
+        const float *b = buf + par * 2048;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int slot = (4 * g + q) ^ n;
-            const float4 a = *reinterpret_cast<const float4 *>(buf + n * 64 + slot * 4);
-            const float4 b = *reinterpret_cast<const float4 *>(buf + 1024 + n * 64 + slot * 4);
+            const float4 a = *reinterpret_cast<const float4 *>(b + n * 64 + slot * 4);
+            const float4 c = *reinterpret_cast<const float4 *>(b + 1024 + n * 64 + slot * 4);
             pv[4 * q + 0] = a.x, pv[4 * q + 1] = a.y, pv[4 * q + 2] = a.z, pv[4 * q + 3] = a.w;
-            xv[4 * q + 0] = b.x, xv[4 * q + 1] = b.y, xv[4 * q + 2] = b.z, xv[4 * q + 3] = b.w;
+            xv[4 * q + 0] = c.x, xv[4 * q + 1] = c.y, xv[4 * q + 2] = c.z, xv[4 * q + 3] = c.w;
         }
     };
 
     RBG_STAMP(0);
-    // Two waves share a SIMD (w and w + 4).  Started together they would run their MFMA phases together and their epilogues
-    // together, leaving the matrix core idle through every epilogue; the older four get issue priority, so their MFMAs run
-    // at full rate first and from then on one wave's epilogue sits under the other's MFMAs.
-    if (wave < 4) __builtin_amdgcn_s_setprio(2);
-    const bool has_tile = tile < n_tiles;  // (wave-uniform) a wave without work still stages its share of the weights
-    // Weights and biases: staged ONCE per workgroup by DMA (each wave brings 8 rows of W1 / W2, coalesced; wave 0 also the
-    // two bias vectors), then every lane reads its A operands — rows 16 t + n of W1 / W2, k-run 16 g .. 16 g + 15 — into
-    // registers.  (Per-lane global loads of the same runs cost 64 cache lines per instruction and 32 KB per WAVE out of
-    // 256 L2 lines the whole grid shares: ~15 us.)  They go out BEFORE the first tile so that vmcnt(8) — requests retire
-    // in order — means "weights landed" while the tile is still in flight, and no load is visible to hipcc, whose waits
-    // would otherwise drain the DMA queue.
+    const bool has_tile = tile < n_tiles;
     {
         const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)wstage);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = 4 * wave + u, part = i >> 4, rr = 4 * (i & 15) + g;  // destination: slot n of weight row rr
+        for (int u = 0; u < 8; ++u) {
+            const int i = 8 * wave + u, part = i >> 4, rr = 4 * (i & 15) + g;
             const float *w = part ? p.W2 : p.W1;
             lds_dma16(w + min(rr, p.d_out - 1) * 64 + 4 * (n ^ (rr & 15)), w_lds + i * 1024);
         }
-        if (wave == 0) {  // lanes 0-15: b1[4 n ..], lanes 16-31: b2[4 n ..] (clamped inside the vectors; padded columns are zeroed below)
+        if (wave == 0) {
             const float *b = (g & 1) ? p.b2 : p.b1;
             lds_dma16(b + min(4 * n, p.d_out - 4), __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)bstage));
         }
     }
     if (has_tile) {
-        issue(tile);
+        issue(tile, 0);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     RBG_STAMP(1);
-    __syncthreads();  // every wave's share of the weights is in LDS (the only barrier of the kernel)
+    __syncthreads();
     RBG_STAMP(2);
     if (!has_tile) return;
     float w1[NT][16], w2[NT][16], bias[NT][4];
@@ -366,79 +366,40 @@ __global__ __launch_bounds__(512) void bignn_dense_dma_kernel(const BignnParams 
             w1[t][4 * q + 0] = a.x, w1[t][4 * q + 1] = a.y, w1[t][4 * q + 2] = a.z, w1[t][4 * q + 3] = a.w;
             w2[t][4 * q + 0] = b.x, w2[t][4 * q + 1] = b.y, w2[t][4 * q + 2] = b.z, w2[t][4 * q + 3] = b.w;
         }
-        const int c = 16 * t + 4 * g;  // this lane's four output columns of tile t (d_out is a multiple of 4)
-        const int cc = min(c, p.d_out - 4);
-        const float4 ba = *reinterpret_cast<const float4 *>(bstage + cc), bb = *reinterpret_cast<const float4 *>(bstage + 64 + cc);
-        const bool in = c < p.d_out;
-        bias[t][0] = in ? ba.x + bb.x : 0.f, bias[t][1] = in ? ba.y + bb.y : 0.f, bias[t][2] = in ? ba.z + bb.z : 0.f,
-        bias[t][3] = in ? ba.w + bb.w : 0.f;
+        const int c = 16 * t + 4 * g;
+        const float4 ba = *reinterpret_cast<const float4 *>(bstage + c), bb = *reinterpret_cast<const float4 *>(bstage + 64 + c);
+        bias[t][0] = ba.x + bb.x, bias[t][1] = ba.y + bb.y, bias[t][2] = ba.z + bb.z, bias[t][3] = ba.w + bb.w;
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {  // weight rows past d_out (the DMA clamped them to the last row) are zero
-        if (16 * t + n >= p.d_out) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) w1[t][s] = 0.f, w2[t][s] = 0.f;
-        }
-    }
-    float pv[16], xv[16];
+    float pv[16], xv[16], pn[16], xn[16];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    fetch(pv, xv);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads are done before the next DMA overwrites the tile
-    if (tile + stride < n_tiles) issue(tile + stride);
+    fetch(0, pv, xv);
+    if (tile + stride < n_tiles) issue(tile + stride, 1);
     RBG_STAMP(3);
-    int stamp = 4;
-    (void)stamp;
 
-    for (;;) {
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a1 = pv[s] + xv[s];  // lin1 operand (layers.py:56)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], a1, acc[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float a2 = pv[s] * xv[s];  // lin2 operand (layers.py:57)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][s], a2, acc[t], 0, 0, 0);
-        }
-        const int64_t next = tile + stride;
-        const bool more = next < n_tiles;
-        RBG_STAMP(stamp);  // (the last MFMA is issued, not necessarily complete)
-        if (more) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile `next` (issued a whole tile ago) is in LDS
-            RBG_STAMP(stamp + 1);
-            fetch(pv, xv);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // with a dropout mask the epilogue has compiler-visible loads, whose wait must not see a DMA behind them
-            if (!MASK && next + stride < n_tiles) issue(next + stride);
-        }
-        RBG_STAMP(stamp + 2);
-        // epilogue: lane (n, g) holds columns 16 t + 4 g + r of data row n
-        const int64_t row = tile * 16 + n;
-        const bool live = row < p.n_rows;
+    f32x4 acc[NT], old[NT];
+    int64_t old_tile = tile;
+    int par = 0;
+
+    // finishes a tile: lane (n, g) holds columns 16 t + 4 g + r of data row n
+    auto epilogue = [&](const f32x4(&a)[NT], int64_t t_id) __attribute__((always_inline)) {
+        const int64_t row = min(t_id * 16 + n, p.n_rows - 1);
         float v[NT][4];
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int c = 16 * t + 4 * g;
             float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-            if constexpr (MASK)
-                if (live && c < p.d_out) m = *reinterpret_cast<const float4 *>(p.drop_mask + row * p.d_out + c);
+            if constexpr (MASK) m = *reinterpret_cast<const float4 *>(p.drop_mask + row * p.d_out + 16 * t + 4 * g);
             const float mm[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = acc[t][r] + bias[t][r];
-                if (p.leaky_norm) x = x > 0.f ? x : x * p.slope;
+                float x = a[t][r] + bias[t][r];
+                if constexpr (TAIL) x = fmaxf(x, 0.f) + p.slope * fminf(x, 0.f);
                 if constexpr (MASK) x *= mm[r];
                 v[t][r] = x;
-                ss = fmaf(x, x, ss);  // padded columns hold exact zeros
+                ss = fmaf(x, x, ss);
             }
         }
-        if (p.leaky_norm) {
+        if constexpr (TAIL) {
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
             const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
@@ -446,21 +407,81 @@ __global__ __launch_bounds__(512) void bignn_dense_dma_kernel(const BignnParams 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[t][r] *= inv;
-            if (p.inv_norm && g == 0 && live) p.inv_norm[row] = inv;
+            if constexpr (INV) p.inv_norm[row] = inv;  // the four lane groups of a row hold the same value: no predicate
         }
-        if (live) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = 16 * t + 4 * g;
-                if (c < p.d_out) *reinterpret_cast<float4 *>(p.Y + row * p.ldy + c) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<float4 *>(p.Y + row * p.ldy + 16 * t + 4 * g) = make_float4(v[t][0], v[t][1], v[t][2], v[t][3]);
+    };
+    // the MFMAs of k-steps [s0, s1) of the concatenated K = 128 (steps 0-15: lin1 on P + X, 16-31: lin2 on P * X)
+    auto mfma_steps = [&](int s0, int s1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            const int k = s & 15;
+            const float a = s < 16 ? pv[k] + xv[k] : pv[k] * xv[k];  // layers.py:56 / :57
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(s < 16 ? w1[t][k] : w2[t][k], a, acc[t], 0, 0, 0);
+        }
+    };
+    auto body = [&](auto with_old) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_steps(0, 24);
+        if constexpr (decltype(with_old)::value) {
+            epilogue(old, old_tile);
+            // one MFMA, then the epilogue's VALU work in its 32-cycle shadow
+#pragma unroll
+            for (int i = 0; i < 24 * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, 3, 0);
             }
         }
-        RBG_STAMP(stamp + 3);
+    };
+
+    int stamp = 4;
+    (void)stamp;
+    // One iteration = the tile in (pv, xv).  Returns false after the wave's last tile.
+    auto iteration = [&](auto with_old) __attribute__((always_inline)) -> bool {
+        body(with_old);
+        const int64_t next = tile + stride;
+        const bool more = next < n_tiles;
+        RBG_STAMP(stamp);
+        if (more) {
+            // Tile `next` was issued a whole tile ago.  Requests retire in order, and the only ones younger than that
+            // DMA are the epilogue's NT + INV stores, so a counted wait does not sit on their acknowledgements.
+            if constexpr (decltype(with_old)::value)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT + (INV ? 1 : 0)) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fetch(par ^ 1, pn, xn);
+        }
+        RBG_STAMP(stamp + 1);
+        // the last 8 k-steps, with the DMA of tile k + 2 (into the buffer tile k was read from an iteration ago) spread
+        // between them so that its issue cost sits in MFMA shadows
+        const bool more2 = more && next + stride < n_tiles;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (more2) issue_row(next + stride, par, j);
+            mfma_steps(24 + 2 * j, 26 + 2 * j);
+        }
+        RBG_STAMP(stamp + 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) old[t] = acc[t];
+        old_tile = tile;
         stamp += 4;
-        if (!more) break;
-        if (MASK && next + stride < n_tiles) issue(next + stride);
+        if (!more) return false;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) pv[s] = pn[s], xv[s] = xn[s];
         tile = next;
-    }
+        par ^= 1;
+        return true;
+    };
+    if (iteration(std::false_type{}))
+        while (iteration(std::true_type{})) {
+        }
+    epilogue(old, old_tile);
+    RBG_STAMP(stamp);
 }
 
 static int device_cu_count() {
@@ -475,13 +496,20 @@ static int device_cu_count() {
 }
 
 template <int NT>
-static int launch_dense_dma(const BignnParams &p, hipStream_t s) {
+static int launch_dense_pipe(const BignnParams &p, hipStream_t s) {
     const int64_t n_tiles = (p.n_rows + 15) / 16;
-    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 7) / 8, device_cu_count()));
-    if (p.drop_mask)
-        hipLaunchKernelGGL((bignn_dense_dma_kernel<NT, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, device_cu_count()));
+    const dim3 gr((unsigned)grid), bl(256);
+    if (p.drop_mask && p.leaky_norm && p.inv_norm)
+        hipLaunchKernelGGL((bignn_dense_pipe_kernel<NT, true, true, true>), gr, bl, 0, s, p);
+    else if (p.drop_mask)
+        return fail(RBG_EINVAL, "a dropout mask needs the fused tail and the inv_norm buffer");
+    else if (p.leaky_norm && p.inv_norm)
+        hipLaunchKernelGGL((bignn_dense_pipe_kernel<NT, false, true, true>), gr, bl, 0, s, p);
+    else if (p.leaky_norm)
+        hipLaunchKernelGGL((bignn_dense_pipe_kernel<NT, false, true, false>), gr, bl, 0, s, p);
     else
-        hipLaunchKernelGGL((bignn_dense_dma_kernel<NT, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((bignn_dense_pipe_kernel<NT, false, false, false>), gr, bl, 0, s, p);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -537,8 +565,14 @@ static int bignn_conv_impl(const rbg_graph *g, int64_t n_rows, const float *X, i
     const bool vec_out = d_out % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 &&
                          (!p.drop_mask || (reinterpret_cast<uintptr_t>(p.drop_mask) & 15u) == 0) &&
                          ((reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2)) & 15u) == 0;
-    if (fast && d_in == 64 && d_out <= 64 && vec_out && opt_bignn_dma())
-        return d_out <= 32 ? launch_dense_dma<2>(p, s) : launch_dense_dma<4>(p, s);
+    if (fast && d_in == 64 && d_out <= 64 && d_out % 16 == 0 && vec_out && opt_bignn_dma()) {
+        switch (d_out / 16) {
+            case 1: return launch_dense_pipe<1>(p, s);
+            case 2: return launch_dense_pipe<2>(p, s);
+            case 3: return launch_dense_pipe<3>(p, s);
+            default: return launch_dense_pipe<4>(p, s);
+        }
+    }
     if (d_out <= 32) return launch_dense<1>(p, fast, s);
     if (d_out <= 64) return launch_dense<2>(p, fast, s);
     if (d_out <= 128) return launch_dense<4>(p, fast, s);
