@@ -156,7 +156,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
         fused = fused_step_applies(model)
     stepper = FusedBPRAdam(model, lr=lr) if fused else None
     graphed = graphed and not fused and next(model.parameters()).is_cuda and getattr(model, "graph_capturable", True)
-    opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr)
+    opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr, fused=next(model.parameters()).is_cuda)
     gstep = None
     history = []
     warm_up = getattr(model, "warm_up_step", None)  # NCLTrainer._train_epoch (trainer.py:130-133): the last loss term

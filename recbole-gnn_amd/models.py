@@ -250,12 +250,11 @@ class NGCF(GeneralGraphRecommender):
         torch.mul(st["val"], keep.index_select(0, st["tmap"]), out=st["buf_t"])  # A^T[r,c] = A[c,r]; the weights are symmetric
         return st["graph"]
 
-    def forward(self):
+    def _layer_outputs(self):
+        """[E(0), E(1), ..., E(K)] of ngcf.py:92-99 — what ngcf.py:100 concatenates — each [N, d_k]."""
         graph = self.graph
         if self.node_dropout != 0 and self.training:
             graph = self._dropout_graph()
-        elif not torch.is_grad_enabled() and self.message_dropout == 0 and self.fused:
-            return self._forward_fused()
         all_embeddings = self.get_ego_embeddings()
         embeddings_list = [all_embeddings]
         if self.fused and isinstance(graph, ops.GraphHandle) and max(self.hidden_size_list) <= 128:
@@ -266,15 +265,19 @@ class NGCF(GeneralGraphRecommender):
                 all_embeddings = ops.bignn_layer(all_embeddings, gnn.lin1.weight, gnn.lin1.bias, gnn.lin2.weight, gnn.lin2.bias,
                                                  graph, 0.2, p_drop=self.message_dropout)
                 embeddings_list += [all_embeddings]
-            ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
-            return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])
+            return embeddings_list
         for gnn in self.GNNlayers:
             all_embeddings = gnn(all_embeddings, graph, None)
             all_embeddings = F.leaky_relu(all_embeddings, negative_slope=0.2)
             all_embeddings = nn.Dropout(self.message_dropout)(all_embeddings)
             all_embeddings = F.normalize(all_embeddings, p=2, dim=1)
             embeddings_list += [all_embeddings]
-        ngcf_all_embeddings = torch.cat(embeddings_list, dim=1)
+        return embeddings_list
+
+    def forward(self):
+        if not (self.node_dropout != 0 and self.training) and not torch.is_grad_enabled() and self.message_dropout == 0 and self.fused:
+            return self._forward_fused()
+        ngcf_all_embeddings = torch.cat(self._layer_outputs(), dim=1)
         return torch.split(ngcf_all_embeddings, [self.n_users, self.n_items])
 
     def _forward_fused(self):
@@ -300,8 +303,14 @@ class NGCF(GeneralGraphRecommender):
         user = interaction[self.USER_ID]
         pos_item = interaction[self.ITEM_ID]
         neg_item = interaction[self.NEG_ITEM_ID]
-        user_all, item_all = self.forward()
-        u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
+        # ngcf.py:113-117 looks the batch up in the [N, sum(d)] concatenation; the rows of a concatenation are the
+        # concatenation of the rows, so the 3 B rows are gathered from each layer's output instead and the [N, sum(d)]
+        # tensor (72 MB at the Gowalla shape, forward copy + backward un-concatenation) is never formed in training
+        layers = self._layer_outputs()
+        b = user.shape[0]
+        idx = torch.cat([user, pos_item + self.n_users, neg_item + self.n_users])
+        rows = torch.cat([_rows(layer, idx) for layer in layers], dim=1)
+        u_e, pos_e, neg_e = rows[:b], rows[b:2 * b], rows[2 * b:]
         pos_scores = torch.mul(u_e, pos_e).sum(dim=1)
         neg_scores = torch.mul(u_e, neg_e).sum(dim=1)
         mf_loss = self.mf_loss(pos_scores, neg_scores)

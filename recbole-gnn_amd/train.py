@@ -108,7 +108,9 @@ class GraphedStep:
             raise RuntimeError(f"{type(model).__name__}.calculate_loss has data-dependent shapes (torch.unique) and cannot be "
                                "captured into a HIP graph; train it eagerly")
         self.model = model
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True)
+        # fused: one multi-tensor kernel per step instead of the foreach implementation's seven passes over the parameters
+        # (NGCF, Gowalla shape: 135 us of a 1 090 us step); same update rule (torch.optim.Adam, RecBole's default learner)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
         self.static = {k: v.detach().clone() for k, v in example_batch.items()}
         if not model.training:
             model.train()  # (not unconditionally: SGL.train() re-samples its augmented views, sgl.py:94-98)
