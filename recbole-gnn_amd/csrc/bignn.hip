@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "lds_dma.h"
 #include "mfma_common.h"
 
 namespace rbg {
@@ -252,19 +253,6 @@ static int launch_dense(const BignnParams &p, int fast, hipStream_t s) {
 // The concatenated weights are 128 registers per lane (W1 / W2 rows 16 t + n, k-run 16 g .. + 15), filled once per
 // persistent wave from a per-workgroup LDS copy (itself one DMA pass, biases included): the MFMA loop reads registers
 // only, and no load is visible to hipcc, whose own vmcnt waits would otherwise drain the DMA queue it does not count.
-__device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_dst) {  // lds_dst: wave-uniform LDS byte address
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
 // Per-wave clock trace (devtools/microbench/bignn_trace.hip builds this file with RBG_BIGNN_TRACE; the product does not):
 // slot k of wave w receives s_memtime at stamp k.
 #ifdef RBG_BIGNN_TRACE

@@ -15,6 +15,7 @@
 #include <atomic>
 
 #include "internal.h"
+#include "lds_dma.h"
 #include "mfma_common.h"
 
 namespace rbg {
@@ -439,6 +440,172 @@ static int launch_dgrad(const DgradParams &p, bool fast, hipStream_t s) {
     return RBG_OK;
 }
 
+// ---- the NGCF configuration (d_in = d_out = 64): every operand tile arrives by LDS-DMA, the weights live in registers --
+//
+// The same recipe as bignn_dense_pipe_kernel (bignn.hip, lds_dma.h), for a kernel that is bound by memory rather than by
+// the matrix core: per row it reads GY, Y, the dropout mask, X, P (5 x 256 B) and writes G, GP, GX (3 x 256 B) against
+// 2 x 64 x 64 MACs.  One wave per SIMD; per 16-row tile
+//     counted vmcnt wait -> ds_read everything the tile needs into registers -> DMA of the next tile into the same
+//     buffers -> tail backward in the k-run layout (lane = row, 16 k per lane; row dot = in-lane + two shuffles) -> G out
+//     -> 128 x v_mfma_f32_16x16x4_f32 on the transposed products (A = Wt rows, B = G rows) -> GP, GX out as float4
+// so a DMA has the whole tile's compute to land and nothing compiler-visible is loaded inside the loop (the row's 1 / norm
+// comes by a 4-byte-per-lane DMA).  Rows past the end are clamped copies at the loads and the stores (identical inputs,
+// identical outputs): the stores are unconditional, which is what makes the wait countable (12 stores per tile).
+template <bool TAIL, bool MASK>
+__global__ __launch_bounds__(256) void bignn_dgrad_dma_kernel(const DgradParams p) {
+    constexpr int WAVES = 4, NT = 4;
+    constexpr int kGY = 0, kX = 1024, kP = 2048, kY = 3072, kM = 4096, kInv = 5120;  // float offsets in a wave's buffer
+    constexpr int kPerWave = TAIL ? 5376 : 3072;
+    constexpr int kDmaOps = 12 + (TAIL ? 5 : 0) + (MASK ? 4 : 0);  // requests per tile
+    __shared__ __attribute__((aligned(1024))) float tiles[WAVES * kPerWave];
+    __shared__ __attribute__((aligned(1024))) float wstage[2 * 64 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = lane & 15, g = lane >> 4;
+    const int64_t n_tiles = (p.n_rows + 15) >> 4;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t tile = blockIdx.x + (int64_t)gridDim.x * wave;
+    const float *buf = tiles + wave * kPerWave;
+    const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)buf);
+
+    auto issue = [&](int64_t t) __attribute__((always_inline)) {
+        tile_dma(p.GY, p.ldgy, t, p.n_rows, buf_lds + kGY * 4, n, g);
+        if constexpr (TAIL) {
+            tile_dma(p.Y, p.ldy, t, p.n_rows, buf_lds + kY * 4, n, g);
+            if constexpr (MASK) tile_dma(p.drop_mask, 64, t, p.n_rows, buf_lds + kM * 4, n, g);
+            lds_dma4(p.inv_norm + min(t * 16 + n, p.n_rows - 1), buf_lds + kInv * 4);  // lanes 16 g + n: four copies of 16 values
+        }
+        tile_dma(p.X, p.ldx, t, p.n_rows, buf_lds + kX * 4, n, g);
+        tile_dma(p.P, 64, t, p.n_rows, buf_lds + kP * 4, n, g);
+    };
+
+    // transposed weights: staged once per workgroup by DMA, then this lane's A operands — rows 16 t + n of Wt1 / Wt2
+    // (input column c = 16 t + n), k-run 16 g .. 16 g + 15 of the output features — into registers
+    {
+        const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)wstage);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 8 * wave + u, part = i >> 4, rr = 4 * (i & 15) + g;
+            const float *w = part ? p.Wt2 : p.Wt1;
+            lds_dma16(w + rr * 64 + 4 * (n ^ (rr & 15)), w_lds + i * 1024);
+        }
+    }
+    const bool has_tile = tile < n_tiles;
+    if (has_tile) {
+        issue(tile);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaOps) : "memory");  // in-order: the weights have landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!has_tile) return;
+    float w1[NT][16], w2[NT][16];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        tile_run(wstage + 16 * t * 64, n, g, w1[t]);
+        tile_run(wstage + 4096 + 16 * t * 64, n, g, w2[t]);
+    }
+
+    bool first = true;
+    for (;;) {
+        // everything of this tile into registers, then the buffers belong to the next tile's DMA
+        if (first)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // only the previous tile's 12 stores are younger than this DMA
+        first = false;
+        float gy[16], xv[NT][4], pv[NT][4];
+        tile_run(buf + kGY, n, g, gy);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 a = tile_cols(buf + kX, n, g, t), b = tile_cols(buf + kP, n, g, t);
+            xv[t][0] = a.x, xv[t][1] = a.y, xv[t][2] = a.z, xv[t][3] = a.w;
+            pv[t][0] = b.x, pv[t][1] = b.y, pv[t][2] = b.z, pv[t][3] = b.w;
+        }
+        if constexpr (TAIL) {
+            // G = dL/dz from the saved output y = normalize(mask * LeakyReLU(z)) and 1 / ||a|| (ngcf.py:96-98 backwards)
+            float yv[16], mk[16];
+            tile_run(buf + kY, n, g, yv);
+            if constexpr (MASK) tile_run(buf + kM, n, g, mk);
+            const float inv = buf[kInv + n];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t next = tile + stride;
+            if (next < n_tiles) issue(next);
+            float dot = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dot = fmaf(gy[s], yv[s], dot);
+            dot += __shfl_xor(dot, 16);
+            dot += __shfl_xor(dot, 32);
+            const bool clamped = inv >= 1e12f;  // ||a|| < eps: normalize is a / eps, a plain scaling
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float y = yv[s];
+                float da = (clamped ? gy[s] : gy[s] - y * dot) * inv;
+                if constexpr (MASK) da *= mk[s];   // dropout sits between LeakyReLU and normalize
+                gy[s] = y > 0.f ? da : da * p.slope;  // sign(z) = sign(y) where kept; LeakyReLU'(0) = slope as in torch
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t next = tile + stride;
+            if (next < n_tiles) issue(next);
+        }
+        const int64_t row = min(tile * 16 + n, p.n_rows - 1);
+        {
+            float *grow = p.G + row * 64 + 16 * g;  // G is also the operand of the weight-gradient kernel
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(grow + 4 * q) = make_float4(gy[4 * q + 0], gy[4 * q + 1], gy[4 * q + 2], gy[4 * q + 3]);
+        }
+        f32x4 at[NT], ai[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) at[t] = ai[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], gy[s], at[t], 0, 0, 0);  // gt = G W1
+                ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][s], gy[s], ai[t], 0, 0, 0);  // gi = G W2
+            }
+        }
+        // lane (n, g) holds input columns 16 t + 4 g + r of row n
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float4 gp, gx;
+            gp.x = fmaf(ai[t][0], xv[t][0], at[t][0]), gx.x = fmaf(ai[t][0], pv[t][0], at[t][0]);
+            gp.y = fmaf(ai[t][1], xv[t][1], at[t][1]), gx.y = fmaf(ai[t][1], pv[t][1], at[t][1]);
+            gp.z = fmaf(ai[t][2], xv[t][2], at[t][2]), gx.z = fmaf(ai[t][2], pv[t][2], at[t][2]);
+            gp.w = fmaf(ai[t][3], xv[t][3], at[t][3]), gx.w = fmaf(ai[t][3], pv[t][3], at[t][3]);
+            *reinterpret_cast<float4 *>(p.GP + row * 64 + 16 * t + 4 * g) = gp;  // d/dP (to be propagated)
+            *reinterpret_cast<float4 *>(p.GX + row * 64 + 16 * t + 4 * g) = gx;  // the direct part of d/dX
+        }
+        tile += stride;
+        if (tile >= n_tiles) break;
+    }
+}
+
+static int dgrad_cu_count() {
+    static std::atomic<int> cached{0};
+    int v = cached.load();
+    if (v > 0) return v;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+        v = 256;
+    cached = v;
+    return v;
+}
+
+static int launch_dgrad_dma(const DgradParams &p, hipStream_t s) {
+    const int64_t n_tiles = (p.n_rows + 15) / 16;
+    const dim3 gr((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, dgrad_cu_count()))), bl(256);
+    if (p.inv_norm && p.drop_mask)
+        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<true, true>), gr, bl, 0, s, p);
+    else if (p.inv_norm)
+        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<true, false>), gr, bl, 0, s, p);
+    else
+        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<false, false>), gr, bl, 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
 template <int TI>
 static int launch_dgrad_i(const DgradParams &p, bool fast, hipStream_t s) {
     if (p.d_out <= 64) return launch_dgrad<TI, 1>(p, fast, s);
@@ -537,7 +704,10 @@ int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, 
     p.Wt1 = Wt1, p.Wt2 = Wt2, p.G = G, p.GP = GP, p.GX = GX, p.n_rows = n, p.d_in = d_in, p.d_out = d_out, p.slope = slope;
     const bool fast = (d_out % 64 == 0) && (ldgy % 4 == 0) && (!inv_norm || ldy % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(GY) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(drop_mask)) & 15u) == 0;
-    if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
+    const bool dma = fast && opt_bignn_dma() && d_in == 64 && d_out == 64 && ldx % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(GX)) & 15u) == 0;
+    if (dma) rc = launch_dgrad_dma(p, s);
+    else if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
     else if (d_in <= 64) rc = launch_dgrad_i<2>(p, fast, s);
     else rc = launch_dgrad_i<4>(p, fast, s);
     if (rc) return rc;

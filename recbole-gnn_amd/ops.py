@@ -352,23 +352,33 @@ class _BiGNNLayer(torch.autograd.Function):
     def backward(ctx, gy):
         x, p, y, inv, w1, w2 = ctx.saved_tensors[:6]
         mask = ctx.saved_tensors[6] if ctx.has_mask else None
-        gy = gy if gy.stride(1) == 1 else gy.contiguous()
-        n, d_in = x.shape
-        d_out = w1.shape[0]
-        gx = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
-        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
-        gb = torch.empty(d_out, dtype=torch.float32, device=x.device)
-        nbytes = _lib.c_i64()
-        check(lib.rbg_bignn_backward_workspace(n, d_in, d_out, ctypes.byref(nbytes)))
-        work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
-            check(lib.rbg_bignn_backward_f32(ctx.graph.transpose().ptr, c_vp(gy.data_ptr()), gy.stride(0) if n > 1 else d_out,
-                                             c_vp(y.data_ptr()), d_out, c_vp(inv.data_ptr()),
-                                             c_vp(mask.data_ptr()) if mask is not None else None, c_vp(x.data_ptr()),
-                                             x.stride(0) if n > 1 else d_in, c_vp(p.data_ptr()), c_vp(w1.data_ptr()),
-                                             c_vp(w2.data_ptr()), d_in, d_out, ctx.slope, c_vp(gx.data_ptr()), c_vp(gw1.data_ptr()),
-                                             c_vp(gw2.data_ptr()), c_vp(gb.data_ptr()), c_vp(work.data_ptr()), _stream(x)))
+        gx, gw1, gw2, gb = bignn_backward_raw(ctx.graph.transpose(), gy, y, inv, mask, x, p, w1, w2, ctx.slope)
         return gx, gw1, gb, gw2, gb, None, None, None
+
+
+def bignn_backward_raw(graph_t, gy, y, inv, mask, x, p, w1, w2, slope=0.2):
+    """rbg_bignn_backward_f32: the backward of one NGCF layer (autograd of layers.py:54-58 [+ ngcf.py:96-98 when ``inv`` —
+    the rows' 1 / norm saved by the forward — is given; ``mask`` is the forward's scaled dropout mask]) from the upstream
+    gradient ``gy``, the saved output ``y``, input ``x`` and product ``p`` = Â·x.  ``graph_t`` is the TRANSPOSED graph.
+    Returns (dX, dW1, dW2, db)."""
+    gy = gy if gy.stride(1) == 1 else gy.contiguous()
+    n, d_in = x.shape
+    d_out = w1.shape[0]
+    gx = torch.empty((n, d_in), dtype=torch.float32, device=x.device)
+    gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+    gb = torch.empty(d_out, dtype=torch.float32, device=x.device)
+    nbytes = _lib.c_i64()
+    check(lib.rbg_bignn_backward_workspace(n, d_in, d_out, ctypes.byref(nbytes)))
+    work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.rbg_bignn_backward_f32(graph_t.ptr, c_vp(gy.data_ptr()), gy.stride(0) if n > 1 else d_out,
+                                         c_vp(y.data_ptr()) if y is not None else None, d_out,
+                                         c_vp(inv.data_ptr()) if inv is not None else None,
+                                         c_vp(mask.data_ptr()) if mask is not None else None, c_vp(x.data_ptr()),
+                                         x.stride(0) if n > 1 else d_in, c_vp(p.data_ptr()), c_vp(w1.data_ptr()),
+                                         c_vp(w2.data_ptr()), d_in, d_out, float(slope), c_vp(gx.data_ptr()), c_vp(gw1.data_ptr()),
+                                         c_vp(gw2.data_ptr()), c_vp(gb.data_ptr()), c_vp(work.data_ptr()), _stream(x)))
+    return gx, gw1, gw2, gb
 
 
 def bignn_layer(x, w1, b1, w2, b2, graph, slope=0.2, p_drop=0.0, mask=None):

@@ -1361,6 +1361,65 @@ def test_bignn_layer_forward_backward(rbg, cuda, n, d_in, d_out):
         assert abs(float((yd == 0).float().mean()) - 0.25) < 0.05
 
 
+@pytest.mark.parametrize("n", [17, 4099, 70841, 150001])
+@pytest.mark.parametrize("variant", ["plain", "tail", "tail+mask"])
+def test_bignn_backward_dma_kernel(rbg, cuda, n, variant):
+    """rbg_bignn_backward_f32 at d_in = d_out = 64: the LDS-DMA input-gradient kernel (`bignn_dma` option; every pipeline
+    depth, ragged last tile) against the general kernel — dX, dW1, dW2, db — and, at the small sizes, against float64
+    autograd of layers.py:54-58 [+ ngcf.py:96-98]; gy / x are column slices of wider buffers."""
+    rng = np.random.default_rng(n)
+    nu = n // 2
+    ni = n - nu
+    e = 4 * n
+    h = rbg.GraphHandle.from_interactions(rng.integers(0, nu, e), rng.integers(0, ni, e), nu, ni, device=cuda)
+    gen = torch.Generator().manual_seed(n + 3)
+    xbuf, gbuf = torch.randn(n, 72, generator=gen).to(cuda), torch.randn(n, 80, generator=gen).to(cuda)
+    x, gy = xbuf[:, 4:68], gbuf[:, 8:72]
+    w1, w2 = (torch.randn(64, 64, generator=gen) * 0.2).to(cuda), (torch.randn(64, 64, generator=gen) * 0.2).to(cuda)
+    b1, b2 = (torch.randn(64, generator=gen) * 0.1).to(cuda), (torch.randn(64, generator=gen) * 0.1).to(cuda)
+    mask = ((torch.rand(n, 64, generator=gen) >= 0.3).float() / 0.7).to(cuda) if variant == "tail+mask" else None
+    p = rbg.ops.spmm_raw(h, x.contiguous())
+    if variant == "plain":
+        y, inv = None, None
+    else:  # the forward of the fused layer gives y and the rows' 1 / norm
+        z = (p + x) @ w1.T + b1 + (p * x) @ w2.T + b2
+        a = torch.nn.functional.leaky_relu(z, 0.2)
+        if mask is not None:
+            a = a * mask
+        norm = a.norm(dim=1)
+        inv = 1.0 / norm.clamp_min(1e-12)
+        y = a * inv[:, None]
+    out = {}
+    try:
+        for opt in (1, 0):
+            rbg.set_option("bignn_dma", opt)
+            out[opt] = rbg.ops.bignn_backward_raw(h.transpose(), gy, y, inv, mask, x, p, w1, w2, 0.2)
+    finally:
+        rbg.set_option("bignn_dma", 1)
+    for got, ref, name in zip(out[1], out[0], ("dX", "dW1", "dW2", "db")):
+        scale = max(1.0, float(ref.abs().max()))
+        err = float((got - ref).abs().max())
+        assert err <= 1e-5 * scale, (name, err, scale)
+    if n <= 5000:  # float64 autograd of the reference expression on the dense operator
+        rp, c, v = h.export_csr()
+        dense = torch.zeros(n, n, dtype=torch.float64)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        dense.index_put_((torch.from_numpy(rows), torch.from_numpy(c.astype(np.int64))), torch.from_numpy(v.astype(np.float64)), accumulate=True)
+        xr, w1r, b1r, w2r, b2r = [t.detach().double().cpu().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        pr = dense @ xr
+        zr = (pr + xr) @ w1r.T + b1r + (pr * xr) @ w2r.T + b2r
+        if variant != "plain":
+            zr = torch.nn.functional.leaky_relu(zr, 0.2)
+            if mask is not None:
+                zr = zr * mask.double().cpu()
+            zr = torch.nn.functional.normalize(zr, p=2, dim=1)
+        (zr * gy.double().cpu()).sum().backward()
+        for got, ref, name in zip(out[1], (xr.grad, w1r.grad, w2r.grad, b1r.grad), ("dX", "dW1", "dW2", "db")):
+            scale = max(1.0, float(ref.abs().max()))
+            err = float((got.cpu().double() - ref).abs().max())
+            assert err <= 3e-5 * scale, (name, err, scale)
+
+
 def test_ngcf_fused_training_path_matches_op_by_op(rbg, cuda, golden):
     """NGCF.calculate_loss through the fused layers (default) and through the op-by-op structure of ngcf.py:92-104
     (fused_forward=False): same loss, same gradients."""
