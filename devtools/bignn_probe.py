@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import recbole_gnn_amd as rbg  # noqa: E402
 
 dev = torch.device("cuda:0")
+DEFAULT = rbg.get_option("bignn_dma")
 
 
 def time_us(fn, iters=200, warm=10, per_graph=20):
@@ -53,7 +54,7 @@ for shape in ("gowalla", "yelp2018", "amazon-book"):
             for v in (1, 0):
                 rbg.set_option("bignn_dma", v)
                 res[v].append(time_us(run))
-        rbg.set_option("bignn_dma", 1)
+        rbg.set_option("bignn_dma", DEFAULT)
         bytes_ = 3 * n * 64 * 4
         rec = dict(kind="bignn_dense", shape=shape, rows=n, leaky_norm=leaky, us_dma=sorted(res[1])[1], us_general=sorted(res[0])[1],
                    hbm_frac_dma=bytes_ / (sorted(res[1])[1] * 1e-6) / 8e12)
@@ -72,7 +73,7 @@ for _ in range(3):
     for v in (1, 0):
         rbg.set_option("bignn_dma", v)
         res[v].append(time_us(layer))
-rbg.set_option("bignn_dma", 1)
+rbg.set_option("bignn_dma", DEFAULT)
 rec = dict(kind="bignn_layer", shape="gowalla", us_dma=sorted(res[1])[1], us_general=sorted(res[0])[1],
            us_spmm=time_us(lambda: rbg.ops.spmm_raw(g, x, out=y)))
 print(json.dumps(rec), flush=True)

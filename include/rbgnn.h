@@ -84,9 +84,9 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   halving the per-XCD gather working set): -1 = auto (d = 128 and a table <= 512 MB), 0 = off, 1 = on where eligible
  *   "sweep"       : 1 = SpMM launches use the column-sweep plan attached to the graph for that width (if any), 0 = binned kernel
  *   "sweep_lean"  : sweep kernel at d = 64: 1 (default) = DPP row broadcasts + buffer loads in the gather, 0 = the plain gather
- *   "bignn_dma"   : BiGNN dense layer at d_in = 64, d_out in {16, 32, 48, 64}: 1 (default) = rows arrive by LDS-DMA, the
- *                   weights live in registers, one software-pipelined wave per SIMD (16x16x4 fp32 MFMA on Y^T);
- *                   0 = the general kernel
+ *   "bignn_dma"   : the NGCF configuration (d_in = 64; forward d_out in {16, 32, 48, 64}, backward d_out = 64): 1 (default) =
+ *                   row tiles arrive by LDS-DMA (forward: weights in registers, one software-pipelined wave per SIMD,
+ *                   16x16x4 fp32 MFMA on Y^T; backward: input AND weight gradients in one kernel); 0 = the general kernels
  *   "mfma_split"  : 1 (default) = rbg_score_f32 / rbg_full_sort_topk_f32 split both fp32 operands into three bf16 terms and
  *                   form the six products of order >= 2^-16 on the bf16 matrix cores (fp32-MFMA accuracy at 2.3x its
  *                   rate); 0 = the exact-fp32 MFMA chain

@@ -440,23 +440,40 @@ static int launch_dgrad(const DgradParams &p, bool fast, hipStream_t s) {
     return RBG_OK;
 }
 
-// ---- the NGCF configuration (d_in = d_out = 64): every operand tile arrives by LDS-DMA, the weights live in registers --
+// ---- the NGCF configuration (d_in = d_out = 64): the whole layer backward but the propagation in ONE kernel ----------
 //
-// The same recipe as bignn_dense_pipe_kernel (bignn.hip, lds_dma.h), for a kernel that is bound by memory rather than by
-// the matrix core: per row it reads GY, Y, the dropout mask, X, P (5 x 256 B) and writes G, GP, GX (3 x 256 B) against
-// 2 x 64 x 64 MACs.  One wave per SIMD; per 16-row tile
-//     counted vmcnt wait -> ds_read everything the tile needs into registers -> DMA of the next tile into the same
-//     buffers -> tail backward in the k-run layout (lane = row, 16 k per lane; row dot = in-lane + two shuffles) -> G out
-//     -> 128 x v_mfma_f32_16x16x4_f32 on the transposed products (A = Wt rows, B = G rows) -> GP, GX out as float4
-// so a DMA has the whole tile's compute to land and nothing compiler-visible is loaded inside the loop (the row's 1 / norm
-// comes by a 4-byte-per-lane DMA).  Rows past the end are clamped copies at the loads and the stores (identical inputs,
-// identical outputs): the stores are unconditional, which is what makes the wait countable (12 stores per tile).
+// The same recipe as bignn_dense_pipe_kernel (bignn.hip, lds_dma.h).  Per row the input-gradient part reads GY, Y, the
+// dropout mask, X, P (5 x 256 B) and writes GP, GX against 2 x 64 x 64 MACs — bound by memory, with the matrix core mostly
+// idle (as a kernel of its own it ran 26.5 us at the Gowalla shape, 50.7 us before LDS-DMA) — and the weight gradients
+//     dW1 = G^T (P + X),  dW2 = G^T (P * X),  db = column sums of G          (layers.py:56-57 backwards)
+// need exactly the tiles that kernel holds (a separate kernel re-read G, P, X: 54 MB, 21.5 us).  So one wave per SIMD, per
+// 16-row tile:
+//     counted vmcnt wait -> ds_read everything the tile needs into registers (k-runs of GY / Y / mask, the output-layout
+//     columns of X and P, and COLUMNS of X and P — rows 4 s + g, column 16 t + n — for the weight gradients)
+//     -> tail backward in the k-run layout (lane = row; row dot = in-lane + two shuffles); G goes to a private LDS tile
+//        (it is never written to memory) and comes back as columns, the A operand of the weight gradients
+//     -> 128 x v_mfma_f32_16x16x4_f32 for gt = G W1, gi = G W2 (A = Wt rows read from the workgroup's LDS copy four k-steps
+//        at a time, B = G rows), the next tile's DMA issued a quarter per k-group in their shadows
+//     -> 128 more for dW1 / dW2 into 32 f32x4 accumulators (AGPRs); rows past the end enter with G = 0
+//     -> GP = gt + gi * X, GX = gt + gi * P as float4 stores (rows past the end are clamped copies: unconditional stores,
+//        which is what makes the wait countable — 8 stores per tile are the only requests younger than the next DMA).
+// Nothing compiler-visible is loaded from memory inside the loop (the row's 1 / norm comes by a 4-byte-per-lane DMA).
+// At the end (w0 + w2) + (w1 + w3) is formed through LDS and the workgroup writes ONE partial result (<= 256 per launch);
+// wgrad_reduce_kernel sums the partials in a fixed order, so the result is bit-reproducible like the two-kernel path.
+__device__ __forceinline__ float row16_sum(float x) {  // sum over the 16 lanes of a DPP row, result in every lane
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));  // row_mirror
+    return x;
+}
+
 template <bool TAIL, bool MASK>
-__global__ __launch_bounds__(256) void bignn_dgrad_dma_kernel(const DgradParams p) {
+__global__ __launch_bounds__(256) void bignn_backward_fused_kernel(const DgradParams p, float *__restrict__ part) {
     constexpr int WAVES = 4, NT = 4;
-    constexpr int kGY = 0, kX = 1024, kP = 2048, kY = 3072, kM = 4096, kInv = 5120;  // float offsets in a wave's buffer
-    constexpr int kPerWave = TAIL ? 5376 : 3072;
-    constexpr int kDmaOps = 12 + (TAIL ? 5 : 0) + (MASK ? 4 : 0);  // requests per tile
+    constexpr int kGY = 0, kX = 1024, kP = 2048, kG = 3072, kY = 4096, kM = 5120, kInv = 6144;  // float offsets in a wave's buffer
+    constexpr int kPerWave = TAIL ? 6400 : 4096;
+    constexpr int kDmaOps = 12 + (TAIL ? 5 : 0) + (MASK ? 4 : 0);
     __shared__ __attribute__((aligned(1024))) float tiles[WAVES * kPerWave];
     __shared__ __attribute__((aligned(1024))) float wstage[2 * 64 * 64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256) void bignn_dgrad_dma_kernel(const DgradParams 
     const int64_t n_tiles = (p.n_rows + 15) >> 4;
     const int64_t stride = (int64_t)gridDim.x * WAVES;
     int64_t tile = blockIdx.x + (int64_t)gridDim.x * wave;
-    const float *buf = tiles + wave * kPerWave;
+    float *buf = tiles + wave * kPerWave;
     const unsigned buf_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)buf);
 
     auto issue = [&](int64_t t) __attribute__((always_inline)) {
@@ -472,113 +489,226 @@ __global__ __launch_bounds__(256) void bignn_dgrad_dma_kernel(const DgradParams 
         if constexpr (TAIL) {
             tile_dma(p.Y, p.ldy, t, p.n_rows, buf_lds + kY * 4, n, g);
             if constexpr (MASK) tile_dma(p.drop_mask, 64, t, p.n_rows, buf_lds + kM * 4, n, g);
-            lds_dma4(p.inv_norm + min(t * 16 + n, p.n_rows - 1), buf_lds + kInv * 4);  // lanes 16 g + n: four copies of 16 values
+            lds_dma4(p.inv_norm + min(t * 16 + n, p.n_rows - 1), buf_lds + kInv * 4);
         }
         tile_dma(p.X, p.ldx, t, p.n_rows, buf_lds + kX * 4, n, g);
         tile_dma(p.P, 64, t, p.n_rows, buf_lds + kP * 4, n, g);
     };
+    auto issue_part = [&](int64_t t, int q) __attribute__((always_inline)) {  // the same requests in four instalments
+        if (q == 0) {
+            tile_dma(p.GY, p.ldgy, t, p.n_rows, buf_lds + kGY * 4, n, g);
+            if constexpr (TAIL) lds_dma4(p.inv_norm + min(t * 16 + n, p.n_rows - 1), buf_lds + kInv * 4);
+        } else if (q == 1) {
+            if constexpr (TAIL) tile_dma(p.Y, p.ldy, t, p.n_rows, buf_lds + kY * 4, n, g);
+            if constexpr (MASK) tile_dma(p.drop_mask, 64, t, p.n_rows, buf_lds + kM * 4, n, g);
+        } else if (q == 2) {
+            tile_dma(p.X, p.ldx, t, p.n_rows, buf_lds + kX * 4, n, g);
+        } else {
+            tile_dma(p.P, 64, t, p.n_rows, buf_lds + kP * 4, n, g);
+        }
+    };
+    // element (row, 16 tc + n) of a swizzled tile: this lane's column of tile row `row`
+    auto col_at = [&](const float *t, int row, int tc) __attribute__((always_inline)) {
+        return t[row * 64 + (((4 * tc + (n >> 2)) ^ row) << 2) + (n & 3)];
+    };
 
-    // transposed weights: staged once per workgroup by DMA, then this lane's A operands — rows 16 t + n of Wt1 / Wt2
-    // (input column c = 16 t + n), k-run 16 g .. 16 g + 15 of the output features — into registers
     {
         const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)wstage);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = 8 * wave + u, part = i >> 4, rr = 4 * (i & 15) + g;
-            const float *w = part ? p.Wt2 : p.Wt1;
+            const int i = 8 * wave + u, part_i = i >> 4, rr = 4 * (i & 15) + g;
+            const float *w = part_i ? p.Wt2 : p.Wt1;
             lds_dma16(w + rr * 64 + 4 * (n ^ (rr & 15)), w_lds + i * 1024);
         }
     }
     const bool has_tile = tile < n_tiles;
     if (has_tile) {
         issue(tile);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaOps) : "memory");  // in-order: the weights have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDmaOps) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (!has_tile) return;
-    float w1[NT][16], w2[NT][16];
+    f32x4 dw1[NT][NT], dw2[NT][NT];  // [tj][tc]: lane (n, g) holds dW[16 tj + 4 g + r][16 tc + n]
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        tile_run(wstage + 16 * t * 64, n, g, w1[t]);
-        tile_run(wstage + 4096 + 16 * t * 64, n, g, w2[t]);
-    }
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) dw1[a][b] = dw2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float colsum[16];  // sum over this lane's rows of G[row][16 g + s]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) colsum[s] = 0.f;
 
-    bool first = true;
-    for (;;) {
-        // everything of this tile into registers, then the buffers belong to the next tile's DMA
-        if (first)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // only the previous tile's 12 stores are younger than this DMA
-        first = false;
-        float gy[16], xv[NT][4], pv[NT][4];
-        tile_run(buf + kGY, n, g, gy);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float4 a = tile_cols(buf + kX, n, g, t), b = tile_cols(buf + kP, n, g, t);
-            xv[t][0] = a.x, xv[t][1] = a.y, xv[t][2] = a.z, xv[t][3] = a.w;
-            pv[t][0] = b.x, pv[t][1] = b.y, pv[t][2] = b.z, pv[t][3] = b.w;
-        }
-        if constexpr (TAIL) {
-            // G = dL/dz from the saved output y = normalize(mask * LeakyReLU(z)) and 1 / ||a|| (ngcf.py:96-98 backwards)
-            float yv[16], mk[16];
-            tile_run(buf + kY, n, g, yv);
-            if constexpr (MASK) tile_run(buf + kM, n, g, mk);
-            const float inv = buf[kInv + n];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int64_t next = tile + stride;
-            if (next < n_tiles) issue(next);
-            float dot = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) dot = fmaf(gy[s], yv[s], dot);
-            dot += __shfl_xor(dot, 16);
-            dot += __shfl_xor(dot, 32);
-            const bool clamped = inv >= 1e12f;  // ||a|| < eps: normalize is a / eps, a plain scaling
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float y = yv[s];
-                float da = (clamped ? gy[s] : gy[s] - y * dot) * inv;
-                if constexpr (MASK) da *= mk[s];   // dropout sits between LeakyReLU and normalize
-                gy[s] = y > 0.f ? da : da * p.slope;  // sign(z) = sign(y) where kept; LeakyReLU'(0) = slope as in torch
-            }
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int64_t next = tile + stride;
-            if (next < n_tiles) issue(next);
-        }
-        const int64_t row = min(tile * 16 + n, p.n_rows - 1);
-        {
-            float *grow = p.G + row * 64 + 16 * g;  // G is also the operand of the weight-gradient kernel
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4 *>(grow + 4 * q) = make_float4(gy[4 * q + 0], gy[4 * q + 1], gy[4 * q + 2], gy[4 * q + 3]);
-        }
-        f32x4 at[NT], ai[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) at[t] = ai[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
+    if (has_tile) {
+        // (the transposed weights stay in LDS here: 128 more registers next to the 128 of the weight-gradient accumulators
+        //  spill; the A operands are read four k-steps at a time, 32 conflict-free ds_read_b128 per tile)
+        bool first = true;
+        for (;;) {
+            if (first)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // only the previous tile's 8 stores are younger than this DMA
+            first = false;
+            float gy[16], xv[NT][4], pv[NT][4], sb[NT][4], hb[NT][4];
+            tile_run(buf + kGY, n, g, gy);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], gy[s], at[t], 0, 0, 0);  // gt = G W1
-                ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[t][s], gy[s], ai[t], 0, 0, 0);  // gi = G W2
-            }
-        }
-        // lane (n, g) holds input columns 16 t + 4 g + r of row n
+                const float4 a = tile_cols(buf + kX, n, g, t), b = tile_cols(buf + kP, n, g, t);
+                xv[t][0] = a.x, xv[t][1] = a.y, xv[t][2] = a.z, xv[t][3] = a.w;
+                pv[t][0] = b.x, pv[t][1] = b.y, pv[t][2] = b.z, pv[t][3] = b.w;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float4 gp, gx;
-            gp.x = fmaf(ai[t][0], xv[t][0], at[t][0]), gx.x = fmaf(ai[t][0], pv[t][0], at[t][0]);
-            gp.y = fmaf(ai[t][1], xv[t][1], at[t][1]), gx.y = fmaf(ai[t][1], pv[t][1], at[t][1]);
-            gp.z = fmaf(ai[t][2], xv[t][2], at[t][2]), gx.z = fmaf(ai[t][2], pv[t][2], at[t][2]);
-            gp.w = fmaf(ai[t][3], xv[t][3], at[t][3]), gx.w = fmaf(ai[t][3], pv[t][3], at[t][3]);
-            *reinterpret_cast<float4 *>(p.GP + row * 64 + 16 * t + 4 * g) = gp;  // d/dP (to be propagated)
-            *reinterpret_cast<float4 *>(p.GX + row * 64 + 16 * t + 4 * g) = gx;  // the direct part of d/dX
+                for (int s = 0; s < 4; ++s) {  // B operands of the weight gradients: rows 4 s + g, column 16 t + n
+                    const float xc = col_at(buf + kX, 4 * s + g, t), pc = col_at(buf + kP, 4 * s + g, t);
+                    sb[t][s] = pc + xc;  // layers.py:56
+                    hb[t][s] = pc * xc;  // layers.py:57
+                }
+            }
+            float yv[16], mk[16], inv = 0.f;
+            if constexpr (TAIL) {
+                tile_run(buf + kY, n, g, yv);
+                if constexpr (MASK) tile_run(buf + kM, n, g, mk);
+                inv = buf[kInv + n];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every DMA buffer has been read: the next tile may land
+            const int64_t next = tile + stride;
+            const bool more = next < n_tiles;
+            if constexpr (TAIL) {
+                float dot = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) dot = fmaf(gy[s], yv[s], dot);
+                dot += __shfl_xor(dot, 16);
+                dot += __shfl_xor(dot, 32);
+                const bool clamped = inv >= 1e12f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float y = yv[s];
+                    float da = (clamped ? gy[s] : gy[s] - y * dot) * inv;
+                    if constexpr (MASK) da *= mk[s];
+                    gy[s] = y > 0.f ? da : da * p.slope;
+                }
+            }
+            // G into this wave's LDS tile (swizzled like the others), column sums for db
+            const bool row_ok = tile * 16 + n < p.n_rows;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4 *>(buf + kG + n * 64 + (((4 * g + q) ^ n) << 2)) =
+                    make_float4(gy[4 * q + 0], gy[4 * q + 1], gy[4 * q + 2], gy[4 * q + 3]);
+            }
+            if (row_ok) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) colsum[s] += gy[s];
+            }
+            f32x4 at[NT], ai[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) at[t] = ai[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (more) issue_part(next, q);  // the next tile's DMA, a quarter per k-group: its issue cost sits in MFMA shadows
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float4 wa = *reinterpret_cast<const float4 *>(wstage + (16 * t + n) * 64 + (((4 * g + q) ^ n) << 2));
+                    const float4 wb = *reinterpret_cast<const float4 *>(wstage + 4096 + (16 * t + n) * 64 + (((4 * g + q) ^ n) << 2));
+                    at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.x, gy[4 * q + 0], at[t], 0, 0, 0);  // gt = G W1
+                    ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.x, gy[4 * q + 0], ai[t], 0, 0, 0);  // gi = G W2
+                    at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.y, gy[4 * q + 1], at[t], 0, 0, 0);
+                    ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.y, gy[4 * q + 1], ai[t], 0, 0, 0);
+                    at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.z, gy[4 * q + 2], at[t], 0, 0, 0);
+                    ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.z, gy[4 * q + 2], ai[t], 0, 0, 0);
+                    at[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa.w, gy[4 * q + 3], at[t], 0, 0, 0);
+                    ai[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb.w, gy[4 * q + 3], ai[t], 0, 0, 0);
+                }
+            }
+            // weight gradients: A = columns of G (rows past the end contribute nothing), B = columns of P + X / P * X
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool k_ok = tile * 16 + 4 * s + g < p.n_rows;
+                float ga[NT];
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const float v = col_at(buf + kG, 4 * s + g, tj);
+                    ga[tj] = k_ok ? v : 0.f;
+                }
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int tc = 0; tc < NT; ++tc) {
+                        dw1[tj][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[tj], sb[tc][s], dw1[tj][tc], 0, 0, 0);
+                        dw2[tj][tc] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[tj], hb[tc][s], dw2[tj][tc], 0, 0, 0);
+                    }
+            }
+            const int64_t row = min(tile * 16 + n, p.n_rows - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float4 gp, gx;
+                gp.x = fmaf(ai[t][0], xv[t][0], at[t][0]), gx.x = fmaf(ai[t][0], pv[t][0], at[t][0]);
+                gp.y = fmaf(ai[t][1], xv[t][1], at[t][1]), gx.y = fmaf(ai[t][1], pv[t][1], at[t][1]);
+                gp.z = fmaf(ai[t][2], xv[t][2], at[t][2]), gx.z = fmaf(ai[t][2], pv[t][2], at[t][2]);
+                gp.w = fmaf(ai[t][3], xv[t][3], at[t][3]), gx.w = fmaf(ai[t][3], pv[t][3], at[t][3]);
+                *reinterpret_cast<float4 *>(p.GP + row * 64 + 16 * t + 4 * g) = gp;
+                *reinterpret_cast<float4 *>(p.GX + row * 64 + 16 * t + 4 * g) = gx;
+            }
+            tile += stride;
+            if (tile >= n_tiles) break;
         }
-        tile += stride;
-        if (tile >= n_tiles) break;
+    }
+    // Workgroup partial = (w0 + w2) + (w1 + w3), a fixed order (bit-reproducible).  The accumulators travel through LDS in
+    // the lane-linear layout they have in registers (slot i of lane l at [i][l], b128, conflict-free): waves 2 and 3 hand
+    // theirs to waves 0 and 1, then wave 1 hands the sum to wave 0, which writes the partial result.
+#pragma unroll
+    for (int s = 0; s < 16; ++s) colsum[s] = row16_sum(colsum[s]);  // over the 16 rows a lane group holds
+    f32x4 *xa = reinterpret_cast<f32x4 *>(wstage);  // 32 slots x 64 lanes x 16 B = 32 KB (the weights are dead: every loop is done)
+    f32x4 *xb = reinterpret_cast<f32x4 *>(tiles);   // the tiles are dead too
+    f32x4 *ca = reinterpret_cast<f32x4 *>(tiles + 8192), *cb = ca + 4 * 64;  // column sums: 4 slots x 64 lanes
+    auto put = [&](f32x4 *x, f32x4 *c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                x[(a * NT + b) * 64 + lane] = dw1[a][b];
+                x[(16 + a * NT + b) * 64 + lane] = dw2[a][b];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q * 64 + lane] = (f32x4){colsum[4 * q], colsum[4 * q + 1], colsum[4 * q + 2], colsum[4 * q + 3]};
+    };
+    auto take = [&](const f32x4 *x, const f32x4 *c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                dw1[a][b] += x[(a * NT + b) * 64 + lane];
+                dw2[a][b] += x[(16 + a * NT + b) * 64 + lane];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = c[q * 64 + lane];
+            colsum[4 * q] += v[0], colsum[4 * q + 1] += v[1], colsum[4 * q + 2] += v[2], colsum[4 * q + 3] += v[3];
+        }
+    };
+    __syncthreads();
+    if (wave == 2) put(xa, ca);
+    if (wave == 3) put(xb, cb);
+    __syncthreads();
+    if (wave == 0) take(xa, ca);
+    if (wave == 1) take(xb, cb);
+    __syncthreads();
+    if (wave == 1) put(xa, ca);
+    __syncthreads();
+    if (wave == 0) {
+        take(xa, ca);
+        float *out = part + (int64_t)blockIdx.x * (2 * 4096 + 64);
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (16 * tj + 4 * g + r) * 64 + 16 * tc + n;  // dW[j][c]
+                    out[idx] = dw1[tj][tc][r];
+                    out[4096 + idx] = dw2[tj][tc][r];
+                }
+        if (n == 0) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) out[8192 + 16 * g + s] = colsum[s];
+        }
     }
 }
 
@@ -593,16 +723,19 @@ static int dgrad_cu_count() {
     return v;
 }
 
-static int launch_dgrad_dma(const DgradParams &p, hipStream_t s) {
+// grid = number of partial results written to `part`
+static int launch_backward_fused(const DgradParams &p, float *part, int64_t *n_parts, hipStream_t s) {
     const int64_t n_tiles = (p.n_rows + 15) / 16;
-    const dim3 gr((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_tiles + 3) / 4, dgrad_cu_count()))), bl(256);
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>({(n_tiles + 3) / 4, (int64_t)dgrad_cu_count(), (int64_t)256}));
+    const dim3 gr((unsigned)grid), bl(256);
     if (p.inv_norm && p.drop_mask)
-        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<true, true>), gr, bl, 0, s, p);
+        hipLaunchKernelGGL((bignn_backward_fused_kernel<true, true>), gr, bl, 0, s, p, part);
     else if (p.inv_norm)
-        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<true, false>), gr, bl, 0, s, p);
+        hipLaunchKernelGGL((bignn_backward_fused_kernel<true, false>), gr, bl, 0, s, p, part);
     else
-        hipLaunchKernelGGL((bignn_dgrad_dma_kernel<false, false>), gr, bl, 0, s, p);
+        hipLaunchKernelGGL((bignn_backward_fused_kernel<false, false>), gr, bl, 0, s, p, part);
     RBG_HIP(hipGetLastError());
+    *n_parts = grid;
     return RBG_OK;
 }
 
@@ -706,8 +839,18 @@ int rbg_bignn_backward_f32(const rbg_graph *g_t, const float *GY, int64_t ldgy, 
                       ((reinterpret_cast<uintptr_t>(GY) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(drop_mask)) & 15u) == 0;
     const bool dma = fast && opt_bignn_dma() && d_in == 64 && d_out == 64 && ldx % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(GX)) & 15u) == 0;
-    if (dma) rc = launch_dgrad_dma(p, s);
-    else if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
+    if (dma) {
+        // input and weight gradients in one kernel; its <= 256 partial results go through the same fixed-order reduction
+        int64_t n_parts = 0;
+        float *part = reinterpret_cast<float *>(w);
+        if ((rc = launch_backward_fused(p, part, &n_parts, s))) return rc;
+        const int64_t len = 2 * (int64_t)d_out * d_in + d_out;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, s, part, (int)n_parts, len, d_out, d_in,
+                           dW1, dW2, db);
+        RBG_HIP(hipGetLastError());
+        return spmm_strided(g_t, GP, d_in, GX, d_in, d_in, 1, s);  // dX = GX + Â^T GP
+    }
+    if (d_in <= 32) rc = launch_dgrad_i<1>(p, fast, s);
     else if (d_in <= 64) rc = launch_dgrad_i<2>(p, fast, s);
     else rc = launch_dgrad_i<4>(p, fast, s);
     if (rc) return rc;

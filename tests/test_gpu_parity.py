@@ -1296,12 +1296,13 @@ def test_bignn_dense_dma_kernel(rbg, cuda, n, d_out):
     p64, x64 = p.double().cpu(), x.double().cpu()
     z = (p64 + x64) @ w1.double().cpu().T + b1.double().cpu() + (p64 * x64) @ w2.double().cpu().T + b2.double().cpu()
     zn = torch.nn.functional.normalize(torch.nn.functional.leaky_relu(z, 0.2), p=2, dim=1)
-    assert rbg.get_option("bignn_dma") == 1
+    default = rbg.get_option("bignn_dma")
+    assert default != 0
     try:
         for leaky, ref in ((False, z), (True, zn)):
             ybuf = torch.full((n, d_out + 8), 7.0, device=cuda)
             y = ybuf[:, 4:4 + d_out]
-            rbg.set_option("bignn_dma", 1)
+            rbg.set_option("bignn_dma", default)
             rbg.ops.bignn_dense_raw(p, x, w1, b1, w2, b2, out=y, leaky_norm=leaky)
             close(y, ref.float())
             assert torch.all(ybuf[:, :4] == 7.0) and torch.all(ybuf[:, 4 + d_out:] == 7.0)  # nothing outside the slice
@@ -1309,7 +1310,7 @@ def test_bignn_dense_dma_kernel(rbg, cuda, n, d_out):
             y0 = rbg.ops.bignn_dense_raw(p, x, w1, b1, w2, b2, leaky_norm=leaky)
             close(y, y0.cpu(), tol=5e-6)
     finally:
-        rbg.set_option("bignn_dma", 1)
+        rbg.set_option("bignn_dma", default)
 
 
 @pytest.mark.parametrize("n,d_in,d_out", [(1, 8, 8), (33, 16, 24), (500, 64, 64), (257, 20, 50), (300, 128, 64), (129, 64, 128)])
@@ -1364,9 +1365,9 @@ def test_bignn_layer_forward_backward(rbg, cuda, n, d_in, d_out):
 @pytest.mark.parametrize("n", [17, 4099, 70841, 150001])
 @pytest.mark.parametrize("variant", ["plain", "tail", "tail+mask"])
 def test_bignn_backward_dma_kernel(rbg, cuda, n, variant):
-    """rbg_bignn_backward_f32 at d_in = d_out = 64: the LDS-DMA input-gradient kernel (`bignn_dma` option; every pipeline
-    depth, ragged last tile) against the general kernel — dX, dW1, dW2, db — and, at the small sizes, against float64
-    autograd of layers.py:54-58 [+ ngcf.py:96-98]; gy / x are column slices of wider buffers."""
+    """rbg_bignn_backward_f32 at d_in = d_out = 64: the fused input + weight gradient LDS-DMA kernel (`bignn_dma`; every
+    pipeline depth, ragged last tile whose missing rows must not enter the weight gradients) against the general kernels — dX, dW1, dW2, db — and, at the small sizes, against float64 autograd of
+    layers.py:54-58 [+ ngcf.py:96-98]; gy / x are column slices of wider buffers."""
     rng = np.random.default_rng(n)
     nu = n // 2
     ni = n - nu
@@ -1390,16 +1391,21 @@ def test_bignn_backward_dma_kernel(rbg, cuda, n, variant):
         inv = 1.0 / norm.clamp_min(1e-12)
         y = a * inv[:, None]
     out = {}
+    default = rbg.get_option("bignn_dma")
     try:
-        for opt in (1, 0):
+        for opt in (1, 0):  # 1: input + weight gradients in one LDS-DMA kernel, 0: the general kernels
             rbg.set_option("bignn_dma", opt)
             out[opt] = rbg.ops.bignn_backward_raw(h.transpose(), gy, y, inv, mask, x, p, w1, w2, 0.2)
-    finally:
         rbg.set_option("bignn_dma", 1)
+        again = rbg.ops.bignn_backward_raw(h.transpose(), gy, y, inv, mask, x, p, w1, w2, 0.2)
+    finally:
+        rbg.set_option("bignn_dma", default)
     for got, ref, name in zip(out[1], out[0], ("dX", "dW1", "dW2", "db")):
         scale = max(1.0, float(ref.abs().max()))
         err = float((got - ref).abs().max())
         assert err <= 1e-5 * scale, (name, err, scale)
+    for a_, b_ in zip(out[1], again):  # fixed-order partial sums: bit-identical across calls
+        assert torch.equal(a_, b_)
     if n <= 5000:  # float64 autograd of the reference expression on the dense operator
         rp, c, v = h.export_csr()
         dense = torch.zeros(n, n, dtype=torch.float64)
