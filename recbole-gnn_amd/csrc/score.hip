@@ -3,17 +3,14 @@
 // Replaces  scores = torch.matmul(u_embeddings, self.restore_item_e.transpose(0, 1))
 //   recbole_gnn/model/general_recommender/lightgcn.py:131 (ngcf.py:147, sgl.py:240).
 //
-// S[B, n] = U[B, d] · I[n, d]^T in exact fp32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain per
-// output, MI355X guide §3).  This is the only MFMA use on the path: at d = 64 the GEMM has 32 flop
-// per output byte, i.e. it sits at the fp32-MFMA / HBM-write balance point, so the kernel streams
-// item rows once per 128-user block and writes each score exactly once.
+// S[B, n] = U[B, d] · I[n, d]^T with fp32 accuracy: by default both operands are split into three bf16 terms and the six
+// products of order >= 2^-16 run on v_mfma_f32_32x32x16_bf16 (option "mfma_split"; 0 = the exact-fp32 chain on
+// v_mfma_f32_32x32x2_f32).  At d = 64 the GEMM has 32 flop per output byte and the output is 671 MB at B = 4096 x 40 982:
+// the kernel streams item rows once per 128-user block, writes each score exactly once, and is paced by that store stream.
 //
-// Mapping: a wavefront owns a 32-user x 32-item tile.  For v_mfma_f32_32x32x2_f32 lane l supplies
-// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; since the sum over k is order-free we let lane-half
-// h = l>>5 walk k = kc + 32h + s (s = 0..31), so each lane reads ONE contiguous 128-byte run of its
-// user row and of its item row per 64-wide k chunk (8 x global_load_dwordx4), no LDS.  The 4 waves of
-// a workgroup hold 4 different user tiles and walk the same item tiles, so item rows are fetched from
-// L2 once per workgroup and hit in L1 for the other three waves.
+// Mapping: a wavefront owns a 32-user x 32-item tile; the A (user) fragments stay in registers for the whole walk, item tiles
+// are fetched coalesced by the workgroup into a double-buffered LDS tile (score_kernel below has the details and the
+// history of what did not work).
 
 #include <hip/hip_runtime.h>
 
@@ -100,6 +97,10 @@ __device__ __forceinline__ void aligned_emit(AlignedRows &a, int64_t n, int64_t 
 // 16 cross-lane reads + 16 unconditional whole-line stores, no branches.
 __device__ __forceinline__ void aligned_emit_interior(AlignedRows &a, int64_t t, int i, int h, const f32x16 &acc) {
     gfloat *base = a.row0 + (t - 1) * 32;
+    // (r02 phase clock, devtools/microbench/score_trace.hip: a wave spends 53 % of its time in this function, 22 % in the
+    //  product, 12 % in publish.  hipcc emits read / wait / store per row; issuing the 16 cross-lane reads ahead of the 16
+    //  stores does NOT help — 333 vs 308 us at d = 128, and at d = 64 the 16 extra registers force 2 instead of 3 resident
+    //  workgroups: 251 vs 216 us — the time here is the store stream's back-pressure, not LDS latency.)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -152,6 +153,29 @@ __global__ __launch_bounds__(256) void score_generic_kernel(const float *__restr
         store_tile(S, n, B, user_tile * 32, jr, h, acc);
     }
 }
+
+// Per-wave phase clock (devtools/microbench/score_trace.hip builds this file with RBG_SCORE_TRACE; the product does not):
+// cycles spent up to each lap point, summed over the walk.
+#ifdef RBG_SCORE_TRACE
+__device__ unsigned long long *g_score_trace = nullptr;
+#define RBG_SCORE_T0() unsigned long long sc_last = clock64(), sc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RBG_SCORE_LAP(k)                         \
+    do {                                         \
+        const unsigned long long sc_now = clock64(); \
+        sc_acc[k] += sc_now - sc_last;           \
+        sc_last = sc_now;                        \
+    } while (0)
+#define RBG_SCORE_DUMP()                                                                                                  \
+    do {                                                                                                                  \
+        if (g_score_trace && lane == 0)                                                                                   \
+            for (int k = 0; k < 8; ++k)                                                                                   \
+                g_score_trace[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = sc_acc[k];           \
+    } while (0)
+#else
+#define RBG_SCORE_T0() ((void)0)
+#define RBG_SCORE_LAP(k) ((void)0)
+#define RBG_SCORE_DUMP() ((void)0)
+#endif
 
 // d <= 64 NCHUNK <= 256.  A workgroup = 4 waves = 128 users whose A fragments stay in registers; it walks
 // `tiles_per_wave` item tiles.  What the earlier versions of this kernel taught (r01, SQ counters + ISA):
@@ -208,25 +232,34 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
     // so the fetch consumed by publish() was issued one whole iteration earlier and only YOUNGER stores are outstanding
     // when it is awaited (vmcnt(16)); with fetch(t+1) at the top of iteration t the wait also drained tile t-1's stores,
     // whose write acknowledge takes longer than one tile of MFMAs (matrix core busy 59 % -> see DESIGN.md 6.3).
+    RBG_SCORE_T0();
     if (t0 < t1) {
         fetch(t0);
         publish(0);
         if (t0 + 1 < t1) fetch(t0 + 1);
     }
     __syncthreads();
+    RBG_SCORE_LAP(0);
     for (int64_t t = t0; t < t1; ++t) {
         const int buf = (int)(t - t0) & 1;
         f32x16 acc = zero;
         if (wave_live) acc = tile_product(buf);
+        RBG_SCORE_LAP(1);
         if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        RBG_SCORE_LAP(2);
         if (t + 2 < t1) fetch(t + 2);
+        RBG_SCORE_LAP(3);
         if (wave_live) {
             if (t > t0 && t < t_int_end) aligned_emit_interior(al, t, i, h, acc);
             else aligned_emit(al, n, t, t == t0, i, h, acc);
         }
+        RBG_SCORE_LAP(4);
         __syncthreads();
+        RBG_SCORE_LAP(5);
     }
     if (wave_live && t1 > t0) aligned_flush(al, n, t1 - 1, i, h);
+    RBG_SCORE_LAP(6);
+    RBG_SCORE_DUMP();
 }
 
 // (Tried, r02: a role-specialised variant — one loader wave publishing the tiles, four compute waves that only multiply
