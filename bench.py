@@ -237,7 +237,9 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         ex["ngcf_train_step_us(3 BiGNN layers, batch 2048)"] = time_us(ngcf_step, iters=20, warm=3)
         with torch.no_grad():
             ex["ngcf_forward_us"] = time_us(lambda: ngcf.forward(), iters=20, warm=3)
-        del ngcf, opt
+        gs = rbg.GraphedStep(ngcf, batch, lr=1e-3)  # the same step captured once into a HIP graph (train.py)
+        ex["ngcf_train_step_graphed_us"] = time_us(lambda: gs.step(batch), iters=20, warm=3)
+        del ngcf, opt, gs
         np.random.seed(0)
         sgl = rbg.SGL({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "type": "ED",
                        "drop_ratio": 0.1, "ssl_tau": 0.2, "ssl_weight": 0.05, "reg_weight": 1e-4}, ds)
@@ -250,6 +252,9 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             opt.step()
 
         ex["sgl_train_step_us(ED views, InfoNCE, batch 2048)"] = time_us(sgl_step, iters=10, warm=2)
+        gs = rbg.GraphedStep(sgl, batch, lr=1e-3)
+        ex["sgl_train_step_graphed_us"] = time_us(lambda: gs.step(batch), iters=10, warm=2)
+        del gs
         gc = {}
         for mode, flag in (("device_sampling", True), ("numpy_sampling(reference calls)", False)):
             sgl.device_sampling = flag
