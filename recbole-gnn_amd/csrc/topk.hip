@@ -114,7 +114,7 @@ __device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, f
     return __shfl(v, p.k - 1);
 }
 
-// compile-time loop over the 16 accumulator rows: tau[] / row_ok[] / acc[] must be indexed statically or they
+// compile-time loop over the 16 accumulator rows: tau[] / acc[] must be indexed statically or they
 // are demoted to scratch memory (measured: 144 B/lane of scratch and a 1.4 ms kernel)
 template <int R>
 struct RowLoop {
@@ -139,8 +139,34 @@ using ItemTiles = std::conditional_t<SPLIT, RowTile3<NCHUNK, (VEC ? RUN_VEC : RU
 template <int NCHUNK, bool VEC, bool SPLIT>
 using ItemTileMem = std::conditional_t<SPLIT, typename RowTile3<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>::Planes, float[32][NCHUNK * 64 + 4]>;
 
+// Per-wave phase clock (devtools/microbench/topk_trace.hip builds this file with RBG_TOPK_TRACE; the product does not).
+#ifdef RBG_TOPK_TRACE
+__device__ unsigned long long *g_topk_trace = nullptr;
+#define RBG_TOPK_T0() unsigned long long tk_last = clock64(), tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RBG_TOPK_LAP(k)                              \
+    do {                                             \
+        const unsigned long long tk_now = clock64(); \
+        tk_acc[k] += tk_now - tk_last;               \
+        tk_last = tk_now;                            \
+    } while (0)
+#define RBG_TOPK_DUMP()                                                                                             \
+    do {                                                                                                            \
+        if (g_topk_trace && lane == 0)                                                                              \
+            for (int k = 0; k < 8; ++k)                                                                             \
+                g_topk_trace[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = tk_acc[k];      \
+    } while (0)
+#else
+#define RBG_TOPK_T0() ((void)0)
+#define RBG_TOPK_LAP(k) ((void)0)
+#define RBG_TOPK_DUMP() ((void)0)
+#endif
+
 // CAP = list capacity per user: a prune leaves <= k entries and one tile adds <= 32, so CAP >= k + 32 (48 for k <= 16,
 // which lets two workgroups share a CU's LDS; 64 otherwise).
+// (r02, tried: taking the item tiles by LDS-DMA from a "plane image" of the item table — the three bf16 planes in the LDS
+//  layout, built once per call — instead of fetch + split + publish in every workgroup.  Bit-identical results, but no
+//  faster: 231.0 vs 229.5 us at d = 64, 437 vs 457 us at d = 128 (4096 users), +13 us at 128 users for the extra pass: the
+//  fetch and the publish were already hidden behind the other resident workgroup's product and filter.  Removed.)
 template <int NCHUNK, bool VEC, int CAP, bool SPLIT>
 __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
@@ -168,27 +194,33 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
     };
     // thresholds start at the pre-pass bound: an item scoring below the k-th best valid score of ANY item subset
     // cannot be in the top k.  tau[r] belongs to the user of accumulator row (r&3) + 8*(r>>2) + 4h.
+#ifdef RBG_TOPK_TRACE_NOPASS  // (diagnostic build only: nothing ever passes the threshold)
+    const float my_tau = __builtin_inff();
+#else
     const float my_tau = (p.tau0 && bi < p.B) ? p.tau0[bi] : kNegInf;
+#endif
     float tau[16];
-    bool row_ok[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
-        tau[r] = __shfl(my_tau, src);
-        row_ok[r] = b0 + src < p.B;
+        const float tv = __shfl(my_tau, src);
+        tau[r] = (b0 + src < p.B) ? tv : __builtin_inff();  // a row past the end never passes (thresholds only rise)
     }
     const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
 
     // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
     auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
-        const bool item_ok = item < p.n_items && item != 0;
+        // The not-passing case must be a compare and a branch per row: with the row / item validity folded into one bool per
+        // row hipcc kept 16 lane masks in (spilled) scalar registers and materialised every ballot through a VGPR — the
+        // phase clock (r02) had 2.2 k cycles per tile in here with NOTHING passing.
+        const unsigned long long item_mask = __builtin_amdgcn_ballot_w64(item < p.n_items && item != 0);
         RowLoop<0>::run([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             const float s = acc[r];
-            const bool pass = s >= tau[r] && item_ok && row_ok[r];
-            const unsigned long long mask = __ballot(pass);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(s >= tau[r]) & item_mask;
             if (mask == 0ull) return;  // the common case once the thresholds have risen
+            const bool pass = (mask >> lane) & 1ull;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {  // the two lane halves hold two different users
                 const unsigned m = hh ? (unsigned)(mask >> 32) : (unsigned)mask;
@@ -214,18 +246,29 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
         });
     };
     Tiles tiles;
+    RBG_TOPK_T0();
     if (t_begin < t_end) {
         tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
         tiles.publish(s_it[0], tid);
     }
     __syncthreads();
+    RBG_TOPK_LAP(0);
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
         if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
-        if (wave_live) filter_tile(tile_product(buf), t * 32 + i);
+        RBG_TOPK_LAP(1);
+        if (wave_live) {
+            const f32x16 acc = tile_product(buf);
+            RBG_TOPK_LAP(2);
+            filter_tile(acc, t * 32 + i);
+        }
+        RBG_TOPK_LAP(3);
         if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
+        RBG_TOPK_LAP(4);
         __syncthreads();
+        RBG_TOPK_LAP(5);
     }
+    RBG_TOPK_DUMP();
     if (!wave_live) return;
     // hand the lists over: raw candidates (at most kListStride per user; longer lists are pruned first)
     const int lists = p.n_chunks;
