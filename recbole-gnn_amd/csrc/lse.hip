@@ -6,7 +6,8 @@
 //   recbole_gnn/model/general_recommender/sgl.py:195-198 (users), :204-207 (items)
 // which materialises [B, n] three times forward (matmul, /tau, exp) and again in autograd — 336 MB each at
 // B = 2048 x 40 982 items, 82 GB at BASELINE config #5 (10 M users).  Here a 32x32 tile of the product lives only in
-// the accumulator registers of one wavefront (exact-fp32 v_mfma_f32_32x32x2_f32, as score.hip).
+// the accumulator registers of one wavefront (fp32-accurate: bf16 matrix cores on 3-way split operands, or the exact-fp32
+// v_mfma_f32_32x32x2_f32 chain with "mfma_split" = 0, as score.hip).
 //
 // One kernel serves the forward and both gradients.  A wave OWNS 32 rows of one operand ("own", in the MFMA B slot, so
 // the tile's column = lane&31 = own row) and LOOPS over 32-row tiles of the other ("oth", A slot, tile row =
@@ -66,10 +67,17 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // 16-byte aligned rows, full-rate b128 reads of the A fragments, conflict-free b32 reads of the second product's B
 // fragments).  Workgroups are numbered so that the ones an XCD runs back to back share a chunk: the chunk's oth rows
 // stay in that XCD's L2 and cross the fabric once.
-template <int NC, bool GRAD, bool VEC>
-__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? 3 : 1) : (NC == 1 ? 4 : 2))) void lse_tile_kernel(const LseParams p) {
+// SPLIT (option "mfma_split", default): the score product x = <oth, own> runs on the bf16 matrix cores with both operands
+// split into three bf16 terms (mfma_common.h: the accuracy of the fp32 chain, 24 x 32 instead of 32 x 64 cycles per
+// 64 k); the oth tile is then published as three bf16 planes, and — for the gradients, whose second product reads the
+// tile as fp32 columns — as the fp32 tile too.
+template <int NC, bool GRAD, bool VEC, bool SPLIT>
+__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     constexpr int LD = NC * 64 + 4;
-    __shared__ __attribute__((aligned(16))) float s_oth[2][32][LD];
+    constexpr int LDH = NC * 64 + 8;
+    constexpr bool kFp32Tile = GRAD || !SPLIT;  // who reads s_oth: the fp32 first product and / or the gradients' second product
+    __shared__ __attribute__((aligned(16))) float s_oth[kFp32Tile ? 2 : 1][kFp32Tile ? 32 : 1][kFp32Tile ? LD : 4];
+    __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][3][SPLIT ? 32 : 1][SPLIT ? LDH : 8];
     __shared__ float s_coef[2][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -83,6 +91,8 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? 3 : 1) : (NC == 1 ? 4 : 2))
     float bo[NC][32];
 #pragma unroll
     for (int c = 0; c < NC; ++c) load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.own + own_row * p.ld_own, own_ok, c * 64 + h * 32, p.d, bo[c]);
+    std::conditional_t<SPLIT, AFrag3<NC>, int> bo3;
+    if constexpr (SPLIT) split_a(bo, bo3);
     const float c_own = (GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zsum = 0.f;
@@ -122,22 +132,49 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? 3 : 1) : (NC == 1 ? 4 : 2))
 #pragma unroll
         for (int k = 0; k < NC * 2; ++k) {
             const int f = tid + 256 * k, row = f / (NC * 16), c4 = (f % (NC * 16)) * 4;
-            *reinterpret_cast<float4 *>(&s_oth[buf][row][c4]) = stage[k];
+            if constexpr (kFp32Tile) *reinterpret_cast<float4 *>(&s_oth[buf][row][c4]) = stage[k];
+            if constexpr (SPLIT) {
+                bf16x2 h0, m0, l0, h1, m1, l1;
+                split2_bf16(stage[k].x, stage[k].y, h0, m0, l0);
+                split2_bf16(stage[k].z, stage[k].w, h1, m1, l1);
+                *reinterpret_cast<bf16x4 *>(&s_pl[buf][0][row][c4]) = (bf16x4){h0[0], h0[1], h1[0], h1[1]};
+                *reinterpret_cast<bf16x4 *>(&s_pl[buf][1][row][c4]) = (bf16x4){m0[0], m0[1], m1[0], m1[1]};
+                *reinterpret_cast<bf16x4 *>(&s_pl[buf][2][row][c4]) = (bf16x4){l0[0], l0[1], l1[0], l1[1]};
+            }
         }
         if (GRAD && p.coef_oth && tid < 32) s_coef[buf][tid] = stage_coef;
     };
     auto compute = [&](const int buf, const int64_t t) __attribute__((always_inline)) {
         f32x16 x = zero;
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) {  // lane (i, h) walks k = 64c + 32h + s of oth row i, as the own fragment does
-                const float4 a = *reinterpret_cast<const float4 *>(&s_oth[buf][i][c * 64 + h * 32 + s4 * 4]);
-                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bo[c][s4 * 4 + 0], x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bo[c][s4 * 4 + 1], x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bo[c][s4 * 4 + 2], x, 0, 0, 0);
-                x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bo[c][s4 * 4 + 3], x, 0, 0, 0);
-            }
+                for (int q = 0; q < 4; ++q) {  // oth in the A slot (tile row i, 8 consecutive k), own in the B slot; small terms first
+                    const int off = c * 64 + h * 32 + q * 8;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(&s_pl[buf][0][i][off]);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8 *>(&s_pl[buf][1][i][off]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(&s_pl[buf][2][i][off]);
+                    const int sidx = c * 4 + q;
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bo3.h[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bo3.l[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bo3.m[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bo3.h[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bo3.m[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bo3.h[sidx], x, 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) {  // lane (i, h) walks k = 64c + 32h + s of oth row i, as the own fragment does
+                    const float4 a = *reinterpret_cast<const float4 *>(&s_oth[buf][i][c * 64 + h * 32 + s4 * 4]);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bo[c][s4 * 4 + 0], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bo[c][s4 * 4 + 1], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bo[c][s4 * 4 + 2], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bo[c][s4 * 4 + 3], x, 0, 0, 0);
+                }
+        }
         // x[r] = <oth row t*32 + rowmap(r,h), own row own0 + i>
         const int64_t left = p.n_oth - t * 32;  // oth rows of this tile that exist
         if constexpr (!GRAD) {
@@ -254,7 +291,8 @@ struct LseLayout {
 };
 static LseLayout lse_layout(int64_t B, int64_t n, int d) {
     LseLayout L{};
-    const int res_f = d <= 64 ? 4 : 2, res_g = d <= 64 ? 3 : 1;  // resident workgroups per CU (register-limited)
+    const bool split = opt_mfma_split() != 0;  // (the split kernels hold 48 instead of 32 own registers per chunk)
+    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = d <= 64 ? (split ? 2 : 3) : 1;  // resident workgroups per CU (register-limited)
     // one partial array per chunk: own rows x d x 8 bytes (write + read) at ~5 TB/s, in units of a ~1.2 us tile
     auto partial_cost = [&](int64_t rows) { return (double)rows * d * 8.0 / 5e6 / 1.2; };
     lse_geometry(B, n, res_f, 0.02, L.tpc_f, L.nc_f);
@@ -276,10 +314,15 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     p.total_blocks = p.own_blocks * p.n_chunks;
     p.blocks_per_xcd = (p.total_blocks + 7) / 8;
     dim3 grid((unsigned)(p.blocks_per_xcd * 8));
-    if (vec)
-        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, true>), grid, dim3(256), 0, s, p);
+    const bool split = opt_mfma_split() != 0;
+    if (vec && split)
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, true, true>), grid, dim3(256), 0, s, p);
+    else if (vec)
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, true, false>), grid, dim3(256), 0, s, p);
+    else if (split)
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, false, true>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, false, false>), grid, dim3(256), 0, s, p);
 }
 
 template <bool GRAD>
