@@ -52,6 +52,11 @@ __device__ __forceinline__ void store_tile(float *__restrict__ S, int64_t n, int
 // partial.  `sh[r]` = columns of the first tile that precede the row's first line boundary.
 // Everything but `prev` is wave-uniform (scalar registers): addresses are a uniform 64-bit base + a 32-bit lane offset,
 // and a row's phase is recomputed from (c0, n mod 32) instead of being kept per row.
+// The whole-line stores of the interior tiles are non-temporal: S is written once and read by someone else much later
+// (671 MB at B = 4096 x 40 982); with plain stores the lines linger in L2 and their write-back competes with the operand
+// tiles — 216 -> 183-191 us at d = 64, 514 -> 421-426 us at 91 600 items, 308 -> 291-301 us at d = 128 (r02,
+// profiles/r02_split_probe.jsonl).  The partial lines at the head and the tail of a walk stay plain stores (they merge in
+// L2 with the neighbouring walk's part of the line; non-temporal there measured 4-6 % slower).
 // Stores go through an explicit global (address space 1) pointer: carried through this struct the pointer is otherwise
 // treated as generic, the stores become flat_store, and a pending FLAT access forces every later wait to vmcnt(0).
 typedef __attribute__((address_space(1))) float gfloat;
@@ -106,7 +111,7 @@ __device__ __forceinline__ void aligned_emit_interior(AlignedRows &a, int64_t t,
         const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int s = (int)((32u - ((a.c0 + (unsigned)m * a.nm) & 31u)) & 31u);
         const float x = (i >= s) ? a.prev[r] : acc[r];
-        base[(unsigned)m * a.n + (unsigned)(s + i)] = __shfl(x, ((i + s) & 31) + 32 * h);
+        __builtin_nontemporal_store(__shfl(x, ((i + s) & 31) + 32 * h), &base[(unsigned)m * a.n + (unsigned)(s + i)]);
         a.prev[r] = acc[r];
     }
 }
