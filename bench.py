@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--eager", action="store_true", help="N = 1: issue the K timed steps from the host instead of replaying one HIP graph")
     ap.add_argument("--workload", default="gowalla")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--layers", type=int, default=3)
@@ -271,11 +272,34 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     return ex
 
 
-def timed_loop(step, steps, warmup, world, gloo_group):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; (wall s, event ms), MAX over ranks."""
+def capture_steps(step, steps):
+    """The K steps of the timed region as ONE HIP graph (N = 1 only): the library enqueues on torch's current stream and
+    never synchronises or allocates, so a step is capturable as it is; a replay then submits the same 3 K kernels with one
+    host call instead of K ctypes calls — what train.GraphedStep does for the training steps.  None if capture fails."""
+    try:
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph):
+            for _ in range(steps):
+                step()
+        return graph
+    except Exception:  # noqa: BLE001  (the eager loop is always available)
+        return None
+
+
+def timed_loop(step, steps, warmup, world, gloo_group, graph=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; (wall s, event ms), MAX over ranks.
+    With `graph` (the K steps captured by capture_steps) the timed region is one replay of it."""
     import torch.distributed as dist
     for _ in range(warmup):
         step()
+    if graph is not None:
+        graph.replay()  # untimed: uploads the executable graph
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier(group=gloo_group)
@@ -283,8 +307,11 @@ def timed_loop(step, steps, warmup, world, gloo_group):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()  # torch's current stream == the stream every kernel is launched on
-    for _ in range(steps):
-        step()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(steps):
+            step()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -440,7 +467,14 @@ def main():
                      owned_rows_rank0=int(plan.n_owned), halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4,
                      overlap=bool(prop.overlap))
 
-    elapsed, ev_ms = timed_loop(step, args.steps, args.warmup, world, gloo_group if world > 1 else None)
+    # N = 1: the K timed steps are replayed from one HIP graph unless --eager (a 20-step region is 2.6 ms: a single host
+    # hiccup between two ctypes calls would otherwise be a visible share of it); N > 1 stays eager (collectives on side streams)
+    step_graph = capture_steps(step, args.steps) if (world == 1 and not args.eager) else None
+    elapsed, ev_ms = timed_loop(step, args.steps, args.warmup, world, gloo_group if world > 1 else None, graph=step_graph)
+    extra["timed_region"] = "one HIP-graph replay of the K steps" if step_graph is not None else "K host-issued steps"
+    if step_graph is not None:  # and the host-issued loop beside it
+        el_e, _ = timed_loop(step, args.steps, min(args.warmup, 5), world, None)
+        extra["eager_ms_per_step"] = el_e * 1e3 / args.steps
 
     if world > 1 and not args.no_secondary:
         # the other scaling mode, same process group, bounded: its own short timed loop
