@@ -39,6 +39,6 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:spmm_binned_kernel<64, 8, true, false>"
     table[key] = traffic
     table["_bench_command_note"] = ("the key above is refreshed by devtools/profile_session.sh from PMC passes of `python bench.py --steps 100 "
-                                    "--warmup 10 --cpu-seconds 0 --no-extras`: mean over all SpMM launches of that command")
+                                    "--warmup 10 --cpu-seconds 0 --no-extras --eager`: mean over all SpMM launches of that command")
     json.dump(table, open(tpath, "w"), indent=1)
 json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
