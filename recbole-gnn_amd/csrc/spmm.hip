@@ -271,8 +271,8 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
         st4_stream(p.y + (int64_t)row * p.ldy + c0, s, p.nt_store);
     } else {
         float *dst = p.y + (int64_t)row * p.ldy + c0;
-        if (p.mode == MODE_ACCUM) {
-            st4(dst, add4(acc, ld4(dst)));
+        if (p.mode == MODE_ACCUM) {  // the row's old value is read once and rewritten: both streaming
+            st4_stream(dst, add4(acc, ld4_stream(dst, p.nt_store)), p.nt_store);
         } else {
             st4_stream(dst, acc, p.nt_store);
         }
