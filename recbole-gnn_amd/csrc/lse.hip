@@ -192,13 +192,52 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                 if (p.coef_oth) e *= s_coef[buf][o];
                 w[r] = (o < left) ? e : 0.f;
             });
+            if constexpr (SPLIT) {
+                // second product on the bf16 matrix cores too: MFMA u of a pair covers the oth rows rowmap(8 u + j, h),
+                // j = 0..7 — the weights this lane already holds (A slot) against a column of the fp32 tile (B slot), both
+                // split here, six products of order >= 2^-16
+                bf16x8 wh[2], wm[2], wl[2];
 #pragma unroll
-            for (int q = 0; q < NC * 2; ++q) {
-                LseRows<0>::run([&](auto rc) {
-                    constexpr int s = decltype(rc)::value;
-                    const float bv = s_oth[buf][lse_rowmap(s, h)][q * 32 + i];
-                    g[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], bv, g[q], 0, 0, 0);
-                });
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x2 hh, mm, ll;
+                        split2_bf16(w[8 * u + 2 * j], w[8 * u + 2 * j + 1], hh, mm, ll);
+                        wh[u][2 * j] = hh[0], wh[u][2 * j + 1] = hh[1];
+                        wm[u][2 * j] = mm[0], wm[u][2 * j + 1] = mm[1];
+                        wl[u][2 * j] = ll[0], wl[u][2 * j + 1] = ll[1];
+                    }
+#pragma unroll
+                for (int q = 0; q < NC * 2; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        bf16x8 bh, bm, bl;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float b0 = s_oth[buf][lse_rowmap(8 * u + 2 * j, h)][q * 32 + i];
+                            const float b1 = s_oth[buf][lse_rowmap(8 * u + 2 * j + 1, h)][q * 32 + i];
+                            bf16x2 hh, mm, ll;
+                            split2_bf16(b0, b1, hh, mm, ll);
+                            bh[2 * j] = hh[0], bh[2 * j + 1] = hh[1];
+                            bm[2 * j] = mm[0], bm[2 * j + 1] = mm[1];
+                            bl[2 * j] = ll[0], bl[2 * j + 1] = ll[1];
+                        }
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bl, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[u], bm, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[u], bh, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bm, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bh, g[q], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NC * 2; ++q) {
+                    LseRows<0>::run([&](auto rc) {
+                        constexpr int s = decltype(rc)::value;
+                        const float bv = s_oth[buf][lse_rowmap(s, h)][q * 32 + i];
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], bv, g[q], 0, 0, 0);
+                    });
+                }
             }
         }
     };
