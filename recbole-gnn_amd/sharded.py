@@ -374,6 +374,49 @@ class ShardedPropagation:
         dist.all_to_all_single(halo, send[:n_send], output_split_sizes=self._recv_splits,
                                input_split_sizes=self._send_splits, group=self.group)
 
+    def halo_of(self, x, out=None):
+        """The halo rows of x under this plan — ONE exchange (the collective of a layer without its products), on the
+        caller's stream.  Propagations that start from the same x can share it (SGL's three forwards all start from E0,
+        sgl.py:129: SURVEY §8(e) "views share layer-1's all-gather"): pass the result as ``first_halo`` / ``halo_rows``,
+        re-indexed with ``remap_halo`` for a plan whose halo is a subset of this one's (an edge-drop view of this graph
+        under the same partition).  Every rank of the group must call it, like any layer."""
+        plan = self.plan
+        d = x.shape[1]
+        if out is None:
+            out = torch.empty((max(plan.n_halo, 1), d), dtype=x.dtype, device=x.device)
+        if plan.world == 1:
+            return out
+        if self.transport == "nccl":
+            self._buffers(x)
+            self._exchange_nccl(x, out[: plan.n_halo], stream=torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            self._exchange_staged(x, out[: plan.n_halo])
+        return out
+
+    def halo_map_from(self, other_plan):
+        """For every halo slot of this plan its slot in `other_plan`'s halo (int64 tensor on this object's device).  Raises
+        unless this plan's halo ids are a subset of the other's — true for an edge-drop view of the other plan's graph
+        under the same partition (a view drops edges, so it can only need fewer remote rows)."""
+        mine, theirs = np.asarray(self.plan.halo_ids), np.asarray(other_plan.halo_ids)
+        order = np.argsort(theirs, kind="stable")
+        pos = np.searchsorted(theirs[order], mine)
+        if len(mine) and (pos.max(initial=0) >= len(theirs) or not np.array_equal(theirs[order][np.minimum(pos, len(theirs) - 1)], mine)):
+            raise ValueError("this plan's halo is not a subset of the other plan's halo")
+        return torch.as_tensor(order[pos] if len(mine) else np.zeros(0, dtype=np.int64), dtype=torch.int64, device=self.device)
+
+    def remap_halo(self, halo_other, index, out=None):
+        """halo_other[index] ([n_halo, d], padded to one row for an empty halo): the other plan's exchanged halo in this
+        plan's slot order; ``index`` = halo_map_from(other_plan).  A local gather, no communication."""
+        n = int(index.shape[0])
+        if out is None:
+            out = torch.empty((max(n, 1), halo_other.shape[1]), dtype=halo_other.dtype, device=halo_other.device)
+        if n:
+            if halo_other.device.type == "cuda":
+                self.backend.gather_rows(halo_other, index, out=out[:n])
+            else:
+                out[:n] = self.backend.gather_rows(halo_other, index)
+        return out
+
     def _halo_product(self, halo, y, finish, main_h=None):
         """The second half of a layer: Y += A_halo·halo — or, on the last layer (finish = (srcs, out)), the same product
         with the layer mean in its epilogue: out = (srcs... + (Y + A_halo·halo)) / (len(srcs) + 1)."""
@@ -387,12 +430,25 @@ class ShardedPropagation:
             return self.backend.spmm_mean(self.g_halo, halo, y, srcs, out, **kw)
         return self.backend.mean(list(srcs) + [y], out, **kw)  # no halo on this rank: plain mean of the kept layers
 
-    def spmm(self, x, out=None, main=None, finish=None):
+    def spmm(self, x, out=None, main=None, finish=None, halo_rows=None):
         """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows.  `main`: the torch stream the caller runs on
         (looked up once per propagation by forward()).  `finish` = (srcs, out_mean): this is the last layer of a
-        propagation — returns out_mean = (sum(srcs) + Y) / (len(srcs) + 1) instead of Y (HIP backend only)."""
+        propagation — returns out_mean = (sum(srcs) + Y) / (len(srcs) + 1) instead of Y (HIP backend only).
+        `halo_rows` ([n_halo, d], from halo_of / remap_halo): the halo of x is already here — no exchange, no collective."""
         plan = self.plan
         d = x.shape[1]
+        if halo_rows is not None and plan.world > 1:
+            if halo_rows.shape[0] < max(plan.n_halo, 1):
+                raise ValueError("halo_rows has fewer rows than this plan's halo")
+            if x.device.type == "cuda":
+                self._buffers(x)
+                y = out if out is not None else self._y[0 if self._y[0].data_ptr() != x.data_ptr() else 1]
+                kw = {"stream": (main or torch.cuda.current_stream(x.device)).cuda_stream}
+            else:
+                y = out if out is not None else torch.empty((plan.n_owned, d), dtype=x.dtype, device=x.device)
+                kw = {}
+            self.backend.spmm(self.g_int, x, y, False, **kw)
+            return self._halo_product(halo_rows, y, finish, kw.get("stream"))
         if x.device.type == "cuda":
             halo, _ = self._buffers(x)
             if out is not None:
@@ -447,10 +503,12 @@ class ShardedPropagation:
     # forked from the capturing one — segfaults inside torch.cuda.graph on torch 2.10 / ROCm 7.2; with the single-stream
     # layer the capture works (236 vs 260 us) but the process hung in process-group teardown.  The N > 1 path stays
     # eager: a crash or hang cannot be caught and voted on the way an exception is.)
-    def forward(self, e0, n_layers, out=None):
+    def forward(self, e0, n_layers, out=None, first_halo=None):
         """mean(E_0..E_K) for the owned rows (lightgcn.py:70-81); rows [0, n_users_owned) are users.
         The result lives in a buffer this object re-uses: it is valid until the next forward() / spmm() call on this
-        object (propagating two views back to back: pass ``out=`` or clone the first result)."""
+        object (propagating two views back to back: pass ``out=`` or clone the first result).
+        ``first_halo``: the halo rows of e0 in this plan's slot order (halo_of / remap_halo) — the first layer then
+        skips its exchange (K - 1 collectives instead of K)."""
         if hasattr(self.backend, "spmm_mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
             # keep the K - 1 first layer outputs; the K-th product carries the layer mean in its epilogue
             self._buffers(e0)
@@ -459,13 +517,14 @@ class ShardedPropagation:
             main = torch.cuda.current_stream(e0.device) if e0.device.type == "cuda" else None
             srcs, x = [e0], e0
             for k in range(n_layers - 1):
-                x = self.spmm(x, out=self._y[k], main=main)
+                x = self.spmm(x, out=self._y[k], main=main, halo_rows=first_halo if k == 0 else None)
                 srcs.append(x)
-            return self.spmm(x, out=self._y[n_layers - 1], main=main, finish=(srcs, self._mean if out is None else out))
+            return self.spmm(x, out=self._y[n_layers - 1], main=main, finish=(srcs, self._mean if out is None else out),
+                             halo_rows=first_halo if n_layers == 1 else None)
         acc = e0.clone()
         x = e0
-        for _ in range(n_layers):
-            x = self.spmm(x)
+        for k in range(n_layers):
+            x = self.spmm(x, halo_rows=first_halo if k == 0 else None)
             acc += x
         acc /= float(n_layers + 1)
         if out is not None:
@@ -586,6 +645,42 @@ class _ShardedLightGCN(torch.autograd.Function):
 def sharded_lightgcn_forward(prop, e0, n_layers):
     """Differentiable mean(E_0..E_K) of this rank's rows; e0 = the rank's rows of the embedding tables (users first)."""
     return _ShardedLightGCN.apply(e0, prop, n_layers)
+
+
+class _ShardedSGLForward(torch.autograd.Function):
+    """SGL's three propagations (sgl.py:128-145 on the full graph, :219-221 on the two views) of one E0 shard with ONE
+    exchange of E0's halo instead of three: the views' halos are subsets of the full graph's (a view drops edges), so their
+    first layers re-index the full plan's halo rows locally.  3 K - 2 collectives per forward instead of 3 K
+    ("views share layer-1's all-gather of E0").  The backward has nothing to share: each propagation's
+    transposed chain starts from its own gradient."""
+
+    @staticmethod
+    def forward(ctx, e0, main, views, maps, n_layers):
+        ctx.props, ctx.n_layers = [main] + list(views), n_layers
+        halo0 = main.halo_of(e0)
+        outs = [main.forward(e0, n_layers, first_halo=halo0).clone()]
+        for v, m in zip(views, maps):
+            outs.append(v.forward(e0, n_layers, first_halo=v.remap_halo(halo0, m)).clone())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        total = None
+        for prop, g in zip(ctx.props, grads):
+            if g is None:
+                continue
+            gi = prop.backward(g.contiguous(), ctx.n_layers)
+            total = gi.clone() if total is None else total + gi
+        return total, None, None, None, None
+
+
+def sharded_sgl_forward(main, views, e0, n_layers, maps=None):
+    """(mean_full, mean_view_1, ...) for this rank's rows, differentiable; `main` / `views`: ShardedPropagation objects over
+    the full graph's plan and the edge-drop view plans built on the SAME partition (build_plans(owner=..., keep=mask));
+    `maps`: [view.halo_map_from(main.plan)] if the caller keeps them across steps (the views change once per epoch)."""
+    if maps is None:
+        maps = [v.halo_map_from(main.plan) for v in views]
+    return _ShardedSGLForward.apply(e0, main, tuple(views), tuple(maps), n_layers)
 
 
 # ---- the same path behind the C ABI (no torch.distributed): rbg_comm_* / rbg_graph_create_sharded / rbg_*_sharded_f32 ------------

@@ -243,6 +243,24 @@ def _worker_round2(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
                 sc = prop.full_sort_scores(m, users, nu, ni, item_table=table)
                 s_ref = ref[plan.owned[users.numpy()]] @ ref[nu:].T
                 out["score"] = (float(np.abs(table.cpu().numpy() - ref[nu:]).max()), float(np.abs(sc.cpu().numpy() - s_ref).max()))
+        # SGL's three propagations of one E0 with ONE exchange of its halo (sharded_sgl_forward): bit-identical to three
+        # separate propagations, gradient = the sum of the three chains
+        keep2 = np.zeros(len(uid), dtype=np.uint8)
+        keep2[np.random.default_rng(6).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+        plans3 = [sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=m)[rank] for m in (None, keep, keep2)]
+        props3 = [sh.ShardedPropagation(pl, sh.HipBackend(dev), transport="staged") for pl in plans3]
+        owned = plans3[0].owned
+        x3 = torch.from_numpy(e0[owned]).to(dev).requires_grad_(True)
+        outs = sh.sharded_sgl_forward(props3[0], props3[1:], x3, k_layers)
+        sum((o * torch.from_numpy(w[owned]).to(dev)).sum() for o in outs).backward()
+        plain = [pr.forward(torch.from_numpy(e0[owned]).to(dev), k_layers).clone() for pr in props3]
+        torch.cuda.synchronize()
+        gref3 = np.zeros((n, d), dtype=np.float32)
+        for m in (None, keep, keep2):
+            rp, cc, vv = C.build_norm_csr(uid, iid, nu, ni, keep=m)
+            gref3 += C.lightgcn_forward(rp, cc, vv, w[:nu], w[nu:], k_layers)
+        out["sgl_shared"] = (all(bool(torch.equal(o.detach(), q)) for o, q in zip(outs, plain)),
+                             float(np.abs(x3.grad.cpu().numpy() - gref3[owned]).max()))
         gathered = [None] * world
         dist.all_gather_object(gathered, (rank, out))
         if rank == 0:
@@ -269,6 +287,7 @@ def test_two_ranks_device_planner_backward_view_scoring(ref_inter):
             assert same and err <= 1e-5 and gerr <= 1e-5, (rank, name, out[name])
         assert out["score"][0] <= 1e-5 and out["score"][1] <= 1e-5, (rank, out["score"])
         assert out["ngcf"] <= 1e-5, (rank, out["ngcf"])
+        assert out["sgl_shared"][0] and out["sgl_shared"][1] <= 3e-5, (rank, out["sgl_shared"])
 
 
 def test_spmm_mean_epilogue(rbg, cuda, ref_inter):

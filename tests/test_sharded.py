@@ -244,6 +244,84 @@ def _worker2(rank, world, port, uid, iid, nu, ni, k_layers, out_q):
         dist.destroy_process_group()
 
 
+def _worker3(rank, world, port, uid, iid, nu, ni, k_layers, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        n, d = nu + ni, 16
+        rng = np.random.default_rng(2)
+        e0 = rng.standard_normal((n, d)).astype(np.float32)
+        ws = [rng.standard_normal((n, d)).astype(np.float32) for _ in range(3)]
+        masks = []
+        for seed in (5, 6):
+            keep = np.zeros(len(uid), dtype=np.uint8)
+            keep[np.random.default_rng(seed).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+            masks.append(keep)
+        owner = sh.default_partition(uid, iid, nu, ni, world)
+        plans = [sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=m)[rank] for m in (None, *masks)]
+        props = [sh.ShardedPropagation(pl, CpuBackend(), transport="staged") for pl in plans]
+        calls = {"n": 0}
+        for pr in props:  # count the exchanges (each is one collective of the real transport)
+            orig = pr._exchange_staged
+            def counted(x, halo, _o=orig):
+                calls["n"] += 1
+                return _o(x, halo)
+            pr._exchange_staged = counted
+        owned = plans[0].owned
+        x = torch.from_numpy(e0[owned]).requires_grad_(True)
+        outs = sh.sharded_sgl_forward(props[0], props[1:], x, k_layers)
+        n_shared = calls["n"]
+        loss = sum((o * torch.from_numpy(w[owned])).sum() for o, w in zip(outs, ws))
+        loss.backward()
+        # the same three propagations one by one (3 K exchanges), and the oracle on the global graphs
+        calls["n"] = 0
+        plain = [pr.forward(torch.from_numpy(e0[owned]), k_layers).clone() for pr in props]
+        n_plain = calls["n"]
+        errs, gref = [], np.zeros((n, d), dtype=np.float32)
+        for o, pl_out, m, w in zip(outs, plain, (None, *masks), ws):
+            rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni, keep=m)
+            ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)
+            errs.append((bool(torch.equal(o.detach(), pl_out)), float(np.abs(o.detach().numpy() - ref[owned]).max())))
+            gref += C.lightgcn_forward(rowptr, col, val, w[:nu], w[nu:], k_layers)  # M is symmetric: d<w, M e0>/d e0 = M w
+        gerr = float(np.abs(x.grad.numpy() - gref[owned]).max())
+        subset = all(set(pl.halo_ids.tolist()) <= set(plans[0].halo_ids.tolist()) for pl in plans[1:])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, dict(n_shared=n_shared, n_plain=n_plain, errs=errs, gerr=gerr, subset=subset)))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_sgl_forward_shares_the_first_exchange(ref_inter):
+    """sharded_sgl_forward: SGL's three propagations of one E0 (sgl.py:129, :219-221) over world size 2 — the views take
+    their first-layer halo from the full graph's exchange (3 K - 2 exchanges instead of 3 K), results are
+    bit-identical to three separate propagations, match the oracle on the global graphs, and the summed gradient is right."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 41
+    k_layers = 3
+    procs = [ctx.Process(target=_worker3, args=(r, 2, port, uid, iid, nu, ni, k_layers, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        assert out["subset"], rank
+        assert out["n_plain"] == 3 * k_layers and out["n_shared"] == 3 * k_layers - 2, (rank, out["n_shared"], out["n_plain"])
+        for same, err in out["errs"]:
+            assert same and err <= 1e-5, (rank, out["errs"])
+        assert out["gerr"] <= 3e-5, (rank, out["gerr"])
+
+
 def test_two_process_gloo_backward_views_and_scoring(ref_inter):
     """World size 2 over gloo: sharded gradients (the backward is the same sharded product, by symmetry of the global
     matrix), an edge-drop view propagated over its own plan, and full-sort scoring over the all-gathered item table."""
