@@ -37,7 +37,7 @@ def global_reference(uid, iid, nu, ni, e0, k_layers):
     return C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers), (rowptr, col, val)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 4])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("layout", ["ranges", "striped"])
 def test_plan_algebra(rbg, ref_inter, world, layout):
     uid, iid, nu, ni = ref_inter
