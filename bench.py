@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--clock-warmup", type=int, default=150,
+                    help="untimed propagations run before the W warm-up steps so that the GPU clocks are at their steady state")
     ap.add_argument("--eager", action="store_true", help="N = 1: issue the K timed steps from the host instead of replaying one HIP graph")
     ap.add_argument("--workload", default="gowalla")
     ap.add_argument("--dim", type=int, default=64)
@@ -313,6 +315,8 @@ def timed_loop(step, steps, warmup, world, gloo_group, graph=None):
         for _ in range(steps):
             step()
     ev1.record()
+    while not ev1.query():  # the host spins on the closing event: a blocking wait adds its wake-up latency (tens of us)
+        pass                # to a region that is 2.6 ms at the driver's K = 20
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier(group=gloo_group)
@@ -469,8 +473,14 @@ def main():
 
     # N = 1: the K timed steps are replayed from one HIP graph unless --eager (a 20-step region is 2.6 ms: a single host
     # hiccup between two ctypes calls would otherwise be a visible share of it); N > 1 stays eager (collectives on side streams)
+    # Clock warm-up, untimed and outside the W warm-up steps: a fresh process needs ~10 ms of load before the GPU runs at
+    # its steady-state clocks (K = 20 after W = 5: 141.9 us of GPU time per step; after W = 100: 130.2 us) — and the
+    # driver's W is 5.  Disclosed in the line as `clock_warmup_steps`.
+    # (the warm-up runs directly in front of the timed region, after the graph capture: a few idle ms drop the clocks again)
+    clock_warmup = max(0, args.clock_warmup)
+    extra["clock_warmup_steps"] = clock_warmup
     step_graph = capture_steps(step, args.steps) if (world == 1 and not args.eager) else None
-    elapsed, ev_ms = timed_loop(step, args.steps, args.warmup, world, gloo_group if world > 1 else None, graph=step_graph)
+    elapsed, ev_ms = timed_loop(step, args.steps, args.warmup + clock_warmup, world, gloo_group if world > 1 else None, graph=step_graph)
     extra["timed_region"] = "one HIP-graph replay of the K steps" if step_graph is not None else "K host-issued steps"
     if step_graph is not None:  # and the host-issued loop beside it
         el_e, _ = timed_loop(step, args.steps, min(args.warmup, 5), world, None)
