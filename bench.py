@@ -8,12 +8,16 @@ N = 1: BASELINE.json configs[1] — the Gowalla-shaped synthetic power-law graph
        items / 1,027,370 interactions incl. the two PAD rows).
 N > 1: the node-range sharded path (recbole-gnn_amd/sharded.py), trimmed halo exchange per layer (RCCL all_to_all over
        xGMI; single-stream or overlapped on a second stream — both are timed on the real group, the faster is kept).
-       --scaling weak (default): every rank owns one Gowalla-shaped block of a P-times larger graph with PLANTED
-         locality: a fraction p_in (printed) of each user's interactions stays inside the rank's block.  value counts
+       `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run on 127.0.0.1; when the
+       box has fewer than N GPUs the ranks share them and exchange through the host: "transport": "staged").
+       --scaling strong (default): ONE fixed graph cut into node shards, no planted locality; value = global forwards/s.
+         The graph is BASELINE.json's configuration for that GPU count: N = 2 the Gowalla shape (config #2), N = 4 the
+         Amazon-Book shape (config #4), N = 8 config #5's shape (10 M users / 5 M items / 200 M interactions, 128-d, the
+         LightGCN backbone of SGL; falls back to the 1.3 M-node shape at 64-d, reason printed, when the host cannot hold
+         the generator's temporaries).  `same_workload_one_gpu` carries rank 0's single-GPU propagations/s of the same graph.
+       --scaling weak: every rank owns one Gowalla-shaped block of a P-times larger graph with PLANTED locality: a
+         fraction p_in (printed) of each user's interactions stays inside the rank's block.  value counts
          shard-propagations: one global forward over P shards = P propagations.
-       --scaling strong: ONE fixed graph (Amazon-Book shape at N <= 4, the 1.3 M-node shape above) cut into nnz-balanced
-         node ranges, no planted locality; value = global forwards/s.  N = 1 extras carry the single-GPU
-         propagations/s of the same graphs ("strong_scaling_reference").
        Whichever mode is not the headline is measured too and reported under "other_scaling_mode".
 
 Also reported: "roofline" (algorithmic bytes of one SpMM launch / its average duration from HIP events on
@@ -26,8 +30,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the CPU baseline's OpenMP threads stay where they start (reproducible: r02's figure moved 30-98 propagations/s run to run)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,22 +48,29 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--clock-warmup", type=int, default=150,
-                    help="untimed propagations run before the W warm-up steps so that the GPU clocks are at their steady state")
+    ap.add_argument("--clock-warmup", type=int, default=0,
+                    help="extra untimed propagations in front of the W warm-up steps (counted in `warmup_effective`).  0 = the "
+                         "headline is measured at exactly the flags given; the steady-clock figure is reported beside it either way")
     ap.add_argument("--eager", action="store_true", help="N = 1: issue the K timed steps from the host instead of replaying one HIP graph")
-    ap.add_argument("--workload", default="gowalla")
-    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--workload", default=None, help="default: gowalla at N = 1; BASELINE.json's configuration for N at N > 1")
+    ap.add_argument("--dim", type=int, default=None, help="default 64 (128 for config #5's shape)")
     ap.add_argument("--layers", type=int, default=3)
     ap.add_argument("--p-in", type=float, default=0.95, help="N>1: fraction of interactions inside a rank's block")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) measurements at N = 1")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N>1 headline: weak = one workload-shaped block per rank with planted locality p_in (value counts "
-                         "shard-propagations); strong = ONE fixed graph (amazon-book at N <= 4, g-1.3m above) cut into nnz-balanced "
-                         "node ranges, no planted locality (value = global forwards/s).  The other one is reported alongside.")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N>1 headline: strong = ONE fixed graph (BASELINE.json's configuration for N: gowalla / amazon-book / "
+                         "config5) cut into node shards, no planted locality (value = global forwards/s); weak = one "
+                         "gowalla-shaped block per rank with planted locality p_in (value counts shard-propagations).  The other "
+                         "one is reported alongside.")
+    ap.add_argument("--partition", choices=["auto", "ranges", "striped"], default="auto",
+                    help="strong scaling: contiguous nnz-balanced id ranges, or degree-striped (degree order dealt round-robin); "
+                         "auto = the one with the smaller max over ranks of (nnz + halo rows)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins a gloo group, rank 0 prints {\"launch_check\": world} (no GPU needed)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the other scaling mode's measurement")
-    ap.add_argument("--transport", choices=["nccl", "staged"], default="nccl",
+    ap.add_argument("--transport", choices=["nccl", "staged"], default=None,
                     help="N>1 halo transport: RCCL all_to_all (default) or host-staged gloo send/recv (self-test: lets "
                          "several ranks share one GPU)")
     return ap.parse_args()
@@ -83,23 +98,30 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
     for t in sorted({min(t, max_threads) for t in (4, 8, 16, 24, 32, 48, 64, 128, max_threads)}):
         coracle.set_num_threads(t)
         coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers, buffers=buffers)
-        t1 = time.perf_counter()
-        for _ in range(3):
+        reps, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 0.5:  # half a second each: a 3-call burst reads 2-4x the sustained rate on this host
             coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers, buffers=buffers)
-        probe[t] = 3.0 / (time.perf_counter() - t1)
+            reps += 1
+        probe[t] = reps / (time.perf_counter() - t1)
     best = max(probe, key=probe.get)
     coracle.set_num_threads(best)
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers, buffers=buffers)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 500:
-            break
+    samples, total_reps, total_s = [], 0, 0.0
+    for _ in range(3):  # median of three samples of budget / 3 each
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers, buffers=buffers)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s / 3 or reps >= 200:
+                break
+        samples.append(reps / el)
+        total_reps, total_s = total_reps + reps, total_s + el
     coracle.set_num_threads(max_threads)
-    return {"value": reps / el, "unit": "propagations/s", "cores": best, "kind": "port",
+    return {"value": sorted(samples)[1], "unit": "propagations/s", "cores": best, "kind": "port",
+            "samples_prop_per_s": [round(v, 1) for v in samples],
             "thread_probe_prop_per_s": {str(k): round(v, 1) for k, v in probe.items()},
-            "sample": f"{reps} full propagations of the same workload in {el:.1f} s "
+            "thread_pinning": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+            "sample": f"median of 3 samples, {total_reps} full propagations of the same workload in {total_s:.1f} s "
                       f"(oracle/rbg_oracle.c, gcc -O3 + AVX2 clone, OpenMP dynamic rows, buffers reused; {os.cpu_count()} logical cpus visible)"}
 
 
@@ -201,29 +223,33 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     torch.cuda.synchronize()
     ex["graph_build_device_ms"] = (time.perf_counter() - t0) * 1e3
-    # the scale the north_star names ("~1.3 M nodes"): X = 333 MB no longer fits any cache level
+    # The other shapes a roofline figure is quoted for, each with its measured fabric traffic and L2 hit rate (committed PMC
+    # passes, profiles/traffic.json): the scale the north_star names ("~1.3 M nodes": X = 333 MB is beyond every cache),
+    # the Amazon-Book and Yelp2018 shapes, and the Gowalla shape at d = 128 (column-half kernel).
     try:
-        gu, gi, gnu, gni = rbg.synth.make("g-1.3m")
-        gg = rbg.GraphHandle.from_interactions(gu, gi, gnu, gni, device=dev)
-        gn = gnu + gni
-        gx, gy = torch.randn(gn, d, device=dev), torch.empty(gn, d, device=dev)
-        us = time_us(lambda: rbg.ops.spmm_raw(gg, gx, out=gy), iters=10, warm=2)
-        gb, _ = rbg.synth.algorithmic_bytes(gn, gg.nnz, d, k_layers)
-        ex["g-1.3m"] = {"nodes": gn, "nnz": gg.nnz, "spmm_us": us, "roofline_frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                        "kernel": gg.spmm_kernel_name(d)}
         ref = {}
-        go, gl = torch.empty(gn, d, device=dev), torch.empty(max(k_layers, 1), gn, d, device=dev)
-        ref["g-1.3m"] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl), iters=5, warm=1)
-        del gg, gx, gy, go, gl
-        au, ai, anu, ani = rbg.synth.make("amazon-book")
-        ag = rbg.GraphHandle.from_interactions(au, ai, anu, ani, device=dev)
-        ax = torch.randn(anu + ani, d, device=dev)
-        ao, al = torch.empty(anu + ani, d, device=dev), torch.empty(max(k_layers, 1), anu + ani, d, device=dev)
-        ref["amazon-book"] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(ag, ax[:anu], ax[anu:], k_layers, out=ao, layers=al), iters=20, warm=3)
+        for name, dd in (("g-1.3m", d), ("amazon-book", d), ("yelp2018", d), ("gowalla", 2 * d)):
+            gu, gi, gnu, gni = rbg.synth.make(name)
+            gg = rbg.GraphHandle.from_interactions(gu, gi, gnu, gni, device=dev)
+            gn = gnu + gni
+            gx, gy = torch.randn(gn, dd, device=dev), torch.empty(gn, dd, device=dev)
+            big = gn > 1_000_000
+            us = time_us(lambda: rbg.ops.spmm_raw(gg, gx, out=gy), iters=10 if big else 50, warm=2 if big else 5)
+            gb, _ = rbg.synth.algorithmic_bytes(gn, gg.nnz, dd, k_layers)
+            kern = gg.spmm_kernel_name(dd)
+            traffic, l2_hit = traffic_from_profiles(name, dd, kern)
+            key = name if dd == d else f"{name}:d{dd}"
+            ex[key] = {"nodes": gn, "nnz": gg.nnz, "us": us, "frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                       "l2_hit": l2_hit, "algorithmic_bytes_per_layer": gb, "kernel": kern}
+            if name in ("g-1.3m", "amazon-book"):
+                go, gl = torch.empty(gn, dd, device=dev), torch.empty(max(k_layers, 1), gn, dd, device=dev)
+                ref[name] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl),
+                                          iters=5 if big else 20, warm=1 if big else 3)
+                del go, gl
+            del gg, gx, gy
         ex["strong_scaling_reference(single-GPU propagations/s of the --scaling strong graphs)"] = ref
-        del ag, ax, ao, al
     except Exception as e:  # noqa: BLE001
-        ex["g-1.3m_error"] = str(e)[:200]
+        ex["shapes_error"] = str(e)[:200]
     # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
     try:
         cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-5,
@@ -330,55 +356,149 @@ def timed_loop(step, steps, warmup, world, gloo_group, graph=None):
     return elapsed, ev_ms
 
 
-def strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, overlap):
-    """Strong scaling: ONE fixed graph, default_partition (users and items each cut into `world` nnz-balanced node ranges),
-    no planted locality.  The global normalized CSR is built on the device and the rank's blocks are cut out of it there
-    (plan_from_csr) — nothing of size nnz is sorted on the host."""
-    name = "amazon-book" if world <= 4 else "g-1.3m"
-    uid, iid, nu, ni = rbg.synth.make(name)
-    owner = sh.default_partition(uid, iid, nu, ni, world)
+CONFIG5 = (10_000_001, 5_000_001, 200_000_000)  # BASELINE.json configs[4]: users / items / interactions (PAD rows included)
+
+
+def baseline_workload(world):
+    """BASELINE.json's configuration for this GPU count: (workload name, embedding width)."""
+    return {2: ("gowalla", 64), 4: ("amazon-book", 64), 8: ("config5", 128)}.get(world, ("amazon-book", 64))
+
+
+def load_workload(rbg, name, seed, rank, world, gloo_group):
+    """(uid, iid, n_users, n_items, note).  config5 (200 M interactions, 3.2 GB of ids) is generated ONCE on the node and
+    shared through /dev/shm; when the host cannot hold the generator's temporaries the 1.3 M-node shape stands in, with the
+    reason in `note`."""
+    import torch.distributed as dist
+    note = None
+    if name == "config5":
+        nu, ni, e = CONFIG5
+        path = f"/dev/shm/rbg_config5_seed{seed}.npz.npy"
+        ok = os.path.exists(path)
+        reason = None
+        if not ok and rank == 0:
+            try:
+                import psutil
+                avail = psutil.virtual_memory().available / 2 ** 30
+                shm = psutil.disk_usage("/dev/shm").free / 2 ** 30
+            except Exception:  # noqa: BLE001
+                avail, shm = 0.0, 0.0
+            if avail < 64 or shm < 4:
+                reason = f"host has {avail:.0f} GiB available RAM / {shm:.0f} GiB free in /dev/shm (need 64 / 4)"
+            else:
+                t0 = time.time()
+                uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=seed)
+                np.save(path + ".tmp.npy", np.stack([uid, iid]))
+                os.replace(path + ".tmp.npy", path)
+                del uid, iid
+                print(f"[bench] config5 graph generated in {time.time() - t0:.0f} s -> {path}", file=sys.stderr)
+        if world > 1:
+            box = [reason]
+            dist.broadcast_object_list(box, src=0, group=gloo_group)
+            reason = box[0]
+        if reason is None and os.path.exists(path):
+            both = np.load(path, mmap_mode="r")
+            return np.asarray(both[0]), np.asarray(both[1]), nu, ni, None
+        note = f"config5 replaced by g-1.3m: {reason or 'shared graph file missing'}"
+        name = "g-1.3m"
+    uid, iid, nu, ni = rbg.synth.make(name, seed=seed)
+    return uid, iid, nu, ni, note
+
+
+def strong_setup(rbg, sh, name, seed, world, rank, dev, d, gen, transport, gloo_group, overlap, partition="auto"):
+    """Strong scaling: ONE fixed graph cut into node shards (users and items each), no planted locality.  The global
+    normalized CSR is built on the device and the rank's blocks are cut out of it there (plan_from_csr) — nothing of size
+    nnz is sorted on the host."""
+    import torch.distributed as dist
+    uid, iid, nu, ni, note = load_workload(rbg, name, seed, rank, world, gloo_group)
+    owner, part_name, part_stats = sh.choose_partition(uid, iid, nu, ni, world, partition)
     g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     plan = sh.plan_from_csr(*g.device_csr(), nu, owner, rank, world)
     del g
+    torch.cuda.empty_cache()
     prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), group=gloo_group if transport == "staged" else None,
                                  transport=transport, overlap=overlap)
     e0 = xavier(plan.n_owned, d, gen).to(dev)
-    desc = (f"{name}-shape graph ({nu} users / {ni} items / {len(uid)} interactions) cut into {world} nnz-balanced node ranges "
-            f"per side, no planted locality, trimmed halo all_to_all per layer")
-    return prop, e0, plan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * len(uid), d, 3)
+    mine = (int(plan.n_owned), int(plan.int_csr[0][-1]) + int(plan.halo_csr[0][-1]), int(plan.n_halo))
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, mine, group=gloo_group)
+    else:
+        per_rank = [mine]
+    shape = "config5" if (name == "config5" and note is None) else ("g-1.3m" if note else name)
+    desc = (f"{shape}-shape graph ({nu} users / {ni} items / {len(uid)} interactions) cut into {world} node shards per side "
+            f"({part_name} partition), no planted locality, trimmed halo all_to_all per layer")
+    info = {"partition": part_name,
+            "partition_candidates(max over ranks)": {k: {"nnz": max(v["nnz"]), "rows": max(v["rows"]), "min_rows": min(v["rows"])}
+                                                      for k, v in part_stats.items()},
+            "per_rank(owned rows, nnz, halo rows)": per_rank, "workload_note": note}
+    return prop, e0, plan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * len(uid), d, 3), (uid, iid, nu, ni, shape), info
 
 
 def traffic_from_profiles(workload, d, kernel):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json; the counters need
-    their own rocprofv3 runs, so they cannot be collected inside this process).  None when no pass exists for this
-    workload / width / kernel."""
+    """(HBM-side bytes per launch, L2 hit rate) of `kernel` from the committed PMC passes (profiles/traffic.json; the
+    counters need their own rocprofv3 runs — devtools/traffic_session.sh — so they cannot be collected inside this process).
+    (None, None) when no pass exists for this workload / width / kernel."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(path):
-        try:
-            table = json.load(open(path))
-            rec = table.get(f"{workload}:d{d}:{kernel}")
-            if rec is not None:
-                return rec
-        except Exception:
-            return None
-    return None
+    try:
+        rec = json.load(open(path)).get(f"{workload}:d{d}:{kernel}")
+    except Exception:  # noqa: BLE001
+        rec = None
+    if isinstance(rec, dict):
+        return rec.get("traffic"), rec.get("l2_hit")
+    return rec, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here (one per GPU; when the box has fewer
+    GPUs the ranks share them through the host-staged transport) and pass their output through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = list(sys.argv[1:])
+    if args.transport is None and not args.launch_check:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        argv += ["--transport", "nccl" if n_dev >= args.gpus else "staged"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(self_launch(args))  # no launcher around us: start the ranks here
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    if args.launch_check:  # rendezvous only (CPU test of the self-launch path)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t) == world
+        if rank == 0:
+            print(json.dumps({"launch_check": world}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    if args.transport is None:
+        args.transport = "nccl" if torch.cuda.device_count() >= world else "staged"
     dev_index = local_rank if args.transport == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    import torch.distributed as dist
+    gloo_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.transport == "nccl":
@@ -386,19 +506,19 @@ def main():
             gloo_group = dist.new_group(backend="gloo")  # control plane + fallback transport
         else:
             dist.init_process_group("gloo")
-            gloo_group = None
 
     import recbole_gnn_amd as rbg
     from recbole_gnn_amd import sharded as sh
 
-    nu, ni, n_inter = rbg.synth.shape(args.workload)
-    d, k_layers = args.dim, args.layers
-    n = nu + ni
-    b_layer, b_prop = rbg.synth.algorithmic_bytes(n, 2 * n_inter, d, k_layers)
+    k_layers = args.layers
     gen = torch.Generator().manual_seed(args.seed + rank)
     extra = {}
 
     if world == 1:
+        wl_name, d = args.workload or "gowalla", args.dim or 64
+        nu, ni, n_inter = rbg.synth.shape(wl_name)
+        n = nu + ni
+        b_layer, b_prop = rbg.synth.algorithmic_bytes(n, 2 * n_inter, d, k_layers)
         uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, n_inter, seed=args.seed)
         graph = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
         uw_h, iw_h = xavier(nu, d, gen), xavier(ni, d, gen)
@@ -422,10 +542,18 @@ def main():
         kernel_name = graph.spmm_kernel_name(d)
         launches_per_step = k_layers
         units_per_step = 1
-        workload = (f"{args.workload}-shape synthetic power-law bipartite graph: {nu} users / {ni} items / "
+        scaling = "weak"  # N = 1: per-GPU work is what it is; the label only matters at N > 1
+        workload = (f"{wl_name}-shape synthetic power-law bipartite graph: {nu} users / {ni} items / "
                     f"{n_inter} interactions (PAD rows included), nnz(A_hat) = {2 * n_inter}")
     else:
         transport = args.transport
+        scaling = args.scaling
+        base_name, base_d = baseline_workload(world)
+        strong_name = args.workload or base_name
+        d = args.dim or (base_d if strong_name == base_name else 64)
+        weak_name = args.workload if (args.workload and args.workload != "config5") else "gowalla"
+        nu, ni, n_inter = rbg.synth.shape(weak_name)
+        one_gpu = {}
 
         def weak_setup():
             nu_g, ni_g = (nu - 1) * world + 1, (ni - 1) * world + 1
@@ -434,15 +562,18 @@ def main():
             wplan = sh.build_plans(wu, wi, nu_g, ni_g, world, owner=owner, ranks=[rank])[rank]
             wprop = sh.ShardedPropagation(wplan, sh.HipBackend(dev), group=gloo_group if transport == "staged" else None,
                                           transport=transport)
-            desc = (f"{world} x {args.workload}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
+            desc = (f"{world} x {weak_name}-shape blocks, node-range sharded: {nu_g} users / {ni_g} items / "
                     f"{n_inter * world} interactions, PLANTED locality p_in = {args.p_in} (striped communities = the partition), "
                     f"trimmed halo all_to_all per layer")
-            return wprop, xavier(wplan.n_owned, d, gen).to(dev), wplan, desc
+            return wprop, xavier(wplan.n_owned, d, gen).to(dev), wplan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * n_inter, d, k_layers)
 
-        if args.scaling == "weak":
-            prop, e0, plan, workload = weak_setup()
+        if scaling == "weak":
+            prop, e0, plan, workload, (b_layer, b_prop) = weak_setup()
+            strong_graph = None
         else:
-            prop, e0, plan, workload, (b_layer, b_prop) = strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, False)
+            prop, e0, plan, workload, (b_layer, b_prop), strong_graph, pinfo = strong_setup(
+                rbg, sh, strong_name, args.seed, world, rank, dev, d, gen, transport, gloo_group, False, args.partition)
+            extra.update(pinfo)
         if transport == "nccl":
             # rehearse one exchange; if RCCL cannot run it on this node, every rank falls back to the host-staged
             # gloo transport (slow, but the run still reports a labelled number instead of crashing)
@@ -465,42 +596,59 @@ def main():
             prop.forward(e0, k_layers)
 
         launches_per_step = k_layers
-        units_per_step = world if args.scaling == "weak" else 1
+        units_per_step = world if scaling == "weak" else 1
         kernel_name = prop.g_int.spmm_kernel_name(d)
-        extra.update(p_in=args.p_in if args.scaling == "weak" else None, halo_rows_rank0=int(plan.n_halo),
+        extra.update(p_in=args.p_in if scaling == "weak" else None, halo_rows_rank0=int(plan.n_halo),
                      owned_rows_rank0=int(plan.n_owned), halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4,
-                     overlap=bool(prop.overlap))
+                     overlap=bool(prop.overlap), transport=transport,
+                     rccl_ranks=(dist.get_world_size() if transport == "nccl" else 0))
 
-    # N = 1: the K timed steps are replayed from one HIP graph unless --eager (a 20-step region is 2.6 ms: a single host
-    # hiccup between two ctypes calls would otherwise be a visible share of it); N > 1 stays eager (collectives on side streams)
-    # Clock warm-up, untimed and outside the W warm-up steps: a fresh process needs ~10 ms of load before the GPU runs at
-    # its steady-state clocks (K = 20 after W = 5: 141.9 us of GPU time per step; after W = 100: 130.2 us) — and the
-    # driver's W is 5.  Disclosed in the line as `clock_warmup_steps`.
-    # (the warm-up runs directly in front of the timed region, after the graph capture: a few idle ms drop the clocks again)
+    # ---- timing ---------------------------------------------------------------------------------------------------------
+    # N = 1: the K timed steps are replayed from one HIP graph unless --eager (a 20-step region is 2.6 ms: a single host hiccup
+    # between two ctypes calls would otherwise be a visible share of it); N > 1 stays host-issued (collectives on side streams).
+    # The headline is measured at EXACTLY the flags given: W warm-up steps (+ --clock-warmup, default 0, counted in
+    # `warmup_effective`), K timed steps.  A fresh process needs ~10 ms of load before the GPU runs at its steady clocks, more
+    # than the driver's W = 5 gives it, so the steady-clock figure is measured too (150 extra untimed propagations in front of
+    # the same region) and reported beside the headline as `steady_clock`.
     clock_warmup = max(0, args.clock_warmup)
-    extra["clock_warmup_steps"] = clock_warmup
+    if world == 1:  # first of all, the plain protocol: W host-issued warm-up steps, K host-issued timed steps, nothing else
+        el0, ev0 = timed_loop(step, args.steps, args.warmup, world, None)
+        extra["value_at_driver_flags_no_clock_warmup"] = {
+            "value": args.steps / el0, "ms_per_step": el0 * 1e3 / args.steps, "timed_region": "K host-issued steps",
+            "warmup_effective": args.warmup, "avg_launch_us": ev0 * 1e3 / (args.steps * launches_per_step)}
     step_graph = capture_steps(step, args.steps) if (world == 1 and not args.eager) else None
+    if world == 1 and step_graph is not None:
+        time.sleep(0.05)  # the capture left the GPU idle anyway; make the cold start the same run to run
     elapsed, ev_ms = timed_loop(step, args.steps, args.warmup + clock_warmup, world, gloo_group if world > 1 else None, graph=step_graph)
+    # (timed_loop replays the captured graph once, untimed, to upload it: K more propagations of warm-up)
+    extra["warmup_effective"] = args.warmup + clock_warmup + (args.steps if step_graph is not None else 0)
     extra["timed_region"] = "one HIP-graph replay of the K steps" if step_graph is not None else "K host-issued steps"
-    if step_graph is not None:  # and the host-issued loop beside it
-        el_e, _ = timed_loop(step, args.steps, min(args.warmup, 5), world, None)
-        extra["eager_ms_per_step"] = el_e * 1e3 / args.steps
+    if world == 1:
+        el_s, ev_s = timed_loop(step, args.steps, args.warmup + 150, world, None, graph=step_graph)
+        extra["steady_clock"] = {"value": args.steps / el_s, "ms_per_step": el_s * 1e3 / args.steps, "warmup_effective": args.warmup + 150,
+                                 "avg_launch_us": ev_s * 1e3 / (args.steps * launches_per_step),
+                                 "roofline_frac": b_layer / (ev_s * 1e-3 / (args.steps * launches_per_step)) / 1e9 / HBM_PEAK_GBPS}
+        if step_graph is not None:  # and the host-issued loop beside it
+            el_e, _ = timed_loop(step, args.steps, args.warmup, world, None)
+            extra["eager_ms_per_step"] = el_e * 1e3 / args.steps
 
     if world > 1 and not args.no_secondary:
         # the other scaling mode, same process group, bounded: its own short timed loop
         try:
-            if args.scaling == "weak":
-                p2, e2, plan2, desc2, _ = strong_setup(rbg, sh, world, rank, dev, d, gen, transport, gloo_group, prop.overlap)
+            if scaling == "weak":
+                p2, e2, plan2, desc2, _, strong_graph, pinfo2 = strong_setup(rbg, sh, strong_name, args.seed, world, rank, dev, d, gen,
+                                                                             transport, gloo_group, prop.overlap, args.partition)
                 units2, label2 = 1, "strong"
             else:
-                p2, e2, plan2, desc2 = weak_setup()
+                p2, e2, plan2, desc2, _ = weak_setup()
                 p2.set_overlap(prop.overlap)
-                units2, label2 = world, "weak"
+                units2, label2, pinfo2 = world, "weak", {}
             steps2 = max(10, min(args.steps, 100))
             el2, _ = timed_loop(lambda: p2.forward(e2, k_layers), steps2, max(3, min(args.warmup, 10)), world, gloo_group)
             secondary = {"scaling": label2, "value": units2 * steps2 / el2, "unit": "propagations/s", "ms_per_step": el2 * 1e3 / steps2,
                          "steps": steps2, "workload": desc2, "halo_rows_rank0": int(plan2.n_halo), "owned_rows_rank0": int(plan2.n_owned),
                          "p_in": args.p_in if label2 == "weak" else None}
+            secondary.update({k: v for k, v in pinfo2.items() if k == "partition"})
             del p2, e2
         except Exception as ex:  # noqa: BLE001  (a deterministic failure is raised on every rank alike)
             secondary = {"error": str(ex)[:300]}
@@ -533,34 +681,65 @@ def main():
                 "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
                 "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
             }
+            del halo_buf, y_buf
         except Exception as ex:  # noqa: BLE001
             extra["phase_us_error"] = str(ex)[:200]
+        # the same graph on ONE GPU (rank 0, the others wait): what the sharded number has to be compared with
+        if strong_graph is not None:
+            try:
+                if rank == 0:
+                    su, si, snu, sni, sname = strong_graph
+                    del prop, e0
+                    torch.cuda.empty_cache()
+                    g1 = rbg.GraphHandle.from_interactions(su, si, snu, sni, device=dev)
+                    x1 = xavier(snu + sni, d, gen).to(dev)
+                    o1, l1 = torch.empty(snu + sni, d, device=dev), torch.empty(max(k_layers, 1), snu + sni, d, device=dev)
+                    reps = 3 if snu + sni > 4_000_000 else 30
+                    f1 = lambda: rbg.ops.lightgcn_forward_raw(g1, x1[:snu], x1[snu:], k_layers, out=o1, layers=l1)  # noqa: E731
+                    f1()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(reps):
+                        f1()
+                    torch.cuda.synchronize()
+                    one_gpu = {"workload": sname, "value": reps / (time.perf_counter() - t1), "unit": "propagations/s", "reps": reps,
+                               "kernel": g1.spmm_kernel_name(d)}
+                    del g1, x1, o1, l1
+                dist.barrier(group=gloo_group)
+            except Exception as ex:  # noqa: BLE001
+                one_gpu = {"error": str(ex)[:200]}
+            extra["same_workload_one_gpu"] = one_gpu
 
     if rank == 0:
         launch_us = ev_ms * 1e3 / (args.steps * launches_per_step)
         achieved = b_layer / (launch_us * 1e-6) / 1e9
+        value = units_per_step * args.steps / elapsed
+        if world > 1 and scaling == "strong" and one_gpu.get("value"):
+            extra["speedup_vs_one_gpu_same_workload"] = value / one_gpu["value"]
+        traffic, l2_hit = traffic_from_profiles(wl_name, d, kernel_name) if world == 1 else (None, None)
         result = {
             "metric": "LightGCN propagations/sec",
-            "value": units_per_step * args.steps / elapsed,
+            "value": value,
             "unit": "propagations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
-            "scaling": args.scaling if world > 1 else "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload, "embedding_dim": d, "n_layers": k_layers,
                        "algorithmic_bytes_per_layer": b_layer, "algorithmic_bytes_per_propagation": b_prop,
                        "sharding": "none" if world == 1 else
-                       f"node-range x{world}, transport={transport}, {'exchange overlapped on a second stream' if prop.overlap else 'single-stream layers'}"},
+                       f"node shards x{world}, transport={extra['transport']}, "
+                       f"{'exchange overlapped on a second stream' if extra['overlap'] else 'single-stream layers'}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic_from_profiles(args.workload, d, kernel_name) if world == 1 else None,
-                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of "
-                                           "this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per the gfx950 correction)",
+                         "traffic": traffic, "l2_hit": l2_hit,
+                         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,TCC_MISS, separate "
+                                           "passes, devtools/traffic_session.sh; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per the gfx950 correction)",
                          "kernel": kernel_name, "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "

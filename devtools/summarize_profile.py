@@ -37,7 +37,10 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     except Exception:
         table = {}
     key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:spmm_binned_kernel<64, 8, true, false>"
-    table[key] = traffic
+    rec = {"traffic": traffic, "fetch_size_kib": pmc["FETCH_SIZE"]["mean"], "write_size_kib": pmc["WRITE_SIZE"]["mean"]}
+    if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+        rec["l2_hit"] = pmc["TCC_HIT_sum"]["mean"] / (pmc["TCC_HIT_sum"]["mean"] + pmc["TCC_MISS_sum"]["mean"])
+    table[key] = rec
     table["_bench_command_note"] = ("the key above is refreshed by devtools/profile_session.sh from PMC passes of `python bench.py --steps 100 "
                                     "--warmup 10 --cpu-seconds 0 --no-extras --eager`: mean over all SpMM launches of that command")
     json.dump(table, open(tpath, "w"), indent=1)

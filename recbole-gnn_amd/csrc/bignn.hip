@@ -472,14 +472,15 @@ __global__ __launch_bounds__(256) void bignn_dense_pipe_kernel(const BignnParams
     RBG_STAMP(stamp);
 }
 
-static int device_cu_count() {
-    static std::atomic<int> cached{0};
-    int v = cached.load();
-    if (v > 0) return v;
+static int device_cu_count() {  // of the CURRENT device (cached per device: a process may drive several)
+    static std::atomic<int> cached[16] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-        v = 256;
-    cached = v;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const bool slot = dev >= 0 && dev < 16;
+    int v = slot ? cached[dev].load() : 0;
+    if (v > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    if (slot) cached[dev] = v;
     return v;
 }
 

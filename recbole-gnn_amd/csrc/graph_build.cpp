@@ -831,11 +831,28 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
     // the other side's table, and the lean gather may address that table alone)
     sw->class_split = 0;
     if (g->n_users > 0 && g->n_users < g->n_rows) {
+        // ... and every column such a workgroup gathers lies on the OTHER side of the boundary (true for a bipartite graph;
+        // the lean gather addresses one table through a buffer resource, so a column on the wrong side would be read from
+        // outside it): checked entry by entry, otherwise the plan runs with the plain gather
         bool pure = true;
+        std::vector<int8_t> wg_class((size_t)n_wg, -1);
         for (int w = 0; w < n_wg && pure; ++w) {
             bool lo = false, hi = false;
             for (int64_t r = wg_row_ptr[w]; r < wg_row_ptr[w + 1]; ++r) (rows[4 * r] < g->n_users ? lo : hi) = true;
             pure = !(lo && hi);
+            wg_class[(size_t)w] = lo ? 0 : (hi ? 1 : -1);
+        }
+        for (int64_t l = 0; l < n_lg && pure; ++l) {
+            const int cls = wg_class[(size_t)(l / lgs)];
+            for (int64_t q = lg_ptr[l]; q < lg_ptr[l + 1] && pure; ++q) {
+                const uint32_t beg = pieces[2 * q], meta = pieces[2 * q + 1];
+                if ((meta >> 24) & 2u) continue;  // HOT pieces index the LDS tile
+                const int cnt = (int)((meta >> 16) & 0xffu);
+                for (int j = 0; j < cnt && pure; ++j) {
+                    const int32_t c = ent[2 * ((int64_t)beg + j)];
+                    pure = cls < 0 || (cls == 0 ? c >= g->n_users : c < g->n_users);
+                }
+            }
         }
         if (pure) sw->class_split = g->n_users;
     }

@@ -222,16 +222,25 @@ static int shard_layer(rbg_shard *s, const float *X, float *Y, int d, const floa
         int rc;
         if (s->n_send && (rc = rbg_gather_rows_f32(X, d, s->d_send_idx, s->d_send, s->n_send, d, cs))) return rc;
         RBG_NCCL(api, api->GroupStart());
+        // inside the group the first error is remembered, not returned: the group must be closed and halo_ready recorded
+        // on every path, or this rank's (and its peers') next call would wait on a collective that was never issued
+        ncclResult_t first = ncclSuccess;
         int64_t so = 0, ro = 0;
         for (int q = 0; q < nranks; ++q) {
             const int64_t sc = s->send_counts[(size_t)q], rcv = s->recv_counts[(size_t)q];
-            if (sc) RBG_NCCL(api, api->Send(s->d_send + so * d, (size_t)(sc * d), ncclFloat, q, s->comm->comm, cs));
-            if (rcv) RBG_NCCL(api, api->Recv(s->d_halo + ro * d, (size_t)(rcv * d), ncclFloat, q, s->comm->comm, cs));
+            ncclResult_t r = ncclSuccess;
+            if (sc && first == ncclSuccess) r = api->Send(s->d_send + so * d, (size_t)(sc * d), ncclFloat, q, s->comm->comm, cs);
+            if (r != ncclSuccess) first = r;
+            if (rcv && first == ncclSuccess) r = api->Recv(s->d_halo + ro * d, (size_t)(rcv * d), ncclFloat, q, s->comm->comm, cs);
+            if (r != ncclSuccess) first = r;
             so += sc;
             ro += rcv;
         }
-        RBG_NCCL(api, api->GroupEnd());
-        RBG_HIP(hipEventRecord(s->halo_ready, cs));
+        const ncclResult_t end = api->GroupEnd();
+        if (first == ncclSuccess) first = end;
+        (void)hipEventRecord(s->halo_ready, cs);
+        if (first != ncclSuccess)
+            return fail(RBG_EHIP, "halo exchange failed: %s", api->GetErrorString ? api->GetErrorString(first) : "RCCL error");
     }
     int rc;
     const bool last = out_mean != nullptr;

@@ -38,12 +38,13 @@ def global_reference(uid, iid, nu, ni, e0, k_layers):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-@pytest.mark.parametrize("layout", ["ranges", "striped"])
+@pytest.mark.parametrize("layout", ["ranges", "striped", "degree-striped"])
 def test_plan_algebra(rbg, ref_inter, world, layout):
     uid, iid, nu, ni = ref_inter
     n = nu + ni
     sh = rbg.sharded
-    owner = None if layout == "ranges" else sh.striped_partition(nu, ni, world)
+    owner = {"ranges": None, "striped": sh.striped_partition(nu, ni, world),
+             "degree-striped": sh.degree_striped_partition(uid, iid, nu, ni, world)}[layout]
     plans = sh.build_plans(uid, iid, nu, ni, world, owner=owner)
     x = np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
@@ -85,6 +86,29 @@ def test_plan_algebra(rbg, ref_inter, world, layout):
     if layout == "ranges" and world > 1:
         nnz = [p.int_csr[0][-1] + p.halo_csr[0][-1] for p in plans.values()]
         assert max(nnz) < 1.6 * (sum(nnz) / world)  # nnz-balanced
+    if layout == "degree-striped" and world > 1:
+        # rows within one of each other per side, nnz within a few per cent, and the degree-only statistics agree with the plans
+        rows = [p.n_owned for p in plans.values()]
+        nnz = [int(p.int_csr[0][-1] + p.halo_csr[0][-1]) for p in plans.values()]
+        assert max(rows) - min(rows) <= 2 and max(nnz) < 1.15 * (sum(nnz) / world)
+        st = sh.partition_stats(uid, iid, nu, ni, owner, world)
+        assert st["rows"] == rows and st["nnz"] == nnz
+
+
+def test_degree_striped_partition_balances_the_halo(rbg):
+    """contiguous nnz-balanced ranges of popularity-sorted ids give rank 0 a few very heavy rows and a
+    halo of almost the whole other side; dealing the degree order round-robin balances rows, nnz AND halo rows."""
+    sh = rbg.sharded
+    nu, ni, e = 2001, 3001, 60_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=5)
+    for world in (2, 4):
+        ranges = sh.build_plans(uid, iid, nu, ni, world)
+        owner, name, stats = sh.choose_partition(uid, iid, nu, ni, world)
+        assert name == "striped" and set(stats) == {"ranges", "striped"}
+        striped = sh.build_plans(uid, iid, nu, ni, world, owner=owner)
+        ratio = lambda plans: max(p.n_halo / max(p.n_owned, 1) for p in plans.values())  # noqa: E731
+        assert ratio(striped) < 0.5 * ratio(ranges)
+        assert max(p.n_owned for p in striped.values()) < max(p.n_owned for p in ranges.values())
 
 
 def test_block_structure_trims_the_halo(rbg):
