@@ -369,3 +369,87 @@ def test_c_abi_sharded_path_on_a_one_rank_communicator(ref_inter):
     p.join(timeout=120)
     assert p.exitcode == 0
     assert err_layer <= 1e-5 and max(errs) <= 1e-5 and err1 <= 1e-5, (err_layer, errs, err1)
+
+
+# ---- round 3: the sharded training step through the HIP backend ------------------------------------------------------------------
+
+def _worker_train(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        from recbole_gnn_amd import sharded_train as st
+        sh = rbg.sharded
+        dev = torch.device("cuda:0")
+        n = nu + ni
+        rng = np.random.default_rng(3)
+        e0 = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+        masks = []
+        for seed in (5, 6):
+            keep = np.zeros(len(uid), dtype=np.uint8)
+            keep[np.random.default_rng(seed).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+            masks.append(keep)
+        b = 256
+        user, pos, neg = rng.integers(1, nu, b), rng.integers(1, ni, b), rng.integers(1, ni, b)
+        user[:4], pos[:4] = user[4:8], pos[4:8]
+        owner = sh.degree_striped_partition(uid, iid, nu, ni, world)
+        plans = [sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=m)[rank] for m in (None, *masks)]
+        # the single-device model on the same GPU: SGL.calculate_loss / LightGCN.calculate_loss of the mirror (models.py)
+        ds = rbg.InteractionDataset(uid, iid, nu, ni)
+        inter = {"user_id": torch.from_numpy(user).to(dev), "item_id": torch.from_numpy(pos).to(dev), "neg_item_id": torch.from_numpy(neg).to(dev)}
+        out = {}
+        for name in ("sgl", "lightgcn"):
+            cfg = {"device": "cuda:0", "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-3,
+                   "ssl_tau": 0.5, "ssl_weight": 0.05, "type": "ED", "drop_ratio": 0.1, "require_pow": False}
+            model = (rbg.SGL if name == "sgl" else rbg.LightGCN)(cfg, ds)
+            with torch.no_grad():
+                model.user_embedding.weight.copy_(torch.from_numpy(e0[:nu]))
+                model.item_embedding.weight.copy_(torch.from_numpy(e0[nu:]))
+            if name == "sgl":
+                views = [rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev, keep=m) for m in masks]
+                model.sub_graph1, model.sub_graph2 = [(views[0], None)] * k_layers, [(views[1], None)] * k_layers
+            model.train(False)  # (train(True) would redraw the views)
+            ref = model.calculate_loss(inter)
+            ref.backward()
+            ref_grad = torch.cat([model.user_embedding.weight.grad, model.item_embedding.weight.grad]).cpu().numpy()
+            tr = st.ShardedTrainer(plans[0], sh.HipBackend(dev), torch.from_numpy(e0[plans[0].owned]).to(dev), nu, ni, k_layers,
+                                   view_plans=plans[1:] if name == "sgl" else None, transport="staged", lr=1e-2, reg_weight=1e-3,
+                                   ssl_tau=0.5, ssl_weight=0.05)
+            loss = tr.loss(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+            loss.backward()
+            torch.cuda.synchronize()
+            gerr = float(np.abs(tr.e0.grad.cpu().numpy() - ref_grad[plans[0].owned]).max())
+            v0 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+            v1 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+            out[name] = (float(loss.detach()), float(ref.detach()), gerr, float(np.abs(ref_grad).max()), v0, v1)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, out))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_training_step_hip_backend(ref_inter):
+    """sharded_train.ShardedTrainer with the product backend, two ranks sharing cuda:0: the loss value and dL/dE0 of one SGL
+    step (sgl.py:211-233, InfoNCE denominators by the distributed logsumexp over rbg_lse_rows_f32) and of one LightGCN step
+    (lightgcn.py:83-110) against the single-device model mirror on the same GPU; two optimizer steps lower the loss."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_train, args=(r, 2, port, uid, iid, nu, ni, 3, 64, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for name, (loss, ref, gerr, scale, v0, v1) in out.items():
+            assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (rank, name, loss, ref)
+            assert gerr <= 1e-5 * max(1.0, scale), (rank, name, gerr, scale)
+            assert abs(v0 - loss) <= 1e-6 * max(1.0, abs(loss)) and v1 < v0, (rank, name, v0, v1)
