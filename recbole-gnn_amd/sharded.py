@@ -676,6 +676,58 @@ class ShardedPropagation:
         return u @ item_table.T
 
 
+class LayeredShardedPropagation:
+    """A propagation whose layer k has its OWN matrix (SGL's "RW" augmentation, sgl.py:89-91: one sub-graph per layer; the
+    reference passes a list of K (edge_index, edge_weight) pairs to forward, sgl.py:137-139): one ShardedPropagation per
+    layer, all on the same partition, so a layer's output rows are the next layer's input rows.  Same calls as
+    ShardedPropagation where ``sharded_sgl_forward`` / ``ShardedTrainer`` use them; the halo of E0 (first_halo) is the
+    FIRST layer's."""
+
+    def __init__(self, layer_plans, backend, group=None, transport="nccl", overlap=False):
+        if not layer_plans:
+            raise ValueError("at least one layer plan")
+        owned = layer_plans[0].owned
+        for pl in layer_plans[1:]:
+            if not np.array_equal(pl.owned, owned):
+                raise ValueError("the layer plans must share one partition")
+        self.layers = [ShardedPropagation(pl, backend, group=group, transport=transport, overlap=overlap) for pl in layer_plans]
+        self.plan, self.backend = layer_plans[0], backend
+        self.device = self.layers[0].device
+
+    @property
+    def overlap(self):
+        return self.layers[0].overlap
+
+    def halo_map_from(self, other_plan):
+        return self.layers[0].halo_map_from(other_plan)
+
+    def remap_halo(self, halo_other, index, out=None):
+        return self.layers[0].remap_halo(halo_other, index, out=out)
+
+    def forward(self, e0, n_layers, out=None, first_halo=None):
+        if n_layers != len(self.layers):
+            raise ValueError(f"{len(self.layers)} layer plans but n_layers = {n_layers}")
+        acc, x = e0.clone(), e0
+        for k, lay in enumerate(self.layers):
+            x = lay.spmm(x, halo_rows=first_halo if k == 0 else None)
+            acc += x
+        acc /= float(n_layers + 1)
+        if out is not None:
+            out.copy_(acc)
+            return out
+        return acc
+
+    def backward(self, grad_out, n_layers):
+        """dE0 = (g + A_1 (g + A_2 (... (g + A_K g)))) / (K + 1): every A_k symmetric (sgl.py:113-115 rebuilds both
+        directions), so step i is layer K - 1 - i's sharded product."""
+        g = grad_out.contiguous()
+        x = g
+        for lay in reversed(self.layers):
+            x = lay.spmm(x)
+            x = x + g
+        return x / float(n_layers + 1)
+
+
 class _ShardedLightGCN(torch.autograd.Function):
     """Autograd over ShardedPropagation.forward (fused mean) / .backward (Horner chain of the same sharded product)."""
 

@@ -123,7 +123,7 @@ class ShardedTrainer:
         self.n_users, self.n_items, self.n_layers = int(n_users), int(n_items), int(n_layers)
         self.reg_weight, self.ssl_tau, self.ssl_weight, self.require_pow = reg_weight, ssl_tau, ssl_weight, require_pow
         self.main = sh.ShardedPropagation(plan, backend, group=group, transport=transport, overlap=overlap)
-        self.views = [sh.ShardedPropagation(p, backend, group=group, transport=transport, overlap=overlap) for p in (view_plans or [])]
+        self.views = [self._make_view(p, backend, overlap) for p in (view_plans or [])]
         self.maps = [v.halo_map_from(plan) for v in self.views]
         dev = e0_local.device
         self.e0 = e0_local.detach().clone().requires_grad_(True)
@@ -137,11 +137,16 @@ class ShardedTrainer:
         self._cgroup = group
         self.world = plan.world
 
+    def _make_view(self, p, backend, overlap):
+        """One view = one plan (ND / ED: the same sub-graph at every layer) or a list of K plans (RW: one per layer)."""
+        if isinstance(p, (list, tuple)):
+            return sh.LayeredShardedPropagation(list(p), backend, group=self.group, transport=self.transport, overlap=overlap)
+        return sh.ShardedPropagation(p, backend, group=self.group, transport=self.transport, overlap=overlap)
+
     def set_views(self, view_plans):
         """A new pair of views (sgl.py:73-80: rebuilt once per epoch)."""
         backend = self.main.backend
-        self.views = [sh.ShardedPropagation(p, backend, group=self.group, transport=self.transport, overlap=self.main.overlap)
-                      for p in view_plans]
+        self.views = [self._make_view(p, backend, self.main.overlap) for p in view_plans]
         self.maps = [v.halo_map_from(self.plan) for v in self.views]
 
     # -- pieces ------------------------------------------------------------------------------------------------------------

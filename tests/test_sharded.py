@@ -480,3 +480,69 @@ def test_two_process_gloo_training_step(ref_inter, layout):
             values.setdefault(name, []).append(v)
     for name, vs in values.items():  # every rank evaluates the same scalar
         assert max(vs) - min(vs) <= 1e-6 * max(1.0, abs(vs[0])), (name, vs)
+
+
+def _worker_rw(rank, world, port, uid, iid, nu, ni, k_layers, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        n, d = nu + ni, 16
+        rng = np.random.default_rng(4)
+        e0 = rng.standard_normal((n, d)).astype(np.float32)
+        w = rng.standard_normal((n, d)).astype(np.float32)
+        masks = []
+        for seed in range(k_layers):  # RW: an independent edge sample per layer (sgl.py:89-91)
+            keep = np.zeros(len(uid), dtype=np.uint8)
+            keep[np.random.default_rng(20 + seed).permutation(len(uid))[: int(len(uid) * 0.9)]] = 1
+            masks.append(keep)
+        owner = sh.degree_striped_partition(uid, iid, nu, ni, world)
+        full = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank])[rank]
+        layer_plans = [sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank], keep=m)[rank] for m in masks]
+        main = sh.ShardedPropagation(full, CpuBackend(), transport="staged")
+        view = sh.LayeredShardedPropagation(layer_plans, CpuBackend(), transport="staged")
+        x = torch.from_numpy(e0[full.owned]).requires_grad_(True)
+        m_full, m_rw = sh.sharded_sgl_forward(main, [view], x, k_layers)
+        (m_rw * torch.from_numpy(w[full.owned])).sum().backward()
+        csrs = [C.build_norm_csr(uid, iid, nu, ni, keep=m) for m in masks]
+        cur, acc = e0.copy(), e0.copy()
+        for rp, cc, vv in csrs:  # sgl.py:137-139: layer k on ITS graph
+            cur = C.spmm(rp, cc, vv, cur)
+            acc += cur
+        ref = acc / (k_layers + 1)
+        t = w.copy()
+        for rp, cc, vv in reversed(csrs):  # (w + A_1 (w + A_2 (... (w + A_K w)))) / (K + 1)
+            t = w + C.spmm(rp, cc, vv, t)
+        gref = t / (k_layers + 1)
+        rp, cc, vv = C.build_norm_csr(uid, iid, nu, ni)
+        ref_full = C.lightgcn_forward(rp, cc, vv, e0[:nu], e0[nu:], k_layers)
+        res = (float(np.abs(m_rw.detach().numpy() - ref[full.owned]).max()), float(np.abs(x.grad.numpy() - gref[full.owned]).max()),
+               float(np.abs(m_full.detach().numpy() - ref_full[full.owned]).max()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, res))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_rw_views_have_one_plan_per_layer(ref_inter):
+    """sgl.py:89-91 / :137-139 ("RW": one sub-graph per layer) over two shards: LayeredShardedPropagation inside
+    sharded_sgl_forward (E0's halo shared with the full graph's propagation), forward and gradient against the oracle."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_rw, args=(r, 2, port, uid, iid, nu, ni, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, (err, gerr, ferr) in res:
+        assert err <= 1e-5 and gerr <= 1e-5 and ferr <= 1e-5, (rank, err, gerr, ferr)
