@@ -45,6 +45,8 @@ int opt_nt_store() { return g_nt_store.load(); }
 int opt_topk_sample() { return g_topk_sample.load(); }
 int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
+static std::atomic<int> g_shard_single_stream{0};
+int opt_shard_single_stream() { return g_shard_single_stream.load(); }
 int opt_sweep() { return g_sweep.load(); }
 int opt_sweep_lean() { return g_sweep_lean.load(); }
 int opt_bignn_dma() { return g_bignn_dma.load(); }
@@ -461,6 +463,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sweep = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "shard_single_stream")) {
+        g_shard_single_stream = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -498,6 +504,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "nt_store")) {
         *value = g_nt_store.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "shard_single_stream")) {
+        *value = g_shard_single_stream.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

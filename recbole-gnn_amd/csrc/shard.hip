@@ -215,10 +215,15 @@ static int shard_layer(rbg_shard *s, const float *X, float *Y, int d, const floa
     if (!api) return fail(RBG_EUNSUPPORTED, "RCCL is not available");
     const int nranks = s->comm->nranks;
     const bool exchange = nranks > 1 || s->n_send > 0;
+    // "shard_single_stream": pack and exchange on the caller's stream, no fork (nothing overlaps, but the layer is a plain
+    // stream-ordered sequence — the form that HIP-graph capture takes)
+    const bool forked = !opt_shard_single_stream();
     if (exchange) {
-        hipStream_t cs = s->comm_stream;
-        RBG_HIP(hipEventRecord(s->x_ready, ms));
-        RBG_HIP(hipStreamWaitEvent(cs, s->x_ready, 0));
+        hipStream_t cs = forked ? s->comm_stream : ms;
+        if (forked) {
+            RBG_HIP(hipEventRecord(s->x_ready, ms));
+            RBG_HIP(hipStreamWaitEvent(cs, s->x_ready, 0));
+        }
         int rc;
         if (s->n_send && (rc = rbg_gather_rows_f32(X, d, s->d_send_idx, s->d_send, s->n_send, d, cs))) return rc;
         RBG_NCCL(api, api->GroupStart());
@@ -238,7 +243,7 @@ static int shard_layer(rbg_shard *s, const float *X, float *Y, int d, const floa
         }
         const ncclResult_t end = api->GroupEnd();
         if (first == ncclSuccess) first = end;
-        (void)hipEventRecord(s->halo_ready, cs);
+        if (forked) (void)hipEventRecord(s->halo_ready, cs);
         if (first != ncclSuccess)
             return fail(RBG_EHIP, "halo exchange failed: %s", api->GetErrorString ? api->GetErrorString(first) : "RCCL error");
     }
@@ -246,7 +251,7 @@ static int shard_layer(rbg_shard *s, const float *X, float *Y, int d, const floa
     const bool last = out_mean != nullptr;
     if (last && !s->g_halo) return rbg_spmm_mean_f32(s->g_int, X, nullptr, srcs, n_srcs, out_mean, d, ms);
     if ((rc = rbg_spmm_f32(s->g_int, X, Y, d, 0, ms))) return rc;  // overlaps with the exchange on the comm stream
-    if (exchange) RBG_HIP(hipStreamWaitEvent(ms, s->halo_ready, 0));
+    if (exchange && forked) RBG_HIP(hipStreamWaitEvent(ms, s->halo_ready, 0));
     if (!s->g_halo) return RBG_OK;
     if (last) return rbg_spmm_mean_f32(s->g_halo, s->d_halo, Y, srcs, n_srcs, out_mean, d, ms);
     return rbg_spmm_f32(s->g_halo, s->d_halo, Y, d, 1, ms);

@@ -234,6 +234,28 @@ def plan_from_csr(rowptr, col, val, n_users, owner, rank, world):
                      send_idx, send_counts)
 
 
+def self_exchange_plan(plan, every=3):
+    """A world-size-1 plan that exchanges every `every`-th row with ITSELF (test / probe device: one GPU then runs the
+    pack, the collective, the interior and the halo product of the multi-GPU path).  Same result as the plain plan."""
+    if plan.world != 1:
+        raise ValueError("self_exchange_plan takes a world-size-1 plan")
+    rp, col, val = (np.asarray(a) for a in plan.int_csr)
+    n = plan.n_owned
+    halo_nodes = np.arange(0, n, every)
+    slot = -np.ones(n, dtype=np.int64)
+    slot[halo_nodes] = np.arange(len(halo_nodes))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    is_halo = slot[col] >= 0
+
+    def csr(mask, cols):
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(ptr, rows[mask] + 1, 1)
+        return np.cumsum(ptr), cols.astype(np.int32), val[mask].astype(np.float32)
+
+    return ShardPlan(0, 1, plan.owned, plan.n_users_owned, csr(~is_halo, col[~is_halo]), csr(is_halo, slot[col[is_halo]]),
+                     halo_nodes, np.array([len(halo_nodes)]), halo_nodes.copy(), np.array([len(halo_nodes)]))
+
+
 # ---- compute backends ----------------------------------------------------------------------------
 
 class HipBackend:
@@ -835,6 +857,15 @@ class RcclShard:
                                                                        self._lib.c_vp(layers.data_ptr()), e0.shape[1], n_layers,
                                                                        self._stream()))
         self._layers = layers  # stream-ordered use: keep the buffer alive until the next call
+        return out
+
+    def forward_into(self, e0, n_layers, out, layers):
+        """The same propagation into caller-owned buffers (``layers``: [n_layers, n_owned, d]): no allocation, so the call
+        can sit inside a HIP-graph capture — the library issues its grouped ncclSend / ncclRecv on its own comm stream,
+        forked from and joined back to the capturing stream by events."""
+        self._lib.check(self._lib.lib.rbg_lightgcn_forward_sharded_f32(self._shard, self._lib.c_vp(e0.data_ptr()), self._lib.c_vp(out.data_ptr()),
+                                                                       self._lib.c_vp(layers.data_ptr()), e0.shape[1], n_layers,
+                                                                       self._stream()))
         return out
 
     def close(self):
