@@ -50,6 +50,7 @@ extern "C" {
 /* rbg_lightgcn_forward_f32 flags */
 #define RBG_FWD_DEFAULT          0u
 #define RBG_FWD_KEEP_LAST_LAYER  1u  /* also write E_K into layers[K-1] (autograd needs only E_1..E_{K-1}) */
+#define RBG_FWD_LAYERS_SCRATCH   2u  /* the caller will not read `layers`: the library may keep any layout in it (option "slab") */
 
 /* rbg_bignn_conv_f32 flags */
 #define RBG_BIGNN_CONV_ONLY      0u  /* exactly BiGNNConv.forward */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "librbgnn.so")
 RBG_OK = 0
 RBG_EINVAL, RBG_ENOMEM, RBG_EHIP, RBG_ESHAPE, RBG_ENODEV, RBG_EUNSUPPORTED = -1, -2, -3, -4, -5, -6
 GRAPH_DEFAULT, GRAPH_KEEP_HOST, GRAPH_BUILD_ON_HOST, GRAPH_NATURAL_ORDER, GRAPH_INPUTS_ON_DEVICE = 0, 1, 2, 4, 8
-FWD_DEFAULT, FWD_KEEP_LAST_LAYER = 0, 1
+FWD_DEFAULT, FWD_KEEP_LAST_LAYER, FWD_LAYERS_SCRATCH = 0, 1, 2
 BIGNN_CONV_ONLY, BIGNN_LEAKY_NORM = 0, 1
 MAX_FUSED_LAYERS = 8
 

@@ -46,6 +46,8 @@ int opt_topk_sample() { return g_topk_sample.load(); }
 int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
 static std::atomic<int> g_shard_single_stream{0};
+static std::atomic<int> g_slab{0};
+int opt_slab() { return g_slab.load(); }
 int opt_shard_single_stream() { return g_shard_single_stream.load(); }
 int opt_sweep() { return g_sweep.load(); }
 int opt_sweep_lean() { return g_sweep_lean.load(); }
@@ -467,6 +469,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_shard_single_stream = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "slab")) {
+        g_slab = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -508,6 +514,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "shard_single_stream")) {
         *value = g_shard_single_stream.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "slab")) {
+        *value = g_slab.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

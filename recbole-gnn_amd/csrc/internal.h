@@ -37,6 +37,7 @@ int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the bi
 int opt_sweep_lean();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
+int opt_slab();          // rbg_lightgcn_forward_f32: keep the layers as two column slabs (column-half kernel over contiguous half rows)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)

@@ -64,6 +64,8 @@ struct SpmmParams {
     GroupPlan grp[kMaxGroups];
     int32_t mode;
     int32_t nt_store;
+    int32_t slab;  // column-half launch over operands in slab layout [2][rows][D] (SLAB instantiation): X, Y, e0, prev, addend
+    int32_t pad2;
     // MODE_HORNER: y[row] = (addend[row] + acc) / denom   (one step of the backward chain)
     // MODE_NOISE:  y[row] = acc + sign(acc) * addend[row] / max(||addend[row]||, 1e-12) * denom   (addend = noise, denom = eps)
     const float *addend;
@@ -177,7 +179,7 @@ __device__ __forceinline__ float4 lean_piece(__amdgpu_buffer_rsrc_t rs, int cb, 
 // A chunk is LPR consecutive entries; lane sl of the group fetches entry sl of the chunk.
 // XS = compile-time row stride of a contiguous source (D, or 2 D in column-half mode); coff = first column of the slice.
 template <int D, int U, bool CONTIG, int XS = D>
-__device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl, int coff = 0) {
+__device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int end, int g, int G, int sl, int64_t coff = 0) {
     constexpr int LPR = D / 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = beg + g * LPR; e < end; e += G * LPR) {
@@ -240,8 +242,8 @@ __device__ __forceinline__ float4 reduce_groups(float4 a) {
 // D = width of the contiguous [N, D] side arrays (prev, mean_out, addend); c0 = first column of this lane's float4.
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
 
-__device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D, int coff = 0) {
-    const int c0 = coff + sl * 4;
+__device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 acc, int sl, int D, int64_t coff = 0) {
+    const int64_t c0 = coff + sl * 4;
     if (p.mode == MODE_NOISE) {  // simgcl.py:32-33: all_embs + sign(all_embs) * F.normalize(random_noise, dim=-1) * eps
         const float4 nz = ld4(p.addend + (int64_t)row * D + c0);
         float ss = nz.x * nz.x + nz.y * nz.y + nz.z * nz.z + nz.w * nz.w;
@@ -263,7 +265,9 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
         }
         s = add4(s, acc);
         s = make_float4(s.x / p.denom, s.y / p.denom, s.z / p.denom, s.w / p.denom);
-        st4_stream(p.mean_out + (int64_t)row * D + c0, s, p.nt_store);
+        // slab mode: the layers live as column slabs [2][N][D]; the mean leaves in the caller's row-major [N, 2 D]
+        float *mo = p.slab ? p.mean_out + (int64_t)row * (2 * D) + (coff ? D : 0) + sl * 4 : p.mean_out + (int64_t)row * D + c0;
+        st4_stream(mo, s, p.nt_store);
         if (p.y) st4_stream(p.y + (int64_t)row * p.ldy + c0, acc, p.nt_store);
     } else if (p.mode == MODE_HORNER) {
         float4 s = add4(ld4(p.addend + (int64_t)row * D + c0), acc);
@@ -285,12 +289,17 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
 // (The DPP-broadcast + buffer-load gather of the sweep kernel, lean_piece, was also tried here at D = 64: parity holds
 // but the layer runs 43.0 us vs 39.5 us at the Gowalla shape — profiles/r02_binned_lean_gather.jsonl — because with one
 // row per 16 lanes the plain gather already has its 8 loads in flight and the OOB-padded slots cost issue cycles.)
-template <int D, int U, bool CONTIG, bool HALF = false>
+// SLAB (with HALF, option "slab"): the operands are stored as two column slabs [2][rows][D] instead of row-major [rows][2 D],
+// so the half rows an XCD gathers are CONTIGUOUS 4 D-byte lines (r03: with row-major operands the half rows sit at a
+// 8 D-byte stride and use every second L2 line slot only — the mode then reads 190 MB per layer at the Gowalla shape; as
+// slabs 134 MB).  rbg_lightgcn_forward_f32 converts E0 once and keeps the layers as slabs; the mean leaves row-major.
+template <int D, int U, bool CONTIG, bool HALF = false, bool SLAB = false>
 __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     constexpr int LPR = D / 4;
     constexpr int SUBS = 64 / LPR;
-    constexpr int W = HALF ? 2 * D : D;
-    const int coff = HALF ? (int)(blockIdx.x & 1) * D : 0;
+    constexpr int W = (HALF && !SLAB) ? 2 * D : D;
+    const int hoff = HALF ? (int)(blockIdx.x & 1) * D : 0;  // column offset of this half inside a full-width row
+    const int64_t coff = SLAB ? (int64_t)(blockIdx.x & 1) * p.n_rows * D : hoff;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         // to arrive re-reads all partials with agent-scope loads (served past L1) and adds them in segment
         // order, so the result does not depend on arrival order (MI355X guide §6 G16, form R1).
         if (owner) {
-            float *dst = p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + coff + sl * 4;
+            float *dst = p.partials + (int64_t)(part_base + seg) * kPartialSlotFloats + hoff + sl * 4;
             __hip_atomic_store(dst + 0, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dst + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t *arrivals = p.counters + ctr + (coff ? p.n_split : 0);
+            uint32_t *arrivals = p.counters + ctr + (hoff ? p.n_split : 0);
             const unsigned old = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (old == (unsigned)(nseg - 1));
             if (last)  // self-cleaning: the next (stream-ordered) launch finds the counter at zero
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
         if (last_flag && owner) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int i = 0; i < nseg; ++i) {
-                const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + coff + sl * 4;
+                const float *src = p.partials + (int64_t)(part_base + i) * kPartialSlotFloats + hoff + sl * 4;
                 float4 q;
                 q.x = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 q.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -672,7 +681,7 @@ static int64_t grid_for(const rbg_graph *g) {
 
 // Column-half launch of a width-2H problem: XCD x serves group x / 4, column half x & 1, as XCD (x % 4) / 2 of 2.
 template <int H>
-static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
+static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s, bool slab = false) {
     constexpr int SUBS = 64 / (H / 4);
     int64_t m = 0;
     for (int x = 0; x < 8; ++x) {
@@ -685,10 +694,27 @@ static int launch_binned_half(const rbg_graph *g, SpmmParams &p, hipStream_t s) 
     if (grid == 0) return RBG_OK;
     if (grid > INT32_MAX) return fail(RBG_EUNSUPPORTED, "grid too large");
     const dim3 gr((unsigned)grid), bl(256);
-    if (spmm_unroll() == 8) hipLaunchKernelGGL((spmm_binned_kernel<H, 8, true, true>), gr, bl, 0, s, p);
-    else hipLaunchKernelGGL((spmm_binned_kernel<H, 4, true, true>), gr, bl, 0, s, p);
+    if (slab) {
+        if (spmm_unroll() == 8) hipLaunchKernelGGL((spmm_binned_kernel<H, 8, true, true, true>), gr, bl, 0, s, p);
+        else hipLaunchKernelGGL((spmm_binned_kernel<H, 4, true, true, true>), gr, bl, 0, s, p);
+    } else {
+        if (spmm_unroll() == 8) hipLaunchKernelGGL((spmm_binned_kernel<H, 8, true, true>), gr, bl, 0, s, p);
+        else hipLaunchKernelGGL((spmm_binned_kernel<H, 4, true, true>), gr, bl, 0, s, p);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+// the default class split (user rows on XCDs 0-3, item rows on 4-7): what the column-half launches re-map
+static bool half_structure_ok(const rbg_graph *g) {
+    return g->n_groups == 2 && g->xmap.cnt[0] == 4 && g->xmap.cnt[7] == 4 && g->xmap.grp[0] == 0 && g->xmap.grp[3] == 0 &&
+           g->xmap.grp[4] == 1 && g->xmap.grp[7] == 1;
+}
+
+// slab propagation (rbg_lightgcn_forward_f32 with scratch layers, option "slab"): width 64 or 128, square graph
+static bool slab_eligible(const rbg_graph *g, int d) {
+    return (d == 64 || d == 128) && half_structure_ok(g) && g->n_rows == g->n_cols &&
+           (int64_t)g->n_rows * (d / 2) < ((int64_t)1 << 40);
 }
 
 // column-half eligibility of a launch of width D on this graph (see launch_binned)
@@ -821,6 +847,26 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     hipLaunchKernelGGL(spmm_generic_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, d);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+// row-major rows of width 2 H (one array or the two embedding tables) -> column slabs [2][n][H]
+__global__ __launch_bounds__(256) void to_slab_kernel(const RowSrc src, float *dst, int64_t n, int H) {
+    const int q = (2 * H) / 4;
+    const int64_t total = n * q;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / q;
+        const int c4 = (int)(t % q) * 4;
+        const int half = c4 >= H;
+        st4(dst + (int64_t)half * n * H + row * H + (c4 - half * H), ld4(src_row(src, (int)row) + c4));
+    }
+}
+
+// One layer over slab operands (p.x / p.y / p.e0 / p.prev in slab layout, row stride d / 2; p.mean_out row-major).
+static int launch_slab(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) {
+    fill_graph(g, p);
+    p.slab = 1;
+    if (d == 64) return launch_binned_half<32>(g, p, s, true);
+    return launch_binned_half<64>(g, p, s, true);
 }
 
 int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
@@ -1004,6 +1050,40 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     }
     const bool fused = (K - 1) <= RBG_MAX_FUSED_LAYERS;
     if (!fused && !layers) return fail(RBG_EINVAL, "layers buffer is NULL");
+    // Slab propagation (option "slab"; the caller must not look at `layers`: RBG_FWD_LAYERS_SCRATCH): E0 is re-laid out as
+    // two column slabs once, every layer gathers from and writes slabs (column-half kernel, SLAB instantiation), the
+    // last layer's epilogue writes the mean row-major.  layers[K-1] holds E0's slabs, layers[k] layer k + 1's.
+    bool slab = opt_slab() && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER) &&
+                aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
+    for (int i = 0; i < n_graphs && slab; ++i) slab = slab_eligible(graphs[i], d);
+    if (slab) {
+        const int H = d / 2;
+        float *e0s = layers + (int64_t)(K - 1) * nd;
+        const int64_t work = n * (d / 4);
+        hipLaunchKernelGGL(to_slab_kernel, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 8192)), dim3(256), 0, s, e0, e0s, n, H);
+        RBG_HIP(hipGetLastError());
+        for (int k = 0; k < K; ++k) {
+            const rbg_graph *g = graphs[n_graphs == 1 ? 0 : k];
+            SpmmParams p{};
+            const float *x = (k == 0) ? e0s : layers + (int64_t)(k - 1) * nd;
+            p.x = make_src(x, x, 0, H);
+            p.ldy = H;
+            if (k == K - 1) {
+                p.mode = MODE_MEAN;
+                p.y = nullptr;
+                p.mean_out = out_mean;
+                p.e0 = make_src(e0s, e0s, 0, H);
+                p.n_prev = K - 1;
+                for (int i = 0; i < K - 1; ++i) p.prev[i] = layers + (int64_t)i * nd;
+                p.denom = (float)(K + 1);
+            } else {
+                p.mode = MODE_STORE;
+                p.y = layers + (int64_t)k * nd;
+            }
+            if ((rc = launch_slab(g, p, d, s))) return rc;
+        }
+        return RBG_OK;
+    }
     for (int k = 0; k < K; ++k) {
         const rbg_graph *g = graphs[n_graphs == 1 ? 0 : k];
         SpmmParams p{};

@@ -177,7 +177,8 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, ou
     _check_dense(out, "out", graphs[0])
     _check_dense(layers, "layers", graphs[0])
     arr = (c_vp * len(graphs))(*[g.ptr for g in graphs])
-    flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_DEFAULT
+    # (no caller of this wrapper reads `layers` unless keep_layers: the library may use it as scratch in any layout)
+    flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_LAYERS_SCRATCH
     with torch.cuda.device(user_w.device):
         check(lib.rbg_lightgcn_forward_f32(arr, len(graphs), n_users, c_vp(user_w.data_ptr()), c_vp(item_w.data_ptr()),
                                            c_vp(out.data_ptr()), c_vp(layers.data_ptr()), d, n_layers, flags,

@@ -236,6 +236,42 @@ def test_spmm_column_half_mode(rbg, cuda, d):
         rbg.set_tuning(64, 256, 4096)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("k_layers", [1, 2, 3])
+def test_lightgcn_forward_slab_option(rbg, cuda, d, k_layers):
+    """Option "slab" (r03 experiment, off by default — it measured slower): rbg_lightgcn_forward_f32 keeps the
+    layers as two column slabs and runs the column-half kernel over contiguous half rows; E0 converted once, the mean written
+    row-major by the last epilogue.  Same values as the default path (both against float64), split rows included, and the
+    autograd path (which ignores `layers`) unchanged."""
+    nu, ni, e = 3001, 2201, 60_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=5)
+    hub_u = np.concatenate([uid, np.full(5000, 1, dtype=np.int64)])
+    hub_i = np.concatenate([iid, (np.arange(5000) % (ni - 1) + 1).astype(np.int64)])
+    rbg.set_tuning(64, 256, 1024)
+    try:
+        for (u, i) in ((uid, iid), (hub_u, hub_i)):
+            h = rbg.GraphHandle.from_interactions(u, i, nu, ni, device=cuda)
+            rowptr, col, val = C.build_norm_csr(u, i, nu, ni)
+            x = randn((nu + ni, d), 11, cuda)
+            cur = x.cpu().numpy().astype(np.float64)
+            acc = cur.copy()
+            for _ in range(k_layers):
+                cur = O.conv_csr_f64(cur, rowptr, col, val)
+                acc = acc + cur
+            truth = acc / (k_layers + 1)
+            got = {}
+            for slab in (0, 1):
+                rbg.set_option("slab", slab)
+                for _ in range(2):  # split-row counters are self-cleaning
+                    mean, _ = rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), k_layers)
+                close(mean, truth)
+                got[slab] = mean.clone()
+            close(got[0], got[1], tol=2e-6)
+    finally:
+        rbg.set_option("slab", 0)
+        rbg.set_tuning(64, 256, 4096)
+
+
 @pytest.mark.parametrize("n_parts", [2, 4, 8])
 def test_community_partition_changes_only_the_launch_plan(rbg, cuda, n_parts):
     """rbg_graph_create_partitioned: pinning communities to XCDs must give bit-identical results."""
@@ -1539,6 +1575,33 @@ def test_full_sort_topk(rbg, cuda, golden, bk, d):
     s2 = user_all.cpu()[users].double() @ item_all.cpu().double().T
     s2[:, 0] = -np.inf
     close(v2, torch.topk(s2, k, dim=1).values.float(), tol=1e-5 * max(1, d / 64))
+
+
+def test_score_and_topk_at_the_evaluation_batch(rbg, cuda):
+    """the B = 4096 x 40 982-item shape (the multi-walk path of score.hip and the fused top-k's large
+    batch) was only benchmarked.  rbg_score_f32 against float64 on 64 sampled user rows (every column) and on 64 sampled
+    columns (every user row); the fused top-10 (PAD masked, no history) against float64 top-k on the sampled rows."""
+    b, n, d, k = 4096, 40_982, 64, 10
+    u, it = randn((b, d), 91, cuda), randn((n, d), 92, cuda)
+    s = rbg.score(u, it)
+    rows = torch.from_numpy(np.random.default_rng(0).choice(b, 64, replace=False)).sort().values
+    cols = torch.from_numpy(np.random.default_rng(1).choice(n, 64, replace=False)).sort().values
+    ud, itd = u.cpu().double(), it.cpu().double()
+    ref_rows = ud[rows] @ itd.T
+    ref_cols = ud @ itd[cols].T
+    close(s[rows.to(cuda)], ref_rows, tol=2e-6)
+    close(s[:, cols.to(cuda)], ref_cols, tol=2e-6)
+    assert torch.isfinite(s).all()
+    vals, idx = rbg.full_sort_topk(None, u, it, torch.arange(b, device=cuda), k)
+    ref_rows[:, 0] = -np.inf  # PAD item
+    rv, ri = torch.topk(ref_rows, k, dim=1)
+    close(vals[rows.to(cuda)], rv.float(), tol=1e-5)
+    idx_c = idx.cpu()[rows]
+    srt = torch.sort(ref_rows, dim=1, descending=True).values
+    clear = (srt[:, k - 1] - srt[:, k]) > 1e-3
+    for r in torch.nonzero(clear).flatten().tolist():
+        assert set(idx_c[r].tolist()) == set(ri[r].tolist())
+    assert int(clear.sum()) > 32
 
 
 def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
