@@ -75,7 +75,10 @@ template <int NC, bool GRAD, bool VEC, bool SPLIT>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
-    constexpr bool kFp32Tile = GRAD || !SPLIT;  // who reads s_oth: the fp32 first product and / or the gradients' second product
+    // who reads s_oth: the exact-fp32 products.  (r03: with split operands the gradients' second product takes its B
+    // fragments from the SAME bf16 planes the first product reads — the split is elementwise, so the planes already hold
+    // the three terms of every tile element; the per-lane re-split of 16 element pairs per tile is gone, and the fp32 tile with it.)
+    constexpr bool kFp32Tile = !SPLIT;
     __shared__ __attribute__((aligned(16))) float s_oth[kFp32Tile ? 2 : 1][kFp32Tile ? 32 : 1][kFp32Tile ? LD : 4];
     __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][3][SPLIT ? 32 : 1][SPLIT ? LDH : 8];
     __shared__ float s_coef[2][32];
@@ -213,14 +216,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                     for (int u = 0; u < 2; ++u) {
                         bf16x8 bh, bm, bl;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float b0 = s_oth[buf][lse_rowmap(8 * u + 2 * j, h)][q * 32 + i];
-                            const float b1 = s_oth[buf][lse_rowmap(8 * u + 2 * j + 1, h)][q * 32 + i];
-                            bf16x2 hh, mm, ll;
-                            split2_bf16(b0, b1, hh, mm, ll);
-                            bh[2 * j] = hh[0], bh[2 * j + 1] = hh[1];
-                            bm[2 * j] = mm[0], bm[2 * j + 1] = mm[1];
-                            bl[2 * j] = ll[0], bl[2 * j + 1] = ll[1];
+                        for (int j = 0; j < 8; ++j) {
+                            const int orow = lse_rowmap(8 * u + j, h);
+                            bh[j] = s_pl[buf][0][orow][q * 32 + i];
+                            bm[j] = s_pl[buf][1][orow][q * 32 + i];
+                            bl[j] = s_pl[buf][2][orow][q * 32 + i];
                         }
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh, g[q], 0, 0, 0);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bl, g[q], 0, 0, 0);
