@@ -372,7 +372,7 @@ def load_workload(rbg, name, seed, rank, world, gloo_group):
     note = None
     if name == "config5":
         nu, ni, e = CONFIG5
-        path = f"/dev/shm/rbg_config5_seed{seed}.npz.npy"
+        path = f"/dev/shm/rbg_config5_devgen_seed{seed}.npy"
         ok = os.path.exists(path)
         reason = None
         if not ok and rank == 0:
@@ -382,11 +382,13 @@ def load_workload(rbg, name, seed, rank, world, gloo_group):
                 shm = psutil.disk_usage("/dev/shm").free / 2 ** 30
             except Exception:  # noqa: BLE001
                 avail, shm = 0.0, 0.0
-            if avail < 64 or shm < 4:
-                reason = f"host has {avail:.0f} GiB available RAM / {shm:.0f} GiB free in /dev/shm (need 64 / 4)"
+            if avail < 24 or shm < 4:
+                reason = f"host has {avail:.0f} GiB available RAM / {shm:.0f} GiB free in /dev/shm (need 24 / 4)"
             else:
                 t0 = time.time()
-                uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=seed)
+                # the generator's algorithm with torch on this rank's GPU (3 s; the numpy generator needs 181 s and 40 GB
+                # of temporaries at this size): same distribution, its own random stream
+                uid, iid = rbg.synth.powerlaw_bipartite_device(nu, ni, e, torch.device("cuda", torch.cuda.current_device()), seed=seed)
                 np.save(path + ".tmp.npy", np.stack([uid, iid]))
                 os.replace(path + ".tmp.npy", path)
                 del uid, iid
@@ -425,7 +427,8 @@ def strong_setup(rbg, sh, name, seed, world, rank, dev, d, gen, transport, gloo_
     else:
         per_rank = [mine]
     shape = "config5" if (name == "config5" and note is None) else ("g-1.3m" if note else name)
-    desc = (f"{shape}-shape graph ({nu} users / {ni} items / {len(uid)} interactions) cut into {world} node shards per side "
+    gen_note = " (config #5's shape; generated by synth.powerlaw_bipartite_device: the generator's algorithm with torch's RNG)" if shape == "config5" else ""
+    desc = (f"{shape}-shape graph{gen_note} ({nu} users / {ni} items / {len(uid)} interactions) cut into {world} node shards per side "
             f"({part_name} partition), no planted locality, trimmed halo all_to_all per layer")
     info = {"partition": part_name,
             "partition_candidates(max over ranks)": {k: {"nnz": max(v["nnz"]), "rows": max(v["rows"]), "min_rows": min(v["rows"])}
@@ -550,7 +553,7 @@ def main():
         scaling = args.scaling
         base_name, base_d = baseline_workload(world)
         strong_name = args.workload or base_name
-        d = args.dim or (base_d if strong_name == base_name else 64)
+        d = args.dim or (128 if strong_name == "config5" else 64)
         weak_name = args.workload if (args.workload and args.workload != "config5") else "gowalla"
         nu, ni, n_inter = rbg.synth.shape(weak_name)
         one_gpu = {}

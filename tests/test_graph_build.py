@@ -145,3 +145,18 @@ def test_find_communities_recovers_planted_structure(rbg):
     hd = rbg.GraphHandle.from_interactions(pu[uid], pi[iid], nu, ni)
     for a, b in zip(ha.export_csr(), hd.export_csr()):
         assert np.array_equal(a, b)
+
+
+def test_device_generator_has_the_numpy_generators_properties(rbg):
+    """synth.powerlaw_bipartite_device (bench.py's config-#5 workload: the generator's algorithm with torch's RNG, here on the
+    CPU device): exactly n_inter unique pairs, ids in [1, n), PAD rows empty, the same power-law degree profile."""
+    nu, ni, e = 2001, 3001, 60_000
+    u, i = rbg.synth.powerlaw_bipartite_device(nu, ni, e, "cpu", seed=7)
+    assert len(u) == e and len(np.unique(u.astype(np.int64) * ni + i)) == e
+    assert u.min() >= 1 and i.min() >= 1 and u.max() < nu and i.max() < ni
+    u2, i2 = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=7)
+    d1, d2 = np.sort(np.bincount(u, minlength=nu))[::-1], np.sort(np.bincount(u2, minlength=nu))[::-1]
+    assert abs(d1[:20].mean() - d2[:20].mean()) < 0.2 * d2[:20].mean()      # same head
+    assert abs(np.median(d1) - np.median(d2)) <= 2                          # same bulk
+    u3, i3 = rbg.synth.powerlaw_bipartite_device(nu, ni, e, "cpu", seed=7)
+    assert np.array_equal(u, u3) and np.array_equal(i, i3)                  # deterministic
