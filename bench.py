@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--partition", choices=["auto", "ranges", "striped"], default="auto",
                     help="strong scaling: contiguous nnz-balanced id ranges, or degree-striped (degree order dealt round-robin); "
                          "auto = the one with the smaller max over ranks of (nnz + halo rows)")
+    ap.add_argument("--no-train-extra", action="store_true", help="N>1: skip the sharded SGL training-step measurement")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins a gloo group, rank 0 prints {\"launch_check\": world} (no GPU needed)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the other scaling mode's measurement")
@@ -434,7 +435,7 @@ def strong_setup(rbg, sh, name, seed, world, rank, dev, d, gen, transport, gloo_
             "partition_candidates(max over ranks)": {k: {"nnz": max(v["nnz"]), "rows": max(v["rows"]), "min_rows": min(v["rows"])}
                                                       for k, v in part_stats.items()},
             "per_rank(owned rows, nnz, halo rows)": per_rank, "workload_note": note}
-    return prop, e0, plan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * len(uid), d, 3), (uid, iid, nu, ni, shape), info
+    return prop, e0, plan, desc, rbg.synth.algorithmic_bytes(nu + ni, 2 * len(uid), d, 3), (uid, iid, nu, ni, shape, owner), info
 
 
 def traffic_from_profiles(workload, d, kernel):
@@ -476,6 +477,11 @@ def main():
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         raise SystemExit(self_launch(args))  # no launcher around us: start the ranks here
+    # stdout carries the ONE JSON line and nothing else: C++ libraries (gloo's "Rank 0 is connected to ..." banner) write to
+    # file descriptor 1 directly, so descriptor 1 is pointed at stderr for the run and the line goes to a saved copy
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -490,7 +496,7 @@ def main():
             dist.all_reduce(t)
             assert int(t) == world
         if rank == 0:
-            print(json.dumps({"launch_check": world}))
+            print(json.dumps({"launch_check": world}), file=json_out, flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -687,11 +693,55 @@ def main():
             del halo_buf, y_buf
         except Exception as ex:  # noqa: BLE001
             extra["phase_us_error"] = str(ex)[:200]
+        # BASELINE config #5 is "SGL ... 8 x MI355X": one sharded SGL TRAINING step on the strong graph (sharded_train.py: three
+        # propagations over the full graph and two edge-drop views, BPR + reg + InfoNCE with distributed denominators, the
+        # transposed chains, Adam on the owned rows), batch 2048 — a few steps, reported beside the propagation figure
+        if strong_graph is not None and not args.no_train_extra:
+            try:
+                from recbole_gnn_amd import sharded_train as st
+                su, si, snu, sni, sname, owner = strong_graph
+                t_setup = time.perf_counter()
+                u_dev, i_dev = torch.from_numpy(np.ascontiguousarray(su)).to(dev), torch.from_numpy(np.ascontiguousarray(si)).to(dev)
+                view_plans = []
+                for v in range(2):  # the same mask on every rank: same seed, same device type, same Philox stream
+                    gk = torch.Generator(device=dev).manual_seed(args.seed + 101 + v)
+                    keep = torch.zeros(len(su), dtype=torch.bool, device=dev)
+                    keep[torch.randperm(len(su), generator=gk, device=dev)[: int(len(su) * 0.9)]] = True
+                    gv = rbg.GraphHandle.from_interactions(u_dev, i_dev, snu, sni, device=dev, keep=keep)
+                    view_plans.append(sh.plan_from_csr(*gv.device_csr(), snu, owner, rank, world))
+                    del gv, keep
+                del u_dev, i_dev
+                torch.cuda.empty_cache()
+                tr = st.ShardedTrainer(plan, sh.HipBackend(dev), e0, snu, sni, k_layers, view_plans=view_plans,
+                                       group=gloo_group if transport == "staged" else None, transport=transport, lr=1e-3,
+                                       reg_weight=1e-4, ssl_tau=0.2, ssl_weight=0.05, overlap=extra["overlap"])
+                t_setup = time.perf_counter() - t_setup
+                gb = torch.Generator().manual_seed(args.seed + 7)
+                bu, bp, bn = (torch.randint(1, hi, (2048,), generator=gb) for hi in (snu, sni, sni))
+                losses = [tr.step(bu, bp, bn)]  # untimed: buffers, workspaces
+                torch.cuda.synchronize()
+                dist.barrier(group=gloo_group)
+                n_tr = 3
+                t1 = time.perf_counter()
+                for _ in range(n_tr):
+                    losses.append(tr.step(bu, bp, bn))
+                torch.cuda.synchronize()
+                dist.barrier(group=gloo_group)
+                tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=gloo_group)
+                extra["sgl_sharded_train_step"] = {"ms_per_step": float(tt[0]) * 1e3 / n_tr, "steps": n_tr, "batch": 2048, "workload": sname,
+                                                   "views": "2 x ED, drop_ratio 0.1, plans cut on the device", "setup_s": round(t_setup, 1),
+                                                   "loss_first_last": [losses[0], losses[-1]],
+                                                   "view_halo_rows_rank0": [int(p.n_halo) for p in view_plans]}
+                del tr, view_plans
+                torch.cuda.empty_cache()
+            except Exception as ex:  # noqa: BLE001  (diagnostic: never cost the headline its line)
+                extra["sgl_sharded_train_step"] = {"error": str(ex)[:300]}
         # the same graph on ONE GPU (rank 0, the others wait): what the sharded number has to be compared with
         if strong_graph is not None:
             try:
                 if rank == 0:
-                    su, si, snu, sni, sname = strong_graph
+                    su, si, snu, sni, sname, _ = strong_graph
                     del prop, e0
                     torch.cuda.empty_cache()
                     g1 = rbg.GraphHandle.from_interactions(su, si, snu, sni, device=dev)
@@ -756,7 +806,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers, args.cpu_seconds)
             result["cpu_baseline_torch_sparse"] = cpu_baseline_torch_sparse(uid, iid, nu, ni, uw_h.numpy(), iw_h.numpy(), k_layers,
                                                                             min(args.cpu_seconds, 6.0))
-        print(json.dumps(result))
+        print(json.dumps(result), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
