@@ -697,7 +697,8 @@ def main():
         # propagations over the full graph and two edge-drop views, BPR + reg + InfoNCE with distributed denominators, the
         # transposed chains, Adam on the owned rows), batch 2048 — a few steps, reported beside the propagation figure
         if strong_graph is not None and not args.no_train_extra:
-            try:
+            tr, setup_err = None, None
+            try:  # rank-local part (no collectives): view graphs, their plans, the trainer
                 from recbole_gnn_amd import sharded_train as st
                 su, si, snu, sni, sname, owner = strong_graph
                 t_setup = time.perf_counter()
@@ -716,6 +717,16 @@ def main():
                                        group=gloo_group if transport == "staged" else None, transport=transport, lr=1e-3,
                                        reg_weight=1e-4, ssl_tau=0.2, ssl_weight=0.05, overlap=extra["overlap"])
                 t_setup = time.perf_counter() - t_setup
+            except Exception as ex:  # noqa: BLE001
+                tr, setup_err = None, str(ex)[:300]
+            votes = [None] * world  # every rank built its trainer, or nobody steps (a step is full of collectives)
+            dist.all_gather_object(votes, setup_err, group=gloo_group)
+            if any(v is not None for v in votes):
+                extra["sgl_sharded_train_step"] = {"error": next(v for v in votes if v is not None)}
+                tr = None
+            try:
+                if tr is None:
+                    raise StopIteration
                 gb = torch.Generator().manual_seed(args.seed + 7)
                 bu, bp, bn = (torch.randint(1, hi, (2048,), generator=gb) for hi in (snu, sni, sni))
                 losses = [tr.step(bu, bp, bn)]  # untimed: buffers, workspaces
@@ -735,12 +746,14 @@ def main():
                                                    "view_halo_rows_rank0": [int(p.n_halo) for p in view_plans]}
                 del tr, view_plans
                 torch.cuda.empty_cache()
-            except Exception as ex:  # noqa: BLE001  (diagnostic: never cost the headline its line)
+            except StopIteration:
+                pass
+            except Exception as ex:  # noqa: BLE001  (deterministic failures are raised on every rank alike)
                 extra["sgl_sharded_train_step"] = {"error": str(ex)[:300]}
         # the same graph on ONE GPU (rank 0, the others wait): what the sharded number has to be compared with
         if strong_graph is not None:
-            try:
-                if rank == 0:
+            if rank == 0:
+                try:
                     su, si, snu, sni, sname, _ = strong_graph
                     del prop, e0
                     torch.cuda.empty_cache()
@@ -758,9 +771,9 @@ def main():
                     one_gpu = {"workload": sname, "value": reps / (time.perf_counter() - t1), "unit": "propagations/s", "reps": reps,
                                "kernel": g1.spmm_kernel_name(d)}
                     del g1, x1, o1, l1
-                dist.barrier(group=gloo_group)
-            except Exception as ex:  # noqa: BLE001
-                one_gpu = {"error": str(ex)[:200]}
+                except Exception as ex:  # noqa: BLE001
+                    one_gpu = {"error": str(ex)[:200]}
+            dist.barrier(group=gloo_group)
             extra["same_workload_one_gpu"] = one_gpu
 
     if rank == 0:
