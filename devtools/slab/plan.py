@@ -19,7 +19,7 @@ def _round2(x):
     return (x + 1) // 2 * 2
 
 
-def build(rowptr, col, val, n_users, n_items, W, hot_rows, chunk=64):
+def build(rowptr, col, val, n_users, n_items, W, hot_rows, chunk=64, wide=False):
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
@@ -43,6 +43,8 @@ def build(rowptr, col, val, n_users, n_items, W, hot_rows, chunk=64):
         big = d > chunk
         need = -(-d[big] // chunk)
         p[big] = np.minimum(lgw, 1 << np.ceil(np.log2(need)).astype(np.int64))
+        if wide:  # rows too long for the lane-groups of ONE wave: 4 lgw parts over the 4 waves of a workgroup (LDS reduce)
+            p[d > chunk * lgw] = 4 * lgw
         h = is_hot[base[c]:base[c] + n[c]]
         o = np.lexsort((-nh, -(d - nh), -p, ~h))  # hot-set rows first; then parts, cold, hot descending
         i = np.empty(n[c], dtype=np.int64)
@@ -71,22 +73,38 @@ def build(rowptr, col, val, n_users, n_items, W, hot_rows, chunk=64):
         change = np.nonzero(np.diff(p))[0] + 1
         seg_b = np.concatenate([[0], change])
         seg_e = np.concatenate([change, [n[c]]])
-        u_row0, u_nrows, u_lp = [], [], []
+        u_row0, u_nrows, u_lp, u_pbase, u_pp = [], [], [], [], []
         for b, e in zip(seg_b, seg_e):
-            per = lgw // int(p[b])
+            pb = int(p[b])
+            if pb > lgw:  # wide rows: one row = 4 units (a whole workgroup), unit j holds parts [j lgw, (j + 1) lgw)
+                assert pb == 4 * lgw and b % 1 == 0
+                rows_w = np.repeat(np.arange(b, e), 4)
+                u_row0.append(rows_w)
+                u_nrows.append(np.ones(len(rows_w), dtype=np.int64))
+                u_lp.append(np.full(len(rows_w), lgw.bit_length() - 1))
+                u_pbase.append(np.tile(np.arange(4) * lgw, e - b))
+                u_pp.append(np.full(len(rows_w), pb))
+                continue
+            per = lgw // pb
             starts = np.arange(b, e, per)
             u_row0.append(starts)
             u_nrows.append(np.minimum(per, e - starts))
-            u_lp.append(np.full(len(starts), int(p[b]).bit_length() - 1))
+            u_lp.append(np.full(len(starts), pb.bit_length() - 1))
+            u_pbase.append(np.zeros(len(starts), dtype=np.int64))
+            u_pp.append(np.full(len(starts), pb))
         u_row0, u_nrows, u_lp = np.concatenate(u_row0), np.concatenate(u_nrows), np.concatenate(u_lp)
+        u_pbase, u_pp = np.concatenate(u_pbase), np.concatenate(u_pp)
+        u_wide = (u_pp > lgw).astype(np.int64)
+        if wide:
+            assert u_wide.sum() % 4 == 0 and (u_wide[: u_wide.sum()] == 1).all()  # wide units first: workgroup-aligned
         nu_ = len(u_row0)
         # ---- pieces: (unit, lane-group) -> (row, a, b) -------------------------------------------------------------------
         lg = np.arange(lgw)
         prow = u_row0[:, None] + (lg[None, :] >> u_lp[:, None])                      # [nu, lgw] row of the lane-group
         pvalid = (lg[None, :] >> u_lp[:, None]) < u_nrows[:, None]
         prow_c = np.where(pvalid, prow, 0)
-        ppart = lg[None, :] & ((1 << u_lp[:, None]) - 1)
-        pp = 1 << u_lp[:, None]
+        ppart = u_pbase[:, None] + (lg[None, :] & ((1 << u_lp[:, None]) - 1))
+        pp = u_pp[:, None]
         # a piece takes the k-th slice of the row's hot entries AND the k-th slice of its cold entries (both balanced)
         r0 = ptr[prow_c]
         nhr = nh_row[prow_c]
@@ -128,7 +146,7 @@ def build(rowptr, col, val, n_users, n_items, W, hot_rows, chunk=64):
             e[pos, 0] = (ci[eidx] * (W * 4)).astype(np.int32)
             e[pos, 1] = v[eidx].view(np.int32)
         assert covered == tot
-        head = np.stack([u_off[:-1] + ent_off, u_row0, u_nh | (u_nc << 16), u_lp | (u_nrows << 8)], axis=1)
+        head = np.stack([u_off[:-1] + ent_off, u_row0, u_nh | (u_nc << 16), u_lp | (u_nrows << 8) | (u_wide << 16)], axis=1)
         unit_base.append(sum(n_units))
         n_units.append(nu_)
         heads.append(head)
@@ -158,7 +176,7 @@ def emulate(pl, X):
         base = 0 if c == 0 else n[0]
         yc = np.zeros((n[c], X.shape[1]))
         for off, row0, hc, lr in hb:
-            nh, nc, lp, nrows = hc & 0xFFFF, hc >> 16, lr & 0xFF, lr >> 8
+            nh, nc, lp, nrows = hc & 0xFFFF, hc >> 16, lr & 0xFF, (lr >> 8) & 0xFF
             for sec, (s0, ln) in enumerate(((off, nh), (off + lgw * nh, nc))):
                 for k in range(0, ln, 8):
                     sb = min(8, ln - k)

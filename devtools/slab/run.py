@@ -94,17 +94,17 @@ if not args.pmc_run:
     emit(kind="binned", workload=args.workload, us=us, frac=b_layer / (us * 1e-6) / 8e12, err=err)
 
 VARIANTS = {
-    # name: (W, hot KB, chunk, threads per workgroup, workgroups per XCD (0 = one wave per unit), nt entries, DMA buffer bytes)
-    "w16_g256": (16, 0, 64, 256, 0, 1, 0),
-    "w32_g256": (32, 0, 64, 256, 0, 1, 0),
-    "w16_dma4k": (16, 0, 64, 256, 0, 1, 4096),
-    "w16_dma8k": (16, 0, 64, 256, 0, 1, 8192),
-    "w32_dma2k": (32, 0, 64, 256, 0, 1, 2048),
-    "w32_dma4k": (32, 0, 64, 256, 0, 1, 4096),
-    "w32_dma8k": (32, 0, 64, 256, 0, 1, 8192),
-    "w32_dma4k_c32": (32, 0, 32, 256, 0, 1, 4096),
-    "w32_dma4k_c128": (32, 0, 128, 256, 0, 1, 4096),
-    "w64_dma4k": (64, 0, 64, 256, 0, 1, 4096),
+    # name: (W, hot KB, chunk, threads per workgroup, workgroups per XCD (0 = one wave per unit), nt entries, DMA buffer bytes, wide rows)
+    "w16_g256": (16, 0, 64, 256, 0, 1, 0, 0),
+    "w32_g256": (32, 0, 64, 256, 0, 1, 0, 0),
+    "w64_g256": (64, 0, 64, 256, 0, 1, 0, 0),
+    "w16_g256_wide": (16, 0, 64, 256, 0, 1, 0, 1),
+    "w32_g256_wide": (32, 0, 64, 256, 0, 1, 0, 1),
+    "w64_g256_wide": (64, 0, 64, 256, 0, 1, 0, 1),
+    "w32_g256_wide_c32": (32, 0, 32, 256, 0, 1, 0, 1),
+    "w32_g256_wide_c128": (32, 0, 128, 256, 0, 1, 0, 1),
+    "w64_g256_wide_c32": (64, 0, 32, 256, 0, 1, 0, 1),
+    "w32_dma8k": (32, 0, 64, 256, 0, 1, 8192, 0),
 }
 names = [v for v in args.variants.split(",") if v] or list(VARIANTS)
 for name in names:
@@ -118,10 +118,10 @@ for name in names:
         torch.cuda.synchronize()
         emit(kind="binned_pmc")
         continue
-    W, hot_kb, chunk, tpb, wg_per_xcd, nt_ent, dma = VARIANTS[name]
+    W, hot_kb, chunk, tpb, wg_per_xcd, nt_ent, dma, wide = VARIANTS[name]
     hot_rows = hot_kb * 1024 // (W * 4)
     t0 = time.time()
-    pl = slab_plan.build(rowptr, col, val, nu, ni, W, hot_rows, chunk=chunk)
+    pl = slab_plan.build(rowptr, col, val, nu, ni, W, hot_rows, chunk=chunk, wide=bool(wide))
     t_plan = time.time() - t0
     ent = torch.from_numpy(pl["ent"]).to(dev)
     head = torch.from_numpy(pl["head"]).to(dev)
@@ -204,6 +204,6 @@ for name in names:
     us_mean = timeit(lambda: layer(p3), args.iters)
     us_conv = timeit(lambda: convert(Xd, bufs[0], 0), args.iters)
     us_prop = timeit(propagation, max(20, args.iters // 3))
-    emit(kind="slab", name=name, dma=dma, tpb=tpb, n_wg=n_wg, nt_ent=nt_ent, W=W, hot_rows=hot_rows, chunk=chunk, us_layer=us_layer,
+    emit(kind="slab", name=name, wide=wide, dma=dma, tpb=tpb, n_wg=n_wg, nt_ent=nt_ent, W=W, hot_rows=hot_rows, chunk=chunk, us_layer=us_layer,
          frac_layer=b_layer / (us_layer * 1e-6) / 8e12, us_mean_layer=us_mean, us_convert=us_conv, us_propagation=us_prop,
          err_layer=err1, err_mean=errm, plan_s=round(t_plan, 2), stats=pl["stats"])

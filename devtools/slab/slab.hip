@@ -108,7 +108,8 @@ __global__ __launch_bounds__(1024) void slab_spmm_kernel(const SlabParams p) {
 
     for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)w0); t < nun; t += n_w) {
         const int4 h = heads[t];
-        const int row0 = h.y, nh = HOT ? (h.z & 0xffff) : 0, nc = h.z >> 16, lp = h.w & 0xff, nrows = h.w >> 8;
+        const int row0 = h.y, nh = HOT ? (h.z & 0xffff) : 0, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+        const bool wide = (h.w >> 16) & 1;  // the row spans the 4 waves of this workgroup (uniform per workgroup: the plan aligns it)
         const v4i *eb = p.ent + (h.x >> 1);
         Acc acc = {{0.f, 0.f}, {0.f, 0.f}};
         // One section (hot: LDS, cold: L2) = `len` slots per lane-group in batches of 8 (the last one of len % 8, even).
@@ -157,8 +158,23 @@ __global__ __launch_bounds__(1024) void slab_spmm_kernel(const SlabParams p) {
                 if (off < parts) { acc.lo.x += a0; acc.lo.y += a1; acc.hi.x += a2; acc.hi.y += a3; }
             }
         }
+        if (wide) {  // 4 waves x LGW parts of ONE row: per-wave partials through LDS, added in wave order
+            __shared__ float s_wide[4][W];
+            const int wv = (threadIdx.x >> 6) & 3;
+            if (lg == 0) *reinterpret_cast<float4 *>(&s_wide[wv][sl * 4]) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+            __syncthreads();
+            if (wv == 0 && lg == 0) {
+                float4 tsum = *reinterpret_cast<const float4 *>(&s_wide[0][sl * 4]);
+                for (int q = 1; q < 4; ++q) {
+                    const float4 o4 = *reinterpret_cast<const float4 *>(&s_wide[q][sl * 4]);
+                    tsum.x += o4.x; tsum.y += o4.y; tsum.z += o4.z; tsum.w += o4.w;
+                }
+                acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
+            }
+            __syncthreads();
+        }
         const int r = lg >> lp;
-        if ((lg & (parts - 1)) == 0 && r < nrows) {
+        if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || ((threadIdx.x >> 6) & 3) == 0)) {
             const int row = row0 + r;
             const int64_t o = ybase + (int64_t)row * W + sl * 4;
             if (p.mode == SLAB_MEAN) {
