@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""The column-slab propagation in the library (csrc/sell.hip, option "sell") against the binned path: plan time, propagation
+time and parity against the C oracle, several shapes and widths.  JSON lines -> gpurun_out/sell_probe.jsonl"""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import recbole_gnn_amd as rbg
+from oracle import coracle
+
+dev = torch.device("cuda:0")
+shapes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["toy", "ml-100k", "gowalla", "yelp2018", "amazon-book", "g-1.3m"]
+dims = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["64", "128"])]
+log = open(os.path.join(ROOT, "gpurun_out", "sell_probe.jsonl"), "a")
+
+def timeit(fn, iters):
+    """GPU time per call: `iters` calls captured into one HIP graph and replayed (the Python wrapper costs ~110 us per call,
+    more than the slab propagation itself at the Gowalla shape)."""
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        for _ in range(iters): fn()
+    graph.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); graph.replay(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / iters)
+    return sorted(ts)[1]
+
+
+def timeit_eager(fn, iters):
+    for _ in range(max(3, iters // 5)): fn()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters): fn()
+        b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / iters)
+    return sorted(ts)[1]
+
+for name in shapes:
+    uid, iid, nu, ni = rbg.synth.make(name)
+    n = nu + ni
+    g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+    rowptr, col, val = coracle.build_norm_csr(uid, iid, nu, ni)
+    for d in dims:
+        if d == 128 and n > 1_000_000:
+            continue
+        gen = torch.Generator().manual_seed(1)
+        uw, iw = torch.randn(nu, d, generator=gen), torch.randn(ni, d, generator=gen)
+        uwd, iwd = uw.to(dev), iw.to(dev)
+        o, L = torch.empty(n, d, device=dev), torch.empty(3, n, d, device=dev)
+        rec = {"workload": name, "d": d, "nodes": n, "nnz": g.nnz}
+        rbg.set_option("sell", 0)
+        rec["kernel_binned"] = g.propagation_kernel_name(d)
+        big = n > 1_000_000
+        rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
+        ref = coracle.lightgcn_forward(rowptr, col, val, uw.numpy(), iw.numpy(), 3)
+        rec["err_binned"] = float(np.abs(o.cpu().numpy() - ref).max())
+        rec["prop_us_binned"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
+        rbg.set_option("sell", 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rec["plan"] = g.attach_sell(d)
+        torch.cuda.synchronize(); rec["plan_ms"] = (time.perf_counter() - t0) * 1e3
+        rec["kernel_sell"] = g.propagation_kernel_name(d)
+        for k in (1, 2, 3):
+            o.fill_(7.0)
+            rbg.ops.lightgcn_forward_raw(g, uwd, iwd, k, out=o, layers=L[:k]); torch.cuda.synchronize()
+            rk = ref if k == 3 else coracle.lightgcn_forward(rowptr, col, val, uw.numpy(), iw.numpy(), k)
+            rec[f"err_sell_k{k}"] = float(np.abs(o.cpu().numpy() - rk).max())
+        a = o.clone()
+        rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
+        rec["bit_stable"] = bool(torch.equal(a, o))
+        rec["prop_us_sell"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
+        rec["prop_us_sell_host_issued"] = timeit_eager(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
+        rec["speedup"] = rec["prop_us_binned"] / rec["prop_us_sell"]
+        g.detach_sell()
+        print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
+    del g

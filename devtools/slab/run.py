@@ -92,6 +92,17 @@ if not args.pmc_run:
     err = float(np.abs(Yb.cpu().numpy() - Y_ref).max())
     us = timeit(lambda: ops.spmm_raw(gh, Xd, out=Yb), args.iters)
     emit(kind="binned", workload=args.workload, us=us, frac=b_layer / (us * 1e-6) / 8e12, err=err)
+    # the library's own column-slab path (csrc/sell.hip) in the same process
+    uwd, iwd = Xd[:nu].contiguous(), Xd[nu:].contiguous()
+    o_lib, l_lib = torch.empty(N, 64, device=dev), torch.empty(3, N, 64, device=dev)
+    for opt in (0, 1):
+        rbg.set_option("sell", opt)
+        if opt and not gh.has_sell(64):
+            gh.attach_sell(64)
+        ops.lightgcn_forward_raw(gh, uwd, iwd, 3, out=o_lib, layers=l_lib); torch.cuda.synchronize()
+        errl = float(np.abs(o_lib.cpu().numpy() - M_ref).max())
+        usl = timeit(lambda: ops.lightgcn_forward_raw(gh, uwd, iwd, 3, out=o_lib, layers=l_lib), args.iters)
+        emit(kind="library_propagation", sell=opt, kernel=gh.propagation_kernel_name(64), us_propagation=usl, err_mean=errl)
 
 VARIANTS = {
     # name: (W, hot KB, chunk, threads per workgroup, workgroups per XCD (0 = one wave per unit), nt entries, DMA buffer bytes, wide rows)
@@ -126,8 +137,19 @@ for name in names:
     ent = torch.from_numpy(pl["ent"]).to(dev)
     head = torch.from_numpy(pl["head"]).to(dev)
     orig = torch.from_numpy(pl["orig"]).to(dev)
+    if os.environ.get("SLAB_TORCH_PLAN") and wide and not hot_rows:  # the library's planner (torch, on the device) instead
+        from recbole_gnn_amd import sell as lib_sell
+        rp_d, col_d, val_d = gh.device_csr()
+        tp = lib_sell.build_plan(rp_d, col_d, val_d, nu, ni, W=W, chunk=chunk)
+        same = {k: bool(torch.equal(tp[k].cpu(), torch.from_numpy(pl[k]))) for k in ("ent", "head", "orig")}
+        emit(kind="plan_compare", equal=same, n_units_torch=tp["n_units"], n_units_numpy=pl["n_units"])
+        ent, head, orig = tp["ent"], tp["head"], tp["orig"]
     soff = torch.from_numpy(pl["slab_off"].reshape(-1).copy())  # host
-    bufs = [torch.zeros(N * 64, device=dev) for _ in range(4)]  # E0s, E1s, E2s, scratch (slab layout)
+    if os.environ.get("SLAB_CONTIG"):  # the library's buffer layout: layers[K-1] = E0's slabs, layers[k] = layer k + 1's
+        big = torch.zeros(3 * N * 64, device=dev)
+        bufs = [big[2 * N * 64:], big[:N * 64], big[N * 64:2 * N * 64], torch.zeros(N * 64, device=dev)]
+    else:
+        bufs = [torch.zeros(N * 64, device=dev) for _ in range(4)]  # E0s, E1s, E2s, scratch (slab layout)
     out = torch.zeros(N, 64, device=dev)
     back = torch.zeros(N, 64, device=dev)
 

@@ -202,6 +202,20 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
                            const int32_t *hot_rows, int64_t n_hot, int hot_base);
 int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
+/* Column-slab propagation (r03; csrc/sell.hip): attach a SELL-C-sigma plan of this graph for slab width W (32 serves d = 64,
+ * 64 serves d = 128).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
+ * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1).  The planner is
+ * recbole-gnn_amd/sell.py (torch ops on the handle's device CSR); `ent` [n_ent][2], `head` [n_units][4] and `orig` [n_rows] are
+ * DEVICE arrays on the graph's device, `unit_base` / `n_units` host arrays of 2.  Every index the kernel dereferences is
+ * range-checked on the device before the plan is adopted (copied: the caller keeps its arrays).  Graphs built from
+ * interactions (a user / item boundary, square) only; a re-weighted view cannot carry a plan. */
+int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
+                          const int32_t *n_units, const int32_t *orig);
+int rbg_graph_detach_sell(rbg_graph *g);
+int rbg_graph_has_sell(const rbg_graph *g, int d);
+/* Name of the kernel rbg_lightgcn_forward_f32 launches per layer for this graph, width and flags (one graph). */
+int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, char *buf, int len);
+
 /* The handle's CSR arrays in HBM, read-only and valid while the handle lives: rowptr int32 [n_rows + 1], col int32 [nnz],
  * val fp32 [nnz] (any pointer argument may be NULL).  For device-side consumers of the normalized adjacency (the shard
  * planner cuts a rank's blocks out of it without a host round trip). */

@@ -46,6 +46,10 @@ SIGNATURES = {
     "rbg_graph_attach_sweep": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
                                        c_i64, c_int]),
     "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
+    "rbg_graph_attach_sell": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rbg_graph_detach_sell": (c_int, [c_vp]),
+    "rbg_graph_has_sell": (c_int, [c_vp, c_int]),
+    "rbg_lightgcn_forward_kernel_name": (c_int, [c_vp, c_int, c_u32, ctypes.c_char_p, c_int]),
     "rbg_spmm_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "rbg_spmm_mean_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "rbg_spmm_noise_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),

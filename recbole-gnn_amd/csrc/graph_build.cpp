@@ -47,6 +47,8 @@ int opt_score_tiles() { return g_score_tiles.load(); }
 int opt_col_split() { return g_col_split.load(); }
 static std::atomic<int> g_shard_single_stream{0};
 static std::atomic<int> g_slab{0};
+static std::atomic<int> g_sell{1};
+int opt_sell() { return g_sell.load(); }
 int opt_slab() { return g_slab.load(); }
 int opt_shard_single_stream() { return g_shard_single_stream.load(); }
 int opt_sweep() { return g_sweep.load(); }
@@ -292,6 +294,8 @@ static void free_device(rbg_graph *g) {
     if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
     for (SweepDev *sw : g->sweeps) free_sweep(sw);
     g->sweeps.clear();
+    free_sell(g->sell);
+    g->sell = nullptr;
     if (g->base) {  // a view owns only its split-row scratch
         (void)hipFree(g->d_partials);
         (void)hipFree(g->d_counters);
@@ -473,6 +477,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_slab = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell")) {
+        g_sell = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -518,6 +526,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "slab")) {
         *value = g_slab.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell")) {
+        *value = g_sell.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

@@ -37,6 +37,7 @@ int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the bi
 int opt_sweep_lean();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
+int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
 int opt_slab();          // rbg_lightgcn_forward_f32: keep the layers as two column slabs (column-half kernel over contiguous half rows)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
@@ -99,6 +100,19 @@ struct SweepDev {
     int64_t n_pieces = 0, n_ent = 0, n_desc = 0;
 };
 
+// SELL-C-sigma plan of the column-slab propagation (sell.hip; planner recbole-gnn_amd/sell.py).  All device.
+struct SellDev {
+    int W = 0;                       // slab width (the plan serves d = 2 W)
+    int32_t unit_base[2] = {0, 0};   // first unit of row class c
+    int32_t n_units[2] = {0, 0};
+    int32_t n_class[2] = {0, 0};     // rows of class c
+    int32_t *ent = nullptr;          // [n_ent + 128][2]: {internal column * W * 4, bits of val}
+    int32_t *head = nullptr;         // [n_units][4]
+    int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
+    int64_t n_ent = 0;
+};
+void free_sell(SellDev *sw);
+
 }  // namespace rbg
 
 // The graph handle.  Arrays named d_* live in HBM (device >= 0); h_* on the host.
@@ -137,6 +151,7 @@ struct rbg_graph {
     const rbg_graph *base = nullptr;  // a re-weighted view (rbg_graph_create_reweighted): structure + plan borrowed from base,
                                       // d_val borrowed from the caller; only partials / counters are its own
     std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
+    rbg::SellDev *sell = nullptr;         // optional SELL plan of the column-slab propagation (rbg_graph_attach_sell)
 };
 
 namespace rbg {
@@ -163,6 +178,12 @@ int build_device_csr(rbg_graph *g, int64_t n_users, int64_t n_items, int64_t n_i
 int set_device_for(int device);
 
 // spmm.hip — Y[n_rows, d] (row stride ldy) = Â · X (row stride ldx), optionally accumulating.
+// sell.hip — the propagation over an attached SELL plan (layers = scratch [K][N][d]; the mean leaves row-major)
+bool sell_applicable(const rbg_graph *g, int d);
+const char *sell_kernel_name(int d);
+int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
+                 hipStream_t s);
+
 int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
                  hipStream_t s);
 

@@ -1,0 +1,393 @@
+// sell.hip — the propagation of LightGCN.forward / SGL.forward (lightgcn.py:70-81, sgl.py:128-145) over COLUMN SLABS with a
+// sliced-ELL graph (r03).  Used by rbg_lightgcn_forward_f32 at d = 64 when a plan is attached
+// (rbg_graph_attach_sell; planner recbole-gnn_amd/sell.py) and the caller does not read the intermediate layers.
+//
+// Why: the binned kernel (spmm.hip) is bound by L2 misses — an XCD's 4 MB L2 cannot hold the table its rows gather from, and
+// a layer moves 230 MB over the fabric for 53 MB of algorithmic bytes at the Gowalla shape.  Here
+//   * the dense operand is kept as two column slabs [2][row][32] between the layers, rows renumbered per class; XCD x of a
+//     row class gathers ONE slab of the other class's table (5.2 MB instead of 10.5 MB of item rows; 128-byte gathers = whole
+//     L2 lines), so the fabric traffic falls to 134 MB per layer; the CSR is read once per slab;
+//   * the graph is SELL-C-sigma over lane-groups: a unit = the 8 lane-groups (8 lanes x float4) of one wave on consecutive
+//     rows of similar length, its entries stored unit-major and padded to the unit's longest piece, so one wave-wide 16-byte
+//     load fetches a batch of 8 slots per lane-group and nothing is masked; the index broadcast is a DPP quad_perm (a
+//     lane-group is two quads), the gather a buffer load whose padded slots read zeros past the table: 4 VALU + 1 VMEM per
+//     gathered row against 13 + 1 in the binned kernel;
+//   * rows longer than 64 entries are cut into up to 8 pieces in adjacent lane-groups (butterfly), rows longer than 512 into
+//     32 pieces over the four waves of a workgroup (LDS): without the latter the longest row is one wave's serial chain of 48
+//     gather batches and sets the duration of the whole launch (38.3 -> 29.7 us per layer);
+//   * heaviest units first, one wave per unit: the hardware dispatcher balances the load.
+// E0 is converted to slabs once per propagation; the last layer's epilogue adds the layer mean and writes it row-major in
+// the reference's numbering.  Summation order is fixed by the plan: results are bit-stable run to run, no float atomics.
+// Measured (profiles/r03_slab_wide_rows_*): layer 40.3 -> 29.7 us, propagation 131 -> 101 us at the Gowalla shape; 59 -> 44 us
+// per layer at the Yelp2018 shape, 134 -> 100 us at Amazon-Book, 1 188 -> 1 065 us at 1.3 M nodes.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <new>
+#include <type_traits>
+
+#include "internal.h"
+
+namespace rbg {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kSellPast = 0x7ffffff0;  // padding slots: past every table this path accepts, a buffer load returns zeros
+
+struct SellParams {
+    const v4i *ent;          // pairs of entries {internal column * W * 4, bits of val}
+    const int4 *head;        // unit headers {first entry, first row, slots << 16, log2(parts) | rows << 8 | wide << 16}
+    int32_t unit_base[2], n_units[2], n_class[2];
+    const float *xs;         // gathered operand, slab layout
+    float *ys;               // result, slab layout (last = 0)
+    int64_t slab_off[2][2];  // float offset of (class, slab)
+    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, 2 W]
+    int32_t n_prev;
+    const float *prev[RBG_MAX_FUSED_LAYERS + 1];  // slab layout
+    float denom;
+    float *out;
+    const int32_t *orig;     // original node id of (class, internal row)
+};
+
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {  // lane K of every quad, in all its lanes
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true);
+}
+// entry J (0..7) of the 8 a quad holds: lane J / 2, components (J & 1) * 2 + {0, 1}
+template <int J>
+__device__ __forceinline__ int ent_col(const v4i &w) { return quad_bcast<J / 2>((J & 1) ? w.z : w.x); }
+template <int J>
+__device__ __forceinline__ float ent_val(const v4i &w) { return __int_as_float(quad_bcast<J / 2>((J & 1) ? w.w : w.y)); }
+
+template <int J, int N>
+struct SellFor {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, J>{});
+        SellFor<J + 1, N>::run(f);
+    }
+};
+template <int N>
+struct SellFor<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+struct SellAcc {
+    v2f lo, hi;
+};
+__device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
+    const v2f vv = {v, v};
+    a.lo = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 0, 1), a.lo);
+    a.hi = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 2, 3), a.hi);
+}
+
+// W = slab width (32 at d = 64).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows,
+// XCD pair (x & 1) owns slab x & 1 of its class.
+template <int W>
+__global__ __launch_bounds__(1024) void sell_spmm_kernel(const SellParams p) {
+    constexpr int G = W / 4;      // lanes per lane-group
+    constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
+    __shared__ float s_wide[4][W];
+    const int x = blockIdx.x & 7, cls = x >> 2, s = x & 1, xi = (x & 3) >> 1;
+    const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = threadIdx.x >> 6;
+    // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
+    // scalar-load round trips per wave — n_units, pointers, header, offsets)
+    const float *xtab = p.xs + p.slab_off[1 - cls][s];
+    const int n_tab = p.n_class[1 - cls];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, n_tab * W * 4, 0x00020000);
+    const int lane_off = sl * 16;
+    const unsigned nun = (unsigned)p.n_units[cls];
+    const int4 *heads = p.head + p.unit_base[cls];
+    const int64_t ybase = p.slab_off[cls][s];
+    const unsigned n_w = (gridDim.x >> 3) * 8;  // waves of this role: the grid covers the units, so the loop body runs at most once
+    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * 2 + xi) * 4 + wave))); t < nun; t += n_w) {
+    const int4 h = heads[t];
+    const int row0 = h.y, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+    const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
+    const v4i *base = p.ent + (h.x >> 1);
+    SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
+    // batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds for batch k sits at
+    // base + (LGW k) / 2 + lg (sb / 2) + q4
+    if (nc > 0) {
+        int sb = min(8, nc);
+        v4i w = {0, 0, 0, 0};
+        // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
+        if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
+        for (int k = 0; k < nc; k += 8) {
+            const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
+            v4i wn = {0, 0, 0, 0};
+            auto batch = [&](auto nc_) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc_)::value;
+                v4f xv[n];
+                SellFor<0, n>::run([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    xv[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<j>(w) + lane_off, 0, 0));
+                });
+                if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+                SellFor<0, n>::run([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    fma_row(acc, ent_val<j>(w), xv[j]);
+                });
+            };
+            if (sb == 8) batch(std::integral_constant<int, 8>{});
+            else if (sb == 6) batch(std::integral_constant<int, 6>{});
+            else if (sb == 4) batch(std::integral_constant<int, 4>{});
+            else batch(std::integral_constant<int, 2>{});
+            w = wn;
+            sb = sbn;
+        }
+    }
+    // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
+    const int parts = 1 << lp;
+    if (lp > 0) {
+#pragma unroll
+        for (int off = 1; off < LGW; off <<= 1) {
+            const float a0 = __shfl_xor(acc.lo.x, off * G), a1 = __shfl_xor(acc.lo.y, off * G);
+            const float a2 = __shfl_xor(acc.hi.x, off * G), a3 = __shfl_xor(acc.hi.y, off * G);
+            if (off < parts) { acc.lo.x += a0; acc.lo.y += a1; acc.hi.x += a2; acc.hi.y += a3; }
+        }
+    }
+    if (wide) {  // 4 waves x LGW pieces of ONE row: per-wave partial sums through LDS, added in wave order
+        if (lg == 0) *reinterpret_cast<float4 *>(&s_wide[wave][sl * 4]) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+        __syncthreads();
+        if (wave == 0 && lg == 0) {
+            float4 tsum = *reinterpret_cast<const float4 *>(&s_wide[0][sl * 4]);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(&s_wide[q][sl * 4]);
+                tsum.x += o4.x; tsum.y += o4.y; tsum.z += o4.z; tsum.w += o4.w;
+            }
+            acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
+        }
+    }
+    const int r = lg >> lp;
+    if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0)) {
+    const int row = row0 + r;
+    const int64_t o = ybase + (int64_t)row * W + sl * 4;
+    if (p.last) {
+        float4 sum = *reinterpret_cast<const float4 *>(p.prev[0] + o);
+        for (int i = 1; i < p.n_prev; ++i) {
+            const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + o);
+            sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+        }
+        sum.x = (sum.x + acc.lo.x) / p.denom; sum.y = (sum.y + acc.lo.y) / p.denom;
+        sum.z = (sum.z + acc.hi.x) / p.denom; sum.w = (sum.w + acc.hi.y) / p.denom;
+        const int node = p.orig[(cls ? p.n_class[0] : 0) + row];
+        *reinterpret_cast<float4 *>(p.out + (int64_t)node * (2 * W) + s * W + sl * 4) = sum;
+    } else {
+        *reinterpret_cast<float4 *>(p.ys + o) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+    }
+    }
+    }
+}
+
+// the two embedding tables, row-major [n, 2 W] in the reference's numbering -> slabs in the plan's numbering
+template <int W>
+__global__ __launch_bounds__(256) void sell_to_slab_kernel(const float *user_emb, const float *item_emb, int64_t n_users, float *dst,
+                                                           const int32_t *orig, int n0, int n1, int64_t off0, int64_t off1) {
+    const int g = (blockIdx.x * 256 + threadIdx.x) / (2 * W / 4), c4 = ((blockIdx.x * 256 + threadIdx.x) % (2 * W / 4)) * 4;
+    if (g >= n0 + n1) return;
+    const int cls = g >= n0, row = cls ? g - n0 : g;
+    const int64_t node = orig[g];
+    const float *src = node < n_users ? user_emb + node * (2 * W) : item_emb + (node - n_users) * (2 * W);
+    const int s = c4 / W;
+    const int64_t so = (cls ? off1 + (int64_t)s * n1 * W : off0 + (int64_t)s * n0 * W) + (int64_t)row * W + (c4 - s * W);
+    *reinterpret_cast<float4 *>(dst + so) = *reinterpret_cast<const float4 *>(src + c4);
+}
+
+// memory safety of a plan (its content is the planner's business: parity tests pin it): every index the kernel dereferences
+__global__ void sell_check_units_kernel(const int4 *head, int n_units_total, int unit_base1, int n0, int n1, int64_t n_ent, int lgw,
+                                        int *err) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_units_total) return;
+    const int4 h = head[t];
+    const int cls = t >= unit_base1, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff, wide = (h.w >> 16) & 1;
+    const int n_c = cls ? n1 : n0;
+    bool bad = h.x < 0 || (h.x & 1) || (h.z & 0xffff) != 0 || nc < 0 || (nc & 1) || (int64_t)h.x + (int64_t)lgw * nc > n_ent;
+    bad = bad || lp < 0 || (1 << lp) > lgw || nrows < 0 || nrows > (lgw >> lp) || h.y < 0 || h.y + nrows > n_c;
+    const int tl = t - (cls ? unit_base1 : 0);
+    if (wide) {  // a wide row = units 4 j .. 4 j + 3 of its class, all flagged, one row
+        const int4 h0 = head[t - (tl & 3)];
+        bad = bad || !((h0.w >> 16) & 1) || h0.y != h.y || nrows != 1 || (1 << lp) != lgw;
+    } else if (tl & 3) {
+        bad = bad || ((head[t - (tl & 3)].w >> 16) & 1);
+    }
+    if (bad) atomicExch(err, 1 + t);
+}
+__global__ void sell_check_entries_kernel(const int2 *ent, int64_t n_ent, int64_t first_ent1, int n0, int n1, int W, int *err) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
+        const int off = ent[e].x;
+        const int64_t lim = (int64_t)(e >= first_ent1 ? n0 : n1) * W * 4;  // class 0 rows gather the class 1 table and vice versa
+        if (off != kSellPast && (off < 0 || off >= lim || off % (W * 4) != 0)) atomicExch(err, -1);
+    }
+}
+__global__ void sell_check_orig_kernel(const int32_t *orig, int n, int n_users, int n0, int *err) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const int v = orig[g];
+    if (v < 0 || v >= n || ((g < n0) != (v < n_users))) atomicExch(err, -2);
+}
+
+void free_sell(SellDev *sw) {
+    if (!sw) return;
+    if (sw->ent) (void)hipFree(sw->ent);
+    if (sw->head) (void)hipFree(sw->head);
+    if (sw->orig) (void)hipFree(sw->orig);
+    delete sw;
+}
+
+bool sell_applicable(const rbg_graph *g, int d) {
+    return opt_sell() && g && g->sell && g->sell->W * 2 == d;
+}
+
+const char *sell_kernel_name(int d) { return d == 64 ? "sell_spmm_kernel<32>" : "sell_spmm_kernel<64>"; }
+
+template <int W>
+static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
+                          hipStream_t s) {
+    const SellDev *sw = g->sell;
+    const int64_t n = g->n_rows, nd = n * 2 * W;
+    const int n0 = sw->n_class[0], n1 = sw->n_class[1];
+    const int64_t off0 = 0, off1 = (int64_t)n0 * 2 * W;
+    float *e0s = layers + (int64_t)(K - 1) * nd;
+    {
+        const int64_t work = n * (2 * W / 4);
+        hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, user_emb, item_emb, g->n_users, e0s,
+                           sw->orig, n0, n1, off0, off1);
+        RBG_HIP(hipGetLastError());
+    }
+    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
+    const int64_t grid = 8 * ((max_units + 7) / 8);  // two XCDs per (class, slab), four waves per workgroup
+    for (int k = 0; k < K; ++k) {
+        SellParams p{};
+        p.ent = reinterpret_cast<const v4i *>(sw->ent);
+        p.head = reinterpret_cast<const int4 *>(sw->head);
+        for (int c = 0; c < 2; ++c) {
+            p.unit_base[c] = sw->unit_base[c];
+            p.n_units[c] = sw->n_units[c];
+            p.n_class[c] = sw->n_class[c];
+            for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : off0) + (int64_t)q * sw->n_class[c] * W;
+        }
+        p.xs = (k == 0) ? e0s : layers + (int64_t)(k - 1) * nd;
+        p.orig = sw->orig;
+        if (k == K - 1) {
+            p.last = 1;
+            p.n_prev = K;
+            p.prev[0] = e0s;
+            for (int i = 1; i < K; ++i) p.prev[i] = layers + (int64_t)(i - 1) * nd;
+            p.denom = (float)(K + 1);
+            p.out = out_mean;
+        } else {
+            p.ys = layers + (int64_t)k * nd;
+        }
+        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
+        RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
+                 hipStream_t s) {
+    if (d == 64) return sell_forward_w<32>(g, user_emb, item_emb, out_mean, layers, K, s);
+    if (d == 128) return sell_forward_w<64>(g, user_emb, item_emb, out_mean, layers, K, s);
+    return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
+                          const int32_t *n_units, const int32_t *orig) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
+    if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan (the plan holds the values)");
+    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
+    if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
+        return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
+    if (!ent || !head || !unit_base || !n_units || !orig || n_ent < 0 || (n_ent & 1)) return fail(RBG_EINVAL, "NULL or malformed plan array");
+    if (g->n_rows > INT32_MAX || n_ent > INT32_MAX - 256) return fail(RBG_EUNSUPPORTED, "graph too large for a SELL plan");
+    const int n0 = (int)g->n_users, n1 = (int)(g->n_rows - g->n_users);
+    if ((int64_t)std::max(n0, n1) * W * 4 >= kSellPast) return fail(RBG_EUNSUPPORTED, "table too large for 32-bit slab offsets");
+    if (unit_base[0] != 0 || n_units[0] < 0 || n_units[1] < 0 || unit_base[1] != n_units[0])
+        return fail(RBG_EINVAL, "unit_base / n_units malformed");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    const int n_total = n_units[0] + n_units[1];
+    // ---- validate on the device (the arrays are device arrays) ---------------------------------------------------------------
+    int *d_err = nullptr;
+    RBG_HIP(hipMalloc(&d_err, sizeof(int)));
+    RBG_HIP(hipMemset(d_err, 0, sizeof(int)));
+    const int lgw = 64 / (W / 4);
+    int64_t first_ent1 = n_ent;
+    if (n_units[1] > 0) {
+        int4 h1;
+        if (hipMemcpy(&h1, reinterpret_cast<const int4 *>(head) + n_units[0], sizeof(int4), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipFree(d_err);
+            return fail(RBG_EHIP, "reading the plan failed");
+        }
+        first_ent1 = h1.x;
+    }
+    if (n_total) hipLaunchKernelGGL(sell_check_units_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(head), n_total,
+                                    n_units[0], n0, n1, n_ent, lgw, d_err);
+    if (n_ent) hipLaunchKernelGGL(sell_check_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(ent), n_ent, first_ent1, n0,
+                                  n1, W, d_err);
+    hipLaunchKernelGGL(sell_check_orig_kernel, dim3((unsigned)((g->n_rows + 255) / 256)), dim3(256), 0, 0, orig, (int)g->n_rows, n0, n0, d_err);
+    int h_err = 0;
+    const hipError_t ce = hipMemcpy(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_err);
+    if (ce != hipSuccess) return fail(RBG_EHIP, "plan validation failed to run: %s", hipGetErrorString(ce));
+    if (h_err > 0) return fail(RBG_EINVAL, "SELL plan: unit %d is out of range or misaligned", h_err - 1);
+    if (h_err == -1) return fail(RBG_EINVAL, "SELL plan: an entry's column offset is out of range");
+    if (h_err == -2) return fail(RBG_EINVAL, "SELL plan: orig[] is out of range or crosses the user / item boundary");
+    // ---- adopt copies ---------------------------------------------------------------------------------------------------------
+    if ((rc = rbg_graph_detach_sell(g))) return rc;
+    SellDev *sw = new (std::nothrow) SellDev();
+    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
+    sw->W = W;
+    sw->n_ent = n_ent;
+    for (int c = 0; c < 2; ++c) {
+        sw->unit_base[c] = unit_base[c];
+        sw->n_units[c] = n_units[c];
+    }
+    sw->n_class[0] = n0;
+    sw->n_class[1] = n1;
+    const size_t ent_bytes = sizeof(int32_t) * 2 * (size_t)(n_ent + 128), head_bytes = sizeof(int32_t) * 4 * (size_t)std::max(n_total, 1);
+    bool ok = hipMalloc(&sw->ent, ent_bytes) == hipSuccess && hipMalloc(&sw->head, head_bytes) == hipSuccess &&
+              hipMalloc(&sw->orig, sizeof(int32_t) * (size_t)g->n_rows) == hipSuccess;
+    ok = ok && hipMemset(sw->ent, 0, ent_bytes) == hipSuccess;  // (the 128 entries of slack a wave's last 16-byte loads may touch)
+    ok = ok && hipMemcpy(sw->ent, ent, sizeof(int32_t) * 2 * (size_t)n_ent, hipMemcpyDeviceToDevice) == hipSuccess;
+    ok = ok && (n_total == 0 || hipMemcpy(sw->head, head, sizeof(int32_t) * 4 * (size_t)n_total, hipMemcpyDeviceToDevice) == hipSuccess);
+    ok = ok && hipMemcpy(sw->orig, orig, sizeof(int32_t) * (size_t)g->n_rows, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) {
+        free_sell(sw);
+        return fail(RBG_ENOMEM, "device allocation / copy of the SELL plan failed");
+    }
+    g->sell = sw;
+    return RBG_OK;
+}
+
+int rbg_graph_detach_sell(rbg_graph *g) {
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->sell) {
+        if (g->device >= 0) {
+            int rc = set_device_for(g->device);
+            if (rc) return rc;
+            (void)hipDeviceSynchronize();
+        }
+        free_sell(g->sell);
+        g->sell = nullptr;
+    }
+    return RBG_OK;
+}
+
+int rbg_graph_has_sell(const rbg_graph *g, int d) { return (g && g->sell && g->sell->W * 2 == d) ? 1 : 0; }
+
+}  // extern "C"

@@ -187,8 +187,8 @@ __device__ __forceinline__ float4 gather_range(const SpmmParams &p, int beg, int
         int c = 0;
         float v = 0.f;
         if (idx < end) {
-            c = __builtin_nontemporal_load(p.col + idx);
-            v = __builtin_nontemporal_load(p.val + idx);
+            c = p.col[idx];
+            v = p.val[idx];
         }
         const int cnt = min(LPR, end - e);
         int j = 0;
@@ -912,6 +912,17 @@ int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     return RBG_OK;
 }
 
+int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, char *buf, int len) {
+    clear_error();
+    if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
+    // mirrors rbg_lightgcn_forward_f32 for one graph and 16-byte aligned operands
+    if (sell_applicable(g, d) && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER)) {
+        snprintf(buf, (size_t)len, "%s", sell_kernel_name(d));
+        return RBG_OK;
+    }
+    return rbg_spmm_kernel_name(g, d, buf, len);
+}
+
 int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
                    int64_t *n_split_rows, int64_t *grid_blocks) {
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
@@ -1053,6 +1064,11 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     // Slab propagation (option "slab"; the caller must not look at `layers`: RBG_FWD_LAYERS_SCRATCH): E0 is re-laid out as
     // two column slabs once, every layer gathers from and writes slabs (column-half kernel, SLAB instantiation), the
     // last layer's epilogue writes the mean row-major.  layers[K-1] holds E0's slabs, layers[k] layer k + 1's.
+    // Column-slab propagation over an attached SELL plan (sell.hip): one graph for every layer (a plan carries its own row
+    // numbering), the caller does not read `layers` (RBG_FWD_LAYERS_SCRATCH), the mean leaves row-major as always.
+    if (n_graphs == 1 && sell_applicable(g0, d) && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) &&
+        !(flags & RBG_FWD_KEEP_LAST_LAYER) && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean))
+        return sell_forward(g0, user_emb, item_emb, out_mean, layers, d, K, s);
     bool slab = opt_slab() && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER) &&
                 aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
     for (int i = 0; i < n_graphs && slab; ++i) slab = slab_eligible(graphs[i], d);

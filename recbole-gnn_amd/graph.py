@@ -210,6 +210,44 @@ class GraphHandle:
         check(lib.rbg_spmm_kernel_name(self.ptr, d, buf, 128))
         return buf.value.decode()
 
+    def propagation_kernel_name(self, d, scratch_layers=True):
+        """The kernel ``rbg_lightgcn_forward_f32`` launches per layer on this handle (the slab kernel when a SELL plan is
+        attached and the caller does not read the layers, else the SpMM kernel)."""
+        buf = ctypes.create_string_buffer(128)
+        flags = 2 if scratch_layers else 0
+        check(lib.rbg_lightgcn_forward_kernel_name(self.ptr, d, flags, buf, 128))
+        return buf.value.decode()
+
+    # ---- column-slab propagation (sell.py / csrc/sell.hip) -------------------------------------------------------------
+    SELL_AUTO_MAX_ROWS = 4_000_000  # auto-attach (ops.lightgcn_forward) below this size; larger graphs: call attach_sell()
+
+    def sell_eligible(self, d):
+        """A SELL plan serves width d on this handle: built from interactions (a user / item boundary), on a device, d = 64."""
+        return (self.is_device and self.n_users is not None and 0 < self.n_users < self.n_rows and self.n_rows == self.n_cols
+                and d in (64, 128) and not getattr(self, "_is_view", False))
+
+    def has_sell(self, d):
+        return bool(lib.rbg_graph_has_sell(self.ptr, d))
+
+    def attach_sell(self, d=64, chunk=None):
+        """Plan the column-slab propagation for width d (torch ops on this handle's device CSR) and attach it: from then on
+        ``lightgcn_forward`` runs the slab kernel on this handle (option "sell").  Returns the plan's summary."""
+        from . import sell
+        if not self.sell_eligible(d):
+            raise ValueError("a SELL plan needs a device graph built from interactions and d in (64, 128)")
+        rowptr, col, val = self.device_csr()
+        with torch.cuda.device(self.device):
+            plan = sell.build_plan(rowptr, col, val, self.n_users, self.n_rows - self.n_users, W=d // 2,
+                                   chunk=sell.CHUNK if chunk is None else chunk)
+            ub = (ctypes.c_int32 * 2)(*plan["unit_base"])
+            nu = (ctypes.c_int32 * 2)(*plan["n_units"])
+            check(lib.rbg_graph_attach_sell(self.ptr, d // 2, c_vp(plan["ent"].data_ptr()), plan["n_ent"], c_vp(plan["head"].data_ptr()),
+                                            ub, nu, c_vp(plan["orig"].data_ptr())))
+        return {"W": d // 2, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1)}
+
+    def detach_sell(self):
+        check(lib.rbg_graph_detach_sell(self.ptr))
+
     def transpose(self):
         """Handle of Â^T (needed for the backward of a non-symmetric graph)."""
         if self.symmetric:
@@ -267,6 +305,7 @@ class GraphHandle:
         check(lib.rbg_graph_create_reweighted(ctypes.byref(out), self.ptr, c_vp(vals.data_ptr())))
         view = GraphHandle(out.value, symmetric=symmetric, n_users=self.n_users)
         view._keep_alive = (self, vals)
+        view._is_view = True  # (the values are not the handle's own: no SELL plan, which carries values)
         return view
 
     def to(self, device):

@@ -176,6 +176,8 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, ou
         raise ValueError("out must be contiguous [N, d] and layers contiguous [max(K,1), N, d]")
     _check_dense(out, "out", graphs[0])
     _check_dense(layers, "layers", graphs[0])
+    if not keep_layers and len(graphs) == 1 and d in (64, 128):
+        _auto_sell(graphs[0], d)
     arr = (c_vp * len(graphs))(*[g.ptr for g in graphs])
     # (no caller of this wrapper reads `layers` unless keep_layers: the library may use it as scratch in any layout)
     flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_LAYERS_SCRATCH
@@ -184,6 +186,26 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, ou
                                            c_vp(out.data_ptr()), c_vp(layers.data_ptr()), d, n_layers, flags,
                                            _stream(user_w)))
     return out, (layers if keep_layers else None)
+
+
+def _auto_sell(graph, d):
+    """First propagation of width d on an eligible handle: plan the column-slab path once (sell.py, ~10 ms at the Gowalla
+    shape) — option "sell" = 1 (default).  A failed attempt is remembered, not retried."""
+    tried = graph.__dict__.setdefault("_sell_tried", set())
+    if d in tried or torch.cuda.is_current_stream_capturing():  # (planning allocates and synchronises: never inside a capture)
+        return
+    tried.add(d)
+    from . import graph as _g
+    from .sell import NotApplicable
+    if not _g.get_option("sell") or not graph.sell_eligible(d) or graph.n_rows > graph.SELL_AUTO_MAX_ROWS or graph.has_sell(d):
+        return
+    try:
+        graph.attach_sell(d)
+    except NotApplicable:
+        pass  # e.g. a hub row beyond what the slab path sums per row: the binned kernel splits it over workgroups
+    except Exception as ex:  # noqa: BLE001  (the binned kernel serves the call; say why once)
+        import warnings
+        warnings.warn(f"column-slab plan not attached ({ex}); the propagation runs on the binned SpMM kernel")
 
 
 class _LightGCNForward(torch.autograd.Function):

@@ -272,6 +272,117 @@ def test_lightgcn_forward_slab_option(rbg, cuda, d, k_layers):
         rbg.set_tuning(64, 256, 4096)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
+    """csrc/sell.hip behind rbg_lightgcn_forward_f32 (lightgcn.py:70-81): E0 re-laid out as two column slabs in the plan's
+    numbering, K slab layers over the SELL plan, the mean written row-major in the reference's numbering.  A graph with hub
+    rows (cut over the lane-groups of a wave, and over the four waves of a workgroup), empty rows and the PAD rows; K = 1..3
+    against float64; equal to the binned path within rounding; bit-stable; the option, detach and the kernel-name query."""
+    nu, ni, e = 3001, 2201, 60_000
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=5)
+    # hubs: user 1 with 1 500 items, user 7 with 700, item 3 with 900 users (d = 64: wide above 512 entries; d = 128: above 256)
+    hub_u = np.concatenate([uid, np.full(1500, 1), np.full(700, 7), (np.arange(900) * 3 % (nu - 1) + 1)]).astype(np.int64)
+    hub_i = np.concatenate([iid, (np.arange(1500) % (ni - 1) + 1), (np.arange(700) * 3 % (ni - 1) + 1), np.full(900, 3)]).astype(np.int64)
+    key = np.unique(hub_u * ni + hub_i)
+    hub_u, hub_i = key // ni, key % ni
+    h = rbg.GraphHandle.from_interactions(hub_u, hub_i, nu, ni, device=cuda)
+    rowptr, col, val = C.build_norm_csr(hub_u, hub_i, nu, ni)
+    assert np.diff(rowptr).max() > 1024 and np.diff(rowptr).min() == 0
+    x = randn((nu + ni, d), 11, cuda)
+    uw, iw = x[:nu].contiguous(), x[nu:].contiguous()
+    truth, cur = [], x.cpu().numpy().astype(np.float64)
+    acc = cur.copy()
+    for _ in range(3):
+        cur = O.conv_csr_f64(cur, rowptr, col, val)
+        acc = acc + cur
+        truth.append(acc / (len(truth) + 2))
+    try:
+        rbg.set_option("sell", 0)
+        binned = [rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0].clone() for k in (1, 2, 3)]
+        assert "binned" in h.propagation_kernel_name(d) and not h.has_sell(d)
+        rbg.set_option("sell", 1)
+        info = h.attach_sell(d)
+        assert h.has_sell(d) and not h.has_sell(192 - d) and info["padding"] < 1.2
+        assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}>"
+        assert "binned" in h.propagation_kernel_name(d, scratch_layers=False)  # a caller that reads the layers keeps them row-major
+        for k in (1, 2, 3):
+            out = torch.full((nu + ni, d), 7.0, device=cuda)
+            rbg.ops.lightgcn_forward_raw(h, uw, iw, k, out=out)
+            close(out, truth[k - 1])
+            close(out, binned[k - 1], tol=2e-6)
+            again = rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0]
+            assert torch.equal(out, again)  # the plan fixes the summation order
+            assert float(out[0].abs().max()) == float((x[0].abs() / (k + 1)).max()) and float(out[nu].abs().max()) == float((x[nu].abs() / (k + 1)).max())
+        # keep_layers (NCL reads every layer): the row-major path, same values as before
+        mean, layers = rbg.ops.lightgcn_forward_raw(h, uw, iw, 3, keep_layers=True)
+        close(mean, truth[2])
+        close(layers[0], O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rowptr, col, val))
+        # autograd: forward over the slabs, backward = the Horner chain of the binned kernel
+        xg = x.clone().requires_grad_(True)
+        out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], 3)
+        out.backward(torch.ones_like(out))
+        ones = np.ones((nu + ni, d))
+        g_acc, g_cur = ones.copy(), ones.copy()
+        for _ in range(3):
+            g_cur = O.conv_csr_f64(g_cur, rowptr, col, val)
+            g_acc = g_acc + g_cur
+        close(xg.grad, g_acc / 4.0)
+        rbg.set_option("sell", 0)
+        assert "binned" in h.propagation_kernel_name(d)
+        close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], binned[2], tol=0)
+        rbg.set_option("sell", 1)
+        h.detach_sell()
+        assert not h.has_sell(d)
+        close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
+    finally:
+        rbg.set_option("sell", 1)
+
+
+def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):
+    """rbg_graph_attach_sell validates on the device every index the kernel would dereference; ops.lightgcn_forward attaches
+    a plan on the first propagation of an eligible handle (option "sell"), never to a re-weighted view or a host graph."""
+    import ctypes
+    from recbole_gnn_amd import sell
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    lib, vp = rbg._lib.lib, ctypes.c_void_p
+    plan = sell.build_plan(*h.device_csr(), nu, ni, W=32)
+
+    def attach(ent=None, head=None, orig=None, n_ent=None):
+        ent, head, orig = (plan[k] if t is None else t for k, t in (("ent", ent), ("head", head), ("orig", orig)))
+        ub, nun = (ctypes.c_int32 * 2)(*plan["unit_base"]), (ctypes.c_int32 * 2)(*plan["n_units"])
+        return lib.rbg_graph_attach_sell(h.ptr, 32, vp(ent.data_ptr()), plan["n_ent"] if n_ent is None else n_ent, vp(head.data_ptr()), ub, nun,
+                                         vp(orig.data_ptr()))
+
+    bad_ent = plan["ent"].clone()
+    bad_ent[5, 0] = 32 * 4 * (max(nu, ni) + 3)   # a column past the table that is not the padding marker
+    assert attach(ent=bad_ent) == rbg._lib.RBG_EINVAL and b"column offset" in lib.rbg_last_error()
+    bad_head = plan["head"].clone()
+    bad_head[3, 0] = plan["n_ent"]               # a unit whose entries run past the array
+    assert attach(head=bad_head) == rbg._lib.RBG_EINVAL and b"unit" in lib.rbg_last_error()
+    bad_head = plan["head"].clone()
+    bad_head[0, 1] = nu                          # first row beyond the class
+    assert attach(head=bad_head) == rbg._lib.RBG_EINVAL
+    bad_orig = plan["orig"].clone()
+    bad_orig[0] = nu + ni                        # a node id out of range
+    assert attach(orig=bad_orig) == rbg._lib.RBG_EINVAL and b"orig" in lib.rbg_last_error()
+    assert not h.has_sell(64)
+    assert attach() == 0 and h.has_sell(64)
+    host = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni)
+    assert lib.rbg_graph_attach_sell(host.ptr, 32, None, 0, None, None, None, None) == rbg._lib.RBG_ENODEV
+    # auto-attach on the first differentiable propagation; a re-weighted view never gets a plan
+    h2 = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    uw, iw = randn((nu, 64), 1, cuda), randn((ni, 64), 2, cuda)
+    assert not h2.has_sell(64)
+    rbg.ops.lightgcn_forward(h2, uw, iw, 2)
+    assert h2.has_sell(64)
+    view = h2.reweighted(h2.values())
+    rbg.ops.lightgcn_forward(view, uw, iw, 2)
+    assert not view.has_sell(64) and not view.sell_eligible(64)
+    close(rbg.ops.lightgcn_forward(view, uw, iw, 2), rbg.ops.lightgcn_forward(h2, uw, iw, 2), tol=2e-6)
+
+
 @pytest.mark.parametrize("n_parts", [2, 4, 8])
 def test_community_partition_changes_only_the_launch_plan(rbg, cuda, n_parts):
     """rbg_graph_create_partitioned: pinning communities to XCDs must give bit-identical results."""

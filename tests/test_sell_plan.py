@@ -1,0 +1,71 @@
+"""The planner of the column-slab propagation (recbole-gnn_amd/sell.py) on CPU tensors: the plan alone must reproduce
+Y = A X (float64 emulation of exactly the layout csrc/sell.hip reads), cover every entry once, keep wide rows aligned to
+four units, and pad with {K_PAST, 0}.  The kernel itself is checked on the GPU (tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from oracle import coracle as C
+
+
+def _graph(rbg, name):
+    uid, iid, nu, ni = rbg.synth.make(name)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    return uid, iid, nu, ni, rowptr, col, val
+
+
+@pytest.mark.parametrize("W", [32, 64])
+@pytest.mark.parametrize("chunk", [4, 16, 64])
+@pytest.mark.parametrize("name", ["toy", "ml-100k"])
+def test_plan_reproduces_the_product(rbg, name, W, chunk):
+    from recbole_gnn_amd import sell
+    uid, iid, nu, ni, rowptr, col, val = _graph(rbg, name)
+    plan = sell.build_plan(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), nu, ni, W=W, chunk=chunk)
+    n = nu + ni
+    x = np.random.default_rng(0).standard_normal((n, 3))
+    a = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(n, n))
+    assert np.abs(sell.emulate(plan, x) - a @ x).max() < 1e-12
+    lgw = 64 // (W // 4)
+    ent, head = plan["ent"].numpy(), plan["head"].numpy().astype(np.int64)
+    # every real entry exactly once; padding = {K_PAST, 0.0}
+    real = ent[: plan["n_ent"], 0] != sell.K_PAST
+    assert int(real.sum()) == int(rowptr[-1]) and np.all(ent[: plan["n_ent"]][~real, 1] == 0)
+    assert np.all(ent[plan["n_ent"]:] == 0) and len(ent) == plan["n_ent"] + 128
+    # orig is a permutation that keeps the two classes apart
+    orig = plan["orig"].numpy()
+    assert np.array_equal(np.sort(orig), np.arange(n)) and np.all(orig[:nu] < nu) and np.all(orig[nu:] >= nu)
+    for c in (0, 1):
+        h = head[plan["unit_base"][c]: plan["unit_base"][c] + plan["n_units"][c]]
+        nc, lp, nrows, wide = h[:, 2] >> 16, h[:, 3] & 0xFF, (h[:, 3] >> 8) & 0xFF, (h[:, 3] >> 16) & 1
+        assert np.all(h[:, 0] % 2 == 0) and np.all(nc % 2 == 0) and np.all((h[:, 2] & 0xFFFF) == 0)
+        assert np.all((1 << lp) <= lgw) and np.all(nrows <= (lgw >> lp)) and np.all(h[:, 1] + nrows <= [nu, ni][c])
+        # wide rows: whole groups of four units at the front of the class, one row each
+        nw = int(wide.sum())
+        assert nw % 4 == 0 and np.all(wide[:nw] == 1) and np.all(nrows[:nw] == 1)
+        assert np.all(h[:nw, 1].reshape(-1, 4) == h[:nw:4, 1][:, None])
+        # rows in processing order: every row of the class appears in exactly one place
+        rows = np.concatenate([np.arange(r0, r0 + k) for r0, k in zip(h[nw:, 1], nrows[nw:])] + [h[:nw:4, 1]]) if len(h) else np.zeros(0)
+        assert np.array_equal(np.sort(rows), np.arange([nu, ni][c]))
+    if chunk == 4:
+        assert any(((head[:, 3] >> 16) & 1).tolist())  # the small chunk really produced wide rows
+
+
+def test_plan_is_deterministic_and_matches_the_heaviest_first_order(rbg):
+    from recbole_gnn_amd import sell
+    uid, iid, nu, ni, rowptr, col, val = _graph(rbg, "ml-100k")
+    t = [torch.from_numpy(a) for a in (rowptr, col, val)]
+    p1, p2 = sell.build_plan(*t, nu, ni, W=32), sell.build_plan(*t, nu, ni, W=32)
+    for k in ("ent", "head", "orig"):
+        assert torch.equal(p1[k], p2[k])
+    head = p1["head"].numpy().astype(np.int64)
+    for c in (0, 1):
+        h = head[p1["unit_base"][c]: p1["unit_base"][c] + p1["n_units"][c]]
+        slots, kind = h[:, 2] >> 16, h[:, 3] & 0x100FF  # kind = (wide, log2 parts)
+        deg = np.diff(rowptr)[([0, nu][c]):([nu, nu + ni][c])]
+        assert slots.max() <= 64 or deg.max() > 64 * 8 * 4  # no piece longer than the chunk unless even 32 parts cannot hold the row
+        # (parts, degree) descending: wide rows, then 8-, 4-, 2-part rows, then whole rows, each group longest first
+        parts_rank = np.where(h[:, 3] >> 16 & 1, 99, h[:, 3] & 0xFF)
+        assert np.all(np.diff(parts_rank) <= 0)
+        for k in np.unique(kind):
+            assert np.all(np.diff(slots[kind == k]) <= 2)  # (the pieces of one row differ by one entry: +-2 after the rounding)
