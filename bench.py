@@ -175,7 +175,8 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
 
     n = nu + ni
     x, y = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev)
-    ex = {"spmm_single_layer_us": time_us(lambda: rbg.ops.spmm_raw(graph, x, out=y))}
+    ex = {"spmm_single_layer_us": time_us(lambda: rbg.ops.spmm_raw(graph, x, out=y)),  # rbg_spmm_f32: row-major in, row-major out
+          "spmm_single_layer_kernel": graph.spmm_kernel_name(d)}
     b_layer, _ = rbg.synth.algorithmic_bytes(n, 2 * len(uid), d, k_layers)
     ex["spmm_single_layer_roofline_frac"] = b_layer / (ex["spmm_single_layer_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS
     # the headline loop re-uses one buffer set (~110 MB: it lives in the 256 MB Infinity Cache).  Rotating
@@ -200,6 +201,9 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         rbg.ops.lightgcn_forward_raw(gq, uq, iq, k_layers, out=oq, layers=lq)
 
     ex["propagation_hot_us"] = time_us(hot, iters=100)
+    rbg.set_option("sell", 0)
+    ex["propagation_binned_kernel_us"] = time_us(hot, iters=100)  # the same propagation with the column-slab path off
+    rbg.set_option("sell", 1)
     ex["propagation_rotated_us"] = time_us(rotated, iters=100)
     ex["propagation_rotated_sets"] = n_sets
     ex["propagation_rotated_footprint_MB"] = round(n_sets * set_mb, 1)
@@ -237,16 +241,19 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             big = gn > 1_000_000
             us = time_us(lambda: rbg.ops.spmm_raw(gg, gx, out=gy), iters=10 if big else 50, warm=2 if big else 5)
             gb, _ = rbg.synth.algorithmic_bytes(gn, gg.nnz, dd, k_layers)
-            kern = gg.spmm_kernel_name(dd)
+            kern = gg.spmm_kernel_name(dd)  # (the plain layer measured here: rbg_spmm_f32)
             traffic, l2_hit = traffic_from_profiles(name, dd, kern)
             key = name if dd == d else f"{name}:d{dd}"
             ex[key] = {"nodes": gn, "nnz": gg.nnz, "us": us, "frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                        "l2_hit": l2_hit, "algorithmic_bytes_per_layer": gb, "kernel": kern}
+            go, gl = torch.empty(gn, dd, device=dev), torch.empty(max(k_layers, 1), gn, dd, device=dev)
+            pus = time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl),
+                          iters=5 if big else 20, warm=1 if big else 3)
+            ex[key].update(propagation_us=pus, propagation_kernel=gg.propagation_kernel_name(dd),
+                           propagation_frac=(k_layers * gb) / (pus * 1e-6) / 1e9 / HBM_PEAK_GBPS)
             if name in ("g-1.3m", "amazon-book"):
-                go, gl = torch.empty(gn, dd, device=dev), torch.empty(max(k_layers, 1), gn, dd, device=dev)
-                ref[name] = 1e6 / time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl),
-                                          iters=5 if big else 20, warm=1 if big else 3)
-                del go, gl
+                ref[name] = 1e6 / pus
+            del go, gl
             del gg, gx, gy
         ex["strong_scaling_reference(single-GPU propagations/s of the --scaling strong graphs)"] = ref
     except Exception as e:  # noqa: BLE001
@@ -548,7 +555,13 @@ def main():
         if not err <= 1e-5:
             raise SystemExit(f"parity gate failed: max|E_hip - E_oracle| = {err:.3e} > 1e-5")
         extra.update(max_abs_err_vs_oracle=err, bins=graph.bins(d), tuning=rbg.get_tuning())
-        kernel_name = graph.spmm_kernel_name(d)
+        # the kernel a propagation of this handle launches per layer: the column-slab kernel (csrc/sell.hip; a SELL plan is
+        # attached by the first propagation) or the binned SpMM kernel
+        kernel_name = graph.propagation_kernel_name(d)
+        extra["propagation_path"] = {"kernel": kernel_name, "sell_plan_attached": bool(graph.has_sell(d)),
+                                     "launches_per_propagation": (k_layers + 1) if graph.has_sell(d) else k_layers,
+                                     "note": "column-slab path: 1 re-layout of E0 + K slab layers (the last one carries the mean)"
+                                     if graph.has_sell(d) else "K binned SpMM launches (the last one carries the mean)"}
         launches_per_step = k_layers
         units_per_step = 1
         scaling = "weak"  # N = 1: per-GPU work is what it is; the label only matters at N > 1
@@ -808,8 +821,9 @@ def main():
                                            "passes, devtools/traffic_session.sh; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per the gfx950 correction)",
                          "kernel": kernel_name, "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
-                         "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean launch duration; duration = HIP-event "
-                                 "time of the timed region / launches, so inter-kernel gaps and (N>1) halo waits count"},
+                         "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean layer duration; duration = HIP-event "
+                                 "time of the timed region / (steps x K layers), so inter-kernel gaps, the column-slab path's E0 "
+                                 "re-layout launch (1/K of it per layer) and (N>1) halo waits all count against the kernel"},
             "cpu_baseline": None,
         }
         result.update(extra)

@@ -16,7 +16,7 @@ pmc = {}
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "spmm_binned" in r.get("Kernel_Name", ""):
+        if "spmm_binned" in r.get("Kernel_Name", "") or "sell_spmm" in r.get("Kernel_Name", ""):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         v = v[len(v) // 4:]  # skip warm-up dispatches
@@ -36,7 +36,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         table = json.load(open(tpath))
     except Exception:
         table = {}
-    key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:spmm_binned_kernel<64, 8, true, false>"
+    key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:sell_spmm_kernel<32>"
     rec = {"traffic": traffic, "fetch_size_kib": pmc["FETCH_SIZE"]["mean"], "write_size_kib": pmc["WRITE_SIZE"]["mean"]}
     if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
         rec["l2_hit"] = pmc["TCC_HIT_sum"]["mean"] / (pmc["TCC_HIT_sum"]["mean"] + pmc["TCC_MISS_sum"]["mean"])
