@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -110,6 +111,8 @@ struct SellDev {
     int32_t *head = nullptr;         // [n_units][4]
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
     int64_t n_ent = 0;
+    float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain (allocated by the first backward)
+    std::mutex bwd_mutex;
 };
 void free_sell(SellDev *sw);
 
@@ -181,6 +184,7 @@ int set_device_for(int device);
 // sell.hip — the propagation over an attached SELL plan (layers = scratch [K][N][d]; the mean leaves row-major)
 bool sell_applicable(const rbg_graph *g, int d);
 const char *sell_kernel_name(int d);
+int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s);  // RBG_EUNSUPPORTED: run the binned chain
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                  hipStream_t s);
 

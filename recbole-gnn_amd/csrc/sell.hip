@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <new>
 #include <type_traits>
 
@@ -44,7 +45,7 @@ struct SellParams {
     const float *xs;         // gathered operand, slab layout
     float *ys;               // result, slab layout (last = 0)
     int64_t slab_off[2][2];  // float offset of (class, slab)
-    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, 2 W]
+    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, 2 W]; 0: ys = acc (+ prev[0] if n_prev)
     int32_t n_prev;
     const float *prev[RBG_MAX_FUSED_LAYERS + 1];  // slab layout
     float denom;
@@ -179,7 +180,12 @@ __global__ __launch_bounds__(1024) void sell_spmm_kernel(const SellParams p) {
         const int node = p.orig[(cls ? p.n_class[0] : 0) + row];
         *reinterpret_cast<float4 *>(p.out + (int64_t)node * (2 * W) + s * W + sl * 4) = sum;
     } else {
-        *reinterpret_cast<float4 *>(p.ys + o) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+        float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+        if (p.n_prev) {  // a step of the backward chain: y = g + A x  (g in slab layout)
+            const float4 q = *reinterpret_cast<const float4 *>(p.prev[0] + o);
+            y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
+        }
+        *reinterpret_cast<float4 *>(p.ys + o) = y;
     }
     }
     }
@@ -237,6 +243,7 @@ void free_sell(SellDev *sw) {
     if (sw->ent) (void)hipFree(sw->ent);
     if (sw->head) (void)hipFree(sw->head);
     if (sw->orig) (void)hipFree(sw->orig);
+    if (sw->bwd) (void)hipFree(sw->bwd);
     delete sw;
 }
 
@@ -295,6 +302,73 @@ int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_em
     if (d == 64) return sell_forward_w<32>(g, user_emb, item_emb, out_mean, layers, K, s);
     if (d == 128) return sell_forward_w<64>(g, user_emb, item_emb, out_mean, layers, K, s);
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
+}
+
+template <int W>
+static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *grad_e0, int K, hipStream_t s) {
+    SellDev *sw = g->sell;
+    const int64_t n = g->n_rows, nd = n * 2 * W;
+    if (!sw->bwd) {  // three slab buffers (g, ping, pong), allocated by the first backward on this handle — never inside a capture
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
+        std::lock_guard<std::mutex> lock(sw->bwd_mutex);
+        if (!sw->bwd) {
+            float *b = nullptr;
+            if (hipMalloc(&b, sizeof(float) * 3 * (size_t)nd) != hipSuccess) {
+                (void)hipGetLastError();
+                return RBG_EUNSUPPORTED;  // the caller runs the binned chain
+            }
+            sw->bwd = b;
+        }
+    }
+    float *gs = sw->bwd, *ping = sw->bwd + nd, *pong = sw->bwd + 2 * nd;
+    const int n0 = sw->n_class[0], n1 = sw->n_class[1];
+    const int64_t off0 = 0, off1 = (int64_t)n0 * 2 * W;
+    {
+        const int64_t work = n * (2 * W / 4);
+        hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, grad_out, grad_out + (int64_t)n0 * 2 * W,
+                           (int64_t)n0, gs, sw->orig, n0, n1, off0, off1);
+        RBG_HIP(hipGetLastError());
+    }
+    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
+    const int64_t grid = 8 * ((max_units + 7) / 8);
+    // dE0 = (g + A (g + A (... (g + A g)))) / (K + 1): K launches, every one adds g in its epilogue; the last divides and
+    // writes row-major (A symmetric: rbg_lightgcn_backward_f32 is called with the transposed handles, the handle itself here)
+    const float *x = gs;
+    for (int i = 0; i < K; ++i) {
+        SellParams p{};
+        p.ent = reinterpret_cast<const v4i *>(sw->ent);
+        p.head = reinterpret_cast<const int4 *>(sw->head);
+        for (int c = 0; c < 2; ++c) {
+            p.unit_base[c] = sw->unit_base[c];
+            p.n_units[c] = sw->n_units[c];
+            p.n_class[c] = sw->n_class[c];
+            for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : off0) + (int64_t)q * sw->n_class[c] * W;
+        }
+        p.xs = x;
+        p.orig = sw->orig;
+        p.n_prev = 1;
+        p.prev[0] = gs;
+        if (i == K - 1) {
+            p.last = 1;
+            p.denom = (float)(K + 1);
+            p.out = grad_e0;
+        } else {
+            p.ys = (i & 1) ? pong : ping;
+            x = p.ys;
+        }
+        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
+        RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+// RBG_EUNSUPPORTED = "not this time" (no scratch yet and the stream is capturing, or the allocation failed): the caller
+// runs the binned chain instead.
+int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s) {
+    if (d == 64) return sell_backward_w<32>(g, grad_out, grad_e0, K, s);
+    if (d == 128) return sell_backward_w<64>(g, grad_out, grad_e0, K, s);
+    return RBG_EUNSUPPORTED;
 }
 
 }  // namespace rbg

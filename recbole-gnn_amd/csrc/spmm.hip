@@ -1155,6 +1155,13 @@ int rbg_lightgcn_backward_f32(const rbg_graph *const *graphs, int n_graphs, cons
         RBG_HIP(hipMemcpyAsync(grad_e0, grad_out, sizeof(float) * n * d, hipMemcpyDeviceToDevice, s));
         return RBG_OK;
     }
+    // the column-slab chain (sell.hip) when the handle carries a plan: one graph, symmetric (the caller passes the transposed
+    // handles — the handle itself for a graph built from interactions)
+    if (n_graphs == 1 && sell_applicable(graphs[0], d) && aligned16(grad_out) && aligned16(grad_e0)) {
+        rc = sell_backward(graphs[0], grad_out, grad_e0, d, K, s);
+        if (rc != RBG_EUNSUPPORTED) return rc;
+        clear_error();
+    }
     // dE0 = (g + Â_0 (g + Â_1 (... (g + Â_{K-1} g)))) / (K+1): step i uses graph K-1-i; outputs ping-pong so that the
     // last one lands in grad_e0.
     const float *x = grad_out;
