@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The column-slab propagation in the library (csrc/sell.hip, option "sell") against the binned path: plan time, propagation
 time and parity against the C oracle, several shapes and widths.  JSON lines -> gpurun_out/sell_probe.jsonl"""
-import json, os, sys, time
+import ctypes, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -84,6 +84,20 @@ for name in shapes:
         rec["prop_us_sell"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
         rec["prop_us_sell_host_issued"] = timeit_eager(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
         rec["speedup"] = rec["prop_us_binned"] / rec["prop_us_sell"]
+        # E0 converted to slabs first (option "sell_rowmajor" = 0) against gathered where it lies; the backward chain alike
+        gout, ge0, work = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
+        arr = (ctypes.c_void_p * 1)(g.ptr)
+        def bwd():
+            rbg._lib.check(rbg._lib.lib.rbg_lightgcn_backward_f32(arr, 1, ctypes.c_void_p(gout.data_ptr()), ctypes.c_void_p(ge0.data_ptr()),
+                                                                   ctypes.c_void_p(work.data_ptr()), d, 3,
+                                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        for rm in (0, 1):
+            rbg.set_option("sell_rowmajor", rm)
+            rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
+            rec[f"err_rm{rm}"] = float(np.abs(o.cpu().numpy() - ref).max())
+            rec[f"prop_us_sell_rm{rm}"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
+            bwd(); torch.cuda.synchronize()
+            rec[f"bwd_us_sell_rm{rm}"] = timeit(bwd, 10 if big else 100)
         g.detach_sell()
         print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
     del g

@@ -49,6 +49,8 @@ static std::atomic<int> g_shard_single_stream{0};
 static std::atomic<int> g_slab{0};
 static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
+static std::atomic<int> g_sell_rowmajor{1};
+int opt_sell_rowmajor() { return g_sell_rowmajor.load(); }
 int opt_slab() { return g_slab.load(); }
 int opt_shard_single_stream() { return g_shard_single_stream.load(); }
 int opt_sweep() { return g_sweep.load(); }
@@ -481,6 +483,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_rowmajor")) {
+        g_sell_rowmajor = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -530,6 +536,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell")) {
         *value = g_sell.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_rowmajor")) {
+        *value = g_sell_rowmajor.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

@@ -38,6 +38,7 @@ int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the bi
 int opt_sweep_lean();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
+int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
 int opt_slab();          // rbg_lightgcn_forward_f32: keep the layers as two column slabs (column-half kernel over contiguous half rows)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
@@ -108,6 +109,7 @@ struct SellDev {
     int32_t n_units[2] = {0, 0};
     int32_t n_class[2] = {0, 0};     // rows of class c
     int32_t *ent = nullptr;          // [n_ent + 128][2]: {internal column * W * 4, bits of val}
+    int32_t *ent0 = nullptr;         // same, column = original class-local row * 2 W * 4 (a launch that gathers row-major tables); optional
     int32_t *head = nullptr;         // [n_units][4]
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
     int64_t n_ent = 0;

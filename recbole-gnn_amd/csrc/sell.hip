@@ -51,6 +51,11 @@ struct SellParams {
     float denom;
     float *out;
     const int32_t *orig;     // original node id of (class, internal row)
+    // row-major operands in the REFERENCE's numbering (class 0 = the user table [n_class[0], 2 W], class 1 = the item table):
+    const v4i *ent0;         // x_rm: the same entries with the column offset = original class-local row * 2 W * 4
+    const float *rm[2];
+    int32_t x_rm;            // 1: the gathered operand is rm[] (entries ent0) — E0 / the incoming gradient is never converted
+    int32_t prev0_rm;        // 1: prev[0] is rm[] (read through orig[])
 };
 
 template <int K>
@@ -89,7 +94,7 @@ __device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
 // W = slab width (32 at d = 64).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows,
 // XCD pair (x & 1) owns slab x & 1 of its class.
 template <int W>
-__global__ __launch_bounds__(1024) void sell_spmm_kernel(const SellParams p) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
     __shared__ float s_wide[4][W];
@@ -97,19 +102,23 @@ __global__ __launch_bounds__(1024) void sell_spmm_kernel(const SellParams p) {
     const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = threadIdx.x >> 6;
     // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
     // scalar-load round trips per wave — n_units, pointers, header, offsets)
-    const float *xtab = p.xs + p.slab_off[1 - cls][s];
+    // (a row-major table is read as its column half s: 128-byte (W = 32) pieces at a 2 W stride — whole L2 lines, the same
+    // footprint per XCD as a slab)
+    const float *xtab = p.x_rm ? p.rm[1 - cls] + s * W : p.xs + p.slab_off[1 - cls][s];
     const int n_tab = p.n_class[1 - cls];
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, n_tab * W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, p.x_rm ? n_tab * 2 * W * 4 - s * W * 4 : n_tab * W * 4, 0x00020000);
     const int lane_off = sl * 16;
     const unsigned nun = (unsigned)p.n_units[cls];
     const int4 *heads = p.head + p.unit_base[cls];
+    const v4i *ents = p.x_rm ? p.ent0 : p.ent;
     const int64_t ybase = p.slab_off[cls][s];
     const unsigned n_w = (gridDim.x >> 3) * 8;  // waves of this role: the grid covers the units, so the loop body runs at most once
     for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * 2 + xi) * 4 + wave))); t < nun; t += n_w) {
     const int4 h = heads[t];
     const int row0 = h.y, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
     const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
-    const v4i *base = p.ent + (h.x >> 1);
+    const v4i *base = ents + (h.x >> 1);
     SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
     // batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds for batch k sits at
     // base + (LGW k) / 2 + lg (sb / 2) + q4
@@ -169,20 +178,22 @@ __global__ __launch_bounds__(1024) void sell_spmm_kernel(const SellParams p) {
     if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0)) {
     const int row = row0 + r;
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
+    const int cbase = cls ? p.n_class[0] : 0;
+    const int node = (p.last || p.prev0_rm) ? p.orig[cbase + row] : 0;
+    const float *prev0 = p.prev0_rm ? p.rm[cls] + (int64_t)(node - cbase) * (2 * W) + s * W + sl * 4 : p.prev[0] + o;
     if (p.last) {
-        float4 sum = *reinterpret_cast<const float4 *>(p.prev[0] + o);
+        float4 sum = *reinterpret_cast<const float4 *>(prev0);
         for (int i = 1; i < p.n_prev; ++i) {
             const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + o);
             sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
         }
         sum.x = (sum.x + acc.lo.x) / p.denom; sum.y = (sum.y + acc.lo.y) / p.denom;
         sum.z = (sum.z + acc.hi.x) / p.denom; sum.w = (sum.w + acc.hi.y) / p.denom;
-        const int node = p.orig[(cls ? p.n_class[0] : 0) + row];
         *reinterpret_cast<float4 *>(p.out + (int64_t)node * (2 * W) + s * W + sl * 4) = sum;
     } else {
         float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
         if (p.n_prev) {  // a step of the backward chain: y = g + A x  (g in slab layout)
-            const float4 q = *reinterpret_cast<const float4 *>(p.prev[0] + o);
+            const float4 q = *reinterpret_cast<const float4 *>(prev0);
             y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
         }
         *reinterpret_cast<float4 *>(p.ys + o) = y;
@@ -238,9 +249,22 @@ __global__ void sell_check_orig_kernel(const int32_t *orig, int n, int n_users, 
     if (v < 0 || v >= n || ((g < n0) != (v < n_users))) atomicExch(err, -2);
 }
 
+// ent0: the entries for a launch that gathers a ROW-MAJOR table in the reference's numbering (E0, the incoming gradient)
+__global__ void sell_first_entries_kernel(const int2 *ent, int2 *ent0, int64_t n_ent, int64_t first_ent1, const int32_t *orig, int n0, int W) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
+        int2 v = ent[e];
+        if (v.x != kSellPast) {
+            const int obase = e >= first_ent1 ? 0 : n0;  // class 0 rows gather the item table (nodes n0 ..), class 1 rows the user table
+            v.x = (orig[obase + v.x / (W * 4)] - obase) * (2 * W * 4);
+        }
+        ent0[e] = v;
+    }
+}
+
 void free_sell(SellDev *sw) {
     if (!sw) return;
     if (sw->ent) (void)hipFree(sw->ent);
+    if (sw->ent0) (void)hipFree(sw->ent0);
     if (sw->head) (void)hipFree(sw->head);
     if (sw->orig) (void)hipFree(sw->orig);
     if (sw->bwd) (void)hipFree(sw->bwd);
@@ -253,37 +277,57 @@ bool sell_applicable(const rbg_graph *g, int d) {
 
 const char *sell_kernel_name(int d) { return d == 64 ? "sell_spmm_kernel<32>" : "sell_spmm_kernel<64>"; }
 
+static void sell_fill(const SellDev *sw, int W, SellParams &p) {
+    const int64_t off1 = (int64_t)sw->n_class[0] * 2 * W;
+    p.ent = reinterpret_cast<const v4i *>(sw->ent);
+    p.ent0 = reinterpret_cast<const v4i *>(sw->ent0);
+    p.head = reinterpret_cast<const int4 *>(sw->head);
+    p.orig = sw->orig;
+    for (int c = 0; c < 2; ++c) {
+        p.unit_base[c] = sw->unit_base[c];
+        p.n_units[c] = sw->n_units[c];
+        p.n_class[c] = sw->n_class[c];
+        for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : 0) + (int64_t)q * sw->n_class[c] * W;
+    }
+}
+
+template <int W>
+static int sell_to_slab(const SellDev *sw, const float *user_emb, const float *item_emb, float *dst, hipStream_t s) {
+    const int n0 = sw->n_class[0], n1 = sw->n_class[1];
+    const int64_t work = (int64_t)(n0 + n1) * (2 * W / 4);
+    hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, user_emb, item_emb, (int64_t)n0, dst, sw->orig,
+                       n0, n1, (int64_t)0, (int64_t)n0 * 2 * W);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+// K launches.  With ent0 the first one gathers E0 where it lies (two row-major tables) and the mean's epilogue reads E0
+// through orig[]: no conversion (7.7 us of a 101 us propagation at the Gowalla shape); without it E0 is converted to slabs
+// in layers[K - 1] first.
 template <int W>
 static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
                           hipStream_t s) {
     const SellDev *sw = g->sell;
-    const int64_t n = g->n_rows, nd = n * 2 * W;
-    const int n0 = sw->n_class[0], n1 = sw->n_class[1];
-    const int64_t off0 = 0, off1 = (int64_t)n0 * 2 * W;
+    const int64_t nd = g->n_rows * 2 * W;
+    const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor();
     float *e0s = layers + (int64_t)(K - 1) * nd;
-    {
-        const int64_t work = n * (2 * W / 4);
-        hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, user_emb, item_emb, g->n_users, e0s,
-                           sw->orig, n0, n1, off0, off1);
-        RBG_HIP(hipGetLastError());
+    if (!rm) {
+        const int rc = sell_to_slab<W>(sw, user_emb, item_emb, e0s, s);
+        if (rc) return rc;
     }
     const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
     const int64_t grid = 8 * ((max_units + 7) / 8);  // two XCDs per (class, slab), four waves per workgroup
     for (int k = 0; k < K; ++k) {
         SellParams p{};
-        p.ent = reinterpret_cast<const v4i *>(sw->ent);
-        p.head = reinterpret_cast<const int4 *>(sw->head);
-        for (int c = 0; c < 2; ++c) {
-            p.unit_base[c] = sw->unit_base[c];
-            p.n_units[c] = sw->n_units[c];
-            p.n_class[c] = sw->n_class[c];
-            for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : off0) + (int64_t)q * sw->n_class[c] * W;
-        }
+        sell_fill(sw, W, p);
+        p.rm[0] = user_emb;
+        p.rm[1] = item_emb;
+        p.x_rm = (rm && k == 0) ? 1 : 0;
         p.xs = (k == 0) ? e0s : layers + (int64_t)(k - 1) * nd;
-        p.orig = sw->orig;
         if (k == K - 1) {
             p.last = 1;
             p.n_prev = K;
+            p.prev0_rm = rm ? 1 : 0;
             p.prev[0] = e0s;
             for (int i = 1; i < K; ++i) p.prev[i] = layers + (int64_t)(i - 1) * nd;
             p.denom = (float)(K + 1);
@@ -308,7 +352,10 @@ template <int W>
 static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *grad_e0, int K, hipStream_t s) {
     SellDev *sw = g->sell;
     const int64_t n = g->n_rows, nd = n * 2 * W;
-    if (!sw->bwd) {  // three slab buffers (g, ping, pong), allocated by the first backward on this handle — never inside a capture
+    // the incoming gradient is gathered and added where it lies unless the result overwrites it (in-place call) or the plan
+    // has no row-major entries: then it is converted to slabs first
+    const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor() && grad_out != grad_e0;
+    if (!sw->bwd && (K > 1 || !rm)) {  // slab scratch (g, ping, pong), allocated by the first backward on this handle — never inside a capture
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
         std::lock_guard<std::mutex> lock(sw->bwd_mutex);
@@ -322,13 +369,10 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
         }
     }
     float *gs = sw->bwd, *ping = sw->bwd + nd, *pong = sw->bwd + 2 * nd;
-    const int n0 = sw->n_class[0], n1 = sw->n_class[1];
-    const int64_t off0 = 0, off1 = (int64_t)n0 * 2 * W;
-    {
-        const int64_t work = n * (2 * W / 4);
-        hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, grad_out, grad_out + (int64_t)n0 * 2 * W,
-                           (int64_t)n0, gs, sw->orig, n0, n1, off0, off1);
-        RBG_HIP(hipGetLastError());
+    const int n0 = sw->n_class[0];
+    if (!rm) {
+        const int rc = sell_to_slab<W>(sw, grad_out, grad_out + (int64_t)n0 * 2 * W, gs, s);
+        if (rc) return rc;
     }
     const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
     const int64_t grid = 8 * ((max_units + 7) / 8);
@@ -337,16 +381,12 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     const float *x = gs;
     for (int i = 0; i < K; ++i) {
         SellParams p{};
-        p.ent = reinterpret_cast<const v4i *>(sw->ent);
-        p.head = reinterpret_cast<const int4 *>(sw->head);
-        for (int c = 0; c < 2; ++c) {
-            p.unit_base[c] = sw->unit_base[c];
-            p.n_units[c] = sw->n_units[c];
-            p.n_class[c] = sw->n_class[c];
-            for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : off0) + (int64_t)q * sw->n_class[c] * W;
-        }
+        sell_fill(sw, W, p);
+        p.rm[0] = grad_out;
+        p.rm[1] = grad_out + (int64_t)n0 * 2 * W;
+        p.x_rm = (rm && i == 0) ? 1 : 0;
+        p.prev0_rm = rm ? 1 : 0;
         p.xs = x;
-        p.orig = sw->orig;
         p.n_prev = 1;
         p.prev[0] = gs;
         if (i == K - 1) {
@@ -443,6 +483,21 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
     if (!ok) {
         free_sell(sw);
         return fail(RBG_ENOMEM, "device allocation / copy of the SELL plan failed");
+    }
+    // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per propagation)
+    if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast) {
+        if (hipMalloc(&sw->ent0, ent_bytes) == hipSuccess && hipMemset(sw->ent0, 0, ent_bytes) == hipSuccess) {
+            if (n_ent) hipLaunchKernelGGL(sell_first_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent),
+                                          reinterpret_cast<int2 *>(sw->ent0), n_ent, first_ent1, sw->orig, n0, W);
+            if (hipDeviceSynchronize() != hipSuccess) {
+                free_sell(sw);
+                return fail(RBG_EHIP, "building the row-major entries failed");
+            }
+        } else {
+            (void)hipGetLastError();
+            if (sw->ent0) (void)hipFree(sw->ent0);
+            sw->ent0 = nullptr;
+        }
     }
     g->sell = sw;
     return RBG_OK;

@@ -327,6 +327,27 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
             g_cur = O.conv_csr_f64(g_cur, rowptr, col, val)
             g_acc = g_acc + g_cur
         close(xg.grad, g_acc / 4.0)
+        # E0 / the incoming gradient gathered row-major where they lie (option "sell_rowmajor", default) == converted to slabs
+        # first: the same sums in the same order, bit for bit — forward and backward, K = 1..3, a non-uniform gradient
+        gout = randn((nu + ni, d), 23, cuda)
+        res = {}
+        for rm in (1, 0):
+            rbg.set_option("sell_rowmajor", rm)
+            for k in (1, 2, 3):
+                xg = x.clone().requires_grad_(True)
+                out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
+                out.backward(gout)
+                res[rm, k] = (out.detach().clone(), xg.grad.clone())
+        rbg.set_option("sell_rowmajor", 1)
+        gt = gout.cpu().numpy().astype(np.float64)
+        for k in (1, 2, 3):
+            assert torch.equal(res[1, k][0], res[0, k][0]) and torch.equal(res[1, k][1], res[0, k][1])
+            close(res[1, k][0], truth[k - 1])
+            g_acc, g_cur = gt.copy(), gt.copy()
+            for _ in range(k):
+                g_cur = O.conv_csr_f64(g_cur, rowptr, col, val)
+                g_acc = g_acc + g_cur
+            close(res[1, k][1], g_acc / (k + 1))
         rbg.set_option("sell", 0)
         assert "binned" in h.propagation_kernel_name(d)
         close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], binned[2], tol=0)
@@ -336,6 +357,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
     finally:
         rbg.set_option("sell", 1)
+        rbg.set_option("sell_rowmajor", 1)
 
 
 def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):
