@@ -84,6 +84,13 @@ for name in shapes:
         rec["prop_us_sell"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
         rec["prop_us_sell_host_issued"] = timeit_eager(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
         rec["speedup"] = rec["prop_us_binned"] / rec["prop_us_sell"]
+        # the plain layer (rbg_spmm_f32) and the keep_layers chain over the plan against the binned kernel
+        xx, yy = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev)
+        for rm in (0, 1):
+            rbg.set_option("sell_rowmajor", rm)
+            rec[f"spmm_us_rm{rm}"] = timeit(lambda: rbg.ops.spmm_raw(g, xx, out=yy), 10 if big else 100)
+            rec[f"spmm_kernel_rm{rm}"] = g.spmm_kernel_name(d)
+            rec[f"keep_layers_us_rm{rm}"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, keep_layers=True, out=o, layers=L), 10 if big else 100)
         # E0 converted to slabs first (option "sell_rowmajor" = 0) against gathered where it lies; the backward chain alike
         gout, ge0, work = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
         arr = (ctypes.c_void_p * 1)(g.ptr)

@@ -185,7 +185,11 @@ int set_device_for(int device);
 // spmm.hip — Y[n_rows, d] (row stride ldy) = Â · X (row stride ldx), optionally accumulating.
 // sell.hip — the propagation over an attached SELL plan (layers = scratch [K][N][d]; the mean leaves row-major)
 bool sell_applicable(const rbg_graph *g, int d);
+bool sell_rowmajor_applicable(const rbg_graph *g, int d);  // ... and the plan has its row-major entries (option "sell_rowmajor")
 const char *sell_kernel_name(int d);
+int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s);  // rbg_spmm_f32 over the plan
+int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
+                          bool keep_last, hipStream_t s);  // every layer row-major (the caller reads `layers`)
 int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s);  // RBG_EUNSUPPORTED: run the binned chain
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                  hipStream_t s);

@@ -53,9 +53,12 @@ struct SellParams {
     const int32_t *orig;     // original node id of (class, internal row)
     // row-major operands in the REFERENCE's numbering (class 0 = the user table [n_class[0], 2 W], class 1 = the item table):
     const v4i *ent0;         // x_rm: the same entries with the column offset = original class-local row * 2 W * 4
-    const float *rm[2];
+    const float *rm[2];      // x_rm: the gathered operand
+    const float *prm[2];     // prev0_rm: prev[0] (E0's two tables, the incoming gradient, or Y itself for Y += A X), read through orig[]
     int32_t x_rm;            // 1: the gathered operand is rm[] (entries ent0) — E0 / the incoming gradient is never converted
-    int32_t prev0_rm;        // 1: prev[0] is rm[] (read through orig[])
+    int32_t prev0_rm;
+    int32_t prev_rm_all;     // 1: prev[1..] are row-major [N, 2 W] arrays in the reference's numbering as well
+    float *out2;             // last: also store the layer itself (acc), row-major (RBG_FWD_KEEP_LAST_LAYER)
 };
 
 template <int K>
@@ -180,16 +183,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
     const int cbase = cls ? p.n_class[0] : 0;
     const int node = (p.last || p.prev0_rm) ? p.orig[cbase + row] : 0;
-    const float *prev0 = p.prev0_rm ? p.rm[cls] + (int64_t)(node - cbase) * (2 * W) + s * W + sl * 4 : p.prev[0] + o;
+    const int64_t orm = (int64_t)node * (2 * W) + s * W + sl * 4;  // row-major [N, 2 W], the reference's numbering
+    const float *prev0 = p.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * (2 * W)) : p.prev[0] + o;
     if (p.last) {
-        float4 sum = *reinterpret_cast<const float4 *>(prev0);
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.n_prev) sum = *reinterpret_cast<const float4 *>(prev0);
         for (int i = 1; i < p.n_prev; ++i) {
-            const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + o);
+            const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + (p.prev_rm_all ? orm : o));
             sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
         }
+        if (p.out2) *reinterpret_cast<float4 *>(p.out2 + orm) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
         sum.x = (sum.x + acc.lo.x) / p.denom; sum.y = (sum.y + acc.lo.y) / p.denom;
         sum.z = (sum.z + acc.hi.x) / p.denom; sum.w = (sum.w + acc.hi.y) / p.denom;
-        *reinterpret_cast<float4 *>(p.out + (int64_t)node * (2 * W) + s * W + sl * 4) = sum;
+        *reinterpret_cast<float4 *>(p.out + orm) = sum;
     } else {
         float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
         if (p.n_prev) {  // a step of the backward chain: y = g + A x  (g in slab layout)
@@ -320,8 +326,8 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
     for (int k = 0; k < K; ++k) {
         SellParams p{};
         sell_fill(sw, W, p);
-        p.rm[0] = user_emb;
-        p.rm[1] = item_emb;
+        p.rm[0] = p.prm[0] = user_emb;
+        p.rm[1] = p.prm[1] = item_emb;
         p.x_rm = (rm && k == 0) ? 1 : 0;
         p.xs = (k == 0) ? e0s : layers + (int64_t)(k - 1) * nd;
         if (k == K - 1) {
@@ -339,6 +345,85 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
         RBG_HIP(hipGetLastError());
     }
     return RBG_OK;
+}
+
+// Every layer row-major in the reference's numbering (a caller that reads `layers`: NCL, keep_layers): K launches that gather
+// the previous layer where it lies and write layers[k] through orig[]; the last one adds the mean (and keeps its own layer
+// when asked).  ~2 us per layer slower than the slab chain, no scratch layout.
+template <int W>
+static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
+                                   bool keep_last, hipStream_t s) {
+    const SellDev *sw = g->sell;
+    const int64_t nd = g->n_rows * 2 * W;
+    const int n0 = sw->n_class[0];
+    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
+    const int64_t grid = 8 * ((max_units + 7) / 8);
+    for (int k = 0; k < K; ++k) {
+        SellParams p{};
+        sell_fill(sw, W, p);
+        const float *x = k ? layers + (int64_t)(k - 1) * nd : nullptr;
+        p.rm[0] = k ? x : user_emb;
+        p.rm[1] = k ? x + (int64_t)n0 * 2 * W : item_emb;
+        p.x_rm = 1;
+        p.last = 1;
+        if (k == K - 1) {
+            p.n_prev = K;
+            p.prev0_rm = 1;
+            p.prm[0] = user_emb;
+            p.prm[1] = item_emb;
+            p.prev_rm_all = 1;
+            for (int i = 1; i < K; ++i) p.prev[i] = layers + (int64_t)(i - 1) * nd;
+            p.denom = (float)(K + 1);
+            p.out = out_mean;
+            p.out2 = keep_last ? layers + (int64_t)k * nd : nullptr;
+        } else {
+            p.denom = 1.f;
+            p.out = layers + (int64_t)k * nd;
+        }
+        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
+        RBG_HIP(hipGetLastError());
+    }
+    return RBG_OK;
+}
+
+bool sell_rowmajor_applicable(const rbg_graph *g, int d) { return sell_applicable(g, d) && g->sell->ent0 && opt_sell_rowmajor(); }
+
+int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
+                          bool keep_last, hipStream_t s) {
+    if (d == 64) return sell_forward_rowmajor_w<32>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+    if (d == 128) return sell_forward_rowmajor_w<64>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+    return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
+}
+
+// Y = A X (accumulate: Y += A X), X and Y row-major [N, d] in the reference's numbering: rbg_spmm_f32 over the plan.
+template <int W>
+static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumulate, hipStream_t s) {
+    const SellDev *sw = g->sell;
+    const int n0 = sw->n_class[0];
+    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
+    SellParams p{};
+    sell_fill(sw, W, p);
+    p.rm[0] = X;
+    p.rm[1] = X + (int64_t)n0 * 2 * W;
+    p.x_rm = 1;
+    p.last = 1;
+    p.denom = 1.f;
+    p.out = Y;
+    if (accumulate) {  // a thread reads the piece of Y it then overwrites
+        p.n_prev = 1;
+        p.prev0_rm = 1;
+        p.prm[0] = Y;
+        p.prm[1] = Y + (int64_t)n0 * 2 * W;
+    }
+    hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)(8 * ((max_units + 7) / 8))), dim3(256), 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s) {
+    if (d == 64) return sell_spmm_w<32>(g, X, Y, accumulate, s);
+    if (d == 128) return sell_spmm_w<64>(g, X, Y, accumulate, s);
+    return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
@@ -382,8 +467,8 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     for (int i = 0; i < K; ++i) {
         SellParams p{};
         sell_fill(sw, W, p);
-        p.rm[0] = grad_out;
-        p.rm[1] = grad_out + (int64_t)n0 * 2 * W;
+        p.rm[0] = p.prm[0] = grad_out;
+        p.rm[1] = p.prm[1] = grad_out + (int64_t)n0 * 2 * W;
         p.x_rm = (rm && i == 0) ? 1 : 0;
         p.prev0_rm = rm ? 1 : 0;
         p.xs = x;

@@ -894,7 +894,11 @@ extern "C" {
 int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     clear_error();
     if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
-    // mirrors launch_spmm for contiguous, 16-byte aligned fp32 operands in store mode
+    // mirrors rbg_spmm_f32 / launch_spmm for contiguous, 16-byte aligned fp32 operands in store mode
+    if (sell_rowmajor_applicable(g, d)) {
+        snprintf(buf, (size_t)len, "%s", sell_kernel_name(d));
+        return RBG_OK;
+    }
     if (d != 32 && d != 64 && d != 128 && d != 256) {
         snprintf(buf, (size_t)len, "spmm_generic_kernel");
         return RBG_OK;
@@ -916,7 +920,7 @@ int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, 
     clear_error();
     if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
     // mirrors rbg_lightgcn_forward_f32 for one graph and 16-byte aligned operands
-    if (sell_applicable(g, d) && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER)) {
+    if ((sell_applicable(g, d) && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER)) || sell_rowmajor_applicable(g, d)) {
         snprintf(buf, (size_t)len, "%s", sell_kernel_name(d));
         return RBG_OK;
     }
@@ -953,6 +957,7 @@ int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumu
     if (!X || !Y) return fail(RBG_EINVAL, "X or Y is NULL");
     if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
     if ((rc = set_device_for(g->device))) return rc;
+    if (sell_rowmajor_applicable(g, d) && aligned16(X) && aligned16(Y)) return sell_spmm(g, X, Y, d, accumulate, (hipStream_t)stream);
     return spmm_strided(g, X, d, Y, d, d, accumulate, (hipStream_t)stream);
 }
 
@@ -1069,6 +1074,10 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     if (n_graphs == 1 && sell_applicable(g0, d) && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) &&
         !(flags & RBG_FWD_KEEP_LAST_LAYER) && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean))
         return sell_forward(g0, user_emb, item_emb, out_mean, layers, d, K, s);
+    // the same plan with every layer row-major where the caller reads them (NCL, keep_layers)
+    if (n_graphs == 1 && sell_rowmajor_applicable(g0, d) && fused && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) &&
+        aligned16(out_mean))
+        return sell_forward_rowmajor(g0, user_emb, item_emb, out_mean, layers, d, K, (flags & RBG_FWD_KEEP_LAST_LAYER) != 0, s);
     bool slab = opt_slab() && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER) &&
                 aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
     for (int i = 0; i < n_graphs && slab; ++i) slab = slab_eligible(graphs[i], d);

@@ -52,6 +52,8 @@ def spmm_raw(graph, x, out=None, accumulate=False):
         _check_dense(out, "out", graph)
         if tuple(out.shape) != (graph.n_rows, x.shape[1]) or not out.is_contiguous():
             raise ValueError("out must be a contiguous [n_rows, d] tensor")
+    if x.shape[1] in (64, 128):
+        _auto_sell(graph, x.shape[1])  # (eligible handles only: built from interactions; rbg_spmm_f32 then runs over the plan)
     with torch.cuda.device(x.device):
         check(lib.rbg_spmm_f32(graph.ptr, c_vp(x.data_ptr()), c_vp(out.data_ptr()), x.shape[1], int(bool(accumulate)),
                                _stream(x)))

@@ -304,7 +304,11 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         info = h.attach_sell(d)
         assert h.has_sell(d) and not h.has_sell(192 - d) and info["padding"] < 1.2
         assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}>"
-        assert "binned" in h.propagation_kernel_name(d, scratch_layers=False)  # a caller that reads the layers keeps them row-major
+        # a caller that reads the layers gets them row-major: the same kernel gathering / writing the reference's layout
+        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<{d // 2}>" == h.spmm_kernel_name(d)
+        rbg.set_option("sell_rowmajor", 0)
+        assert "binned" in h.propagation_kernel_name(d, scratch_layers=False) and "binned" in h.spmm_kernel_name(d)
+        rbg.set_option("sell_rowmajor", 1)
         for k in (1, 2, 3):
             out = torch.full((nu + ni, d), 7.0, device=cuda)
             rbg.ops.lightgcn_forward_raw(h, uw, iw, k, out=out)
@@ -313,10 +317,25 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
             again = rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0]
             assert torch.equal(out, again)  # the plan fixes the summation order
             assert float(out[0].abs().max()) == float((x[0].abs() / (k + 1)).max()) and float(out[nu].abs().max()) == float((x[nu].abs() / (k + 1)).max())
-        # keep_layers (NCL reads every layer): the row-major path, same values as before
-        mean, layers = rbg.ops.lightgcn_forward_raw(h, uw, iw, 3, keep_layers=True)
-        close(mean, truth[2])
-        close(layers[0], O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rowptr, col, val))
+        # keep_layers (NCL reads every layer): every layer row-major through the plan; equal to the slab chain bit for bit
+        x64 = x.cpu().numpy().astype(np.float64)
+        for k in (1, 2, 3):
+            mean, layers = rbg.ops.lightgcn_forward_raw(h, uw, iw, k, keep_layers=True)
+            close(mean, truth[k - 1])
+            assert torch.equal(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0])
+            cur = x64
+            for j in range(k):
+                cur = O.conv_csr_f64(cur, rowptr, col, val)
+                close(layers[j], cur)
+        # the plain layer (rbg_spmm_f32: NGCF, SimGCL) over the plan, Y = A X and Y += A X
+        y = rbg.ops.spmm_raw(h, x)
+        close(y, O.conv_csr_f64(x64, rowptr, col, val))
+        y2 = x.clone()
+        rbg.ops.spmm_raw(h, x, out=y2, accumulate=True)
+        close(y2, x64 + O.conv_csr_f64(x64, rowptr, col, val))
+        rbg.set_option("sell_rowmajor", 0)
+        close(rbg.ops.spmm_raw(h, x), y, tol=2e-6)  # the binned kernel
+        rbg.set_option("sell_rowmajor", 1)
         # autograd: forward over the slabs, backward = the Horner chain of the binned kernel
         xg = x.clone().requires_grad_(True)
         out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], 3)
