@@ -204,7 +204,10 @@ int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
 /* Column-slab propagation (r03; csrc/sell.hip): attach a SELL-C-sigma plan of this graph for slab width W (32 serves d = 64,
  * 64 serves d = 128).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
- * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1).  The planner is
+ * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1); with the layers kept row-major the
+ * same kernel serves the other flag combinations, rbg_lightgcn_backward_f32 and rbg_spmm_f32 at that width (option
+ * "sell_rowmajor", default 1: E0 / the gradient / X are gathered where they lie through a twin of the entry array in the
+ * reference's numbering, built at attach time, +8 bytes per entry).  The planner is
  * recbole-gnn_amd/sell.py (torch ops on the handle's device CSR); `ent` [n_ent][2], `head` [n_units][4] and `orig` [n_rows] are
  * DEVICE arrays on the graph's device, `unit_base` / `n_units` host arrays of 2.  Every index the kernel dereferences is
  * range-checked on the device before the plan is adopted (copied: the caller keeps its arrays).  Graphs built from
