@@ -33,7 +33,7 @@ for f in glob.glob("gpurun_out/traffic/*_p*/**/*counter_collection.csv", recursi
     wl, dim = m.group(1), int(m.group(2))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "spmm_binned_kernel" in k or "spmm_sweep_kernel" in k or "spmm_generic_kernel" in k:
+        if "spmm_binned_kernel" in k or "spmm_sweep_kernel" in k or "spmm_generic_kernel" in k or "sell_spmm_kernel" in k:
             acc[(wl, dim)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("gpurun_out/traffic/*_p1.log"):
     for line in open(f):
@@ -55,3 +55,4 @@ table.pop("_bench_command_note", None)
 json.dump(table, open(table_path, "w"), indent=1)
 PY
 find $OUT -name "*.csv" -size +1M -delete
+cp profiles/traffic.json $OUT/traffic.json  # (gpurun merges gpurun_out/ back, not profiles/)

@@ -12,7 +12,7 @@
 //     load fetches a batch of 8 slots per lane-group and nothing is masked; the index broadcast is a DPP quad_perm (a
 //     lane-group is two quads), the gather a buffer load whose padded slots read zeros past the table: 4 VALU + 1 VMEM per
 //     gathered row against 13 + 1 in the binned kernel;
-//   * rows longer than 64 entries are cut into up to 8 pieces in adjacent lane-groups (butterfly), rows longer than 512 into
+//   * rows longer than 128 entries are cut into up to 8 pieces in adjacent lane-groups (butterfly), rows longer than 1 024 into
 //     32 pieces over the four waves of a workgroup (LDS): without the latter the longest row is one wave's serial chain of 48
 //     gather batches and sets the duration of the whole launch (38.3 -> 29.7 us per layer);
 //   * heaviest units first, one wave per unit: the hardware dispatcher balances the load.

@@ -21,12 +21,13 @@ from __future__ import annotations
 import torch
 
 K_PAST = 0x7FFFFFF0
-CHUNK = 64
-MAX_PIECE = 512  # longest piece a plan accepts: a wide row has 4 LGW pieces, summed serially per lane-group
+CHUNK = 128  # (sweep, profiles/r03_sell_chunk_probe.jsonl: 24..192 within 4 %, best 128-192; from 256 on the longest piece is the critical path again)
+MAX_PIECE = 512  # longest piece a plan accepts (or nnz / 8192 if that is more): a wide row has 4 LGW pieces, each summed
+                 # serially by one lane-group at ~20 entries per us — beyond this the hub row's chain would outlast the launch
 
 
 class NotApplicable(ValueError):
-    """The graph is outside what the slab path serves (a hub row longer than 4 LGW x MAX_PIECE entries, a table beyond 32-bit
+    """The graph is outside what the slab path serves (a hub row longer than 4 LGW x max(MAX_PIECE, nnz / 8192) entries, a table beyond 32-bit
     slab offsets): the caller keeps the binned kernel, which splits such rows over workgroups."""
 
 
@@ -49,8 +50,9 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
     if max(n) * W * 4 >= K_PAST:
         raise NotApplicable("table too large for 32-bit slab offsets")
     max_deg = int(deg.max()) if deg.numel() else 0
-    if max_deg > MAX_PIECE * 4 * lgw:
-        raise NotApplicable(f"a row of {max_deg} entries is longer than the {4 * lgw} pieces of {MAX_PIECE} the slab path sums per row")
+    max_piece = max(MAX_PIECE, int(col.numel()) // 8192)
+    if max_deg > max_piece * 4 * lgw:
+        raise NotApplicable(f"a row of {max_deg} entries is longer than the {4 * lgw} pieces of {max_piece} the slab path sums per row")
     order, inv, parts_of = [], [], []
     for c in (0, 1):
         d = deg[base[c]:base[c] + n[c]]

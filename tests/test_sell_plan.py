@@ -63,7 +63,7 @@ def test_plan_is_deterministic_and_matches_the_heaviest_first_order(rbg):
         h = head[p1["unit_base"][c]: p1["unit_base"][c] + p1["n_units"][c]]
         slots, kind = h[:, 2] >> 16, h[:, 3] & 0x100FF  # kind = (wide, log2 parts)
         deg = np.diff(rowptr)[([0, nu][c]):([nu, nu + ni][c])]
-        assert slots.max() <= 64 or deg.max() > 64 * 8 * 4  # no piece longer than the chunk unless even 32 parts cannot hold the row
+        assert slots.max() <= sell.CHUNK or deg.max() > sell.CHUNK * 8 * 4  # no piece longer than the chunk unless even 32 parts cannot hold the row
         # (parts, degree) descending: wide rows, then 8-, 4-, 2-part rows, then whole rows, each group longest first
         parts_rank = np.where(h[:, 3] >> 16 & 1, 99, h[:, 3] & 0xFF)
         assert np.all(np.diff(parts_rank) <= 0)
