@@ -91,6 +91,12 @@ for name in shapes:
             rec[f"spmm_us_rm{rm}"] = timeit(lambda: rbg.ops.spmm_raw(g, xx, out=yy), 10 if big else 100)
             rec[f"spmm_kernel_rm{rm}"] = g.spmm_kernel_name(d)
             rec[f"keep_layers_us_rm{rm}"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, keep_layers=True, out=o, layers=L), 10 if big else 100)
+        # the factored chain (compact entries after the first launch) against the valued one
+        for fac in (0, 1):
+            rbg.set_option("sell_factored", fac)
+            rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
+            rec[f"err_fac{fac}"] = float(np.abs(o.cpu().numpy() - ref).max())
+            rec[f"prop_us_fac{fac}"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
         # E0 converted to slabs first (option "sell_rowmajor" = 0) against gathered where it lies; the backward chain alike
         gout, ge0, work = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev), torch.empty(n, d, device=dev)
         arr = (ctypes.c_void_p * 1)(g.ptr)

@@ -214,6 +214,12 @@ int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
  * interactions (a user / item boundary, square) only; a re-weighted view cannot carry a plan. */
 int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
                           const int32_t *n_units, const int32_t *orig);
+/* Row factors of an attached plan: r [n_rows] (device, the PLAN's row numbering = orig[]) with val_ij = r_i * r_j — the symmetric
+ * normalisation D^-1/2 A D^-1/2 of dataset.py:41-79 (r = deg^-1/2, 0 for an empty row).  Checked on the device against every
+ * stored value (1e-6 relative).  With factors the slab chains of rbg_lightgcn_forward_f32 / _backward_f32 keep r (.) E_k between
+ * the layers and every launch after the first reads 4 bytes per entry (the column offset) instead of 8 (option "sell_factored",
+ * default 1); results differ from the unfactored chain by rounding only. */
+int rbg_graph_sell_set_factors(rbg_graph *g, const float *r);
 int rbg_graph_detach_sell(rbg_graph *g);
 int rbg_graph_has_sell(const rbg_graph *g, int d);
 /* Name of the kernel rbg_lightgcn_forward_f32 launches per layer for this graph, width and flags (one graph). */

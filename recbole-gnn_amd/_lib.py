@@ -47,6 +47,7 @@ SIGNATURES = {
                                        c_i64, c_int]),
     "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
     "rbg_graph_attach_sell": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "rbg_graph_sell_set_factors": (c_int, [c_vp, c_vp]),
     "rbg_graph_detach_sell": (c_int, [c_vp]),
     "rbg_graph_has_sell": (c_int, [c_vp, c_int]),
     "rbg_lightgcn_forward_kernel_name": (c_int, [c_vp, c_int, c_u32, ctypes.c_char_p, c_int]),

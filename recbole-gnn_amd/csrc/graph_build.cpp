@@ -49,6 +49,8 @@ static std::atomic<int> g_shard_single_stream{0};
 static std::atomic<int> g_slab{0};
 static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
+static std::atomic<int> g_sell_factored{1};
+int opt_sell_factored() { return g_sell_factored.load(); }
 static std::atomic<int> g_sell_rowmajor{1};
 int opt_sell_rowmajor() { return g_sell_rowmajor.load(); }
 int opt_slab() { return g_slab.load(); }
@@ -487,6 +489,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_rowmajor = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_factored")) {
+        g_sell_factored = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -540,6 +546,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_rowmajor")) {
         *value = g_sell_rowmajor.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_factored")) {
+        *value = g_sell_factored.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

@@ -38,6 +38,7 @@ int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the bi
 int opt_sweep_lean();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
+int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
 int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
 int opt_slab();          // rbg_lightgcn_forward_f32: keep the layers as two column slabs (column-half kernel over contiguous half rows)
@@ -110,6 +111,8 @@ struct SellDev {
     int32_t n_class[2] = {0, 0};     // rows of class c
     int32_t *ent = nullptr;          // [n_ent + 128][2]: {internal column * W * 4, bits of val}
     int32_t *ent0 = nullptr;         // same, column = original class-local row * 2 W * 4 (a launch that gathers row-major tables); optional
+    int32_t *entc = nullptr;         // [n_ent + 256]: the offsets column of ent alone (launches of the factored chain)
+    float *rs = nullptr, *irs = nullptr;  // [n_rows] each (one allocation): r_i with val_ij = r_i r_j, and 1 / r_i; the plan's numbering; optional
     int32_t *head = nullptr;         // [n_units][4]
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
     int64_t n_ent = 0;
@@ -186,7 +189,8 @@ int set_device_for(int device);
 // sell.hip — the propagation over an attached SELL plan (layers = scratch [K][N][d]; the mean leaves row-major)
 bool sell_applicable(const rbg_graph *g, int d);
 bool sell_rowmajor_applicable(const rbg_graph *g, int d);  // ... and the plan has its row-major entries (option "sell_rowmajor")
-const char *sell_kernel_name(int d);
+const char *sell_kernel_name(int d, bool compact);
+bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact entries from the second launch on
 int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s);  // rbg_spmm_f32 over the plan
 int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                           bool keep_last, hipStream_t s);  // every layer row-major (the caller reads `layers`)

@@ -35,6 +35,7 @@ namespace rbg {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 constexpr int kSellPast = 0x7ffffff0;  // padding slots: past every table this path accepts, a buffer load returns zeros
 
@@ -59,6 +60,13 @@ struct SellParams {
     int32_t prev0_rm;
     int32_t prev_rm_all;     // 1: prev[1..] are row-major [N, 2 W] arrays in the reference's numbering as well
     float *out2;             // last: also store the layer itself (acc), row-major (RBG_FWD_KEEP_LAST_LAYER)
+    // factored chain (val_ij = r_i r_j, the symmetric normalisation): the slabs between the layers hold z = r (.) y, a launch that
+    // gathers z reads COLUMN OFFSETS ONLY (entc: 4 bytes per entry instead of 8) and scales its row sums by r_i
+    const int32_t *entc;     // compact: the offsets column of ent
+    const float *rs, *irs;   // r_i and 1 / r_i (0 for an empty row), the plan's numbering
+    int32_t compact;         // 1: gather through entc (the operand is a scaled slab), acc *= r_i
+    int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
+    int32_t prev_scaled;     // 1 (last): prev[1..] are scaled slabs: their sum is multiplied by 1 / r_i
 };
 
 template <int K>
@@ -94,9 +102,55 @@ __device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
     a.hi = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 2, 3), a.hi);
 }
 
+// The gathers of one unit: batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds
+// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  COMPACT: an entry is its column offset alone (the operand is
+// pre-scaled by the column's factor) — 8 bytes per lane and batch, an add instead of an FMA.
+template <int J>
+__device__ __forceinline__ int ent_col(const v2i &w) { return quad_bcast<J / 2>((J & 1) ? w.y : w.x); }
+
+template <int W, bool COMPACT>
+__device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional_t<COMPACT, v2i, v4i> *base, const int nc, const int lg,
+                                            const int q4, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+    constexpr int LGW = 64 / (W / 4);
+    using WT = std::conditional_t<COMPACT, v2i, v4i>;
+    if (nc <= 0) return;
+    int sb = min(8, nc);
+    WT w = {};
+    // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
+    if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
+    for (int k = 0; k < nc; k += 8) {
+        const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
+        WT wn = {};
+        auto batch = [&](auto nc_) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc_)::value;
+            v4f xv[n];
+            SellFor<0, n>::run([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                xv[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<j>(w) + lane_off, 0, 0));
+            });
+            if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+            SellFor<0, n>::run([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (COMPACT) {
+                    acc.lo += __builtin_shufflevector(xv[j], xv[j], 0, 1);
+                    acc.hi += __builtin_shufflevector(xv[j], xv[j], 2, 3);
+                } else {
+                    fma_row(acc, ent_val<j>(w), xv[j]);
+                }
+            });
+        };
+        if (sb == 8) batch(std::integral_constant<int, 8>{});
+        else if (sb == 6) batch(std::integral_constant<int, 6>{});
+        else if (sb == 4) batch(std::integral_constant<int, 4>{});
+        else batch(std::integral_constant<int, 2>{});
+        w = wn;
+        sb = sbn;
+    }
+}
+
 // W = slab width (32 at d = 64).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows,
 // XCD pair (x & 1) owns slab x & 1 of its class.
-template <int W>
+template <int W, bool COMPACT>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
@@ -121,39 +175,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const int4 h = heads[t];
     const int row0 = h.y, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
     const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
-    const v4i *base = ents + (h.x >> 1);
     SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
-    // batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds for batch k sits at
-    // base + (LGW k) / 2 + lg (sb / 2) + q4
-    if (nc > 0) {
-        int sb = min(8, nc);
-        v4i w = {0, 0, 0, 0};
-        // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
-        if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
-        for (int k = 0; k < nc; k += 8) {
-            const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
-            v4i wn = {0, 0, 0, 0};
-            auto batch = [&](auto nc_) __attribute__((always_inline)) {
-                constexpr int n = decltype(nc_)::value;
-                v4f xv[n];
-                SellFor<0, n>::run([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    xv[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<j>(w) + lane_off, 0, 0));
-                });
-                if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
-                SellFor<0, n>::run([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    fma_row(acc, ent_val<j>(w), xv[j]);
-                });
-            };
-            if (sb == 8) batch(std::integral_constant<int, 8>{});
-            else if (sb == 6) batch(std::integral_constant<int, 6>{});
-            else if (sb == 4) batch(std::integral_constant<int, 4>{});
-            else batch(std::integral_constant<int, 2>{});
-            w = wn;
-            sb = sbn;
-        }
-    }
+    if constexpr (COMPACT) sell_gather<W, true>(acc, reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1), nc, lg, q4, rs, lane_off);
+    else sell_gather<W, false>(acc, ents + (h.x >> 1), nc, lg, q4, rs, lane_off);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
     const int parts = 1 << lp;
     if (lp > 0) {
@@ -185,23 +209,36 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const int node = (p.last || p.prev0_rm) ? p.orig[cbase + row] : 0;
     const int64_t orm = (int64_t)node * (2 * W) + s * W + sl * 4;  // row-major [N, 2 W], the reference's numbering
     const float *prev0 = p.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * (2 * W)) : p.prev[0] + o;
+    float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+    const float r_i = (COMPACT || p.store_scaled) ? p.rs[cbase + row] : 1.f;
+    if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
     if (p.last) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.n_prev) sum = *reinterpret_cast<const float4 *>(prev0);
-        for (int i = 1; i < p.n_prev; ++i) {
-            const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + (p.prev_rm_all ? orm : o));
-            sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+        if (p.prev_scaled) {  // the layers in between are stored scaled: E_k = z_k / r_i
+            float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 1; i < p.n_prev; ++i) {
+                const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + o);
+                zs.x += q.x; zs.y += q.y; zs.z += q.z; zs.w += q.w;
+            }
+            const float ir = p.irs[cbase + row];
+            sum.x += zs.x * ir; sum.y += zs.y * ir; sum.z += zs.z * ir; sum.w += zs.w * ir;
+        } else {
+            for (int i = 1; i < p.n_prev; ++i) {
+                const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + (p.prev_rm_all ? orm : o));
+                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+            }
         }
-        if (p.out2) *reinterpret_cast<float4 *>(p.out2 + orm) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-        sum.x = (sum.x + acc.lo.x) / p.denom; sum.y = (sum.y + acc.lo.y) / p.denom;
-        sum.z = (sum.z + acc.hi.x) / p.denom; sum.w = (sum.w + acc.hi.y) / p.denom;
+        if (p.out2) *reinterpret_cast<float4 *>(p.out2 + orm) = y;
+        sum.x = (sum.x + y.x) / p.denom; sum.y = (sum.y + y.y) / p.denom;
+        sum.z = (sum.z + y.z) / p.denom; sum.w = (sum.w + y.w) / p.denom;
         *reinterpret_cast<float4 *>(p.out + orm) = sum;
     } else {
-        float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-        if (p.n_prev) {  // a step of the backward chain: y = g + A x  (g in slab layout)
+        if (p.n_prev) {  // a step of the backward chain: y = g + A x
             const float4 q = *reinterpret_cast<const float4 *>(prev0);
             y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
         }
+        if (p.store_scaled) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }
         *reinterpret_cast<float4 *>(p.ys + o) = y;
     }
     }
@@ -267,10 +304,44 @@ __global__ void sell_first_entries_kernel(const int2 *ent, int2 *ent0, int64_t n
     }
 }
 
+__global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) entc[e] = ent[e].x;
+}
+
+// factor check: one thread per (unit, lane-group) walks its slots; every stored value must be r[row] * r[col] to 1e-6 relative
+__global__ void sell_check_factors_kernel(const int2 *ent, const int4 *head, int n_units_total, int unit_base1, int n0, int W, int lgw,
+                                          const float *r, int *err) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = (int)(gid / lgw), lg = (int)(gid % lgw);
+    if (t >= n_units_total) return;
+    const int4 h = head[t];
+    const int cls = t >= unit_base1, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+    const int rr = lg >> lp;
+    if (rr >= nrows) return;
+    const int rbase = cls ? n0 : 0, cbase = cls ? 0 : n0;
+    const float ri = r[rbase + h.y + rr];
+    for (int k = 0; k < nc; k += 8) {
+        const int sb = min(8, nc - k);
+        const int2 *b = ent + h.x + (int64_t)lgw * k + lg * sb;
+        for (int j = 0; j < sb; ++j) {
+            const int2 e = b[j];
+            if (e.x == kSellPast) continue;
+            const float v = __int_as_float(e.y), f = ri * r[cbase + e.x / (W * 4)];
+            if (!(fabsf(v - f) <= 1e-6f * fabsf(v))) atomicExch(err, 1);
+        }
+    }
+}
+__global__ void sell_inverse_kernel(const float *r, float *ir, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ir[i] = r[i] > 0.f ? 1.f / r[i] : 0.f;
+}
+
 void free_sell(SellDev *sw) {
     if (!sw) return;
     if (sw->ent) (void)hipFree(sw->ent);
     if (sw->ent0) (void)hipFree(sw->ent0);
+    if (sw->entc) (void)hipFree(sw->entc);
+    if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
     if (sw->head) (void)hipFree(sw->head);
     if (sw->orig) (void)hipFree(sw->orig);
     if (sw->bwd) (void)hipFree(sw->bwd);
@@ -281,7 +352,24 @@ bool sell_applicable(const rbg_graph *g, int d) {
     return opt_sell() && g && g->sell && g->sell->W * 2 == d;
 }
 
-const char *sell_kernel_name(int d) { return d == 64 ? "sell_spmm_kernel<32>" : "sell_spmm_kernel<64>"; }
+// the chains run factored (compact entries from the second launch on) when the plan carries row factors
+static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_sell_factored(); }
+
+const char *sell_kernel_name(int d, bool compact) {
+    if (d == 64) return compact ? "sell_spmm_kernel<32, true>" : "sell_spmm_kernel<32, false>";
+    return compact ? "sell_spmm_kernel<64, true>" : "sell_spmm_kernel<64, false>";
+}
+bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
+
+template <int W>
+static int sell_launch(const SellDev *sw, const SellParams &p, hipStream_t s) {
+    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
+    const unsigned grid = (unsigned)(8 * ((max_units + 7) / 8));  // two XCDs per (class, slab), four waves per workgroup
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, false>), dim3(grid), dim3(256), 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
 
 static void sell_fill(const SellDev *sw, int W, SellParams &p) {
     const int64_t off1 = (int64_t)sw->n_class[0] * 2 * W;
@@ -289,6 +377,9 @@ static void sell_fill(const SellDev *sw, int W, SellParams &p) {
     p.ent0 = reinterpret_cast<const v4i *>(sw->ent0);
     p.head = reinterpret_cast<const int4 *>(sw->head);
     p.orig = sw->orig;
+    p.entc = sw->entc;
+    p.rs = sw->rs;
+    p.irs = sw->irs;
     for (int c = 0; c < 2; ++c) {
         p.unit_base[c] = sw->unit_base[c];
         p.n_units[c] = sw->n_units[c];
@@ -316,13 +407,12 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
     const SellDev *sw = g->sell;
     const int64_t nd = g->n_rows * 2 * W;
     const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor();
+    const bool fac = sell_factored(sw);
     float *e0s = layers + (int64_t)(K - 1) * nd;
     if (!rm) {
         const int rc = sell_to_slab<W>(sw, user_emb, item_emb, e0s, s);
         if (rc) return rc;
     }
-    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
-    const int64_t grid = 8 * ((max_units + 7) / 8);  // two XCDs per (class, slab), four waves per workgroup
     for (int k = 0; k < K; ++k) {
         SellParams p{};
         sell_fill(sw, W, p);
@@ -330,9 +420,12 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
         p.rm[1] = p.prm[1] = item_emb;
         p.x_rm = (rm && k == 0) ? 1 : 0;
         p.xs = (k == 0) ? e0s : layers + (int64_t)(k - 1) * nd;
+        p.compact = (fac && k > 0) ? 1 : 0;          // layers[k - 1] holds r (.) E_k
+        p.store_scaled = (fac && k < K - 1) ? 1 : 0;
         if (k == K - 1) {
             p.last = 1;
             p.n_prev = K;
+            p.prev_scaled = fac ? 1 : 0;
             p.prev0_rm = rm ? 1 : 0;
             p.prev[0] = e0s;
             for (int i = 1; i < K; ++i) p.prev[i] = layers + (int64_t)(i - 1) * nd;
@@ -341,8 +434,7 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
         } else {
             p.ys = layers + (int64_t)k * nd;
         }
-        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
-        RBG_HIP(hipGetLastError());
+        if (int rc = sell_launch<W>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -356,8 +448,6 @@ static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, co
     const SellDev *sw = g->sell;
     const int64_t nd = g->n_rows * 2 * W;
     const int n0 = sw->n_class[0];
-    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
-    const int64_t grid = 8 * ((max_units + 7) / 8);
     for (int k = 0; k < K; ++k) {
         SellParams p{};
         sell_fill(sw, W, p);
@@ -380,8 +470,7 @@ static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, co
             p.denom = 1.f;
             p.out = layers + (int64_t)k * nd;
         }
-        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
-        RBG_HIP(hipGetLastError());
+        if (int rc = sell_launch<W>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -400,7 +489,6 @@ template <int W>
 static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumulate, hipStream_t s) {
     const SellDev *sw = g->sell;
     const int n0 = sw->n_class[0];
-    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
     SellParams p{};
     sell_fill(sw, W, p);
     p.rm[0] = X;
@@ -415,9 +503,7 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumul
         p.prm[0] = Y;
         p.prm[1] = Y + (int64_t)n0 * 2 * W;
     }
-    hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)(8 * ((max_units + 7) / 8))), dim3(256), 0, s, p);
-    RBG_HIP(hipGetLastError());
-    return RBG_OK;
+    return sell_launch<W>(sw, p, s);
 }
 
 int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s) {
@@ -440,6 +526,7 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     // the incoming gradient is gathered and added where it lies unless the result overwrites it (in-place call) or the plan
     // has no row-major entries: then it is converted to slabs first
     const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor() && grad_out != grad_e0;
+    const bool fac = sell_factored(sw);
     if (!sw->bwd && (K > 1 || !rm)) {  // slab scratch (g, ping, pong), allocated by the first backward on this handle — never inside a capture
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
@@ -459,8 +546,6 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
         const int rc = sell_to_slab<W>(sw, grad_out, grad_out + (int64_t)n0 * 2 * W, gs, s);
         if (rc) return rc;
     }
-    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
-    const int64_t grid = 8 * ((max_units + 7) / 8);
     // dE0 = (g + A (g + A (... (g + A g)))) / (K + 1): K launches, every one adds g in its epilogue; the last divides and
     // writes row-major (A symmetric: rbg_lightgcn_backward_f32 is called with the transposed handles, the handle itself here)
     const float *x = gs;
@@ -470,6 +555,8 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
         p.rm[0] = p.prm[0] = grad_out;
         p.rm[1] = p.prm[1] = grad_out + (int64_t)n0 * 2 * W;
         p.x_rm = (rm && i == 0) ? 1 : 0;
+        p.compact = (fac && i > 0) ? 1 : 0;
+        p.store_scaled = (fac && i < K - 1) ? 1 : 0;
         p.prev0_rm = rm ? 1 : 0;
         p.xs = x;
         p.n_prev = 1;
@@ -482,8 +569,7 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
             p.ys = (i & 1) ? pong : ping;
             x = p.ys;
         }
-        hipLaunchKernelGGL(sell_spmm_kernel<W>, dim3((unsigned)grid), dim3(256), 0, s, p);
-        RBG_HIP(hipGetLastError());
+        if (int rc = sell_launch<W>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -569,6 +655,18 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
         free_sell(sw);
         return fail(RBG_ENOMEM, "device allocation / copy of the SELL plan failed");
     }
+    // the offsets column alone (the factored chain's launches read 4 bytes per entry)
+    {
+        const size_t cb = sizeof(int32_t) * (size_t)(n_ent + 256);
+        if (hipMalloc(&sw->entc, cb) == hipSuccess && hipMemset(sw->entc, 0, cb) == hipSuccess) {
+            if (n_ent) hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc,
+                                          n_ent);
+        } else {
+            (void)hipGetLastError();
+            if (sw->entc) (void)hipFree(sw->entc);
+            sw->entc = nullptr;
+        }
+    }
     // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per propagation)
     if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast) {
         if (hipMalloc(&sw->ent0, ent_bytes) == hipSuccess && hipMemset(sw->ent0, 0, ent_bytes) == hipSuccess) {
@@ -581,10 +679,52 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
         } else {
             (void)hipGetLastError();
             if (sw->ent0) (void)hipFree(sw->ent0);
+    if (sw->entc) (void)hipFree(sw->entc);
+    if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
             sw->ent0 = nullptr;
         }
     }
     g->sell = sw;
+    return RBG_OK;
+}
+
+int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
+    clear_error();
+    if (!g || !g->sell) return fail(RBG_EINVAL, "no SELL plan attached");
+    if (!r) return fail(RBG_EINVAL, "r is NULL");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    SellDev *sw = g->sell;
+    if (!sw->entc) return fail(RBG_EUNSUPPORTED, "the plan has no compact entries");
+    const int n = (int)g->n_rows, n_total = sw->n_units[0] + sw->n_units[1], lgw = 64 / (sw->W / 4);
+    (void)hipDeviceSynchronize();  // (not concurrently with launches on this handle)
+    if (sw->rs) (void)hipFree(sw->rs);
+    sw->rs = sw->irs = nullptr;
+    float *buf = nullptr;
+    int *d_err = nullptr;
+    if (hipMalloc(&buf, sizeof(float) * 2 * (size_t)n) != hipSuccess || hipMalloc(&d_err, sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (buf) (void)hipFree(buf);
+        return fail(RBG_ENOMEM, "device allocation of the row factors failed");
+    }
+    bool ok = hipMemcpy(buf, r, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice) == hipSuccess && hipMemset(d_err, 0, sizeof(int)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sell_inverse_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, buf, buf + n, n);
+        const int64_t work = (int64_t)n_total * lgw;
+        if (work) hipLaunchKernelGGL(sell_check_factors_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, 0,
+                                     reinterpret_cast<const int2 *>(sw->ent), reinterpret_cast<const int4 *>(sw->head), n_total, sw->n_units[0],
+                                     sw->n_class[0], sw->W, lgw, buf, d_err);
+    }
+    int h_err = 0;
+    ok = ok && hipMemcpy(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_err);
+    if (!ok || h_err) {
+        (void)hipFree(buf);
+        if (!ok) return fail(RBG_EHIP, "checking the row factors failed to run");
+        return fail(RBG_EINVAL, "the plan's values are not r[row] * r[col]");
+    }
+    sw->rs = buf;
+    sw->irs = buf + n;
     return RBG_OK;
 }
 

@@ -243,7 +243,10 @@ class GraphHandle:
             nu = (ctypes.c_int32 * 2)(*plan["n_units"])
             check(lib.rbg_graph_attach_sell(self.ptr, d // 2, c_vp(plan["ent"].data_ptr()), plan["n_ent"], c_vp(plan["head"].data_ptr()),
                                             ub, nu, c_vp(plan["orig"].data_ptr())))
-        return {"W": d // 2, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1)}
+            if plan["factors"] is not None:  # val_ij = r_i r_j: the chains read 4-byte entries after their first launch
+                check(lib.rbg_graph_sell_set_factors(self.ptr, c_vp(plan["factors"].data_ptr())))
+        return {"W": d // 2, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1),
+                "factored": plan["factors"] is not None}
 
     def detach_sell(self):
         check(lib.rbg_graph_detach_sell(self.ptr))

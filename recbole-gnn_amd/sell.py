@@ -14,7 +14,7 @@ the graph handle's device CSR with torch ops (on the handle's GPU: ~10 ms at the
   ``[batch][lane-group][slot]``, so one wave-wide 16-byte load fetches a batch and no lane masks anything.
 
 Entry = {byte offset of the slab row (internal column * W * 4), bits of val}; padding = {K_PAST, 0.0} (a buffer load past
-the table returns zeros).  Unit header = {first entry, first row, slots << 16, log2(parts) | rows << 8 | wide << 16}.
+the table returns zeros).  ``factors`` = r with val_ij = r_i r_j when the values are the symmetric normalisation (else None).  Unit header = {first entry, first row, slots << 16, log2(parts) | rows << 8 | wide << 16}.
 The same planner runs on CPU tensors (tests)."""
 from __future__ import annotations
 
@@ -158,7 +158,20 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
     head = torch.cat(heads).to(torch.int32)
     orig = torch.cat([order[0] + base[0], order[1] + base[1]]).to(torch.int32)
     return dict(ent=ent.contiguous(), head=head.contiguous(), orig=orig.contiguous(), unit_base=unit_base, n_units=n_units, n_class=n,
-                W=W, n_ent=ent_off)
+                W=W, n_ent=ent_off, factors=_row_factors(rowptr, col, val, deg, orig))
+
+
+def _row_factors(rowptr, col, val, deg, orig):
+    """r [N] float32 in the PLAN's numbering with val_ij = r_i r_j when the graph is the symmetric normalisation
+    D^-1/2 A D^-1/2 with D = the row counts (dataset.py:41-79; SGL's edge-drop views alike), else None.  With factors the
+    slab chains keep r (.) E_k between the layers and read 4 bytes per entry (csrc/sell.hip, rbg_graph_sell_set_factors)."""
+    if val.numel() == 0:
+        return None
+    r = torch.where(deg > 0, deg.to(torch.float64).clamp(min=1).pow(-0.5), torch.zeros((), dtype=torch.float64, device=deg.device))
+    rows = torch.repeat_interleave(torch.arange(deg.numel(), dtype=torch.int64, device=deg.device), deg)
+    f = r[rows] * r[col]
+    ok = bool(((val.to(torch.float64) - f).abs() <= 4e-7 * f).all())
+    return r[orig.to(torch.int64)].to(torch.float32).contiguous() if ok else None
 
 
 def emulate(plan, x):

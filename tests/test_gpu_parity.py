@@ -303,9 +303,10 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         rbg.set_option("sell", 1)
         info = h.attach_sell(d)
         assert h.has_sell(d) and not h.has_sell(192 - d) and info["padding"] < 1.2
-        assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}>"
+        # val_ij = r_i r_j (the symmetric normalisation): the chain's launches after the first read 4-byte entries
+        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}, true>"
         # a caller that reads the layers gets them row-major: the same kernel gathering / writing the reference's layout
-        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<{d // 2}>" == h.spmm_kernel_name(d)
+        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<{d // 2}, false>" == h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 0)
         assert "binned" in h.propagation_kernel_name(d, scratch_layers=False) and "binned" in h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 1)
@@ -322,7 +323,11 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         for k in (1, 2, 3):
             mean, layers = rbg.ops.lightgcn_forward_raw(h, uw, iw, k, keep_layers=True)
             close(mean, truth[k - 1])
+            close(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0], tol=2e-6)  # (the slab chain runs factored)
+            rbg.set_option("sell_factored", 0)
             assert torch.equal(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0])
+            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}, false>"
+            rbg.set_option("sell_factored", 1)
             cur = x64
             for j in range(k):
                 cur = O.conv_csr_f64(cur, rowptr, col, val)
@@ -348,19 +353,27 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         close(xg.grad, g_acc / 4.0)
         # E0 / the incoming gradient gathered row-major where they lie (option "sell_rowmajor", default) == converted to slabs
         # first: the same sums in the same order, bit for bit — forward and backward, K = 1..3, a non-uniform gradient
+        # ... with the factored chain (compact entries, scaled slabs) and without
         gout = randn((nu + ni, d), 23, cuda)
         res = {}
-        for rm in (1, 0):
-            rbg.set_option("sell_rowmajor", rm)
-            for k in (1, 2, 3):
-                xg = x.clone().requires_grad_(True)
-                out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
-                out.backward(gout)
-                res[rm, k] = (out.detach().clone(), xg.grad.clone())
+        for fac in (1, 0):
+            rbg.set_option("sell_factored", fac)
+            for rm in (1, 0):
+                rbg.set_option("sell_rowmajor", rm)
+                for k in (1, 2, 3):
+                    xg = x.clone().requires_grad_(True)
+                    out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
+                    out.backward(gout)
+                    res[fac, rm, k] = (out.detach().clone(), xg.grad.clone())
         rbg.set_option("sell_rowmajor", 1)
+        rbg.set_option("sell_factored", 1)
         gt = gout.cpu().numpy().astype(np.float64)
         for k in (1, 2, 3):
-            assert torch.equal(res[1, k][0], res[0, k][0]) and torch.equal(res[1, k][1], res[0, k][1])
+            for fac in (1, 0):
+                assert torch.equal(res[fac, 1, k][0], res[fac, 0, k][0]) and torch.equal(res[fac, 1, k][1], res[fac, 0, k][1])
+            close(res[1, 1, k][0], res[0, 1, k][0], tol=2e-6)
+            close(res[1, 1, k][1], res[0, 1, k][1], tol=2e-6)
+            res[1, k] = res[1, 1, k]
             close(res[1, k][0], truth[k - 1])
             g_acc, g_cur = gt.copy(), gt.copy()
             for _ in range(k):
@@ -377,6 +390,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
     finally:
         rbg.set_option("sell", 1)
         rbg.set_option("sell_rowmajor", 1)
+        rbg.set_option("sell_factored", 1)
 
 
 def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):

@@ -69,3 +69,22 @@ def test_plan_is_deterministic_and_matches_the_heaviest_first_order(rbg):
         assert np.all(np.diff(parts_rank) <= 0)
         for k in np.unique(kind):
             assert np.all(np.diff(slots[kind == k]) <= 2)  # (the pieces of one row differ by one entry: +-2 after the rounding)
+
+
+def test_row_factors_are_found_for_the_symmetric_normalisation_only(rbg):
+    """val_ij = r_i r_j with r = deg^-1/2 (dataset.py:41-79): the planner returns r in the plan's numbering, and nothing for
+    values that do not factor (a re-weighted graph) — rbg_graph_sell_set_factors re-checks every value on the device."""
+    from recbole_gnn_amd import sell
+    uid, iid, nu, ni, rowptr, col, val = _graph(rbg, "ml-100k")
+    t = [torch.from_numpy(a) for a in (rowptr, col, val)]
+    plan = sell.build_plan(*t, nu, ni, W=32)
+    r = plan["factors"].numpy().astype(np.float64)
+    deg = np.diff(rowptr)[plan["orig"].numpy()]
+    want = np.where(deg > 0, np.maximum(deg, 1) ** -0.5, 0.0)
+    assert np.abs(r - want).max() < 1e-7 and r[deg == 0].max(initial=0.0) == 0.0
+    rows = np.repeat(np.arange(nu + ni), np.diff(rowptr))
+    inv = np.empty(nu + ni, dtype=np.int64)
+    inv[plan["orig"].numpy()] = np.arange(nu + ni)
+    assert np.abs(r[inv[rows]] * r[inv[col]] - val).max() < 1e-6 * val.max()
+    other = val * np.random.default_rng(0).uniform(0.5, 1.5, len(val)).astype(np.float32)
+    assert sell.build_plan(t[0], t[1], torch.from_numpy(other), nu, ni, W=32)["factors"] is None
