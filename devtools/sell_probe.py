@@ -111,6 +111,11 @@ for name in shapes:
             rec[f"prop_us_sell_rm{rm}"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
             bwd(); torch.cuda.synchronize()
             rec[f"bwd_us_sell_rm{rm}"] = timeit(bwd, 10 if big else 100)
+        if d == 128:  # two slabs of 64 (a W = 64 plan) against the four slabs of 32 measured above
+            g.attach_sell(128, W=64)
+            rec["kernel_w64"] = g.propagation_kernel_name(d)
+            rec["prop_us_sell_w64"] = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 10 if big else 100)
+            rec["spmm_us_w64"] = timeit(lambda: rbg.ops.spmm_raw(g, xx, out=yy), 10 if big else 100)
         g.detach_sell()
         print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
     del g

@@ -189,7 +189,7 @@ int set_device_for(int device);
 // sell.hip — the propagation over an attached SELL plan (layers = scratch [K][N][d]; the mean leaves row-major)
 bool sell_applicable(const rbg_graph *g, int d);
 bool sell_rowmajor_applicable(const rbg_graph *g, int d);  // ... and the plan has its row-major entries (option "sell_rowmajor")
-const char *sell_kernel_name(int d, bool compact);
+const char *sell_kernel_name(const rbg_graph *g, int d, bool compact);
 bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact entries from the second launch on
 int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s);  // rbg_spmm_f32 over the plan
 int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,

@@ -45,7 +45,7 @@ struct SellParams {
     int32_t unit_base[2], n_units[2], n_class[2];
     const float *xs;         // gathered operand, slab layout
     float *ys;               // result, slab layout (last = 0)
-    int64_t slab_off[2][2];  // float offset of (class, slab)
+    int64_t slab_off[2][4];  // float offset of (class, slab)
     int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, 2 W]; 0: ys = acc (+ prev[0] if n_prev)
     int32_t n_prev;
     const float *prev[RBG_MAX_FUSED_LAYERS + 1];  // slab layout
@@ -108,9 +108,9 @@ __device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
 template <int J>
 __device__ __forceinline__ int ent_col(const v2i &w) { return quad_bcast<J / 2>((J & 1) ? w.y : w.x); }
 
-template <int W, bool COMPACT>
+template <int W, bool COMPACT, int SHIFT>
 __device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional_t<COMPACT, v2i, v4i> *base, const int nc, const int lg,
-                                            const int q4, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+                                            const int q4, const __amdgpu_buffer_rsrc_t rs, const int lane_off, const bool shift) {
     constexpr int LGW = 64 / (W / 4);
     using WT = std::conditional_t<COMPACT, v2i, v4i>;
     if (nc <= 0) return;
@@ -118,6 +118,12 @@ __device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional
     WT w = {};
     // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
     if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
+    auto widen = [&](WT &e) __attribute__((always_inline)) {  // offsets of a row-major table twice as wide (padding stays out of range)
+        if constexpr (SHIFT && !COMPACT) {
+            if (shift) { e.x = (int)((unsigned)e.x << SHIFT); e.z = (int)((unsigned)e.z << SHIFT); }
+        }
+    };
+    widen(w);
     for (int k = 0; k < nc; k += 8) {
         const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
         WT wn = {};
@@ -143,6 +149,7 @@ __device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional
         else if (sb == 6) batch(std::integral_constant<int, 6>{});
         else if (sb == 4) batch(std::integral_constant<int, 4>{});
         else batch(std::integral_constant<int, 2>{});
+        widen(wn);
         w = wn;
         sb = sbn;
     }
@@ -150,12 +157,13 @@ __device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional
 
 // W = slab width (32 at d = 64).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows,
 // XCD pair (x & 1) owns slab x & 1 of its class.
-template <int W, bool COMPACT>
+template <int W, int NS, bool COMPACT>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
+    constexpr int D = NS * W;     // row width: NS slabs (2: two XCDs share a (class, slab) role; 4: one XCD per role)
     __shared__ float s_wide[4][W];
-    const int x = blockIdx.x & 7, cls = x >> 2, s = x & 1, xi = (x & 3) >> 1;
+    const int x = blockIdx.x & 7, cls = x >> 2, s = x & (NS - 1), xi = NS == 2 ? (x & 3) >> 1 : 0;
     const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = threadIdx.x >> 6;
     // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
     // scalar-load round trips per wave — n_units, pointers, header, offsets)
@@ -164,20 +172,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const float *xtab = p.x_rm ? p.rm[1 - cls] + s * W : p.xs + p.slab_off[1 - cls][s];
     const int n_tab = p.n_class[1 - cls];
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, p.x_rm ? n_tab * 2 * W * 4 - s * W * 4 : n_tab * W * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, p.x_rm ? (unsigned)n_tab * (D * 4) - s * W * 4 : n_tab * W * 4, 0x00020000);
     const int lane_off = sl * 16;
     const unsigned nun = (unsigned)p.n_units[cls];
     const int4 *heads = p.head + p.unit_base[cls];
     const v4i *ents = p.x_rm ? p.ent0 : p.ent;
     const int64_t ybase = p.slab_off[cls][s];
-    const unsigned n_w = (gridDim.x >> 3) * 8;  // waves of this role: the grid covers the units, so the loop body runs at most once
-    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * 2 + xi) * 4 + wave))); t < nun; t += n_w) {
+    constexpr int XR = NS == 2 ? 2 : 1;             // XCDs per role
+    const unsigned n_w = (gridDim.x >> 3) * 4 * XR;  // waves of this role: the grid covers the units, so the loop body runs at most once
+    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave))); t < nun; t += n_w) {
     const int4 h = heads[t];
     const int row0 = h.y, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
     const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
+    // the epilogue's row-indexed scalars are requested before the gathers (they would otherwise be two dependent round trips
+    // at the end of the wave: orig[] -> the row-major addend)
+    const int r = lg >> lp;
+    const int row = row0 + (r < nrows ? r : 0);
+    const int cbase = cls ? p.n_class[0] : 0;
+    int node = 0;
+    float r_i = 1.f;
+    if constexpr (COMPACT) {  // (the valued instantiation has no register to spare: it asks at the end)
+        if (p.last || p.prev0_rm) node = p.orig[cbase + row];
+        r_i = p.rs[cbase + row];
+    }
     SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
-    if constexpr (COMPACT) sell_gather<W, true>(acc, reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1), nc, lg, q4, rs, lane_off);
-    else sell_gather<W, false>(acc, ents + (h.x >> 1), nc, lg, q4, rs, lane_off);
+    // (ent0's offsets are rows of 2 W floats: a 4 W row-major operand doubles them)
+    if constexpr (COMPACT) sell_gather<W, true, 0>(acc, reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1), nc, lg, q4, rs, lane_off, false);
+    else sell_gather<W, false, (NS == 4 ? 1 : 0)>(acc, ents + (h.x >> 1), nc, lg, q4, rs, lane_off, p.x_rm != 0);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
     const int parts = 1 << lp;
     if (lp > 0) {
@@ -201,16 +222,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
             acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
         }
     }
-    const int r = lg >> lp;
     if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0)) {
-    const int row = row0 + r;
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
-    const int cbase = cls ? p.n_class[0] : 0;
-    const int node = (p.last || p.prev0_rm) ? p.orig[cbase + row] : 0;
-    const int64_t orm = (int64_t)node * (2 * W) + s * W + sl * 4;  // row-major [N, 2 W], the reference's numbering
-    const float *prev0 = p.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * (2 * W)) : p.prev[0] + o;
+    if constexpr (!COMPACT) {
+        if (p.last || p.prev0_rm) node = p.orig[cbase + row];
+    }
+    const int64_t orm = (int64_t)node * D + s * W + sl * 4;  // row-major [N, D], the reference's numbering
+    const float *prev0 = p.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * D) : p.prev[0] + o;
     float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-    const float r_i = (COMPACT || p.store_scaled) ? p.rs[cbase + row] : 1.f;
+    if constexpr (!COMPACT) {
+        if (p.store_scaled) r_i = p.rs[cbase + row];
+    }
     if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
     if (p.last) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -245,15 +267,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     }
 }
 
-// the two embedding tables, row-major [n, 2 W] in the reference's numbering -> slabs in the plan's numbering
-template <int W>
+// the two embedding tables, row-major [n, NS W] in the reference's numbering -> slabs in the plan's numbering
+template <int W, int NS>
 __global__ __launch_bounds__(256) void sell_to_slab_kernel(const float *user_emb, const float *item_emb, int64_t n_users, float *dst,
                                                            const int32_t *orig, int n0, int n1, int64_t off0, int64_t off1) {
-    const int g = (blockIdx.x * 256 + threadIdx.x) / (2 * W / 4), c4 = ((blockIdx.x * 256 + threadIdx.x) % (2 * W / 4)) * 4;
+    constexpr int D = NS * W;
+    const int g = (blockIdx.x * 256 + threadIdx.x) / (D / 4), c4 = ((blockIdx.x * 256 + threadIdx.x) % (D / 4)) * 4;
     if (g >= n0 + n1) return;
     const int cls = g >= n0, row = cls ? g - n0 : g;
     const int64_t node = orig[g];
-    const float *src = node < n_users ? user_emb + node * (2 * W) : item_emb + (node - n_users) * (2 * W);
+    const float *src = node < n_users ? user_emb + node * D : item_emb + (node - n_users) * D;
     const int s = c4 / W;
     const int64_t so = (cls ? off1 + (int64_t)s * n1 * W : off0 + (int64_t)s * n0 * W) + (int64_t)row * W + (c4 - s * W);
     *reinterpret_cast<float4 *>(dst + so) = *reinterpret_cast<const float4 *>(src + c4);
@@ -349,30 +372,33 @@ void free_sell(SellDev *sw) {
 }
 
 bool sell_applicable(const rbg_graph *g, int d) {
-    return opt_sell() && g && g->sell && g->sell->W * 2 == d;
+    return opt_sell() && g && g->sell && (g->sell->W * 2 == d || (g->sell->W == 32 && d == 128));
 }
 
 // the chains run factored (compact entries from the second launch on) when the plan carries row factors
 static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_sell_factored(); }
 
-const char *sell_kernel_name(int d, bool compact) {
-    if (d == 64) return compact ? "sell_spmm_kernel<32, true>" : "sell_spmm_kernel<32, false>";
-    return compact ? "sell_spmm_kernel<64, true>" : "sell_spmm_kernel<64, false>";
+const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
+    const int W = g->sell->W;
+    if (W == 32 && d == 64) return compact ? "sell_spmm_kernel<32, 2, true>" : "sell_spmm_kernel<32, 2, false>";
+    if (W == 32) return compact ? "sell_spmm_kernel<32, 4, true>" : "sell_spmm_kernel<32, 4, false>";
+    return compact ? "sell_spmm_kernel<64, 2, true>" : "sell_spmm_kernel<64, 2, false>";
 }
 bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
 
-template <int W>
+template <int W, int NS>
 static int sell_launch(const SellDev *sw, const SellParams &p, hipStream_t s) {
     const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
-    const unsigned grid = (unsigned)(8 * ((max_units + 7) / 8));  // two XCDs per (class, slab), four waves per workgroup
-    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sell_spmm_kernel<W, false>), dim3(grid), dim3(256), 0, s, p);
+    constexpr int per = NS == 2 ? 8 : 4;  // units per 8 workgroups: two XCDs (NS = 2) or one (NS = 4) per (class, slab), four waves each
+    const unsigned grid = (unsigned)(8 * ((max_units + per - 1) / per));
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
 
-static void sell_fill(const SellDev *sw, int W, SellParams &p) {
-    const int64_t off1 = (int64_t)sw->n_class[0] * 2 * W;
+static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
+    const int64_t off1 = (int64_t)sw->n_class[0] * NS * W;
     p.ent = reinterpret_cast<const v4i *>(sw->ent);
     p.ent0 = reinterpret_cast<const v4i *>(sw->ent0);
     p.head = reinterpret_cast<const int4 *>(sw->head);
@@ -384,16 +410,16 @@ static void sell_fill(const SellDev *sw, int W, SellParams &p) {
         p.unit_base[c] = sw->unit_base[c];
         p.n_units[c] = sw->n_units[c];
         p.n_class[c] = sw->n_class[c];
-        for (int q = 0; q < 2; ++q) p.slab_off[c][q] = (c ? off1 : 0) + (int64_t)q * sw->n_class[c] * W;
+        for (int q = 0; q < NS; ++q) p.slab_off[c][q] = (c ? off1 : 0) + (int64_t)q * sw->n_class[c] * W;
     }
 }
 
-template <int W>
+template <int W, int NS>
 static int sell_to_slab(const SellDev *sw, const float *user_emb, const float *item_emb, float *dst, hipStream_t s) {
     const int n0 = sw->n_class[0], n1 = sw->n_class[1];
-    const int64_t work = (int64_t)(n0 + n1) * (2 * W / 4);
-    hipLaunchKernelGGL(sell_to_slab_kernel<W>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, user_emb, item_emb, (int64_t)n0, dst, sw->orig,
-                       n0, n1, (int64_t)0, (int64_t)n0 * 2 * W);
+    const int64_t work = (int64_t)(n0 + n1) * (NS * W / 4);
+    hipLaunchKernelGGL((sell_to_slab_kernel<W, NS>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, user_emb, item_emb, (int64_t)n0, dst,
+                       sw->orig, n0, n1, (int64_t)0, (int64_t)n0 * NS * W);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -401,21 +427,21 @@ static int sell_to_slab(const SellDev *sw, const float *user_emb, const float *i
 // K launches.  With ent0 the first one gathers E0 where it lies (two row-major tables) and the mean's epilogue reads E0
 // through orig[]: no conversion (7.7 us of a 101 us propagation at the Gowalla shape); without it E0 is converted to slabs
 // in layers[K - 1] first.
-template <int W>
+template <int W, int NS>
 static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
                           hipStream_t s) {
     const SellDev *sw = g->sell;
-    const int64_t nd = g->n_rows * 2 * W;
+    const int64_t nd = g->n_rows * NS * W;
     const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor();
     const bool fac = sell_factored(sw);
     float *e0s = layers + (int64_t)(K - 1) * nd;
     if (!rm) {
-        const int rc = sell_to_slab<W>(sw, user_emb, item_emb, e0s, s);
+        const int rc = sell_to_slab<W, NS>(sw, user_emb, item_emb, e0s, s);
         if (rc) return rc;
     }
     for (int k = 0; k < K; ++k) {
         SellParams p{};
-        sell_fill(sw, W, p);
+        sell_fill(sw, W, NS, p);
         p.rm[0] = p.prm[0] = user_emb;
         p.rm[1] = p.prm[1] = item_emb;
         p.x_rm = (rm && k == 0) ? 1 : 0;
@@ -434,7 +460,7 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
         } else {
             p.ys = layers + (int64_t)k * nd;
         }
-        if (int rc = sell_launch<W>(sw, p, s)) return rc;
+        if (int rc = sell_launch<W, NS>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -442,18 +468,18 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
 // Every layer row-major in the reference's numbering (a caller that reads `layers`: NCL, keep_layers): K launches that gather
 // the previous layer where it lies and write layers[k] through orig[]; the last one adds the mean (and keeps its own layer
 // when asked).  ~2 us per layer slower than the slab chain, no scratch layout.
-template <int W>
+template <int W, int NS>
 static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
                                    bool keep_last, hipStream_t s) {
     const SellDev *sw = g->sell;
-    const int64_t nd = g->n_rows * 2 * W;
+    const int64_t nd = g->n_rows * NS * W;
     const int n0 = sw->n_class[0];
     for (int k = 0; k < K; ++k) {
         SellParams p{};
-        sell_fill(sw, W, p);
+        sell_fill(sw, W, NS, p);
         const float *x = k ? layers + (int64_t)(k - 1) * nd : nullptr;
         p.rm[0] = k ? x : user_emb;
-        p.rm[1] = k ? x + (int64_t)n0 * 2 * W : item_emb;
+        p.rm[1] = k ? x + (int64_t)n0 * NS * W : item_emb;
         p.x_rm = 1;
         p.last = 1;
         if (k == K - 1) {
@@ -470,7 +496,7 @@ static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, co
             p.denom = 1.f;
             p.out = layers + (int64_t)k * nd;
         }
-        if (int rc = sell_launch<W>(sw, p, s)) return rc;
+        if (int rc = sell_launch<W, NS>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -479,20 +505,22 @@ bool sell_rowmajor_applicable(const rbg_graph *g, int d) { return sell_applicabl
 
 int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                           bool keep_last, hipStream_t s) {
-    if (d == 64) return sell_forward_rowmajor_w<32>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
-    if (d == 128) return sell_forward_rowmajor_w<64>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+    const int W = g->sell->W;
+    if (W == 32 && d == 64) return sell_forward_rowmajor_w<32, 2>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+    if (W == 32 && d == 128) return sell_forward_rowmajor_w<32, 4>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+    if (W == 64 && d == 128) return sell_forward_rowmajor_w<64, 2>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 // Y = A X (accumulate: Y += A X), X and Y row-major [N, d] in the reference's numbering: rbg_spmm_f32 over the plan.
-template <int W>
+template <int W, int NS>
 static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumulate, hipStream_t s) {
     const SellDev *sw = g->sell;
     const int n0 = sw->n_class[0];
     SellParams p{};
-    sell_fill(sw, W, p);
+    sell_fill(sw, W, NS, p);
     p.rm[0] = X;
-    p.rm[1] = X + (int64_t)n0 * 2 * W;
+    p.rm[1] = X + (int64_t)n0 * NS * W;
     p.x_rm = 1;
     p.last = 1;
     p.denom = 1.f;
@@ -501,28 +529,32 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumul
         p.n_prev = 1;
         p.prev0_rm = 1;
         p.prm[0] = Y;
-        p.prm[1] = Y + (int64_t)n0 * 2 * W;
+        p.prm[1] = Y + (int64_t)n0 * NS * W;
     }
-    return sell_launch<W>(sw, p, s);
+    return sell_launch<W, NS>(sw, p, s);
 }
 
 int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s) {
-    if (d == 64) return sell_spmm_w<32>(g, X, Y, accumulate, s);
-    if (d == 128) return sell_spmm_w<64>(g, X, Y, accumulate, s);
+    const int W = g->sell->W;
+    if (W == 32 && d == 64) return sell_spmm_w<32, 2>(g, X, Y, accumulate, s);
+    if (W == 32 && d == 128) return sell_spmm_w<32, 4>(g, X, Y, accumulate, s);
+    if (W == 64 && d == 128) return sell_spmm_w<64, 2>(g, X, Y, accumulate, s);
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                  hipStream_t s) {
-    if (d == 64) return sell_forward_w<32>(g, user_emb, item_emb, out_mean, layers, K, s);
-    if (d == 128) return sell_forward_w<64>(g, user_emb, item_emb, out_mean, layers, K, s);
+    const int W = g->sell->W;
+    if (W == 32 && d == 64) return sell_forward_w<32, 2>(g, user_emb, item_emb, out_mean, layers, K, s);
+    if (W == 32 && d == 128) return sell_forward_w<32, 4>(g, user_emb, item_emb, out_mean, layers, K, s);
+    if (W == 64 && d == 128) return sell_forward_w<64, 2>(g, user_emb, item_emb, out_mean, layers, K, s);
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
-template <int W>
+template <int W, int NS>
 static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *grad_e0, int K, hipStream_t s) {
     SellDev *sw = g->sell;
-    const int64_t n = g->n_rows, nd = n * 2 * W;
+    const int64_t n = g->n_rows, nd = n * NS * W;
     // the incoming gradient is gathered and added where it lies unless the result overwrites it (in-place call) or the plan
     // has no row-major entries: then it is converted to slabs first
     const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor() && grad_out != grad_e0;
@@ -543,7 +575,7 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     float *gs = sw->bwd, *ping = sw->bwd + nd, *pong = sw->bwd + 2 * nd;
     const int n0 = sw->n_class[0];
     if (!rm) {
-        const int rc = sell_to_slab<W>(sw, grad_out, grad_out + (int64_t)n0 * 2 * W, gs, s);
+        const int rc = sell_to_slab<W, NS>(sw, grad_out, grad_out + (int64_t)n0 * NS * W, gs, s);
         if (rc) return rc;
     }
     // dE0 = (g + A (g + A (... (g + A g)))) / (K + 1): K launches, every one adds g in its epilogue; the last divides and
@@ -551,9 +583,9 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     const float *x = gs;
     for (int i = 0; i < K; ++i) {
         SellParams p{};
-        sell_fill(sw, W, p);
+        sell_fill(sw, W, NS, p);
         p.rm[0] = p.prm[0] = grad_out;
-        p.rm[1] = p.prm[1] = grad_out + (int64_t)n0 * 2 * W;
+        p.rm[1] = p.prm[1] = grad_out + (int64_t)n0 * NS * W;
         p.x_rm = (rm && i == 0) ? 1 : 0;
         p.compact = (fac && i > 0) ? 1 : 0;
         p.store_scaled = (fac && i < K - 1) ? 1 : 0;
@@ -569,7 +601,7 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
             p.ys = (i & 1) ? pong : ping;
             x = p.ys;
         }
-        if (int rc = sell_launch<W>(sw, p, s)) return rc;
+        if (int rc = sell_launch<W, NS>(sw, p, s)) return rc;
     }
     return RBG_OK;
 }
@@ -577,8 +609,10 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
 // RBG_EUNSUPPORTED = "not this time" (no scratch yet and the stream is capturing, or the allocation failed): the caller
 // runs the binned chain instead.
 int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s) {
-    if (d == 64) return sell_backward_w<32>(g, grad_out, grad_e0, K, s);
-    if (d == 128) return sell_backward_w<64>(g, grad_out, grad_e0, K, s);
+    const int W = g->sell->W;
+    if (W == 32 && d == 64) return sell_backward_w<32, 2>(g, grad_out, grad_e0, K, s);
+    if (W == 32 && d == 128) return sell_backward_w<32, 4>(g, grad_out, grad_e0, K, s);
+    if (W == 64 && d == 128) return sell_backward_w<64, 2>(g, grad_out, grad_e0, K, s);
     return RBG_EUNSUPPORTED;
 }
 
@@ -742,6 +776,6 @@ int rbg_graph_detach_sell(rbg_graph *g) {
     return RBG_OK;
 }
 
-int rbg_graph_has_sell(const rbg_graph *g, int d) { return (g && g->sell && g->sell->W * 2 == d) ? 1 : 0; }
+int rbg_graph_has_sell(const rbg_graph *g, int d) { return (g && g->sell && (g->sell->W * 2 == d || (g->sell->W == 32 && d == 128))) ? 1 : 0; }
 
 }  // extern "C"

@@ -896,7 +896,7 @@ int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
     // mirrors rbg_spmm_f32 / launch_spmm for contiguous, 16-byte aligned fp32 operands in store mode
     if (sell_rowmajor_applicable(g, d)) {
-        snprintf(buf, (size_t)len, "%s", sell_kernel_name(d, false));
+        snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, false));
         return RBG_OK;
     }
     if (d != 32 && d != 64 && d != 128 && d != 256) {
@@ -922,11 +922,11 @@ int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, 
     // mirrors rbg_lightgcn_forward_f32 for one graph and 16-byte aligned operands
     // (the slab chain of a factored plan: its launches after the first — the majority — read compact entries)
     if (sell_applicable(g, d) && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER)) {
-        snprintf(buf, (size_t)len, "%s", sell_kernel_name(d, sell_chain_factored(g)));
+        snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, sell_chain_factored(g)));
         return RBG_OK;
     }
     if (sell_rowmajor_applicable(g, d)) {
-        snprintf(buf, (size_t)len, "%s", sell_kernel_name(d, false));
+        snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, false));
         return RBG_OK;
     }
     return rbg_spmm_kernel_name(g, d, buf, len);

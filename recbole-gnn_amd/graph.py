@@ -229,23 +229,27 @@ class GraphHandle:
     def has_sell(self, d):
         return bool(lib.rbg_graph_has_sell(self.ptr, d))
 
-    def attach_sell(self, d=64, chunk=None):
-        """Plan the column-slab propagation for width d (torch ops on this handle's device CSR) and attach it: from then on
-        ``lightgcn_forward`` runs the slab kernel on this handle (option "sell").  Returns the plan's summary."""
+    def attach_sell(self, d=64, chunk=None, W=32):
+        """Plan the column-slab propagation (torch ops on this handle's device CSR) and attach it: from then on
+        ``lightgcn_forward`` / ``spmm`` run the slab kernel on this handle (option "sell").  A plan of slab width W = 32 serves
+        d = 64 (two slabs, two XCDs per (class, slab) role) AND d = 128 (four slabs, one XCD per role); W = 64 serves d = 128
+        with two slabs (slower: 256-byte slab rows, twice the L2 footprint per XCD).  Returns the plan's summary."""
         from . import sell
         if not self.sell_eligible(d):
             raise ValueError("a SELL plan needs a device graph built from interactions and d in (64, 128)")
         rowptr, col, val = self.device_csr()
         with torch.cuda.device(self.device):
-            plan = sell.build_plan(rowptr, col, val, self.n_users, self.n_rows - self.n_users, W=d // 2,
+            if W not in (32, 64) or d not in (2 * W, 128):
+                raise ValueError(f"slab width {W} does not serve d = {d}")
+            plan = sell.build_plan(rowptr, col, val, self.n_users, self.n_rows - self.n_users, W=W,
                                    chunk=sell.CHUNK if chunk is None else chunk)
             ub = (ctypes.c_int32 * 2)(*plan["unit_base"])
             nu = (ctypes.c_int32 * 2)(*plan["n_units"])
-            check(lib.rbg_graph_attach_sell(self.ptr, d // 2, c_vp(plan["ent"].data_ptr()), plan["n_ent"], c_vp(plan["head"].data_ptr()),
+            check(lib.rbg_graph_attach_sell(self.ptr, W, c_vp(plan["ent"].data_ptr()), plan["n_ent"], c_vp(plan["head"].data_ptr()),
                                             ub, nu, c_vp(plan["orig"].data_ptr())))
             if plan["factors"] is not None:  # val_ij = r_i r_j: the chains read 4-byte entries after their first launch
                 check(lib.rbg_graph_sell_set_factors(self.ptr, c_vp(plan["factors"].data_ptr())))
-        return {"W": d // 2, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1),
+        return {"W": W, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1),
                 "factored": plan["factors"] is not None}
 
     def detach_sell(self):

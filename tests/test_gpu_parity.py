@@ -302,11 +302,11 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         assert "binned" in h.propagation_kernel_name(d) and not h.has_sell(d)
         rbg.set_option("sell", 1)
         info = h.attach_sell(d)
-        assert h.has_sell(d) and not h.has_sell(192 - d) and info["padding"] < 1.2
+        assert h.has_sell(64) and h.has_sell(128) and not h.has_sell(32) and info["padding"] < 1.2  # (W = 32 serves both widths)
         # val_ij = r_i r_j (the symmetric normalisation): the chain's launches after the first read 4-byte entries
-        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}, true>"
+        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true>"
         # a caller that reads the layers gets them row-major: the same kernel gathering / writing the reference's layout
-        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<{d // 2}, false>" == h.spmm_kernel_name(d)
+        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<32, {d // 32}, false>" == h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 0)
         assert "binned" in h.propagation_kernel_name(d, scratch_layers=False) and "binned" in h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 1)
@@ -326,7 +326,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
             close(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0], tol=2e-6)  # (the slab chain runs factored)
             rbg.set_option("sell_factored", 0)
             assert torch.equal(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0])
-            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{d // 2}, false>"
+            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
             rbg.set_option("sell_factored", 1)
             cur = x64
             for j in range(k):
@@ -384,6 +384,11 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         assert "binned" in h.propagation_kernel_name(d)
         close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], binned[2], tol=0)
         rbg.set_option("sell", 1)
+        if d == 128:  # the two-slab form of d = 128 (256-byte slab rows): a plan of W = 64
+            h.attach_sell(128, W=64)
+            assert h.has_sell(128) and not h.has_sell(64) and h.propagation_kernel_name(128) == "sell_spmm_kernel<64, 2, true>"
+            close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
+            close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x64, rowptr, col, val))
         h.detach_sell()
         assert not h.has_sell(d)
         close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
