@@ -202,8 +202,8 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
                            const int32_t *hot_rows, int64_t n_hot, int hot_base);
 int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
-/* Column-slab propagation (r03; csrc/sell.hip): attach a SELL-C-sigma plan of this graph for slab width W (32 serves d = 64,
- * 64 serves d = 128).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
+/* Column-slab propagation (r03; csrc/sell.hip): attach a SELL-C-sigma plan of this graph for slab width W (32 serves d = 64
+ * with two slabs AND d = 128 with four; 64 serves d = 128 with two slabs, slower).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
  * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1); with the layers kept row-major the
  * same kernel serves the other flag combinations, rbg_lightgcn_backward_f32 and rbg_spmm_f32 at that width (option
  * "sell_rowmajor", default 1: E0 / the gradient / X are gathered where they lie through a twin of the entry array in the
