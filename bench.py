@@ -559,8 +559,10 @@ def main():
         # attached by the first propagation) or the binned SpMM kernel
         kernel_name = graph.propagation_kernel_name(d)
         extra["propagation_path"] = {"kernel": kernel_name, "sell_plan_attached": bool(graph.has_sell(d)),
-                                     "launches_per_propagation": (k_layers + 1) if graph.has_sell(d) else k_layers,
-                                     "note": "column-slab path: 1 re-layout of E0 + K slab layers (the last one carries the mean)"
+                                     "launches_per_propagation": k_layers + (1 if graph.has_sell(d) and not rbg.get_option("sell_rowmajor") else 0),
+                                     "note": ("column-slab path: K launches of sell_spmm_kernel — the first gathers E0 where it lies through the "
+                                              "valued entries (instantiation <.., false>), the others read the scaled slabs through 4-byte entries "
+                                              "(<.., true>, the name quoted); the last one carries the mean")
                                      if graph.has_sell(d) else "K binned SpMM launches (the last one carries the mean)"}
         launches_per_step = k_layers
         units_per_step = 1
@@ -822,8 +824,8 @@ def main():
                          "kernel": kernel_name, "avg_launch_us": launch_us,
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean layer duration; duration = HIP-event "
-                                 "time of the timed region / (steps x K layers), so inter-kernel gaps, the column-slab path's E0 "
-                                 "re-layout launch (1/K of it per layer) and (N>1) halo waits all count against the kernel"},
+                                 "time of the timed region / (steps x K layers), so inter-kernel gaps and (N>1) halo waits count against "
+                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r03_bench_kernel_stats.csv"},
             "cpu_baseline": None,
         }
         result.update(extra)
