@@ -49,6 +49,8 @@ static std::atomic<int> g_shard_single_stream{0};
 static std::atomic<int> g_slab{0};
 static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
+static std::atomic<int> g_sell_upw{1};
+int opt_sell_units_per_wave() { return g_sell_upw.load(); }
 static std::atomic<int> g_sell_factored{1};
 int opt_sell_factored() { return g_sell_factored.load(); }
 static std::atomic<int> g_sell_rowmajor{1};
@@ -493,6 +495,11 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_factored = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_units_per_wave")) {
+        if (value < 1 || value > 64) return fail(RBG_EINVAL, "sell_units_per_wave = %lld (1..64)", (long long)value);
+        g_sell_upw = value;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sweep_lean")) {
         g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
@@ -550,6 +557,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_factored")) {
         *value = g_sell_factored.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_units_per_wave")) {
+        *value = g_sell_upw.load();
         return RBG_OK;
     }
     if (!strcmp(key, "col_split")) {

@@ -221,6 +221,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
             }
             acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
         }
+        __syncthreads();  // (a wave that walks on to another wide unit must not overwrite s_wide under wave 0's reads)
     }
     if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0)) {
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
@@ -390,7 +391,8 @@ template <int W, int NS>
 static int sell_launch(const SellDev *sw, const SellParams &p, hipStream_t s) {
     const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
     constexpr int per = NS == 2 ? 8 : 4;  // units per 8 workgroups: two XCDs (NS = 2) or one (NS = 4) per (class, slab), four waves each
-    const unsigned grid = (unsigned)(8 * ((max_units + per - 1) / per));
+    const int64_t upw = std::max(1, opt_sell_units_per_wave());  // > 1: a wave walks units t, t + n_w, ... (fewer, longer waves)
+    const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((max_units + per - 1) / per + upw - 1) / upw));
     if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
