@@ -92,7 +92,13 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   form the six products of order >= 2^-16 on the bf16 matrix cores (fp32-MFMA accuracy at 2.3x its
  *                   rate); 0 = the exact-fp32 MFMA chain
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
- *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192) */
+ *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
+ *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan
+ *                   (rbg_graph_attach_sell) where it applies; 0 = the binned kernel
+ *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)
+ *   "sell_units_per_wave" : units a wave of the column-slab kernel walks (default 1 = one wave per unit; more measured slower)
+ *   "slab"        : measured-and-off r03 variant of the binned kernel over column halves (default 0)
+ *   "shard_single_stream" : 1 = the C-ABI sharded layer packs and exchanges on the caller's stream (capturable); default 0 */
 int rbg_set_option(const char *key, int64_t value);
 int rbg_get_option(const char *key, int64_t *value);
 
