@@ -242,6 +242,89 @@ def lightgcn_forward(graphs, user_w, item_w, n_layers):
     return _LightGCNForward.apply(user_w, item_w, n_layers, *graphs)
 
 
+# ---- independent propagations of one E0 on concurrent HIP streams (SGL: the full graph + two views) ----------------------
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = torch.device(device).index or 0
+    pool = _SIDE_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def _fork_join(fns, device):
+    """Run fns[0] on the current stream and fns[1:] on side streams forked from it by an event, then join.  The callables
+    only LAUNCH on memory the caller allocated on the current stream beforehand (nothing is allocated or freed on a side
+    stream, so the caching allocator — and a HIP-graph capture of the caller — see one stream's worth of lifetimes)."""
+    main = torch.cuda.current_stream(device)
+    side = _side_streams(device, len(fns) - 1)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    for s, fn in zip(side, fns[1:]):
+        s.wait_event(fork)
+        with torch.cuda.stream(s):
+            fn()
+    fns[0]()
+    for s in side:
+        done = torch.cuda.Event()
+        done.record(s)
+        main.wait_event(done)
+
+
+class _LightGCNForwardViews(torch.autograd.Function):
+    """V propagations of the SAME E0 over V graphs (sgl.py:219-221: the full graph and the two augmented views), each a
+    chain of K dependent launches that leaves a third of the GPU idle in its ramps and tails: the chains are
+    issued on V HIP streams and run concurrently, forward and backward.  Values are those of V ``lightgcn_forward`` calls.
+    MEASURED SLOWER than the sequential issue (328 vs 268 us for SGL's three forwards at the Gowalla shape): every launch
+    already covers all XCDs and owns their L2s (one slab of one table each); concurrent launches evict each other.  Kept,
+    tested, off by default (``SGL.concurrent_views``)."""
+
+    @staticmethod
+    def forward(ctx, user_w, item_w, n_layers, *graphs):
+        ctx.graphs, ctx.n_layers, ctx.n_users = graphs, n_layers, user_w.shape[0]
+        user_w, item_w = user_w.contiguous(), item_w.contiguous()
+        n, d = user_w.shape[0] + item_w.shape[0], user_w.shape[1]
+        f = dict(dtype=torch.float32, device=user_w.device)
+        outs = [torch.empty((n, d), **f) for _ in graphs]
+        scratch = [torch.empty((max(n_layers, 1), n, d), **f) for _ in graphs]
+        for g in graphs:
+            if d in (64, 128):
+                _auto_sell(g, d)  # (plans are built on the caller's stream, before the fork)
+        _fork_join([lambda g=g, o=o, l=l: lightgcn_forward_raw(g, user_w, item_w, n_layers, out=o, layers=l)
+                    for g, o, l in zip(graphs, outs, scratch)], user_w.device)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        k_layers, graphs = ctx.n_layers, ctx.graphs
+        live = [(gr.transpose(), g.contiguous()) for gr, g in zip(graphs, grads) if g is not None]
+        if not live:
+            return (None, None, None) + (None,) * len(graphs)
+        dev = live[0][1].device
+        parts = [torch.empty_like(g) for _, g in live]
+        works = [torch.empty_like(g) if k_layers >= 2 else None for _, g in live]
+
+        def chain(gr, g, out, work):
+            arr = (c_vp * 1)(gr.ptr)
+            with torch.cuda.device(dev):
+                check(lib.rbg_lightgcn_backward_f32(arr, 1, c_vp(g.data_ptr()), c_vp(out.data_ptr()),
+                                                    c_vp(work.data_ptr()) if work is not None else None, g.shape[1], k_layers,
+                                                    _stream(g)))
+        _fork_join([lambda gr=gr, g=g, o=o, w=w: chain(gr, g, o, w) for (gr, g), o, w in zip(live, parts, works)], dev)
+        total = parts[0]
+        for p in parts[1:]:
+            total = total + p
+        return (total[:ctx.n_users], total[ctx.n_users:], None) + (None,) * len(graphs)
+
+
+def lightgcn_forward_views(graphs, user_w, item_w, n_layers):
+    """[mean_v] for V single-graph propagations of one E0, differentiable, issued on concurrent streams."""
+    return list(_LightGCNForwardViews.apply(user_w, item_w, n_layers, *graphs))
+
+
 # ---- NGCF ----------------------------------------------------------------------------------
 
 def bignn_conv_raw(graph, x, w1, b1, w2, b2, out=None, leaky_norm=False, slope=0.2):

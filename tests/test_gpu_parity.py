@@ -1865,3 +1865,50 @@ def test_full_size_properties(rbg, cuda, gowalla):
     a2 = a.clone()
     a2[:nu] += 1.0
     assert torch.equal(rbg.ops.spmm_raw(h, a2)[:nu], ya[:nu])
+
+
+def test_sgl_views_on_concurrent_streams(rbg, cuda):
+    """SGL's three propagations of a step (sgl.py:219-221) issued on three HIP streams (ops.lightgcn_forward_views) give the
+    propagations of the three sequential calls bit for bit, the same loss and gradients — eagerly and replayed from a HIP graph
+    (GraphedStep captures the fork / join)."""
+    uid, iid, nu, ni = rbg.synth.make("ml-100k")
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    cfg = {"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 3, "type": "ED", "drop_ratio": 0.1,
+           "ssl_tau": 0.5, "ssl_weight": 0.05, "reg_weight": 1e-4, "require_pow": True}
+    torch.manual_seed(3)
+    model = rbg.SGL(cfg, ds)
+    model.train()
+    gen = torch.Generator().manual_seed(1)
+    batch = {"user_id": torch.randint(1, nu, (256,), generator=gen).to(cuda), "item_id": torch.randint(1, ni, (256,), generator=gen).to(cuda),
+             "neg_item_id": torch.randint(1, ni, (256,), generator=gen).to(cuda)}
+    res = {}
+    for conc in (True, False):
+        model.concurrent_views = conc
+        model.zero_grad(set_to_none=True)
+        loss = model.calculate_loss(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[conc] = (loss.detach().clone(), model.user_embedding.weight.grad.clone(), model.item_embedding.weight.grad.clone())
+    # (the batch-row scatters of the loss use float atomics: their order, not the streams, decides the last bits)
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 1e-6 * abs(float(res[False][0]))
+    close(res[True][1], res[False][1], tol=1e-6)
+    close(res[True][2], res[False][2], tol=1e-6)
+    assert float(res[True][1].abs().max()) > 0
+    views = model.propagate_views()  # (sequential: the loop above ended with concurrent_views = False, the default)
+    model.concurrent_views = True
+    for (ua, ia), (ub, ib) in zip(model.propagate_views(), views):  # the propagations themselves: bit for bit
+        assert torch.equal(ua, ub) and torch.equal(ia, ib)
+    # the captured step: same parameters after two replays with and without the concurrent issue
+    finals = {}
+    for conc in (True, False):
+        torch.manual_seed(3)
+        m = rbg.SGL(cfg, ds)
+        m.sub_graph1, m.sub_graph2 = model.sub_graph1, model.sub_graph2  # the same views
+        m.train()
+        m.concurrent_views = conc
+        step = rbg.GraphedStep(m, batch, lr=1e-3)
+        for _ in range(2):
+            step.step(batch)
+        torch.cuda.synchronize()
+        finals[conc] = m.user_embedding.weight.detach().clone()
+    close(finals[True], finals[False], tol=1e-4)  # (Adam on ~0 gradients: see test_graphed_step above)
