@@ -147,20 +147,21 @@ def _worker(rank, world, port, uid, iid, nu, ni, k_layers, layout, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layout", ["ranges", "striped"])
-def test_two_process_gloo_exchange(ref_inter, layout):
+@pytest.mark.parametrize("layout,world", [("ranges", 2), ("striped", 2), ("striped", 3)])
+def test_two_process_gloo_exchange(ref_inter, layout, world):
+    """(world 3: more than one peer per rank — send / receive lists grouped by owner, uneven splits)"""
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if layout == "striped" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, uid, iid, nu, ni, 3, layout, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if layout == "striped" else 0) + 3 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, uid, iid, nu, ni, 3, layout, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert len(res) == 2
+    assert len(res) == world
     for rank, err, n_halo, n_send in res:
         assert err <= 1e-5, (rank, err)
         assert n_halo > 0 and n_send > 0  # the exchange path really ran
@@ -455,16 +456,16 @@ def _worker_train(rank, world, port, uid, iid, nu, ni, k_layers, layout, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layout", ["ranges", "striped"])
-def test_two_process_gloo_training_step(ref_inter, layout):
+@pytest.mark.parametrize("layout,world", [("ranges", 2), ("striped", 2), ("striped", 4)])
+def test_two_process_gloo_training_step(ref_inter, layout, world):
     """SGL.calculate_loss (sgl.py:211-233: three propagations, BPR, reg, InfoNCE over ALL users / items)
-    and LightGCN.calculate_loss (lightgcn.py:83-110) over two node shards — replicated batch rows by all-reduce, distributed
-    logsumexp, sharded Adam — match the single-device value and dL/dE0 to 1e-5."""
+    and LightGCN.calculate_loss (lightgcn.py:83-110) over two (and four) node shards — replicated batch rows by all-reduce,
+    distributed logsumexp, sharded Adam — match the single-device value and dL/dE0 to 1e-5."""
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + (11 if layout == "striped" else 0)
-    procs = [ctx.Process(target=_worker_train, args=(r, 2, port, uid, iid, nu, ni, 2, layout, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + (11 if layout == "striped" else 0) + 3 * world
+    procs = [ctx.Process(target=_worker_train, args=(r, world, port, uid, iid, nu, ni, 2, layout, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=600)
