@@ -40,7 +40,7 @@ for name in shapes:
         uwd, iwd = uw.to(dev), iw.to(dev)
         o, L = torch.empty(n, d, device=dev), torch.empty(3, n, d, device=dev)
         g.attach_sell(d)
-        for upw in (1, 2, 3, 4, 6, 8):
+        for upw in [int(c) for c in os.environ.get("UPW", "1,2,3,4,6,8").split(",")]:
             rbg.set_option("sell_units_per_wave", upw)
             rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
             err = float(np.abs(o.cpu().numpy() - ref).max())
@@ -48,4 +48,12 @@ for name in shapes:
             rec = {"workload": name, "d": d, "units_per_wave": upw, "prop_us": us, "err": err}
             print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
         rbg.set_option("sell_units_per_wave", 1)
+        for nt in [int(c) for c in os.environ.get("NT", "").split(",") if c]:  # non-temporal epilogue accesses (option "sell_nt")
+            rbg.set_option("sell_nt", nt)
+            rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L); torch.cuda.synchronize()
+            err = float(np.abs(o.cpu().numpy() - ref).max())
+            us = timeit(lambda: rbg.ops.lightgcn_forward_raw(g, uwd, iwd, 3, out=o, layers=L), 100)
+            rec = {"workload": name, "d": d, "sell_nt": nt, "prop_us": us, "err": err}
+            print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
+        rbg.set_option("sell_nt", 0)
         g.detach_sell()

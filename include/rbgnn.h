@@ -97,6 +97,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   (rbg_graph_attach_sell) where it applies; 0 = the binned kernel
  *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)
  *   "sell_units_per_wave" : units a wave of the column-slab kernel walks (default 1 = one wave per unit; more measured slower)
+ *   "sell_nt"     : non-temporal hints in that kernel's epilogue (bit 0 stores, bit 1 the mean's addend loads; default 0, no effect measured)
  *   "slab"        : measured-and-off r03 variant of the binned kernel over column halves (default 0)
  *   "shard_single_stream" : 1 = the C-ABI sharded layer packs and exchanges on the caller's stream (capturable); default 0 */
 int rbg_set_option(const char *key, int64_t value);

@@ -51,6 +51,8 @@ static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
 static std::atomic<int> g_sell_upw{1};
 int opt_sell_units_per_wave() { return g_sell_upw.load(); }
+static std::atomic<int> g_sell_nt{0};
+int opt_sell_nt() { return g_sell_nt.load(); }
 static std::atomic<int> g_sell_factored{1};
 int opt_sell_factored() { return g_sell_factored.load(); }
 static std::atomic<int> g_sell_rowmajor{1};
@@ -495,6 +497,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_factored = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_nt")) {
+        g_sell_nt = (int)(value & 3);
+        return RBG_OK;
+    }
     if (!strcmp(key, "sell_units_per_wave")) {
         if (value < 1 || value > 64) return fail(RBG_EINVAL, "sell_units_per_wave = %lld (1..64)", (long long)value);
         g_sell_upw = value;
@@ -557,6 +563,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_factored")) {
         *value = g_sell_factored.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_nt")) {
+        *value = g_sell_nt.load();
         return RBG_OK;
     }
     if (!strcmp(key, "sell_units_per_wave")) {

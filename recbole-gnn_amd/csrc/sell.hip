@@ -67,6 +67,7 @@ struct SellParams {
     int32_t compact;         // 1: gather through entc (the operand is a scaled slab), acc *= r_i
     int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
     int32_t prev_scaled;     // 1 (last): prev[1..] are scaled slabs: their sum is multiplied by 1 / r_i
+    int32_t nt;              // option "sell_nt"
 };
 
 template <int K>
@@ -92,6 +93,17 @@ struct SellFor<N, N> {
     template <class F>
     static __device__ __forceinline__ void run(F &&) {}
 };
+
+// epilogue accesses with an optional non-temporal hint (option "sell_nt": 1 = stores, 2 = the mean's addend loads)
+__device__ __forceinline__ void st4(float *p, const float4 v, const bool nt) {
+    v4f w = {v.x, v.y, v.z, v.w};
+    if (nt) __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<v4f *>(p) = w;
+}
+__device__ __forceinline__ float4 ld4(const float *p, const bool nt) {
+    const v4f w = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)) : *reinterpret_cast<const v4f *>(p);
+    return make_float4(w.x, w.y, w.z, w.w);
+}
 
 struct SellAcc {
     v2f lo, hi;
@@ -237,32 +249,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
     if (p.last) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.n_prev) sum = *reinterpret_cast<const float4 *>(prev0);
+        const bool ntl = (p.nt & 2) != 0, nts = (p.nt & 1) != 0;
+        if (p.n_prev) sum = ld4(prev0, ntl);
         if (p.prev_scaled) {  // the layers in between are stored scaled: E_k = z_k / r_i
             float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int i = 1; i < p.n_prev; ++i) {
-                const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + o);
+                const float4 q = ld4(p.prev[i] + o, ntl);
                 zs.x += q.x; zs.y += q.y; zs.z += q.z; zs.w += q.w;
             }
             const float ir = p.irs[cbase + row];
             sum.x += zs.x * ir; sum.y += zs.y * ir; sum.z += zs.z * ir; sum.w += zs.w * ir;
         } else {
             for (int i = 1; i < p.n_prev; ++i) {
-                const float4 q = *reinterpret_cast<const float4 *>(p.prev[i] + (p.prev_rm_all ? orm : o));
+                const float4 q = ld4(p.prev[i] + (p.prev_rm_all ? orm : o), ntl);
                 sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
             }
         }
-        if (p.out2) *reinterpret_cast<float4 *>(p.out2 + orm) = y;
+        if (p.out2) st4(p.out2 + orm, y, nts);
         sum.x = (sum.x + y.x) / p.denom; sum.y = (sum.y + y.y) / p.denom;
         sum.z = (sum.z + y.z) / p.denom; sum.w = (sum.w + y.w) / p.denom;
-        *reinterpret_cast<float4 *>(p.out + orm) = sum;
+        st4(p.out + orm, sum, nts);
     } else {
         if (p.n_prev) {  // a step of the backward chain: y = g + A x
             const float4 q = *reinterpret_cast<const float4 *>(prev0);
             y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
         }
         if (p.store_scaled) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }
-        *reinterpret_cast<float4 *>(p.ys + o) = y;
+        st4(p.ys + o, y, (p.nt & 1) != 0);
     }
     }
     }
@@ -406,6 +419,7 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.head = reinterpret_cast<const int4 *>(sw->head);
     p.orig = sw->orig;
     p.entc = sw->entc;
+    p.nt = opt_sell_nt();
     p.rs = sw->rs;
     p.irs = sw->irs;
     for (int c = 0; c < 2; ++c) {
