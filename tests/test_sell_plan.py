@@ -88,3 +88,29 @@ def test_row_factors_are_found_for_the_symmetric_normalisation_only(rbg):
     assert np.abs(r[inv[rows]] * r[inv[col]] - val).max() < 1e-6 * val.max()
     other = val * np.random.default_rng(0).uniform(0.5, 1.5, len(val)).astype(np.float32)
     assert sell.build_plan(t[0], t[1], torch.from_numpy(other), nu, ni, W=32)["factors"] is None
+
+
+def test_hub_row_limit_scales_with_the_graph(rbg):
+    """A row is summed serially by 4 LGW lane-groups: beyond 4 LGW x max(MAX_PIECE, nnz / 8192) entries the planner says
+    NotApplicable (the caller keeps the binned kernel, which splits hub rows over workgroups) — a 20 000-entry hub is refused
+    in a small graph and planned in a large one."""
+    from recbole_gnn_amd import sell
+    lgw = 8
+    hub = sell.MAX_PIECE * 4 * lgw + 1000
+    nu, ni = 400, hub + 10
+
+    def graph(extra):
+        u = np.concatenate([np.full(hub, 1), np.arange(extra) % (nu - 2) + 2]).astype(np.int64)
+        i = np.concatenate([np.arange(hub) + 1, (np.arange(extra) * 7919) % (ni - 1) + 1]).astype(np.int64)
+        key = np.unique(u * ni + i)
+        u, i = key // ni, key % ni
+        rowptr, col, val = C.build_norm_csr(u, i, nu, ni)
+        return [torch.from_numpy(a) for a in (rowptr, col, val)]
+
+    with pytest.raises(sell.NotApplicable):
+        sell.build_plan(*graph(1000), nu, ni, W=32)
+    big = graph(2_400_000)  # nnz / 8192 > hub / 32: the hub's 32 pieces are no longer the longest chain by far
+    assert big[1].numel() // 8192 * 4 * lgw >= hub
+    plan = sell.build_plan(*big, nu, ni, W=32)
+    head = plan["head"].numpy().astype(np.int64)
+    assert ((head[:, 3] >> 16) & 1).sum() >= 4  # the hub is a wide row: four units
