@@ -63,6 +63,20 @@ def test_ops_refuse_host_graphs_and_missing_gpu(rbg):
     assert rc == rbg._lib.RBG_ENODEV
     with pytest.raises((RuntimeError, TypeError)):
         rbg.ops.spmm_raw(g, torch.zeros(4, 4))
+    # the column-slab plan (rbg_graph_attach_sell, r03) is a device structure: a host graph cannot carry one
+    i32 = (ctypes.c_int32 * 2)(0, 0)
+    assert lib.rbg_graph_attach_sell(g.ptr, 32, ctypes.c_void_p(8), 0, ctypes.c_void_p(8), i32, i32, ctypes.c_void_p(8)) == rbg._lib.RBG_ENODEV
+    assert lib.rbg_graph_attach_sell(None, 32, None, 0, None, None, None, None) == rbg._lib.RBG_EINVAL
+    assert lib.rbg_graph_sell_set_factors(g.ptr, ctypes.c_void_p(8)) == rbg._lib.RBG_EINVAL  # no plan attached
+    assert lib.rbg_graph_has_sell(g.ptr, 64) == 0 and lib.rbg_graph_detach_sell(g.ptr) == 0
+    assert not g.sell_eligible(64)
+    with pytest.raises(ValueError):
+        g.attach_sell(64)
+    for key in ("sell", "sell_rowmajor", "sell_factored"):
+        assert rbg.get_option(key) == 1
+    assert rbg.get_option("sell_units_per_wave") == 1 and rbg.get_option("sell_nt") == 0
+    with pytest.raises(rbg.RbgError):
+        rbg.set_option("sell_units_per_wave", 0)
     if rbg.device_count() == 0:
         with pytest.raises(rbg.RbgError) as ei:
             rbg.GraphHandle.from_interactions([1], [1], 2, 2, device=0)
