@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     constexpr bool kFp32Tile = !SPLIT;
     __shared__ __attribute__((aligned(16))) float s_oth[kFp32Tile ? 2 : 1][kFp32Tile ? 32 : 1][kFp32Tile ? LD : 4];
     __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][3][SPLIT ? 32 : 1][SPLIT ? LDH : 8];
+    // (r03) the gradients' second product reads the tile by COLUMN (8 oth rows of one feature column per lane): a transposed
+    // copy of the planes [plane][column][row], row stride 36 bf16 (8-byte aligned, 18 dwords: b64 reads of 32 columns land in
+    // 32 different bank pairs), makes a B fragment two 8-byte reads instead of eight 2-byte reads plus their packing
+    constexpr int LDT = 36;
+    constexpr bool kPlT = SPLIT && GRAD;
+    __shared__ __attribute__((aligned(16))) __bf16 s_plt[kPlT ? 2 : 1][3][kPlT ? NC * 64 : 1][kPlT ? LDT : 4];
     __shared__ float s_coef[2][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                 *reinterpret_cast<bf16x4 *>(&s_pl[buf][0][row][c4]) = (bf16x4){h0[0], h0[1], h1[0], h1[1]};
                 *reinterpret_cast<bf16x4 *>(&s_pl[buf][1][row][c4]) = (bf16x4){m0[0], m0[1], m1[0], m1[1]};
                 *reinterpret_cast<bf16x4 *>(&s_pl[buf][2][row][c4]) = (bf16x4){l0[0], l0[1], l1[0], l1[1]};
+                if constexpr (kPlT) {
+                    s_plt[buf][0][c4 + 0][row] = h0[0], s_plt[buf][0][c4 + 1][row] = h0[1], s_plt[buf][0][c4 + 2][row] = h1[0], s_plt[buf][0][c4 + 3][row] = h1[1];
+                    s_plt[buf][1][c4 + 0][row] = m0[0], s_plt[buf][1][c4 + 1][row] = m0[1], s_plt[buf][1][c4 + 2][row] = m1[0], s_plt[buf][1][c4 + 3][row] = m1[1];
+                    s_plt[buf][2][c4 + 0][row] = l0[0], s_plt[buf][2][c4 + 1][row] = l0[1], s_plt[buf][2][c4 + 2][row] = l1[0], s_plt[buf][2][c4 + 3][row] = l1[1];
+                }
             }
         }
         if (GRAD && p.coef_oth && tid < 32) s_coef[buf][tid] = stage_coef;
@@ -214,14 +225,14 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                 for (int q = 0; q < NC * 2; ++q)
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
+                        // rows rowmap(8 u + j, h), j = 0..7 = 16 u + 4 h + {0..3} and 16 u + 8 + 4 h + {0..3}: two runs of the transposed planes
                         bf16x8 bh, bm, bl;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int orow = lse_rowmap(8 * u + j, h);
-                            bh[j] = s_pl[buf][0][orow][q * 32 + i];
-                            bm[j] = s_pl[buf][1][orow][q * 32 + i];
-                            bl[j] = s_pl[buf][2][orow][q * 32 + i];
-                        }
+                        auto col8 = [&](const int pl) __attribute__((always_inline)) {
+                            const __bf16 *src = &s_plt[buf][pl][q * 32 + i][16 * u + 4 * h];
+                            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(src), hi = *reinterpret_cast<const bf16x4 *>(src + 8);
+                            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        };
+                        bh = col8(0), bm = col8(1), bl = col8(2);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh, g[q], 0, 0, 0);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bl, g[q], 0, 0, 0);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm[u], bm, g[q], 0, 0, 0);
