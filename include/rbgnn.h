@@ -96,6 +96,12 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan
  *                   (rbg_graph_attach_sell) where it applies; 0 = the binned kernel
  *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)
+ *   "sell_auto"   : 1 (default) = rbg_graph_create* plans the column-slab propagation (rbg_graph_plan_sell) for every device graph
+ *                   with a user / item boundary; 0 = no plan until rbg_graph_plan_sell / rbg_graph_attach_sell is called
+ *   "sell_depth"  : gather batches a wave of the column-slab kernel keeps in flight: 1 or 2 (two register sets)
+ *   "sell_class_serial" : -1 (default) = auto (tables beyond ~200 MB), 0 = one launch per layer (user rows on XCDs 0-3, item
+ *                   rows on 4-7), 1 = one launch per row class (all eight XCDs gather from ONE table at a time)
+ *   "fail_alloc_after" : test hook: the (n + 1)-th device allocation of the plan code from now fails once (-1 = off)
  *   "sell_units_per_wave" : units a wave of the column-slab kernel walks (default 1 = one wave per unit; more measured slower)
  *   "sell_nt"     : non-temporal hints in that kernel's epilogue (bit 0 stores, bit 1 the mean's addend loads; default 0, no effect measured)
  *   "slab"        : measured-and-off r03 variant of the binned kernel over column halves (default 0)
@@ -209,8 +215,34 @@ int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_f
                            const int32_t *hot_rows, int64_t n_hot, int hot_base);
 int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
-/* Column-slab propagation (r03; csrc/sell.hip): attach a SELL-C-sigma plan of this graph for slab width W (32 serves d = 64
- * with two slabs AND d = 128 with four; 64 serves d = 128 with two slabs, slower).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
+/* Column-slab propagation: the planner inside the library (r04; csrc/sell_plan.hip).  Cuts this device graph's normalized CSR
+ * (the product of get_norm_adj_mat, recbole_gnn/data/dataset.py:49-79, or of an SGL view rebuild, sgl.py:107-126) into the
+ * SELL-C-sigma form the column-slab kernel reads (slab width W: 32 serves d = 32 / 64 / 128; 64 serves d = 128, slower), on
+ * the device (rocPRIM sorts / scans + one-pass kernels; two small host round trips), then installs it with its derived arrays
+ * (row-major twin, 4-byte offsets column, row factors r = deg^-1/2 when the values are r_i r_j, the CSR position of every
+ * slot).  chunk = entries per piece of a split row (0 = default 128).  rbg_graph_create* calls this itself
+ * for every device graph with a user / item boundary (option "sell_auto", default 1): a caller that binds only
+ * rbg_graph_create + rbg_lightgcn_forward_f32 / rbg_spmm_f32 (layers.py:19-20, lightgcn.py:74-76) runs the column-slab kernel.
+ * RBG_EUNSUPPORTED: the graph is outside what the plan serves (no boundary / not bipartite, a hub row longer than
+ * 4 LGW x max(512, nnz / 8192) entries, a table beyond 32-bit slab offsets); the handle keeps the binned kernel and
+ * rbg_graph_sell_status says why.  Not concurrently with launches on the handle. */
+int rbg_graph_plan_sell(rbg_graph *g, int W, int chunk);
+/* "planned" / "attached" / "view of a planned graph", or the reason the handle has no plan. */
+int rbg_graph_sell_status(const rbg_graph *g, char *buf, int len);
+/* Shape of the installed plan (any pointer may be NULL; n_units = int32[2]); RBG_EINVAL without a plan. */
+int rbg_graph_sell_info(const rbg_graph *g, int *W, int *chunk, int64_t *n_ent, int32_t *n_units, int *factored, int *rowmajor);
+/* The plan's device arrays (read-only, valid while the plan lives): ent [n_ent + 128][2], head [n_units][4], orig [n_rows],
+ * factors [n_rows] or NULL, src [n_ent] (CSR position of every slot, -1 = padding) or NULL. */
+int rbg_graph_sell_arrays(const rbg_graph *g, const int32_t **ent, const int32_t **head, const int32_t **orig, const float **factors,
+                          const int32_t **src);
+/* A re-weighted view (rbg_graph_create_reweighted) of a planned graph borrows the plan and owns a COPY of its valued entries:
+ * call this after every rewrite of the view's `vals` array (NGCF edge dropout, ngcf.py:74-90) — it refreshes the copy on
+ * `stream` (4 bytes read + 4 written per entry).  The view runs the column-slab kernel from its first refresh on; a caller
+ * that never refreshes keeps the binned kernel, which reads `vals` at launch time.  A no-op without a plan. */
+int rbg_graph_refresh_values(rbg_graph *view, void *stream);
+
+/* Column-slab propagation (r03; csrc/sell.hip): attach an EXTERNALLY built SELL-C-sigma plan of this graph for slab width W
+ * (the executable specification recbole-gnn_amd/sell.py; the tests compare rbg_graph_plan_sell with it).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
  * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1); with the layers kept row-major the
  * same kernel serves the other flag combinations, rbg_lightgcn_backward_f32 and rbg_spmm_f32 at that width (option
  * "sell_rowmajor", default 1: E0 / the gradient / X are gathered where they lie through a twin of the entry array in the

@@ -48,6 +48,11 @@ SIGNATURES = {
     "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
     "rbg_graph_attach_sell": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_sell_set_factors": (c_int, [c_vp, c_vp]),
+    "rbg_graph_plan_sell": (c_int, [c_vp, c_int, c_int]),
+    "rbg_graph_sell_status": (c_int, [c_vp, ctypes.c_char_p, c_int]),
+    "rbg_graph_sell_info": (c_int, [c_vp, P(c_int), P(c_int), P(c_i64), P(c_i32), P(c_int), P(c_int)]),
+    "rbg_graph_sell_arrays": (c_int, [c_vp, P(c_vp), P(c_vp), P(c_vp), P(c_vp), P(c_vp)]),
+    "rbg_graph_refresh_values": (c_int, [c_vp, c_vp]),
     "rbg_graph_detach_sell": (c_int, [c_vp]),
     "rbg_graph_has_sell": (c_int, [c_vp, c_int]),
     "rbg_lightgcn_forward_kernel_name": (c_int, [c_vp, c_int, c_u32, ctypes.c_char_p, c_int]),

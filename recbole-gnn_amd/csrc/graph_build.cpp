@@ -57,6 +57,25 @@ static std::atomic<int> g_sell_factored{1};
 int opt_sell_factored() { return g_sell_factored.load(); }
 static std::atomic<int> g_sell_rowmajor{1};
 int opt_sell_rowmajor() { return g_sell_rowmajor.load(); }
+static std::atomic<int> g_sell_auto{1}, g_sell_depth{1}, g_sell_class_serial{-1};
+int opt_sell_auto() { return g_sell_auto.load(); }
+int opt_sell_depth() { return g_sell_depth.load(); }
+int opt_sell_class_serial() { return g_sell_class_serial.load(); }
+// fault injection for the tests: the (n + 1)-th dev_malloc from now fails once (option "fail_alloc_after" = n; -1 = off)
+static std::atomic<int64_t> g_fail_alloc_after{-1};
+hipError_t dev_malloc(void **p, size_t bytes) {
+    int64_t left = g_fail_alloc_after.load();
+    while (left >= 0) {
+        if (g_fail_alloc_after.compare_exchange_weak(left, left - 1)) {
+            if (left == 0) {
+                *p = nullptr;
+                return hipErrorOutOfMemory;
+            }
+            break;
+        }
+    }
+    return hipMalloc(p, bytes ? bytes : 1);
+}
 int opt_slab() { return g_slab.load(); }
 int opt_shard_single_stream() { return g_shard_single_stream.load(); }
 int opt_sweep() { return g_sweep.load(); }
@@ -402,8 +421,29 @@ int upload_graph(rbg_graph *g) {
     return RBG_OK;
 }
 
+// Every device graph with a user / item boundary gets the column-slab plan at creation (option "sell_auto"): the fast kernel is
+// a property of the handle, not of an adapter above the C ABI.  A graph the plan does not serve (a hub row beyond its reach,
+// a table beyond 32-bit offsets, no boundary, out of memory) keeps the binned kernel: the reason is kept for
+// rbg_graph_sell_status, the creation itself never fails because of it.
+static void auto_plan(rbg_graph *g) {
+    if (g->device < 0 || !opt_sell_auto() || !opt_sell()) {
+        g->sell_note = g->device < 0 ? "host graph" : "planning disabled (options \"sell_auto\" / \"sell\")";
+        return;
+    }
+    if (g->n_parts > 1) {
+        g->sell_note = "rows are pinned to XCDs by the caller's community partition";
+        return;
+    }
+    const int rc = plan_sell(g, 32, 0);
+    if (rc != RBG_OK) {
+        if (g->sell_note.empty() || rc != RBG_EUNSUPPORTED) g->sell_note = t_error;
+        clear_error();
+    }
+}
+
 static int finish_create(rbg_graph **out, rbg_graph *g, int rc) {
     if (rc == RBG_OK && g->device >= 0) rc = upload_graph(g);
+    if (rc == RBG_OK) auto_plan(g);
     if (rc != RBG_OK) {
         free_device(g);
         delete g;
@@ -493,6 +533,24 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_rowmajor = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_auto")) {
+        g_sell_auto = value ? 1 : 0;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_depth")) {
+        if (value != 1 && value != 2) return fail(RBG_EINVAL, "sell_depth must be 1 or 2");
+        g_sell_depth = (int)value;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_class_serial")) {
+        if (value < -1 || value > 1) return fail(RBG_EINVAL, "sell_class_serial must be -1 (auto), 0 or 1");
+        g_sell_class_serial = (int)value;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "fail_alloc_after")) {
+        g_fail_alloc_after = value < 0 ? -1 : value;
+        return RBG_OK;
+    }
     if (!strcmp(key, "sell_factored")) {
         g_sell_factored = value ? 1 : 0;
         return RBG_OK;
@@ -559,6 +617,22 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_rowmajor")) {
         *value = g_sell_rowmajor.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_auto")) {
+        *value = g_sell_auto.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_depth")) {
+        *value = g_sell_depth.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_class_serial")) {
+        *value = g_sell_class_serial.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "fail_alloc_after")) {
+        *value = g_fail_alloc_after.load();
         return RBG_OK;
     }
     if (!strcmp(key, "sell_factored")) {
@@ -662,6 +736,7 @@ int rbg_graph_create_partitioned(rbg_graph **out, int64_t n_users, int64_t n_ite
             delete g;
             return rc;
         }
+        auto_plan(g);
         *out = g;
         return RBG_OK;
     }
@@ -1004,6 +1079,10 @@ int rbg_graph_create_reweighted(rbg_graph **out, const rbg_graph *src, const flo
         delete g;
         return fail(RBG_ENOMEM, "device allocation of the view's scratch failed");
     }
+    // the base graph's column-slab plan, with the view's own copy of the valued entries (used from the first
+    // rbg_graph_refresh_values on; until then — and without a plan — the view's launches read `vals` directly)
+    if (root->sell && sell_make_view(g, root) != RBG_OK) clear_error();
+    g->sell_note = g->sell ? "view of a planned graph" : "the base graph has no plan with row-major entries";
     *out = g;
     return RBG_OK;
 }

@@ -43,6 +43,14 @@ int opt_sell_nt();         // sell.hip epilogue: bit 0 = non-temporal stores, bi
 int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
 int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
+int opt_sell_auto();     // rbg_graph_create*: plan the column-slab propagation for every device graph with a user / item boundary
+int opt_sell_depth();    // sell.hip: gather batches a wave keeps in flight (1 or 2)
+int opt_sell_class_serial();  // sell.hip: -1 = auto (by table size), 0 = both row classes in one launch, 1 = one launch per class
+// hipMalloc behind the fault-injection hook of the tests (option "fail_alloc_after"): every allocation of the plan code goes
+// through it, so that a test can walk the error paths one allocation at a time
+hipError_t dev_malloc(void **p, size_t bytes);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc(reinterpret_cast<void **>(p), bytes); }
 int opt_slab();          // rbg_lightgcn_forward_f32: keep the layers as two column slabs (column-half kernel over contiguous half rows)
 int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of the columns
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
@@ -117,11 +125,23 @@ struct SellDev {
     float *rs = nullptr, *irs = nullptr;  // [n_rows] each (one allocation): r_i with val_ij = r_i r_j, and 1 / r_i; the plan's numbering; optional
     int32_t *head = nullptr;         // [n_units][4]
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
+    int32_t *src = nullptr;          // [n_ent]: CSR entry of every slot (-1 = padding): re-weighted views refresh their values through it; optional
     int64_t n_ent = 0;
-    float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain (allocated by the first backward)
+    int64_t first_ent1 = 0;          // first entry of class 1's units
+    int chunk = 0;                   // the planner's chunk (0: an attached plan)
+    bool native = false;             // built by rbg_graph_plan_sell (the values are the graph's own)
+    const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan
+    bool view_fresh = false;         // a view's values have been refreshed at least once (rbg_graph_refresh_values)
+    float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain WITHOUT row-major entries (allocated by the first such backward)
     std::mutex bwd_mutex;
 };
 void free_sell(SellDev *sw);
+// sell.hip: validate the plan in sw (ent / head / orig filled), build the derived arrays (entc, ent0, first-batch blocks) and
+// install it on g (sw is freed on failure)
+int sell_adopt(rbg_graph *g, SellDev *sw, bool validate);
+int sell_set_factors(rbg_graph *g, const float *r);  // rbg_graph_sell_set_factors without the error reset
+// sell_plan.hip
+int plan_sell(rbg_graph *g, int W, int chunk);
 
 }  // namespace rbg
 
@@ -161,7 +181,8 @@ struct rbg_graph {
     const rbg_graph *base = nullptr;  // a re-weighted view (rbg_graph_create_reweighted): structure + plan borrowed from base,
                                       // d_val borrowed from the caller; only partials / counters are its own
     std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
-    rbg::SellDev *sell = nullptr;         // optional SELL plan of the column-slab propagation (rbg_graph_attach_sell)
+    rbg::SellDev *sell = nullptr;         // optional SELL plan of the column-slab propagation (rbg_graph_plan_sell / _attach_sell)
+    std::string sell_note;                // why the handle has no plan (rbg_graph_sell_status)
 };
 
 namespace rbg {
@@ -193,10 +214,16 @@ bool sell_applicable(const rbg_graph *g, int d);
 bool sell_rowmajor_applicable(const rbg_graph *g, int d);  // ... and the plan has its row-major entries (option "sell_rowmajor")
 const char *sell_kernel_name(const rbg_graph *g, int d, bool compact);
 bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact entries from the second launch on
-int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s);  // rbg_spmm_f32 over the plan
-int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
-                          bool keep_last, hipStream_t s);  // every layer row-major (the caller reads `layers`)
-int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s);  // RBG_EUNSUPPORTED: run the binned chain
+// rbg_spmm_f32 / rbg_spmm_noise_f32 (noise != NULL) over the plan
+// (X: row stride ldx floats — d, or a column block of a wider buffer when sell_stride_ok; Y contiguous)
+int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s);
+bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx);
+// every layer row-major (the caller reads `layers`, or one graph per layer)
+int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,
+                          float *layers, int d, int K, bool keep_last, hipStream_t s);
+// RBG_EUNSUPPORTED: run the binned chain.  `work` = the caller's [N, d] scratch of rbg_lightgcn_backward_f32 (K >= 2)
+int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, float *work, int d, int K, hipStream_t s);
+int sell_make_view(rbg_graph *view, const rbg_graph *base);  // a re-weighted view borrows the base graph's plan (RBG_EUNSUPPORTED: none)
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                  hipStream_t s);
 

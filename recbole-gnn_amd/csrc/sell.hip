@@ -46,19 +46,19 @@ struct SellParams {
     const float *xs;         // gathered operand, slab layout
     float *ys;               // result, slab layout (last = 0)
     int64_t slab_off[2][4];  // float offset of (class, slab)
-    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, 2 W]; 0: ys = acc (+ prev[0] if n_prev)
+    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, NS W]; 0: ys = acc (+ prev[0] if n_prev)
     int32_t n_prev;
     const float *prev[RBG_MAX_FUSED_LAYERS + 1];  // slab layout
     float denom;
     float *out;
     const int32_t *orig;     // original node id of (class, internal row)
-    // row-major operands in the REFERENCE's numbering (class 0 = the user table [n_class[0], 2 W], class 1 = the item table):
+    // row-major operands in the REFERENCE's numbering (class 0 = the user table [n_class[0], NS W], class 1 = the item table):
     const v4i *ent0;         // x_rm: the same entries with the column offset = original class-local row * 2 W * 4
     const float *rm[2];      // x_rm: the gathered operand
     const float *prm[2];     // prev0_rm: prev[0] (E0's two tables, the incoming gradient, or Y itself for Y += A X), read through orig[]
     int32_t x_rm;            // 1: the gathered operand is rm[] (entries ent0) — E0 / the incoming gradient is never converted
     int32_t prev0_rm;
-    int32_t prev_rm_all;     // 1: prev[1..] are row-major [N, 2 W] arrays in the reference's numbering as well
+    int32_t prev_rm_all;     // 1: prev[1..] are row-major [N, NS W] arrays in the reference's numbering as well
     float *out2;             // last: also store the layer itself (acc), row-major (RBG_FWD_KEEP_LAST_LAYER)
     // factored chain (val_ij = r_i r_j, the symmetric normalisation): the slabs between the layers hold z = r (.) y, a launch that
     // gathers z reads COLUMN OFFSETS ONLY (entc: 4 bytes per entry instead of 8) and scales its row sums by r_i
@@ -68,6 +68,13 @@ struct SellParams {
     int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
     int32_t prev_scaled;     // 1 (last): prev[1..] are scaled slabs: their sum is multiplied by 1 / r_i
     int32_t nt;              // option "sell_nt"
+    // r04
+    int32_t cls_only;        // -1: XCDs 0-3 run class 0, 4-7 class 1; c: all eight XCDs run class c (one launch per class: the live
+                             // gathered set is ONE table — tables beyond the Infinity Cache)
+    int32_t rm_ld;           // x_rm: floats between the rows of rm[] (NS W when contiguous; a column block of a wider buffer otherwise)
+    int32_t rm_shift;        // x_rm: log2(rm_ld / (2 W)) (-1: rm_ld = W): ent0's offsets are rows of 2 W floats
+    const float *noise;      // last (row-major out): out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps   (simgcl.py:30-33)
+    float eps;
 };
 
 template <int K>
@@ -79,6 +86,9 @@ template <int J>
 __device__ __forceinline__ int ent_col(const v4i &w) { return quad_bcast<J / 2>((J & 1) ? w.z : w.x); }
 template <int J>
 __device__ __forceinline__ float ent_val(const v4i &w) { return __int_as_float(quad_bcast<J / 2>((J & 1) ? w.w : w.y)); }
+// COMPACT: an entry is its column offset alone (the operand is pre-scaled by the column's factor)
+template <int J>
+__device__ __forceinline__ int ent_col(const v2i &w) { return quad_bcast<J / 2>((J & 1) ? w.y : w.x); }
 
 template <int J, int N>
 struct SellFor {
@@ -114,87 +124,199 @@ __device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
     a.hi = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 2, 3), a.hi);
 }
 
-// The gathers of one unit: batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds
-// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  COMPACT: an entry is its column offset alone (the operand is
-// pre-scaled by the column's factor) — 8 bytes per lane and batch, an add instead of an FMA.
-template <int J>
-__device__ __forceinline__ int ent_col(const v2i &w) { return quad_bcast<J / 2>((J & 1) ? w.y : w.x); }
+// Eight gathered rows in registers: named members (an array indexed through lambdas went to scratch: hipcc kept it in memory)
+struct SellRows {
+    v4f r0, r1, r2, r3, r4, r5, r6, r7;
+    template <int J>
+    __device__ __forceinline__ v4f &at() {
+        if constexpr (J == 0) return r0;
+        else if constexpr (J == 1) return r1;
+        else if constexpr (J == 2) return r2;
+        else if constexpr (J == 3) return r3;
+        else if constexpr (J == 4) return r4;
+        else if constexpr (J == 5) return r5;
+        else if constexpr (J == 6) return r6;
+        else return r7;
+    }
+};
 
-template <int W, bool COMPACT, int SHIFT>
-__device__ __forceinline__ void sell_gather(SellAcc &acc, const std::conditional_t<COMPACT, v2i, v4i> *base, const int nc, const int lg,
-                                            const int q4, const __amdgpu_buffer_rsrc_t rs, const int lane_off, const bool shift) {
+// N gathers of one batch: the index broadcast is folded into the address add (v_add_u32_dpp), padding slots read zeros past the table
+template <int J, int N>
+struct SellIssue {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellRows &x, const WT &w, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+        x.template at<J>() = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<J>(w) + lane_off, 0, 0));
+        SellIssue<J + 1, N>::run(x, w, rs, lane_off);
+    }
+};
+template <int N>
+struct SellIssue<N, N> {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellRows &, const WT &, const __amdgpu_buffer_rsrc_t, const int) {}
+};
+template <int J, int N>
+struct SellConsume {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellAcc &acc, SellRows &x, const WT &w) {
+        const v4f v = x.template at<J>();
+        if constexpr (std::is_same<WT, v2i>::value) {
+            acc.lo += __builtin_shufflevector(v, v, 0, 1);
+            acc.hi += __builtin_shufflevector(v, v, 2, 3);
+        } else {
+            fma_row(acc, ent_val<J>(w), v);
+        }
+        SellConsume<J + 1, N>::run(acc, x, w);
+    }
+};
+template <int N>
+struct SellConsume<N, N> {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellAcc &, SellRows &, const WT &) {}
+};
+// n in {2, 4, 6, 8} slots: pairs issued / consumed behind nested tests.  (Four separate bodies selected by n — the r03 form —
+// let hipcc merge their common tails into one block that picks the register by a pointer phi: the rows went to scratch.)
+template <class WT>
+__device__ __forceinline__ void sell_issue_n(const int n, SellRows &x, const WT &w, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+    SellIssue<0, 2>::run(x, w, rs, lane_off);
+    if (n > 2) {
+        SellIssue<2, 4>::run(x, w, rs, lane_off);
+        if (n > 4) {
+            SellIssue<4, 6>::run(x, w, rs, lane_off);
+            if (n > 6) SellIssue<6, 8>::run(x, w, rs, lane_off);
+        }
+    }
+}
+template <class WT>
+__device__ __forceinline__ void sell_consume_n(const int n, SellAcc &acc, SellRows &x, const WT &w) {
+    SellConsume<0, 2>::run(acc, x, w);
+    if (n > 2) {
+        SellConsume<2, 4>::run(acc, x, w);
+        if (n > 4) {
+            SellConsume<4, 6>::run(acc, x, w);
+            if (n > 6) SellConsume<6, 8>::run(acc, x, w);
+        }
+    }
+}
+
+// offsets of a row-major table whose rows are 2 W << sh floats apart (sh = -1: W floats) from ent0's (rows of 2 W floats);
+// padding stays out of range (the shifted padding offset of a 4 W row wrapped into the table for lanes 2.. of a
+// lane-group — harmless only while row 0 is finite)
+template <class WT>
+__device__ __forceinline__ void sell_widen(WT &e, const int sh) {
+    if constexpr (std::is_same<WT, v4i>::value) {
+        if (sh > 0) {
+            if (e.x != kSellPast) e.x <<= sh;
+            if (e.z != kSellPast) e.z <<= sh;
+        } else if (sh < 0) {  // half the stride; kSellPast / 2 is still past every table that has row-major entries
+            e.x >>= 1;
+            e.z >>= 1;
+        }
+    }
+}
+
+// The gathers of one unit: batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds
+// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  DEPTH = 1: one batch of gathers in flight per wave.
+// (r04, measured and removed: the unit's first batch from a fixed-stride block requested together with the header instead of
+// after it — 93.4 vs 93.5 us per propagation at the Gowalla shape, 126.0 vs 126.2 at Yelp2018: the header -> entries round trip
+// is not on the critical path; profiles/r04_launch_forms.jsonl)
+template <int W, int NS, class WT>
+__device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
+                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
     constexpr int LGW = 64 / (W / 4);
-    using WT = std::conditional_t<COMPACT, v2i, v4i>;
     if (nc <= 0) return;
     int sb = min(8, nc);
-    WT w = {};
     // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
+    WT w = {};
     if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
-    auto widen = [&](WT &e) __attribute__((always_inline)) {  // offsets of a row-major table twice as wide (padding stays out of range)
-        if constexpr (SHIFT && !COMPACT) {
-            if (shift) { e.x = (int)((unsigned)e.x << SHIFT); e.z = (int)((unsigned)e.z << SHIFT); }
-        }
-    };
-    widen(w);
+    sell_widen(w, sh);
     for (int k = 0; k < nc; k += 8) {
         const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
         WT wn = {};
-        auto batch = [&](auto nc_) __attribute__((always_inline)) {
-            constexpr int n = decltype(nc_)::value;
-            v4f xv[n];
-            SellFor<0, n>::run([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                xv[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<j>(w) + lane_off, 0, 0));
-            });
-            if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
-            SellFor<0, n>::run([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if constexpr (COMPACT) {
-                    acc.lo += __builtin_shufflevector(xv[j], xv[j], 0, 1);
-                    acc.hi += __builtin_shufflevector(xv[j], xv[j], 2, 3);
-                } else {
-                    fma_row(acc, ent_val<j>(w), xv[j]);
-                }
-            });
-        };
-        if (sb == 8) batch(std::integral_constant<int, 8>{});
-        else if (sb == 6) batch(std::integral_constant<int, 6>{});
-        else if (sb == 4) batch(std::integral_constant<int, 4>{});
-        else batch(std::integral_constant<int, 2>{});
-        widen(wn);
+        SellRows x;
+        sell_issue_n(sb, x, w, rs, lane_off);
+        if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+        sell_consume_n(sb, acc, x, w);
+        sell_widen(wn, sh);
         w = wn;
         sb = sbn;
     }
 }
 
-// W = slab width (32 at d = 64).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows,
-// XCD pair (x & 1) owns slab x & 1 of its class.
-template <int W, int NS, bool COMPACT>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p) {
+// DEPTH = 2: the gathers of batch b + 1 are issued before batch b is consumed (two register sets, the loop unrolled over
+// them): 16 wave-loads in flight per wave instead of 8 draining to 0 between batches (the wave's memory pipe
+// emptied at every s_waitcnt).  Same summation order as DEPTH = 1: bit-identical results.
+template <int W, int NS, class WT>
+__device__ __forceinline__ void sell_gather2(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
+                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
+    constexpr int LGW = 64 / (W / 4);
+    if (nc <= 0) return;
+    const int nb = (nc + 7) >> 3;
+    auto size_of = [&](int b) __attribute__((always_inline)) { return min(8, nc - 8 * b); };
+    auto load = [&](int b, int sz) __attribute__((always_inline)) {
+        WT e = {};
+        if (2 * q4 < sz) e = base[((LGW * 8 * b) >> 1) + lg * (sz >> 1) + q4];
+        sell_widen(e, sh);
+        return e;
+    };
+    int szP = size_of(0), szQ = 0;
+    WT wP = load(0, szP), wQ = {};
+    SellRows xP, xQ;
+    sell_issue_n(szP, xP, wP, rs, lane_off);
+    if (nb > 1) wQ = load(1, size_of(1));
+    for (int b = 0; b < nb; b += 2) {
+        szQ = b + 1 < nb ? size_of(b + 1) : 0;
+        if (szQ) sell_issue_n(szQ, xQ, wQ, rs, lane_off);
+        WT wN = {};
+        if (b + 2 < nb) wN = load(b + 2, size_of(b + 2));
+        sell_consume_n(szP, acc, xP, wP);
+        if (!szQ) break;
+        szP = b + 2 < nb ? size_of(b + 2) : 0;
+        wP = wN;
+        if (szP) sell_issue_n(szP, xP, wP, rs, lane_off);
+        WT wN2 = {};
+        if (b + 3 < nb) wN2 = load(b + 3, size_of(b + 3));
+        sell_consume_n(szQ, acc, xQ, wQ);
+        wQ = wN2;
+        if (!szP) break;
+    }
+}
+
+__device__ __forceinline__ float sell_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
+
+// W = slab width (32).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows (or all eight
+// one class: cls_only), XCD x of a class owns slab x % NS; the 4 / NS (8 / NS) XCDs of a (class, slab) role share its units.
+template <int W, int NS, bool COMPACT, int DEPTH>
+__global__ __launch_bounds__(DEPTH == 2 ? 256 : 1024) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? (COMPACT ? 5 : 4) : 8))) void sell_spmm_kernel(const SellParams p) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
-    constexpr int D = NS * W;     // row width: NS slabs (2: two XCDs share a (class, slab) role; 4: one XCD per role)
+    constexpr int D = NS * W;     // row width: NS slabs
+    using WT = std::conditional_t<COMPACT, v2i, v4i>;
     __shared__ float s_wide[4][W];
-    const int x = blockIdx.x & 7, cls = x >> 2, s = x & (NS - 1), xi = NS == 2 ? (x & 3) >> 1 : 0;
+    const int x = blockIdx.x & 7;
+    const bool serial = p.cls_only >= 0;
+    const int cls = serial ? p.cls_only : x >> 2;
+    const int xr = serial ? x : (x & 3);
+    const int s = xr & (NS - 1), xi = xr / NS;
+    const int XR = (serial ? 8 : 4) / NS;  // XCDs per role
     const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = threadIdx.x >> 6;
     // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
     // scalar-load round trips per wave — n_units, pointers, header, offsets)
-    // (a row-major table is read as its column half s: 128-byte (W = 32) pieces at a 2 W stride — whole L2 lines, the same
+    // (a row-major table is read as its column piece s: 128-byte (W = 32) pieces at an NS W stride — whole L2 lines, the same
     // footprint per XCD as a slab)
     const float *xtab = p.x_rm ? p.rm[1 - cls] + s * W : p.xs + p.slab_off[1 - cls][s];
     const int n_tab = p.n_class[1 - cls];
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, p.x_rm ? (unsigned)n_tab * (D * 4) - s * W * 4 : n_tab * W * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, p.x_rm ? (unsigned)n_tab * (unsigned)(p.rm_ld * 4) - s * W * 4 : n_tab * W * 4,
+                                          0x00020000);
     const int lane_off = sl * 16;
     const unsigned nun = (unsigned)p.n_units[cls];
     const int4 *heads = p.head + p.unit_base[cls];
     const v4i *ents = p.x_rm ? p.ent0 : p.ent;
     const int64_t ybase = p.slab_off[cls][s];
-    constexpr int XR = NS == 2 ? 2 : 1;             // XCDs per role
     const unsigned n_w = (gridDim.x >> 3) * 4 * XR;  // waves of this role: the grid covers the units, so the loop body runs at most once
     for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave))); t < nun; t += n_w) {
     const int4 h = heads[t];
-    const int row0 = h.y, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+    const int row0 = h.y, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
     const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
     // the epilogue's row-indexed scalars are requested before the gathers (they would otherwise be two dependent round trips
     // at the end of the wave: orig[] -> the row-major addend)
@@ -203,14 +325,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
     const int cbase = cls ? p.n_class[0] : 0;
     int node = 0;
     float r_i = 1.f;
-    if constexpr (COMPACT) {  // (the valued instantiation has no register to spare: it asks at the end)
+    if constexpr (COMPACT || DEPTH == 2) {  // (the valued DEPTH-1 instantiation has no register to spare: it asks at the end)
         if (p.last || p.prev0_rm) node = p.orig[cbase + row];
-        r_i = p.rs[cbase + row];
+        if (COMPACT || p.store_scaled) r_i = p.rs[cbase + row];
     }
     SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
-    // (ent0's offsets are rows of 2 W floats: a 4 W row-major operand doubles them)
-    if constexpr (COMPACT) sell_gather<W, true, 0>(acc, reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1), nc, lg, q4, rs, lane_off, false);
-    else sell_gather<W, false, (NS == 4 ? 1 : 0)>(acc, ents + (h.x >> 1), nc, lg, q4, rs, lane_off, p.x_rm != 0);
+    // (ent0's offsets are rows of 2 W floats: a 4 W or a W row-major operand rescales them)
+    const WT *ebase;
+    if constexpr (COMPACT) ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
+    else ebase = ents + (h.x >> 1);
+    const int sh = (!COMPACT && p.x_rm) ? p.rm_shift : 0;
+    if constexpr (DEPTH == 2) sell_gather2<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
+    else sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
     const int parts = 1 << lp;
     if (lp > 0) {
@@ -235,15 +361,33 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
         }
         __syncthreads();  // (a wave that walks on to another wide unit must not overwrite s_wide under wave 0's reads)
     }
-    if ((lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0)) {
+    const bool owner = (lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0);
+    // the noise row's norm spans all NS slabs: every lane-group reads the whole row (all lanes take part in the shuffles)
+    float nsc = 0.f;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.last && p.noise) {
+        if constexpr (!(COMPACT || DEPTH == 2)) node = p.orig[cbase + row];
+        const float *nrow = p.noise + (int64_t)node * D + sl * 4;
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(nrow + q * W);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (q == s) nz = v;
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off);
+        nsc = p.eps / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    if (owner) {
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
-    if constexpr (!COMPACT) {
+    if constexpr (!(COMPACT || DEPTH == 2)) {
         if (p.last || p.prev0_rm) node = p.orig[cbase + row];
     }
     const int64_t orm = (int64_t)node * D + s * W + sl * 4;  // row-major [N, D], the reference's numbering
     const float *prev0 = p.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * D) : p.prev[0] + o;
     float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-    if constexpr (!COMPACT) {
+    if constexpr (!(COMPACT || DEPTH == 2)) {
         if (p.store_scaled) r_i = p.rs[cbase + row];
     }
     if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
@@ -268,6 +412,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void 
         if (p.out2) st4(p.out2 + orm, y, nts);
         sum.x = (sum.x + y.x) / p.denom; sum.y = (sum.y + y.y) / p.denom;
         sum.z = (sum.z + y.z) / p.denom; sum.w = (sum.w + y.w) / p.denom;
+        if (p.noise) {  // (a plain layer: n_prev = 0, denom = 1: sum = y)
+            sum.x = fmaf(sell_sgn(sum.x) * nz.x, nsc, sum.x); sum.y = fmaf(sell_sgn(sum.y) * nz.y, nsc, sum.y);
+            sum.z = fmaf(sell_sgn(sum.z) * nz.z, nsc, sum.z); sum.w = fmaf(sell_sgn(sum.w) * nz.w, nsc, sum.w);
+        }
         st4(p.out + orm, sum, nts);
     } else {
         if (p.n_prev) {  // a step of the backward chain: y = g + A x
@@ -286,9 +434,11 @@ template <int W, int NS>
 __global__ __launch_bounds__(256) void sell_to_slab_kernel(const float *user_emb, const float *item_emb, int64_t n_users, float *dst,
                                                            const int32_t *orig, int n0, int n1, int64_t off0, int64_t off1) {
     constexpr int D = NS * W;
-    const int g = (blockIdx.x * 256 + threadIdx.x) / (D / 4), c4 = ((blockIdx.x * 256 + threadIdx.x) % (D / 4)) * 4;
-    if (g >= n0 + n1) return;
-    const int cls = g >= n0, row = cls ? g - n0 : g;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = gid / (D / 4);
+    const int c4 = (int)(gid % (D / 4)) * 4;
+    if (g >= (int64_t)n0 + n1) return;
+    const int cls = g >= n0, row = (int)(cls ? g - n0 : g);
     const int64_t node = orig[g];
     const float *src = node < n_users ? user_emb + node * D : item_emb + (node - n_users) * D;
     const int s = c4 / W;
@@ -302,10 +452,10 @@ __global__ void sell_check_units_kernel(const int4 *head, int n_units_total, int
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_units_total) return;
     const int4 h = head[t];
-    const int cls = t >= unit_base1, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff, wide = (h.w >> 16) & 1;
+    const int cls = t >= unit_base1, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff, wide = (h.w >> 16) & 1;
     const int n_c = cls ? n1 : n0;
-    bool bad = h.x < 0 || (h.x & 1) || (h.z & 0xffff) != 0 || nc < 0 || (nc & 1) || (int64_t)h.x + (int64_t)lgw * nc > n_ent;
-    bad = bad || lp < 0 || (1 << lp) > lgw || nrows < 0 || nrows > (lgw >> lp) || h.y < 0 || h.y + nrows > n_c;
+    bool bad = h.x < 0 || (h.x & 1) || (h.z & 0xffff) != 0 || (nc & 1) || nc > 65534 || (int64_t)h.x + (int64_t)lgw * nc > n_ent;
+    bad = bad || lp < 0 || (1 << lp) > lgw || nrows < 0 || nrows > (lgw >> lp) || h.y < 0 || h.y + nrows > n_c || (h.w >> 17) != 0;
     const int tl = t - (cls ? unit_base1 : 0);
     if (wide) {  // a wide row = units 4 j .. 4 j + 3 of its class, all flagged, one row
         const int4 h0 = head[t - (tl & 3)];
@@ -345,6 +495,14 @@ __global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int6
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) entc[e] = ent[e].x;
 }
 
+// a re-weighted view's values: ent0v[pos].y = vals[src[pos]]
+__global__ void sell_refresh_values_kernel(int2 *ent, const int32_t *src, const float *vals, int64_t n_ent) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
+        const int sidx = src[e];
+        if (sidx >= 0) ent[e].y = __float_as_int(vals[sidx]);
+    }
+}
+
 // factor check: one thread per (unit, lane-group) walks its slots; every stored value must be r[row] * r[col] to 1e-6 relative
 __global__ void sell_check_factors_kernel(const int2 *ent, const int4 *head, int n_units_total, int unit_base1, int n0, int W, int lgw,
                                           const float *r, int *err) {
@@ -352,7 +510,7 @@ __global__ void sell_check_factors_kernel(const int2 *ent, const int4 *head, int
     const int t = (int)(gid / lgw), lg = (int)(gid % lgw);
     if (t >= n_units_total) return;
     const int4 h = head[t];
-    const int cls = t >= unit_base1, nc = h.z >> 16, lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+    const int cls = t >= unit_base1, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
     const int rr = lg >> lp;
     if (rr >= nrows) return;
     const int rbase = cls ? n0 : 0, cbase = cls ? 0 : n0;
@@ -375,41 +533,70 @@ __global__ void sell_inverse_kernel(const float *r, float *ir, int n) {
 
 void free_sell(SellDev *sw) {
     if (!sw) return;
-    if (sw->ent) (void)hipFree(sw->ent);
+    if (!sw->borrowed) {  // (a view owns its valued row-major entries and their first-batch block only)
+        if (sw->ent) (void)hipFree(sw->ent);
+        if (sw->entc) (void)hipFree(sw->entc);
+        if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
+        if (sw->head) (void)hipFree(sw->head);
+        if (sw->orig) (void)hipFree(sw->orig);
+        if (sw->src) (void)hipFree(sw->src);
+    }
     if (sw->ent0) (void)hipFree(sw->ent0);
-    if (sw->entc) (void)hipFree(sw->entc);
-    if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
-    if (sw->head) (void)hipFree(sw->head);
-    if (sw->orig) (void)hipFree(sw->orig);
     if (sw->bwd) (void)hipFree(sw->bwd);
     delete sw;
 }
 
+static bool sell_width_ok(const SellDev *sw, int d) { return sw->W * 2 == d || (sw->W == 32 && (d == 128 || d == 32)); }
+// a re-weighted view runs its plan only after the caller has refreshed it once (rbg_graph_refresh_values: the plan holds a COPY
+// of the values, the binned kernel reads the caller's array at launch time)
+static bool sell_usable(const rbg_graph *g) { return g && g->sell && (!g->sell->borrowed || g->sell->view_fresh); }
+
 bool sell_applicable(const rbg_graph *g, int d) {
-    return opt_sell() && g && g->sell && (g->sell->W * 2 == d || (g->sell->W == 32 && d == 128));
+    return opt_sell() && sell_usable(g) && !g->sell->borrowed && sell_width_ok(g->sell, d);
 }
 
 // the chains run factored (compact entries from the second launch on) when the plan carries row factors
-static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_sell_factored(); }
+static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_sell_factored() && !sw->borrowed; }
+
+static int sell_depth() { return opt_sell_depth() == 2 ? 2 : 1; }
 
 const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
-    const int W = g->sell->W;
-    if (W == 32 && d == 64) return compact ? "sell_spmm_kernel<32, 2, true>" : "sell_spmm_kernel<32, 2, false>";
-    if (W == 32) return compact ? "sell_spmm_kernel<32, 4, true>" : "sell_spmm_kernel<32, 4, false>";
-    return compact ? "sell_spmm_kernel<64, 2, true>" : "sell_spmm_kernel<64, 2, false>";
+    static thread_local char buf[64];
+    const int W = g->sell->W, ns = d / W;
+    snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", W == 64 ? 1 : sell_depth());
+    return buf;
 }
 bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
 
-template <int W, int NS>
-static int sell_launch(const SellDev *sw, const SellParams &p, hipStream_t s) {
-    const int64_t max_units = std::max(sw->n_units[0], sw->n_units[1]);
-    constexpr int per = NS == 2 ? 8 : 4;  // units per 8 workgroups: two XCDs (NS = 2) or one (NS = 4) per (class, slab), four waves each
+// one launch per row class (all eight XCDs on one table at a time) when the two tables together overflow the Infinity Cache
+static bool sell_class_serial(const SellDev *sw, int NS) {
+    const int o = opt_sell_class_serial();
+    if (o >= 0) return o != 0;
+    return ((int64_t)sw->n_class[0] + sw->n_class[1]) * NS * sw->W * 4 > ((int64_t)200 << 20);
+}
+
+template <int W, int NS, int DEPTH>
+static int sell_launch_d(const SellDev *sw, SellParams &p, hipStream_t s) {
+    const bool serial = sell_class_serial(sw, NS);
     const int64_t upw = std::max(1, opt_sell_units_per_wave());  // > 1: a wave walks units t, t + n_w, ... (fewer, longer waves)
-    const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((max_units + per - 1) / per + upw - 1) / upw));
-    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(256), 0, s, p);
+    for (int c = serial ? 0 : -1; c < (serial ? 2 : 0); ++c) {
+        p.cls_only = c;
+        const int64_t units = c < 0 ? std::max(sw->n_units[0], sw->n_units[1]) : sw->n_units[c];
+        const int per = 4 * ((c < 0 ? 4 : 8) / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
+        const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((units + per - 1) / per + upw - 1) / upw));
+        if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true, DEPTH>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false, DEPTH>), dim3(grid), dim3(256), 0, s, p);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
+}
+
+template <int W, int NS>
+static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
+    if constexpr (W == 32) {
+        if (sell_depth() == 2) return sell_launch_d<W, NS, 2>(sw, p, s);
+    }
+    return sell_launch_d<W, NS, 1>(sw, p, s);
 }
 
 static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
@@ -422,6 +609,9 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.nt = opt_sell_nt();
     p.rs = sw->rs;
     p.irs = sw->irs;
+    p.cls_only = -1;
+    p.rm_ld = NS * W;
+    p.rm_shift = NS == 4 ? 1 : (NS == 1 ? -1 : 0);
     for (int c = 0; c < 2; ++c) {
         p.unit_base[c] = sw->unit_base[c];
         p.n_units[c] = sw->n_units[c];
@@ -481,16 +671,17 @@ static int sell_forward_w(const rbg_graph *g, const float *user_emb, const float
     return RBG_OK;
 }
 
-// Every layer row-major in the reference's numbering (a caller that reads `layers`: NCL, keep_layers): K launches that gather
-// the previous layer where it lies and write layers[k] through orig[]; the last one adds the mean (and keeps its own layer
-// when asked).  ~2 us per layer slower than the slab chain, no scratch layout.
+// Every layer row-major in the reference's numbering (a caller that reads `layers`: NCL, keep_layers; a list of per-layer
+// graphs — SGL's RW views, sgl.py:89-91 — since every plan has its own row numbering): K launches that gather the previous
+// layer where it lies and write layers[k] through orig[]; the last one adds the mean (and keeps its own layer when asked).
+// ~2 us per layer slower than the slab chain, no scratch layout.
 template <int W, int NS>
-static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int K,
-                                   bool keep_last, hipStream_t s) {
-    const SellDev *sw = g->sell;
-    const int64_t nd = g->n_rows * NS * W;
-    const int n0 = sw->n_class[0];
+static int sell_forward_rowmajor_w(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,
+                                   float *layers, int K, bool keep_last, hipStream_t s) {
+    const int64_t nd = graphs[0]->n_rows * NS * W;
     for (int k = 0; k < K; ++k) {
+        const SellDev *sw = graphs[n_graphs == 1 ? 0 : k]->sell;
+        const int n0 = sw->n_class[0];
         SellParams p{};
         sell_fill(sw, W, NS, p);
         const float *x = k ? layers + (int64_t)(k - 1) * nd : nullptr;
@@ -517,30 +708,51 @@ static int sell_forward_rowmajor_w(const rbg_graph *g, const float *user_emb, co
     return RBG_OK;
 }
 
-bool sell_rowmajor_applicable(const rbg_graph *g, int d) { return sell_applicable(g, d) && g->sell->ent0 && opt_sell_rowmajor(); }
+bool sell_rowmajor_applicable(const rbg_graph *g, int d) {
+    return opt_sell() && sell_usable(g) && sell_width_ok(g->sell, d) && g->sell->ent0 && opt_sell_rowmajor();
+}
 
-int sell_forward_rowmajor(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
-                          bool keep_last, hipStream_t s) {
-    const int W = g->sell->W;
-    if (W == 32 && d == 64) return sell_forward_rowmajor_w<32, 2>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
-    if (W == 32 && d == 128) return sell_forward_rowmajor_w<32, 4>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
-    if (W == 64 && d == 128) return sell_forward_rowmajor_w<64, 2>(g, user_emb, item_emb, out_mean, layers, K, keep_last, s);
+#define RBG_SELL_DISPATCH(W_, d_, CALL)                              \
+    do {                                                             \
+        if ((W_) == 32 && (d_) == 64) return CALL(32, 2);            \
+        if ((W_) == 32 && (d_) == 128) return CALL(32, 4);           \
+        if ((W_) == 32 && (d_) == 32) return CALL(32, 1);            \
+        if ((W_) == 64 && (d_) == 128) return CALL(64, 2);           \
+    } while (0)
+
+int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,
+                          float *layers, int d, int K, bool keep_last, hipStream_t s) {
+    const int W = graphs[0]->sell->W;
+    for (int i = 1; i < n_graphs; ++i)
+        if (graphs[i]->sell->W != W) return fail(RBG_EUNSUPPORTED, "per-layer plans of different slab widths");
+#define CALL(W_, NS_) sell_forward_rowmajor_w<W_, NS_>(graphs, n_graphs, user_emb, item_emb, out_mean, layers, K, keep_last, s)
+    RBG_SELL_DISPATCH(W, d, CALL);
+#undef CALL
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 // Y = A X (accumulate: Y += A X), X and Y row-major [N, d] in the reference's numbering: rbg_spmm_f32 over the plan.
+// noise != NULL: Y = A X + sign(A X) * noise / |noise row| * eps (rbg_spmm_noise_f32; simgcl.py:29-33).
 template <int W, int NS>
-static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumulate, hipStream_t s) {
+static int sell_spmm_w(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int accumulate, const float *noise, float eps, hipStream_t s) {
     const SellDev *sw = g->sell;
     const int n0 = sw->n_class[0];
     SellParams p{};
     sell_fill(sw, W, NS, p);
     p.rm[0] = X;
-    p.rm[1] = X + (int64_t)n0 * NS * W;
+    p.rm[1] = X + (int64_t)n0 * ldx;
+    if (ldx != NS * W) {  // X is a column block of a wider row-major buffer (NGCF's concatenated output, ngcf.py:100)
+        p.rm_ld = (int32_t)ldx;
+        int sh = 0;
+        while (((int64_t)2 * W << sh) < ldx) ++sh;
+        p.rm_shift = sh;
+    }
     p.x_rm = 1;
     p.last = 1;
     p.denom = 1.f;
     p.out = Y;
+    p.noise = noise;
+    p.eps = eps;
     if (accumulate) {  // a thread reads the piece of Y it then overwrites
         p.n_prev = 1;
         p.prev0_rm = 1;
@@ -550,45 +762,61 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, float *Y, int accumul
     return sell_launch<W, NS>(sw, p, s);
 }
 
-int sell_spmm(const rbg_graph *g, const float *X, float *Y, int d, int accumulate, hipStream_t s) {
+// the row strides of X the plan's row-major entries reach: d itself, or 2 W << k (k <= 3) while 32-bit offsets hold every row
+bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx) {
+    if (ldx == d) return true;
+    const SellDev *sw = g->sell;
+    const int64_t w2 = 2 * sw->W;
+    if (ldx < d || ldx % w2 || ldx / w2 > 8 || ((ldx / w2) & (ldx / w2 - 1))) return false;
+    return (int64_t)std::max(sw->n_class[0], sw->n_class[1]) * ldx * 4 < kSellPast;
+}
+
+int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s) {
     const int W = g->sell->W;
-    if (W == 32 && d == 64) return sell_spmm_w<32, 2>(g, X, Y, accumulate, s);
-    if (W == 32 && d == 128) return sell_spmm_w<32, 4>(g, X, Y, accumulate, s);
-    if (W == 64 && d == 128) return sell_spmm_w<64, 2>(g, X, Y, accumulate, s);
+#define CALL(W_, NS_) sell_spmm_w<W_, NS_>(g, X, ldx, Y, accumulate, noise, eps, s)
+    RBG_SELL_DISPATCH(W, d, CALL);
+#undef CALL
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 int sell_forward(const rbg_graph *g, const float *user_emb, const float *item_emb, float *out_mean, float *layers, int d, int K,
                  hipStream_t s) {
     const int W = g->sell->W;
-    if (W == 32 && d == 64) return sell_forward_w<32, 2>(g, user_emb, item_emb, out_mean, layers, K, s);
-    if (W == 32 && d == 128) return sell_forward_w<32, 4>(g, user_emb, item_emb, out_mean, layers, K, s);
-    if (W == 64 && d == 128) return sell_forward_w<64, 2>(g, user_emb, item_emb, out_mean, layers, K, s);
+#define CALL(W_, NS_) sell_forward_w<W_, NS_>(g, user_emb, item_emb, out_mean, layers, K, s)
+    RBG_SELL_DISPATCH(W, d, CALL);
+#undef CALL
     return fail(RBG_EUNSUPPORTED, "sell path at d = %d", d);
 }
 
 template <int W, int NS>
-static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *grad_e0, int K, hipStream_t s) {
+static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *grad_e0, float *work, int K, hipStream_t s) {
     SellDev *sw = g->sell;
     const int64_t n = g->n_rows, nd = n * NS * W;
-    // the incoming gradient is gathered and added where it lies unless the result overwrites it (in-place call) or the plan
-    // has no row-major entries: then it is converted to slabs first
-    const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor() && grad_out != grad_e0;
+    // the incoming gradient is gathered and added where it lies unless the plan has no row-major entries: then it is converted
+    // to slabs first
+    const bool rm = sw->ent0 != nullptr && opt_sell_rowmajor() && grad_out != grad_e0 && (K < 2 || work);
     const bool fac = sell_factored(sw);
-    if (!sw->bwd && (K > 1 || !rm)) {  // slab scratch (g, ping, pong), allocated by the first backward on this handle — never inside a capture
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
-        std::lock_guard<std::mutex> lock(sw->bwd_mutex);
+    // Scratch.  With row-major entries the K - 1 slab intermediates alternate between the caller's `work` and grad_e0 itself
+    // (the last launch gathers `work` and writes grad_e0 row-major): nothing of the handle is written, so chains on different
+    // streams do not meet.  Without them: a per-handle scratch (g, ping, pong), allocated by the first such
+    // backward — never inside a capture — and ONE chain at a time on the handle.
+    float *gs = nullptr, *ping = nullptr, *pong = nullptr;
+    if (!rm) {
         if (!sw->bwd) {
-            float *b = nullptr;
-            if (hipMalloc(&b, sizeof(float) * 3 * (size_t)nd) != hipSuccess) {
-                (void)hipGetLastError();
-                return RBG_EUNSUPPORTED;  // the caller runs the binned chain
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
+            std::lock_guard<std::mutex> lock(sw->bwd_mutex);
+            if (!sw->bwd) {
+                float *b = nullptr;
+                if (dev_malloc(&b, sizeof(float) * 3 * (size_t)nd) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return RBG_EUNSUPPORTED;  // the caller runs the binned chain
+                }
+                sw->bwd = b;
             }
-            sw->bwd = b;
         }
+        gs = sw->bwd, ping = sw->bwd + nd, pong = sw->bwd + 2 * nd;
     }
-    float *gs = sw->bwd, *ping = sw->bwd + nd, *pong = sw->bwd + 2 * nd;
     const int n0 = sw->n_class[0];
     if (!rm) {
         const int rc = sell_to_slab<W, NS>(sw, grad_out, grad_out + (int64_t)n0 * NS * W, gs, s);
@@ -614,7 +842,8 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
             p.denom = (float)(K + 1);
             p.out = grad_e0;
         } else {
-            p.ys = (i & 1) ? pong : ping;
+            if (rm) p.ys = ((K - 2 - i) % 2 == 0) ? work : grad_e0;
+            else p.ys = (i & 1) ? pong : ping;
             x = p.ys;
         }
         if (int rc = sell_launch<W, NS>(sw, p, s)) return rc;
@@ -624,127 +853,84 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
 
 // RBG_EUNSUPPORTED = "not this time" (no scratch yet and the stream is capturing, or the allocation failed): the caller
 // runs the binned chain instead.
-int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, int d, int K, hipStream_t s) {
+int sell_backward(const rbg_graph *g, const float *grad_out, float *grad_e0, float *work, int d, int K, hipStream_t s) {
     const int W = g->sell->W;
-    if (W == 32 && d == 64) return sell_backward_w<32, 2>(g, grad_out, grad_e0, K, s);
-    if (W == 32 && d == 128) return sell_backward_w<32, 4>(g, grad_out, grad_e0, K, s);
-    if (W == 64 && d == 128) return sell_backward_w<64, 2>(g, grad_out, grad_e0, K, s);
+#define CALL(W_, NS_) sell_backward_w<W_, NS_>(g, grad_out, grad_e0, work, K, s)
+    RBG_SELL_DISPATCH(W, d, CALL);
+#undef CALL
     return RBG_EUNSUPPORTED;
 }
 
-}  // namespace rbg
-
-using namespace rbg;
-
-extern "C" {
-
-int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
-                          const int32_t *n_units, const int32_t *orig) {
-    clear_error();
-    if (!g) return fail(RBG_EINVAL, "graph is NULL");
-    if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
-    if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan (the plan holds the values)");
-    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
-    if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
-        return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
-    if (!ent || !head || !unit_base || !n_units || !orig || n_ent < 0 || (n_ent & 1)) return fail(RBG_EINVAL, "NULL or malformed plan array");
-    if (g->n_rows > INT32_MAX || n_ent > INT32_MAX - 256) return fail(RBG_EUNSUPPORTED, "graph too large for a SELL plan");
-    const int n0 = (int)g->n_users, n1 = (int)(g->n_rows - g->n_users);
-    if ((int64_t)std::max(n0, n1) * W * 4 >= kSellPast) return fail(RBG_EUNSUPPORTED, "table too large for 32-bit slab offsets");
-    if (unit_base[0] != 0 || n_units[0] < 0 || n_units[1] < 0 || unit_base[1] != n_units[0])
-        return fail(RBG_EINVAL, "unit_base / n_units malformed");
-    int rc = set_device_for(g->device);
-    if (rc) return rc;
-    const int n_total = n_units[0] + n_units[1];
-    // ---- validate on the device (the arrays are device arrays) ---------------------------------------------------------------
+// ---- adoption: validation, derived arrays ---------------------------------------------------------------------------------------
+static int sell_validate(const rbg_graph *g, const SellDev *sw) {
+    const int n0 = sw->n_class[0], n1 = sw->n_class[1], n_total = sw->n_units[0] + sw->n_units[1], lgw = 64 / (sw->W / 4);
     int *d_err = nullptr;
-    RBG_HIP(hipMalloc(&d_err, sizeof(int)));
-    RBG_HIP(hipMemset(d_err, 0, sizeof(int)));
-    const int lgw = 64 / (W / 4);
-    int64_t first_ent1 = n_ent;
-    if (n_units[1] > 0) {
-        int4 h1;
-        if (hipMemcpy(&h1, reinterpret_cast<const int4 *>(head) + n_units[0], sizeof(int4), hipMemcpyDeviceToHost) != hipSuccess) {
-            (void)hipFree(d_err);
-            return fail(RBG_EHIP, "reading the plan failed");
-        }
-        first_ent1 = h1.x;
+    if (dev_malloc(&d_err, sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RBG_ENOMEM, "device allocation failed");
     }
-    if (n_total) hipLaunchKernelGGL(sell_check_units_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(head), n_total,
-                                    n_units[0], n0, n1, n_ent, lgw, d_err);
-    if (n_ent) hipLaunchKernelGGL(sell_check_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(ent), n_ent, first_ent1, n0,
-                                  n1, W, d_err);
-    hipLaunchKernelGGL(sell_check_orig_kernel, dim3((unsigned)((g->n_rows + 255) / 256)), dim3(256), 0, 0, orig, (int)g->n_rows, n0, n0, d_err);
+    hipError_t ce = hipMemset(d_err, 0, sizeof(int));
+    if (n_total) hipLaunchKernelGGL(sell_check_units_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head),
+                                    n_total, sw->n_units[0], n0, n1, sw->n_ent, lgw, d_err);
+    if (sw->n_ent) hipLaunchKernelGGL(sell_check_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->n_ent,
+                                      sw->first_ent1, n0, n1, sw->W, d_err);
+    hipLaunchKernelGGL(sell_check_orig_kernel, dim3((unsigned)((g->n_rows + 255) / 256)), dim3(256), 0, 0, sw->orig, (int)g->n_rows, n0, n0, d_err);
     int h_err = 0;
-    const hipError_t ce = hipMemcpy(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost);
+    if (ce == hipSuccess) ce = hipMemcpy(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipFree(d_err);
     if (ce != hipSuccess) return fail(RBG_EHIP, "plan validation failed to run: %s", hipGetErrorString(ce));
     if (h_err > 0) return fail(RBG_EINVAL, "SELL plan: unit %d is out of range or misaligned", h_err - 1);
     if (h_err == -1) return fail(RBG_EINVAL, "SELL plan: an entry's column offset is out of range");
     if (h_err == -2) return fail(RBG_EINVAL, "SELL plan: orig[] is out of range or crosses the user / item boundary");
-    // ---- adopt copies ---------------------------------------------------------------------------------------------------------
-    if ((rc = rbg_graph_detach_sell(g))) return rc;
-    SellDev *sw = new (std::nothrow) SellDev();
-    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
-    sw->W = W;
-    sw->n_ent = n_ent;
-    for (int c = 0; c < 2; ++c) {
-        sw->unit_base[c] = unit_base[c];
-        sw->n_units[c] = n_units[c];
+    return RBG_OK;
+}
+
+// optional array: a failed allocation leaves the plan without it (and the error state clean)
+template <class T>
+static bool sell_opt_alloc(T **p, size_t bytes, bool zero) {
+    *p = nullptr;
+    if (dev_malloc(p, bytes) != hipSuccess || (zero && hipMemset(*p, 0, bytes) != hipSuccess)) {
+        (void)hipGetLastError();
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+        return false;
     }
-    sw->n_class[0] = n0;
-    sw->n_class[1] = n1;
-    const size_t ent_bytes = sizeof(int32_t) * 2 * (size_t)(n_ent + 128), head_bytes = sizeof(int32_t) * 4 * (size_t)std::max(n_total, 1);
-    bool ok = hipMalloc(&sw->ent, ent_bytes) == hipSuccess && hipMalloc(&sw->head, head_bytes) == hipSuccess &&
-              hipMalloc(&sw->orig, sizeof(int32_t) * (size_t)g->n_rows) == hipSuccess;
-    ok = ok && hipMemset(sw->ent, 0, ent_bytes) == hipSuccess;  // (the 128 entries of slack a wave's last 16-byte loads may touch)
-    ok = ok && hipMemcpy(sw->ent, ent, sizeof(int32_t) * 2 * (size_t)n_ent, hipMemcpyDeviceToDevice) == hipSuccess;
-    ok = ok && (n_total == 0 || hipMemcpy(sw->head, head, sizeof(int32_t) * 4 * (size_t)n_total, hipMemcpyDeviceToDevice) == hipSuccess);
-    ok = ok && hipMemcpy(sw->orig, orig, sizeof(int32_t) * (size_t)g->n_rows, hipMemcpyDeviceToDevice) == hipSuccess;
-    if (!ok) {
+    return true;
+}
+
+int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
+    int rc = validate ? sell_validate(g, sw) : RBG_OK;
+    if (rc == RBG_OK) rc = rbg_graph_detach_sell(g);
+    if (rc) {
         free_sell(sw);
-        return fail(RBG_ENOMEM, "device allocation / copy of the SELL plan failed");
+        return rc;
     }
+    const int n0 = sw->n_class[0], n1 = sw->n_class[1], W = sw->W;
+    const int64_t n_ent = sw->n_ent;
     // the offsets column alone (the factored chain's launches read 4 bytes per entry)
-    {
-        const size_t cb = sizeof(int32_t) * (size_t)(n_ent + 256);
-        if (hipMalloc(&sw->entc, cb) == hipSuccess && hipMemset(sw->entc, 0, cb) == hipSuccess) {
-            if (n_ent) hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc,
-                                          n_ent);
-        } else {
-            (void)hipGetLastError();
-            if (sw->entc) (void)hipFree(sw->entc);
-            sw->entc = nullptr;
-        }
-    }
-    // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per propagation)
-    if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast) {
-        if (hipMalloc(&sw->ent0, ent_bytes) == hipSuccess && hipMemset(sw->ent0, 0, ent_bytes) == hipSuccess) {
-            if (n_ent) hipLaunchKernelGGL(sell_first_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent),
-                                          reinterpret_cast<int2 *>(sw->ent0), n_ent, first_ent1, sw->orig, n0, W);
-            if (hipDeviceSynchronize() != hipSuccess) {
-                free_sell(sw);
-                return fail(RBG_EHIP, "building the row-major entries failed");
-            }
-        } else {
-            (void)hipGetLastError();
-            if (sw->ent0) (void)hipFree(sw->ent0);
-    if (sw->entc) (void)hipFree(sw->entc);
-    if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
-            sw->ent0 = nullptr;
-        }
+    if (sell_opt_alloc(&sw->entc, sizeof(int32_t) * (size_t)(n_ent + 256), true) && n_ent)
+        hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc, n_ent);
+    // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per
+    // propagation).  A failed allocation leaves the plan without the twin — and touches nothing else (r03: this branch freed
+    // entc and rs without clearing them)
+    if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast && sell_opt_alloc(&sw->ent0, sizeof(int32_t) * 2 * (size_t)(n_ent + 128), true) && n_ent)
+        hipLaunchKernelGGL(sell_first_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent),
+                           reinterpret_cast<int2 *>(sw->ent0), n_ent, sw->first_ent1, sw->orig, n0, W);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+        free_sell(sw);
+        return fail(RBG_EHIP, "building the derived arrays of the SELL plan failed");
     }
     g->sell = sw;
     return RBG_OK;
 }
 
-int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
-    clear_error();
+int sell_set_factors(rbg_graph *g, const float *r) {
     if (!g || !g->sell) return fail(RBG_EINVAL, "no SELL plan attached");
     if (!r) return fail(RBG_EINVAL, "r is NULL");
     int rc = set_device_for(g->device);
     if (rc) return rc;
     SellDev *sw = g->sell;
+    if (sw->borrowed) return fail(RBG_EUNSUPPORTED, "a re-weighted view has no row factors");
     if (!sw->entc) return fail(RBG_EUNSUPPORTED, "the plan has no compact entries");
     const int n = (int)g->n_rows, n_total = sw->n_units[0] + sw->n_units[1], lgw = 64 / (sw->W / 4);
     (void)hipDeviceSynchronize();  // (not concurrently with launches on this handle)
@@ -752,7 +938,7 @@ int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
     sw->rs = sw->irs = nullptr;
     float *buf = nullptr;
     int *d_err = nullptr;
-    if (hipMalloc(&buf, sizeof(float) * 2 * (size_t)n) != hipSuccess || hipMalloc(&d_err, sizeof(int)) != hipSuccess) {
+    if (dev_malloc(&buf, sizeof(float) * 2 * (size_t)n) != hipSuccess || dev_malloc(&d_err, sizeof(int)) != hipSuccess) {
         (void)hipGetLastError();
         if (buf) (void)hipFree(buf);
         return fail(RBG_ENOMEM, "device allocation of the row factors failed");
@@ -778,6 +964,93 @@ int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
     return RBG_OK;
 }
 
+// A re-weighted view of a planned graph: the structure (units, offsets, numbering) is the base's; the view owns a copy of the
+// row-major entries whose values rbg_graph_refresh_values rewrites from the caller's array through src[].
+int sell_make_view(rbg_graph *view, const rbg_graph *base) {
+    const SellDev *b = base->sell;
+    if (!b || b->borrowed || !b->ent0 || !b->src) return RBG_EUNSUPPORTED;
+    SellDev *sw = new (std::nothrow) SellDev();
+    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
+    sw->borrowed = b;
+    sw->W = b->W;
+    sw->chunk = b->chunk;
+    sw->n_ent = b->n_ent;
+    sw->first_ent1 = b->first_ent1;
+    for (int c = 0; c < 2; ++c) sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c];
+    sw->ent = b->ent, sw->entc = b->entc, sw->head = b->head, sw->orig = b->orig, sw->src = b->src;
+    const size_t bytes = sizeof(int32_t) * 2 * (size_t)(b->n_ent + 128);
+    if (dev_malloc(&sw->ent0, bytes) != hipSuccess || hipMemcpy(sw->ent0, b->ent0, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        free_sell(sw);
+        return RBG_EUNSUPPORTED;  // (the view keeps the binned kernel)
+    }
+    view->sell = sw;
+    return RBG_OK;
+}
+
+}  // namespace rbg
+
+using namespace rbg;
+
+extern "C" {
+
+int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
+                          const int32_t *n_units, const int32_t *orig) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
+    if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan of its own (it borrows its base graph's)");
+    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
+    if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
+        return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
+    if (!ent || !head || !unit_base || !n_units || !orig || n_ent < 0 || (n_ent & 1)) return fail(RBG_EINVAL, "NULL or malformed plan array");
+    if (g->n_rows > INT32_MAX || n_ent > INT32_MAX - 256) return fail(RBG_EUNSUPPORTED, "graph too large for a SELL plan");
+    const int n0 = (int)g->n_users, n1 = (int)(g->n_rows - g->n_users);
+    if ((int64_t)std::max(n0, n1) * W * 4 >= kSellPast) return fail(RBG_EUNSUPPORTED, "table too large for 32-bit slab offsets");
+    if (unit_base[0] != 0 || n_units[0] < 0 || n_units[1] < 0 || unit_base[1] != n_units[0])
+        return fail(RBG_EINVAL, "unit_base / n_units malformed");
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    const int n_total = n_units[0] + n_units[1];
+    int64_t first_ent1 = n_ent;
+    if (n_units[1] > 0) {
+        int4 h1;
+        if (hipMemcpy(&h1, reinterpret_cast<const int4 *>(head) + n_units[0], sizeof(int4), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(RBG_EHIP, "reading the plan failed");
+        first_ent1 = h1.x;
+    }
+    // ---- a copy of the caller's arrays, validated on the device before it is adopted ------------------------------------------------
+    SellDev *sw = new (std::nothrow) SellDev();
+    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
+    sw->W = W;
+    sw->n_ent = n_ent;
+    sw->first_ent1 = first_ent1;
+    for (int c = 0; c < 2; ++c) {
+        sw->unit_base[c] = unit_base[c];
+        sw->n_units[c] = n_units[c];
+    }
+    sw->n_class[0] = n0;
+    sw->n_class[1] = n1;
+    const size_t ent_bytes = sizeof(int32_t) * 2 * (size_t)(n_ent + 128), head_bytes = sizeof(int32_t) * 4 * (size_t)std::max(n_total, 1);
+    bool ok = dev_malloc(&sw->ent, ent_bytes) == hipSuccess && dev_malloc(&sw->head, head_bytes) == hipSuccess &&
+              dev_malloc(&sw->orig, sizeof(int32_t) * (size_t)g->n_rows) == hipSuccess;
+    ok = ok && hipMemset(sw->ent, 0, ent_bytes) == hipSuccess;  // (the 128 entries of slack a wave's last 16-byte loads may touch)
+    ok = ok && hipMemcpy(sw->ent, ent, sizeof(int32_t) * 2 * (size_t)n_ent, hipMemcpyDeviceToDevice) == hipSuccess;
+    ok = ok && (n_total == 0 || hipMemcpy(sw->head, head, sizeof(int32_t) * 4 * (size_t)n_total, hipMemcpyDeviceToDevice) == hipSuccess);
+    ok = ok && hipMemcpy(sw->orig, orig, sizeof(int32_t) * (size_t)g->n_rows, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        free_sell(sw);
+        return fail(RBG_ENOMEM, "device allocation / copy of the SELL plan failed");
+    }
+    return sell_adopt(g, sw, true);
+}
+
+int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
+    clear_error();
+    return sell_set_factors(g, r);
+}
+
 int rbg_graph_detach_sell(rbg_graph *g) {
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->sell) {
@@ -792,6 +1065,51 @@ int rbg_graph_detach_sell(rbg_graph *g) {
     return RBG_OK;
 }
 
-int rbg_graph_has_sell(const rbg_graph *g, int d) { return (g && g->sell && (g->sell->W * 2 == d || (g->sell->W == 32 && d == 128))) ? 1 : 0; }
+int rbg_graph_has_sell(const rbg_graph *g, int d) { return (sell_usable(g) && sell_width_ok(g->sell, d)) ? 1 : 0; }
+
+int rbg_graph_sell_info(const rbg_graph *g, int *W, int *chunk, int64_t *n_ent, int32_t *n_units, int *factored, int *rowmajor) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (!g->sell) return fail(RBG_EINVAL, "no SELL plan on this handle");
+    const SellDev *sw = g->sell;
+    if (W) *W = sw->W;
+    if (chunk) *chunk = sw->chunk;
+    if (n_ent) *n_ent = sw->n_ent;
+    if (n_units) n_units[0] = sw->n_units[0], n_units[1] = sw->n_units[1];
+    if (factored) *factored = (sw->rs && sw->entc && !sw->borrowed) ? 1 : 0;
+    if (rowmajor) *rowmajor = sw->ent0 ? 1 : 0;
+    return RBG_OK;
+}
+
+int rbg_graph_sell_arrays(const rbg_graph *g, const int32_t **ent, const int32_t **head, const int32_t **orig, const float **factors,
+                          const int32_t **src) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (!g->sell) return fail(RBG_EINVAL, "no SELL plan on this handle");
+    if (ent) *ent = g->sell->ent;
+    if (head) *head = g->sell->head;
+    if (orig) *orig = g->sell->orig;
+    if (factors) *factors = g->sell->rs;
+    if (src) *src = g->sell->src;
+    return RBG_OK;
+}
+
+int rbg_graph_refresh_values(rbg_graph *g, void *stream) {
+    clear_error();
+    if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    if (!g->base) return fail(RBG_EINVAL, "rbg_graph_refresh_values: not a re-weighted view");
+    SellDev *sw = g->sell;
+    if (!sw || !sw->borrowed) return RBG_OK;  // no plan on the base graph: the view's launches read the caller's array directly
+    int rc = set_device_for(g->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (sw->n_ent) {
+        hipLaunchKernelGGL(sell_refresh_values_kernel, dim3((unsigned)std::min<int64_t>((sw->n_ent + 255) / 256, 16384)), dim3(256), 0, s,
+                           reinterpret_cast<int2 *>(sw->ent0), sw->src, g->d_val, sw->n_ent);
+        RBG_HIP(hipGetLastError());
+    }
+    sw->view_fresh = true;
+    return RBG_OK;
+}
 
 }  // extern "C"

@@ -871,6 +871,10 @@ static int launch_slab(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
 
 int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int64_t ldy, int d, int accumulate,
                  hipStream_t s) {
+    // contiguous operands on a planned handle: the column-slab kernel over row-major tables (every caller of the plain product
+    // comes through here: rbg_spmm_f32, the NGCF layer and its backward, the sharded interior / halo blocks)
+    if (ldy == d && sell_rowmajor_applicable(g, d) && sell_stride_ok(g, d, ldx) && aligned16(X) && aligned16(Y) && g->n_rows > 0)
+        return sell_spmm(g, X, ldx, Y, d, accumulate, nullptr, 0.f, s);
     SpmmParams p{};
     p.x = make_src(X, X, 0, ldx);
     p.y = Y;
@@ -962,7 +966,6 @@ int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumu
     if (!X || !Y) return fail(RBG_EINVAL, "X or Y is NULL");
     if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
     if ((rc = set_device_for(g->device))) return rc;
-    if (sell_rowmajor_applicable(g, d) && aligned16(X) && aligned16(Y)) return sell_spmm(g, X, Y, d, accumulate, (hipStream_t)stream);
     return spmm_strided(g, X, d, Y, d, d, accumulate, (hipStream_t)stream);
 }
 
@@ -1022,6 +1025,8 @@ int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float
     if (!X || !Y || !noise) return fail(RBG_EINVAL, "NULL pointer");
     if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
     if ((rc = set_device_for(g->device))) return rc;
+    if (sell_rowmajor_applicable(g, d) && aligned16(X) && aligned16(Y) && aligned16(noise))
+        return sell_spmm(g, X, d, Y, d, 0, noise, eps, (hipStream_t)stream);
     SpmmParams p{};
     p.x = make_src(X, X, 0, d);
     p.y = Y;
@@ -1076,13 +1081,15 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     // last layer's epilogue writes the mean row-major.  layers[K-1] holds E0's slabs, layers[k] layer k + 1's.
     // Column-slab propagation over an attached SELL plan (sell.hip): one graph for every layer (a plan carries its own row
     // numbering), the caller does not read `layers` (RBG_FWD_LAYERS_SCRATCH), the mean leaves row-major as always.
-    if (n_graphs == 1 && sell_applicable(g0, d) && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) &&
+    // (a plan splits the rows at ITS boundary: a CSR-built handle does not pin n_users, so the caller's must agree)
+    if (n_graphs == 1 && sell_applicable(g0, d) && g0->sell->n_class[0] == n_users && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) &&
         !(flags & RBG_FWD_KEEP_LAST_LAYER) && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean))
         return sell_forward(g0, user_emb, item_emb, out_mean, layers, d, K, s);
     // the same plan with every layer row-major where the caller reads them (NCL, keep_layers)
-    if (n_graphs == 1 && sell_rowmajor_applicable(g0, d) && fused && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) &&
-        aligned16(out_mean))
-        return sell_forward_rowmajor(g0, user_emb, item_emb, out_mean, layers, d, K, (flags & RBG_FWD_KEEP_LAST_LAYER) != 0, s);
+    // ... and with one graph per layer (SGL's RW views, sgl.py:89-91: every plan has its own row numbering)
+    bool all_rm = fused && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
+    for (int i = 0; i < n_graphs && all_rm; ++i) all_rm = sell_rowmajor_applicable(graphs[i], d) && graphs[i]->sell->n_class[0] == n_users;
+    if (all_rm) return sell_forward_rowmajor(graphs, n_graphs, user_emb, item_emb, out_mean, layers, d, K, (flags & RBG_FWD_KEEP_LAST_LAYER) != 0, s);
     bool slab = opt_slab() && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER) &&
                 aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
     for (int i = 0; i < n_graphs && slab; ++i) slab = slab_eligible(graphs[i], d);
@@ -1172,7 +1179,7 @@ int rbg_lightgcn_backward_f32(const rbg_graph *const *graphs, int n_graphs, cons
     // the column-slab chain (sell.hip) when the handle carries a plan: one graph, symmetric (the caller passes the transposed
     // handles — the handle itself for a graph built from interactions)
     if (n_graphs == 1 && sell_applicable(graphs[0], d) && aligned16(grad_out) && aligned16(grad_e0)) {
-        rc = sell_backward(graphs[0], grad_out, grad_e0, d, K, s);
+        rc = sell_backward(graphs[0], grad_out, grad_e0, work, d, K, s);
         if (rc != RBG_EUNSUPPORTED) return rc;
         clear_error();
     }

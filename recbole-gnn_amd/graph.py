@@ -218,29 +218,73 @@ class GraphHandle:
         check(lib.rbg_lightgcn_forward_kernel_name(self.ptr, d, flags, buf, 128))
         return buf.value.decode()
 
-    # ---- column-slab propagation (sell.py / csrc/sell.hip) -------------------------------------------------------------
-    SELL_AUTO_MAX_ROWS = 4_000_000  # auto-attach (ops.lightgcn_forward) below this size; larger graphs: call attach_sell()
-
+    # ---- column-slab propagation (csrc/sell_plan.hip + csrc/sell.hip) -----------------------------------------------------
     def sell_eligible(self, d):
-        """A SELL plan serves width d on this handle: built from interactions (a user / item boundary), on a device, d = 64."""
+        """A SELL plan can serve width d on this handle: built from interactions (a user / item boundary), on a device."""
         return (self.is_device and self.n_users is not None and 0 < self.n_users < self.n_rows and self.n_rows == self.n_cols
-                and d in (64, 128) and not getattr(self, "_is_view", False))
+                and d in (32, 64, 128) and not getattr(self, "_is_view", False))
 
     def has_sell(self, d):
         return bool(lib.rbg_graph_has_sell(self.ptr, d))
 
-    def attach_sell(self, d=64, chunk=None, W=32):
-        """Plan the column-slab propagation (torch ops on this handle's device CSR) and attach it: from then on
-        ``lightgcn_forward`` / ``spmm`` run the slab kernel on this handle (option "sell").  A plan of slab width W = 32 serves
-        d = 64 (two slabs, two XCDs per (class, slab) role) AND d = 128 (four slabs, one XCD per role); W = 64 serves d = 128
-        with two slabs (slower: 256-byte slab rows, twice the L2 footprint per XCD).  Returns the plan's summary."""
-        from . import sell
+    def sell_status(self):
+        """"planned" / "attached" / "view of a planned graph", or the reason this handle runs the binned kernel."""
+        buf = ctypes.create_string_buffer(256)
+        check(lib.rbg_graph_sell_status(self.ptr, buf, 256))
+        return buf.value.decode()
+
+    def sell_info(self):
+        """Shape of the installed plan (raises without one)."""
+        W, chunk, n_ent, fac, rm = c_int(), c_int(), c_i64(), c_int(), c_int()
+        nu = (ctypes.c_int32 * 2)()
+        check(lib.rbg_graph_sell_info(self.ptr, ctypes.byref(W), ctypes.byref(chunk), ctypes.byref(n_ent), nu, ctypes.byref(fac),
+                                      ctypes.byref(rm)))
+        return {"W": W.value, "chunk": chunk.value, "n_ent": n_ent.value, "n_units": [nu[0], nu[1]], "factored": bool(fac.value),
+                "rowmajor": bool(rm.value), "padding": n_ent.value / max(self.nnz, 1)}
+
+    def sell_arrays(self):
+        """The installed plan's device arrays as torch tensors that alias them (read-only by contract; they keep this handle
+        alive): ent [n_ent, 2], head [n_units, 4], orig [N] (int32), factors [N] float32 or None, src [n_ent] int32 or None."""
+        info = self.sell_info()
+        ptrs = [c_vp() for _ in range(5)]
+        check(lib.rbg_graph_sell_arrays(self.ptr, *[ctypes.byref(q) for q in ptrs]))
+        n_units = sum(info["n_units"])
+        shapes = [((info["n_ent"], 2), "<i4"), ((n_units, 4), "<i4"), ((self.n_rows,), "<i4"), ((self.n_rows,), "<f4"),
+                  ((info["n_ent"],), "<i4")]
+        out = []
+        for q, (shape, ts) in zip(ptrs, shapes):
+            n = int(np.prod(shape))
+            if not q.value:
+                out.append(None)
+            elif n == 0:
+                out.append(torch.empty(shape, dtype=torch.int32 if ts == "<i4" else torch.float32, device=self.device))
+            else:
+                out.append(torch.as_tensor(self._view(q.value, n, ts), device=self.device).view(*shape))
+        return dict(zip(("ent", "head", "orig", "factors", "src"), out))
+
+    def plan_sell(self, W=32, chunk=0):
+        """Plan the column-slab propagation inside the library (``rbg_graph_plan_sell``: rocPRIM sorts and one-pass kernels on
+        this handle's device CSR) and install it.  ``rbg_graph_create*`` already did this for every eligible handle (option
+        "sell_auto"); call it to re-plan with another slab width / chunk.  A plan of slab width 32 serves d = 32, 64 and 128;
+        W = 64 serves d = 128 with two slabs (slower).  Raises ``RbgError`` (code RBG_EUNSUPPORTED) when the graph is outside
+        what the plan serves; ``sell_status()`` then says why."""
+        with torch.cuda.device(self.device):
+            check(lib.rbg_graph_plan_sell(self.ptr, int(W), int(chunk)))
+        return self.sell_info()
+
+    def attach_sell(self, d=64, chunk=None, W=32, planner="native"):
+        """Kept name of r03.  ``planner="native"`` = ``plan_sell``; ``planner="spec"`` builds the plan with the executable
+        specification ``sell.build_plan`` (torch ops) and attaches it through ``rbg_graph_attach_sell`` — the tests compare
+        the two bit for bit."""
         if not self.sell_eligible(d):
-            raise ValueError("a SELL plan needs a device graph built from interactions and d in (64, 128)")
+            raise ValueError("a SELL plan needs a device graph built from interactions and d in (32, 64, 128)")
+        if W not in (32, 64) or (W == 64 and d != 128):
+            raise ValueError(f"slab width {W} does not serve d = {d}")
+        if planner == "native":
+            return self.plan_sell(W, 0 if chunk is None else chunk)
+        from . import sell
         rowptr, col, val = self.device_csr()
         with torch.cuda.device(self.device):
-            if W not in (32, 64) or d not in (2 * W, 128):
-                raise ValueError(f"slab width {W} does not serve d = {d}")
             plan = sell.build_plan(rowptr, col, val, self.n_users, self.n_rows - self.n_users, W=W,
                                    chunk=sell.CHUNK if chunk is None else chunk)
             ub = (ctypes.c_int32 * 2)(*plan["unit_base"])
@@ -249,11 +293,27 @@ class GraphHandle:
                                             ub, nu, c_vp(plan["orig"].data_ptr())))
             if plan["factors"] is not None:  # val_ij = r_i r_j: the chains read 4-byte entries after their first launch
                 check(lib.rbg_graph_sell_set_factors(self.ptr, c_vp(plan["factors"].data_ptr())))
-        return {"W": W, "n_units": plan["n_units"], "n_ent": plan["n_ent"], "padding": plan["n_ent"] / max(self.nnz, 1),
-                "factored": plan["factors"] is not None}
+        return self.sell_info()
 
     def detach_sell(self):
         check(lib.rbg_graph_detach_sell(self.ptr))
+
+    def refresh_values(self):
+        """After rewriting the ``vals`` tensor of a re-weighted view in place: refresh the copy of the values the view's
+        column-slab plan holds (``rbg_graph_refresh_values``, on the current stream).  A no-op on handles without a plan."""
+        if getattr(self, "_is_view", False):
+            with torch.cuda.device(self.device):
+                check(lib.rbg_graph_refresh_values(self.ptr, c_vp(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def _view(self, ptr, n, typestr):
+        handle = self
+
+        class _View:  # the CUDA array interface: torch wraps the memory without copying it
+            def __init__(self):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr or 0, False), "version": 2}
+                self._owner = handle
+
+        return _View()
 
     def transpose(self):
         """Handle of Â^T (needed for the backward of a non-symmetric graph)."""

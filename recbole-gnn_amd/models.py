@@ -248,6 +248,8 @@ class NGCF(GeneralGraphRecommender):
         keep = self._draw_edge_keep(st["val"].shape[0]).to(torch.float32)
         torch.mul(st["val"], keep, out=st["buf"])
         torch.mul(st["val"], keep.index_select(0, st["tmap"]), out=st["buf_t"])  # A^T[r,c] = A[c,r]; the weights are symmetric
+        st["graph"].refresh_values()  # (the views' column-slab plans hold a copy of the weights)
+        st["graph"]._transpose.refresh_values()
         return st["graph"]
 
     def _layer_outputs(self):

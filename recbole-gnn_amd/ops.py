@@ -52,7 +52,7 @@ def spmm_raw(graph, x, out=None, accumulate=False):
         _check_dense(out, "out", graph)
         if tuple(out.shape) != (graph.n_rows, x.shape[1]) or not out.is_contiguous():
             raise ValueError("out must be a contiguous [n_rows, d] tensor")
-    if x.shape[1] in (64, 128):
+    if x.shape[1] in (32, 64, 128):
         _auto_sell(graph, x.shape[1])  # (eligible handles only: built from interactions; rbg_spmm_f32 then runs over the plan)
     with torch.cuda.device(x.device):
         check(lib.rbg_spmm_f32(graph.ptr, c_vp(x.data_ptr()), c_vp(out.data_ptr()), x.shape[1], int(bool(accumulate)),
@@ -178,8 +178,9 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, ou
         raise ValueError("out must be contiguous [N, d] and layers contiguous [max(K,1), N, d]")
     _check_dense(out, "out", graphs[0])
     _check_dense(layers, "layers", graphs[0])
-    if not keep_layers and len(graphs) == 1 and d in (64, 128):
-        _auto_sell(graphs[0], d)
+    if d in (32, 64, 128):
+        for g in graphs:
+            _auto_sell(g, d)
     arr = (c_vp * len(graphs))(*[g.ptr for g in graphs])
     # (no caller of this wrapper reads `layers` unless keep_layers: the library may use it as scratch in any layout)
     flags = _lib.FWD_KEEP_LAST_LAYER if keep_layers else _lib.FWD_LAYERS_SCRATCH
@@ -191,23 +192,21 @@ def lightgcn_forward_raw(graphs, user_w, item_w, n_layers, keep_layers=False, ou
 
 
 def _auto_sell(graph, d):
-    """First propagation of width d on an eligible handle: plan the column-slab path once (sell.py, ~10 ms at the Gowalla
-    shape) — option "sell" = 1 (default).  A failed attempt is remembered, not retried."""
-    tried = graph.__dict__.setdefault("_sell_tried", set())
-    if d in tried or torch.cuda.is_current_stream_capturing():  # (planning allocates and synchronises: never inside a capture)
+    """A handle created while option "sell_auto" was off (or before a re-plan was wanted) gets its column-slab plan on its
+    first propagation: one call into the library's planner (``rbg_graph_plan_sell``).  Handles created normally already carry
+    one — ``rbg_graph_create*`` plans — and a failed attempt is remembered, not retried."""
+    if graph.__dict__.get("_sell_tried") or torch.cuda.is_current_stream_capturing():  # (planning allocates and synchronises)
         return
-    tried.add(d)
+    graph._sell_tried = True
     from . import graph as _g
-    from .sell import NotApplicable
-    if not _g.get_option("sell") or not graph.sell_eligible(d) or graph.n_rows > graph.SELL_AUTO_MAX_ROWS or graph.has_sell(d):
+    if not _g.get_option("sell") or not graph.sell_eligible(d) or graph.has_sell(d):
         return
     try:
-        graph.attach_sell(d)
-    except NotApplicable:
-        pass  # e.g. a hub row beyond what the slab path sums per row: the binned kernel splits it over workgroups
-    except Exception as ex:  # noqa: BLE001  (the binned kernel serves the call; say why once)
-        import warnings
-        warnings.warn(f"column-slab plan not attached ({ex}); the propagation runs on the binned SpMM kernel")
+        graph.plan_sell()
+    except _lib.RbgError as ex:
+        if ex.code != _lib.RBG_EUNSUPPORTED:  # (not applicable: sell_status() holds the reason, the binned kernel serves the call)
+            import warnings
+            warnings.warn(f"column-slab plan not built ({ex}); the propagation runs on the binned SpMM kernel")
 
 
 class _LightGCNForward(torch.autograd.Function):

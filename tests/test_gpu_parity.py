@@ -297,16 +297,20 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         acc = acc + cur
         truth.append(acc / (len(truth) + 2))
     try:
+        assert h.has_sell(d) and h.sell_status() == "planned"  # rbg_graph_create planned the handle (option "sell_auto")
         rbg.set_option("sell", 0)
         binned = [rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0].clone() for k in (1, 2, 3)]
-        assert "binned" in h.propagation_kernel_name(d) and not h.has_sell(d)
+        assert "binned" in h.propagation_kernel_name(d)
         rbg.set_option("sell", 1)
+        h.detach_sell()
+        assert not h.has_sell(d)
         info = h.attach_sell(d)
-        assert h.has_sell(64) and h.has_sell(128) and not h.has_sell(32) and info["padding"] < 1.2  # (W = 32 serves both widths)
+        assert h.has_sell(64) and h.has_sell(128) and h.has_sell(32) and info["padding"] < 1.2  # (W = 32 serves the three widths)
+        dep = rbg.get_option("sell_depth")
         # val_ij = r_i r_j (the symmetric normalisation): the chain's launches after the first read 4-byte entries
-        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true>"
+        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true, {dep}>"
         # a caller that reads the layers gets them row-major: the same kernel gathering / writing the reference's layout
-        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<32, {d // 32}, false>" == h.spmm_kernel_name(d)
+        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<32, {d // 32}, false, {dep}>" == h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 0)
         assert "binned" in h.propagation_kernel_name(d, scratch_layers=False) and "binned" in h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 1)
@@ -326,7 +330,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
             close(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0], tol=2e-6)  # (the slab chain runs factored)
             rbg.set_option("sell_factored", 0)
             assert torch.equal(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0])
-            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
+            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false, {dep}>"
             rbg.set_option("sell_factored", 1)
             cur = x64
             for j in range(k):
@@ -386,7 +390,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         rbg.set_option("sell", 1)
         if d == 128:  # the two-slab form of d = 128 (256-byte slab rows): a plan of W = 64
             h.attach_sell(128, W=64)
-            assert h.has_sell(128) and not h.has_sell(64) and h.propagation_kernel_name(128) == "sell_spmm_kernel<64, 2, true>"
+            assert h.has_sell(128) and not h.has_sell(64) and h.propagation_kernel_name(128) == "sell_spmm_kernel<64, 2, true, 1>"
             close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
             close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x64, rowptr, col, val))
         h.detach_sell()
@@ -405,7 +409,12 @@ def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):
     from recbole_gnn_amd import sell
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
-    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    rbg.set_option("sell_auto", 0)  # (this handle is planned from outside: rbg_graph_attach_sell, the specification's arrays)
+    try:
+        h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    finally:
+        rbg.set_option("sell_auto", 1)
+    assert not h.has_sell(64) and "disabled" in h.sell_status()
     lib, vp = rbg._lib.lib, ctypes.c_void_p
     plan = sell.build_plan(*h.device_csr(), nu, ni, W=32)
 
@@ -431,15 +440,26 @@ def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):
     assert attach() == 0 and h.has_sell(64)
     host = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni)
     assert lib.rbg_graph_attach_sell(host.ptr, 32, None, 0, None, None, None, None) == rbg._lib.RBG_ENODEV
-    # auto-attach on the first differentiable propagation; a re-weighted view never gets a plan
-    h2 = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    # a handle created with planning off gets its plan on the first propagation (ops._auto_sell -> rbg_graph_plan_sell);
+    # created normally it carries one from rbg_graph_create on
     uw, iw = randn((nu, 64), 1, cuda), randn((ni, 64), 2, cuda)
-    assert not h2.has_sell(64)
-    rbg.ops.lightgcn_forward(h2, uw, iw, 2)
-    assert h2.has_sell(64)
-    view = h2.reweighted(h2.values())
-    rbg.ops.lightgcn_forward(view, uw, iw, 2)
-    assert not view.has_sell(64) and not view.sell_eligible(64)
+    rbg.set_option("sell_auto", 0)
+    try:
+        h3 = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    finally:
+        rbg.set_option("sell_auto", 1)
+    assert not h3.has_sell(64)
+    rbg.ops.lightgcn_forward(h3, uw, iw, 2)
+    assert h3.has_sell(64) and h3.sell_status() == "planned"
+    h2 = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    assert h2.has_sell(64) and h2.sell_status() == "planned"
+    # a re-weighted view borrows the plan but runs it only once its values have been refreshed (the plan holds a copy)
+    vals = h2.values()
+    view = h2.reweighted(vals)
+    assert not view.has_sell(64) and not view.sell_eligible(64) and "binned" in view.spmm_kernel_name(64)
+    close(rbg.ops.lightgcn_forward(view, uw, iw, 2), rbg.ops.lightgcn_forward(h2, uw, iw, 2), tol=2e-6)
+    view.refresh_values()
+    assert view.has_sell(64) and view.spmm_kernel_name(64).startswith("sell_spmm_kernel<32, 2, false")
     close(rbg.ops.lightgcn_forward(view, uw, iw, 2), rbg.ops.lightgcn_forward(h2, uw, iw, 2), tol=2e-6)
 
 

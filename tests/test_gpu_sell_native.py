@@ -1,0 +1,506 @@
+"""r04: the column-slab plan as a property of the C ABI (csrc/sell_plan.hip: rbg_graph_plan_sell inside rbg_graph_create*).
+
+* the native planner's arrays equal the executable specification's (recbole-gnn_amd/sell.py) bit for bit;
+* a caller that binds librbgnn.so with raw ctypes only (rbg_graph_create -> rbg_lightgcn_forward_f32,
+  the sites layers.py:19-20 / lightgcn.py:74-76) runs sell_spmm_kernel and matches the oracle;
+* every caller of the plain product goes through the plan: the NGCF layer (layers.py:54-58) contiguous and as a column block
+  of the concatenated buffer (ngcf.py:100), the SimGCL noise epilogue (simgcl.py:29-33), re-weighted views (ngcf.py:74-90),
+  per-layer graph lists (sgl.py:89-91), d = 32;
+* the kernel's launch forms (two batches in flight, first-batch blocks, one launch per row class) are bit-identical;
+* every allocation of the plan code can fail without leaving a dangling pointer (fault injection: option "fail_alloc_after");
+* parity at the north_star's named scale (1.3 M nodes) and at the single-GPU Amazon-Book shape through the plan.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import coracle as C
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def close(got, ref, tol=TOL):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    scale = max(1.0, float(np.abs(ref).max()) if ref.size else 1.0)
+    err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) if ref.size else 0.0
+    assert err <= tol * scale, f"max abs err {err:.3e} > {tol * scale:.3e}"
+    return err
+
+
+def randn(shape, seed, dev):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float32).to(dev)
+
+
+def hub_graph(rbg, seed=5, nu=3001, ni=2201, e=60_000):
+    """power-law graph + hubs (user 1: 1 500 items, user 7: 700, item 3: 900 users), empty rows, the PAD rows"""
+    uid, iid = rbg.synth.powerlaw_bipartite(nu, ni, e, seed=seed)
+    hub_u = np.concatenate([uid, np.full(1500, 1), np.full(700, 7), (np.arange(900) * 3 % (nu - 1) + 1)]).astype(np.int64)
+    hub_i = np.concatenate([iid, (np.arange(1500) % (ni - 1) + 1), (np.arange(700) * 3 % (ni - 1) + 1), np.full(900, 3)]).astype(np.int64)
+    key = np.unique(hub_u * ni + hub_i)
+    return key // ni, key % ni, nu, ni
+
+
+def graphs(rbg, name):
+    if name == "hubs":
+        return hub_graph(rbg)
+    if name == "duplicates":  # duplicated interactions stay separate entries (equal keys in the planner's sort)
+        rng = np.random.default_rng(3)
+        nu, ni = 60, 90
+        uid, iid = rng.integers(1, nu, 2500), rng.integers(1, ni, 2500)
+        return np.concatenate([uid, uid[:400]]), np.concatenate([iid, iid[:400]]), nu, ni
+    return rbg.synth.make(name)
+
+
+# ---- the planner ------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("W,chunk", [(32, 0), (32, 4), (32, 16), (64, 0), (64, 8)])
+@pytest.mark.parametrize("name", ["toy", "ml-100k", "hubs", "duplicates"])
+def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
+    """rbg_graph_plan_sell (rocPRIM sorts / scans + one-pass kernels) against sell.build_plan (torch ops) on the handle's own
+    device CSR: entries (offsets AND value bits), unit headers, row numbering — bit for bit; the factors to one ulp (float64
+    pow(-0.5) there, 1 / sqrt in double here); the slot -> CSR position map reproduces every entry."""
+    from recbole_gnn_amd import sell
+    uid, iid, nu, ni = graphs(rbg, name)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    assert h.sell_status() == "planned"
+    info = h.plan_sell(W=W, chunk=chunk)
+    spec = sell.build_plan(*h.device_csr(), nu, ni, W=W, chunk=chunk or sell.CHUNK)
+    arr = h.sell_arrays()
+    assert info["n_ent"] == spec["n_ent"] and info["n_units"] == spec["n_units"] and info["W"] == W
+    assert torch.equal(arr["head"], spec["head"]), "unit headers differ"
+    assert torch.equal(arr["orig"], spec["orig"]), "row numbering differs"
+    assert torch.equal(arr["ent"], spec["ent"][: spec["n_ent"]]), "entries differ"
+    assert info["factored"] and spec["factors"] is not None
+    f_nat, f_spec = arr["factors"].view(torch.int32), spec["factors"].view(torch.int32)
+    assert int((f_nat - f_spec).abs().max()) <= 1
+    # src: the CSR position of every slot
+    rowptr, col, val = h.device_csr()
+    src = arr["src"].long()
+    real = src >= 0
+    assert int(real.sum()) == h.nnz and torch.equal(real, arr["ent"][:, 0] != sell.K_PAST)
+    assert torch.equal(arr["ent"][real, 1], val[src[real]].view(torch.int32))
+    assert torch.equal(torch.sort(src[real]).values, torch.arange(h.nnz, device=cuda))
+    # and the product through it
+    x = randn((nu + ni, 2 * W if W == 32 else 128), 4, cuda)
+    rp, cl, vl = C.build_norm_csr(uid, iid, nu, ni)
+    assert h.spmm_kernel_name(x.shape[1]).startswith(f"sell_spmm_kernel<{W}, 2, false")
+    close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rp, cl, vl))
+
+
+def test_plan_reasons_are_visible(rbg, cuda):
+    """A graph outside the plan's reach keeps the binned kernel and says why (rbg_graph_sell_status): a hub row beyond
+    4 LGW x max(512, nnz / 8192) entries; a CSR without a user / item boundary; a host graph; planning switched off."""
+    lgw = 8
+    hub = 512 * 4 * lgw + 1000
+    nu, ni = 400, hub + 10
+    u = np.concatenate([np.full(hub, 1), np.arange(1000) % (nu - 2) + 2]).astype(np.int64)
+    i = np.concatenate([np.arange(hub) + 1, (np.arange(1000) * 7919) % (ni - 1) + 1]).astype(np.int64)
+    key = np.unique(u * ni + i)
+    u, i = key // ni, key % ni
+    h = rbg.GraphHandle.from_interactions(u, i, nu, ni, device=cuda)
+    assert not h.has_sell(64) and "longer than" in h.sell_status() and "binned" in h.propagation_kernel_name(64)
+    with pytest.raises(rbg.RbgError) as ei:
+        h.plan_sell()
+    assert ei.value.code == rbg._lib.RBG_EUNSUPPORTED
+    x = randn((nu + ni, 64), 1, cuda)
+    rp, cl, vl = C.build_norm_csr(u, i, nu, ni)
+    x64 = x.cpu().numpy().astype(np.float64)  # (float64: the hub row is a sum of 17 384 terms, the fp32 restatement itself is 1e-4 off)
+    l1 = O.conv_csr_f64(x64, rp, cl, vl)
+    close(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), 2)[0], (x64 + l1 + O.conv_csr_f64(l1, rp, cl, vl)) / 3)
+    hc = rbg.GraphHandle.from_csr(rp, cl, vl, nu + ni, device=cuda)
+    assert not hc.has_sell(64) and "boundary" in hc.sell_status()
+    assert rbg.GraphHandle.from_interactions(u, i, nu, ni).sell_status() == "host graph"
+    rbg.set_option("sell_auto", 0)
+    try:
+        assert "disabled" in rbg.GraphHandle.from_interactions(u[:50], i[:50], nu, ni, device=cuda).sell_status()
+    finally:
+        rbg.set_option("sell_auto", 1)
+    # a CSR graph WITH the two row classes and a bipartite structure (a shard's interior block) is planned
+    hb = rbg.GraphHandle.from_csr(*C.build_norm_csr(u[:3000] % 300 + 1, i[:3000] % 500 + 1, 400, 600), 1000, device=cuda, n_class0_rows=400)
+    assert hb.sell_status() == "planned" and hb.spmm_kernel_name(64).startswith("sell_spmm_kernel")
+
+
+RAW_CALLER = r'''
+import ctypes, sys, json
+import numpy as np, torch
+lib = ctypes.CDLL(sys.argv[1])
+z = np.load(sys.argv[2])
+uid, iid, nu, ni = np.ascontiguousarray(z["uid"]), np.ascontiguousarray(z["iid"]), int(z["n_users"]), int(z["n_items"])
+vp, i64 = ctypes.c_void_p, ctypes.c_int64
+lib.rbg_last_error.restype = ctypes.c_char_p
+lib.rbg_graph_create.argtypes = [ctypes.POINTER(vp), i64, i64, i64, vp, vp, ctypes.c_int, ctypes.c_uint32]
+lib.rbg_lightgcn_forward_f32.argtypes = [ctypes.POINTER(vp), ctypes.c_int, i64, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, vp]
+lib.rbg_lightgcn_forward_kernel_name.argtypes = [vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int]
+lib.rbg_spmm_kernel_name.argtypes = [vp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+lib.rbg_spmm_f32.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]
+lib.rbg_graph_destroy.argtypes = [vp]
+g = vp()
+rc = lib.rbg_graph_create(ctypes.byref(g), nu, ni, len(uid), uid.ctypes.data, iid.ctypes.data, 0, 0)
+assert rc == 0, lib.rbg_last_error()
+d, K = 64, 3
+gen = torch.Generator().manual_seed(7)
+uw = torch.randn(nu, d, generator=gen).cuda(); iw = torch.randn(ni, d, generator=gen).cuda()
+out = torch.empty(nu + ni, d, device="cuda"); layers = torch.empty(K, nu + ni, d, device="cuda")
+buf = ctypes.create_string_buffer(128); buf2 = ctypes.create_string_buffer(128)
+assert lib.rbg_lightgcn_forward_kernel_name(g, d, 2, buf, 128) == 0 and lib.rbg_spmm_kernel_name(g, d, buf2, 128) == 0
+arr = (vp * 1)(g)
+s = torch.cuda.current_stream().cuda_stream
+rc = lib.rbg_lightgcn_forward_f32(arr, 1, nu, uw.data_ptr(), iw.data_ptr(), out.data_ptr(), layers.data_ptr(), d, K, 2, s)
+assert rc == 0, lib.rbg_last_error()
+x = torch.cat([uw, iw]); y = torch.empty_like(x)
+rc = lib.rbg_spmm_f32(g, x.data_ptr(), y.data_ptr(), d, 0, s)
+assert rc == 0, lib.rbg_last_error()
+torch.cuda.synchronize()
+np.savez(sys.argv[3], out=out.cpu().numpy(), y=y.cpu().numpy(), uw=uw.cpu().numpy(), iw=iw.cpu().numpy())
+lib.rbg_graph_destroy(g)
+print(json.dumps({"fwd": buf.value.decode(), "spmm": buf2.value.decode(), "modules": sorted(m for m in sys.modules if "recbole" in m or "oracle" in m)}))
+'''
+
+
+def test_raw_ctypes_caller_runs_the_column_slab_kernel(tmp_path):
+    """INTEGRATION.md's stub, literally: ctypes.CDLL on librbgnn.so, rbg_graph_create with host id arrays, rbg_lightgcn_forward_f32
+    and rbg_spmm_f32 on torch-owned HBM — no recbole_gnn_amd import in that process.  The kernel the library reports is the
+    column-slab one and the numbers match the oracle."""
+    import json
+    script = tmp_path / "raw_caller.py"
+    script.write_text(textwrap.dedent(RAW_CALLER))
+    out = tmp_path / "out.npz"
+    lib = os.path.join(ROOT, "recbole-gnn_amd", "librbgnn.so")
+    fix = os.path.join(ROOT, "tests", "golden", "ref_test_inter.npz")
+    r = subprocess.run([sys.executable, str(script), lib, fix, str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rep["modules"] == [], rep
+    assert rep["fwd"].startswith("sell_spmm_kernel<32, 2, true") and rep["spmm"].startswith("sell_spmm_kernel<32, 2, false"), rep
+    z, f = np.load(out), np.load(fix)
+    rp, cl, vl = C.build_norm_csr(f["uid"], f["iid"], int(f["n_users"]), int(f["n_items"]))
+    close(z["out"], C.lightgcn_forward(rp, cl, vl, z["uw"], z["iw"], 3))
+    close(z["y"], C.spmm(rp, cl, vl, np.concatenate([z["uw"], z["iw"]])))
+
+
+# ---- every caller of the product --------------------------------------------------------------------------------------------
+
+def _truth_layers(x64, rowptr, col, val, k):
+    out, cur = [], x64
+    for _ in range(k):
+        cur = O.conv_csr_f64(cur, rowptr, col, val)
+        out.append(cur)
+    return out
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_launch_forms_are_bit_identical(rbg, cuda, d):
+    """Options "sell_depth" (two gather batches in flight) and "sell_class_serial" (one launch per row class) change how a
+    launch is issued, not what it sums or in which order: the propagation (K = 1..3, forward and backward), the plain layer,
+    Y += A X and the noise epilogue — bit-identical to the default form, and equal to float64 within 1e-5."""
+    uid, iid, nu, ni = hub_graph(rbg)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    x = randn((nu + ni, d), 11, cuda)
+    gout = randn((nu + ni, d), 12, cuda)
+    noise = torch.rand(nu + ni, d, generator=torch.Generator().manual_seed(6)).to(cuda)
+    x64 = x.cpu().numpy().astype(np.float64)
+
+    def run():
+        res = []
+        for k in (1, 2, 3):
+            xg = x.clone().requires_grad_(True)
+            out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
+            out.backward(gout)
+            res += [out.detach().clone(), xg.grad.clone()]
+            res.append(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), k, keep_layers=True)[0].clone())
+        res.append(rbg.ops.spmm_raw(h, x).clone())
+        acc = x.clone()
+        rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
+        res.append(acc)
+        res.append(rbg.ops.spmm_noise_raw(h, x, noise, 0.1).clone())
+        return res
+
+    names = set()
+    try:
+        base = run()
+        lay = _truth_layers(x64, rowptr, col, val, 3)
+        close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
+        close(base[9], lay[0])
+        for depth, serial in [(2, 0), (1, 1), (2, 1)]:
+            rbg.set_option("sell_depth", depth)
+            rbg.set_option("sell_class_serial", serial)
+            names.add(h.propagation_kernel_name(d))
+            for a, b in zip(run(), base):
+                assert torch.equal(a, b), (depth, serial)
+    finally:
+        rbg.set_option("sell_depth", 1)
+        rbg.set_option("sell_class_serial", -1)
+    assert names == {f"sell_spmm_kernel<32, {d // 32}, true, 1>", f"sell_spmm_kernel<32, {d // 32}, true, 2>"}
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_noise_epilogue_over_the_plan(rbg, cuda, golden, d):
+    """rbg_spmm_noise_f32 (simgcl.py:29-33) on a planned handle runs the column-slab kernel: the noise row's norm spans all the
+    slabs of the row; against the torch expression in float64 and against the binned kernel."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    n = nu + ni
+    x = randn((n, d), 5, cuda)
+    noise = torch.rand(n, d, generator=torch.Generator().manual_seed(6)).to(cuda)
+    assert h.spmm_kernel_name(d).startswith("sell_spmm_kernel")
+    y = rbg.ops.spmm_noise_raw(h, x, noise, 0.1)
+    ax = torch.from_numpy(O.conv_csr_f64(x.cpu().numpy().astype(np.float64), g["rowptr"], g["col"].astype(np.int64), g["val"]))
+    ref = ax + torch.sign(ax) * torch.nn.functional.normalize(noise.cpu().double(), dim=-1) * 0.1
+    mask = ax.abs() > 1e-6
+    assert float((y.cpu().double() - ref)[mask].abs().max()) <= 1e-5
+    assert torch.all(y[0] == 0) and torch.all(y[nu] == 0)
+    rbg.set_option("sell", 0)
+    try:
+        yb = rbg.ops.spmm_noise_raw(h, x, noise, 0.1)
+    finally:
+        rbg.set_option("sell", 1)
+    assert float((y - yb)[mask.to(cuda)].abs().max()) <= 2e-6
+
+
+def test_ngcf_layer_over_the_plan(rbg, cuda):
+    """BiGNNConv (layers.py:54-58): the product inside rbg_bignn_conv_f32 / rbg_bignn_layer_f32 / rbg_bignn_backward_f32 runs
+    over the plan — also when X is a 64-wide column block of the [N, 256] concatenated buffer (ngcf.py:100; the row stride
+    scales the row-major entries' offsets) — and equals the binned path within rounding and float64 within 1e-5."""
+    uid, iid, nu, ni = hub_graph(rbg, seed=9)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    n, d = nu + ni, 64
+    gen = torch.Generator().manual_seed(3)
+    w1, w2 = (torch.randn(d, d, generator=gen) * 0.2).to(cuda), (torch.randn(d, d, generator=gen) * 0.2).to(cuda)
+    b1, b2 = torch.randn(d, generator=gen).to(cuda) * 0.1, torch.randn(d, generator=gen).to(cuda) * 0.1
+    wide = randn((n, 256), 8, cuda)
+    for x in (wide[:, 64:128], wide[:, :64].contiguous()):
+        x64 = x.cpu().numpy().astype(np.float64)
+        p64 = O.conv_csr_f64(x64, rowptr, col, val)
+        ref = (p64 + x64) @ w1.cpu().numpy().astype(np.float64).T + b1.cpu().numpy() + (p64 * x64) @ w2.cpu().numpy().astype(np.float64).T + b2.cpu().numpy()
+        y, _ = rbg.ops.bignn_conv_raw(h, x, w1, b1, w2, b2)
+        close(y, ref, tol=2e-5)
+        rbg.set_option("sell", 0)
+        try:
+            yb, _ = rbg.ops.bignn_conv_raw(h, x, w1, b1, w2, b2)
+        finally:
+            rbg.set_option("sell", 1)
+        close(y, yb, tol=5e-6)
+    # the training layer and its backward
+    xg = wide[:, :64].contiguous().requires_grad_(True)
+    res = {}
+    for sell in (1, 0):
+        rbg.set_option("sell", sell)
+        try:
+            xg.grad = None
+            out = rbg.ops.bignn_layer(xg, w1, b1, w2, b2, h, 0.2)
+            out.backward(torch.ones_like(out))
+            res[sell] = (out.detach().clone(), xg.grad.clone())
+        finally:
+            rbg.set_option("sell", 1)
+    close(res[1][0], res[0][0], tol=5e-6)
+    close(res[1][1], res[0][1], tol=2e-5)
+
+
+def test_reweighted_view_runs_the_plan_after_a_refresh(rbg, cuda):
+    """NGCF's edge dropout (ngcf.py:74-90): a re-weighted view of a planned graph borrows the plan and owns a copy of the valued
+    entries; rbg_graph_refresh_values rewrites the copy from the caller's array through the slot -> CSR position map.  Weights
+    that are NOT symmetric (every directed edge dropped independently), duplicated interactions whose copies get different
+    weights, a second rewrite; until the first refresh the view stays on the binned kernel, which reads the array itself."""
+    uid, iid, nu, ni = graphs(rbg, "duplicates")
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    n = nu + ni
+    x = randn((n, 64), 2, cuda)
+    x64 = x.cpu().numpy().astype(np.float64)
+    vals = h.values()
+    buf = vals.clone()
+    view = h.reweighted(buf)
+    assert "binned" in view.spmm_kernel_name(64)
+    for trial in range(3):
+        w = torch.rand(h.nnz, generator=torch.Generator().manual_seed(trial)).to(cuda)
+        buf.copy_(vals * (w >= 0.3) * (0.5 + w))
+        if trial:
+            view.refresh_values()
+            assert view.spmm_kernel_name(64).startswith("sell_spmm_kernel<32, 2, false")
+        ref = O.conv_csr_f64(x64, rowptr, col, buf.cpu().numpy())
+        close(rbg.ops.spmm_raw(view, x), ref)
+        mean, layers = rbg.ops.lightgcn_forward_raw(view, x[:nu].contiguous(), x[nu:].contiguous(), 2, keep_layers=True)
+        l1 = ref
+        l2 = O.conv_csr_f64(l1, rowptr, col, buf.cpu().numpy())
+        close(layers[0], l1)
+        close(mean, (x64 + l1 + l2) / 3)
+    close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x64, rowptr, col, val))  # the base graph's own values are untouched
+    view.destroy()
+    h.destroy()
+
+
+def test_per_layer_graphs_over_their_own_plans(rbg, cuda, golden):
+    """SGL's RW views (sgl.py:89-91): one graph per layer, each with its own plan and row numbering — the layers pass row-major
+    between them (rbg_lightgcn_forward_f32 with n_graphs = K)."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    rng = np.random.default_rng(8)
+    hs, csrs = [], []
+    for k in range(3):
+        keep = (rng.random(len(g["uid"])) < 0.8).astype(np.uint8)
+        hs.append(rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda, keep=keep))
+        csrs.append(C.build_norm_csr(g["uid"], g["iid"], nu, ni, keep=keep))
+        assert hs[-1].sell_status() == "planned"
+    x = randn((nu + ni, 64), 4, cuda)
+    cur = x.cpu().numpy().astype(np.float64)
+    acc = cur.copy()
+    for rp, cl, vl in csrs:
+        cur = O.conv_csr_f64(cur, rp, cl, vl)
+        acc += cur
+    out = rbg.ops.lightgcn_forward_raw(hs, x[:nu].contiguous(), x[nu:].contiguous(), 3)[0]
+    close(out, acc / 4)
+    rbg.set_option("sell", 0)
+    try:
+        close(out, rbg.ops.lightgcn_forward_raw(hs, x[:nu].contiguous(), x[nu:].contiguous(), 3)[0], tol=2e-6)
+    finally:
+        rbg.set_option("sell", 1)
+
+
+# ---- error paths ------------------------------------------------------------------------------------------------------------
+
+def test_every_allocation_of_the_plan_code_may_fail(rbg, cuda):
+    """Fault injection (option "fail_alloc_after" = n: the (n + 1)-th device allocation of the plan code fails once): walk
+    rbg_graph_plan_sell, rbg_graph_attach_sell + rbg_graph_sell_set_factors, the view constructor and the backward's lazy
+    scratch one allocation at a time; after every failure the handle propagates correctly (with the plan it still has, or the
+    binned kernel) and is destroyed cleanly — r03's attach freed entc / rs without clearing them when the row-major twin failed
+    (ADVICE r03, medium)."""
+    from recbole_gnn_amd import sell
+    uid, iid, nu, ni = rbg.synth.make("toy")
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    x = randn((nu + ni, 64), 3, cuda)
+    uw, iw = x[:nu].contiguous(), x[nu:].contiguous()
+    ref = C.lightgcn_forward(rowptr, col, val, uw.cpu().numpy(), iw.cpu().numpy(), 3)
+    gref = None
+
+    def check(h):
+        nonlocal gref
+        close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], ref)
+        xg = x.clone().requires_grad_(True)
+        rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], 3).sum().backward()
+        if gref is None:
+            gref = xg.grad.clone()
+        close(xg.grad, gref, tol=2e-6)
+        close(rbg.ops.spmm_raw(h, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
+
+    rbg.set_option("sell_auto", 0)
+    try:
+        outcomes = []
+        for n in range(0, 64):
+            h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+            rbg.set_option("fail_alloc_after", n)
+            try:
+                h.plan_sell()
+                failed = False
+            except rbg.RbgError as ex:
+                failed = True
+                assert ex.code in (rbg._lib.RBG_ENOMEM, rbg._lib.RBG_EHIP), ex
+            consumed = rbg.get_option("fail_alloc_after") < 0
+            rbg.set_option("fail_alloc_after", -1)
+            outcomes.append((failed, consumed, h.has_sell(64)))
+            check(h)
+            h.destroy()
+            if not consumed:
+                break
+        assert not outcomes[-1][0] and outcomes[-1][2] and len(outcomes) > 8  # the walk reached the end of the planner
+        assert any(f for f, _, _ in outcomes) and any((not f) and c and p for f, c, p in outcomes)  # hard failures AND optional arrays
+        # the external attach + factors + lazy backward scratch
+        for n in range(0, 24):
+            h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+            rbg.set_option("fail_alloc_after", n)
+            try:
+                h.attach_sell(64, planner="spec")
+            except rbg.RbgError:
+                pass
+            rbg.set_option("sell_rowmajor", 0)  # (the backward then needs the per-handle slab scratch)
+            try:
+                check(h)
+            finally:
+                rbg.set_option("sell_rowmajor", 1)
+            consumed = rbg.get_option("fail_alloc_after") < 0
+            rbg.set_option("fail_alloc_after", -1)
+            check(h)
+            h.destroy()
+            if not consumed:
+                break
+        # the view
+        h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+        h.plan_sell()
+        for n in range(0, 6):
+            rbg.set_option("fail_alloc_after", n)
+            v = h.reweighted(h.values())
+            consumed = rbg.get_option("fail_alloc_after") < 0
+            rbg.set_option("fail_alloc_after", -1)
+            v.refresh_values()
+            close(rbg.ops.spmm_raw(v, x), C.spmm(rowptr, col, val, x.cpu().numpy()))
+            v.destroy()
+            if not consumed:
+                break
+        torch.cuda.synchronize()
+    finally:
+        rbg.set_option("fail_alloc_after", -1)
+        rbg.set_option("sell_auto", 1)
+        rbg.set_option("sell_rowmajor", 1)
+
+
+# ---- the north_star's named scale -------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["amazon-book", "g-1.3m"])
+def test_parity_at_scale_through_the_plan(rbg, cuda, name):
+    """Single-GPU Amazon-Book shape (52 644 / 91 600 / 2 984 108) and the north_star's "1.3 M nodes" shape (550 000 / 750 000 /
+    18 850 000), d = 64, K = 3, through the column-slab plan (both launch forms: one launch per layer, one per row class):
+    every layer on sampled rows, the heaviest hubs and the PAD rows against float64 (sums over the rows' neighbour lists of
+    the previous float64 layer — which needs THAT layer on every row: computed with scipy in float64 here), and the linearity /
+    fixed-point properties on every row."""
+    import scipy.sparse as sp
+    uid, iid, nu, ni = rbg.synth.make(name)
+    n, d = nu + ni, 64
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    assert h.sell_status() == "planned" and h.propagation_kernel_name(d).startswith("sell_spmm_kernel<32, 2, true")
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    got = h.export_csr()
+    assert np.array_equal(got[0], rowptr) and np.array_equal(got[1], col) and np.array_equal(got[2], val)
+    a = sp.csr_matrix((val.astype(np.float64), col, rowptr), shape=(n, n))
+    gen = torch.Generator().manual_seed(2020)
+    uw, iw = O.xavier_uniform(nu, d, gen), O.xavier_uniform(ni, d, gen)
+    e0 = np.concatenate([uw.numpy(), iw.numpy()]).astype(np.float64)
+    acc, cur = e0.copy(), e0
+    for _ in range(3):
+        cur = a @ cur
+        acc += cur
+    ref = acc / 4
+    deg = np.diff(rowptr)
+    rows = np.unique(np.concatenate([np.random.default_rng(0).integers(0, n, 4000), np.argsort(deg)[-50:], [0, nu, n - 1]]))
+    scale = float(np.abs(ref).max())
+    try:
+        for serial in (0, 1):
+            rbg.set_option("sell_class_serial", serial)
+            mean, _ = rbg.ops.lightgcn_forward_raw(h, uw.to(cuda), iw.to(cuda), 3)
+            err = float(np.abs(mean.cpu().numpy().astype(np.float64) - ref).max())
+            assert err <= 1e-5 and err <= 1e-5 * scale, (serial, err, scale)  # absolute AND normalized
+            y = rbg.ops.spmm_raw(h, torch.from_numpy(e0.astype(np.float32)).to(cuda))
+            r1 = a[rows] @ e0
+            e1 = float(np.abs(y[torch.from_numpy(rows).to(cuda)].cpu().numpy() - r1).max())
+            assert e1 <= 1e-5 * max(float(np.abs(r1).max()), 1e-30) * 4 and e1 <= 1e-5, e1
+    finally:
+        rbg.set_option("sell_class_serial", -1)
+    # fixed point: A sqrt(deg) = sqrt(deg) on every non-isolated row, N(0, 1)-scale check of the gather
+    root = torch.from_numpy(np.sqrt(deg.astype(np.float64)).astype(np.float32)).to(cuda)
+    xr = root[:, None].expand(n, d).contiguous()
+    yr = rbg.ops.spmm_raw(h, xr)
+    rel = ((yr - xr).abs() / root[:, None].clamp(min=1.0)).max()
+    assert float(rel) <= 5e-5 and float(yr[root == 0].abs().max()) == 0.0
