@@ -143,6 +143,7 @@ int sell_set_factors(rbg_graph *g, const float *r);  // rbg_graph_sell_set_facto
 // sell_plan.hip
 int plan_sell(rbg_graph *g, int W, int chunk);
 
+
 }  // namespace rbg
 
 // The graph handle.  Arrays named d_* live in HBM (device >= 0); h_* on the host.

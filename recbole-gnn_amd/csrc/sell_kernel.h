@@ -1,0 +1,424 @@
+// sell_kernel.h — device code of the column-slab propagation shared by its two launch forms: one wave per unit, one launch per
+// layer (sell.hip) and the r04 experiment of a persistent K-layer launch (devtools/experiments/sell_persist.hip).  DESIGN 2.1c.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "internal.h"
+
+namespace rbg {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+constexpr int kSellPast = 0x7ffffff0;  // padding slots: past every table this path accepts, a buffer load returns zeros
+
+struct SellParams {
+    const v4i *ent;          // pairs of entries {internal column * W * 4, bits of val}
+    const int4 *head;        // unit headers {first entry, first row, slots << 16, log2(parts) | rows << 8 | wide << 16}
+    int32_t unit_base[2], n_units[2], n_class[2];
+    const float *xs;         // gathered operand, slab layout
+    float *ys;               // result, slab layout (last = 0)
+    int64_t slab_off[2][4];  // float offset of (class, slab)
+    int32_t last;            // 1: out[orig[row]] = (sum_i prev[i] + acc) / denom, row-major [N, NS W]; 0: ys = acc (+ prev[0] if n_prev)
+    int32_t n_prev;
+    const float *prev[RBG_MAX_FUSED_LAYERS + 1];  // slab layout
+    float denom;
+    float *out;
+    const int32_t *orig;     // original node id of (class, internal row)
+    // row-major operands in the REFERENCE's numbering (class 0 = the user table [n_class[0], NS W], class 1 = the item table):
+    const v4i *ent0;         // x_rm: the same entries with the column offset = original class-local row * 2 W * 4
+    const float *rm[2];      // x_rm: the gathered operand
+    const float *prm[2];     // prev0_rm: prev[0] (E0's two tables, the incoming gradient, or Y itself for Y += A X), read through orig[]
+    int32_t x_rm;            // 1: the gathered operand is rm[] (entries ent0) — E0 / the incoming gradient is never converted
+    int32_t prev0_rm;
+    int32_t prev_rm_all;     // 1: prev[1..] are row-major [N, NS W] arrays in the reference's numbering as well
+    float *out2;             // last: also store the layer itself (acc), row-major (RBG_FWD_KEEP_LAST_LAYER)
+    // factored chain (val_ij = r_i r_j, the symmetric normalisation): the slabs between the layers hold z = r (.) y, a launch that
+    // gathers z reads COLUMN OFFSETS ONLY (entc: 4 bytes per entry instead of 8) and scales its row sums by r_i
+    const int32_t *entc;     // compact: the offsets column of ent
+    const float *rs, *irs;   // r_i and 1 / r_i (0 for an empty row), the plan's numbering
+    int32_t compact;         // 1: gather through entc (the operand is a scaled slab), acc *= r_i
+    int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
+    int32_t prev_scaled;     // 1 (last): prev[1..] are scaled slabs: their sum is multiplied by 1 / r_i
+    int32_t nt;              // option "sell_nt"
+    // r04
+    int32_t cls_only;        // -1: XCDs 0-3 run class 0, 4-7 class 1; c: all eight XCDs run class c (one launch per class: the live
+                             // gathered set is ONE table — tables beyond the Infinity Cache)
+    int32_t rm_ld;           // x_rm: floats between the rows of rm[] (NS W when contiguous; a column block of a wider buffer otherwise)
+    int32_t rm_shift;        // x_rm: log2(rm_ld / (2 W)) (-1: rm_ld = W): ent0's offsets are rows of 2 W floats
+    const float *noise;      // last (row-major out): out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps   (simgcl.py:30-33)
+    float eps;
+};
+
+// The parameter block is read where the launch put it — the kernel-argument segment (constant address space) — through this
+// reference type: a by-value copy handed to an inlined function by reference stayed in scratch memory (432 bytes per lane).
+typedef const __attribute__((address_space(4))) SellParams SellParamsK;
+__device__ __forceinline__ SellParamsK &sell_kernarg() {
+    return *(SellParamsK *)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// One layer of a chain as the host describes it (sell.hip's chain builders)
+struct SellChainLayer {
+    const float *xs;
+    float *ys;
+    int32_t x_rm, compact, store_scaled, last, n_prev, prev0_rm, prev_scaled, pad;
+};
+
+// What changes from layer to layer of a chain (wave-uniform: scalar registers); the one-launch-per-layer kernel fills it from
+// the parameter block (a persistent K-layer kernel would fill it from a per-layer table).
+struct SellLayer {
+    const float *xs;
+    float *ys;
+    int32_t x_rm, store_scaled, last, n_prev, prev0_rm, prev_scaled;
+};
+__device__ __forceinline__ SellLayer sell_layer_of(SellParamsK &p) {
+    return SellLayer{p.xs, p.ys, p.x_rm, p.store_scaled, p.last, p.n_prev, p.prev0_rm, p.prev_scaled};
+}
+
+template <int K>
+__device__ __forceinline__ int quad_bcast(int v) {  // lane K of every quad, in all its lanes
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true);
+}
+// entry J (0..7) of the 8 a quad holds: lane J / 2, components (J & 1) * 2 + {0, 1}
+template <int J>
+__device__ __forceinline__ int ent_col(const v4i &w) { return quad_bcast<J / 2>((J & 1) ? w.z : w.x); }
+template <int J>
+__device__ __forceinline__ float ent_val(const v4i &w) { return __int_as_float(quad_bcast<J / 2>((J & 1) ? w.w : w.y)); }
+// COMPACT: an entry is its column offset alone (the operand is pre-scaled by the column's factor)
+template <int J>
+__device__ __forceinline__ int ent_col(const v2i &w) { return quad_bcast<J / 2>((J & 1) ? w.y : w.x); }
+
+template <int J, int N>
+struct SellFor {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&f) {
+        f(std::integral_constant<int, J>{});
+        SellFor<J + 1, N>::run(f);
+    }
+};
+template <int N>
+struct SellFor<N, N> {
+    template <class F>
+    static __device__ __forceinline__ void run(F &&) {}
+};
+
+// epilogue accesses with an optional non-temporal hint (option "sell_nt": 1 = stores, 2 = the mean's addend loads)
+__device__ __forceinline__ void st4(float *p, const float4 v, const bool nt) {
+    v4f w = {v.x, v.y, v.z, v.w};
+    if (nt) __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<v4f *>(p) = w;
+}
+__device__ __forceinline__ float4 ld4(const float *p, const bool nt) {
+    const v4f w = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)) : *reinterpret_cast<const v4f *>(p);
+    return make_float4(w.x, w.y, w.z, w.w);
+}
+
+struct SellAcc {
+    v2f lo, hi;
+};
+__device__ __forceinline__ void fma_row(SellAcc &a, float v, v4f x) {
+    const v2f vv = {v, v};
+    a.lo = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 0, 1), a.lo);
+    a.hi = __builtin_elementwise_fma(vv, __builtin_shufflevector(x, x, 2, 3), a.hi);
+}
+
+// Eight gathered rows in registers: named members (an array indexed through lambdas went to scratch: hipcc kept it in memory)
+struct SellRows {
+    v4f r0, r1, r2, r3, r4, r5, r6, r7;
+    template <int J>
+    __device__ __forceinline__ v4f &at() {
+        if constexpr (J == 0) return r0;
+        else if constexpr (J == 1) return r1;
+        else if constexpr (J == 2) return r2;
+        else if constexpr (J == 3) return r3;
+        else if constexpr (J == 4) return r4;
+        else if constexpr (J == 5) return r5;
+        else if constexpr (J == 6) return r6;
+        else return r7;
+    }
+};
+
+// N gathers of one batch: the index broadcast is folded into the address add (v_add_u32_dpp), padding slots read zeros past the table
+template <int J, int N>
+struct SellIssue {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellRows &x, const WT &w, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+        x.template at<J>() = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, ent_col<J>(w) + lane_off, 0, 0));
+        SellIssue<J + 1, N>::run(x, w, rs, lane_off);
+    }
+};
+template <int N>
+struct SellIssue<N, N> {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellRows &, const WT &, const __amdgpu_buffer_rsrc_t, const int) {}
+};
+template <int J, int N>
+struct SellConsume {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellAcc &acc, SellRows &x, const WT &w) {
+        const v4f v = x.template at<J>();
+        if constexpr (std::is_same<WT, v2i>::value) {
+            acc.lo += __builtin_shufflevector(v, v, 0, 1);
+            acc.hi += __builtin_shufflevector(v, v, 2, 3);
+        } else {
+            fma_row(acc, ent_val<J>(w), v);
+        }
+        SellConsume<J + 1, N>::run(acc, x, w);
+    }
+};
+template <int N>
+struct SellConsume<N, N> {
+    template <class WT>
+    static __device__ __forceinline__ void run(SellAcc &, SellRows &, const WT &) {}
+};
+// n in {2, 4, 6, 8} slots: pairs issued / consumed behind nested tests.  (Four separate bodies selected by n — the r03 form —
+// let hipcc merge their common tails into one block that picks the register by a pointer phi: the rows went to scratch.)
+template <class WT>
+__device__ __forceinline__ void sell_issue_n(const int n, SellRows &x, const WT &w, const __amdgpu_buffer_rsrc_t rs, const int lane_off) {
+    SellIssue<0, 2>::run(x, w, rs, lane_off);
+    if (n > 2) {
+        SellIssue<2, 4>::run(x, w, rs, lane_off);
+        if (n > 4) {
+            SellIssue<4, 6>::run(x, w, rs, lane_off);
+            if (n > 6) SellIssue<6, 8>::run(x, w, rs, lane_off);
+        }
+    }
+}
+template <class WT>
+__device__ __forceinline__ void sell_consume_n(const int n, SellAcc &acc, SellRows &x, const WT &w) {
+    SellConsume<0, 2>::run(acc, x, w);
+    if (n > 2) {
+        SellConsume<2, 4>::run(acc, x, w);
+        if (n > 4) {
+            SellConsume<4, 6>::run(acc, x, w);
+            if (n > 6) SellConsume<6, 8>::run(acc, x, w);
+        }
+    }
+}
+
+// offsets of a row-major table whose rows are 2 W << sh floats apart (sh = -1: W floats) from ent0's (rows of 2 W floats);
+// padding stays out of range (the shifted padding offset of a 4 W row wrapped into the table for lanes 2.. of a
+// lane-group — harmless only while row 0 is finite)
+template <class WT>
+__device__ __forceinline__ void sell_widen(WT &e, const int sh) {
+    if constexpr (std::is_same<WT, v4i>::value) {
+        if (sh > 0) {
+            if (e.x != kSellPast) e.x <<= sh;
+            if (e.z != kSellPast) e.z <<= sh;
+        } else if (sh < 0) {  // half the stride; kSellPast / 2 is still past every table that has row-major entries
+            e.x >>= 1;
+            e.z >>= 1;
+        }
+    }
+}
+
+// The gathers of one unit: batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds
+// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  DEPTH = 1: one batch of gathers in flight per wave.
+// (r04, measured and removed: the unit's first batch from a fixed-stride block requested together with the header instead of
+// after it — 93.4 vs 93.5 us per propagation at the Gowalla shape, 126.0 vs 126.2 at Yelp2018: the header -> entries round trip
+// is not on the critical path; profiles/r04_launch_forms.jsonl)
+template <int W, int NS, class WT>
+__device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
+                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
+    constexpr int LGW = 64 / (W / 4);
+    if (nc <= 0) return;
+    int sb = min(8, nc);
+    // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
+    WT w = {};
+    if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
+    sell_widen(w, sh);
+    for (int k = 0; k < nc; k += 8) {
+        const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
+        WT wn = {};
+        SellRows x;
+        sell_issue_n(sb, x, w, rs, lane_off);
+        if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+        sell_consume_n(sb, acc, x, w);
+        sell_widen(wn, sh);
+        w = wn;
+        sb = sbn;
+    }
+}
+
+// DEPTH = 2: the gathers of batch b + 1 are issued before batch b is consumed (two register sets, the loop unrolled over
+// them): 16 wave-loads in flight per wave instead of 8 draining to 0 between batches (the wave's memory pipe
+// emptied at every s_waitcnt).  Same summation order as DEPTH = 1: bit-identical results.
+template <int W, int NS, class WT>
+__device__ __forceinline__ void sell_gather2(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
+                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
+    constexpr int LGW = 64 / (W / 4);
+    if (nc <= 0) return;
+    const int nb = (nc + 7) >> 3;
+    auto size_of = [&](int b) __attribute__((always_inline)) { return min(8, nc - 8 * b); };
+    auto load = [&](int b, int sz) __attribute__((always_inline)) {
+        WT e = {};
+        if (2 * q4 < sz) e = base[((LGW * 8 * b) >> 1) + lg * (sz >> 1) + q4];
+        sell_widen(e, sh);
+        return e;
+    };
+    int szP = size_of(0), szQ = 0;
+    WT wP = load(0, szP), wQ = {};
+    SellRows xP, xQ;
+    sell_issue_n(szP, xP, wP, rs, lane_off);
+    if (nb > 1) wQ = load(1, size_of(1));
+    for (int b = 0; b < nb; b += 2) {
+        szQ = b + 1 < nb ? size_of(b + 1) : 0;
+        if (szQ) sell_issue_n(szQ, xQ, wQ, rs, lane_off);
+        WT wN = {};
+        if (b + 2 < nb) wN = load(b + 2, size_of(b + 2));
+        sell_consume_n(szP, acc, xP, wP);
+        if (!szQ) break;
+        szP = b + 2 < nb ? size_of(b + 2) : 0;
+        wP = wN;
+        if (szP) sell_issue_n(szP, xP, wP, rs, lane_off);
+        WT wN2 = {};
+        if (b + 3 < nb) wN2 = load(b + 3, size_of(b + 3));
+        sell_consume_n(szQ, acc, xQ, wQ);
+        wQ = wN2;
+        if (!szP) break;
+    }
+}
+
+__device__ __forceinline__ float sell_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
+
+// the buffer resource of the table a (class, slab) role gathers from
+// (a row-major table is read as its column piece s: 128-byte (W = 32) pieces at an NS W stride — whole L2 lines, the same
+// footprint per XCD as a slab)
+template <int W, int NS>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sell_table_rsrc(SellParamsK &p, const SellLayer &L, const int cls, const int s) {
+    const float *xtab = L.x_rm ? p.rm[1 - cls] + s * W : L.xs + p.slab_off[1 - cls][s];
+    const int n_tab = p.n_class[1 - cls];
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0,
+                                             L.x_rm ? (unsigned)n_tab * (unsigned)(p.rm_ld * 4) - s * W * 4 : n_tab * W * 4, 0x00020000);
+}
+
+// One unit: the gathers of its lane-groups, the reduction of split rows, the epilogue.  h = the unit's header; rs = the buffer
+// resource of the gathered table (class 1 - cls, slab s); s_wide = the workgroup's [4][W] LDS scratch of wide rows.
+template <int W, int NS, bool COMPACT, int DEPTH>
+__device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, const int cls, const int s, const int4 h, const __amdgpu_buffer_rsrc_t rs,
+                                          const v4i *ents, const int64_t ybase, float (*s_wide)[W]) {
+    constexpr int G = W / 4;      // lanes per lane-group
+    constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
+    constexpr int D = NS * W;     // row width: NS slabs
+    using WT = std::conditional_t<COMPACT, v2i, v4i>;
+    const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = (threadIdx.x >> 6) & 3;
+    const int lane_off = sl * 16;
+    const int row0 = h.y, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
+    const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
+    // the epilogue's row-indexed scalars are requested before the gathers (they would otherwise be two dependent round trips
+    // at the end of the wave: orig[] -> the row-major addend)
+    const int r = lg >> lp;
+    const int row = row0 + (r < nrows ? r : 0);
+    const int cbase = cls ? p.n_class[0] : 0;
+    int node = 0;
+    float r_i = 1.f;
+    if constexpr (COMPACT || DEPTH == 2) {  // (the valued DEPTH-1 instantiation has no register to spare: it asks at the end)
+        if (L.last || L.prev0_rm) node = p.orig[cbase + row];
+        if (COMPACT || L.store_scaled) r_i = p.rs[cbase + row];
+    }
+    SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
+    // (ent0's offsets are rows of 2 W floats: a 4 W or a W row-major operand rescales them)
+    const WT *ebase;
+    if constexpr (COMPACT) ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
+    else ebase = ents + (h.x >> 1);
+    const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
+    if constexpr (DEPTH == 2) sell_gather2<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
+    else sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
+    // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
+    const int parts = 1 << lp;
+    if (lp > 0) {
+#pragma unroll
+        for (int off = 1; off < LGW; off <<= 1) {
+            const float a0 = __shfl_xor(acc.lo.x, off * G), a1 = __shfl_xor(acc.lo.y, off * G);
+            const float a2 = __shfl_xor(acc.hi.x, off * G), a3 = __shfl_xor(acc.hi.y, off * G);
+            if (off < parts) { acc.lo.x += a0; acc.lo.y += a1; acc.hi.x += a2; acc.hi.y += a3; }
+        }
+    }
+    if (wide) {  // 4 waves x LGW pieces of ONE row: per-wave partial sums through LDS, added in wave order
+        if (lg == 0) *reinterpret_cast<float4 *>(&s_wide[wave][sl * 4]) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+        __syncthreads();
+        if (wave == 0 && lg == 0) {
+            float4 tsum = *reinterpret_cast<const float4 *>(&s_wide[0][sl * 4]);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const float4 o4 = *reinterpret_cast<const float4 *>(&s_wide[q][sl * 4]);
+                tsum.x += o4.x; tsum.y += o4.y; tsum.z += o4.z; tsum.w += o4.w;
+            }
+            acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
+        }
+        __syncthreads();  // (a wave that walks on to another wide unit must not overwrite s_wide under wave 0's reads)
+    }
+    const bool owner = (lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0);
+    // the noise row's norm spans all NS slabs: every lane-group reads the whole row (all lanes take part in the shuffles)
+    float nsc = 0.f;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L.last && p.noise) {
+        if constexpr (!(COMPACT || DEPTH == 2)) node = p.orig[cbase + row];
+        const float *nrow = p.noise + (int64_t)node * D + sl * 4;
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(nrow + q * W);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            if (q == s) nz = v;
+        }
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) ss += __shfl_xor(ss, off);
+        nsc = p.eps / fmaxf(sqrtf(ss), 1e-12f);
+    }
+    if (owner) {
+    const int64_t o = ybase + (int64_t)row * W + sl * 4;
+    if constexpr (!(COMPACT || DEPTH == 2)) {
+        if (L.last || L.prev0_rm) node = p.orig[cbase + row];
+    }
+    const int64_t orm = (int64_t)node * D + s * W + sl * 4;  // row-major [N, D], the reference's numbering
+    const float *prev0 = L.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * D) : p.prev[0] + o;
+    float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
+    if constexpr (!(COMPACT || DEPTH == 2)) {
+        if (L.store_scaled) r_i = p.rs[cbase + row];
+    }
+    if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
+    if (L.last) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ntl = (p.nt & 2) != 0, nts = (p.nt & 1) != 0;
+        if (L.n_prev) sum = ld4(prev0, ntl);
+        if (L.prev_scaled) {  // the layers in between are stored scaled: E_k = z_k / r_i
+            float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 1; i < L.n_prev; ++i) {
+                const float4 q = ld4(p.prev[i] + o, ntl);
+                zs.x += q.x; zs.y += q.y; zs.z += q.z; zs.w += q.w;
+            }
+            const float ir = p.irs[cbase + row];
+            sum.x += zs.x * ir; sum.y += zs.y * ir; sum.z += zs.z * ir; sum.w += zs.w * ir;
+        } else {
+            for (int i = 1; i < L.n_prev; ++i) {
+                const float4 q = ld4(p.prev[i] + (p.prev_rm_all ? orm : o), ntl);
+                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+            }
+        }
+        if (p.out2) st4(p.out2 + orm, y, nts);
+        sum.x = (sum.x + y.x) / p.denom; sum.y = (sum.y + y.y) / p.denom;
+        sum.z = (sum.z + y.z) / p.denom; sum.w = (sum.w + y.w) / p.denom;
+        if (p.noise) {  // (a plain layer: n_prev = 0, denom = 1: sum = y)
+            sum.x = fmaf(sell_sgn(sum.x) * nz.x, nsc, sum.x); sum.y = fmaf(sell_sgn(sum.y) * nz.y, nsc, sum.y);
+            sum.z = fmaf(sell_sgn(sum.z) * nz.z, nsc, sum.z); sum.w = fmaf(sell_sgn(sum.w) * nz.w, nsc, sum.w);
+        }
+        st4(p.out + orm, sum, nts);
+    } else {
+        if (L.n_prev) {  // a step of the backward chain: y = g + A x
+            const float4 q = *reinterpret_cast<const float4 *>(prev0);
+            y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w;
+        }
+        if (L.store_scaled) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }
+        st4(L.ys + o, y, (p.nt & 1) != 0);
+    }
+    }
+}
+
+}  // namespace rbg
