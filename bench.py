@@ -119,6 +119,9 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
         total_reps, total_s = total_reps + reps, total_s + el
     coracle.set_num_threads(max_threads)
     return {"value": sorted(samples)[1], "unit": "propagations/s", "cores": best, "kind": "port",
+            "cores_note": f"best of the thread probe = {best} of the {os.cpu_count()} logical CPUs of this host: the OpenMP row loop of the "
+                          "restatement stops scaling past one CCD (see thread_probe_prop_per_s), so this is the reference's CPU path on "
+                          f"{best} cores, not on all of them",
             "samples_prop_per_s": [round(v, 1) for v in samples],
             "thread_probe_prop_per_s": {str(k): round(v, 1) for k, v in probe.items()},
             "thread_pinning": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
@@ -201,9 +204,12 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         rbg.ops.lightgcn_forward_raw(gq, uq, iq, k_layers, out=oq, layers=lq)
 
     ex["propagation_hot_us"] = time_us(hot, iters=100)
-    rbg.set_option("sell", 0)
-    ex["propagation_binned_kernel_us"] = time_us(hot, iters=100)  # the same propagation with the column-slab path off
-    rbg.set_option("sell", 1)
+    prev_sell = rbg.get_option("sell")
+    try:
+        rbg.set_option("sell", 0)
+        ex["propagation_binned_kernel_us"] = time_us(hot, iters=100)  # the same propagation with the column-slab path off
+    finally:
+        rbg.set_option("sell", prev_sell)
     ex["propagation_rotated_us"] = time_us(rotated, iters=100)
     ex["propagation_rotated_sets"] = n_sets
     ex["propagation_rotated_footprint_MB"] = round(n_sets * set_mb, 1)
@@ -249,8 +255,17 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             go, gl = torch.empty(gn, dd, device=dev), torch.empty(max(k_layers, 1), gn, dd, device=dev)
             pus = time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl),
                           iters=5 if big else 20, warm=1 if big else 3)
-            ex[key].update(propagation_us=pus, propagation_kernel=gg.propagation_kernel_name(dd),
+            ex[key].update(propagation_us=pus, propagation_kernel=gg.propagation_kernel_name(dd), sell_status=gg.sell_status(),
                            propagation_frac=(k_layers * gb) / (pus * 1e-6) / 1e9 / HBM_PEAK_GBPS)
+            # a parity figure for every shape that is timed: the fixed point A sqrt(deg) = sqrt(deg) on every
+            # row through the same kernel — relative to sqrt(deg); the oracle-checked tests of these
+            # shapes are tests/test_gpu_sell_native.py::test_parity_at_scale_through_the_plan
+            deg_all = np.bincount(np.concatenate([gu, gi + gnu]), minlength=gn)
+            root = torch.from_numpy(np.sqrt(deg_all).astype(np.float32)).to(dev)
+            xr = root[:, None].expand(gn, dd).contiguous()
+            yr = rbg.ops.spmm_raw(gg, xr, out=gy)
+            ex[key]["fixed_point_rel_err"] = float(((yr - xr).abs() / root[:, None].clamp(min=1.0)).max())
+            del xr, yr, root
             if name in ("g-1.3m", "amazon-book"):
                 ref[name] = 1e6 / pus
             del go, gl
@@ -556,9 +571,10 @@ def main():
             raise SystemExit(f"parity gate failed: max|E_hip - E_oracle| = {err:.3e} > 1e-5")
         extra.update(max_abs_err_vs_oracle=err, bins=graph.bins(d), tuning=rbg.get_tuning())
         # the kernel a propagation of this handle launches per layer: the column-slab kernel (csrc/sell.hip; a SELL plan is
-        # attached by the first propagation) or the binned SpMM kernel
+        # built by rbg_graph_create itself) or — sell_status says why — the binned SpMM kernel
         kernel_name = graph.propagation_kernel_name(d)
-        extra["propagation_path"] = {"kernel": kernel_name, "sell_plan_attached": bool(graph.has_sell(d)),
+        extra["propagation_path"] = {"kernel": kernel_name, "sell_plan_attached": bool(graph.has_sell(d)), "sell_status": graph.sell_status(),
+                                     "planner": "rbg_graph_plan_sell inside rbg_graph_create (csrc/sell_plan.hip)",
                                      "launches_per_propagation": k_layers + (1 if graph.has_sell(d) and not rbg.get_option("sell_rowmajor") else 0),
                                      "note": ("column-slab path: K launches of sell_spmm_kernel — the first gathers E0 where it lies through the "
                                               "valued entries (instantiation <.., false>), the others read the scaled slabs through 4-byte entries "
@@ -646,6 +662,15 @@ def main():
     elapsed, ev_ms = timed_loop(step, args.steps, args.warmup + clock_warmup, world, gloo_group if world > 1 else None, graph=step_graph)
     # (timed_loop replays the captured graph once, untimed, to upload it: K more propagations of warm-up)
     extra["warmup_effective"] = args.warmup + clock_warmup + (args.steps if step_graph is not None else 0)
+    # EVERY propagation this process issued before the headline's timed region: the parity step, the
+    # plain-protocol loop (W + K), the capture's warm-up step, then the region's own warm-up (`warmup_effective`)
+    if world == 1:
+        extra["propagations_before_timed_region"] = {
+            "parity_gate": 1, "plain_protocol_loop": args.warmup + args.steps,
+            "graph_capture_warmup": 1 if step_graph is not None else 0, "region_warmup": extra["warmup_effective"],
+            "total": 1 + args.warmup + args.steps + (1 if step_graph is not None else 0) + extra["warmup_effective"],
+            "note": "the plain-protocol figure (value_at_driver_flags_no_clock_warmup: W warm-up steps exactly, K host-issued steps) is "
+                    "the one measured with nothing but the parity step in front of it"}
     extra["timed_region"] = "one HIP-graph replay of the K steps" if step_graph is not None else "K host-issued steps"
     if world == 1:
         el_s, ev_s = timed_loop(step, args.steps, args.warmup + 150, world, None, graph=step_graph)
@@ -825,10 +850,17 @@ def main():
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean layer duration; duration = HIP-event "
                                  "time of the timed region / (steps x K layers), so inter-kernel gaps and (N>1) halo waits count against "
-                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r03_bench_kernel_stats.csv"},
+                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r04_bench_kernel_stats.csv"},
             "cpu_baseline": None,
         }
         result.update(extra)
+        if world > 1:
+            real = extra.get("transport") == "nccl" and torch.cuda.device_count() >= world
+            result["measured"] = bool(real)
+            if not real:
+                result["measured_note"] = ("NOT a measurement of multi-GPU scaling: the ranks share "
+                                           f"{torch.cuda.device_count()} GPU(s) and exchange halos through the host (staged gloo transport); "
+                                           "a functional run of the N > 1 code path only")
         if world == 1 and not args.no_extras:
             result["extras"] = extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev)
         if world == 1 and args.cpu_seconds > 0:

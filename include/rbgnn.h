@@ -98,9 +98,11 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)
  *   "sell_auto"   : 1 (default) = rbg_graph_create* plans the column-slab propagation (rbg_graph_plan_sell) for every device graph
  *                   with a user / item boundary; 0 = no plan until rbg_graph_plan_sell / rbg_graph_attach_sell is called
- *   "sell_depth"  : gather batches a wave of the column-slab kernel keeps in flight: 1 or 2 (two register sets)
- *   "sell_class_serial" : -1 (default) = auto (tables beyond ~200 MB), 0 = one launch per layer (user rows on XCDs 0-3, item
- *                   rows on 4-7), 1 = one launch per row class (all eight XCDs gather from ONE table at a time)
+ *   "sell_depth"  : gather batches a wave of the column-slab kernel keeps in flight: 1 (default) or 2 (two register sets;
+ *                   measured +7 % time at the Gowalla shape, neutral elsewhere)
+ *   "sell_class_serial" : 1 = one launch per row class (all eight XCDs gather from ONE table at a time); default (-1 / 0) = one
+ *                   launch per layer (user rows on XCDs 0-3, item rows on 4-7).  Measured neutral (-0.4 % at 1.3 M nodes, +4 % at
+ *                   the Amazon-Book shape)
  *   "fail_alloc_after" : test hook: the (n + 1)-th device allocation of the plan code from now fails once (-1 = off)
  *   "sell_units_per_wave" : units a wave of the column-slab kernel walks (default 1 = one wave per unit; more measured slower)
  *   "sell_nt"     : non-temporal hints in that kernel's epilogue (bit 0 stores, bit 1 the mean's addend loads; default 0, no effect measured)

@@ -198,12 +198,10 @@ const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
 }
 bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
 
-// one launch per row class (all eight XCDs on one table at a time) when the two tables together overflow the Infinity Cache
-static bool sell_class_serial(const SellDev *sw, int NS) {
-    const int o = opt_sell_class_serial();
-    if (o >= 0) return o != 0;
-    return ((int64_t)sw->n_class[0] + sw->n_class[1]) * NS * sw->W * 4 > ((int64_t)200 << 20);
-}
+// one launch per row class (all eight XCDs on one table at a time: the live gathered set is one table instead of two).  Measured
+// (profiles/r04_launch_forms.jsonl): G-1.3M 3 323 -> 3 310 us per propagation (-0.4 %), Amazon-Book 292 -> 304 us (+4 %): the
+// Infinity Cache is not what bounds the 1.3 M-node shape (its fabric traffic is: 7.3 TB/s) — off unless asked for.
+static bool sell_class_serial(const SellDev *, int) { return opt_sell_class_serial() == 1; }
 
 template <int W, int NS, int DEPTH>
 static int sell_launch_d(const SellDev *sw, SellParams &p, hipStream_t s) {

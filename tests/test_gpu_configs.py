@@ -233,6 +233,12 @@ def test_config5_sgl_ed_views_d128(rbg, cuda, frac, record_property):
     print(f"generated in {t_gen:.0f} s, model + one ED view in {t_build:.0f} s, max degree "
           f"{int(np.bincount(uid, minlength=nu).max())}")
     assert view.nnz == 2 * int(e * (1 - 0.1)) and model.graph.nnz == 2 * e
+    # the full graph and the view were planned by rbg_graph_create itself (no row cap: 15 M rows, 400 M entries cut in HBM), so
+    # everything below runs the column-slab kernel over four 32-wide slabs (this config ran the binned one)
+    for gph in (model.graph, view):
+        assert gph.sell_status() == "planned", gph.sell_status()
+        assert gph.propagation_kernel_name(d).startswith("sell_spmm_kernel<32, 4, true") and gph.spmm_kernel_name(d).startswith("sell_spmm_kernel<32, 4")
+    print("plan of the full graph:", model.graph.sell_info())
     if frac == 1.0:  # the full shape, by its constants (GPUTEST's tail shows which size ran: the id carries the fraction)
         assert (nu, ni, model.graph.nnz, view.nnz) == (10_000_001, 5_000_001, 400_000_000, 360_000_000)
 

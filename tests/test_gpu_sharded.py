@@ -471,3 +471,77 @@ def test_captured_sharded_propagation_replays_bit_identically_and_exits_cleanly(
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["replay_bit_identical"] == [True, True, True] and rec["replay_follows_input"] and rec["clean_exit"], rec
     assert rec["halo_rows"] > 0
+
+
+# ---- feature-column sharding (colsharded.py) ----------------------------------------------------------------------------
+
+def _worker_columns(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh, cs = rbg.sharded, rbg.colsharded
+        dev = torch.device("cuda:0")
+        n = nu + ni
+        rng = np.random.default_rng(4)
+        e0 = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+        user, pos, neg = rng.integers(1, nu, 256), rng.integers(1, ni, 256), rng.integers(1, ni, 256)
+        ds = rbg.InteractionDataset(uid, iid, nu, ni)
+        inter = {"user_id": torch.from_numpy(user).to(dev), "item_id": torch.from_numpy(pos).to(dev), "neg_item_id": torch.from_numpy(neg).to(dev)}
+        model = rbg.LightGCN({"device": "cuda:0", "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-3,
+                              "require_pow": False}, ds)
+        with torch.no_grad():
+            model.user_embedding.weight.copy_(torch.from_numpy(e0[:nu]))
+            model.item_embedding.weight.copy_(torch.from_numpy(e0[nu:]))
+        ref = model.calculate_loss(inter)
+        ref.backward()
+        ref_grad = torch.cat([model.user_embedding.weight.grad, model.item_embedding.weight.grad])
+        with torch.no_grad():
+            ru, ri = model.forward()
+        ref_out = torch.cat([ru, ri])
+        prop = cs.ColumnShardedPropagation(model.graph, nu, ni, d, sh.HipBackend(dev), rank=rank, world=world, group=dist.group.WORLD)
+        kernel = model.graph.propagation_kernel_name(prop.width)
+        tr = cs.ColumnShardedTrainer(prop, prop.slab_of(torch.from_numpy(e0).to(dev)), k_layers, lr=1e-2, reg_weight=1e-3)
+        out = prop.forward(tr.e0.detach(), k_layers)
+        loss = tr.loss(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        loss.backward()
+        torch.cuda.synchronize()
+        oerr = float((out - ref_out[:, prop.lo:prop.hi]).abs().max())
+        gerr = float((tr.e0.grad - ref_grad[:, prop.lo:prop.hi]).abs().max())
+        serr = float((prop.full_sort_scores(out, inter["user_id"][:8]) - ref_out[inter["user_id"][:8]] @ ref_out[nu:].T).abs().max())
+        v0 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        v1 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        res = (float(loss.detach()), float(ref.detach()), oerr, gerr, float(ref_grad.abs().max()), serr, v0, v1, kernel)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, res))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,d", [(2, 64), (4, 128), (2, 128)])
+def test_ranks_column_sharded_training_step_hip_backend(ref_inter, world, d):
+    """colsharded.ColumnShardedTrainer with the product backend, P ranks sharing cuda:0 (host-staged all-reduces): every rank
+    propagates its d / P columns through the column-slab kernel with NO exchange in the K layers (32 columns: <32, 1, .>; 64:
+    <32, 2, .>), and the loss, dL/dE0, the all-reduced score block and two optimizer steps match the single-device LightGCN
+    mirror on the same GPU (lightgcn.py:70-133)."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000) + 5 * world + d
+    procs = [ctx.Process(target=_worker_columns, args=(r, world, port, uid, iid, nu, ni, 3, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, (loss, ref, oerr, gerr, gscale, serr, v0, v1, kernel) in res:
+        assert kernel.startswith(f"sell_spmm_kernel<32, {d // world // 32}, true"), kernel
+        assert abs(loss - ref) <= 1e-5 * max(1.0, abs(ref)), (rank, loss, ref)
+        assert oerr <= 1e-5 and gerr <= 1e-5 * max(1.0, gscale) and serr <= 1e-5, (rank, oerr, gerr, serr)
+        assert abs(v0 - loss) <= 1e-6 * max(1.0, abs(loss)) and v1 < v0, (rank, v0, v1)
