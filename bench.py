@@ -703,6 +703,33 @@ def main():
             secondary = {"error": str(ex)[:300]}
         extra["other_scaling_mode"] = secondary
 
+    if world > 1 and strong_graph is not None and not args.no_secondary:
+        # The OTHER sharding of the same graph (r04, colsharded.py): every rank holds the whole graph and d / N columns of the
+        # tables — the K layers exchange nothing.  Timed with the same loop (barrier + synchronize, max over ranks); a global
+        # forward = all N slabs, so value = steps / time.  Reported beside the node-range headline the north_star names.
+        try:
+            su, si, snu, sni = strong_graph[:4]
+            width = d // world if d % world == 0 else 0
+            if width in (32, 64, 128):
+                from recbole_gnn_amd import colsharded as cs
+                gfull = rbg.GraphHandle.from_interactions(su, si, snu, sni, device=dev)
+                cprop = cs.ColumnShardedPropagation(gfull, snu, sni, d, sh.HipBackend(dev), rank=rank, world=world, group=gloo_group)
+                slab = xavier(snu + sni, width, gen).to(dev)
+                stepsc = max(10, min(args.steps, 100))
+                elc, evc = timed_loop(lambda: cprop.forward(slab, k_layers), stepsc, max(3, min(args.warmup, 10)), world, gloo_group)
+                bl_c, _ = rbg.synth.algorithmic_bytes(snu + sni, gfull.nnz, width, k_layers)
+                extra["column_sharding"] = {
+                    "value": stepsc / elc, "unit": "propagations/s", "ms_per_step": elc * 1e3 / stepsc, "steps": stepsc,
+                    "columns_per_rank": width, "kernel": gfull.propagation_kernel_name(width), "bytes_exchanged_per_layer": 0,
+                    "per_rank_roofline_frac": bl_c / (evc * 1e-3 / (stepsc * k_layers)) / 1e9 / HBM_PEAK_GBPS,
+                    "note": "feature-column sharding: the graph (its column-slab plan) is replicated, every rank propagates d / N columns "
+                            "of the tables; only the loss exchanges anything ([2 B] score partials per training step)"}
+                del gfull, cprop, slab
+            else:
+                extra["column_sharding"] = {"skipped": f"d / N = {d} / {world}: not a width the column-slab plan serves (32, 64, 128)"}
+        except Exception as ex:  # noqa: BLE001
+            extra["column_sharding"] = {"error": str(ex)[:200]}
+
     if world > 1:
         # phase breakdown of one sharded layer (each phase alone, back to back; rank-0 view) so the scaling
         # number comes with its explanation: halo exchange vs interior SpMM vs halo SpMM
