@@ -91,6 +91,10 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "mfma_split"  : 1 (default) = rbg_score_f32 / rbg_full_sort_topk_f32 split both fp32 operands into three bf16 terms and
  *                   form the six products of order >= 2^-16 on the bf16 matrix cores (fp32-MFMA accuracy at 2.3x its
  *                   rate); 0 = the exact-fp32 MFMA chain
+ *   "score_uniform" : 1 (default) = rbg_score_f32 with B >= 64 q users (q = 32 / gcd(n mod 32, 32)) gives every workgroup the users of
+ *                   ONE alignment class of the contiguous [B, n] output and shifts its item tiles to that class's line boundary:
+ *                   whole aligned lines are stored straight from the accumulators (r04: 178 -> 156 us at 4096 x 40 982 x 64);
+ *                   0 = the shifted store stream (16 cross-lane reads per tile), which small batches always use
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
  *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan

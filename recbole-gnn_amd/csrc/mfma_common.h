@@ -58,11 +58,15 @@ struct RowTile {
     float4 stage[NCHUNK * 2];
 
     __device__ __forceinline__ void fetch(const float *base, int64_t ld, int64_t n_rows, int d, int64_t tile, int tid) {
+        fetch_rows(base, ld, n_rows, d, tile * 32, tid);
+    }
+    // rows [row0, row0 + 32), clamped into [0, n_rows) on both sides (row0 may be negative: a tile shifted to a line boundary)
+    __device__ __forceinline__ void fetch_rows(const float *base, int64_t ld, int64_t n_rows, int d, int64_t row0, int tid) {
 #pragma unroll
         for (int k = 0; k < NCHUNK * 2; ++k) {
             const int f = tid + 256 * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            const int64_t r = tile * 32 + row;
-            const float *src = base + (r < n_rows ? r : n_rows - 1) * ld + c4;
+            const int64_t r = row0 + row;
+            const float *src = base + (r < n_rows ? (r < 0 ? 0 : r) : n_rows - 1) * ld + c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == RUN_FAST) {
                 v = *reinterpret_cast<const float4 *>(src);
@@ -157,11 +161,14 @@ struct RowTile3 {
     float4 stage[NSTAGE];
 
     __device__ __forceinline__ void fetch(const float *base, int64_t ld, int64_t n_rows, int d, int64_t tile, int tid) {
+        fetch_rows(base, ld, n_rows, d, tile * 32, tid);
+    }
+    __device__ __forceinline__ void fetch_rows(const float *base, int64_t ld, int64_t n_rows, int d, int64_t row0, int tid) {
 #pragma unroll
         for (int k = 0; k < NSTAGE; ++k) {
             const int f = tid + THREADS * k, row = f / (NCHUNK * 16), c4 = (f % (NCHUNK * 16)) * 4;
-            const int64_t r = tile * 32 + row;
-            const float *src = base + (r < n_rows ? r : n_rows - 1) * ld + c4;
+            const int64_t r = row0 + row;
+            const float *src = base + (r < n_rows ? (r < 0 ? 0 : r) : n_rows - 1) * ld + c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == RUN_FAST) {
                 v = *reinterpret_cast<const float4 *>(src);

@@ -267,6 +267,88 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
     RBG_SCORE_DUMP();
 }
 
+// r04: the same walk without the shifted store stream.  Rows u and u' of the contiguous [B, n] output start at the same
+// offset inside a 128-byte line iff (u - u') n = 0 mod 32, i.e. u = u' mod q with q = 32 / gcd(n mod 32, 32).  A workgroup that
+// takes its 128 users from ONE residue class r (user = r + q k) has one phase for all its rows, so it can shift its ITEM
+// tiles instead of its data: tile t covers items [32 t - delta, 32 t - delta + 32) with delta = (address of S[r][0] / 4) mod 32,
+// and every store instruction writes two whole, aligned lines straight from the accumulator — no cross-lane read (16
+// ds_bpermute per tile in score_kernel, where a wave spent 53 % of its time), no carried half lines (16 registers), no
+// head / tail code beyond a column mask on the first and the last tile.  Used when every class holds >= 64 users
+// (B >= 64 q; the reference's own evaluation batches of a few users keep score_kernel).
+// (a fourth resident workgroup per CU — the 16 carry registers are gone — measured 161 vs 157 us: three it stays)
+template <int NCHUNK, bool VEC, bool FAST, bool SPLIT>
+__global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) void score_uni_kernel(const float *__restrict__ U, int64_t ldu,
+                                                    const float *__restrict__ I, int64_t ldi, float *__restrict__ S,
+                                                    int64_t B, int64_t n, int d, int tiles_per_wave, int q) {
+    constexpr int MODE = FAST ? RUN_FAST : (VEC ? RUN_VEC : RUN_ANY);
+    using Tile = std::conditional_t<SPLIT, RowTile3<NCHUNK, MODE>, RowTile<NCHUNK, MODE>>;
+    using TileMem = std::conditional_t<SPLIT, typename RowTile3<NCHUNK, MODE>::Planes, float[32][NCHUNK * 64 + 4]>;
+    __shared__ __attribute__((aligned(16))) TileMem s_it[2];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform
+    const int i = lane & 31, h = lane >> 5;
+    const int r = (int)(blockIdx.y % (unsigned)q);                       // the residue class of this workgroup's users
+    const int64_t ut = (int64_t)(blockIdx.y / (unsigned)q) * 4 + wave;   // 32-user tile inside the class
+    const int64_t k_first = ut * 32;                                      // user = r + q (k_first + m)
+    const bool wave_live = r + (int64_t)q * k_first < B;                  // an idle wave still fetches and meets the barriers
+    const int delta = (int)(((reinterpret_cast<uintptr_t>(S) >> 2) + (uint64_t)r * (uint64_t)n) & 31u);
+    const int64_t n_tiles = (n + delta + 31) / 32;
+    const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wave;
+    const int64_t t1 = (t0 + tiles_per_wave < n_tiles) ? t0 + tiles_per_wave : n_tiles;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const int64_t ur = r + (int64_t)q * (k_first + i);                    // this lane's A row (clamped: never stored beyond B)
+    const float *urow = U + (ur < B ? ur : B - 1) * ldu;
+    float a[NCHUNK][32];
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) load_run32f<(FAST ? RUN_FAST : RUN_ANY)>(urow, true, c * 64 + h * 32, d, a[c]);
+    std::conditional_t<SPLIT, AFrag3<NCHUNK>, int> a3;
+    if constexpr (SPLIT) split_a(a, a3);  // the fp32 runs are dead after this
+    Tile tile;
+    auto fetch = [&](const int64_t t) __attribute__((always_inline)) { tile.fetch_rows(I, ldi, n, d, t * 32 - delta, tid); };
+    auto publish = [&](const int buf) __attribute__((always_inline)) { tile.publish(s_it[buf], tid); };
+    auto tile_product = [&](const int buf) __attribute__((always_inline)) {
+        if constexpr (SPLIT) return Tile::product(s_it[buf], a3, i, h);
+        else return Tile::product(s_it[buf], a, i, h);
+    };
+    // output rows of this wave: S + (r + q (k_first + m)) n, m = rowmap(reg, h): a uniform base + a 32-bit offset m q n
+    gfloat *const row0 = (gfloat *)(S + (r + (int64_t)q * k_first) * n);
+    const unsigned qn = (unsigned)((int64_t)q * n);
+    int64_t rows_left = (B - 1 - (r + (int64_t)q * k_first)) / q + 1;    // valid rows of this wave's tile
+    rows_left = rows_left < 0 ? 0 : (rows_left > 32 ? 32 : rows_left);
+    auto emit = [&](const int64_t t, const f32x16 &acc) __attribute__((always_inline)) {
+        const int64_t c0 = t * 32 - delta;                                // first column of the tile (uniform)
+        gfloat *base = row0 + c0;
+        if (rows_left == 32 && c0 >= 0 && c0 + 32 <= n) {                 // interior: 16 unconditional whole-line stores
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) __builtin_nontemporal_store(acc[rr], &base[(unsigned)mfma_rowmap(rr, h) * qn + (unsigned)i]);
+        } else {
+            const bool col_ok = c0 + i >= 0 && c0 + i < n;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int m = mfma_rowmap(rr, h);
+                if (col_ok && m < rows_left) base[(int64_t)m * qn + i] = acc[rr];
+            }
+        }
+    };
+    // the same pipeline as score_kernel: product(t) | publish(t + 1) | fetch(t + 2) | stores(t) | barrier
+    if (t0 < t1) {
+        fetch(t0);
+        publish(0);
+        if (t0 + 1 < t1) fetch(t0 + 1);
+    }
+    __syncthreads();
+    for (int64_t t = t0; t < t1; ++t) {
+        const int buf = (int)(t - t0) & 1;
+        f32x16 acc = zero;
+        if (wave_live) acc = tile_product(buf);
+        if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        if (t + 2 < t1) fetch(t + 2);
+        if (wave_live) emit(t, acc);
+        __syncthreads();
+    }
+}
+
 // (Tried, r02: a role-specialised variant — one loader wave publishing the tiles, four compute waves that only multiply
 // and store, so that no wave ever waits on `vmcnt` behind its own stores.  Correct, but slower: 237 vs 216 us at d = 64,
 // 359 vs 308 us at d = 128 (B = 4096 x 40 982, interleaved timing, profiles/r02_split_probe.jsonl): with 5-wave
@@ -293,6 +375,28 @@ static int launch_score(const float *U, int64_t ldu, const float *I, int64_t ldi
     const int64_t gx = (n_tiles + tiles_per_wave - 1) / tiles_per_wave;
     if (gx > INT32_MAX || gy > 65535) return fail(RBG_EUNSUPPORTED, "score grid too large (B = %lld)", (long long)B);
     dim3 grid((unsigned)gx, (unsigned)gy);
+    if constexpr (NCHUNK != 0) {
+        // uniform-phase form (score_uni_kernel): the users of a workgroup come from one residue class mod q
+        int q = 1;
+        for (int g = (int)(n & 31); q < 32 && (g * q) % 32 != 0; q <<= 1) {}
+        if (opt_score_uniform() && B >= 64 * (int64_t)q && (int64_t)q * n * 32 < ((int64_t)1 << 32)) {
+            const int64_t bc = (B + q - 1) / q, wg_per_class = ((bc + 31) / 32 + 3) / 4;
+            const int64_t gyu = wg_per_class * q;
+            if (gyu <= 65535) {
+                dim3 gridu((unsigned)((n_tiles + 1 + tiles_per_wave - 1) / tiles_per_wave), (unsigned)gyu);  // (+1: the shift may add a tile)
+                const bool fastu = vec && d == 64 * NCHUNK;
+                if (opt_mfma_split()) {
+                    if (fastu) hipLaunchKernelGGL((score_uni_kernel<NCHUNK, true, true, true>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                    else if (vec) hipLaunchKernelGGL((score_uni_kernel<NCHUNK, true, false, true>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                    else hipLaunchKernelGGL((score_uni_kernel<NCHUNK, false, false, true>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                } else if (fastu) hipLaunchKernelGGL((score_uni_kernel<NCHUNK, true, true, false>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                else if (vec) hipLaunchKernelGGL((score_uni_kernel<NCHUNK, true, false, false>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                else hipLaunchKernelGGL((score_uni_kernel<NCHUNK, false, false, false>), gridu, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave, q);
+                RBG_HIP(hipGetLastError());
+                return RBG_OK;
+            }
+        }
+    }
     if constexpr (NCHUNK == 0) {
         if (vec)
             hipLaunchKernelGGL((score_generic_kernel<true>), grid, dim3(256), 0, s, U, ldu, I, ldi, S, B, n, d, (int)tiles_per_wave);

@@ -504,3 +504,46 @@ def test_parity_at_scale_through_the_plan(rbg, cuda, name):
     yr = rbg.ops.spmm_raw(h, xr)
     rel = ((yr - xr).abs() / root[:, None].clamp(min=1.0)).max()
     assert float(rel) <= 5e-5 and float(yr[root == 0].abs().max()) == 0.0
+
+
+# ---- scoring: the uniform-phase store stream (csrc/score.hip::score_uni_kernel) ------------------------------------------------
+
+def test_score_uniform_phase_store_stream(rbg, cuda):
+    """r04: workgroups of rbg_score_f32 (lightgcn.py:123-133) take their 128 users from ONE alignment class u = r mod q
+    (q = 32 / gcd(n mod 32, 32)) and shift their item tiles to that class's line boundary, so every store is a whole aligned
+    line straight from the accumulator.  Every q (n mod 32 = 0, 16, 8, 4, 2, odd), user counts that leave classes ragged,
+    output bases at several 128-byte phases, d = 64 / 20 / 128 / 256, forced walk lengths: bit-identical to the shuffled store
+    stream (option "score_uniform" = 0: the same products in the same order), float64-checked, and nothing outside the
+    [B, n] block is written."""
+    import ctypes
+    lib, c_vp = rbg._lib.lib, ctypes.c_void_p
+    gen = torch.Generator().manual_seed(78)
+    pad = 96
+    try:
+        for tiles in (0, 1, 3):
+            rbg.set_option("score_tiles", tiles)
+            for d in (64, 20, 128, 256):
+                for n in (1024, 1040, 1000, 996, 994, 993, 65, 33):
+                    for b in (2048, 2051, 4096 + 7, 70 * 32):
+                        if (tiles or d != 64) and (n, b) not in ((994, 2051), (993, 70 * 32), (1040, 2048)):
+                            continue
+                        u = torch.randn(b, d, generator=gen).to(cuda)
+                        it = torch.randn(n, d, generator=gen).to(cuda)
+                        for off in (0, 1, 21):
+                            res = []
+                            for uni in (1, 0):
+                                rbg.set_option("score_uniform", uni)
+                                buf = torch.full((pad + off + b * n + pad,), -777.0, device=cuda)
+                                out = buf[pad + off: pad + off + b * n]
+                                rc = lib.rbg_score_f32(c_vp(u.data_ptr()), d, c_vp(it.data_ptr()), d, c_vp(out.data_ptr()), b, n, d,
+                                                       c_vp(torch.cuda.current_stream().cuda_stream))
+                                assert rc == 0, lib.rbg_last_error()
+                                assert bool((buf[: pad + off] == -777.0).all()) and bool((buf[pad + off + b * n:] == -777.0).all()), \
+                                    (tiles, d, b, n, off, uni, "wrote outside the output")
+                                res.append(out.view(b, n).clone())
+                            assert torch.equal(res[0], res[1]), (tiles, d, b, n, off)
+                        ref = u[:64].cpu().double() @ it.cpu().double().T
+                        close(res[0][:64], ref, tol=2e-6 * max(1, d / 64))
+    finally:
+        rbg.set_option("score_tiles", 0)
+        rbg.set_option("score_uniform", 1)
