@@ -81,7 +81,7 @@ class ColumnShardedPropagation:
     """One rank's share: the replicated graph + columns ``[lo, hi)`` of everything dense.
 
     ``backend``: ``sharded.HipBackend`` (the product: librbgnn.so on this rank's GPU) or any object with the same
-    ``make_graph / spmm`` calls (the tests inject the CPU oracle).  ``graph``: the backend's handle of the FULL normalized
+    ``make_graph / spmm`` calls (the tests inject a CPU test double).  ``graph``: the backend's handle of the FULL normalized
     adjacency (``backend.make_graph(csr, n, n_users)`` or a ``GraphHandle`` built from the interactions)."""
 
     def __init__(self, graph, n_users, n_items, d, backend, rank=0, world=1, group=None):
