@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--partition", choices=["auto", "ranges", "striped"], default="auto",
                     help="strong scaling: contiguous nnz-balanced id ranges, or degree-striped (degree order dealt round-robin); "
                          "auto = the one with the smaller max over ranks of (nnz + halo rows)")
+    ap.add_argument("--shard", choices=["rows", "columns"], default="rows",
+                    help="N>1 headline: rows = node-range shards + halo exchange (the mode BASELINE.json's north_star names); columns = "
+                         "feature-column shards (colsharded.py: the K layers exchange nothing).  Both are measured in a strong-scaling "
+                         "run; this picks which one is `value`, the other is reported under `column_sharding` / `node_range_sharding`")
     ap.add_argument("--no-train-extra", action="store_true", help="N>1: skip the sharded SGL training-step measurement")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins a gloo group, rank 0 prints {\"launch_check\": world} (no GPU needed)")
@@ -703,6 +707,11 @@ def main():
             secondary = {"error": str(ex)[:300]}
         extra["other_scaling_mode"] = secondary
 
+    if world > 1:
+        try:
+            extra["halo_per_layer(rank 0)"] = prop.halo_bytes_per_layer(d)
+        except Exception:  # noqa: BLE001
+            pass
     if world > 1 and strong_graph is not None and not args.no_secondary:
         # The OTHER sharding of the same graph (r04, colsharded.py): every rank holds the whole graph and d / N columns of the
         # tables — the K layers exchange nothing.  Timed with the same loop (barrier + synchronize, max over ranks); a global
@@ -881,6 +890,14 @@ def main():
             "cpu_baseline": None,
         }
         result.update(extra)
+        if world > 1 and args.shard == "columns" and isinstance(extra.get("column_sharding"), dict) and extra["column_sharding"].get("value"):
+            cs_ = extra["column_sharding"]  # the column-sharded propagation becomes the headline, the node-range one is kept beside it
+            result["node_range_sharding"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "roofline_frac": result["roofline"]["frac"],
+                                             "sharding": result["config"]["sharding"]}
+            result["value"], result["ms_per_step"], result["steps"] = cs_["value"], cs_["ms_per_step"], cs_["steps"]
+            result["config"]["sharding"] = f"feature-column shards x{world}: {cs_['columns_per_rank']} columns per rank, nothing exchanged in the K layers"
+            result["roofline"].update(frac=cs_["per_rank_roofline_frac"], achieved=cs_["per_rank_roofline_frac"] * HBM_PEAK_GBPS, kernel=cs_["kernel"],
+                                      note="per-rank: algorithmic bytes of the rank's slab layer / its mean layer duration")
         if world > 1:
             real = extra.get("transport") == "nccl" and torch.cuda.device_count() >= world
             result["measured"] = bool(real)

@@ -2,7 +2,7 @@
 
 ``Y = Â·X`` acts on every column of X independently, so the K layers of ``LightGCN.forward`` / ``SGL.forward``
 (lightgcn.py:70-81, sgl.py:128-145) need NO communication at all when the embedding tables are cut by COLUMNS instead of by
-rows: rank r holds the whole normalized adjacency (its column-slab plan: 3.3 GB at the config-#5 shape — replicated, as the
+rows: rank r holds the whole normalized adjacency (CSR 3.3 GB + column-slab plan ≈ 10 GB at the config-#5 shape, of 288 — replicated, as the
 reference replicates the dataset on every host) and the ``d / P`` columns ``[r d/P, (r + 1) d/P)`` of the two tables, of every
 layer, of the mean and of the Adam moments.  On an unstructured power-law graph this is the only sharding whose K layers scale:
 the node-range mode (``sharded.py``, the mode the north_star names) ships 98 % of the table per layer at P = 4 on the

@@ -367,9 +367,23 @@ class ShardedPropagation:
     Which is faster depends on the machine: on one GPU with a world-size-1 RCCL group (r01, devtools/nccl1_probe.py) the
     second stream cost ~35 us of cross-stream event latency per layer and hid nothing (there was no link time to hide:
     325 vs 259 us per propagation); with real peers the single-stream layer exposes the whole collective.  ``autotune``
-    measures both on the actual group and keeps the faster."""
+    measures both on the actual group and keeps the faster.  Default (``overlap=None``): on under "nccl" with more than one rank.
 
-    def __init__(self, plan, backend, group=None, transport="nccl", overlap=False):
+    r04: the INTERIOR block (square, user rows then item rows, bipartite) is planned by ``rbg_graph_create_csr_classes`` like any
+    other handle and runs the column-slab kernel at d = 32 / 64 / 128; the rectangular halo block stays on the binned kernel.
+    ``halo_bytes_per_layer`` says what a rank receives per layer — on an unstructured power-law graph almost the whole table
+    (Amazon-Book shape, P = 4: 106 056 of 108 183 foreign rows): see ``colsharded.py`` for the sharding that exchanges nothing."""
+
+    def halo_bytes_per_layer(self, d):
+        """bytes this rank RECEIVES per layer at width d (fp32 rows of its halo), and the share of the foreign rows that is"""
+        n_total = sum(int(c) for c in self.plan.recv_counts)
+        return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
+
+    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None):
+        # overlap = None (default): on with real peers under the RCCL transport (the exchange hides behind the interior product),
+        # off otherwise (a one-rank group has no link time to hide: r01); ``autotune`` still measures both on the actual group
+        if overlap is None:
+            overlap = transport == "nccl" and plan.world > 1
         self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev
