@@ -203,17 +203,24 @@ bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_facto
 // Infinity Cache is not what bounds the 1.3 M-node shape (its fabric traffic is: 7.3 TB/s) — off unless asked for.
 static bool sell_class_serial(const SellDev *, int) { return opt_sell_class_serial() == 1; }
 
+// one launch: both row classes (c = -1: user rows on XCDs 0-3, item rows on 4-7) or one class on all eight XCDs
 template <int W, int NS, int DEPTH>
-static int sell_launch_d(const SellDev *sw, SellParams &p, hipStream_t s) {
-    const bool serial = sell_class_serial(sw, NS);
+static void sell_launch_one(const SellDev *sw, SellParams &p, int c, hipStream_t s) {
     const int64_t upw = std::max(1, opt_sell_units_per_wave());  // > 1: a wave walks units t, t + n_w, ... (fewer, longer waves)
-    for (int c = serial ? 0 : -1; c < (serial ? 2 : 0); ++c) {
-        p.cls_only = c;
-        const int64_t units = c < 0 ? std::max(sw->n_units[0], sw->n_units[1]) : sw->n_units[c];
-        const int per = 4 * ((c < 0 ? 4 : 8) / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
-        const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((units + per - 1) / per + upw - 1) / upw));
-        if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true, DEPTH>), dim3(grid), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false, DEPTH>), dim3(grid), dim3(256), 0, s, p);
+    p.cls_only = c;
+    const int64_t units = c < 0 ? std::max(sw->n_units[0], sw->n_units[1]) : sw->n_units[c];
+    const int per = 4 * ((c < 0 ? 4 : 8) / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
+    const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((units + per - 1) / per + upw - 1) / upw));
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true, DEPTH>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false, DEPTH>), dim3(grid), dim3(256), 0, s, p);
+}
+
+template <int W, int NS>
+static int sell_launch_class(const SellDev *sw, SellParams &p, int c, hipStream_t s) {
+    if (W == 32 && sell_depth() == 2) {
+        if constexpr (W == 32) sell_launch_one<W, NS, 2>(sw, p, c, s);
+    } else {
+        sell_launch_one<W, NS, 1>(sw, p, c, s);
     }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
@@ -221,10 +228,9 @@ static int sell_launch_d(const SellDev *sw, SellParams &p, hipStream_t s) {
 
 template <int W, int NS>
 static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
-    if constexpr (W == 32) {
-        if (sell_depth() == 2) return sell_launch_d<W, NS, 2>(sw, p, s);
-    }
-    return sell_launch_d<W, NS, 1>(sw, p, s);
+    if (!sell_class_serial(sw, NS)) return sell_launch_class<W, NS>(sw, p, -1, s);
+    if (int rc = sell_launch_class<W, NS>(sw, p, 0, s)) return rc;
+    return sell_launch_class<W, NS>(sw, p, 1, s);
 }
 
 static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
@@ -265,14 +271,72 @@ static int sell_to_slab(const SellDev *sw, const float *user_emb, const float *i
 // (r04, measured and removed from the build: ONE persistent launch for the K layers — workgroup tickets or a static deal, a layer
 // barrier across the XCDs — is 27 - 110 % SLOWER than the K launches in every form tried: contended same-address atomics cost
 // 30 - 100 ns each on this chip, and the hardware's kernel boundary + dispatcher beat the software barrier + deal;
-// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl)
+// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl, DESIGN 6.10.  Also measured and removed: the K layers as
+// the TWO independent per-class launch chains the bipartite graph allows (U1 -> I2 -> U3, I1 -> U2 -> I3) on two streams, so that
+// one chain's waves fill the other's ramp / tail: 111 - 120 vs 92 us — profiles/r04_two_chains_probe.jsonl.)
+static void sell_layer_params(SellParams &p, const SellParams &base, const SellChainLayer &l) {
+    p = base;
+    p.xs = l.xs, p.ys = l.ys, p.x_rm = l.x_rm, p.compact = l.compact, p.store_scaled = l.store_scaled;
+    p.last = l.last, p.n_prev = l.n_prev, p.prev0_rm = l.prev0_rm, p.prev_scaled = l.prev_scaled;
+}
+
+// a chain = the parameter block its layers share + what differs per layer, issued as K launches.
+// (r04, measured and removed from the build: ONE persistent launch for the K layers — workgroup tickets or a static deal, a layer
+// barrier across the XCDs — is 27 - 110 % SLOWER than the K launches in every form tried: contended same-address atomics cost
+// 30 - 100 ns each on this chip, and the hardware's kernel boundary + dispatcher beat the software barrier + deal;
+// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl, DESIGN 6.10.  Also measured and removed: the K layers as
+// the TWO independent per-class launch chains the bipartite graph allows (U1 -> I2 -> U3, I1 -> U2 -> I3) on two streams, so that
+// one chain's waves fill the other's ramp / tail: 111 - 120 vs 92 us — profiles/r04_two_chains_probe.jsonl.)
+static void sell_layer_params(SellParams &p, const SellParams &base, const SellChainLayer &l) {
+    p = base;
+    p.xs = l.xs, p.ys = l.ys, p.x_rm = l.x_rm, p.compact = l.compact, p.store_scaled = l.store_scaled;
+    p.last = l.last, p.n_prev = l.n_prev, p.prev0_rm = l.prev0_rm, p.prev_scaled = l.prev_scaled;
+}
+
+// Two chains (option "sell_two_chains"): the graph is bipartite, so the user rows of layer k + 1 need the ITEM rows
+// of layer k only and vice versa — the K layers are two independent chains of per-class launches, U1 -> I2 -> U3 ... and
+// I1 -> U2 -> I3 ..., each launch spanning all eight XCDs.  Issued on two streams (the caller's and the plan's side stream,
+// which has the lower priority), the hardware can fill the ramp / tail / launch gap of one chain's kernel with waves of the other
+// chain's — the ~9 us per launch in which the address units idle — with nothing but its own dependency tracking (events).
+// The chains meet twice: the mean's epilogue of class c reads the class-c rows of layer K - 1, which the OTHER chain wrote
+// (one event per class), and at the end (join).  Same kernels, same sums: bit-identical.
+template <int W, int NS>
+static int sell_run_two_chains(const rbg_graph *g, const SellParams &base, const SellChainLayer *lay, int K, hipStream_t s) {
+    SellDev *sw = g->sell;
+    hipStream_t side = opt_sell_two_chains() == 2 ? sw->side_low : sw->side;
+    std::unique_lock<std::mutex> lock(sw->chain_mutex, std::try_to_lock);
+    if (!lock.owns_lock() || !side) return RBG_EUNSUPPORTED;  // (another chain is being issued on this handle: the plain form)
+    RBG_HIP(hipEventRecord(sw->ev[0], s));
+    RBG_HIP(hipStreamWaitEvent(side, sw->ev[0], 0));
+    for (int k = 0; k < K; ++k) {
+        for (int c = 0; c < 2; ++c) {
+            hipStream_t st = ((c + k) & 1) ? side : s;
+            // the last layer of a FORWARD chain adds layers 1 .. K - 1 of its own class: layer K - 1 (kernel (c, K - 2)) ran on the other chain
+            if (k == K - 1 && K >= 2 && lay[k].last && lay[k].n_prev > 1) RBG_HIP(hipStreamWaitEvent(st, sw->ev[2 + c], 0));
+            SellParams p;
+            sell_layer_params(p, base, lay[k]);
+            if (int rc = sell_launch_class<W, NS>(sw, p, c, st)) return rc;
+            if (k == K - 2) RBG_HIP(hipEventRecord(sw->ev[2 + c], st));
+        }
+    }
+    RBG_HIP(hipEventRecord(sw->ev[1], side));
+    RBG_HIP(hipStreamWaitEvent(s, sw->ev[1], 0));
+    return RBG_OK;
+}
+
+// a chain = the parameter block its layers share + what differs per layer, issued as K launches.
+// (r04, measured and removed from the build: ONE persistent launch for the K layers — workgroup tickets or a static deal, a layer
+// barrier across the XCDs — is 27 - 110 % SLOWER than the K launches in every form tried: contended same-address atomics cost
+// 30 - 100 ns each on this chip, and the hardware's kernel boundary + dispatcher beat the software barrier + deal;
+// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl, DESIGN 6.10.  Also measured and removed: the K layers as
+// the TWO independent per-class launch chains the bipartite graph allows (U1 -> I2 -> U3, I1 -> U2 -> I3) on two streams, so that
+// one chain's waves fill the other's ramp / tail: 111 - 120 vs 92 us — profiles/r04_two_chains_probe.jsonl.)
 template <int W, int NS>
 static int sell_run_chain(const rbg_graph *g, const SellParams &base, const SellChainLayer *lay, int K, hipStream_t s) {
     const SellDev *sw = g->sell;
     for (int k = 0; k < K; ++k) {
-        SellParams p = base;
-        p.xs = lay[k].xs, p.ys = lay[k].ys, p.x_rm = lay[k].x_rm, p.compact = lay[k].compact, p.store_scaled = lay[k].store_scaled;
-        p.last = lay[k].last, p.n_prev = lay[k].n_prev, p.prev0_rm = lay[k].prev0_rm, p.prev_scaled = lay[k].prev_scaled;
+        SellParams p;
+        sell_layer_params(p, base, lay[k]);
         if (int rc = sell_launch<W, NS>(sw, p, s)) return rc;
     }
     return RBG_OK;
