@@ -264,64 +264,10 @@ static int sell_to_slab(const SellDev *sw, const float *user_emb, const float *i
     return RBG_OK;
 }
 
-// K launches.  With ent0 the first one gathers E0 where it lies (two row-major tables) and the mean's epilogue reads E0
-// through orig[]: no conversion (7.7 us of a 101 us propagation at the Gowalla shape); without it E0 is converted to slabs
-// in layers[K - 1] first.
-// a chain = the parameter block its layers share + what differs per layer, issued as K launches.
-// (r04, measured and removed from the build: ONE persistent launch for the K layers — workgroup tickets or a static deal, a layer
-// barrier across the XCDs — is 27 - 110 % SLOWER than the K launches in every form tried: contended same-address atomics cost
-// 30 - 100 ns each on this chip, and the hardware's kernel boundary + dispatcher beat the software barrier + deal;
-// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl, DESIGN 6.10.  Also measured and removed: the K layers as
-// the TWO independent per-class launch chains the bipartite graph allows (U1 -> I2 -> U3, I1 -> U2 -> I3) on two streams, so that
-// one chain's waves fill the other's ramp / tail: 111 - 120 vs 92 us — profiles/r04_two_chains_probe.jsonl.)
 static void sell_layer_params(SellParams &p, const SellParams &base, const SellChainLayer &l) {
     p = base;
     p.xs = l.xs, p.ys = l.ys, p.x_rm = l.x_rm, p.compact = l.compact, p.store_scaled = l.store_scaled;
     p.last = l.last, p.n_prev = l.n_prev, p.prev0_rm = l.prev0_rm, p.prev_scaled = l.prev_scaled;
-}
-
-// a chain = the parameter block its layers share + what differs per layer, issued as K launches.
-// (r04, measured and removed from the build: ONE persistent launch for the K layers — workgroup tickets or a static deal, a layer
-// barrier across the XCDs — is 27 - 110 % SLOWER than the K launches in every form tried: contended same-address atomics cost
-// 30 - 100 ns each on this chip, and the hardware's kernel boundary + dispatcher beat the software barrier + deal;
-// devtools/experiments/sell_persist.hip, profiles/r04_persist_probe.jsonl, DESIGN 6.10.  Also measured and removed: the K layers as
-// the TWO independent per-class launch chains the bipartite graph allows (U1 -> I2 -> U3, I1 -> U2 -> I3) on two streams, so that
-// one chain's waves fill the other's ramp / tail: 111 - 120 vs 92 us — profiles/r04_two_chains_probe.jsonl.)
-static void sell_layer_params(SellParams &p, const SellParams &base, const SellChainLayer &l) {
-    p = base;
-    p.xs = l.xs, p.ys = l.ys, p.x_rm = l.x_rm, p.compact = l.compact, p.store_scaled = l.store_scaled;
-    p.last = l.last, p.n_prev = l.n_prev, p.prev0_rm = l.prev0_rm, p.prev_scaled = l.prev_scaled;
-}
-
-// Two chains (option "sell_two_chains"): the graph is bipartite, so the user rows of layer k + 1 need the ITEM rows
-// of layer k only and vice versa — the K layers are two independent chains of per-class launches, U1 -> I2 -> U3 ... and
-// I1 -> U2 -> I3 ..., each launch spanning all eight XCDs.  Issued on two streams (the caller's and the plan's side stream,
-// which has the lower priority), the hardware can fill the ramp / tail / launch gap of one chain's kernel with waves of the other
-// chain's — the ~9 us per launch in which the address units idle — with nothing but its own dependency tracking (events).
-// The chains meet twice: the mean's epilogue of class c reads the class-c rows of layer K - 1, which the OTHER chain wrote
-// (one event per class), and at the end (join).  Same kernels, same sums: bit-identical.
-template <int W, int NS>
-static int sell_run_two_chains(const rbg_graph *g, const SellParams &base, const SellChainLayer *lay, int K, hipStream_t s) {
-    SellDev *sw = g->sell;
-    hipStream_t side = opt_sell_two_chains() == 2 ? sw->side_low : sw->side;
-    std::unique_lock<std::mutex> lock(sw->chain_mutex, std::try_to_lock);
-    if (!lock.owns_lock() || !side) return RBG_EUNSUPPORTED;  // (another chain is being issued on this handle: the plain form)
-    RBG_HIP(hipEventRecord(sw->ev[0], s));
-    RBG_HIP(hipStreamWaitEvent(side, sw->ev[0], 0));
-    for (int k = 0; k < K; ++k) {
-        for (int c = 0; c < 2; ++c) {
-            hipStream_t st = ((c + k) & 1) ? side : s;
-            // the last layer of a FORWARD chain adds layers 1 .. K - 1 of its own class: layer K - 1 (kernel (c, K - 2)) ran on the other chain
-            if (k == K - 1 && K >= 2 && lay[k].last && lay[k].n_prev > 1) RBG_HIP(hipStreamWaitEvent(st, sw->ev[2 + c], 0));
-            SellParams p;
-            sell_layer_params(p, base, lay[k]);
-            if (int rc = sell_launch_class<W, NS>(sw, p, c, st)) return rc;
-            if (k == K - 2) RBG_HIP(hipEventRecord(sw->ev[2 + c], st));
-        }
-    }
-    RBG_HIP(hipEventRecord(sw->ev[1], side));
-    RBG_HIP(hipStreamWaitEvent(s, sw->ev[1], 0));
-    return RBG_OK;
 }
 
 // a chain = the parameter block its layers share + what differs per layer, issued as K launches.
