@@ -782,6 +782,15 @@ int rbg_graph_create_csr_classes(rbg_graph **out, int64_t n_rows, int64_t n_cols
     for (int64_t e = 0; e < nnz; ++e)
         if (col[e] < 0 || col[e] >= n_cols)
             return fail(RBG_EINVAL, "col[%lld] = %d out of [0,%lld)", (long long)e, col[e], (long long)n_cols);
+    if (n_class0_rows < 0 && n_rows == n_cols && nnz > 0) {  // a square CSR without stated classes: the bipartite boundary, if there is one
+        int64_t s_lo = 0, s_hi = n_rows;
+        for (int64_t r = 0; r < n_rows && s_lo <= s_hi; ++r)
+            for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                s_lo = std::max<int64_t>(s_lo, std::min<int64_t>(r, col[e]) + 1);
+                s_hi = std::min<int64_t>(s_hi, std::max<int64_t>(r, col[e]));
+            }
+        if (s_lo <= s_hi && s_lo > 0 && s_lo < n_rows) n_class0_rows = s_lo;
+    }
     rbg_graph *g = new (std::nothrow) rbg_graph();
     if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
     g->device = device;
@@ -814,10 +823,19 @@ int rbg_graph_create_coo(rbg_graph **out, int64_t n_nodes, int64_t nnz, const in
     if (n_nodes >= (int64_t)INT32_MAX || nnz >= (int64_t)INT32_MAX)
         return fail(RBG_EUNSUPPORTED, "size >= 2^31");
     const int64_t *src = edge_index, *dst = edge_index + nnz;
-    for (int64_t e = 0; e < nnz; ++e)
+    // The reference's default branch hands over the bipartite adjacency as a pair (dataset.py:60-66,77-79: users first, items
+    // after) without saying where the items start.  If every edge joins a node below some boundary to a node at or above
+    // it, that boundary is found here — any value in (largest lower endpoint, smallest upper endpoint] is one; the lowest is
+    // taken: the last user normally has interactions, the first item id is the isolated [PAD] — and the handle gets the two
+    // row classes and, with them, the column-slab plan (r04).
+    int64_t s_lo = 0, s_hi = n_nodes;
+    for (int64_t e = 0; e < nnz; ++e) {
         if (src[e] < 0 || src[e] >= n_nodes || dst[e] < 0 || dst[e] >= n_nodes)
             return fail(RBG_EINVAL, "edge %lld (%lld -> %lld) out of [0,%lld)", (long long)e, (long long)src[e],
                         (long long)dst[e], (long long)n_nodes);
+        s_lo = std::max(s_lo, std::min(src[e], dst[e]) + 1);
+        s_hi = std::min(s_hi, std::max(src[e], dst[e]));
+    }
     rbg_graph *g = new (std::nothrow) rbg_graph();
     if (!g) return fail(RBG_ENOMEM, "graph handle allocation failed");
     g->device = device;
@@ -825,6 +843,7 @@ int rbg_graph_create_coo(rbg_graph **out, int64_t n_nodes, int64_t nnz, const in
     g->tuning = current_tuning();
     g->n_rows = g->n_cols = n_nodes;
     g->nnz = nnz;
+    if (nnz > 0 && s_lo <= s_hi && s_lo > 0 && s_lo < n_nodes) g->row_split = s_lo;  // bipartite: rows [0, s_lo) / [s_lo, N)
     int rc = RBG_OK;
     try {
         // adj_t: row = target, col = source; sort by (target, source) via counting sort on source then

@@ -119,8 +119,13 @@ def test_plan_reasons_are_visible(rbg, cuda):
     x64 = x.cpu().numpy().astype(np.float64)  # (float64: the hub row is a sum of 17 384 terms, the fp32 restatement itself is 1e-4 off)
     l1 = O.conv_csr_f64(x64, rp, cl, vl)
     close(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), 2)[0], (x64 + l1 + O.conv_csr_f64(l1, rp, cl, vl)) / 3)
+    # a square CSR / COO without stated classes: the bipartite boundary is detected (r04) — here the hub still rules the plan out
     hc = rbg.GraphHandle.from_csr(rp, cl, vl, nu + ni, device=cuda)
-    assert not hc.has_sell(64) and "boundary" in hc.sell_status()
+    assert not hc.has_sell(64) and "longer than" in hc.sell_status()
+    # ... and a graph that is NOT bipartite (a triangle among the users) has no boundary
+    tri_rp = np.array([0, 2, 4, 6, 6], dtype=np.int64)
+    tri = rbg.GraphHandle.from_csr(tri_rp, np.array([1, 2, 0, 2, 0, 1], dtype=np.int32), np.full(6, 0.5, dtype=np.float32), 4, device=cuda)
+    assert not tri.has_sell(64) and "boundary" in tri.sell_status()
     assert rbg.GraphHandle.from_interactions(u, i, nu, ni).sell_status() == "host graph"
     rbg.set_option("sell_auto", 0)
     try:
@@ -188,6 +193,28 @@ def test_raw_ctypes_caller_runs_the_column_slab_kernel(tmp_path):
     rp, cl, vl = C.build_norm_csr(f["uid"], f["iid"], int(f["n_users"]), int(f["n_items"]))
     close(z["out"], C.lightgcn_forward(rp, cl, vl, z["uw"], z["iw"], 3))
     close(z["y"], C.spmm(rp, cl, vl, np.concatenate([z["uw"], z["iw"]])))
+
+
+def test_default_branch_pair_gets_the_plan(rbg, cuda, golden):
+    """The reference's DEFAULT branch (enable_sparse unset: get_norm_adj_mat returns (edge_index, edge_weight), dataset.py:77-79;
+    LightGCNConv.forward(x, edge_index, edge_weight), layers.py:13-17) hands the adjacency over as a pair without a user / item
+    boundary: rbg_graph_create_coo detects the boundary of the bipartite structure, so that handle is planned as well — and a
+    model built without enable_sparse runs the column-slab kernel layer by layer."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    ei, ew = rbg.norm_edges(g["uid"], g["iid"], nu, ni)
+    h = rbg.ops.graph_from_pair(ei, ew, nu + ni, cuda)
+    assert h.sell_status() == "planned" and h.spmm_kernel_name(64).startswith("sell_spmm_kernel<32, 2, false")
+    x = randn((nu + ni, 64), 3, cuda)
+    close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x.cpu().numpy().astype(np.float64), g["rowptr"], g["col"].astype(np.int64), g["val"]))
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], nu, ni)
+    torch.manual_seed(0)
+    model = rbg.LightGCN({"device": str(cuda), "embedding_size": 64, "n_layers": 3}, ds)  # enable_sparse: None, the reference default
+    with torch.no_grad():
+        u, i = model.forward()
+    ref = C.lightgcn_forward(g["rowptr"], g["col"].astype(np.int64), g["val"], model.user_embedding.weight.detach().cpu().numpy(),
+                             model.item_embedding.weight.detach().cpu().numpy(), 3)
+    close(torch.cat([u, i]), ref)
 
 
 # ---- every caller of the product --------------------------------------------------------------------------------------------
