@@ -252,16 +252,22 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
             }
         }
     };
+    // Pipeline (r04): iteration t runs  compute(t) from LDS | publish(t + 1) LDS <- stage | fetch(t + 2) -> stage | barrier,
+    // so the fetch a publish consumes was issued one whole iteration earlier.  (r03 fetched tile t + 1 at the top of
+    // iteration t and published it at the bottom: with the products knocked out the loop still ran at one memory latency
+    // per tile.  Measured neutral (399 vs 397 us): the gradient kernel is not bound by the fetch but by the missing overlap of its
+    // phases at two workgroups per CU — profiles/r04_lse_phase_probe.jsonl.)
     if (t0 < t1) {
         fetch(t0);
         publish(0);
+        if (t0 + 1 < t1) fetch(t0 + 1);
     }
     __syncthreads();
     for (int64_t t = t0; t < t1; ++t) {
         const int buf = (int)(t - t0) & 1;
-        if (t + 1 < t1) fetch(t + 1);  // in flight while this tile feeds the matrix core
         if (wave_live) compute(buf, t);
         if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        if (t + 2 < t1) fetch(t + 2);
         __syncthreads();
     }
     if (!wave_live) return;
