@@ -134,6 +134,7 @@ struct SellDev {
     const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan
     bool view_fresh = false;         // a view's values have been refreshed at least once (rbg_graph_refresh_values)
     float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain WITHOUT row-major entries (allocated by the first such backward)
+    int64_t bwd_floats = 0;
     std::mutex bwd_mutex;
 };
 void free_sell(SellDev *sw);
@@ -218,6 +219,7 @@ const char *sell_kernel_name(const rbg_graph *g, int d, bool compact);
 bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact entries from the second launch on
 // rbg_spmm_f32 / rbg_spmm_noise_f32 (noise != NULL) over the plan
 // (X: row stride ldx floats — d, or a column block of a wider buffer when sell_stride_ok; Y contiguous)
+bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx);  // the plain layer runs on the plan (row-major entries, or the slab scratch)
 int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s);
 bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx);
 // every layer row-major (the caller reads `layers`, or one graph per layer)

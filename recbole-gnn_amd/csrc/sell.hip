@@ -370,6 +370,13 @@ bool sell_rowmajor_applicable(const rbg_graph *g, int d) {
     return opt_sell() && sell_usable(g) && sell_width_ok(g->sell, d) && g->sell->ent0 && opt_sell_rowmajor();
 }
 
+// the plain layer Y (+)= A X on the plan: through the row-major entries, or — a plan without them (tables beyond 32-bit byte
+// offsets) on contiguous X — through the handle's slab scratch
+bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx) {
+    if (sell_rowmajor_applicable(g, d)) return sell_stride_ok(g, d, ldx);
+    return sell_applicable(g, d) && ldx == d;
+}
+
 #define RBG_SELL_DISPATCH(W_, d_, CALL)                              \
     do {                                                             \
         if ((W_) == 32 && (d_) == 64) return CALL(32, 2);            \
@@ -391,21 +398,52 @@ int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const fl
 
 // Y = A X (accumulate: Y += A X), X and Y row-major [N, d] in the reference's numbering: rbg_spmm_f32 over the plan.
 // noise != NULL: Y = A X + sign(A X) * noise / |noise row| * eps (rbg_spmm_noise_f32; simgcl.py:29-33).
+// The per-handle slab scratch of the launches of a plan WITHOUT row-major entries (tables beyond 32-bit byte offsets, or option
+// "sell_rowmajor" = 0): at least `floats` floats, (re)allocated outside captures only; ONE such launch sequence at a time on
+// the handle.  RBG_EUNSUPPORTED = not available now (the caller runs the binned kernels).
+static int sell_scratch(SellDev *sw, int64_t floats, hipStream_t s) {
+    if (sw->bwd && sw->bwd_floats >= floats) return RBG_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
+    std::lock_guard<std::mutex> lock(sw->bwd_mutex);
+    if (sw->bwd && sw->bwd_floats >= floats) return RBG_OK;
+    if (sw->bwd) {  // a wider table than the first call's: launches in flight still read the old block
+        (void)hipDeviceSynchronize();
+        (void)hipFree(sw->bwd);
+        sw->bwd = nullptr, sw->bwd_floats = 0;
+    }
+    float *b = nullptr;
+    if (dev_malloc(&b, sizeof(float) * (size_t)floats) != hipSuccess) {
+        (void)hipGetLastError();
+        return RBG_EUNSUPPORTED;
+    }
+    sw->bwd = b, sw->bwd_floats = floats;
+    return RBG_OK;
+}
+
 template <int W, int NS>
 static int sell_spmm_w(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int accumulate, const float *noise, float eps, hipStream_t s) {
     const SellDev *sw = g->sell;
     const int n0 = sw->n_class[0];
     SellParams p{};
     sell_fill(sw, W, NS, p);
-    p.rm[0] = X;
-    p.rm[1] = X + (int64_t)n0 * ldx;
+    if (!sw->ent0 || !opt_sell_rowmajor()) {  // no row-major entries: X goes through the handle's slab scratch (ldx == d here)
+        const int rc = sell_scratch(g->sell, g->n_rows * NS * W, s);
+        if (rc) return rc;
+        const int rc2 = sell_to_slab<W, NS>(sw, X, X + (int64_t)n0 * ldx, sw->bwd, s);
+        if (rc2) return rc2;
+        p.xs = sw->bwd;
+    } else {
+        p.rm[0] = X;
+        p.rm[1] = X + (int64_t)n0 * ldx;
+        p.x_rm = 1;
+    }
     if (ldx != NS * W) {  // X is a column block of a wider row-major buffer (NGCF's concatenated output, ngcf.py:100)
         p.rm_ld = (int32_t)ldx;
         int sh = 0;
         while (((int64_t)2 * W << sh) < ldx) ++sh;
         p.rm_shift = sh;
     }
-    p.x_rm = 1;
     p.last = 1;
     p.denom = 1.f;
     p.out = Y;
@@ -460,19 +498,8 @@ static int sell_backward_w(const rbg_graph *g, const float *grad_out, float *gra
     // backward — never inside a capture — and ONE chain at a time on the handle.
     float *gs = nullptr, *ping = nullptr, *pong = nullptr;
     if (!rm) {
-        if (!sw->bwd) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return RBG_EUNSUPPORTED;
-            std::lock_guard<std::mutex> lock(sw->bwd_mutex);
-            if (!sw->bwd) {
-                float *b = nullptr;
-                if (dev_malloc(&b, sizeof(float) * 3 * (size_t)nd) != hipSuccess) {
-                    (void)hipGetLastError();
-                    return RBG_EUNSUPPORTED;  // the caller runs the binned chain
-                }
-                sw->bwd = b;
-            }
-        }
+        const int rc = sell_scratch(sw, 3 * nd, s);
+        if (rc) return rc;  // (RBG_EUNSUPPORTED: the caller runs the binned chain)
         gs = sw->bwd, ping = sw->bwd + nd, pong = sw->bwd + 2 * nd;
     }
     const int n0 = sw->n_class[0];

@@ -873,8 +873,10 @@ int spmm_strided(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int6
                  hipStream_t s) {
     // contiguous operands on a planned handle: the column-slab kernel over row-major tables (every caller of the plain product
     // comes through here: rbg_spmm_f32, the NGCF layer and its backward, the sharded interior / halo blocks)
-    if (ldy == d && sell_rowmajor_applicable(g, d) && sell_stride_ok(g, d, ldx) && aligned16(X) && aligned16(Y) && g->n_rows > 0)
-        return sell_spmm(g, X, ldx, Y, d, accumulate, nullptr, 0.f, s);
+    if (ldy == d && sell_plain_applicable(g, d, ldx) && aligned16(X) && aligned16(Y) && g->n_rows > 0) {
+        const int rc = sell_spmm(g, X, ldx, Y, d, accumulate, nullptr, 0.f, s);
+        if (rc != RBG_EUNSUPPORTED) return rc;  // (no slab scratch available now: the binned kernel below)
+    }
     SpmmParams p{};
     p.x = make_src(X, X, 0, ldx);
     p.y = Y;
@@ -895,14 +897,21 @@ using namespace rbg;
 
 extern "C" {
 
+static int csr_kernel_name(const rbg_graph *g, int d, char *buf, int len);
+
 int rbg_spmm_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     clear_error();
     if (!g || !buf || len <= 0) return fail(RBG_EINVAL, "NULL argument");
     // mirrors rbg_spmm_f32 / launch_spmm for contiguous, 16-byte aligned fp32 operands in store mode
-    if (sell_rowmajor_applicable(g, d)) {
+    if (sell_plain_applicable(g, d, d)) {
         snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, false));
         return RBG_OK;
     }
+    return csr_kernel_name(g, d, buf, len);
+}
+
+// the kernel over the CSR arrays (no plan, or a launch the plan does not serve)
+static int csr_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     if (d != 32 && d != 64 && d != 128 && d != 256) {
         snprintf(buf, (size_t)len, "spmm_generic_kernel");
         return RBG_OK;
@@ -933,7 +942,7 @@ int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, 
         snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, false));
         return RBG_OK;
     }
-    return rbg_spmm_kernel_name(g, d, buf, len);
+    return csr_kernel_name(g, d, buf, len);  // (per-layer outputs without row-major entries: the CSR kernels)
 }
 
 int rbg_graph_bins(const rbg_graph *g, int d, int64_t *n_short, int64_t *n_wave, int64_t *n_block_tasks,
@@ -1025,8 +1034,10 @@ int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float
     if (!X || !Y || !noise) return fail(RBG_EINVAL, "NULL pointer");
     if (X == Y) return fail(RBG_EINVAL, "X and Y alias");
     if ((rc = set_device_for(g->device))) return rc;
-    if (sell_rowmajor_applicable(g, d) && aligned16(X) && aligned16(Y) && aligned16(noise))
-        return sell_spmm(g, X, d, Y, d, 0, noise, eps, (hipStream_t)stream);
+    if (sell_plain_applicable(g, d, d) && aligned16(X) && aligned16(Y) && aligned16(noise)) {
+        rc = sell_spmm(g, X, d, Y, d, 0, noise, eps, (hipStream_t)stream);
+        if (rc != RBG_EUNSUPPORTED) return rc;
+    }
     SpmmParams p{};
     p.x = make_src(X, X, 0, d);
     p.y = Y;

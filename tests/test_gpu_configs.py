@@ -238,9 +238,9 @@ def test_config5_sgl_ed_views_d128(rbg, cuda, frac, record_property):
     for gph in (model.graph, view):
         assert gph.sell_status() == "planned", gph.sell_status()
         assert gph.propagation_kernel_name(d).startswith("sell_spmm_kernel<32, 4, true")
-        # (the PLAIN layer Y = A X gathers a row-major table: 10 M rows x 512 B is beyond the plan's 32-bit offsets — no row-major
-        # twin at this size, rbg_spmm_f32 keeps the binned kernel; the chains convert E0 to slabs once and run the plan)
-        assert not gph.sell_info()["rowmajor"] and "binned" in gph.spmm_kernel_name(d)
+        # (10 M rows x 512 B is beyond the plan's 32-bit offsets: no row-major twin of the entries at this size.  The chains
+        # convert E0 to slabs once; the PLAIN layer Y = A X converts X into the handle's slab scratch — r04, was binned)
+        assert not gph.sell_info()["rowmajor"] and gph.spmm_kernel_name(d).startswith("sell_spmm_kernel<32, 4, false")
     print("plan of the full graph:", model.graph.sell_info())
     if frac == 1.0:  # the full shape, by its constants (GPUTEST's tail shows which size ran: the id carries the fraction)
         assert (nu, ni, model.graph.nnz, view.nnz) == (10_000_001, 5_000_001, 400_000_000, 360_000_000)

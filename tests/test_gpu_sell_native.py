@@ -298,6 +298,36 @@ def test_noise_epilogue_over_the_plan(rbg, cuda, golden, d):
     assert float((y - yb)[mask.to(cuda)].abs().max()) <= 2e-6
 
 
+def test_plain_layer_of_a_plan_without_row_major_entries(rbg, cuda, golden):
+    """A plan without the row-major twin of its entries (tables beyond 32-bit byte offsets: the config-#5 shape; here: option
+    "sell_rowmajor" = 0) still serves rbg_spmm_f32 / rbg_spmm_noise_f32: X is converted into the handle's slab scratch and the
+    launch writes row-major.  The scratch grows when a wider table follows a narrower one on the same handle."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    n = nu + ni
+    rbg.set_option("sell_rowmajor", 0)
+    try:
+        for d in (32, 64, 128, 64):
+            x = randn((n, d), 11 + d, cuda)
+            assert h.spmm_kernel_name(d).startswith("sell_spmm_kernel"), h.spmm_kernel_name(d)
+            y = rbg.ops.spmm_raw(h, x)
+            ref = O.conv_csr_f64(x.cpu().numpy().astype(np.float64), g["rowptr"], g["col"].astype(np.int64), g["val"])
+            assert close(y, ref) <= 1e-5
+            y2 = y.clone()
+            rbg.ops.spmm_raw(h, x, out=y2, accumulate=True)  # Y += A X reads Y where it lies
+            assert close(y2, 2 * ref) <= 2e-5
+            rbg.set_option("sell_rowmajor", 1)
+            assert torch.equal(rbg.ops.spmm_raw(h, x), y)  # the two operand layouts of one kernel: the same sums in the same order
+            rbg.set_option("sell_rowmajor", 0)
+        noise = torch.rand(n, 64, generator=torch.Generator().manual_seed(6)).to(cuda)
+        yn = rbg.ops.spmm_noise_raw(h, x, noise, 0.1)
+        rbg.set_option("sell_rowmajor", 1)
+        assert torch.equal(rbg.ops.spmm_noise_raw(h, x, noise, 0.1), yn)
+    finally:
+        rbg.set_option("sell_rowmajor", 1)
+
+
 def test_ngcf_layer_over_the_plan(rbg, cuda):
     """BiGNNConv (layers.py:54-58): the product inside rbg_bignn_conv_f32 / rbg_bignn_layer_f32 / rbg_bignn_backward_f32 runs
     over the plan — also when X is a 64-wide column block of the [N, 256] concatenated buffer (ngcf.py:100; the row stride
