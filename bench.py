@@ -295,7 +295,14 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             ex["ngcf_forward_us"] = time_us(lambda: ngcf.forward(), iters=20, warm=3)
         gs = rbg.GraphedStep(ngcf, batch, lr=1e-3)  # the same step captured once into a HIP graph (train.py)
         ex["ngcf_train_step_graphed_us"] = time_us(lambda: gs.step(batch), iters=20, warm=3)
-        del ngcf, opt, gs
+        del opt, gs
+        # the same step without autograd: per layer one forward and one backward library call, the loss on the rows of the
+        # concatenation by rbg_concat_bpr_*, torch's fused Adam (train.FusedNGCFAdam), eager and replayed from a HIP graph
+        fs = rbg.FusedNGCFAdam(ngcf, lr=1e-3)
+        ex["ngcf_fused_step_us"] = time_us(lambda: fs.step(batch), iters=20, warm=3)
+        fg = rbg.FusedNGCFAdam(ngcf, lr=1e-3, graphed=True)
+        ex["ngcf_fused_step_graphed_us"] = time_us(lambda: fg.step(batch), iters=20, warm=4)
+        del ngcf, fs, fg
         np.random.seed(0)
         sgl = rbg.SGL({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "type": "ED",
                        "drop_ratio": 0.1, "ssl_tau": 0.2, "ssl_weight": 0.05, "reg_weight": 1e-4}, ds)

@@ -43,4 +43,13 @@ if len(sys.argv) > 2 and sys.argv[2] == "graph":
         stepper.step(batch)
     b.record(); torch.cuda.synchronize()
     out["us_graphed"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+if len(sys.argv) > 2 and sys.argv[2] == "fused":
+    fg = rbg.FusedNGCFAdam(model, lr=1e-3, graphed=True)
+    for _ in range(4):
+        fg.step(batch)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(20):
+        fg.step(batch)
+    b.record(); torch.cuda.synchronize()
+    out["us_fused_graphed"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
 print(json.dumps(out))

@@ -166,6 +166,98 @@ __global__ __launch_bounds__(256) void emb_reg_grad_nopow_kernel(const float *__
     }
 }
 
+// ---- the mini-batch loss of NGCF on the CONCATENATION of its layer outputs (ngcf.py:100-126) without forming it ----------
+// u_e = cat_t(E_t[user]) etc.: a score is the sum over the tables of the per-table dots, a block norm the root of the sum over
+// the tables of the per-table sums of squares.  Pass 1 (concat_bpr_begin_kernel): scores, BPR value, dLoss/d(pos - neg) per
+// triple and the three sums of squares.  Pass 2 (concat_bpr_scatter_kernel), once per table, after that table's dense gradient
+// from the layer above has been written: the rows' gradients added in place.
+struct ConcatTables {
+    const float *tab[RBG_MAX_CONCAT];
+    int width[RBG_MAX_CONCAT];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
+                                                               const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                               int64_t B, float gamma, float *__restrict__ coef,
+                                                               float *__restrict__ sums, float *__restrict__ loss) {
+    __shared__ float red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss, |U|^2, |P|^2, |N|^2
+    for (int e = 0; e < kElemsPerWave; ++e) {
+        const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * kElemsPerWave + e;
+        if (b >= B) break;
+        const int64_t ru = user[b], rp = n_users + pos[b], rn = n_users + neg[b];
+        float sp = 0.f, sn = 0.f, qu = 0.f, qp = 0.f, qn = 0.f;
+        for (int t = 0; t < T.n; ++t) {
+            const int w = T.width[t];
+            const float *ue = T.tab[t] + ru * w, *pe = T.tab[t] + rp * w, *ne = T.tab[t] + rn * w;
+            for (int k = lane; k < w; k += 64) {
+                const float u = ue[k], p = pe[k], n = ne[k];
+                sp = fmaf(u, p, sp);
+                sn = fmaf(u, n, sn);
+                qu = fmaf(u, u, qu);
+                qp = fmaf(p, p, qp);
+                qn = fmaf(n, n, qn);
+            }
+        }
+        sp = wave_sum(sp), sn = wave_sum(sn), qu = wave_sum(qu), qp = wave_sum(qp), qn = wave_sum(qn);
+        const float x = sp - sn;
+        const float sig = 1.0f / (1.0f + expf(-x));
+        if (lane == 0) coef[b] = -(sig * (1.0f - sig)) / (gamma + sig) / (float)B;
+        part[0] += -logf(gamma + sig) / (float)B;
+        part[1] += qu, part[2] += qp, part[3] += qn;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave][i] = part[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (t != 0.f) atomicAdd(threadIdx.x == 0 ? loss : sums + (threadIdx.x - 1), t);
+    }
+}
+
+// EmbLoss(norm = 2) on the three concatenated blocks: require_pow False: (|U| + |P| + |N|) / B, d/d(row) = row / |block| / B;
+// True: (|U|^2 + |P|^2 + |N|^2) / B / 2, d/d(row) = row / B
+__global__ __launch_bounds__(256) void concat_bpr_scatter_kernel(const float *__restrict__ tab, int w, int64_t n_users,
+                                                                 const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
+                                                                 const int64_t *__restrict__ neg, int64_t B, float reg_weight,
+                                                                 int require_pow, const float *__restrict__ coef,
+                                                                 const float *__restrict__ sums, float *__restrict__ grad,
+                                                                 float *__restrict__ loss_reg) {
+    const int lane = threadIdx.x & 63;
+    float s3[3];
+    if (require_pow) {
+        s3[0] = s3[1] = s3[2] = reg_weight / (float)B;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float nrm = sqrtf(sums[i]);
+            s3[i] = nrm > 0.f ? reg_weight / (float)B / nrm : 0.f;
+        }
+    }
+    if (loss_reg && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float r = require_pow ? ((sums[0] + sums[1]) + sums[2]) * 0.5f : (sqrtf(sums[0]) + sqrtf(sums[1])) + sqrtf(sums[2]);
+        atomicAdd(loss_reg, reg_weight * r / (float)B);
+    }
+    for (int e = 0; e < kElemsPerWave; ++e) {
+        const int64_t b = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
+        if (b >= B) break;
+        const int64_t ru = user[b], rp = n_users + pos[b], rn = n_users + neg[b];
+        const float c = coef[b];
+        const float *ue = tab + ru * w, *pe = tab + rp * w, *ne = tab + rn * w;
+        float *gu = grad + ru * w, *gp = grad + rp * w, *gn = grad + rn * w;
+        for (int k = lane; k < w; k += 64) {
+            const float u = ue[k], p = pe[k], n = ne[k];
+            atomicAdd(gu + k, fmaf(c, p - n, s3[0] * u));
+            atomicAdd(gp + k, fmaf(c, u, s3[1] * p));
+            atomicAdd(gn + k, fmaf(-c, u, s3[2] * n));
+        }
+    }
+}
+
 // torch.optim.Adam single step (foreach/fused semantics): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   Rows [0,n_users) of the [N,d] state live in the
 // user table, the rest in the item table.
@@ -232,6 +324,42 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     hipLaunchKernelGGL(emb_sumsq_kernel, grid, dim3(256), 0, s, user_emb, item_emb, user, pos, neg, B, d, workspace);
     hipLaunchKernelGGL(emb_reg_grad_nopow_kernel, grid, dim3(256), 0, s, user_emb, item_emb, n_users, user, pos, neg, B, d, reg_weight,
                        workspace, grad_e0, loss);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int n_tables, int64_t n_users, int64_t n_items,
+                             const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, float *coef, float *sums,
+                             float *loss, void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || B < 0 || n_tables <= 0 || n_tables > RBG_MAX_CONCAT) return fail(RBG_ESHAPE, "bad shape (1..%d tables)", RBG_MAX_CONCAT);
+    if (!tables || !widths || !sums || !loss || (B > 0 && (!user || !pos || !neg || !coef))) return fail(RBG_EINVAL, "NULL pointer");
+    ConcatTables T{};
+    T.n = n_tables;
+    for (int t = 0; t < n_tables; ++t) {
+        if (!tables[t] || widths[t] <= 0) return fail(RBG_EINVAL, "table %d: NULL or width <= 0", t);
+        T.tab[t] = tables[t], T.width[t] = widths[t];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    RBG_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(float), s));
+    RBG_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    if (B == 0) return RBG_OK;
+    hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, T, n_users,
+                       user, pos, neg, B, 1e-10f, coef, sums, loss);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_concat_bpr_scatter_f32(const float *table, int width, int64_t n_users, const int64_t *user, const int64_t *pos,
+                               const int64_t *neg, int64_t B, float reg_weight, int require_pow, const float *coef,
+                               const float *sums, float *grad_table, float *loss_reg, void *stream) {
+    clear_error();
+    if (n_users < 0 || B < 0 || width <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (B == 0) return RBG_OK;
+    if (!table || !user || !pos || !neg || !coef || !sums || !grad_table) return fail(RBG_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(concat_bpr_scatter_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0,
+                       (hipStream_t)stream, table, width, n_users, user, pos, neg, B, reg_weight, require_pow ? 1 : 0, coef, sums, grad_table,
+                       loss_reg);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

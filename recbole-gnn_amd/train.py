@@ -81,6 +81,139 @@ class FusedBPRAdam:
         return self.loss
 
 
+class FusedNGCFAdam:
+    """NGCF's training step (ngcf.py:106-126 + ``loss.backward()`` + Adam) as library calls on preallocated buffers, no autograd:
+    per layer ONE forward call (``rbg_bignn_layer_f32``: product, both transforms, LeakyReLU, dropout mask, normalize) and ONE
+    backward call (``rbg_bignn_backward_f32``); the loss on the rows of the concatenation ``cat(E_0..E_K)`` (ngcf.py:100,
+    113-117) is ``rbg_concat_bpr_begin_f32`` + one ``rbg_concat_bpr_scatter_f32`` per layer, which adds a layer's sparse row
+    gradients IN PLACE onto the dense gradient the layer above has just written (autograd: zeros + index_add + add per layer,
+    and ~40 small launches for the loss).  The update is torch's fused Adam on gradients that live in this object's buffers.
+    ``graphed=True`` captures the whole step into one HIP graph after the first call (fixed batch size).
+
+    The model keeps its parameters, so ``full_sort_predict`` etc. see the trained weights.  ``message_dropout`` draws its masks
+    with torch's generator per step, ``node_dropout`` goes through the model's re-weighted views — both as in ``NGCF``."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
+        from .models import NGCF
+        if not (isinstance(model, NGCF) and type(model).calculate_loss is NGCF.calculate_loss and model.fused
+                and isinstance(model.graph, ops.GraphHandle) and max(model.hidden_size_list) <= 128):
+            raise TypeError("FusedNGCFAdam drives a plain NGCF model on a device graph handle with layer widths <= 128")
+        self.model, self.graphed = model, bool(graphed)
+        self.widths = list(model.hidden_size_list)
+        if len(self.widths) > 8:
+            raise ValueError("at most 7 layers (RBG_MAX_CONCAT tables)")
+        dev, n = model.device, model.n_users + model.n_items
+        f = dict(dtype=torch.float32, device=dev)
+        self.e = [torch.empty((n, w), **f) for w in self.widths]         # E_0 (the ego table) .. E_K
+        self.g = [torch.empty((n, w), **f) for w in self.widths]         # dLoss/dE_t
+        self.p = [torch.empty((n, w), **f) for w in self.widths[:-1]]    # A E_{t} saved by layer t + 1's forward
+        self.inv = [torch.empty(n, **f) for _ in self.widths[1:]]
+        nbytes = _lib.c_i64()
+        need = 8
+        for d_in, d_out in zip(self.widths[:-1], self.widths[1:]):
+            check(lib.rbg_bignn_backward_workspace(n, d_in, d_out, _lib.ctypes.byref(nbytes)))
+            need = max(need, nbytes.value)
+        self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.coef, self.sums, self.loss = None, torch.zeros(3, **f), torch.zeros((), **f)
+        self._tabs = (c_vp * len(self.e))(*[t.data_ptr() for t in self.e])
+        self._widths = (_lib.c_int * len(self.e))(*self.widths)
+        # gradients of the parameters live here; the embedding tables' are the two row ranges of g[0]
+        nu = model.n_users
+        model.user_embedding.weight.grad = self.g[0][:nu]
+        model.item_embedding.weight.grad = self.g[0][nu:]
+        self.gb = []
+        for gnn in model.GNNlayers:
+            gb = torch.zeros_like(gnn.lin1.bias)
+            gnn.lin1.weight.grad, gnn.lin2.weight.grad = torch.zeros_like(gnn.lin1.weight), torch.zeros_like(gnn.lin2.weight)
+            gnn.lin1.bias.grad, gnn.lin2.bias.grad = gb, gb  # (the two biases add into the same output: one gradient)
+            self.gb.append(gb)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
+        self._graph, self._static, self._calls = None, None, 0
+
+    # ---- one step's launches on the current stream --------------------------------------------------------------------------
+    def _enqueue(self, user, pos, neg):
+        m = self.model
+        dev, nu, b = m.device, m.n_users, user.shape[0]
+        graph = m._dropout_graph() if (m.node_dropout != 0 and m.training) else m.graph
+        graph_t = graph.transpose()
+        if self.coef is None or self.coef.shape[0] != b:
+            self.coef = torch.empty(b, dtype=torch.float32, device=dev)
+        st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
+        k_layers = len(self.widths) - 1
+        masks = []
+        with torch.cuda.device(dev):
+            torch.cat([m.user_embedding.weight.data, m.item_embedding.weight.data], dim=0, out=self.e[0])
+            for t, gnn in enumerate(m.GNNlayers):
+                d_in, d_out = self.widths[t], self.widths[t + 1]
+                mask = None
+                if m.message_dropout > 0:  # fresh nn.Dropout(p)(x) of ngcf.py:97: drawn on every forward
+                    mask = ops.dropout_mask(self.e[0].shape[0], d_out, m.message_dropout, dev)
+                masks.append(mask)
+                check(lib.rbg_bignn_layer_f32(graph.ptr, c_vp(self.e[t].data_ptr()), d_in, c_vp(gnn.lin1.weight.data_ptr()),
+                                              c_vp(gnn.lin1.bias.data_ptr()), c_vp(gnn.lin2.weight.data_ptr()), c_vp(gnn.lin2.bias.data_ptr()),
+                                              c_vp(self.e[t + 1].data_ptr()), d_out, c_vp(self.p[t].data_ptr()), c_vp(self.inv[t].data_ptr()),
+                                              c_vp(mask.data_ptr()) if mask is not None else None, d_in, d_out, 0.2, st))
+            check(lib.rbg_concat_bpr_begin_f32(self._tabs, self._widths, len(self.e), nu, m.n_items, c_vp(user.data_ptr()),
+                                               c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, c_vp(self.coef.data_ptr()),
+                                               c_vp(self.sums.data_ptr()), c_vp(self.loss.data_ptr()), st))
+            self.g[k_layers].zero_()
+            for t in range(k_layers, -1, -1):
+                # the rows of E_t that the batch reads: their gradient on top of what layer t + 1's backward wrote
+                check(lib.rbg_concat_bpr_scatter_f32(c_vp(self.e[t].data_ptr()), self.widths[t], nu, c_vp(user.data_ptr()),
+                                                     c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, float(m.reg_weight), 0,
+                                                     c_vp(self.coef.data_ptr()), c_vp(self.sums.data_ptr()), c_vp(self.g[t].data_ptr()),
+                                                     c_vp(self.loss.data_ptr()) if t == k_layers else None, st))
+                if t == 0:
+                    break
+                gnn, d_in, d_out = m.GNNlayers[t - 1], self.widths[t - 1], self.widths[t]
+                mask = masks[t - 1]
+                check(lib.rbg_bignn_backward_f32(graph_t.ptr, c_vp(self.g[t].data_ptr()), d_out, c_vp(self.e[t].data_ptr()), d_out,
+                                                 c_vp(self.inv[t - 1].data_ptr()), c_vp(mask.data_ptr()) if mask is not None else None,
+                                                 c_vp(self.e[t - 1].data_ptr()), d_in, c_vp(self.p[t - 1].data_ptr()),
+                                                 c_vp(gnn.lin1.weight.data_ptr()), c_vp(gnn.lin2.weight.data_ptr()), d_in, d_out, 0.2,
+                                                 c_vp(self.g[t - 1].data_ptr()), c_vp(gnn.lin1.weight.grad.data_ptr()),
+                                                 c_vp(gnn.lin2.weight.grad.data_ptr()), c_vp(self.gb[t - 1].data_ptr()),
+                                                 c_vp(self.work.data_ptr()), st))
+            self.opt.step()
+
+    @staticmethod
+    def _indices(model, interaction):
+        dev = model.device
+        return tuple(interaction[k].to(device=dev, dtype=torch.int64).contiguous() for k in (model.USER_ID, model.ITEM_ID, model.NEG_ITEM_ID))
+
+    @torch.no_grad()
+    def step(self, interaction):
+        """One optimisation step on a batch of (user, pos item, neg item) triples; returns the loss (device scalar)."""
+        m = self.model
+        if m.restore_user_e is not None or m.restore_item_e is not None:  # ngcf.py:108-109
+            m.restore_user_e, m.restore_item_e = None, None
+        user, pos, neg = self._indices(m, interaction)
+        if not self.graphed:
+            self._enqueue(user, pos, neg)
+            return self.loss
+        if self._graph is None:
+            # the first calls run eagerly on a side stream (lazy allocations — the handle's transposed view, the optimizer
+            # state — must exist before capture), the third is captured
+            self._calls += 1
+            if self._calls <= 2:
+                side = torch.cuda.Stream(device=m.device)
+                side.wait_stream(torch.cuda.current_stream(m.device))
+                with torch.cuda.stream(side):
+                    self._enqueue(user, pos, neg)
+                torch.cuda.current_stream(m.device).wait_stream(side)
+                return self.loss
+            self._static = tuple(t.clone() for t in (user, pos, neg))
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._enqueue(*self._static)
+        if user.shape != self._static[0].shape:
+            raise ValueError("a graphed step replays a fixed batch size; run the epoch's last, shorter batch on a second, eager instance")
+        for dst, src in zip(self._static, (user, pos, neg)):
+            dst.copy_(src)
+        self._graph.replay()
+        return self.loss
+
+
 def _total(loss):
     """RecBole's trainer sums a tuple of loss terms (XSimGCL returns mf, reg, cl separately, xsimgcl.py:90)."""
     return sum(loss) if isinstance(loss, tuple) else loss

@@ -1,0 +1,133 @@
+"""train.FusedNGCFAdam: NGCF's training step (ngcf.py:106-126 + backward + Adam) as library calls, against the autograd path
+of the model mirror (whose forward / loss / gradients test_gpu_parity.py checks against the reference formulas) on the same
+parameters, batches and dropout draws; and rbg_concat_bpr_{begin,scatter}_f32 alone against torch in float64."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(rbg, cuda, golden, **cfg):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    torch.manual_seed(4)
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3, "hidden_size_list": [64, 32, 64], "message_dropout": 0.0,
+              "node_dropout": 0.0, "reg_weight": 1e-3}
+    config.update(cfg)
+    return rbg.NGCF(config, ds)
+
+
+def _batches(golden, cuda, n, b, seed=9):
+    nu, ni = int(golden["n_users"]), int(golden["n_items"])
+    gen = torch.Generator().manual_seed(seed)
+    return [{"user_id": torch.randint(1, nu, (b,), generator=gen).to(cuda), "item_id": torch.randint(1, ni, (b,), generator=gen).to(cuda),
+             "neg_item_id": torch.randint(1, ni, (b,), generator=gen).to(cuda)} for _ in range(n)]
+
+
+@pytest.mark.parametrize("p_drop,node_drop", [(0.0, 0.0), (0.1, 0.0), (0.0, 0.2)])
+def test_fused_step_takes_the_autograd_step(rbg, cuda, golden, p_drop, node_drop):
+    model = _model(rbg, cuda, golden, message_dropout=p_drop, node_dropout=node_drop)
+    twin = _model(rbg, cuda, golden, message_dropout=p_drop, node_dropout=node_drop)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    stepper = rbg.FusedNGCFAdam(model, lr=1e-3)
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    for step_no, batch in enumerate(_batches(golden, cuda, 3, 96)):
+        torch.manual_seed(100 + step_no)  # the same edge / message dropout draws on both sides
+        lf = float(stepper.step(batch))
+        torch.manual_seed(100 + step_no)
+        opt.zero_grad(set_to_none=True)
+        le = twin.calculate_loss(batch)
+        le.backward()
+        if step_no == 0:  # same parameters: same loss, same gradients
+            assert abs(lf - float(le.detach())) <= 2e-6 * max(1.0, abs(float(le)))
+            for (name, pf), pe in zip(model.named_parameters(), twin.parameters()):
+                scale = max(float(pe.grad.abs().max()), 1e-12)
+                assert float((pf.grad - pe.grad).abs().max()) <= 2e-5 * scale, name
+        opt.step()
+        assert abs(lf - float(le.detach())) <= 2e-4 * max(1.0, abs(float(le.detach())))
+    # (Adam divides by |g|: where a gradient is ~0 the order of the float atomics decides the sign of a step of size lr)
+    for pf, pe in zip(model.parameters(), twin.parameters()):
+        assert float((pf.detach() - pe.detach()).abs().max()) <= 1e-4 * max(1.0, float(pe.detach().abs().max()))
+
+
+def test_fused_step_replayed_from_a_hip_graph(rbg, cuda, golden):
+    model, twin = _model(rbg, cuda, golden, message_dropout=0.1), _model(rbg, cuda, golden, message_dropout=0.1)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    a, b = rbg.FusedNGCFAdam(model, lr=1e-3, graphed=True), rbg.FusedNGCFAdam(twin, lr=1e-3)
+    losses = []
+    for batch in _batches(golden, cuda, 6, 64):
+        la, lb = float(a.step(batch)), float(b.step(batch))  # (different dropout draws: the trajectories agree statistically)
+        losses.append((la, lb))
+    assert a._graph is not None
+    assert all(np.isfinite(x) and np.isfinite(y) and abs(x - y) < 0.25 for x, y in losses), losses
+    with pytest.raises(ValueError):
+        a.step({k: v[:10] for k, v in _batches(golden, cuda, 1, 64)[0].items()})
+    # without dropout a replayed step IS the eager step
+    model, twin = _model(rbg, cuda, golden), _model(rbg, cuda, golden)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    a, b = rbg.FusedNGCFAdam(model, lr=1e-3, graphed=True), rbg.FusedNGCFAdam(twin, lr=1e-3)
+    for batch in _batches(golden, cuda, 5, 64):
+        la, lb = float(a.step(batch)), float(b.step(batch))
+        assert abs(la - lb) <= 2e-4 * max(1.0, abs(lb))
+    for pa, pb in zip(model.parameters(), twin.parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-4 * max(1.0, float(pb.detach().abs().max()))
+    with torch.no_grad():  # the model's own parameters were trained: evaluation sees them
+        s = model.full_sort_predict({"user_id": torch.arange(1, 5, device=cuda)})
+    assert bool(torch.isfinite(s).all())
+
+
+def test_fused_step_refuses_what_it_does_not_compute(rbg, cuda, golden):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    light = rbg.LightGCN({"device": str(cuda), "embedding_size": 64, "n_layers": 2, "enable_sparse": True}, ds)
+    with pytest.raises(TypeError):
+        rbg.FusedNGCFAdam(light)
+    with pytest.raises(TypeError):
+        rbg.FusedNGCFAdam(_model(rbg, cuda, golden, fused_forward=False))
+
+
+@pytest.mark.parametrize("require_pow", [False, True])
+@pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
+def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow):
+    """BPRLoss + reg_weight * EmbLoss on the rows of cat(tables) (ngcf.py:113-126) and their gradient w.r.t. every table."""
+    from recbole_gnn_amd._lib import c_vp, check, lib
+    nu, ni, b, reg = 50, 70, 333, 0.37
+    gen = torch.Generator().manual_seed(1)
+    tabs = [torch.randn(nu + ni, w, generator=gen).to(cuda) for w in widths]
+    user = torch.randint(0, nu, (b,), generator=gen).to(cuda)
+    pos, neg = torch.randint(0, ni, (b,), generator=gen).to(cuda), torch.randint(0, ni, (b,), generator=gen).to(cuda)
+    # float64 reference of ngcf.py:113-126 (recbole BPRLoss / EmbLoss)
+    t64 = [t.double().requires_grad_(True) for t in tabs]
+    allc = torch.cat(t64, dim=1)
+    u, p, n = allc[user], allc[nu + pos], allc[nu + neg]
+    bpr = -torch.log(1e-10 + torch.sigmoid((u * p).sum(1) - (u * n).sum(1))).mean()
+    emb = sum(torch.norm(x, p=2).pow(2) for x in (u, p, n)) / b / 2 if require_pow else sum(torch.norm(x, p=2) for x in (u, p, n)) / b
+    loss_ref = bpr + reg * emb
+    loss_ref.backward()
+    coef, sums, loss = torch.empty(b, device=cuda), torch.empty(3, device=cuda), torch.empty((), device=cuda)
+    ptrs = (c_vp * len(tabs))(*[t.data_ptr() for t in tabs])
+    wid = (ctypes.c_int * len(tabs))(*widths)
+    st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
+    check(lib.rbg_concat_bpr_begin_f32(ptrs, wid, len(tabs), nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b,
+                                       c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st))
+    for i, (t, w) in enumerate(zip(tabs, widths)):
+        base = torch.randn(nu + ni, w, generator=gen).to(cuda)  # "what the layer above wrote": the scatter adds onto it
+        grad = base.clone()
+        check(lib.rbg_concat_bpr_scatter_f32(c_vp(t.data_ptr()), w, nu, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, reg,
+                                             int(require_pow), c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(grad.data_ptr()),
+                                             c_vp(loss.data_ptr()) if i == 1 % len(tabs) else None, st))
+        got = (grad - base).double().cpu()
+        ref = t64[i].grad.cpu()
+        assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+    # argument checks
+    assert lib.rbg_concat_bpr_begin_f32(ptrs, wid, 9, nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b,
+                                        c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st) != 0
+    assert lib.rbg_concat_bpr_scatter_f32(None, 64, nu, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, reg, 0,
+                                          c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(coef.data_ptr()), None, st) != 0
