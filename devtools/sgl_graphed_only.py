@@ -14,7 +14,18 @@ model.train(); model.graph_construction()
 g = torch.Generator().manual_seed(1)
 batch = {"user_id": torch.randint(1, nu, (2048,), generator=g).to(dev), "item_id": torch.randint(1, ni, (2048,), generator=g).to(dev),
          "neg_item_id": torch.randint(1, ni, (2048,), generator=g).to(dev)}
-gs = rbg.GraphedStep(model, batch, lr=1e-3)
-for _ in range(25):
-    gs.step(batch)
-torch.cuda.synchronize()
+import json
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+out = {}
+for name, gs in (("autograd_graphed", rbg.GraphedStep(model, batch, lr=1e-3)), ("fused_eager", rbg.FusedSGLAdam(model, lr=1e-3)),
+                 ("fused_graphed", rbg.FusedSGLAdam(model, lr=1e-3, graphed=True))):
+    if len(sys.argv) > 1 and sys.argv[1] != name:
+        continue
+    for _ in range(5):
+        gs.step(batch)
+    torch.cuda.synchronize(); a.record()
+    for _ in range(20):
+        gs.step(batch)
+    b.record(); torch.cuda.synchronize()
+    out[name + "_us"] = round(a.elapsed_time(b) * 1e3 / 20, 1)
+print(json.dumps(out))

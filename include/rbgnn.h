@@ -411,16 +411,17 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
 /* NGCF's mini-batch loss (ngcf.py:106-126: BPRLoss on the scores of, and EmbLoss on, the rows of the CONCATENATION of the
  * layer outputs, ngcf.py:100) without forming the concatenation or gathering from it.  tables[t] (HOST array of DEVICE
  * pointers, 1..RBG_MAX_CONCAT) is E_t [N, widths[t]] contiguous, rows [0, n_users) users then items.
- * begin: zeroes sums[3] and *loss; writes coef[b] = dBPR/d(pos_b - neg_b), the three blocks' sums of squares and
- *        *loss = BPRLoss(gamma = 1e-10).
+ * begin: zeroes sums[3] and *loss; writes coef[b] = dBPR/d(pos_b - neg_b), the three blocks' sums of squares and *loss =
+ *        form 0: recbole's BPRLoss, -mean(log(1e-10 + sigmoid(pos - neg)));  form 1: -sum(logsigmoid(pos - neg)), the
+ *        spelling of sgl.py:147-162 (one table: the propagated mean).
  * scatter (once per table, in any order, after begin): ADDS the loss gradient w.r.t. table t's rows onto grad_table
  *        [N, width] — the dense gradient the layer above has already written, or zeros for the last layer — with float
  *        atomics; when loss_reg is non-NULL (pass it on exactly one of the calls) also adds reg_weight * EmbLoss to it.
  *        require_pow = 0: EmbLoss's default (norms), 1: the squared form. */
 #define RBG_MAX_CONCAT 8
 int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int n_tables, int64_t n_users, int64_t n_items,
-                             const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, float *coef, float *sums,
-                             float *loss, void *stream);
+                             const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int form, float *coef,
+                             float *sums, float *loss, void *stream);
 int rbg_concat_bpr_scatter_f32(const float *table, int width, int64_t n_users, const int64_t *user, const int64_t *pos,
                                const int64_t *neg, int64_t B, float reg_weight, int require_pow, const float *coef,
                                const float *sums, float *grad_table, float *loss_reg, void *stream);

@@ -179,7 +179,7 @@ struct ConcatTables {
 
 __global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
                                                                const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
-                                                               int64_t B, float gamma, float *__restrict__ coef,
+                                                               int64_t B, float gamma, int form, float *__restrict__ coef,
                                                                float *__restrict__ sums, float *__restrict__ loss) {
     __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,9 +203,15 @@ __global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, i
         }
         sp = wave_sum(sp), sn = wave_sum(sn), qu = wave_sum(qu), qp = wave_sum(qp), qn = wave_sum(qn);
         const float x = sp - sn;
-        const float sig = 1.0f / (1.0f + expf(-x));
-        if (lane == 0) coef[b] = -(sig * (1.0f - sig)) / (gamma + sig) / (float)B;
-        part[0] += -logf(gamma + sig) / (float)B;
+        if (form == 0) {  // recbole BPRLoss: -mean(log(gamma + sigmoid(x)))
+            const float sig = 1.0f / (1.0f + expf(-x));
+            if (lane == 0) coef[b] = -(sig * (1.0f - sig)) / (gamma + sig) / (float)B;
+            part[0] += -logf(gamma + sig) / (float)B;
+        } else {  // sgl.py:147-162: -sum(logsigmoid(x)); d/dx = -sigmoid(-x)
+            const float en = expf(-fabsf(x));  // logsigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+            if (lane == 0) coef[b] = -(x >= 0.f ? en : 1.0f) / (1.0f + en);
+            part[0] += log1pf(en) - fminf(x, 0.f);
+        }
         part[1] += qu, part[2] += qp, part[3] += qn;
     }
     if (lane == 0) {
@@ -329,9 +335,10 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
 }
 
 int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int n_tables, int64_t n_users, int64_t n_items,
-                             const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, float *coef, float *sums,
-                             float *loss, void *stream) {
+                             const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int form, float *coef,
+                             float *sums, float *loss, void *stream) {
     clear_error();
+    if (form != 0 && form != 1) return fail(RBG_EINVAL, "form = %d (0: BPRLoss mean, 1: sum of -logsigmoid)", form);
     if (n_users < 0 || n_items < 0 || B < 0 || n_tables <= 0 || n_tables > RBG_MAX_CONCAT) return fail(RBG_ESHAPE, "bad shape (1..%d tables)", RBG_MAX_CONCAT);
     if (!tables || !widths || !sums || !loss || (B > 0 && (!user || !pos || !neg || !coef))) return fail(RBG_EINVAL, "NULL pointer");
     ConcatTables T{};
@@ -345,7 +352,7 @@ int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int 
     RBG_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
     if (B == 0) return RBG_OK;
     hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, T, n_users,
-                       user, pos, neg, B, 1e-10f, coef, sums, loss);
+                       user, pos, neg, B, 1e-10f, form, coef, sums, loss);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

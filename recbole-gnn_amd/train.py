@@ -81,7 +81,56 @@ class FusedBPRAdam:
         return self.loss
 
 
-class FusedNGCFAdam:
+class _FusedStep:
+    """What the autograd-free steps share: the batch's index tensors, and — ``graphed=True`` — the capture of one step's
+    launches into a HIP graph after two eager warm-up steps (lazy allocations must exist before capture), replayed per batch
+    of the captured size and re-captured when the graph handles the step reads change (SGL samples new views per epoch)."""
+
+    def _init_graphed(self, graphed):
+        self.graphed = bool(graphed)
+        self._graph, self._static, self._calls, self._key = None, None, 0, None
+
+    def _handles(self):
+        return (self.model.graph,)
+
+    @torch.no_grad()
+    def step(self, interaction):
+        """One optimisation step on a batch of (user, pos item, neg item) triples; returns the loss (device scalar)."""
+        m = self.model
+        if m.restore_user_e is not None or m.restore_item_e is not None:  # (ngcf.py:108-109, sgl.py:212-213)
+            m.restore_user_e, m.restore_item_e = None, None
+        dev = m.device
+        user, pos, neg = (interaction[k].to(device=dev, dtype=torch.int64).contiguous() for k in (m.USER_ID, m.ITEM_ID, m.NEG_ITEM_ID))
+        if not self.graphed:
+            self._enqueue(user, pos, neg)
+            return self.loss
+        key = tuple(id(h) for h in self._handles())
+        if self._graph is not None and key != self._key:
+            self._graph, self._calls = None, 1  # new views: their plans exist, one eager step re-warms
+        if self._graph is None:
+            self._calls += 1
+            if self._calls <= 2:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._enqueue(user, pos, neg)
+                torch.cuda.current_stream(dev).wait_stream(side)
+                return self.loss
+            self._static = tuple(t.clone() for t in (user, pos, neg))
+            self._keep = self._handles()  # (a captured graph has their device pointers baked in)
+            self._key = key
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._enqueue(*self._static)
+        if user.shape != self._static[0].shape:
+            raise ValueError("a graphed step replays a fixed batch size; run the epoch's last, shorter batch on a second, eager instance")
+        for dst, src in zip(self._static, (user, pos, neg)):
+            dst.copy_(src)
+        self._graph.replay()
+        return self.loss
+
+
+class FusedNGCFAdam(_FusedStep):
     """NGCF's training step (ngcf.py:106-126 + ``loss.backward()`` + Adam) as library calls on preallocated buffers, no autograd:
     per layer ONE forward call (``rbg_bignn_layer_f32``: product, both transforms, LeakyReLU, dropout mask, normalize) and ONE
     backward call (``rbg_bignn_backward_f32``); the loss on the rows of the concatenation ``cat(E_0..E_K)`` (ngcf.py:100,
@@ -98,7 +147,8 @@ class FusedNGCFAdam:
         if not (isinstance(model, NGCF) and type(model).calculate_loss is NGCF.calculate_loss and model.fused
                 and isinstance(model.graph, ops.GraphHandle) and max(model.hidden_size_list) <= 128):
             raise TypeError("FusedNGCFAdam drives a plain NGCF model on a device graph handle with layer widths <= 128")
-        self.model, self.graphed = model, bool(graphed)
+        self.model = model
+        self._init_graphed(graphed)
         self.widths = list(model.hidden_size_list)
         if len(self.widths) > 8:
             raise ValueError("at most 7 layers (RBG_MAX_CONCAT tables)")
@@ -128,7 +178,6 @@ class FusedNGCFAdam:
             gnn.lin1.bias.grad, gnn.lin2.bias.grad = gb, gb  # (the two biases add into the same output: one gradient)
             self.gb.append(gb)
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
-        self._graph, self._static, self._calls = None, None, 0
 
     # ---- one step's launches on the current stream --------------------------------------------------------------------------
     def _enqueue(self, user, pos, neg):
@@ -154,7 +203,7 @@ class FusedNGCFAdam:
                                               c_vp(self.e[t + 1].data_ptr()), d_out, c_vp(self.p[t].data_ptr()), c_vp(self.inv[t].data_ptr()),
                                               c_vp(mask.data_ptr()) if mask is not None else None, d_in, d_out, 0.2, st))
             check(lib.rbg_concat_bpr_begin_f32(self._tabs, self._widths, len(self.e), nu, m.n_items, c_vp(user.data_ptr()),
-                                               c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, c_vp(self.coef.data_ptr()),
+                                               c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, 0, c_vp(self.coef.data_ptr()),
                                                c_vp(self.sums.data_ptr()), c_vp(self.loss.data_ptr()), st))
             self.g[k_layers].zero_()
             for t in range(k_layers, -1, -1):
@@ -176,42 +225,86 @@ class FusedNGCFAdam:
                                                  c_vp(self.work.data_ptr()), st))
             self.opt.step()
 
-    @staticmethod
-    def _indices(model, interaction):
-        dev = model.device
-        return tuple(interaction[k].to(device=dev, dtype=torch.int64).contiguous() for k in (model.USER_ID, model.ITEM_ID, model.NEG_ITEM_ID))
 
-    @torch.no_grad()
-    def step(self, interaction):
-        """One optimisation step on a batch of (user, pos item, neg item) triples; returns the loss (device scalar)."""
+
+class FusedSGLAdam(_FusedStep):
+    """SGL's training step (sgl.py:211-233 + ``loss.backward()`` + Adam) as library calls on preallocated buffers, no autograd:
+    three propagations (the full graph and the two views, sgl.py:219-221), the sum-reduced BPR term on the propagated mean
+    (``rbg_concat_bpr_*`` form 1), both InfoNCE halves with their table gradients (``rbg_infonce_f32``), three backward
+    chains, EmbLoss on the ego rows, torch's fused Adam on a gradient that lives in this object's buffers.  ``graphed=True``
+    replays the step from a HIP graph, re-captured when the model samples new views (``SGL.train()``, sgl.py:94-98)."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
+        from .models import SGL
+        if not (isinstance(model, SGL) and type(model).calculate_loss is SGL.calculate_loss and type(model).forward is SGL.forward
+                and isinstance(model.graph, ops.GraphHandle) and model.user_embedding.weight.shape[1] <= 128):
+            raise TypeError("FusedSGLAdam drives a plain SGL model on device graph handles with embedding width <= 128")
+        self.model = model
+        self._init_graphed(graphed)
+        dev, nu = model.device, model.n_users
+        n, d = nu + model.n_items, model.user_embedding.weight.shape[1]
+        f = dict(dtype=torch.float32, device=dev)
+        self.mean = [torch.empty((n, d), **f) for _ in range(3)]   # the full graph, view 1, view 2
+        self.gm = [torch.empty((n, d), **f) for _ in range(3)]     # dLoss/d(mean)
+        self.ge = [torch.empty((n, d), **f) for _ in range(3)]     # dLoss/dE0 through each propagation; ge[0] ends as the total
+        self.layers = torch.empty((max(model.n_layers, 1), n, d), **f)
+        self.work = torch.empty((n, d), **f)
+        self.coef, self.nce_work = None, None
+        self.sums, self.reg_ws, self.loss = torch.zeros(3, **f), torch.zeros(3, **f), torch.zeros((), **f)
+        self._tab = (c_vp * 1)(self.mean[0].data_ptr())
+        self._wid = (_lib.c_int * 1)(d)
+        model.user_embedding.weight.grad = self.ge[0][:nu]
+        model.item_embedding.weight.grad = self.ge[0][nu:]
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
+
+    def _views(self):
         m = self.model
-        if m.restore_user_e is not None or m.restore_item_e is not None:  # ngcf.py:108-109
-            m.restore_user_e, m.restore_item_e = None, None
-        user, pos, neg = self._indices(m, interaction)
-        if not self.graphed:
-            self._enqueue(user, pos, neg)
-            return self.loss
-        if self._graph is None:
-            # the first calls run eagerly on a side stream (lazy allocations — the handle's transposed view, the optimizer
-            # state — must exist before capture), the third is captured
-            self._calls += 1
-            if self._calls <= 2:
-                side = torch.cuda.Stream(device=m.device)
-                side.wait_stream(torch.cuda.current_stream(m.device))
-                with torch.cuda.stream(side):
-                    self._enqueue(user, pos, neg)
-                torch.cuda.current_stream(m.device).wait_stream(side)
-                return self.loss
-            self._static = tuple(t.clone() for t in (user, pos, neg))
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._enqueue(*self._static)
-        if user.shape != self._static[0].shape:
-            raise ValueError("a graphed step replays a fixed batch size; run the epoch's last, shorter batch on a second, eager instance")
-        for dst, src in zip(self._static, (user, pos, neg)):
-            dst.copy_(src)
-        self._graph.replay()
-        return self.loss
+        if m.sub_graph1 is None:
+            m.graph_construction()
+        views = [[m.graph], [g for g, _ in m.sub_graph1], [g for g, _ in m.sub_graph2]]
+        return [v[:1] if all(g is v[0] for g in v) else v for v in views]  # (RW: one graph per layer)
+
+    def _handles(self):
+        return tuple(g for v in self._views() for g in v)
+
+    def _enqueue(self, user, pos, neg):
+        m = self.model
+        dev, nu, ni, b, k_layers = m.device, m.n_users, m.n_items, user.shape[0], m.n_layers
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        d = uw.shape[1]
+        views = self._views()
+        if self.coef is None or self.coef.shape[0] != b:
+            self.coef = torch.empty(b, dtype=torch.float32, device=dev)
+            nbytes, need = _lib.c_i64(), 8
+            for rows in (nu, ni):
+                check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
+                need = max(need, nbytes.value)
+            self.nce_work = torch.empty(need, dtype=torch.uint8, device=dev)
+        st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
+        ptr = lambda t, row=0: c_vp(t.data_ptr() + 4 * row * d)  # noqa: E731  (rows [row, ...) of a contiguous [*, d] table)
+        with torch.cuda.device(dev):
+            for v in range(3):
+                ops.lightgcn_forward_raw(views[v], uw, iw, k_layers, out=self.mean[v], layers=self.layers)
+            # sgl.py:147-162 on the full graph's mean: value, then the rows' gradients onto zeros
+            check(lib.rbg_concat_bpr_begin_f32(self._tab, self._wid, 1, nu, ni, ptr(user), ptr(pos), ptr(neg), b, 1, ptr(self.coef),
+                                               ptr(self.sums), ptr(self.loss), st))
+            for g in self.gm:
+                g.zero_()
+            check(lib.rbg_concat_bpr_scatter_f32(ptr(self.mean[0]), d, nu, ptr(user), ptr(pos), ptr(neg), b, 0.0, 0, ptr(self.coef),
+                                                 ptr(self.sums), ptr(self.gm[0]), None, st))
+            # sgl.py:176-209: users, then items, between the two views
+            for row0, rows, idx in ((0, nu, user), (nu, ni, pos)):
+                check(lib.rbg_infonce_f32(ptr(self.mean[1], row0), ptr(self.mean[2], row0), rows, d, ptr(idx), b, float(m.ssl_tau),
+                                          float(m.ssl_weight), ptr(self.loss), ptr(self.gm[1], row0), ptr(self.gm[2], row0),
+                                          ptr(self.nce_work), st))
+            for v in range(3):
+                ts = [g.transpose() for g in views[v]]
+                arr = (c_vp * len(ts))(*[g.ptr for g in ts])
+                check(lib.rbg_lightgcn_backward_f32(arr, len(ts), ptr(self.gm[v]), ptr(self.ge[v]), ptr(self.work), d, k_layers, st))
+            self.ge[0].add_(self.ge[1]).add_(self.ge[2])
+            check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(m.reg_weight),
+                                                 ptr(self.ge[0]), ptr(self.loss), ptr(self.reg_ws), st))
+            self.opt.step()
 
 
 def _total(loss):

@@ -1,4 +1,5 @@
-"""train.FusedNGCFAdam: NGCF's training step (ngcf.py:106-126 + backward + Adam) as library calls, against the autograd path
+"""train.FusedNGCFAdam / train.FusedSGLAdam: the training steps of NGCF (ngcf.py:106-126) and SGL (sgl.py:211-233) + backward +
+Adam as library calls, against the autograd path
 of the model mirror (whose forward / loss / gradients test_gpu_parity.py checks against the reference formulas) on the same
 parameters, batches and dropout draws; and rbg_concat_bpr_{begin,scatter}_f32 alone against torch in float64."""
 import ctypes
@@ -92,9 +93,72 @@ def test_fused_step_refuses_what_it_does_not_compute(rbg, cuda, golden):
         rbg.FusedNGCFAdam(_model(rbg, cuda, golden, fused_forward=False))
 
 
+# ---- SGL ---------------------------------------------------------------------------------------------------------------------
+
+def _sgl(rbg, cuda, golden, aug="ED", **cfg):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    torch.manual_seed(4)
+    np.random.seed(3)
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3, "enable_sparse": True, "type": aug, "drop_ratio": 0.1, "ssl_tau": 0.5,
+              "ssl_weight": 0.05, "reg_weight": 1e-3, "device_sampling": False}
+    config.update(cfg)
+    return rbg.SGL(config, ds)
+
+
+@pytest.mark.parametrize("aug", ["ED", "ND", "RW"])
+def test_fused_sgl_step_takes_the_autograd_step(rbg, cuda, golden, aug):
+    model, twin = _sgl(rbg, cuda, golden, aug), _sgl(rbg, cuda, golden, aug)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2  # both train on the very same views
+    stepper = rbg.FusedSGLAdam(model, lr=1e-3)
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    for step_no, batch in enumerate(_batches(golden, cuda, 3, 96)):
+        lf = float(stepper.step(batch))
+        opt.zero_grad(set_to_none=True)
+        le = twin.calculate_loss(batch)
+        le.backward()
+        ref = float(le.detach())
+        if step_no == 0:
+            assert abs(lf - ref) <= 5e-6 * max(1.0, abs(ref))
+            for (name, pf), pe in zip(model.named_parameters(), twin.parameters()):
+                scale = max(float(pe.grad.abs().max()), 1e-12)
+                assert float((pf.grad - pe.grad).abs().max()) <= 2e-5 * scale, name
+        opt.step()
+        assert abs(lf - ref) <= 2e-4 * max(1.0, abs(ref))
+    for pf, pe in zip(model.parameters(), twin.parameters()):
+        assert float((pf.detach() - pe.detach()).abs().max()) <= 1e-4 * max(1.0, float(pe.detach().abs().max()))
+
+
+def test_fused_sgl_step_replayed_and_recaptured(rbg, cuda, golden):
+    model, twin = _sgl(rbg, cuda, golden), _sgl(rbg, cuda, golden)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2
+    a, b = rbg.FusedSGLAdam(model, lr=1e-3, graphed=True), rbg.FusedSGLAdam(twin, lr=1e-3)
+    batches = _batches(golden, cuda, 9, 64)
+    for batch in batches[:5]:
+        la, lb = float(a.step(batch)), float(b.step(batch))
+        assert abs(la - lb) <= 2e-4 * max(1.0, abs(lb))
+    first = a._graph
+    assert first is not None
+    model.train()  # a new epoch samples new views (sgl.py:94-98): the replay must not keep reading the old handles
+    twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2
+    for batch in batches[5:]:
+        la, lb = float(a.step(batch)), float(b.step(batch))
+        assert abs(la - lb) <= 2e-4 * max(1.0, abs(lb))
+    assert a._graph is not None and a._graph is not first
+    for pa, pb in zip(model.parameters(), twin.parameters()):
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-4 * max(1.0, float(pb.detach().abs().max()))
+    with pytest.raises(TypeError):
+        rbg.FusedSGLAdam(_model(rbg, cuda, golden))
+
+
+@pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
-def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow):
+def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow, form):
     """BPRLoss + reg_weight * EmbLoss on the rows of cat(tables) (ngcf.py:113-126) and their gradient w.r.t. every table."""
     from recbole_gnn_amd._lib import c_vp, check, lib
     nu, ni, b, reg = 50, 70, 333, 0.37
@@ -106,7 +170,8 @@ def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow):
     t64 = [t.double().requires_grad_(True) for t in tabs]
     allc = torch.cat(t64, dim=1)
     u, p, n = allc[user], allc[nu + pos], allc[nu + neg]
-    bpr = -torch.log(1e-10 + torch.sigmoid((u * p).sum(1) - (u * n).sum(1))).mean()
+    x = (u * p).sum(1) - (u * n).sum(1)
+    bpr = -torch.log(1e-10 + torch.sigmoid(x)).mean() if form == 0 else -torch.nn.functional.logsigmoid(x).sum()  # (sgl.py:147-162)
     emb = sum(torch.norm(x, p=2).pow(2) for x in (u, p, n)) / b / 2 if require_pow else sum(torch.norm(x, p=2) for x in (u, p, n)) / b
     loss_ref = bpr + reg * emb
     loss_ref.backward()
@@ -114,7 +179,7 @@ def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow):
     ptrs = (c_vp * len(tabs))(*[t.data_ptr() for t in tabs])
     wid = (ctypes.c_int * len(tabs))(*widths)
     st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
-    check(lib.rbg_concat_bpr_begin_f32(ptrs, wid, len(tabs), nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b,
+    check(lib.rbg_concat_bpr_begin_f32(ptrs, wid, len(tabs), nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, form,
                                        c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st))
     for i, (t, w) in enumerate(zip(tabs, widths)):
         base = torch.randn(nu + ni, w, generator=gen).to(cuda)  # "what the layer above wrote": the scatter adds onto it
@@ -127,7 +192,9 @@ def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow):
         assert float((got - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     assert abs(float(loss) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
     # argument checks
-    assert lib.rbg_concat_bpr_begin_f32(ptrs, wid, 9, nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b,
+    assert lib.rbg_concat_bpr_begin_f32(ptrs, wid, 9, nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, 0,
+                                        c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st) != 0
+    assert lib.rbg_concat_bpr_begin_f32(ptrs, wid, len(tabs), nu, ni, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, 2,
                                         c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st) != 0
     assert lib.rbg_concat_bpr_scatter_f32(None, 64, nu, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, reg, 0,
                                           c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(coef.data_ptr()), None, st) != 0
