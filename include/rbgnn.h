@@ -95,6 +95,9 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   ONE alignment class of the contiguous [B, n] output and shifts its item tiles to that class's line boundary:
  *                   whole aligned lines are stored straight from the accumulators (r04: 178 -> 156 us at 4096 x 40 982 x 64);
  *                   0 = the shifted store stream (16 cross-lane reads per tile), which small batches always use
+ *   "lse_onepass" : 1 (default) = rbg_infonce_f32 with gradients takes the denominators and the batch rows' gradient out of ONE
+ *                   pass over the table (the unnormalised gradient accumulates beside the denominator; no separate forward
+ *                   launch); 0 = forward launch + two gradient launches
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
  *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan

@@ -41,6 +41,7 @@ struct LseParams {
     const float *coef_own;  // [n_own] or NULL (gradients)
     const float *coef_oth;  // [n_oth] or NULL
     float *out;             // forward: [n_chunks][n_own]; gradients: [n_chunks][n_own][d]
+    float *den_out;         // gradients only, or NULL: [n_chunks][n_own] row sums of the weights (the forward's output) from the same pass
     int tiles_per_chunk, n_chunks;
     int64_t own_blocks, total_blocks, blocks_per_xcd;  // workgroup j = chunk * own_blocks + own_block, j < total_blocks
 };
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                 if (p.coef_oth) e *= s_coef[buf][o];
                 w[r] = (o < left) ? e : 0.f;
             });
+            if (p.den_out) {  // (uniform) forward and own-side gradient in one pass: the weights' row sums are the denominators
+                LseRows<0>::run([&](auto rc) { zsum += w[decltype(rc)::value]; });
+            }
             if constexpr (SPLIT) {
                 // second product on the bf16 matrix cores too: MFMA u of a pair covers the oth rows rowmap(8 u + j, h),
                 // j = 0..7 — the weights this lane already holds (A slot) against a column of the fp32 tile (B slot), both
@@ -275,6 +279,10 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
         zsum += __shfl_xor(zsum, 32);
         if (h == 0 && own_ok) p.out[chunk * p.n_own + own_row] = zsum;
     } else {
+        if (p.den_out) {
+            zsum += __shfl_xor(zsum, 32);
+            if (h == 0 && own_ok) p.den_out[chunk * p.n_own + own_row] = zsum;
+        }
         // g[q][r]: own row own0 + rowmap(r,h), feature column q*32 + i
         float *base = p.out + chunk * p.n_own * p.d;
 #pragma unroll
@@ -314,6 +322,17 @@ __global__ void lse_reduce_kernel(const float *__restrict__ part, int n_chunks, 
     out[x] = a;
 }
 
+// out[b][k] = coef[b] * sum_c part[c][b][k], fixed order (the own-side gradient of the one-pass form: the launch ran with
+// unit coefficients because the denominators came out of the same pass)
+__global__ void lse_reduce_scaled_kernel(const float *__restrict__ part, int n_chunks, int64_t B, int d, const float *__restrict__ coef,
+                                         float *__restrict__ out) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= B * d) return;
+    float a = 0.f;
+    for (int c = 0; c < n_chunks; ++c) a += part[(int64_t)c * B * d + x];
+    out[x] = a * coef[x / d];
+}
+
 // Chunking.  Measured (per-workgroup clock trace, r01): the kernel is matrix-core bound per CU, all workgroups start at
 // once and the dispatcher spreads them evenly, so the launch lasts as long as the fullest CU: ceil(blocks / 256)
 // workgroups x tiles per chunk.  832 workgroups (3.25 per CU) ran 130 us where 768 run 89 us.  Pick the chunk count
@@ -343,7 +362,7 @@ struct LseLayout {
     int tpc_f, nc_f;  // forward (own = Q)
     int tpc_q, nc_q;  // dQ (own = Q)
     int tpc_c, nc_c;  // dC (own = C)
-    int64_t off_coef, off_q, off_c, bytes;
+    int64_t off_coef, off_q, off_c, off_den, bytes;
 };
 static LseLayout lse_layout(int64_t B, int64_t n, int d) {
     LseLayout L{};
@@ -360,7 +379,8 @@ static LseLayout lse_layout(int64_t B, int64_t n, int d) {
     const int64_t q_bytes = std::max<int64_t>((int64_t)L.nc_q * B * d * 4, (int64_t)L.nc_f * B * 4);
     L.off_c = L.off_q + up(q_bytes);
     const int64_t c_bytes = L.nc_c > 1 ? (int64_t)L.nc_c * n * d * 4 : 0;
-    L.bytes = L.off_c + up(c_bytes) + 256;
+    L.off_den = L.off_c + up(c_bytes);  // [nc_q][B]: the denominators' partial sums of the one-pass form
+    L.bytes = L.off_den + up((int64_t)L.nc_q * B * 4) + 256;
     return L;
 }
 
@@ -401,6 +421,66 @@ static bool lse_vec(const float *Q, int64_t ldq, const float *C, int64_t ldc, in
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
+
+// The forward and the own-side gradient in ONE pass over the candidates (r04): with a fixed shift (no running maximum) the
+// unnormalised gradient sum_j w[b][j] C[j] accumulates beside the denominator sum_j w[b][j], so the separate forward launch
+// (57 us of a 385 us InfoNCE half at 2048 x 40 982, d = 64) disappears; the normalisation moves into the chunk reduction.
+// Leaves the gradient partials in the workspace for lse_onepass_finish.
+static int lse_onepass_begin(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale, float shift,
+                             float *lse, void *workspace, hipStream_t s) {
+    const LseLayout L = lse_layout(B, n, d);
+    char *w = reinterpret_cast<char *>(workspace);
+    float *part_q = reinterpret_cast<float *>(w + L.off_q), *den = reinterpret_cast<float *>(w + L.off_den);
+    LseParams p{};
+    p.d = d;
+    p.s2 = scale * kLog2e;
+    p.shift2 = shift * kLog2e;
+    p.own = Q, p.ld_own = ldq, p.n_own = B;
+    p.oth = C, p.ld_oth = ldc, p.n_oth = n;
+    p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
+    p.out = part_q;
+    p.den_out = den;
+    lse_launch_d<true>(p, lse_vec(Q, ldq, C, ldc, d), s);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(lse_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, B, shift, lse);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+// grad_Q from the partials of lse_onepass_begin, grad_C by the usual second pass
+static int lse_onepass_finish(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale, float shift,
+                              const float *lse, const float *grad_lse, float *grad_Q, float *grad_C, void *workspace, hipStream_t s) {
+    const LseLayout L = lse_layout(B, n, d);
+    char *w = reinterpret_cast<char *>(workspace);
+    float *coef = reinterpret_cast<float *>(w + L.off_coef);
+    float *part_q = reinterpret_cast<float *>(w + L.off_q), *part_c = reinterpret_cast<float *>(w + L.off_c);
+    hipLaunchKernelGGL(lse_coef_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, grad_lse, lse, B, scale, shift, coef);
+    RBG_HIP(hipGetLastError());
+    if (grad_Q) {
+        const int64_t len = B * d;
+        hipLaunchKernelGGL(lse_reduce_scaled_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_q, L.nc_q, B, d, coef, grad_Q);
+        RBG_HIP(hipGetLastError());
+    }
+    if (grad_C) {
+        LseParams p{};
+        p.d = d;
+        p.s2 = scale * kLog2e;
+        p.shift2 = shift * kLog2e;
+        p.own = C, p.ld_own = ldc, p.n_own = n;
+        p.oth = Q, p.ld_oth = ldq, p.n_oth = B;
+        p.coef_own = nullptr, p.coef_oth = coef;
+        p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
+        p.out = L.nc_c > 1 ? part_c : grad_C;
+        lse_launch_d<true>(p, lse_vec(Q, ldq, C, ldc, d), s);
+        RBG_HIP(hipGetLastError());
+        if (L.nc_c > 1) {
+            const int64_t len = n * d;
+            hipLaunchKernelGGL(lse_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_c, L.nc_c, len, grad_C);
+            RBG_HIP(hipGetLastError());
+        }
+    }
+    return RBG_OK;
+}
 
 }  // namespace rbg
 
@@ -668,12 +748,16 @@ int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const in
     RBG_HIP(hipGetLastError());
     hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos);
     RBG_HIP(hipGetLastError());
-    int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
+    const bool grads = grad_T1 || grad_T2;
+    const bool onepass = grads && opt_lse_onepass();  // denominators and dA out of one pass over the table
+    int rc = onepass ? lse_onepass_begin(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, s)
+                     : rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
     RBG_HIP(hipGetLastError());
-    if (!grad_T1 && !grad_T2) return RBG_OK;
-    rc = rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
+    if (!grads) return RBG_OK;
+    rc = onepass ? lse_onepass_finish(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, s)
+                 : rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(nce_batch_back_kernel, dim3(bb), dim3(256), 0, s, dA, A, C, inv1, T1, idx, B, d, weight * scale, dC, grad_T1);
     RBG_HIP(hipGetLastError());

@@ -155,6 +155,38 @@ def test_fused_sgl_step_replayed_and_recaptured(rbg, cuda, golden):
         rbg.FusedSGLAdam(_model(rbg, cuda, golden))
 
 
+@pytest.mark.parametrize("n,b,d", [(40_982, 2048, 64), (1500, 257, 64), (3000, 96, 128), (700, 33, 20)])
+def test_infonce_one_pass_form(rbg, cuda, n, b, d):
+    """rbg_infonce_f32 with gradients (option "lse_onepass", default): denominators and the batch rows' gradient out of one
+    pass over the table — against the three-launch form and against sgl.py:191-199 in float64."""
+    gen = torch.Generator().manual_seed(n)
+    t1, t2 = torch.randn(n, d, generator=gen).to(cuda), torch.randn(n, d, generator=gen).to(cuda)
+    idx = torch.randint(0, n, (b,), generator=gen).to(cuda)
+    tau = 0.2
+    res = {}
+    for mode in (1, 0):
+        rbg.set_option("lse_onepass", mode)
+        try:
+            a, c = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+            loss = rbg.ops.info_nce(a, c, idx, tau)
+            loss.backward()
+            res[mode] = (float(loss.detach()), a.grad.clone(), c.grad.clone())
+        finally:
+            rbg.set_option("lse_onepass", 1)
+    a, c = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+    na, nc = torch.nn.functional.normalize(a[idx], dim=1), torch.nn.functional.normalize(c, dim=1)
+    ref = -torch.log(torch.exp((na * nc[idx]).sum(1) / tau) / torch.exp(na @ nc.T / tau).sum(1)).sum()
+    ref.backward()
+    for mode in (1, 0):
+        loss, g1, g2 = res[mode]
+        assert abs(loss - float(ref)) <= 1e-5 * abs(float(ref))
+        for got, want in ((g1, a.grad), (g2, c.grad)):
+            assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+    for x, y in zip(res[1][1:], res[0][1:]):
+        assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
+
+
 @pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
