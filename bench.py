@@ -318,6 +318,13 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         gs = rbg.GraphedStep(sgl, batch, lr=1e-3)
         ex["sgl_train_step_graphed_us"] = time_us(lambda: gs.step(batch), iters=10, warm=2)
         del gs
+        # the same step without autograd (train.FusedSGLAdam: three propagations, rbg_concat_bpr_*, rbg_infonce_f32, three
+        # backward chains, EmbLoss, fused Adam), eager and replayed from a HIP graph
+        fs = rbg.FusedSGLAdam(sgl, lr=1e-3)
+        ex["sgl_fused_step_us"] = time_us(lambda: fs.step(batch), iters=10, warm=3)
+        fg = rbg.FusedSGLAdam(sgl, lr=1e-3, graphed=True)
+        ex["sgl_fused_step_graphed_us"] = time_us(lambda: fg.step(batch), iters=10, warm=4)
+        del fs, fg
         gc = {}
         for mode, flag in (("device_sampling", True), ("numpy_sampling(reference calls)", False)):
             sgl.device_sampling = flag
