@@ -435,6 +435,13 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
                       float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                       void *stream);
 
+/* The same update with the step count in device memory, for callers that replay the step from a HIP graph (a host-side count
+ * would bake the bias corrections of the captured step into every replay): `step` is a DEVICE int64 (0 before the first
+ * call; incremented by the call), `factors` 2 floats of device scratch.  d must be a multiple of 4. */
+int rbg_adam_step_dev_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                          float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                          float eps, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * contrastive (InfoNCE) denominator without the [B, n] matrix
  * ------------------------------------------------------------------------------------------- */

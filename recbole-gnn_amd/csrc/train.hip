@@ -282,6 +282,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ user_emb,
     }
 }
 
+// The same update with the step count in DEVICE memory (a HIP-graph replay must not bake the bias corrections in): a one-thread
+// launch increments *step and writes {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)}; the update reads them.  float4 lanes when the user
+// table's float count is a multiple of 4 (d % 4 == 0).
+__global__ void adam_tick_kernel(int64_t *__restrict__ step, float lr, float beta1, float beta2, float *__restrict__ factors) {
+    const int64_t t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    factors[0] = (float)((double)lr / bc1);
+    factors[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ user_emb, float *__restrict__ item_emb, int64_t n_users_d,
+                                                       const float *__restrict__ grad, float *__restrict__ m, float *__restrict__ v,
+                                                       int64_t nd, const float *__restrict__ factors, float beta1, float beta2, float eps) {
+    const float lr_over_bc1 = factors[0], inv_sqrt_bc2 = factors[1];
+    const int64_t n4 = nd >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = q << 2;
+        const float4 g = *reinterpret_cast<const float4 *>(grad + i);
+        float4 mi = *reinterpret_cast<const float4 *>(m + i), vi = *reinterpret_cast<const float4 *>(v + i);
+        float *pp = i < n_users_d ? user_emb + i : item_emb + (i - n_users_d);
+        float4 pv = *reinterpret_cast<const float4 *>(pp);
+#define RBG_ADAM1(c)                                                        \
+        mi.c = beta1 * mi.c + (1.0f - beta1) * g.c;                         \
+        vi.c = beta2 * vi.c + (1.0f - beta2) * g.c * g.c;                   \
+        pv.c = pv.c - lr_over_bc1 * (mi.c / (sqrtf(vi.c) * inv_sqrt_bc2 + eps));
+        RBG_ADAM1(x) RBG_ADAM1(y) RBG_ADAM1(z) RBG_ADAM1(w)
+#undef RBG_ADAM1
+        *reinterpret_cast<float4 *>(m + i) = mi;
+        *reinterpret_cast<float4 *>(v + i) = vi;
+        *reinterpret_cast<float4 *>(pp) = pv;
+    }
+}
+
 }  // namespace rbg
 
 using namespace rbg;
@@ -384,6 +418,26 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
     const unsigned blocks = (unsigned)std::min<int64_t>((nd + 255) / 256, 4096);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, user_emb, item_emb, n_users * d, grad,
                        exp_avg, exp_avg_sq, nd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_adam_step_dev_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                          float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                          float eps, void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (d % 4) return fail(RBG_EUNSUPPORTED, "rbg_adam_step_dev_f32: d = %d is not a multiple of 4", d);
+    if (!step || !factors) return fail(RBG_EINVAL, "NULL pointer");
+    const int64_t nd = (n_users + n_items) * d;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, lr, beta1, beta2, factors);
+    RBG_HIP(hipGetLastError());
+    if (nd == 0) return RBG_OK;
+    if (!grad || !exp_avg || !exp_avg_sq || (n_users && !user_emb) || (n_items && !item_emb)) return fail(RBG_EINVAL, "NULL pointer");
+    const unsigned blocks = (unsigned)std::min<int64_t>((nd / 4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, s, user_emb, item_emb, n_users * d, grad, exp_avg, exp_avg_sq, nd,
+                       factors, beta1, beta2, eps);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

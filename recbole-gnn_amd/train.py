@@ -22,6 +22,9 @@ def fused_step_applies(model):
 
 
 class FusedBPRAdam:
+    """``step()`` enqueues the five calls; every one of them — incl. Adam, whose step count lives on the device — can be
+    captured into a HIP graph by the caller (``torch.cuda.graph``) and replayed."""
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         # exactly LightGCN: subclasses (SimGCL, XSimGCL) override forward / calculate_loss — contrastive terms, perturbed
         # passes, a layer mean without E0 — none of which this hard-wired BPR + reg step computes
@@ -39,6 +42,8 @@ class FusedBPRAdam:
         self.work = torch.empty((n, d), **f)
         self.exp_avg = torch.zeros((n, d), **f)
         self.exp_avg_sq = torch.zeros((n, d), **f)
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=dev)  # Adam's step count (device: replayable)
+        self.adam_factors = torch.zeros(2, **f)
         self.loss = torch.zeros((), **f)
         self.reg_ws = torch.zeros(3, **f)  # the three block norms of EmbLoss(require_pow=False)
 
@@ -74,11 +79,39 @@ class FusedBPRAdam:
                                                      c_vp(self.grad_e0.data_ptr()), c_vp(self.loss.data_ptr()),
                                                      c_vp(self.reg_ws.data_ptr()), st))
             self.step_count += 1
-            check(lib.rbg_adam_step_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, d,
-                                        c_vp(self.grad_e0.data_ptr()), c_vp(self.exp_avg.data_ptr()),
-                                        c_vp(self.exp_avg_sq.data_ptr()), self.step_count, self.lr, self.betas[0],
-                                        self.betas[1], self.eps, st))
+            if d % 4 == 0:
+                check(lib.rbg_adam_step_dev_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, d,
+                                                c_vp(self.grad_e0.data_ptr()), c_vp(self.exp_avg.data_ptr()),
+                                                c_vp(self.exp_avg_sq.data_ptr()), c_vp(self.step_dev.data_ptr()),
+                                                c_vp(self.adam_factors.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps, st))
+            else:  # (host-side step count: not replayable)
+                check(lib.rbg_adam_step_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, d,
+                                            c_vp(self.grad_e0.data_ptr()), c_vp(self.exp_avg.data_ptr()),
+                                            c_vp(self.exp_avg_sq.data_ptr()), self.step_count, self.lr, self.betas[0],
+                                            self.betas[1], self.eps, st))
         return self.loss
+
+
+class _TableAdam:
+    """torch.optim.Adam (no weight decay, no amsgrad) on the two embedding tables, one launch over both
+    (``rbg_adam_step_dev_f32``: the step count lives on the device, so the call can be replayed from a HIP graph)."""
+
+    def __init__(self, model, lr, betas, eps):
+        self.model, self.lr, self.betas, self.eps = model, float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        uw = model.user_embedding.weight
+        n, d = model.n_users + model.n_items, uw.shape[1]
+        f = dict(dtype=torch.float32, device=uw.device)
+        self.exp_avg, self.exp_avg_sq = torch.zeros((n, d), **f), torch.zeros((n, d), **f)
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=uw.device)
+        self.factors = torch.zeros(2, **f)
+
+    def step(self, grad):
+        m = self.model
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        check(lib.rbg_adam_step_dev_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, uw.shape[1], c_vp(grad.data_ptr()),
+                                        c_vp(self.exp_avg.data_ptr()), c_vp(self.exp_avg_sq.data_ptr()), c_vp(self.step_dev.data_ptr()),
+                                        c_vp(self.factors.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps,
+                                        c_vp(torch.cuda.current_stream(uw.device).cuda_stream)))
 
 
 class _FusedStep:
@@ -169,7 +202,7 @@ class FusedNGCFAdam(_FusedStep):
         self._widths = (_lib.c_int * len(self.e))(*self.widths)
         # gradients of the parameters live here; the embedding tables' are the two row ranges of g[0]
         nu = model.n_users
-        model.user_embedding.weight.grad = self.g[0][:nu]
+        model.user_embedding.weight.grad = self.g[0][:nu]  # (for inspection; the tables are updated from g[0] directly)
         model.item_embedding.weight.grad = self.g[0][nu:]
         self.gb = []
         for gnn in model.GNNlayers:
@@ -177,7 +210,11 @@ class FusedNGCFAdam(_FusedStep):
             gnn.lin1.weight.grad, gnn.lin2.weight.grad = torch.zeros_like(gnn.lin1.weight), torch.zeros_like(gnn.lin2.weight)
             gnn.lin1.bias.grad, gnn.lin2.bias.grad = gb, gb  # (the two biases add into the same output: one gradient)
             self.gb.append(gb)
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
+        # the two tables (all but 25 k of the 4.6 M parameters at the Gowalla shape): one library launch on the ego gradient;
+        # the layers' weights and biases: torch's fused Adam, one multi-tensor launch
+        self.table_opt = _TableAdam(model, lr, betas, eps)
+        self.opt = torch.optim.Adam([p for gnn in model.GNNlayers for p in gnn.parameters()], lr=lr, betas=betas, eps=eps,
+                                    capturable=True, fused=True)
 
     # ---- one step's launches on the current stream --------------------------------------------------------------------------
     def _enqueue(self, user, pos, neg):
@@ -223,6 +260,7 @@ class FusedNGCFAdam(_FusedStep):
                                                  c_vp(self.g[t - 1].data_ptr()), c_vp(gnn.lin1.weight.grad.data_ptr()),
                                                  c_vp(gnn.lin2.weight.grad.data_ptr()), c_vp(self.gb[t - 1].data_ptr()),
                                                  c_vp(self.work.data_ptr()), st))
+            self.table_opt.step(self.g[0])
             self.opt.step()
 
 
@@ -231,7 +269,7 @@ class FusedSGLAdam(_FusedStep):
     """SGL's training step (sgl.py:211-233 + ``loss.backward()`` + Adam) as library calls on preallocated buffers, no autograd:
     three propagations (the full graph and the two views, sgl.py:219-221), the sum-reduced BPR term on the propagated mean
     (``rbg_concat_bpr_*`` form 1), both InfoNCE halves with their table gradients (``rbg_infonce_f32``), three backward
-    chains, EmbLoss on the ego rows, torch's fused Adam on a gradient that lives in this object's buffers.  ``graphed=True``
+    chains, EmbLoss on the ego rows, Adam on the two tables in one library launch (``_TableAdam``).  ``graphed=True``
     replays the step from a HIP graph, re-captured when the model samples new views (``SGL.train()``, sgl.py:94-98)."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
@@ -253,9 +291,11 @@ class FusedSGLAdam(_FusedStep):
         self.sums, self.reg_ws, self.loss = torch.zeros(3, **f), torch.zeros(3, **f), torch.zeros((), **f)
         self._tab = (c_vp * 1)(self.mean[0].data_ptr())
         self._wid = (_lib.c_int * 1)(d)
-        model.user_embedding.weight.grad = self.ge[0][:nu]
+        if len(list(model.parameters())) != 2:
+            raise TypeError("FusedSGLAdam updates the two embedding tables; this model has other parameters")
+        self.table_opt = _TableAdam(model, lr, betas, eps)
+        model.user_embedding.weight.grad = self.ge[0][:nu]  # (for inspection; the tables are updated from ge[0] directly)
         model.item_embedding.weight.grad = self.ge[0][nu:]
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, eps=eps, capturable=True, fused=True)
 
     def _views(self):
         m = self.model
@@ -304,7 +344,7 @@ class FusedSGLAdam(_FusedStep):
             self.ge[0].add_(self.ge[1]).add_(self.ge[2])
             check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(m.reg_weight),
                                                  ptr(self.ge[0]), ptr(self.loss), ptr(self.reg_ws), st))
-            self.opt.step()
+            self.table_opt.step(self.ge[0])
 
 
 def _total(loss):

@@ -44,7 +44,7 @@ def test_fused_step_takes_the_autograd_step(rbg, cuda, golden, p_drop, node_drop
         le = twin.calculate_loss(batch)
         le.backward()
         if step_no == 0:  # same parameters: same loss, same gradients
-            assert abs(lf - float(le.detach())) <= 2e-6 * max(1.0, abs(float(le)))
+            assert abs(lf - float(le.detach())) <= 2e-6 * max(1.0, abs(float(le.detach())))
             for (name, pf), pe in zip(model.named_parameters(), twin.parameters()):
                 scale = max(float(pe.grad.abs().max()), 1e-12)
                 assert float((pf.grad - pe.grad).abs().max()) <= 2e-5 * scale, name
@@ -185,6 +185,49 @@ def test_infonce_one_pass_form(rbg, cuda, n, b, d):
     assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
     for x, y in zip(res[1][1:], res[0][1:]):
         assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
+
+
+def test_adam_with_the_step_count_on_the_device(rbg, cuda):
+    """rbg_adam_step_dev_f32 == torch.optim.Adam over the two tables, also when ONE captured call is replayed: the bias
+    corrections advance with the device-side count (a host-side count would repeat the captured step's)."""
+    from recbole_gnn_amd._lib import c_vp, check, lib
+    nu, ni, d = 37, 53, 64
+    gen = torch.Generator().manual_seed(0)
+    uw, iw = torch.randn(nu, d, generator=gen).to(cuda), torch.randn(ni, d, generator=gen).to(cuda)
+    ref = [uw.clone().requires_grad_(True), iw.clone().requires_grad_(True)]
+    opt = torch.optim.Adam(ref, lr=1e-2)
+    grad = torch.empty(nu + ni, d, device=cuda)
+    m, v = torch.zeros_like(grad), torch.zeros_like(grad)
+    step, fac = torch.zeros((), dtype=torch.int64, device=cuda), torch.zeros(2, device=cuda)
+
+    def call():
+        check(lib.rbg_adam_step_dev_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), nu, ni, d, c_vp(grad.data_ptr()), c_vp(m.data_ptr()),
+                                        c_vp(v.data_ptr()), c_vp(step.data_ptr()), c_vp(fac.data_ptr()), 1e-2, 0.9, 0.999, 1e-8,
+                                        c_vp(torch.cuda.current_stream(cuda).cuda_stream)))
+
+    graph = None
+    for it in range(6):
+        g = torch.randn(nu + ni, d, generator=gen).to(cuda)
+        grad.copy_(g)
+        ref[0].grad, ref[1].grad = g[:nu].clone(), g[nu:].clone()
+        opt.step()
+        if it < 2:
+            call()
+        else:
+            if graph is None:
+                graph = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device=cuda)
+                side.wait_stream(torch.cuda.current_stream(cuda))
+                with torch.cuda.stream(side):
+                    pass
+                with torch.cuda.graph(graph):
+                    call()
+            graph.replay()
+        torch.cuda.synchronize()
+        assert int(step) == it + 1
+        assert float((uw - ref[0].detach()).abs().max()) <= 2e-6 and float((iw - ref[1].detach()).abs().max()) <= 2e-6
+    assert lib.rbg_adam_step_dev_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), nu, ni, 6, c_vp(grad.data_ptr()), c_vp(m.data_ptr()),
+                                     c_vp(v.data_ptr()), c_vp(step.data_ptr()), c_vp(fac.data_ptr()), 1e-2, 0.9, 0.999, 1e-8, None) != 0
 
 
 @pytest.mark.parametrize("form", [0, 1])
