@@ -24,7 +24,20 @@ def timed(users, reps=20):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+if len(sys.argv) > 1 and sys.argv[1] == "short":  # 24-entry lists (three workgroups per CU) against 48-entry lists, interleaved
+    for B in (128, 1024, 4096):
+        users = torch.randint(1, nu, (B,), device=dev)
+        out = {"B": B}
+        res = {}
+        for rep in range(3):
+            for mode in (1, 0):
+                rbg.set_option("topk_short_lists", mode)
+                out.setdefault("short_us" if mode else "long_us", []).append(round(timed(users), 1))
+                res[mode] = rbg.full_sort_topk(g, ua, it, users, 10)
+        out["same_items"] = bool(torch.equal(res[0][1], res[1][1]))
+        out["same_scores"] = bool(torch.equal(res[0][0], res[1][0]))
+        print(json.dumps(out), flush=True)
+elif len(sys.argv) > 1 and sys.argv[1] == "sweep":
     for B in (128, 1024, 4096):
         users = torch.randint(1, nu, (B,), device=dev)
         for sample in (1024, 2048, 4096, 8192, 16384):

@@ -99,6 +99,9 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   pass over the table (the unnormalised gradient accumulates beside the denominator; no separate forward
  *                   launch); 0 = forward launch + two gradient launches
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
+ *   "topk_short_lists" : rbg_full_sort_topk_f32 at k <= 12, d <= 64 keeps 24-entry candidate lists (three workgroups per CU instead of
+ *                   two; a tile's arrivals that do not fit are appended in rounds with a prune between): 1 (default) from
+ *                   2048 users, 2 always, 0 never.  Same results.
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
  *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan
  *                   (rbg_graph_attach_sell) where it applies; 0 = the binned kernel

@@ -46,6 +46,8 @@ int opt_topk_sample() { return g_topk_sample.load(); }
 int opt_score_tiles() { return g_score_tiles.load(); }
 static std::atomic<int> g_score_uniform{1};
 int opt_score_uniform() { return g_score_uniform.load(); }
+static std::atomic<int> g_topk_short{1};
+int opt_topk_short_lists() { return g_topk_short.load(); }
 static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 int opt_col_split() { return g_col_split.load(); }
@@ -588,6 +590,11 @@ int rbg_set_option(const char *key, int64_t value) {
         g_lse_onepass = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "topk_short_lists")) {
+        if (value < 0 || value > 2) return fail(RBG_EINVAL, "topk_short_lists must be 0, 1 or 2");
+        g_topk_short = (int)value;
+        return RBG_OK;
+    }
     if (!strcmp(key, "score_tiles")) {
         if (value < 0 || value > 4096) return fail(RBG_EINVAL, "score_tiles must be 0 (auto) or 1..4096");
         g_score_tiles = (int)value;
@@ -685,6 +692,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "lse_onepass")) {
         *value = g_lse_onepass.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "topk_short_lists")) {
+        *value = g_topk_short.load();
         return RBG_OK;
     }
     if (!strcmp(key, "score_tiles")) {

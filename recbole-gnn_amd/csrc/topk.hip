@@ -168,7 +168,7 @@ __device__ unsigned long long *g_topk_trace = nullptr;
 //  faster: 231.0 vs 229.5 us at d = 64, 437 vs 457 us at d = 128 (4096 users), +13 us at 128 users for the extra pass: the
 //  fetch and the publish were already hidden behind the other resident workgroup's product and filter.  Removed.)
 template <int NCHUNK, bool VEC, int CAP, bool SPLIT>
-__global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
+__global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(const TopkParams p) {
     using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     __shared__ float l_val[4][32][CAP];
@@ -229,19 +229,50 @@ __global__ __launch_bounds__(256) void score_topk_kernel(const TopkParams p) {
                 float *lv = l_val[wave][lu];
                 int *li = l_idx[wave][lu];
                 int base = l_cnt[wave][lu];
-                const int add = __popc(m);
-                if (base + add > CAP) {  // full: prune to the best k valid ones (CAP >= k + 32, so 32 arrivals then fit)
-                    const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
-                    if (h == hh) tau[r] = fmaxf(tau[r], nt);
-                    base = l_cnt[wave][lu];
+                if constexpr (CAP >= 48) {
+                    const int add = __popc(m);
+                    if (base + add > CAP) {  // full: prune to the best k valid ones (CAP >= k + 32, so 32 arrivals then fit)
+                        const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
+                        if (h == hh) tau[r] = fmaxf(tau[r], nt);
+                        base = l_cnt[wave][lu];
+                    }
+                    if (h == hh && pass) {
+                        const int slot = base + __popc(m & ((1u << i) - 1u));
+                        lv[slot] = s;
+                        li[slot] = (int)item;
+                    }
+                    if (lane == 0) l_cnt[wave][lu] = base + add;
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    // short lists (three workgroups per CU): a tile's arrivals may not fit even after a prune — fill the list,
+                    // prune, go on with the rest (rare: the thresholds start at the pre-pass bound)
+                    unsigned rem = m;
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    while (true) {
+                        const int add = __popc(rem);
+                        const bool mine = h == hh && ((rem >> i) & 1u);
+                        const int rank = __popc(rem & ((1u << i) - 1u));
+                        if (base + add <= CAP) {
+                            if (mine) {
+                                lv[base + rank] = s;
+                                li[base + rank] = (int)item;
+                            }
+                            if (lane == 0) l_cnt[wave][lu] = base + add;
+                            __builtin_amdgcn_wave_barrier();
+                            break;
+                        }
+                        const int room = CAP - base;
+                        if (mine && rank < room) {
+                            lv[base + rank] = s;
+                            li[base + rank] = (int)item;
+                        }
+                        for (int q = 0; q < room; ++q) rem &= rem - 1u;  // those lanes are in
+                        if (lane == 0) l_cnt[wave][lu] = CAP;
+                        const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
+                        if (h == hh) tau[r] = fmaxf(tau[r], nt);
+                        base = __builtin_amdgcn_readfirstlane(l_cnt[wave][lu]);
+                    }
                 }
-                if (h == hh && pass) {
-                    const int slot = base + __popc(m & ((1u << i) - 1u));
-                    lv[slot] = s;
-                    li[slot] = (int)item;
-                }
-                if (lane == 0) l_cnt[wave][lu] = base + add;
-                __builtin_amdgcn_wave_barrier();
             }
         });
     };
@@ -531,7 +562,20 @@ static void launch_topk_c(const TopkParams &p, bool vec, dim3 grid, hipStream_t 
     else launch_topk<4, CAP>(p, vec, grid, s);
 }
 
+// 24-entry lists (r04): 52.7 KB of LDS and 168 registers per workgroup = three resident workgroups per CU instead of two.
+// Measured (devtools/topk_probe.py short, interleaved, identical results): 4096 users 223.5 -> 212.5 us, 1024 users equal,
+// 128 users 77.9 -> 80.4 us: on from 2048 users (option "topk_short_lists": 0 = never, 2 = always).
+static bool topk_short_lists(int k, int d, int64_t B) {
+    const int o = opt_topk_short_lists();
+    return k <= 12 && d <= 64 && opt_mfma_split() != 0 && (o == 2 || (o == 1 && B >= 2048));
+}
+
 static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
+    if (topk_short_lists(p.k, p.d, p.B)) {
+        if (vec) hipLaunchKernelGGL((score_topk_kernel<1, true, 24, true>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((score_topk_kernel<1, false, 24, true>), grid, dim3(256), 0, s, p);
+        return;
+    }
     if (p.k <= 16) launch_topk_c<48>(p, vec, grid, s);
     else launch_topk_c<64>(p, vec, grid, s);
 }
@@ -542,11 +586,11 @@ struct TopkLayout {
     int tpc, nc, max_splits, splits, tpc_s;
     int64_t n_tiles, sample_tiles, main_lists, bytes;
 };
-static TopkLayout topk_layout(int64_t B, int64_t n_items) {
+static TopkLayout topk_layout(int64_t B, int64_t n_items, int64_t want_blocks) {
     TopkLayout L{};
     L.n_tiles = (n_items + 31) / 32;
     L.sample_tiles = std::min<int64_t>(opt_topk_sample() / 32, L.n_tiles);
-    topk_geometry(B, L.n_tiles, 512, 8, 128, L.tpc, L.nc);
+    topk_geometry(B, L.n_tiles, want_blocks, 8, 128, L.tpc, L.nc);
     L.main_lists = B * (int64_t)L.nc;
     // the pre-pass splits its sample over up to 64 workgroups per 128 users (aim: ~512 workgroups, >= 2 tiles each)
     const int64_t user_blocks = std::max<int64_t>(1, (B + 127) / 128);
@@ -567,7 +611,7 @@ extern "C" {
 
 int rbg_full_sort_topk_workspace(int64_t B, int64_t n_items, int k, int64_t *bytes) {
     if (!bytes || B < 0 || n_items < 0 || k < 1) return fail(RBG_EINVAL, "bad argument");
-    *bytes = topk_layout(B, n_items).bytes;
+    *bytes = std::max(topk_layout(B, n_items, 512).bytes, topk_layout(B, n_items, 768).bytes);  // (either residency of the main pass)
     return RBG_OK;
 }
 
@@ -589,7 +633,7 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     }
     const int64_t user_tiles = (B + 127) / 128;  // workgroups along the batch
     if (user_tiles > 65535) return fail(RBG_EUNSUPPORTED, "B = %lld too large for one call", (long long)B);
-    const TopkLayout L = topk_layout(B, n_items);
+    const TopkLayout L = topk_layout(B, n_items, topk_short_lists(k, d, B) ? 768 : 512);  // three or two resident workgroups per CU
     char *w = reinterpret_cast<char *>(workspace);
     float *main_val = reinterpret_cast<float *>(w);
     int32_t *main_idx = reinterpret_cast<int32_t *>(main_val + L.main_lists * kListStride);

@@ -1797,6 +1797,33 @@ def test_score_and_topk_at_the_evaluation_batch(rbg, cuda):
     assert int(clear.sum()) > 32
 
 
+def test_full_sort_topk_short_lists(rbg, cuda, golden):
+    """The 24-entry candidate lists of the large-batch top-k (option "topk_short_lists"): identical output to the 48-entry
+    lists — also WITHOUT a pre-pass bound (a small item set: the thresholds start at -inf, every tile brings 32 arrivals per
+    user, so every append goes through the fill / prune / go-on rounds) and with history masks and repeated users."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    cases = [(h, randn((nu, 64), 5, cuda), randn((ni, 64), 6, cuda), torch.from_numpy(np.random.default_rng(1).integers(0, nu, 2100)).to(cuda), 10),
+             (None, randn((3000, 64), 7, cuda), randn((40_982, 64), 8, cuda), torch.arange(2999, -1, -1, device=cuda), 12),
+             (None, randn((300, 33), 9, cuda), randn((5000, 33), 10, cuda), torch.arange(300, device=cuda).repeat(8), 1)]
+    try:
+        for hist, ua, it, users, k in cases:
+            out = {}
+            for mode in (0, 2):
+                rbg.set_option("topk_short_lists", mode)
+                out[mode] = rbg.full_sort_topk(hist, ua, it, users, k)
+            assert torch.equal(out[0][1], out[2][1]) and torch.equal(out[0][0], out[2][0])
+        hist, ua, it, users, k = cases[0]
+        scores, (rv, ri) = reference_topk(ua.cpu(), it.cpu(), users.cpu(), k, g["uid"], g["iid"])
+        rbg.set_option("topk_short_lists", 2)
+        close(rbg.full_sort_topk(hist, ua, it, users, k)[0], rv.float(), tol=1e-5)
+    finally:
+        rbg.set_option("topk_short_lists", 1)
+    with pytest.raises(rbg.RbgError):
+        rbg.set_option("topk_short_lists", 3)
+
+
 def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
