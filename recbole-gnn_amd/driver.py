@@ -15,7 +15,7 @@ import torch
 from .graph import InteractionDataset
 from .models import LightGCN
 from .graph import GraphHandle
-from .train import FusedBPRAdam, GraphedStep, fused_step_applies
+from .train import GraphedStep, fused_stepper
 
 
 def load_inter(path, user_field="user_id", item_field="item_id", sep="\t"):
@@ -147,14 +147,17 @@ def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096, history=None):
 
 
 def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None, graphed=True):
-    """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  LightGCN with
-    ``require_pow`` uses the fused step (train.py); any other model goes through torch autograd + torch.optim.Adam, the
+    """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  Plain LightGCN /
+    NGCF / SGL models use their autograd-free step (``train.fused_stepper``; ``fused=False`` forces the autograd path, whose
+    gradients the fused steps are tested against); any other model goes through torch autograd + torch.optim.Adam, the
     whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly;
     models whose loss has data-dependent shapes — SimGCL, XSimGCL — always run eagerly)."""
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed)
-    if fused is None:  # only the plain LightGCN objective: SimGCL / XSimGCL subclass it with different losses
-        fused = fused_step_applies(model)
-    stepper = FusedBPRAdam(model, lr=lr) if fused else None
+    # the autograd-free steps (train.py): plain LightGCN, NGCF, SGL — subclasses with other losses (SimGCL, XSimGCL, NCL) do not qualify
+    stepper = fused_stepper(model, lr=lr, graphed=graphed) if fused in (None, True) else None
+    if fused and stepper is None:
+        raise TypeError(f"no fused training step for {type(model).__name__} in this configuration")
+    fused = stepper is not None
     graphed = graphed and not fused and next(model.parameters()).is_cuda and getattr(model, "graph_capturable", True)
     opt = None if (fused or graphed) else torch.optim.Adam(model.parameters(), lr=lr, fused=next(model.parameters()).is_cuda)
     gstep = None

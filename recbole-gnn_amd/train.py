@@ -117,7 +117,8 @@ class _TableAdam:
 class _FusedStep:
     """What the autograd-free steps share: the batch's index tensors, and — ``graphed=True`` — the capture of one step's
     launches into a HIP graph after two eager warm-up steps (lazy allocations must exist before capture), replayed per batch
-    of the captured size and re-captured when the graph handles the step reads change (SGL samples new views per epoch)."""
+    of the captured size (a batch of another size — an epoch's last one — is enqueued eagerly on its own scratch) and
+    re-captured when the graph handles the step reads change (SGL samples new views per epoch)."""
 
     def _init_graphed(self, graphed):
         self.graphed = bool(graphed)
@@ -155,8 +156,9 @@ class _FusedStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._enqueue(*self._static)
-        if user.shape != self._static[0].shape:
-            raise ValueError("a graphed step replays a fixed batch size; run the epoch's last, shorter batch on a second, eager instance")
+        if user.shape != self._static[0].shape:  # (an epoch's last, shorter batch: the same launches, not replayed)
+            self._enqueue(user, pos, neg)
+            return self.loss
         for dst, src in zip(self._static, (user, pos, neg)):
             dst.copy_(src)
         self._graph.replay()
@@ -197,7 +199,7 @@ class FusedNGCFAdam(_FusedStep):
             check(lib.rbg_bignn_backward_workspace(n, d_in, d_out, _lib.ctypes.byref(nbytes)))
             need = max(need, nbytes.value)
         self.work = torch.empty(need, dtype=torch.uint8, device=dev)
-        self.coef, self.sums, self.loss = None, torch.zeros(3, **f), torch.zeros((), **f)
+        self.coef, self._coef, self.sums, self.loss = None, {}, torch.zeros(3, **f), torch.zeros((), **f)
         self._tabs = (c_vp * len(self.e))(*[t.data_ptr() for t in self.e])
         self._widths = (_lib.c_int * len(self.e))(*self.widths)
         # gradients of the parameters live here; the embedding tables' are the two row ranges of g[0]
@@ -222,8 +224,9 @@ class FusedNGCFAdam(_FusedStep):
         dev, nu, b = m.device, m.n_users, user.shape[0]
         graph = m._dropout_graph() if (m.node_dropout != 0 and m.training) else m.graph
         graph_t = graph.transpose()
-        if self.coef is None or self.coef.shape[0] != b:
-            self.coef = torch.empty(b, dtype=torch.float32, device=dev)
+        if b not in self._coef:  # (per batch size: a captured graph keeps reading the buffer of ITS size)
+            self._coef[b] = torch.empty(b, dtype=torch.float32, device=dev)
+        self.coef = self._coef[b]
         st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
         k_layers = len(self.widths) - 1
         masks = []
@@ -287,7 +290,7 @@ class FusedSGLAdam(_FusedStep):
         self.ge = [torch.empty((n, d), **f) for _ in range(3)]     # dLoss/dE0 through each propagation; ge[0] ends as the total
         self.layers = torch.empty((max(model.n_layers, 1), n, d), **f)
         self.work = torch.empty((n, d), **f)
-        self.coef, self.nce_work = None, None
+        self.coef, self.nce_work, self._scratch = None, None, {}
         self.sums, self.reg_ws, self.loss = torch.zeros(3, **f), torch.zeros(3, **f), torch.zeros((), **f)
         self._tab = (c_vp * 1)(self.mean[0].data_ptr())
         self._wid = (_lib.c_int * 1)(d)
@@ -313,13 +316,13 @@ class FusedSGLAdam(_FusedStep):
         uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
         d = uw.shape[1]
         views = self._views()
-        if self.coef is None or self.coef.shape[0] != b:
-            self.coef = torch.empty(b, dtype=torch.float32, device=dev)
+        if b not in self._scratch:  # (per batch size: a captured graph keeps reading the buffers of ITS size)
             nbytes, need = _lib.c_i64(), 8
             for rows in (nu, ni):
                 check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
                 need = max(need, nbytes.value)
-            self.nce_work = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._scratch[b] = (torch.empty(b, dtype=torch.float32, device=dev), torch.empty(need, dtype=torch.uint8, device=dev))
+        self.coef, self.nce_work = self._scratch[b]
         st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
         ptr = lambda t, row=0: c_vp(t.data_ptr() + 4 * row * d)  # noqa: E731  (rows [row, ...) of a contiguous [*, d] table)
         with torch.cuda.device(dev):
@@ -345,6 +348,24 @@ class FusedSGLAdam(_FusedStep):
             check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(m.reg_weight),
                                                  ptr(self.ge[0]), ptr(self.loss), ptr(self.reg_ws), st))
             self.table_opt.step(self.ge[0])
+
+
+def fused_stepper(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=True):
+    """The autograd-free training step of `model` if this package has one — ``FusedBPRAdam`` (plain LightGCN),
+    ``FusedNGCFAdam`` (plain NGCF, fused layers, widths <= 128), ``FusedSGLAdam`` (plain SGL, d <= 128), all on device graph
+    handles — else None (``GraphedStep`` / an eager loop serve every other model).  ``graphed`` applies to the latter two."""
+    from .models import NGCF, SGL
+    if not next(model.parameters()).is_cuda:
+        return None
+    if fused_step_applies(model) and isinstance(model.graph, ops.GraphHandle):
+        return FusedBPRAdam(model, lr=lr, betas=betas, eps=eps)
+    for cls, step in ((NGCF, FusedNGCFAdam), (SGL, FusedSGLAdam)):
+        if type(model) is cls:
+            try:
+                return step(model, lr=lr, betas=betas, eps=eps, graphed=graphed)
+            except TypeError:
+                return None
+    return None
 
 
 def _total(loss):
@@ -383,7 +404,7 @@ class GraphedStep:
         # warm-up on a side stream (allocator / lazy-initialisation effects must be out of the way before capture); the
         # parameters and the optimiser state are put back afterwards, so the warm-up leaves no trace in the training run
         saved = [p.detach().clone() for p in model.parameters()]
-        side = torch.cuda.Stream(device=self.static[next(iter(self.static))].device)
+        side = self._side = torch.cuda.Stream(device=self.static[next(iter(self.static))].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
@@ -409,6 +430,11 @@ class GraphedStep:
         return found
 
     def _capture(self):
+        # the previous capture's loss holds that step's autograd graph, which holds the graph handles it ran on: let go of it
+        # BEFORE the capture starts — dropped inside it, the last reference to an old epoch's views would destroy them there
+        # (hipFree during a capture invalidates it: SGL's second epoch failed with hipErrorStreamCaptureInvalidated)
+        self.loss = None
+        self.graph = None
         self._captured_graphs = self._graph_objects(self.model)
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
@@ -436,9 +462,17 @@ class GraphedStep:
         return self.loss
 
     def eager_step(self, batch):
-        """The same step without the graph (odd-sized batches).  Gradients left by the graph's buffers are dropped first."""
-        self.opt.zero_grad(set_to_none=True)
-        loss = _total(self.model.calculate_loss(batch))
-        loss.backward()
-        self.opt.step()
-        return loss.detach()
+        """The same step without the graph (odd-sized batches).  Gradients left by the graph's buffers are dropped first.
+        Runs on the warm-up's side stream, like everything this object does outside a replay: autograd binds the parameters'
+        AccumulateGrad nodes to the stream of their first use, and nodes bound to the DEFAULT stream invalidate the next
+        capture (SGL re-captures every epoch, right after an epoch's odd-sized last batch came through here)."""
+        cur = torch.cuda.current_stream(self._side.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            self.opt.zero_grad(set_to_none=True)
+            loss = _total(self.model.calculate_loss(batch))
+            loss.backward()
+            self.opt.step()
+            loss = loss.detach()
+        cur.wait_stream(self._side)
+        return loss

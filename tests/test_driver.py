@@ -122,3 +122,27 @@ def test_fit_trains_the_subclass_objective(rbg, cuda, ref_inter, name):
     assert abs(la[0] - total) <= 1e-4 * max(1.0, abs(total))
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert float((pa - pb).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["NGCF", "SGL"])
+def test_fit_uses_the_autograd_free_step(rbg, cuda, ref_inter, name):
+    """driver.fit picks train.FusedNGCFAdam / FusedSGLAdam for the plain models (replayed from a HIP graph, the epoch's shorter
+    last batch enqueued eagerly): two epochs give the losses of the autograd path (``fused=False``) on a twin model."""
+    uid, iid, nu, ni = ref_inter
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    cfg = {"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2, "hidden_size_list": [64, 64], "message_dropout": 0.0,
+           "node_dropout": 0.0, "reg_weight": 1e-4, "device_sampling": False}
+    out = []
+    for fused in (None, False):
+        torch.manual_seed(1)
+        np.random.seed(7)  # (SGL's views, sampled by model.train() at the start of every epoch)
+        m = getattr(rbg, name)(cfg, ds)
+        assert isinstance(rbg.fused_stepper(m), rbg.FusedNGCFAdam if name == "NGCF" else rbg.FusedSGLAdam)
+        out.append((rbg.driver.fit(m, uid, iid, epochs=2, lr=1e-3, batch_size=500, seed=5, fused=fused), m))
+    (la, ma), (lb, mb) = out
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 5e-4 * max(1.0, abs(y)), (la, lb)
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert float((pa - pb).abs().max()) <= 2e-3 * max(1.0, float(pb.abs().max()))
+    assert rbg.fused_stepper(rbg.SimGCL({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2}, ds)) is None

@@ -66,14 +66,17 @@ def test_fused_step_replayed_from_a_hip_graph(rbg, cuda, golden):
         losses.append((la, lb))
     assert a._graph is not None
     assert all(np.isfinite(x) and np.isfinite(y) and abs(x - y) < 0.25 for x, y in losses), losses
-    with pytest.raises(ValueError):
-        a.step({k: v[:10] for k, v in _batches(golden, cuda, 1, 64)[0].items()})
+    short = {k: v[:10] for k, v in _batches(golden, cuda, 1, 64)[0].items()}  # an epoch's last batch: enqueued, not replayed
+    assert np.isfinite(float(a.step(short))) and np.isfinite(float(b.step(short)))
+    assert np.isfinite(float(a.step(_batches(golden, cuda, 1, 64)[0])))  # ... and the captured size still replays
     # without dropout a replayed step IS the eager step
     model, twin = _model(rbg, cuda, golden), _model(rbg, cuda, golden)
     twin.load_state_dict(model.state_dict())
     model.train(), twin.train()
     a, b = rbg.FusedNGCFAdam(model, lr=1e-3, graphed=True), rbg.FusedNGCFAdam(twin, lr=1e-3)
-    for batch in _batches(golden, cuda, 5, 64):
+    for n, batch in enumerate(_batches(golden, cuda, 6, 64)):
+        if n == 4:
+            batch = {k: v[:23] for k, v in batch.items()}  # a shorter batch between replays shares the optimizer state
         la, lb = float(a.step(batch)), float(b.step(batch))
         assert abs(la - lb) <= 2e-4 * max(1.0, abs(lb))
     for pa, pb in zip(model.parameters(), twin.parameters()):
