@@ -770,10 +770,10 @@ int rbg_bignn_wgrad_f32(const float *G, int64_t ldg, const float *P, const float
     hipStream_t s = (hipStream_t)stream;
     const int64_t w = (int64_t)d_out * d_in;
     if (n_rows == 0) {
-        RBG_HIP(hipMemsetAsync(dW1, 0, (size_t)w * 4, s));
-        RBG_HIP(hipMemsetAsync(dW2, 0, (size_t)w * 4, s));
-        if (db) RBG_HIP(hipMemsetAsync(db, 0, (size_t)d_out * 4, s));
-        return RBG_OK;
+        int zrc = zero_async(dW1, (size_t)w * 4, s);
+        if (!zrc) zrc = zero_async(dW2, (size_t)w * 4, s);
+        if (!zrc && db) zrc = zero_async(db, (size_t)d_out * 4, s);
+        return zrc;
     }
     if (!G || !P || !X) return fail(RBG_EINVAL, "NULL pointer");
     WgradParams p{};

@@ -530,8 +530,8 @@ int rbg_lse_rows_backward_f32(const float *Q, int64_t ldq, int64_t B, const floa
     if (!workspace || (B && (!lse || !grad_lse))) return fail(RBG_EINVAL, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (B == 0 || n == 0) {
-        if (grad_Q && B) RBG_HIP(hipMemsetAsync(grad_Q, 0, (size_t)B * d * 4, s));
-        if (grad_C && n) RBG_HIP(hipMemsetAsync(grad_C, 0, (size_t)n * d * 4, s));
+        if (grad_Q && B && (rc = zero_async(grad_Q, (size_t)B * d * 4, s))) return rc;
+        if (grad_C && n && (rc = zero_async(grad_C, (size_t)n * d * 4, s))) return rc;
         return RBG_OK;
     }
     const LseLayout L = lse_layout(B, n, d);

@@ -26,6 +26,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// hipMemsetAsync is NOT used on the caller's stream anywhere in this library: captured into a HIP graph, a memset node writes
+// its value correctly on the first replay and garbage bytes on later ones (ROCm 7.2, measured: devtools/memset_probe.py — the
+// fused NGCF step's EmbLoss sums read 0xD9D9D9D9 at its 51st replay).  A fill KERNEL is a kernel node like any other.
+__global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, int64_t n_words) {
+    const int64_t n4 = n_words >> 2;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) p[(n4 << 2) + threadIdx.x] = 0u;
+}
+
+int zero_async(void *ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return RBG_OK;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(ptr) & 3)) return fail(RBG_EINVAL, "zero_async: %zu bytes at %p (4-byte units)", bytes, ptr);
+    uint32_t *p = static_cast<uint32_t *>(ptr);
+    int64_t words = (int64_t)(bytes >> 2);
+    const int64_t head = std::min<int64_t>(words, (int64_t)((16 - (reinterpret_cast<uintptr_t>(ptr) & 15)) & 15) >> 2);  // up to the 16-byte boundary
+    if (head) {
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, p, head);
+        p += head, words -= head;
+    }
+    if (words) {
+        const unsigned blocks = (unsigned)std::min<int64_t>(((words >> 2) + 255) / 256 + 1, 4096);
+        hipLaunchKernelGGL(zero_words_kernel, dim3(blocks), dim3(256), 0, s, p, words);
+    }
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
 constexpr int kElemsPerWave = 4;  // batch elements per wavefront: 16 per workgroup, ONE loss atomic per workgroup
 // (one atomic per element on the single loss word serialised the whole kernel: 80 us for 6 144 elements)
 
@@ -328,8 +356,8 @@ int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, co
     if (n_users < 0 || n_items < 0 || B < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
     if (!out_mean || !grad_mean || !loss || (B > 0 && (!user || !pos || !neg))) return fail(RBG_EINVAL, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    RBG_HIP(hipMemsetAsync(grad_mean, 0, sizeof(float) * (size_t)(n_users + n_items) * d, s));
-    RBG_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    int zrc = zero_async(grad_mean, sizeof(float) * (size_t)(n_users + n_items) * d, s);
+    if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
     hipLaunchKernelGGL(bpr_grad_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, out_mean, n_users, user, pos, neg, B, d,
                        1e-10f, grad_mean, loss);
@@ -359,7 +387,7 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     if (B == 0 || reg_weight == 0.f) return RBG_OK;
     if (!user_emb || !item_emb || !user || !pos || !neg || !grad_e0 || !loss || !workspace) return fail(RBG_EINVAL, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    RBG_HIP(hipMemsetAsync(workspace, 0, 3 * sizeof(float), s));
+    if (int zrc = zero_async(workspace, 3 * sizeof(float), s)) return zrc;
     const dim3 grid((unsigned)((3 * B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave)));
     hipLaunchKernelGGL(emb_sumsq_kernel, grid, dim3(256), 0, s, user_emb, item_emb, user, pos, neg, B, d, workspace);
     hipLaunchKernelGGL(emb_reg_grad_nopow_kernel, grid, dim3(256), 0, s, user_emb, item_emb, n_users, user, pos, neg, B, d, reg_weight,
@@ -382,8 +410,8 @@ int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int 
         T.tab[t] = tables[t], T.width[t] = widths[t];
     }
     hipStream_t s = (hipStream_t)stream;
-    RBG_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(float), s));
-    RBG_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    int zrc = zero_async(sums, 3 * sizeof(float), s);
+    if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
     hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, T, n_users,
                        user, pos, neg, B, 1e-10f, form, coef, sums, loss);

@@ -106,7 +106,7 @@ def test_fit_trains_the_subclass_objective(rbg, cuda, ref_inter, name):
     with pytest.raises(TypeError):
         rbg.FusedBPRAdam(a)
     torch.manual_seed(77)
-    la = rbg.driver.fit(a, uid, iid, epochs=1, lr=1e-3, batch_size=512, seed=5)
+    la = rbg.driver.fit(a, uid, iid, epochs=1, lr=1e-3, batch_size=512, seed=5, device_sampler=False)
     torch.manual_seed(77)
     opt = torch.optim.Adam(b.parameters(), lr=1e-3)
     b.train()
@@ -146,3 +146,34 @@ def test_fit_uses_the_autograd_free_step(rbg, cuda, ref_inter, name):
     for pa, pb in zip(ma.parameters(), mb.parameters()):
         assert float((pa - pb).abs().max()) <= 2e-3 * max(1.0, float(pb.abs().max()))
     assert rbg.fused_stepper(rbg.SimGCL({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2}, ds)) is None
+
+
+@pytest.mark.gpu
+def test_device_sampler(rbg, cuda, ref_inter):
+    """BPRSampler on the GPU: every interaction once per epoch, negatives never training positives (nor PAD), reproducible from
+    the seed, reshuffled and redrawn every epoch — the host sampler's contract with no host work per batch."""
+    uid, iid, nu, ni = ref_inter
+    pos = set((uid * ni + iid).tolist())
+
+    def epoch(s):
+        out = [tuple(b[k].cpu().numpy() for k in ("user_id", "item_id", "neg_item_id")) for b in s]
+        assert all(b["user_id"].is_cuda for b in [next(iter(s))])
+        return [np.concatenate(c) for c in zip(*out)]
+
+    s = rbg.driver.BPRSampler(uid, iid, ni, batch_size=300, seed=11, device=cuda)
+    u1, p1, n1 = epoch(s)
+    u2, p2, n2 = epoch(s)
+    for u, p, n in ((u1, p1, n1), (u2, p2, n2)):
+        assert len(u) == len(uid) and sorted((u * ni + p).tolist()) == sorted((uid * ni + iid).tolist())
+        assert n.min() >= 1 and n.max() < ni and not (set((u * ni + n).tolist()) & pos)
+    assert not np.array_equal(u1, u2) and len(s) == (len(uid) + 299) // 300
+    u3, p3, n3 = epoch(rbg.driver.BPRSampler(uid, iid, ni, batch_size=300, seed=11, device=cuda))
+    assert np.array_equal(u1, u3) and np.array_equal(p1, p3) and np.array_equal(n1, n3)
+    # a user who interacted with all items but one: the only legal negative is found
+    small = 40
+    dense_u = np.ones(small - 2, dtype=np.int64)
+    dense_i = np.arange(1, small - 1, dtype=np.int64)
+    s = rbg.driver.BPRSampler(dense_u, dense_i, small, batch_size=16, seed=0, device=cuda)
+    s.ROUNDS = 400  # (a draw is legal with probability 1/39 here: 400 redraw rounds leave 3e-5 of the draws on a positive)
+    negs = np.concatenate([b["neg_item_id"].cpu().numpy() for b in s])
+    assert np.all(negs == small - 1)
