@@ -336,8 +336,32 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             torch.cuda.synchronize()
             gc[mode] = (time.perf_counter() - t0) / 3 * 1e3
         ex["sgl_graph_construction_ms(two ED views)"] = gc
+        del sgl
     except Exception as e:  # noqa: BLE001  (diagnostics only: never cost the headline its JSON line)
         ex["model_steps_error"] = str(e)[:200]
+    # whole epochs through the minimal driver (driver.fit: device-side BPR sampler, the models' autograd-free steps, SGL's views
+    # re-sampled per epoch): seconds for the SECOND epoch of every model = 502 batches of 2048 at the Gowalla shape
+    try:
+        ep = {}
+        for name in ("LightGCN", "NGCF", "SGL"):
+            torch.manual_seed(0)
+            np.random.seed(0)
+            mm = getattr(rbg, name)({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "require_pow": True}, ds)
+            marks = []
+
+            def mark(_msg, marks=marks):
+                torch.cuda.synchronize()
+                marks.append(time.perf_counter())
+
+            t0 = time.perf_counter()
+            rbg.driver.fit(mm, uid, iid, epochs=2, lr=1e-3, log=mark)
+            ep[name] = {"epoch_s": round(marks[1] - marks[0], 4), "first_epoch_s(incl. warm-up and capture)": round(marks[0] - t0, 4),
+                        "stepper": type(rbg.fused_stepper(mm)).__name__}
+            del mm
+        ep["batches_per_epoch"] = (len(uid) + 2047) // 2048
+        ex["driver_epoch(device sampler, fused steps, model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep
+    except Exception as e:  # noqa: BLE001
+        ex["driver_epoch_error"] = str(e)[:200]
     return ex
 
 
