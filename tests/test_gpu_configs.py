@@ -124,6 +124,17 @@ def test_config3_ngcf_yelp2018_shape(rbg, cuda):
         close(layer.lin1.weight.grad, w1.grad, tol=2e-5)
         close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
         close(layer.lin1.bias.grad, b1.grad, tol=2e-5)
+    # the autograd-free step (train.FusedNGCFAdam) on the same parameters and batch: the same loss and gradients, against the
+    # oracle's — lr = 0 leaves the parameters where the reference gradients were taken
+    stepper = rbg.FusedNGCFAdam(model, lr=0.0)
+    fused_loss = stepper.step({k: v.to(cuda) for k, v in batch.items()})
+    close(fused_loss.reshape(()), ref_loss.detach().reshape(()))
+    close(stepper.g[0][:nu], leaves[0].grad, tol=2e-5)
+    close(stepper.g[0][nu:], leaves[1].grad, tol=2e-5)
+    for layer, gb, (w1, b1, w2, b2) in zip(model.GNNlayers, stepper.gb, lp):
+        close(layer.lin1.weight.grad, w1.grad, tol=2e-5)
+        close(layer.lin2.weight.grad, w2.grad, tol=2e-5)
+        close(gb, b1.grad, tol=2e-5)
 
 
 # ---- #4 -------------------------------------------------------------------------------------------------------------
