@@ -322,17 +322,6 @@ __global__ void lse_reduce_kernel(const float *__restrict__ part, int n_chunks, 
     out[x] = a;
 }
 
-// out[b][k] = coef[b] * sum_c part[c][b][k], fixed order (the own-side gradient of the one-pass form: the launch ran with
-// unit coefficients because the denominators came out of the same pass)
-__global__ void lse_reduce_scaled_kernel(const float *__restrict__ part, int n_chunks, int64_t B, int d, const float *__restrict__ coef,
-                                         float *__restrict__ out) {
-    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= B * d) return;
-    float a = 0.f;
-    for (int c = 0; c < n_chunks; ++c) a += part[(int64_t)c * B * d + x];
-    out[x] = a * coef[x / d];
-}
-
 // Chunking.  Measured (per-workgroup clock trace, r01): the kernel is matrix-core bound per CU, all workgroups start at
 // once and the dispatcher spreads them evenly, so the launch lasts as long as the fullest CU: ceil(blocks / 256)
 // workgroups x tiles per chunk.  832 workgroups (3.25 per CU) ran 130 us where 768 run 89 us.  Pick the chunk count
@@ -421,66 +410,6 @@ static bool lse_vec(const float *Q, int64_t ldq, const float *C, int64_t ldc, in
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
-
-// The forward and the own-side gradient in ONE pass over the candidates (r04): with a fixed shift (no running maximum) the
-// unnormalised gradient sum_j w[b][j] C[j] accumulates beside the denominator sum_j w[b][j], so the separate forward launch
-// (57 us of a 385 us InfoNCE half at 2048 x 40 982, d = 64) disappears; the normalisation moves into the chunk reduction.
-// Leaves the gradient partials in the workspace for lse_onepass_finish.
-static int lse_onepass_begin(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale, float shift,
-                             float *lse, void *workspace, hipStream_t s) {
-    const LseLayout L = lse_layout(B, n, d);
-    char *w = reinterpret_cast<char *>(workspace);
-    float *part_q = reinterpret_cast<float *>(w + L.off_q), *den = reinterpret_cast<float *>(w + L.off_den);
-    LseParams p{};
-    p.d = d;
-    p.s2 = scale * kLog2e;
-    p.shift2 = shift * kLog2e;
-    p.own = Q, p.ld_own = ldq, p.n_own = B;
-    p.oth = C, p.ld_oth = ldc, p.n_oth = n;
-    p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
-    p.out = part_q;
-    p.den_out = den;
-    lse_launch_d<true>(p, lse_vec(Q, ldq, C, ldc, d), s);
-    RBG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(lse_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, B, shift, lse);
-    RBG_HIP(hipGetLastError());
-    return RBG_OK;
-}
-
-// grad_Q from the partials of lse_onepass_begin, grad_C by the usual second pass
-static int lse_onepass_finish(const float *Q, int64_t ldq, int64_t B, const float *C, int64_t ldc, int64_t n, int d, float scale, float shift,
-                              const float *lse, const float *grad_lse, float *grad_Q, float *grad_C, void *workspace, hipStream_t s) {
-    const LseLayout L = lse_layout(B, n, d);
-    char *w = reinterpret_cast<char *>(workspace);
-    float *coef = reinterpret_cast<float *>(w + L.off_coef);
-    float *part_q = reinterpret_cast<float *>(w + L.off_q), *part_c = reinterpret_cast<float *>(w + L.off_c);
-    hipLaunchKernelGGL(lse_coef_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, grad_lse, lse, B, scale, shift, coef);
-    RBG_HIP(hipGetLastError());
-    if (grad_Q) {
-        const int64_t len = B * d;
-        hipLaunchKernelGGL(lse_reduce_scaled_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_q, L.nc_q, B, d, coef, grad_Q);
-        RBG_HIP(hipGetLastError());
-    }
-    if (grad_C) {
-        LseParams p{};
-        p.d = d;
-        p.s2 = scale * kLog2e;
-        p.shift2 = shift * kLog2e;
-        p.own = C, p.ld_own = ldc, p.n_own = n;
-        p.oth = Q, p.ld_oth = ldq, p.n_oth = B;
-        p.coef_own = nullptr, p.coef_oth = coef;
-        p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
-        p.out = L.nc_c > 1 ? part_c : grad_C;
-        lse_launch_d<true>(p, lse_vec(Q, ldq, C, ldc, d), s);
-        RBG_HIP(hipGetLastError());
-        if (L.nc_c > 1) {
-            const int64_t len = n * d;
-            hipLaunchKernelGGL(lse_reduce_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, s, part_c, L.nc_c, len, grad_C);
-            RBG_HIP(hipGetLastError());
-        }
-    }
-    return RBG_OK;
-}
 
 }  // namespace rbg
 
@@ -696,6 +625,90 @@ __global__ __launch_bounds__(256) void nce_table_back_kernel(const float *__rest
     }
 }
 
+// ---- the one-pass form's small kernels, fused (r04): 11 launches per InfoNCE half -> 7 ----------------------------------
+// den[b] = sum_c den_part[c][b];  lse = log(den) + shift;  term[b] = lse - scale pos[b];  coef[b] = weight * scale / den[b]
+// (= the upstream gradient weight times scale * exp(shift - lse)).  One thread per batch row; the loss is the fixed-order sum of
+// term[] by nce_sum_kernel (one block: reproducible).
+__global__ __launch_bounds__(256) void nce_finish_kernel(const float *__restrict__ den_part, int n_chunks, const float *__restrict__ pos,
+                                                         int64_t B, float scale, float shift, float weight, float *__restrict__ term,
+                                                         float *__restrict__ coef) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float den = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < n_chunks; ++c) den += den_part[(int64_t)c * B + b];
+    const float lse = logf(den) + shift;
+    term[b] = lse - scale * pos[b];
+    coef[b] = weight * scale * expf(shift - lse);
+}
+
+__global__ __launch_bounds__(256) void nce_sum_kernel(const float *__restrict__ term, int64_t B, float weight, float *__restrict__ loss) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 256) acc += term[b];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss += weight * (((part[0] + part[1]) + part[2]) + part[3]);
+}
+
+// nce_batch_back_kernel with dA[b] = coef[b] * sum_c part_q[c][b] formed here (the chunk reduction of the batch-side gradient)
+__global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const float *__restrict__ part_q, int n_chunks, const float *__restrict__ coef,
+                                                                   const float *__restrict__ A, const float *__restrict__ C,
+                                                                   const float *__restrict__ inv1, const int64_t *__restrict__ idx, int64_t B,
+                                                                   int d, float ws, float *__restrict__ dC, float *__restrict__ grad_T1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t r = idx[b];
+    const float cb = coef[b];
+    float g0 = 0.f, g1 = 0.f;  // d <= 128: columns lane and lane + 64
+    const bool in0 = lane < d, in1 = lane + 64 < d;
+#pragma unroll 8
+    for (int c = 0; c < n_chunks; ++c) {  // (unrolled: the chunks' loads go out together instead of one latency each)
+        const float *src = part_q + ((int64_t)c * B + b) * d;
+        g0 += in0 ? src[lane] : 0.f;
+        g1 += in1 ? src[lane + 64] : 0.f;
+    }
+    g0 = lane < d ? g0 * cb - ws * C[r * d + lane] : 0.f;
+    g1 = lane + 64 < d ? g1 * cb - ws * C[r * d + lane + 64] : 0.f;
+    const float a0 = lane < d ? A[b * d + lane] : 0.f, a1 = lane + 64 < d ? A[b * d + lane + 64] : 0.f;
+    const float dot = wave_sum(fmaf(g0, a0, g1 * a1));
+    const float iv = inv1[b];
+    const bool clamped = iv >= 1.0f / kNormEps;
+    if (lane < d) {
+        if (grad_T1) atomicAdd(grad_T1 + r * d + lane, (clamped ? g0 : g0 - a0 * dot) * iv);
+        atomicAdd(dC + r * d + lane, -ws * a0);
+    }
+    if (lane + 64 < d) {
+        if (grad_T1) atomicAdd(grad_T1 + r * d + lane + 64, (clamped ? g1 : g1 - a1 * dot) * iv);
+        atomicAdd(dC + r * d + lane + 64, -ws * a1);
+    }
+}
+
+// nce_table_back_kernel with g = sum_c part_c[c][j] formed here (the chunk reduction of the table-side gradient; the batch rows'
+// positive-term contributions were added onto chunk 0 by the kernel above)
+__global__ __launch_bounds__(256) void nce_table_back_parts_kernel(const float *__restrict__ part_c, int n_chunks, const float *__restrict__ C,
+                                                                   const float *__restrict__ inv, int64_t n, int d, float *__restrict__ grad_T2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    float g0 = 0.f, g1 = 0.f;
+    const bool in0 = lane < d, in1 = lane + 64 < d;
+#pragma unroll 8
+    for (int c = 0; c < n_chunks; ++c) {
+        const float *src = part_c + ((int64_t)c * n + j) * d;
+        g0 += in0 ? src[lane] : 0.f;
+        g1 += in1 ? src[lane + 64] : 0.f;
+    }
+    const float c0 = lane < d ? C[j * d + lane] : 0.f, c1 = lane + 64 < d ? C[j * d + lane + 64] : 0.f;
+    const float dot = wave_sum(fmaf(g0, c0, g1 * c1));
+    const float iv = inv[j];
+    const bool clamped = iv >= 1.0f / kNormEps;
+    if (lane < d) grad_T2[j * d + lane] += (clamped ? g0 : g0 - c0 * dot) * iv;
+    if (lane + 64 < d) grad_T2[j * d + lane + 64] += (clamped ? g1 : g1 - c1 * dot) * iv;
+}
+
 struct NceLayout {
     int64_t off_C, off_inv2, off_A, off_inv1, off_pos, off_lse, off_gl, off_dA, off_dC, off_lse_ws, bytes;
 };
@@ -715,6 +728,54 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
     L.off_lse_ws = o, o += lse_layout(B, n, d).bytes;
     L.bytes = o + 256;
     return L;
+}
+
+// rbg_infonce_f32 with gradients, one-pass form (r04, option "lse_onepass").  With a FIXED shift (unit rows: 1 / tau; no running
+// maximum) the unnormalised batch-side gradient sum_j w[b][j] C[j] accumulates beside the denominator sum_j w[b][j] in ONE pass over
+// the table, so the separate forward launch (57 us of a 385 us half at 2048 x 40 982, d = 64) is gone; the normalisation moves
+// into the consumers of the chunk partials, which also absorb the chunk reductions: 8 launches per half instead of 13.
+static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC, const float *T1,
+                           const int64_t *idx, int64_t n, int d, int64_t B, float scale, float weight, float *loss, float *grad_T1,
+                           float *grad_T2, void *lse_ws, hipStream_t s) {
+    const LseLayout L = lse_layout(B, n, d);
+    char *w = reinterpret_cast<char *>(lse_ws);
+    float *coef = reinterpret_cast<float *>(w + L.off_coef), *part_q = reinterpret_cast<float *>(w + L.off_q);
+    float *part_c = L.nc_c > 1 ? reinterpret_cast<float *>(w + L.off_c) : dC, *den = reinterpret_cast<float *>(w + L.off_den);
+    const bool vec = lse_vec(A, d, C, d, d);
+    LseParams p{};
+    p.d = d;
+    p.s2 = scale * kLog2e;
+    p.shift2 = scale * kLog2e;
+    // pass 1 (own = the batch rows): denominators' and gradient's partials per chunk
+    p.own = A, p.ld_own = d, p.n_own = B;
+    p.oth = C, p.ld_oth = d, p.n_oth = n;
+    p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
+    p.out = part_q;
+    p.den_out = den;
+    lse_launch_d<true>(p, vec, s);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nce_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, pos, B, scale, scale, weight, term, coef);
+    hipLaunchKernelGGL(nce_sum_kernel, dim3(1), dim3(256), 0, s, term, B, weight, loss);
+    RBG_HIP(hipGetLastError());
+    // pass 2 (own = the table rows): needs the finished denominators (coef)
+    p.own = C, p.n_own = n;
+    p.oth = A, p.n_oth = B;
+    p.coef_own = nullptr, p.coef_oth = coef;
+    p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
+    p.out = part_c;
+    p.den_out = nullptr;
+    lse_launch_d<true>(p, vec, s);
+    RBG_HIP(hipGetLastError());
+    const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
+    hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, part_q, L.nc_q, coef, A, C, inv1, idx, B, d, weight * scale,
+                       part_c, grad_T1);
+    RBG_HIP(hipGetLastError());
+    if (grad_T2) {
+        hipLaunchKernelGGL(nce_table_back_parts_kernel, dim3(nb), dim3(256), 0, s, part_c, L.nc_c, C, inv2, n, d, grad_T2);
+        RBG_HIP(hipGetLastError());
+    }
+    (void)T1;
+    return RBG_OK;
 }
 
 }  // namespace rbg
@@ -750,14 +811,13 @@ int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const in
     RBG_HIP(hipGetLastError());
     const bool grads = grad_T1 || grad_T2;
     const bool onepass = grads && opt_lse_onepass();  // denominators and dA out of one pass over the table
-    int rc = onepass ? lse_onepass_begin(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, s)
-                     : rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
+    if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, T1, idx, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s);
+    int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
     RBG_HIP(hipGetLastError());
     if (!grads) return RBG_OK;
-    rc = onepass ? lse_onepass_finish(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, s)
-                 : rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
+    rc = rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(nce_batch_back_kernel, dim3(bb), dim3(256), 0, s, dA, A, C, inv1, T1, idx, B, d, weight * scale, dC, grad_T1);
     RBG_HIP(hipGetLastError());
