@@ -492,6 +492,8 @@ def dropout_mask(n, d, p_drop, device):
     """The scaled keep mask of ``nn.Dropout(p)`` (0 or 1 / (1 - p)) as an fp32 [n, d] tensor: two launches (Bernoulli draw,
     scale) on torch's generator — the compare / cast / divide spelling cost four passes over [N, d] per layer, 140 us of a
     660 us NGCF step at the Gowalla shape."""
+    if p_drop >= 1.0:  # nn.Dropout(p = 1): everything dropped
+        return torch.zeros((n, d), dtype=torch.float32, device=device)
     return torch.empty((n, d), dtype=torch.float32, device=device).bernoulli_(1.0 - p_drop).mul_(1.0 / (1.0 - p_drop))
 
 
