@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""Option "sell_two_chains": the K layers as two per-class launch chains on two streams vs K launches; us, HIP-graph replay."""
+"""[HISTORICAL: the library option this probe drives (`sell_two_chains`) was removed with the experiment; kept as the harness that
+produced profiles/r04_*_probe.jsonl — it does not run against the current library.]
+Option "sell_two_chains": the K layers as two per-class launch chains on two streams vs K launches; us, HIP-graph replay."""
 import ctypes, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import recbole_gnn_amd as rbg
 dev = torch.device("cuda:0")

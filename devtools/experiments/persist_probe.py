@@ -1,8 +1,10 @@
 #!/usr/bin/env python
-"""The persistent K-layer launch (option "sell_persist") against the K launches: propagation and backward chain, us."""
+"""[HISTORICAL: the library option this probe drives (`sell_persist`) was removed with the experiment; kept as the harness that
+produced profiles/r04_*_probe.jsonl — it does not run against the current library.]
+The persistent K-layer launch (option "sell_persist") against the K launches: propagation and backward chain, us."""
 import ctypes, json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import recbole_gnn_amd as rbg
 dev = torch.device("cuda:0")

@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""Upper bound of a hot-row tile: the propagation with the gathers of the plan's first T slab rows (its numbering is degree-
+"""[HISTORICAL: the library option this probe drives (`sell_skip_hot`) was removed with the experiment; kept as the harness that
+produced profiles/r04_*_probe.jsonl — it does not run against the current library.]
+Upper bound of a hot-row tile: the propagation with the gathers of the plan's first T slab rows (its numbering is degree-
 descending: the hottest rows) reading nothing (option "sell_skip_hot": WRONG results, timing only)."""
 import json, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import recbole_gnn_amd as rbg
 dev = torch.device("cuda:0")
