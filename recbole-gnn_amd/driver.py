@@ -163,14 +163,51 @@ def topk_metrics(topk_idx, truth, k):
     }
 
 
+def topk_metric_sums(topk_idx, rows, truth_keys, n_truth, stride, k):
+    """The same five metrics, summed over the batch, as tensor ops on whatever device the inputs live on (no host work per
+    batch).  topk_idx [B, k] int64 (-1 = fewer than k rankable items); rows [B] = the batch users' ranks in the sorted list of
+    evaluated users; truth_keys: sorted unique ``rank * stride + item``; n_truth [n_eval_users]."""
+    cand = rows[:, None] * stride + topk_idx
+    at = torch.searchsorted(truth_keys, cand.reshape(-1)).clamp_(max=max(truth_keys.numel() - 1, 0)).reshape(cand.shape)
+    hit = (truth_keys[at] == cand) & (topk_idx >= 0) if truth_keys.numel() else torch.zeros_like(cand, dtype=torch.bool)
+    nt = n_truth[rows].to(torch.float64)
+    n_hit = hit.sum(1).to(torch.float64)
+    disc = 1.0 / torch.log2(torch.arange(2, k + 2, dtype=torch.float64, device=cand.device))
+    dcg = (hit.to(torch.float64) * disc).sum(1)
+    idcg = torch.cat([torch.zeros(1, dtype=torch.float64, device=cand.device), torch.cumsum(disc, 0)])[nt.clamp(max=k).long()]
+    first = torch.where(hit.any(1), hit.to(torch.int64).argmax(1) + 1, torch.zeros_like(rows))
+    return torch.stack([(n_hit / nt.clamp(min=1)).sum(), (n_hit / k).sum(), (n_hit > 0).to(torch.float64).sum(),
+                        (dcg / idcg.clamp(min=1e-12)).sum(), torch.where(first > 0, 1.0 / first.clamp(min=1).to(torch.float64), 0.0).sum()])
+
+
+METRIC_NAMES = ("recall", "precision", "hit", "ndcg", "mrr")
+
+
 @torch.no_grad()
-def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096, history=None):
+def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096, history=None, device_metrics=True):
     """Full-sort evaluation (``mode: full``): every user with ground truth in (eval_uid, eval_iid) is ranked against all
     items, PAD and history masked, by the fused score/top-k kernel; metrics averaged over users.
     ``history``: GraphHandle whose user rows are the interactions to mask (RecBole's sampler ``used_ids``: the training
-    set for the valid phase, training + valid for the test phase); None = the model's training graph."""
+    set for the valid phase, training + valid for the test phase); None = the model's training graph.
+    ``device_metrics``: ground truth as sorted keys in HBM and the metrics as tensor ops next to the top-k lists (one host
+    read at the end); False = the per-batch numpy path (``topk_metrics``), which the device path is tested against."""
     model.eval()
     model.restore_user_e = model.restore_item_e = None
+    if device_metrics and model.device.type == "cuda":
+        dev = model.device
+        eu = torch.as_tensor(np.asarray(eval_uid, dtype=np.int64), device=dev)
+        ei = torch.as_tensor(np.asarray(eval_iid, dtype=np.int64), device=dev)
+        users, rank = torch.unique(eu, return_inverse=True)  # (sorted)
+        stride = int(model.n_items) + 1
+        truth_keys = torch.unique(rank * stride + ei)
+        n_truth = torch.bincount(truth_keys // stride, minlength=users.numel())
+        sums = torch.zeros(len(METRIC_NAMES), dtype=torch.float64, device=dev)
+        for s in range(0, users.numel(), batch_users):
+            ub = users[s:s + batch_users]
+            _, idx = model.full_sort_topk({"user_id": ub}, k, history=history)
+            sums += topk_metric_sums(idx, torch.arange(s, s + ub.numel(), device=dev), truth_keys, n_truth, stride, k)
+        out = (sums / max(int(users.numel()), 1)).cpu().tolist()
+        return {f"{name}@{k}": v for name, v in zip(METRIC_NAMES, out)}
     truth = {}
     for u, i in zip(eval_uid.tolist(), eval_iid.tolist()):
         truth.setdefault(u, set()).add(i)

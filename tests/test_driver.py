@@ -177,3 +177,39 @@ def test_device_sampler(rbg, cuda, ref_inter):
     s.ROUNDS = 400  # (a draw is legal with probability 1/39 here: 400 redraw rounds leave 3e-5 of the draws on a positive)
     negs = np.concatenate([b["neg_item_id"].cpu().numpy() for b in s])
     assert np.all(negs == small - 1)
+
+
+def test_metric_sums_as_tensor_ops(rbg):
+    """driver.topk_metric_sums (what evaluate() runs next to the top-k lists) == driver.topk_metrics summed, incl. -1 slots,
+    users without hits and a ground truth longer than k."""
+    rng = np.random.default_rng(0)
+    n_items, k, b = 50, 7, 40
+    truth = [set(rng.choice(np.arange(1, n_items), size=rng.integers(1, 12), replace=False).tolist()) for _ in range(b)]
+    topk = np.stack([rng.choice(np.arange(1, n_items), size=k, replace=False) for _ in range(b)])
+    topk[3, 4:] = -1
+    topk[7] = -1
+    ref = rbg.driver.topk_metrics(topk, truth, k)
+    stride = n_items + 1
+    keys = torch.tensor(sorted(r * stride + i for r, t in enumerate(truth) for i in t))
+    n_truth = torch.tensor([len(t) for t in truth])
+    got = rbg.driver.topk_metric_sums(torch.from_numpy(topk), torch.arange(b), keys, n_truth, stride, k)
+    for name, v in zip(rbg.driver.METRIC_NAMES, got.tolist()):
+        assert abs(v - float(ref[name].sum())) <= 1e-9, name
+    half = rbg.driver.topk_metric_sums(torch.from_numpy(topk[20:]), torch.arange(20, b), keys, n_truth, stride, k)  # a later batch
+    assert abs(float(half[0]) - float(ref["recall"][20:].sum())) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_evaluate_on_the_device_equals_the_numpy_path(rbg, cuda, ref_inter):
+    uid, iid, nu, ni = ref_inter
+    (tr_u, tr_i), (va_u, va_i), (te_u, te_i) = rbg.driver.split_by_user(uid, iid, seed=2020)
+    ds = rbg.InteractionDataset(tr_u, tr_i, nu, ni)
+    torch.manual_seed(0)
+    model = rbg.LightGCN({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2}, ds)
+    dup_u, dup_i = np.concatenate([te_u, te_u[:5]]), np.concatenate([te_i, te_i[:5]])  # repeated pairs count once
+    for eu, ei in ((va_u, va_i), (dup_u, dup_i)):
+        a = rbg.driver.evaluate(model, eu, ei, k=10, batch_users=100)
+        b = rbg.driver.evaluate(model, eu, ei, k=10, batch_users=100, device_metrics=False)
+        assert set(a) == set(b)
+        for name in a:
+            assert abs(a[name] - b[name]) <= 1e-12, name
