@@ -171,7 +171,8 @@ class FusedNGCFAdam(_FusedStep):
     backward call (``rbg_bignn_backward_f32``); the loss on the rows of the concatenation ``cat(E_0..E_K)`` (ngcf.py:100,
     113-117) is ``rbg_concat_bpr_begin_f32`` + one ``rbg_concat_bpr_scatter_f32`` per layer, which adds a layer's sparse row
     gradients IN PLACE onto the dense gradient the layer above has just written (autograd: zeros + index_add + add per layer,
-    and ~40 small launches for the loss).  The update is torch's fused Adam on gradients that live in this object's buffers.
+    and ~40 small launches for the loss).  The update: one library launch for the two embedding tables (``_TableAdam``: Adam's
+    step count on the device), torch's fused Adam for the layers' weights — both on gradients that live in this object's buffers.
     ``graphed=True`` captures the whole step into one HIP graph after the first call (fixed batch size).
 
     The model keeps its parameters, so ``full_sort_predict`` etc. see the trained weights.  ``message_dropout`` draws its masks
@@ -265,7 +266,6 @@ class FusedNGCFAdam(_FusedStep):
                                                  c_vp(self.work.data_ptr()), st))
             self.table_opt.step(self.g[0])
             self.opt.step()
-
 
 
 class FusedSGLAdam(_FusedStep):
