@@ -13,7 +13,6 @@ import numpy as np
 import torch
 
 from .graph import InteractionDataset
-from .models import LightGCN
 from .graph import GraphHandle
 from .train import GraphedStep, fused_stepper
 
