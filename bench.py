@@ -934,6 +934,12 @@ def main():
                                              "sharding": result["config"]["sharding"]}
             result["value"], result["ms_per_step"], result["steps"] = cs_["value"], cs_["ms_per_step"], cs_["steps"]
             result["config"]["sharding"] = f"feature-column shards x{world}: {cs_['columns_per_rank']} columns per rank, nothing exchanged in the K layers"
+            result["config"]["workload"] = (result["config"]["workload"].split(" cut into ")[0] +
+                                            f": every rank holds the whole graph and {cs_['columns_per_rank']} of the {d} embedding columns")
+            if "speedup_vs_one_gpu_same_workload" in result:  # (that figure belongs to the node-range run)
+                result["node_range_sharding"]["speedup_vs_one_gpu_same_workload"] = result.pop("speedup_vs_one_gpu_same_workload")
+                if one_gpu.get("value"):
+                    result["speedup_vs_one_gpu_same_workload"] = cs_["value"] / one_gpu["value"]
             result["roofline"].update(frac=cs_["per_rank_roofline_frac"], achieved=cs_["per_rank_roofline_frac"] * HBM_PEAK_GBPS, kernel=cs_["kernel"],
                                       note="per-rank: algorithmic bytes of the rank's slab layer / its mean layer duration")
         if world > 1:
