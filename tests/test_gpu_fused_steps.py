@@ -233,6 +233,45 @@ def test_adam_with_the_step_count_on_the_device(rbg, cuda):
                                      c_vp(v.data_ptr()), c_vp(step.data_ptr()), c_vp(fac.data_ptr()), 1e-2, 0.9, 0.999, 1e-8, None) != 0
 
 
+def test_zero_fill_kernel_alignment_and_bounds(rbg, cuda):
+    """The library zeroes through a fill kernel (csrc/train.hip zero_async — a captured hipMemsetAsync node writes garbage on later
+    replays): any 4-byte alignment, any word count, nothing outside the range — and the same values on every replay of a graph."""
+    from recbole_gnn_amd._lib import c_vp, check, lib
+    tab = torch.zeros(4, 64, device=cuda)
+    ptrs, wid = (c_vp * 1)(tab.data_ptr()), (ctypes.c_int * 1)(64)
+    idx = torch.zeros(1, dtype=torch.int64, device=cuda)
+    st = lambda: c_vp(torch.cuda.current_stream(cuda).cuda_stream)  # noqa: E731
+    buf = torch.empty(64, device=cuda)
+    for off in range(5):  # rbg_concat_bpr_begin_f32 with B = 0: zero sums[3] and loss[1], nothing else
+        buf.fill_(7.0)
+        check(lib.rbg_concat_bpr_begin_f32(ptrs, wid, 1, 2, 2, c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), 0, 0,
+                                           c_vp(buf.data_ptr()), c_vp(buf[off:].data_ptr()), c_vp(buf[40 + off:].data_ptr()), st()))
+        want = torch.full((64,), 7.0)
+        want[off:off + 3] = 0
+        want[40 + off] = 0
+        assert torch.equal(buf.cpu(), want), off
+    for (nu, ni, d, off) in ((3, 4, 5, 1), (100, 57, 64, 3), (1, 1, 1, 2), (1000, 999, 33, 0)):  # rbg_bpr_grad_f32 with B = 0: grad_mean [N, d]
+        big = torch.full(((nu + ni) * d + 16,), 7.0, device=cuda)
+        loss = torch.full((1,), 7.0, device=cuda)
+        check(lib.rbg_bpr_grad_f32(c_vp(big.data_ptr()), nu, ni, c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), 0, d,
+                                   c_vp(big[off:].data_ptr()), c_vp(loss.data_ptr()), st()))
+        want = torch.full_like(big, 7.0).cpu()
+        want[off:off + (nu + ni) * d] = 0
+        assert torch.equal(big.cpu(), want) and float(loss) == 0.0, (nu, ni, d, off)
+    sums, loss = torch.ones(3, device=cuda), torch.ones((), device=cuda)
+    side = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(side):
+        pass
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        check(lib.rbg_concat_bpr_begin_f32(ptrs, wid, 1, 2, 2, c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), c_vp(idx.data_ptr()), 0, 0,
+                                           c_vp(buf.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st()))
+    for _ in range(60):
+        sums.fill_(1.0), loss.fill_(1.0)
+        g.replay()
+        assert float(sums.abs().sum()) == 0.0 and float(loss) == 0.0
+
+
 @pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
