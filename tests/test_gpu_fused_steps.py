@@ -233,6 +233,26 @@ def test_adam_with_the_step_count_on_the_device(rbg, cuda):
                                      c_vp(v.data_ptr()), c_vp(step.data_ptr()), c_vp(fac.data_ptr()), 1e-2, 0.9, 0.999, 1e-8, None) != 0
 
 
+@pytest.mark.parametrize("name", ["NGCF", "SGL"])
+def test_many_replays_of_a_captured_step(rbg, cuda, golden, name):
+    """80 steps of the captured step against the eagerly enqueued one on a twin (the hipMemsetAsync hazard showed at the 51st
+    replay): finite, and the two trajectories stay together."""
+    mk = (lambda: _model(rbg, cuda, golden)) if name == "NGCF" else (lambda: _sgl(rbg, cuda, golden))
+    model, twin = mk(), mk()
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    if name == "SGL":
+        twin.sub_graph1, twin.sub_graph2 = model.sub_graph1, model.sub_graph2
+    cls = rbg.FusedNGCFAdam if name == "NGCF" else rbg.FusedSGLAdam
+    a, b = cls(model, lr=1e-3, graphed=True), cls(twin, lr=1e-3)
+    batches = _batches(golden, cuda, 8, 64)
+    for n in range(80):
+        la, lb = float(a.step(batches[n % 8])), float(b.step(batches[n % 8]))
+        assert np.isfinite(la) and np.isfinite(lb)
+        assert abs(la - lb) <= 2e-3 * max(1.0, abs(lb)), (n, la, lb)
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+
+
 def test_zero_fill_kernel_alignment_and_bounds(rbg, cuda):
     """The library zeroes through a fill kernel (csrc/train.hip zero_async — a captured hipMemsetAsync node writes garbage on later
     replays): any 4-byte alignment, any word count, nothing outside the range — and the same values on every replay of a graph."""
