@@ -339,6 +339,27 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         del sgl
     except Exception as e:  # noqa: BLE001  (diagnostics only: never cost the headline its JSON line)
         ex["model_steps_error"] = str(e)[:200]
+    # BASELINE config #3 as named: NGCF on the Yelp2018 shape (forward = ngcf.py:73-104 -> [N, 256]; one training step)
+    try:
+        yu, yi, ynu, yni = rbg.synth.make("yelp2018")
+        yds = rbg.InteractionDataset(yu, yi, ynu, yni)
+        torch.manual_seed(0)
+        ym = rbg.NGCF({"device": str(dev), "enable_sparse": True, "embedding_size": d, "hidden_size_list": [d] * 3, "message_dropout": 0.0,
+                       "reg_weight": 1e-5}, yds)
+        gy_ = torch.Generator().manual_seed(1)
+        yb = {"user_id": torch.randint(1, ynu, (2048,), generator=gy_).to(dev), "item_id": torch.randint(1, yni, (2048,), generator=gy_).to(dev),
+              "neg_item_id": torch.randint(1, yni, (2048,), generator=gy_).to(dev)}
+        ym.eval()
+        with torch.no_grad():
+            fwd_us = time_us(lambda: ym.forward(), iters=20, warm=3)
+        ym.train()
+        yf = rbg.FusedNGCFAdam(ym, lr=1e-3, graphed=True)
+        ex["config3_ngcf_yelp2018_shape"] = {"nodes": ynu + yni, "nnz": 2 * len(yu), "forward_us([N, 256] out)": fwd_us,
+                                             "fused_step_graphed_us(batch 2048)": time_us(lambda: yf.step(yb), iters=20, warm=4),
+                                             "kernel": ym.graph.spmm_kernel_name(d)}
+        del ym, yf, yds
+    except Exception as e:  # noqa: BLE001
+        ex["config3_error"] = str(e)[:200]
     # whole epochs through the minimal driver (driver.fit: device-side BPR sampler, the models' autograd-free steps, SGL's views
     # re-sampled per epoch): seconds for the SECOND epoch of every model = 502 batches of 2048 at the Gowalla shape
     try:
