@@ -18,6 +18,18 @@ import torch.nn.functional as F
 from . import ops
 
 
+def _once_mask(ids):
+    """mask[i] = True for exactly ONE occurrence of every distinct id in `ids` — what ``torch.unique`` selects, with static
+    shapes (a sort and a neighbour compare instead of a data-dependent output length), so a loss over the unique ids can be
+    written as a masked loss over the whole batch and the step stays capturable into a HIP graph."""
+    s, order = torch.sort(ids)
+    first = torch.ones_like(s, dtype=torch.bool)
+    first[1:] = s[1:] != s[:-1]
+    mask = torch.empty_like(first)
+    mask[order] = first
+    return mask
+
+
 def _rows(table, idx):
     """``table[idx]`` / ``embedding(idx)`` of the reference, spelled index_select: same values, but the backward is one
     atomic ``index_add_`` launch instead of torch's sort-based index_put / embedding backward (115 us per lookup at
@@ -506,7 +518,10 @@ class SimGCL(LightGCN):
     adds sign(e) * normalize(U(0,1) noise) * eps after every layer — the noise is drawn with ``torch.rand_like`` in the
     reference's order, the add is the SpMM's epilogue (``ops.spmm_noise``)."""
 
-    graph_capturable = False  # calculate_loss calls torch.unique (simgcl.py:52-53): data-dependent shapes
+    # simgcl.py:52-53 restricts the contrast to ``torch.unique`` of the batch's ids: a data-dependent shape (a device-to-host sync
+    # per step, no HIP-graph capture).  ``static_unique`` (default) computes the SAME loss with static shapes: one occurrence of
+    # every id is kept by a mask over rows (the sum) and columns (the denominators) — equal up to summation order.
+    graph_capturable = True
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -516,6 +531,8 @@ class SimGCL(LightGCN):
         self.cl_rate = config["lambda"] if config["lambda"] is not None else 0.5
         self.eps = config["eps"] if config["eps"] is not None else 0.1
         self.temperature = config["temperature"] if config["temperature"] is not None else 0.2
+        self.static_unique = config["static_unique"] if config["static_unique"] is not None else True
+        self.graph_capturable = bool(self.static_unique)
 
     def _layers(self, perturbed):
         all_embs = self.get_ego_embeddings()
@@ -537,20 +554,29 @@ class SimGCL(LightGCN):
         mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
         return torch.split(mean, [self.n_users, self.n_items])
 
-    def calculate_cl_loss(self, x1, x2):
+    def calculate_cl_loss(self, x1, x2, once=None):
+        """simgcl.py:38-43.  ``once``: the rows / columns that count (one occurrence per distinct id of the batch) when x1, x2
+        hold the WHOLE batch instead of its unique ids."""
         x1, x2 = F.normalize(x1, dim=-1), F.normalize(x2, dim=-1)
         pos_score = torch.exp((x1 * x2).sum(dim=-1) / self.temperature)
-        ttl_score = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature).sum(dim=1)
-        return -torch.log(pos_score / ttl_score).sum()
+        logits = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature)
+        if once is None:
+            return -torch.log(pos_score / logits.sum(dim=1)).sum()
+        w = once.to(logits.dtype)
+        return -(torch.log(pos_score / (logits * w[None, :]).sum(dim=1)) * w).sum()
 
     def calculate_loss(self, interaction):
         loss = super().calculate_loss(interaction)
-        user = torch.unique(interaction[self.USER_ID])
-        pos_item = torch.unique(interaction[self.ITEM_ID])
+        user, pos_item = interaction[self.USER_ID], interaction[self.ITEM_ID]
         u1, i1 = self.forward(perturbed=True)
         u2, i2 = self.forward(perturbed=True)
-        user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user))
-        item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item))
+        if self.static_unique:
+            user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user), _once_mask(user))
+            item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item), _once_mask(pos_item))
+        else:
+            user, pos_item = torch.unique(user), torch.unique(pos_item)
+            user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user))
+            item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item))
         return loss + self.cl_rate * (user_cl_loss + item_cl_loss)
 
 
@@ -577,11 +603,10 @@ class XSimGCL(SimGCL):
             return user_all, item_all, user_cl, item_cl
         return user_all, item_all
 
-    def calculate_cl_loss(self, x1, x2):
-        x1, x2 = F.normalize(x1, dim=-1), F.normalize(x2, dim=-1)
-        pos_score = torch.exp((x1 * x2).sum(dim=-1) / self.temperature)
-        ttl_score = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature).sum(dim=1)
-        return -torch.log(pos_score / ttl_score).mean()
+    def calculate_cl_loss(self, x1, x2, once=None):
+        """xsimgcl.py:50-54: SimGCL's contrast as a MEAN over the (distinct) rows."""
+        total = super().calculate_cl_loss(x1, x2, once)
+        return total / (x1.shape[0] if once is None else once.sum().to(total.dtype))
 
     def calculate_loss(self, interaction):
         if self.restore_user_e is not None or self.restore_item_e is not None:
@@ -592,9 +617,13 @@ class XSimGCL(SimGCL):
         mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
         reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
                                  _rows(self.item_embedding.weight, neg_item), require_pow=self.require_pow)
-        user_u, item_u = torch.unique(user), torch.unique(pos_item)
-        user_cl_loss = self.calculate_cl_loss(_rows(user_all, user_u), _rows(user_cl, user_u))
-        item_cl_loss = self.calculate_cl_loss(_rows(item_all, item_u), _rows(item_cl, item_u))
+        if self.static_unique:
+            user_cl_loss = self.calculate_cl_loss(u_e, _rows(user_cl, user), _once_mask(user))
+            item_cl_loss = self.calculate_cl_loss(pos_e, _rows(item_cl, pos_item), _once_mask(pos_item))
+        else:
+            user_u, item_u = torch.unique(user), torch.unique(pos_item)
+            user_cl_loss = self.calculate_cl_loss(_rows(user_all, user_u), _rows(user_cl, user_u))
+            item_cl_loss = self.calculate_cl_loss(_rows(item_all, item_u), _rows(item_cl, item_u))
         return mf_loss, self.reg_weight * reg_loss, self.cl_rate * (user_cl_loss + item_cl_loss)
 
 

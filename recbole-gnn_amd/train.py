@@ -381,9 +381,10 @@ class GraphedStep:
     half of the step's wall time (NGCF, Gowalla shape: 1.5 ms of kernels in a 3.5 ms step, r01) — the rest is launch
     latency.  A graph replay submits the same kernels, in the same order on the same buffers, with one call.  Works for
     every model of this package whose loss has static shapes (all device work is enqueued on torch's current stream and
-    nothing synchronises): LightGCN, NGCF, SGL.  SimGCL / XSimGCL call ``torch.unique`` on the batch (simgcl.py:52-53):
-    a data-dependent shape needs a device-to-host sync, which stream capture forbids, and a replay would bake in the
-    first batch's unique count — those models declare ``graph_capturable = False`` and are refused here.
+    nothing synchronises): LightGCN, NGCF, SGL, and SimGCL / XSimGCL with their ``static_unique`` form (the reference's
+    ``torch.unique`` of the batch, simgcl.py:52-53, is a data-dependent shape: a device-to-host sync, which stream capture
+    forbids, and a replay would bake in the first batch's unique count; the models' default writes the same loss with a
+    one-occurrence mask).  Models that declare ``graph_capturable = False`` (``static_unique = False``, NCL) are refused here.
 
     ``step(batch)`` copies the batch's index tensors into the captured input buffers and replays; batches must have the
     size of ``example_batch`` (RecBole's last, shorter batch of an epoch goes through ``eager_step``)."""

@@ -102,11 +102,11 @@ def test_fit_trains_the_subclass_objective(rbg, cuda, ref_inter, name):
     a = getattr(rbg, name)(cfg, ds)
     torch.manual_seed(1)
     b = getattr(rbg, name)(cfg, ds)
-    assert not rbg.train.fused_step_applies(a) and not a.graph_capturable
+    assert not rbg.train.fused_step_applies(a) and a.graph_capturable  # (static_unique: the same loss with static shapes)
     with pytest.raises(TypeError):
         rbg.FusedBPRAdam(a)
-    torch.manual_seed(77)
-    la = rbg.driver.fit(a, uid, iid, epochs=1, lr=1e-3, batch_size=512, seed=5, device_sampler=False)
+    torch.manual_seed(77)  # (graphed=False: a replayed step draws its noise from the graph's own generator state)
+    la = rbg.driver.fit(a, uid, iid, epochs=1, lr=1e-3, batch_size=512, seed=5, device_sampler=False, graphed=False)
     torch.manual_seed(77)
     opt = torch.optim.Adam(b.parameters(), lr=1e-3)
     b.train()
@@ -213,3 +213,37 @@ def test_evaluate_on_the_device_equals_the_numpy_path(rbg, cuda, ref_inter):
         assert set(a) == set(b)
         for name in a:
             assert abs(a[name] - b[name]) <= 1e-12, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["SimGCL", "XSimGCL"])
+def test_static_unique_is_the_unique_loss(rbg, cuda, ref_inter, name):
+    """simgcl.py:52-53 / xsimgcl.py:86-87 contrast the ``torch.unique`` ids of the batch; the default ``static_unique`` form keeps one
+    occurrence per id by a mask over rows and columns: the same value and gradients on batches full of repeats (same noise
+    draws), and the step can be captured — fit() replays it from a HIP graph for more than one epoch."""
+    uid, iid, nu, ni = ref_inter
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    cfg = {"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2, "require_pow": True}
+    torch.manual_seed(1)
+    a = getattr(rbg, name)(cfg, ds)
+    torch.manual_seed(1)
+    b = getattr(rbg, name)(dict(cfg, static_unique=False), ds)
+    assert a.graph_capturable and not b.graph_capturable
+    gen = torch.Generator().manual_seed(3)
+    batch = {"user_id": torch.randint(1, 40, (256,), generator=gen).to(cuda), "item_id": torch.randint(1, 60, (256,), generator=gen).to(cuda),
+             "neg_item_id": torch.randint(1, ni, (256,), generator=gen).to(cuda)}
+    out = []
+    for m in (a, b):
+        m.train()
+        torch.manual_seed(9)
+        loss = m.calculate_loss(batch)
+        loss = sum(loss) if isinstance(loss, tuple) else loss
+        loss.backward()
+        out.append((float(loss.detach()), [p.grad.clone() for p in m.parameters()]))
+    assert abs(out[0][0] - out[1][0]) <= 1e-5 * max(1.0, abs(out[1][0]))
+    for ga, gb in zip(out[0][1], out[1][1]):
+        assert float((ga - gb).abs().max()) <= 1e-5 * max(1e-6, float(gb.abs().max()))
+    with pytest.raises(RuntimeError):
+        rbg.GraphedStep(b, batch)
+    hist = rbg.driver.fit(a, uid, iid, epochs=3, lr=1e-3, batch_size=500, seed=5)  # HIP-graph replay + an odd-sized last batch per epoch
+    assert all(np.isfinite(h) for h in hist) and hist[-1] < hist[0]
