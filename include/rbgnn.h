@@ -476,6 +476,14 @@ int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes);
 int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau,
                     float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream);
 
+/* The same with weights: *loss += weight * sum_b row_w[b] * ( log sum_j col_w[j] exp(<a_b, c_j> / tau) - <a_b, p_b> / tau ).
+ * row_w [B] / col_w [n]: device arrays or NULL (= 1).  With T1, T2 the batch's gathered rows ([B, d], idx = 0..B-1, n = B) and
+ * row_w = col_w = "one occurrence per distinct id" this is the contrast of simgcl.py:38-43,52-57 / xsimgcl.py:50-54,86-89 over
+ * torch.unique of the batch (for the mean form divide row_w by its sum), without a data-dependent shape. */
+int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau, float weight,
+                           const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
+                           void *stream);
+
 /* Full-sort evaluation of one batch without the [B, n_items] score matrix.
  * Replaces full_sort_predict (lightgcn.py:123-133) + RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
  *   scores = user_all[users] @ item_all.T;  scores[:, 0] = -inf;  scores[history_index] = -inf;  topk(scores, k)

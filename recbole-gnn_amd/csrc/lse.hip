@@ -630,16 +630,17 @@ __global__ __launch_bounds__(256) void nce_table_back_kernel(const float *__rest
 // (= the upstream gradient weight times scale * exp(shift - lse)).  One thread per batch row; the loss is the fixed-order sum of
 // term[] by nce_sum_kernel (one block: reproducible).
 __global__ __launch_bounds__(256) void nce_finish_kernel(const float *__restrict__ den_part, int n_chunks, const float *__restrict__ pos,
-                                                         int64_t B, float scale, float shift, float weight, float *__restrict__ term,
-                                                         float *__restrict__ coef) {
+                                                         const float *__restrict__ row_w, int64_t B, float scale, float shift, float weight,
+                                                         float *__restrict__ term, float *__restrict__ coef) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     float den = 0.f;
 #pragma unroll 8
     for (int c = 0; c < n_chunks; ++c) den += den_part[(int64_t)c * B + b];
     const float lse = logf(den) + shift;
-    term[b] = lse - scale * pos[b];
-    coef[b] = weight * scale * expf(shift - lse);
+    const float r = row_w ? row_w[b] : 1.f;  // (rbg_infonce_masked_f32: a row's weight in the sum)
+    term[b] = r * (lse - scale * pos[b]);
+    coef[b] = r * weight * scale * expf(shift - lse);
 }
 
 __global__ __launch_bounds__(256) void nce_sum_kernel(const float *__restrict__ term, int64_t B, float weight, float *__restrict__ loss) {
@@ -655,13 +656,15 @@ __global__ __launch_bounds__(256) void nce_sum_kernel(const float *__restrict__ 
 // nce_batch_back_kernel with dA[b] = coef[b] * sum_c part_q[c][b] formed here (the chunk reduction of the batch-side gradient)
 __global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const float *__restrict__ part_q, int n_chunks, const float *__restrict__ coef,
                                                                    const float *__restrict__ A, const float *__restrict__ C,
-                                                                   const float *__restrict__ inv1, const int64_t *__restrict__ idx, int64_t B,
-                                                                   int d, float ws, float *__restrict__ dC, float *__restrict__ grad_T1) {
+                                                                   const float *__restrict__ inv1, const int64_t *__restrict__ idx,
+                                                                   const float *__restrict__ row_w, int64_t B, int d, float ws,
+                                                                   float *__restrict__ dC, float *__restrict__ grad_T1) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const int64_t r = idx[b];
     const float cb = coef[b];
+    if (row_w) ws *= row_w[b];  // the positive term carries the row's weight too
     float g0 = 0.f, g1 = 0.f;  // d <= 128: columns lane and lane + 64
     const bool in0 = lane < d, in1 = lane + 64 < d;
 #pragma unroll 8
@@ -734,9 +737,9 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 // maximum) the unnormalised batch-side gradient sum_j w[b][j] C[j] accumulates beside the denominator sum_j w[b][j] in ONE pass over
 // the table, so the separate forward launch (57 us of a 385 us half at 2048 x 40 982, d = 64) is gone; the normalisation moves
 // into the consumers of the chunk partials, which also absorb the chunk reductions: 8 launches per half instead of 13.
-static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC, const float *T1,
-                           const int64_t *idx, int64_t n, int d, int64_t B, float scale, float weight, float *loss, float *grad_T1,
-                           float *grad_T2, void *lse_ws, hipStream_t s) {
+static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
+                           const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
+                           float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s) {
     const LseLayout L = lse_layout(B, n, d);
     char *w = reinterpret_cast<char *>(lse_ws);
     float *coef = reinterpret_cast<float *>(w + L.off_coef), *part_q = reinterpret_cast<float *>(w + L.off_q);
@@ -752,29 +755,30 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
     p.out = part_q;
     p.den_out = den;
+    p.coef_oth = col_w;  // (masked form: a candidate's weight in every denominator; NULL = 1)
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nce_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, pos, B, scale, scale, weight, term, coef);
+    hipLaunchKernelGGL(nce_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, pos, row_w, B, scale, scale, weight, term, coef);
     hipLaunchKernelGGL(nce_sum_kernel, dim3(1), dim3(256), 0, s, term, B, weight, loss);
     RBG_HIP(hipGetLastError());
+    if (!grad_T1 && !grad_T2) return RBG_OK;  // (value only; the masked form has no other forward)
     // pass 2 (own = the table rows): needs the finished denominators (coef)
     p.own = C, p.n_own = n;
     p.oth = A, p.n_oth = B;
-    p.coef_own = nullptr, p.coef_oth = coef;
+    p.coef_own = col_w, p.coef_oth = coef;
     p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
     p.out = part_c;
     p.den_out = nullptr;
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
-    hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, part_q, L.nc_q, coef, A, C, inv1, idx, B, d, weight * scale,
+    hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale,
                        part_c, grad_T1);
     RBG_HIP(hipGetLastError());
     if (grad_T2) {
         hipLaunchKernelGGL(nce_table_back_parts_kernel, dim3(nb), dim3(256), 0, s, part_c, L.nc_c, C, inv2, n, d, grad_T2);
         RBG_HIP(hipGetLastError());
     }
-    (void)T1;
     return RBG_OK;
 }
 
@@ -788,8 +792,8 @@ int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes) {
     return RBG_OK;
 }
 
-int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau,
-                    float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
+static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau, float weight,
+                        const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
     clear_error();
     if (B < 0 || n <= 0 || d <= 0) return fail(RBG_ESHAPE, "B = %lld, n = %lld, d = %d", (long long)B, (long long)n, d);
     if (d > 128) return fail(RBG_EUNSUPPORTED, "infonce: d = %d > 128", d);
@@ -810,8 +814,9 @@ int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const in
     hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos);
     RBG_HIP(hipGetLastError());
     const bool grads = grad_T1 || grad_T2;
-    const bool onepass = grads && opt_lse_onepass();  // denominators and dA out of one pass over the table
-    if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, T1, idx, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s);
+    const bool masked = row_w || col_w;
+    const bool onepass = masked || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
+    if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s);
     int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
@@ -826,6 +831,17 @@ int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const in
         RBG_HIP(hipGetLastError());
     }
     return RBG_OK;
+}
+
+int rbg_infonce_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau,
+                    float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
+    return infonce_impl(T1, T2, n, d, idx, B, tau, weight, nullptr, nullptr, loss, grad_T1, grad_T2, workspace, stream);
+}
+
+int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau, float weight,
+                           const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
+                           void *stream) {
+    return infonce_impl(T1, T2, n, d, idx, B, tau, weight, row_w, col_w, loss, grad_T1, grad_T2, workspace, stream);
 }
 
 }  // extern "C"

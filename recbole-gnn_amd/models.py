@@ -557,6 +557,11 @@ class SimGCL(LightGCN):
     def calculate_cl_loss(self, x1, x2, once=None):
         """simgcl.py:38-43.  ``once``: the rows / columns that count (one occurrence per distinct id of the batch) when x1, x2
         hold the WHOLE batch instead of its unique ids."""
+        if once is not None and x1.is_cuda and x1.shape[1] <= 128:
+            # one library call: normalisations, positives, masked denominators and both gradients (rbg_infonce_masked_f32 on the
+            # batch's gathered rows as both "tables"); ~40 elementwise / reduction launches per side in torch otherwise
+            w = once.to(torch.float32)
+            return ops.info_nce(x1, x2, torch.arange(x1.shape[0], device=x1.device), self.temperature, row_w=w, col_w=w)
         x1, x2 = F.normalize(x1, dim=-1), F.normalize(x2, dim=-1)
         pos_score = torch.exp((x1 * x2).sum(dim=-1) / self.temperature)
         logits = torch.exp(torch.matmul(x1, x2.transpose(0, 1)) / self.temperature)

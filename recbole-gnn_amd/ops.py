@@ -671,7 +671,7 @@ class _InfoNCE(torch.autograd.Function):
     """Loss and both table gradients come out of ONE library call; backward only scales them."""
 
     @staticmethod
-    def forward(ctx, t1, t2, idx, tau):
+    def forward(ctx, t1, t2, idx, tau, row_w, col_w):
         t1, t2 = t1.contiguous(), t2.contiguous()
         idx = idx.to(device=t1.device, dtype=torch.int64).contiguous()
         n, d = t2.shape
@@ -683,10 +683,15 @@ class _InfoNCE(torch.autograd.Function):
         nbytes = _lib.c_i64()
         check(lib.rbg_infonce_workspace(b, n, d, ctypes.byref(nbytes)))
         work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=t1.device)
+        ptr = lambda t: c_vp(t.data_ptr()) if t is not None else None  # noqa: E731
         with torch.cuda.device(t1.device):
-            check(lib.rbg_infonce_f32(c_vp(t1.data_ptr()), c_vp(t2.data_ptr()), n, d, c_vp(idx.data_ptr()), b, float(tau), 1.0,
-                                      c_vp(loss.data_ptr()), c_vp(g1.data_ptr()) if need1 else None,
-                                      c_vp(g2.data_ptr()) if need2 else None, c_vp(work.data_ptr()), _stream(t1)))
+            if row_w is None and col_w is None:
+                check(lib.rbg_infonce_f32(ptr(t1), ptr(t2), n, d, ptr(idx), b, float(tau), 1.0, ptr(loss), ptr(g1), ptr(g2), ptr(work), _stream(t1)))
+            else:
+                row_w = row_w.to(device=t1.device, dtype=torch.float32).contiguous() if row_w is not None else None
+                col_w = col_w.to(device=t1.device, dtype=torch.float32).contiguous() if col_w is not None else None
+                check(lib.rbg_infonce_masked_f32(ptr(t1), ptr(t2), n, d, ptr(idx), b, float(tau), 1.0, ptr(row_w), ptr(col_w), ptr(loss),
+                                                 ptr(g1), ptr(g2), ptr(work), _stream(t1)))
         ctx.save_for_backward(*(g for g in (g1, g2) if g is not None))
         ctx.have = (need1, need2)
         return loss.reshape(())
@@ -696,17 +701,24 @@ class _InfoNCE(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         g1 = saved.pop(0) * grad_out if ctx.have[0] else None
         g2 = saved.pop(0) * grad_out if ctx.have[1] else None
-        return g1, g2, None, None
+        return g1, g2, None, None, None, None
 
 
-def info_nce(t1, t2, idx, tau):
+def info_nce(t1, t2, idx, tau, row_w=None, col_w=None):
     """-sum_b log( exp(<a_b,p_b>/tau) / sum_j exp(<a_b,c_j>/tau) ) with a = normalize(t1[idx]), p = normalize(t2[idx]),
-    c = normalize(t2): one half of SGL.calc_ssl_loss (sgl.py:191-208) — rbg_infonce_f32."""
+    c = normalize(t2): one half of SGL.calc_ssl_loss (sgl.py:191-208) — rbg_infonce_f32.  ``row_w`` [B] weights the batch rows of
+    the sum, ``col_w`` [n] the candidates inside every denominator (rbg_infonce_masked_f32; constants: no gradient w.r.t. them):
+    with the batch's gathered rows as both tables and a one-occurrence mask for both this is SimGCL's contrast over
+    ``torch.unique`` of the batch (simgcl.py:38-57) without its data-dependent shape."""
     _check_dense(t1, "t1")
     _check_dense(t2, "t2")
     if t1.shape != t2.shape:
         raise ValueError(f"the two views differ in shape: {tuple(t1.shape)} vs {tuple(t2.shape)}")
-    return _InfoNCE.apply(t1, t2, idx, float(tau))
+    if row_w is not None and tuple(row_w.shape) != (idx.shape[0],):
+        raise ValueError("row_w must have one weight per batch row")
+    if col_w is not None and tuple(col_w.shape) != (t2.shape[0],):
+        raise ValueError("col_w must have one weight per row of t2")
+    return _InfoNCE.apply(t1, t2, idx, float(tau), row_w, col_w)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -292,6 +292,41 @@ def test_zero_fill_kernel_alignment_and_bounds(rbg, cuda):
         assert float(sums.abs().sum()) == 0.0 and float(loss) == 0.0
 
 
+@pytest.mark.parametrize("n,b,d", [(2048, 2048, 64), (300, 300, 64), (1000, 77, 128), (50, 200, 20)])
+def test_infonce_with_row_and_column_weights(rbg, cuda, n, b, d):
+    """rbg_infonce_masked_f32: weight * sum_b row_w[b] (log sum_j col_w[j] exp(<a_b, c_j> / tau) - <a_b, p_b> / tau) and its
+    gradients against float64 — with 0 / 1 masks (SimGCL's contrast over the distinct ids of a batch) and with real weights;
+    value-only calls; rows whose own column is masked."""
+    gen = torch.Generator().manual_seed(n + b)
+    t1, t2 = torch.randn(n, d, generator=gen).to(cuda), torch.randn(n, d, generator=gen).to(cuda)
+    idx = torch.randint(0, n, (b,), generator=gen).to(cuda)
+    tau = 0.2
+    for kind in ("mask", "weights", "rows_only", "cols_only"):
+        row_w = (torch.rand(b, generator=gen) < 0.6).float() if kind == "mask" else torch.rand(b, generator=gen)
+        col_w = (torch.rand(n, generator=gen) < 0.7).float() if kind == "mask" else torch.rand(n, generator=gen) + 0.1
+        col_w[0] = 1.0  # (never an empty candidate set)
+        rw = None if kind == "cols_only" else row_w.to(cuda)
+        cw = None if kind == "rows_only" else col_w.to(cuda)
+        a, c = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+        loss = rbg.ops.info_nce(a, c, idx, tau, row_w=rw, col_w=cw)
+        loss.backward()
+        with torch.no_grad():
+            value_only = rbg.ops.info_nce(t1, t2, idx, tau, row_w=rw, col_w=cw)
+        a64, c64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+        na, nc = torch.nn.functional.normalize(a64[idx], dim=1), torch.nn.functional.normalize(c64, dim=1)
+        r64 = torch.ones(b, dtype=torch.float64, device=cuda) if rw is None else rw.double()
+        w64 = torch.ones(n, dtype=torch.float64, device=cuda) if cw is None else cw.double()
+        ref = (r64 * (torch.log((torch.exp(na @ nc.T / tau) * w64[None, :]).sum(1)) - (na * nc[idx]).sum(1) / tau)).sum()
+        ref.backward()
+        scale = max(1.0, abs(float(ref)))
+        assert abs(float(loss.detach()) - float(ref)) <= 1e-5 * scale, kind
+        assert abs(float(value_only) - float(ref)) <= 1e-5 * scale, kind
+        for got, want in ((a.grad, a64.grad), (c.grad, c64.grad)):
+            assert float((got.double() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-12), kind
+    with pytest.raises(ValueError):
+        rbg.ops.info_nce(t1, t2, idx, tau, row_w=torch.ones(b + 1, device=cuda))
+
+
 @pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
