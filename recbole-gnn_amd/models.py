@@ -160,7 +160,7 @@ class LightGCN(GeneralGraphRecommender):
             for _ in range(self.n_layers):
                 all_embeddings = self.gcn_conv(all_embeddings, self.graph, None)
                 embeddings_list.append(all_embeddings)
-            mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+            mean = ops.layer_mean(embeddings_list)
         return torch.split(mean, [self.n_users, self.n_items])
 
     def calculate_loss(self, interaction):
@@ -551,7 +551,7 @@ class SimGCL(LightGCN):
 
     def forward(self, perturbed=False):
         embeddings_list = self._layers(perturbed)
-        mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+        mean = ops.layer_mean(embeddings_list)
         return torch.split(mean, [self.n_users, self.n_items])
 
     def calculate_cl_loss(self, x1, x2, once=None):
@@ -601,7 +601,7 @@ class XSimGCL(SimGCL):
         embeddings_list = self._layers(perturbed)
         if 1 <= self.layer_cl <= self.n_layers:
             all_embs_cl = embeddings_list[self.layer_cl - 1]
-        mean = torch.mean(torch.stack(embeddings_list, dim=1), dim=1)
+        mean = ops.layer_mean(embeddings_list)
         user_all, item_all = torch.split(mean, [self.n_users, self.n_items])
         if perturbed:
             user_cl, item_cl = torch.split(all_embs_cl, [self.n_users, self.n_items])
@@ -686,7 +686,7 @@ class NCL(GeneralGraphRecommender):
         for _ in range(max(self.n_layers, self.hyper_layers * 2)):
             all_embeddings = self.gcn_conv(all_embeddings, self.graph, None)
             embeddings_list.append(all_embeddings)
-        mean = torch.mean(torch.stack(embeddings_list[: self.n_layers + 1], dim=1), dim=1)
+        mean = ops.layer_mean(embeddings_list[: self.n_layers + 1])
         user_all, item_all = torch.split(mean, [self.n_users, self.n_items])
         return user_all, item_all, embeddings_list
 

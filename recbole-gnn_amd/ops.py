@@ -241,6 +241,36 @@ def lightgcn_forward(graphs, user_w, item_w, n_layers):
     return _LightGCNForward.apply(user_w, item_w, n_layers, *graphs)
 
 
+class _LayerMean(torch.autograd.Function):
+    """mean over a list of equally shaped layer outputs — ``torch.mean(torch.stack(list, dim=1), dim=1)`` of lightgcn.py:77-78 /
+    simgcl.py:34-35 / ncl.py:99-100 — as ONE launch (rbg_mean_f32) instead of a stack copy and a reduction over it; the backward
+    is one scaling whose result every input shares."""
+
+    @staticmethod
+    def forward(ctx, *layers):
+        xs = [t.contiguous() for t in layers]
+        out = torch.empty_like(xs[0])
+        arr = (c_vp * len(xs))(*[t.data_ptr() for t in xs])
+        with torch.cuda.device(out.device):
+            check(lib.rbg_mean_f32(arr, len(xs), out.numel(), 1.0 / len(xs), c_vp(out.data_ptr()), _stream(out)))
+        ctx.k = len(xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad * (1.0 / ctx.k)
+        return (g,) * ctx.k
+
+
+def layer_mean(layers):
+    """Mean of a list of [N, d] tensors (differentiable).  Falls back to the reference's stack + mean off the GPU, for other
+    dtypes or more layers than one launch of the library takes."""
+    layers = list(layers)
+    if (len(layers) > _lib.MAX_FUSED_LAYERS + 1 or not layers[0].is_cuda or any(t.dtype != torch.float32 or t.shape != layers[0].shape for t in layers)):
+        return torch.mean(torch.stack(layers, dim=1), dim=1)
+    return _LayerMean.apply(*layers)
+
+
 # ---- independent propagations of one E0 on concurrent HIP streams (SGL: the full graph + two views) ----------------------
 
 _SIDE_STREAMS = {}
