@@ -14,7 +14,7 @@ import torch
 
 from .graph import InteractionDataset
 from .graph import GraphHandle
-from .train import GraphedStep, fused_stepper
+from .train import GraphedStep, fused_stepper, total_without_last
 
 
 def load_inter(path, user_field="user_id", item_field="item_id", sep="\t"):
@@ -253,14 +253,17 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
             if fused:
                 total += stepper.step(batch)
             elif graphed:
+                reduce = total_without_last if (warm_up is not None and epoch < warm_up) else None
+                if gstep is not None:
+                    gstep.set_reduce(reduce)  # (NCL: the prototype term joins after warm_up_step epochs — one re-capture)
                 if gstep is None and len(batch["user_id"]) == min(batch_size, len(train_uid)):
-                    gstep = GraphedStep(model, batch, lr=lr)
+                    gstep = GraphedStep(model, batch, lr=lr, reduce=reduce)
                 if gstep is not None and len(batch["user_id"]) == len(gstep.static["user_id"]):
                     total += gstep.step(batch).detach().reshape(())
                 elif gstep is not None:
                     total += gstep.eager_step(batch).reshape(())
                 else:  # a first batch that is not full-sized: nothing captured yet
-                    gstep = GraphedStep(model, batch, lr=lr)
+                    gstep = GraphedStep(model, batch, lr=lr, reduce=reduce)
                     total += gstep.step(batch).detach().reshape(())
             else:
                 opt.zero_grad(set_to_none=True)

@@ -64,11 +64,22 @@ def find_communities(uid, iid, n_users, n_items, n_parts=8, iters=24, seed=0):
     return label.astype(np.int32), cut, float(load.max() / max(load.mean(), 1.0))
 
 
+_PARKED = []  # native handles whose Python owner died during a stream capture (GraphHandle.destroy)
+
+
+def flush_parked():
+    """Destroy the handles parked during a capture; a no-op inside one."""
+    if _PARKED and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        while _PARKED:
+            lib.rbg_graph_destroy(_PARKED.pop())
+
+
 class GraphHandle:
     """Owns one ``rbg_graph*``.  Opaque to models, exactly like the reference's ``self.edge_index``
     (a torch_sparse SparseTensor when ``enable_sparse``; abstract_recommender.py:15-18)."""
 
     def __init__(self, ptr, symmetric, n_users=None):
+        flush_parked()
         self._ptr = c_vp(ptr)
         self.symmetric = bool(symmetric)
         n_rows, n_cols, nnz, dev = c_i64(), c_i64(), c_i64(), c_int()
@@ -388,8 +399,16 @@ class GraphHandle:
 
     def destroy(self):
         if getattr(self, "_ptr", None):
-            lib.rbg_graph_destroy(self._ptr)
-            self._ptr = c_vp()
+            ptr, self._ptr = self._ptr, c_vp()
+            # rbg_graph_destroy frees HBM (hipFree): inside a stream capture that invalidates the capture — and a handle can die
+            # there through no fault of the capturing code: Python's cyclic collector runs whenever it likes and handles do sit in
+            # cycles (NGCF's two edge-dropout views point at each other).  Such a handle is parked and destroyed by the next
+            # destroy / create outside a capture (seen as a 1-in-6 hipErrorStreamCaptureInvalidated in tests/test_driver.py).
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                _PARKED.append(ptr)
+                return
+            lib.rbg_graph_destroy(ptr)
+            flush_parked()
 
     def __del__(self):
         try:

@@ -640,7 +640,9 @@ class NCL(GeneralGraphRecommender):
     ``calculate_loss`` returns the reference's 3-tuple (BPR + reg, ssl, proto): NCLTrainer sums it, without the last
     term during the first ``warm_up_step`` epochs, and calls ``e_step`` every ``m_step`` epochs (trainer.py:35-40,130-133)."""
 
-    graph_capturable = False  # e_step swaps the centroid tensors between epochs; the loss tuple is summed by the trainer
+    # (capturable: e_step rewrites the prototype tensors IN PLACE, so a captured step keeps reading the current ones; which terms
+    # of the loss tuple the trainer sums — trainer.py:130-133 — is the stepper's ``reduce``, see train.GraphedStep)
+    graph_capturable = True
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -669,8 +671,15 @@ class NCL(GeneralGraphRecommender):
         self.to(self.device)
 
     def e_step(self):
-        self.user_centroids, self.user_2cluster = self.run_kmeans(self.user_embedding.weight.detach())
-        self.item_centroids, self.item_2cluster = self.run_kmeans(self.item_embedding.weight.detach())
+        for side, table in (("user", self.user_embedding.weight), ("item", self.item_embedding.weight)):
+            cent, assign = self.run_kmeans(table.detach())
+            old_c, old_a = getattr(self, f"{side}_centroids"), getattr(self, f"{side}_2cluster")
+            if old_c is not None and old_c.shape == cent.shape and old_a.shape == assign.shape:
+                old_c.copy_(cent)  # same storage: a HIP graph captured on the previous prototypes reads the new ones
+                old_a.copy_(assign)
+            else:
+                setattr(self, f"{side}_centroids", cent)
+                setattr(self, f"{side}_2cluster", assign)
 
     def run_kmeans(self, x):
         """ncl.py:66-81: k clusters of the rows of x; centroids L2-normalized, node -> cluster as int64."""

@@ -284,6 +284,8 @@ class HipBackend:
         return ctx
 
     def __del__(self):
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return  # (collected inside somebody's stream capture: leaked rather than invalidating it — see GraphHandle.destroy)
         for ctx in getattr(self, "_ctxs", []):
             try:
                 self._lib.lib.rbg_shard_ctx_destroy(ctx)
@@ -891,6 +893,7 @@ class RcclShard:
 
     def __del__(self):
         try:
-            self.close()
+            if not torch.cuda.is_current_stream_capturing():  # (close() synchronises and frees: never inside a capture)
+                self.close()
         except Exception:  # noqa: BLE001
             pass

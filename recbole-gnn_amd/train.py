@@ -373,6 +373,11 @@ def _total(loss):
     return sum(loss) if isinstance(loss, tuple) else loss
 
 
+def total_without_last(loss):
+    """NCLTrainer._train_epoch during the warm-up epochs (trainer.py:130-133): the prototype term is left out."""
+    return sum(loss[:-1]) if isinstance(loss, tuple) else loss
+
+
 class GraphedStep:
     """One whole training step — ``zero_grad; calculate_loss; backward; Adam.step`` (RecBole ``Trainer._train_epoch``
     [recbole==1.1.1]) — captured ONCE into a HIP graph and replayed per batch.
@@ -389,7 +394,8 @@ class GraphedStep:
     ``step(batch)`` copies the batch's index tensors into the captured input buffers and replays; batches must have the
     size of ``example_batch`` (RecBole's last, shorter batch of an epoch goes through ``eager_step``)."""
 
-    def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, warmup=2):
+    def __init__(self, model, example_batch, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, warmup=2, reduce=None):
+        self.reduce = reduce or _total  # how a tuple of loss terms becomes the trained scalar (``set_reduce`` re-captures)
         if not next(model.parameters()).is_cuda:
             raise RuntimeError("GraphedStep needs the model on a GPU")
         if not getattr(model, "graph_capturable", True):
@@ -440,13 +446,21 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            self.loss = _total(self.model.calculate_loss(self.static))
+            self.loss = self.reduce(self.model.calculate_loss(self.static))
             self.loss.backward()
             self.opt.step()
 
+    def set_reduce(self, reduce):
+        """Another combination of the model's loss terms from now on (NCL after its warm-up epochs): the step is re-captured,
+        parameters and optimizer state carry over."""
+        reduce = reduce or _total
+        if reduce is not self.reduce:
+            self.reduce = reduce
+            self._capture()
+
     def _eager(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = _total(self.model.calculate_loss(self.static))
+        loss = self.reduce(self.model.calculate_loss(self.static))
         loss.backward()
         self.opt.step()
         return loss
@@ -471,7 +485,7 @@ class GraphedStep:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side):
             self.opt.zero_grad(set_to_none=True)
-            loss = _total(self.model.calculate_loss(batch))
+            loss = self.reduce(self.model.calculate_loss(batch))
             loss.backward()
             self.opt.step()
             loss = loss.detach()

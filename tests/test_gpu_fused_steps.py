@@ -327,6 +327,39 @@ def test_infonce_with_row_and_column_weights(rbg, cuda, n, b, d):
         rbg.ops.info_nce(t1, t2, idx, tau, row_w=torch.ones(b + 1, device=cuda))
 
 
+def test_a_graph_handle_dying_inside_a_capture_does_not_invalidate_it(rbg, cuda, golden):
+    """rbg_graph_destroy frees HBM; Python's cyclic collector can run it at any moment — also inside somebody's stream capture
+    (handles do sit in cycles: NGCF's two edge-dropout views point at each other).  A handle that dies there is parked and
+    destroyed at the next destroy / create outside a capture."""
+    import gc
+    from recbole_gnn_amd import graph as G
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    x = torch.ones(16, device=cuda)
+    a = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    b = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    a._transpose, b._transpose = b, a  # a cycle: only the collector frees the pair
+    del a, b
+    gc.disable()
+    try:
+        side = torch.cuda.Stream(device=cuda)
+        with torch.cuda.stream(side):
+            pass
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            y = x * 2
+            assert gc.collect() >= 2  # the two handles die here
+            assert len(G._PARKED) == 2
+            z = y + 1
+        gr.replay()
+        torch.cuda.synchronize()
+        assert float(z.sum()) == 48.0
+    finally:
+        gc.enable()
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)  # the next create flushes
+    assert len(G._PARKED) == 0 and h.nnz == 2 * len(g["uid"])
+
+
 @pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
