@@ -170,6 +170,11 @@ class LightGCN(GeneralGraphRecommender):
         pos_item = interaction[self.ITEM_ID]
         neg_item = interaction[self.NEG_ITEM_ID]
         user_all, item_all = self.forward()
+        # BPR + reg with their gradients in three library launches when user_all / item_all are the halves of one [N, d] tensor
+        fused = ops.bpr_emb_loss(user_all, item_all, self.user_embedding.weight, self.item_embedding.weight, user, pos_item, neg_item,
+                                 self.reg_weight, self.require_pow) if type(self.mf_loss) is BPRLoss and self.mf_loss.gamma == 1e-10 else None
+        if fused is not None:
+            return fused
         u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
         pos_scores = torch.mul(u_e, pos_e).sum(dim=1)
         neg_scores = torch.mul(u_e, neg_e).sum(dim=1)
@@ -736,6 +741,10 @@ class NCL(GeneralGraphRecommender):
         context_embedding = embeddings_list[self.hyper_layers * 2]
         ssl_loss = self.ssl_layer_loss(context_embedding, center_embedding, user, pos_item)
         proto_loss = self.ProtoNCE_loss(center_embedding, user, pos_item)
+        fused = ops.bpr_emb_loss(user_all, item_all, self.user_embedding.weight, self.item_embedding.weight, user, pos_item, neg_item,
+                                 self.reg_weight, False)
+        if fused is not None:
+            return fused, ssl_loss, proto_loss
         u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
         mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
         reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),

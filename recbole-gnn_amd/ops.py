@@ -241,6 +241,55 @@ def lightgcn_forward(graphs, user_w, item_w, n_layers):
     return _LightGCNForward.apply(user_w, item_w, n_layers, *graphs)
 
 
+class _BprEmbLoss(torch.autograd.Function):
+    """BPRLoss on the propagated rows + reg_weight * EmbLoss on the ego rows (lightgcn.py:93-110; ncl.py:186-196) with their
+    gradients in two or three library launches (rbg_bpr_grad_f32 + rbg_emb_reg_grad[_nopow]_f32) instead of six index_selects,
+    ~20 elementwise / reduction launches and — in backward — six zero-filled tables with an index_add each."""
+
+    @staticmethod
+    def forward(ctx, mean, uw, iw, user, pos, neg, reg_weight, require_pow):
+        nu, d = uw.shape
+        ni, b = iw.shape[0], user.shape[0]
+        gm, ge = torch.empty_like(mean), torch.zeros_like(mean)
+        loss = torch.zeros((), dtype=torch.float32, device=mean.device)
+        st = _stream(mean)
+        ptr = lambda t: c_vp(t.data_ptr())  # noqa: E731
+        with torch.cuda.device(mean.device):
+            check(lib.rbg_bpr_grad_f32(ptr(mean), nu, ni, ptr(user), ptr(pos), ptr(neg), b, d, ptr(gm), ptr(loss), st))
+            if reg_weight != 0:
+                if require_pow:
+                    check(lib.rbg_emb_reg_grad_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(reg_weight), ptr(ge), ptr(loss), st))
+                else:
+                    ws = torch.empty(3, dtype=torch.float32, device=mean.device)
+                    check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(reg_weight), ptr(ge),
+                                                         ptr(loss), ptr(ws), st))
+        ctx.save_for_backward(gm, ge)
+        ctx.nu = nu
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        gm, ge = ctx.saved_tensors
+        ge = ge * go
+        return gm * go, ge[: ctx.nu], ge[ctx.nu:], None, None, None, None, None
+
+
+def bpr_emb_loss(user_all, item_all, user_w, item_w, user, pos, neg, reg_weight, require_pow):
+    """``BPRLoss(<u, p>, <u, n>) + reg_weight * EmbLoss(ego rows)`` of lightgcn.py:93-110 for ``user_all, item_all`` = the two
+    halves of ONE contiguous [N, d] tensor (what ``torch.split`` of the propagated mean returns), or None when the inputs do not
+    have that form (the caller then spells the loss in torch)."""
+    base = user_all._base if user_all._base is not None and user_all._base is item_all._base else None
+    nu, ni = user_w.shape[0], item_w.shape[0]
+    if (base is None or not base.is_cuda or base.dtype != torch.float32 or base.dim() != 2 or not base.is_contiguous()
+            or base.shape[0] != nu + ni or user_all.shape[0] != nu or item_all.shape[0] != ni
+            or user_all.data_ptr() != base.data_ptr() or item_all.data_ptr() != base.data_ptr() + 4 * nu * base.shape[1]
+            or user_w.shape[1] != base.shape[1] or not (user_w.is_contiguous() and item_w.is_contiguous())):
+        return None
+    dev = base.device
+    user, pos, neg = (t.to(device=dev, dtype=torch.int64).contiguous() for t in (user, pos, neg))
+    return _BprEmbLoss.apply(base, user_w, item_w, user, pos, neg, float(reg_weight), bool(require_pow))
+
+
 class _LayerMean(torch.autograd.Function):
     """mean over a list of equally shaped layer outputs — ``torch.mean(torch.stack(list, dim=1), dim=1)`` of lightgcn.py:77-78 /
     simgcl.py:34-35 / ncl.py:99-100 — as ONE launch (rbg_mean_f32) instead of a stack copy and a reduction over it; the backward
