@@ -174,7 +174,7 @@ class LightGCN(GeneralGraphRecommender):
         fused = ops.bpr_emb_loss(user_all, item_all, self.user_embedding.weight, self.item_embedding.weight, user, pos_item, neg_item,
                                  self.reg_weight, self.require_pow) if type(self.mf_loss) is BPRLoss and self.mf_loss.gamma == 1e-10 else None
         if fused is not None:
-            return fused
+            return fused[0] + fused[1]
         u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
         pos_scores = torch.mul(u_e, pos_e).sum(dim=1)
         neg_scores = torch.mul(u_e, neg_e).sum(dim=1)
@@ -623,10 +623,16 @@ class XSimGCL(SimGCL):
             self.restore_user_e, self.restore_item_e = None, None
         user, pos_item, neg_item = interaction[self.USER_ID], interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]
         user_all, item_all, user_cl, item_cl = self.forward(perturbed=True)
-        u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
-        mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
-        reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
-                                 _rows(self.item_embedding.weight, neg_item), require_pow=self.require_pow)
+        u_e, pos_e = _rows(user_all, user), _rows(item_all, pos_item)
+        fused = ops.bpr_emb_loss(user_all, item_all, self.user_embedding.weight, self.item_embedding.weight, user, pos_item, neg_item,
+                                 self.reg_weight, self.require_pow) if type(self.mf_loss) is BPRLoss and self.mf_loss.gamma == 1e-10 else None
+        if fused is not None:
+            mf_loss, reg_term = fused
+        else:
+            neg_e = _rows(item_all, neg_item)
+            mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
+            reg_term = self.reg_weight * self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
+                                                       _rows(self.item_embedding.weight, neg_item), require_pow=self.require_pow)
         if self.static_unique:
             user_cl_loss = self.calculate_cl_loss(u_e, _rows(user_cl, user), _once_mask(user))
             item_cl_loss = self.calculate_cl_loss(pos_e, _rows(item_cl, pos_item), _once_mask(pos_item))
@@ -634,7 +640,7 @@ class XSimGCL(SimGCL):
             user_u, item_u = torch.unique(user), torch.unique(pos_item)
             user_cl_loss = self.calculate_cl_loss(_rows(user_all, user_u), _rows(user_cl, user_u))
             item_cl_loss = self.calculate_cl_loss(_rows(item_all, item_u), _rows(item_cl, item_u))
-        return mf_loss, self.reg_weight * reg_loss, self.cl_rate * (user_cl_loss + item_cl_loss)
+        return mf_loss, reg_term, self.cl_rate * (user_cl_loss + item_cl_loss)
 
 
 class NCL(GeneralGraphRecommender):
@@ -744,7 +750,7 @@ class NCL(GeneralGraphRecommender):
         fused = ops.bpr_emb_loss(user_all, item_all, self.user_embedding.weight, self.item_embedding.weight, user, pos_item, neg_item,
                                  self.reg_weight, False)
         if fused is not None:
-            return fused, ssl_loss, proto_loss
+            return fused[0] + fused[1], ssl_loss, proto_loss
         u_e, pos_e, neg_e = _rows(user_all, user), _rows(item_all, pos_item), _rows(item_all, neg_item)
         mf_loss = self.mf_loss(torch.mul(u_e, pos_e).sum(dim=1), torch.mul(u_e, neg_e).sum(dim=1))
         reg_loss = self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),

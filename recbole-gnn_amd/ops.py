@@ -251,33 +251,33 @@ class _BprEmbLoss(torch.autograd.Function):
         nu, d = uw.shape
         ni, b = iw.shape[0], user.shape[0]
         gm, ge = torch.empty_like(mean), torch.zeros_like(mean)
-        loss = torch.zeros((), dtype=torch.float32, device=mean.device)
+        loss, reg = torch.zeros((), dtype=torch.float32, device=mean.device), torch.zeros((), dtype=torch.float32, device=mean.device)
         st = _stream(mean)
         ptr = lambda t: c_vp(t.data_ptr())  # noqa: E731
         with torch.cuda.device(mean.device):
             check(lib.rbg_bpr_grad_f32(ptr(mean), nu, ni, ptr(user), ptr(pos), ptr(neg), b, d, ptr(gm), ptr(loss), st))
             if reg_weight != 0:
                 if require_pow:
-                    check(lib.rbg_emb_reg_grad_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(reg_weight), ptr(ge), ptr(loss), st))
+                    check(lib.rbg_emb_reg_grad_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(reg_weight), ptr(ge), ptr(reg), st))
                 else:
                     ws = torch.empty(3, dtype=torch.float32, device=mean.device)
                     check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(reg_weight), ptr(ge),
-                                                         ptr(loss), ptr(ws), st))
+                                                         ptr(reg), ptr(ws), st))
         ctx.save_for_backward(gm, ge)
         ctx.nu = nu
-        return loss
+        return loss, reg
 
     @staticmethod
-    def backward(ctx, go):
+    def backward(ctx, go_mf, go_reg):
         gm, ge = ctx.saved_tensors
-        ge = ge * go
-        return gm * go, ge[: ctx.nu], ge[ctx.nu:], None, None, None, None, None
+        ge = ge * go_reg
+        return gm * go_mf, ge[: ctx.nu], ge[ctx.nu:], None, None, None, None, None
 
 
 def bpr_emb_loss(user_all, item_all, user_w, item_w, user, pos, neg, reg_weight, require_pow):
-    """``BPRLoss(<u, p>, <u, n>) + reg_weight * EmbLoss(ego rows)`` of lightgcn.py:93-110 for ``user_all, item_all`` = the two
-    halves of ONE contiguous [N, d] tensor (what ``torch.split`` of the propagated mean returns), or None when the inputs do not
-    have that form (the caller then spells the loss in torch)."""
+    """``(BPRLoss(<u, p>, <u, n>), reg_weight * EmbLoss(ego rows))`` of lightgcn.py:93-110 / xsimgcl.py:78-85 for ``user_all,
+    item_all`` = the two halves of ONE contiguous [N, d] tensor (what ``torch.split`` of the propagated mean returns), or None
+    when the inputs do not have that form (the caller then spells the loss in torch)."""
     base = user_all._base if user_all._base is not None and user_all._base is item_all._base else None
     nu, ni = user_w.shape[0], item_w.shape[0]
     if (base is None or not base.is_cuda or base.dtype != torch.float32 or base.dim() != 2 or not base.is_contiguous()
