@@ -364,7 +364,7 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     # re-sampled per epoch): seconds for the SECOND epoch of every model = 502 batches of 2048 at the Gowalla shape
     try:
         ep = {}
-        for name in ("LightGCN", "NGCF", "SGL"):
+        for name in ("LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL", "NCL"):
             torch.manual_seed(0)
             np.random.seed(0)
             mm = getattr(rbg, name)({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "require_pow": True}, ds)
@@ -377,10 +377,10 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             t0 = time.perf_counter()
             rbg.driver.fit(mm, uid, iid, epochs=2, lr=1e-3, log=mark)
             ep[name] = {"epoch_s": round(marks[1] - marks[0], 4), "first_epoch_s(incl. warm-up and capture)": round(marks[0] - t0, 4),
-                        "stepper": type(rbg.fused_stepper(mm)).__name__}
+                        "stepper": (type(rbg.fused_stepper(mm)).__name__ if name in ("LightGCN", "NGCF", "SGL") else "GraphedStep (autograd step as one HIP graph)")}
             del mm
         ep["batches_per_epoch"] = (len(uid) + 2047) // 2048
-        ex["driver_epoch(device sampler, fused steps, model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep
+        ex["driver_epoch(device sampler; fused steps for LightGCN / NGCF / SGL, replayed autograd steps for the others; model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep
     except Exception as e:  # noqa: BLE001
         ex["driver_epoch_error"] = str(e)[:200]
     return ex
