@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librbgnn.so")
+# (RBGNN_LIB: a diagnostic build of the same sources, e.g. devtools/microbench/librbgnn_selltrace.so — never a fallback)
+LIB_PATH = os.environ.get("RBGNN_LIB") or os.path.join(_HERE, "librbgnn.so")
 
 RBG_OK = 0
 RBG_EINVAL, RBG_ENOMEM, RBG_EHIP, RBG_ESHAPE, RBG_ENODEV, RBG_EUNSUPPORTED = -1, -2, -3, -4, -5, -6

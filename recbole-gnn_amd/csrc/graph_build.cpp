@@ -67,6 +67,10 @@ static std::atomic<int> g_sell_auto{1}, g_sell_depth{1}, g_sell_class_serial{-1}
 int opt_sell_auto() { return g_sell_auto.load(); }
 int opt_sell_depth() { return g_sell_depth.load(); }
 int opt_sell_class_serial() { return g_sell_class_serial.load(); }
+static std::atomic<int> g_sell_stream{0}, g_sell_stream_wgs{8}, g_sell_stream_fit{0};
+int opt_sell_stream() { return g_sell_stream.load(); }
+int opt_sell_stream_wgs() { return g_sell_stream_wgs.load(); }
+int opt_sell_stream_fit() { return g_sell_stream_fit.load(); }
 // fault injection for the tests: the (n + 1)-th dev_malloc from now fails once (option "fail_alloc_after" = n; -1 = off)
 static std::atomic<int64_t> g_fail_alloc_after{-1};
 hipError_t dev_malloc(void **p, size_t bytes) {
@@ -553,6 +557,19 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_class_serial = (int)value;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_stream")) {
+        g_sell_stream = value ? 1 : 0;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_wgs")) {
+        if (value < 1 || value > 8) return fail(RBG_EINVAL, "sell_stream_wgs = %lld (1..8 workgroups per CU)", (long long)value);
+        g_sell_stream_wgs = (int)value;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_fit")) {
+        g_sell_stream_fit = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "fail_alloc_after")) {
         g_fail_alloc_after = value < 0 ? -1 : value;
         return RBG_OK;
@@ -644,6 +661,18 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_depth")) {
         *value = g_sell_depth.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream")) {
+        *value = g_sell_stream.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_wgs")) {
+        *value = g_sell_stream_wgs.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_fit")) {
+        *value = g_sell_stream_fit.load();
         return RBG_OK;
     }
     if (!strcmp(key, "sell_class_serial")) {

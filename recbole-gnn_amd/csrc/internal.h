@@ -45,6 +45,9 @@ int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-maj
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
 int opt_sell_auto();     // rbg_graph_create*: plan the column-slab propagation for every device graph with a user / item boundary
 int opt_sell_depth();    // sell.hip: gather batches a wave keeps in flight (1 or 2)
+int opt_sell_stream();      // sell.hip: 1 = the resident-round launch (sell_stream.h), 0 = one wave per unit
+int opt_sell_stream_wgs();  // ... workgroups (four waves) per CU of its grid
+int opt_sell_stream_fit();  // ... 1 = the fewest waves that give every wave the same number of units
 int opt_sell_class_serial();  // sell.hip: -1 = auto (by table size), 0 = both row classes in one launch, 1 = one launch per class
 // hipMalloc behind the fault-injection hook of the tests (option "fail_alloc_after"): every allocation of the plan code goes
 // through it, so that a test can walk the error paths one allocation at a time
@@ -133,6 +136,7 @@ struct SellDev {
     int32_t *src = nullptr;          // [n_ent]: CSR entry of every slot (-1 = padding): re-weighted views refresh their values through it; optional
     int64_t n_ent = 0;
     int64_t first_ent1 = 0;          // first entry of class 1's units
+    int32_t wide_end[2] = {0, 0};    // one past the last wide unit of class c (class-local): the resident-round launch's guard
     int chunk = 0;                   // the planner's chunk (0: an attached plan)
     bool native = false;             // built by rbg_graph_plan_sell (the values are the graph's own)
     const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan

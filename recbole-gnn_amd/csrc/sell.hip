@@ -30,6 +30,7 @@
 
 #include "internal.h"
 #include "sell_kernel.h"
+#include "sell_stream.h"
 
 namespace rbg {
 
@@ -39,6 +40,8 @@ template <int W, int NS, bool COMPACT, int DEPTH>
 __global__ __launch_bounds__(DEPTH == 2 ? 256 : 1024) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? (COMPACT ? 5 : 4) : 8))) void sell_spmm_kernel(const SellParams p_) {
     SellParamsK &p = sell_kernarg();  // (= p_, read in place)
     __shared__ float s_wide[4][W];
+    SellClock clk;
+    clk.start();
     const int x = blockIdx.x & 7;
     const bool serial = p.cls_only >= 0;
     const int cls = serial ? p.cls_only : x >> 2;
@@ -55,8 +58,13 @@ __global__ __launch_bounds__(DEPTH == 2 ? 256 : 1024) __attribute__((amdgpu_wave
     const v4i *ents = p.x_rm ? p.ent0 : p.ent;
     const int64_t ybase = p.slab_off[cls][s];
     const unsigned n_w = (gridDim.x >> 3) * 4 * XR;  // waves of this role: the grid covers the units, so the loop body runs at most once
-    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave))); t < nun; t += n_w)
-        sell_unit<W, NS, COMPACT, DEPTH>(p, L, cls, s, heads[t], rs, ents, ybase, s_wide);
+    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave))); t < nun; t += n_w) {
+        const int4 h = heads[t];
+        clk.lap(0);
+        sell_unit<W, NS, COMPACT, DEPTH>(p, L, cls, s, h, rs, ents, ybase, s_wide, clk);
+        clk.lap(3);
+    }
+    clk.dump((COMPACT ? 2 : 0) + (p.last ? 1 : 0));
 }
 
 // the two embedding tables, row-major [n, NS W] in the reference's numbering -> slabs in the plan's numbering
@@ -125,6 +133,17 @@ __global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int6
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) entc[e] = ent[e].x;
 }
 
+// one past the last WIDE unit of either class (class-local index): the resident-round launch keeps the four units of a wide
+// row in one workgroup only inside its first tier
+__global__ void sell_wide_end_kernel(const int4 *head, int n_units_total, int unit_base1, int *wide_end) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_units_total) return;
+    if ((head[t].w >> 16) & 1) {
+        const int cls = t >= unit_base1;
+        atomicMax(wide_end + cls, t - (cls ? unit_base1 : 0) + 1);
+    }
+}
+
 // a re-weighted view's values: ent0v[pos].y = vals[src[pos]]
 __global__ void sell_refresh_values_kernel(int2 *ent, const int32_t *src, const float *vals, int64_t n_ent) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
@@ -176,7 +195,7 @@ void free_sell(SellDev *sw) {
     delete sw;
 }
 
-static bool sell_width_ok(const SellDev *sw, int d) { return sw->W * 2 == d || (sw->W == 32 && (d == 128 || d == 32)); }
+static bool sell_width_ok(const SellDev *sw, int d) { return (sw->W >= 32 && sw->W * 2 == d) || (sw->W == 32 && (d == 128 || d == 32)) || (sw->W == 16 && d == 64); }
 // a re-weighted view runs its plan only after the caller has refreshed it once (rbg_graph_refresh_values: the plan holds a COPY
 // of the values, the binned kernel reads the caller's array at launch time)
 static bool sell_usable(const rbg_graph *g) { return g && g->sell && (!g->sell->borrowed || g->sell->view_fresh); }
@@ -190,10 +209,17 @@ static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_
 
 static int sell_depth() { return opt_sell_depth() == 2 ? 2 : 1; }
 
+static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int64_t *rounds_out, int *wgs_out);
 const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
     static thread_local char buf[64];
     const int W = g->sell->W, ns = d / W;
-    snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", W == 64 ? 1 : sell_depth());
+    int64_t rounds = 0;
+    int wgs = 0;
+    const int c = opt_sell_class_serial() == 1 ? 0 : -1;
+    if (opt_sell_stream() && sell_stream_grid(g->sell, ns, c, compact, &rounds, &wgs))
+        snprintf(buf, sizeof buf, "sell_stream_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", (compact && wgs == 8) ? 8 : 7);
+    else
+        snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", W == 32 ? sell_depth() : 1);
     return buf;
 }
 bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
@@ -215,8 +241,72 @@ static void sell_launch_one(const SellDev *sw, SellParams &p, int c, hipStream_t
     else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false, DEPTH>), dim3(grid), dim3(256), 0, s, p);
 }
 
+// The resident-round form (sell_stream.h): the grid is what the chip holds at once ("sell_stream_wgs" workgroups of four
+// waves per CU), a wave walks its role's units in snake order.  false = not this launch (a class has more wide units than a
+// role has waves: the four units of a wide row must meet in one workgroup's first tier) — the caller launches one wave per unit.
+static int sell_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        (void)hipGetLastError();
+        return v;
+    }();
+    return n;
+}
+// the grid of a resident-round launch: `rounds` workgroup indices (eight workgroups each, one per XCD); false = not this launch
+static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int64_t *rounds_out, int *wgs_out) {
+    const int xr = (c < 0 ? 4 : 8) / NS;  // XCDs per (class, slab) role
+    if (xr < 1) return false;
+    int64_t units = 0;
+    for (int cls = 0; cls < 2; ++cls)
+        if (c < 0 || c == cls) units = std::max<int64_t>(units, sw->n_units[cls]);
+    const int per = 4 * xr;  // waves one workgroup index adds to every role
+    // workgroups (four waves) per CU: the valued form needs 72 registers (7 waves per SIMD), the compact one fits 64 with five
+    // loop-invariant words in scratch or 69 without
+    const int wgs = std::min(opt_sell_stream_wgs(), compact ? 8 : 7);
+    const int64_t cap = std::max<int64_t>(1, (int64_t)wgs * sell_cu_count() / 8);  // workgroup indices the chip holds at once
+    int64_t rounds = std::min<int64_t>(cap, (units + per - 1) / per);
+    if (opt_sell_stream_fit() && rounds > 0) {  // every wave the same number of units: T tiers, the fewest waves that cover them
+        const int64_t tiers = (units + rounds * per - 1) / (rounds * per);
+        rounds = (units + tiers * per - 1) / (tiers * per);
+    }
+    rounds = std::max<int64_t>(rounds, 1);
+    for (int cls = 0; cls < 2; ++cls)
+        if ((c < 0 || c == cls) && sw->wide_end[cls] > rounds * per) return false;
+    *rounds_out = rounds, *wgs_out = wgs;
+    return true;
+}
+template <int W, int NS>
+static bool sell_stream_launch(const SellDev *sw, const SellParams &p, int c, hipStream_t s) {
+    int64_t rounds = 0;
+    int wgs = 0;
+    if (!sell_stream_grid(sw, NS, c, p.compact != 0, &rounds, &wgs)) return false;
+    const int xr = (c < 0 ? 4 : 8) / NS;
+    SellStreamParams q;
+    q.p = p;
+    q.p.cls_only = c;
+    for (int x = 0; x < 8; ++x) {
+        SellRoleK &R = q.role[x];
+        const int cls = c < 0 ? x >> 2 : c, xl = c < 0 ? (x & 3) : x;
+        R = SellRoleK{};
+        R.cls = cls, R.s = xl & (NS - 1), R.xi = xl / NS, R.xr = xr;
+        R.n_units = sw->n_units[cls], R.unit_base = sw->unit_base[cls];
+        R.n_tab = sw->n_class[1 - cls], R.cbase = cls ? sw->n_class[0] : 0;
+        R.ybase = p.slab_off[cls][R.s], R.xoff = p.slab_off[1 - cls][R.s];
+    }
+    const unsigned grid = (unsigned)(8 * rounds);
+    if (!p.compact) hipLaunchKernelGGL((sell_stream_kernel<W, NS, false, 7>), dim3(grid), dim3(256), 0, s, q);
+    else if (wgs == 8) hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 8>), dim3(grid), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 7>), dim3(grid), dim3(256), 0, s, q);
+    return true;
+}
+
 template <int W, int NS>
 static int sell_launch_class(const SellDev *sw, SellParams &p, int c, hipStream_t s) {
+    if (opt_sell_stream() && sell_stream_launch<W, NS>(sw, p, c, s)) {
+        RBG_HIP(hipGetLastError());
+        return RBG_OK;
+    }
     if (W == 32 && sell_depth() == 2) {
         if constexpr (W == 32) sell_launch_one<W, NS, 2>(sw, p, c, s);
     } else {
@@ -383,6 +473,7 @@ bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx) {
         if ((W_) == 32 && (d_) == 128) return CALL(32, 4);           \
         if ((W_) == 32 && (d_) == 32) return CALL(32, 1);            \
         if ((W_) == 64 && (d_) == 128) return CALL(64, 2);           \
+        if ((W_) == 16 && (d_) == 64) return CALL(16, 4);            \
     } while (0)
 
 int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,
@@ -601,6 +692,21 @@ int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
     if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast && sell_opt_alloc(&sw->ent0, sizeof(int32_t) * 2 * (size_t)(n_ent + 128), true) && n_ent)
         hipLaunchKernelGGL(sell_first_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent),
                            reinterpret_cast<int2 *>(sw->ent0), n_ent, sw->first_ent1, sw->orig, n0, W);
+    // where the wide units end (the resident-round launch's guard)
+    int *d_we = nullptr;
+    bool we_ok = dev_malloc(&d_we, 2 * sizeof(int)) == hipSuccess && hipMemset(d_we, 0, 2 * sizeof(int)) == hipSuccess;
+    const int n_total = sw->n_units[0] + sw->n_units[1];
+    if (we_ok && n_total)
+        hipLaunchKernelGGL(sell_wide_end_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head), n_total,
+                           sw->n_units[0], d_we);
+    int h_we[2] = {INT32_MAX, INT32_MAX};  // (unknown = "never": the one-wave-per-unit launch)
+    if (we_ok) we_ok = hipMemcpy(h_we, d_we, sizeof h_we, hipMemcpyDeviceToHost) == hipSuccess;
+    if (d_we) (void)hipFree(d_we);
+    if (!we_ok) {
+        (void)hipGetLastError();
+        h_we[0] = h_we[1] = INT32_MAX;
+    }
+    sw->wide_end[0] = h_we[0], sw->wide_end[1] = h_we[1];
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
         free_sell(sw);
         return fail(RBG_EHIP, "building the derived arrays of the SELL plan failed");
@@ -661,7 +767,8 @@ int sell_make_view(rbg_graph *view, const rbg_graph *base) {
     sw->chunk = b->chunk;
     sw->n_ent = b->n_ent;
     sw->first_ent1 = b->first_ent1;
-    for (int c = 0; c < 2; ++c) sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c];
+    for (int c = 0; c < 2; ++c)
+        sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c], sw->wide_end[c] = b->wide_end[c];
     sw->ent = b->ent, sw->entc = b->entc, sw->head = b->head, sw->orig = b->orig, sw->src = b->src;
     const size_t bytes = sizeof(int32_t) * 2 * (size_t)(b->n_ent + 128);
     if (dev_malloc(&sw->ent0, bytes) != hipSuccess || hipMemcpy(sw->ent0, b->ent0, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
@@ -685,7 +792,7 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
     if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan of its own (it borrows its base graph's)");
-    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
+    if (W != 16 && W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (16, 32 or 64)", W);
     if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
         return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
     if (!ent || !head || !unit_base || !n_units || !orig || n_ent < 0 || (n_ent & 1)) return fail(RBG_EINVAL, "NULL or malformed plan array");

@@ -81,6 +81,51 @@ __device__ __forceinline__ SellLayer sell_layer_of(SellParamsK &p) {
     return SellLayer{p.xs, p.ys, p.x_rm, p.store_scaled, p.last, p.n_prev, p.prev0_rm, p.prev_scaled};
 }
 
+
+// Per-wave clock (devtools/microbench/sell_trace.hip builds sell.hip with RBG_SELL_TRACE; the product does not): 16 words per
+// wave — [0] s_memrealtime at entry, [1] at exit (100 MHz, chip-wide), [2] units walked, [3] slots gathered, [4..9] s_memtime
+// cycles per phase: 0 entry -> the first unit's header is there and its first entries are requested, 1 -> a unit's first batch
+// of gathers is issued (its entries have arrived), 2 -> the unit's last batch is consumed, 3 -> reduction + epilogue, the store
+// is issued, 4 hand-over to the next unit; [10] XCC id, [11] HW_ID; four regions of 32 768 waves (by launch kind).  In the product
+// every method is empty.
+#ifdef RBG_SELL_TRACE
+__device__ unsigned long long *g_sell_trace = nullptr;
+struct SellClock {
+    unsigned long long rt0, last, acc[6], units, slots;
+    __device__ __forceinline__ void start() {
+        rt0 = __builtin_amdgcn_s_memrealtime();
+        last = __builtin_amdgcn_s_memtime();
+        for (int k = 0; k < 6; ++k) acc[k] = 0;
+        units = slots = 0;
+    }
+    __device__ __forceinline__ void lap(int k) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[k] += now - last;
+        last = now;
+    }
+    __device__ __forceinline__ void count(int n) { ++units, slots += n; }
+    __device__ __forceinline__ void dump(int region) {  // region: 0 valued launch, 2 compact, + 1 for a chain's last launch
+        if (!g_sell_trace || (threadIdx.x & 63)) return;
+        const size_t wv = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wv >= 32768) return;
+        unsigned long long *tr = g_sell_trace + ((size_t)region * 32768 + wv) * 16;
+        tr[0] = rt0, tr[1] = __builtin_amdgcn_s_memrealtime(), tr[2] = units, tr[3] = slots;
+        for (int k = 0; k < 6; ++k) tr[4 + k] = acc[k];
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        tr[10] = xcc & 0xf, tr[11] = hw;
+    }
+};
+#else
+struct SellClock {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void lap(int) {}
+    __device__ __forceinline__ void count(int) {}
+    __device__ __forceinline__ void dump(int) {}
+};
+#endif
+
 template <int K>
 __device__ __forceinline__ int quad_bcast(int v) {  // lane K of every quad, in all its lanes
     return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xF, 0xF, true);
@@ -225,7 +270,7 @@ __device__ __forceinline__ void sell_widen(WT &e, const int sh) {
 // is not on the critical path; profiles/r04_launch_forms.jsonl)
 template <int W, int NS, class WT>
 __device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
-                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
+                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh, SellClock &clk) {
     constexpr int LGW = 64 / (W / 4);
     if (nc <= 0) return;
     int sb = min(8, nc);
@@ -239,6 +284,7 @@ __device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const
         SellRows x;
         sell_issue_n(sb, x, w, rs, lane_off);
         if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+        if (k == 0) clk.lap(1);
         sell_consume_n(sb, acc, x, w);
         sell_widen(wn, sh);
         w = wn;
@@ -302,7 +348,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sell_table_rsrc(SellParamsK &p
 // resource of the gathered table (class 1 - cls, slab s); s_wide = the workgroup's [4][W] LDS scratch of wide rows.
 template <int W, int NS, bool COMPACT, int DEPTH>
 __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, const int cls, const int s, const int4 h, const __amdgpu_buffer_rsrc_t rs,
-                                          const v4i *ents, const int64_t ybase, float (*s_wide)[W]) {
+                                          const v4i *ents, const int64_t ybase, float (*s_wide)[W], SellClock &clk) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
     constexpr int D = NS * W;     // row width: NS slabs
@@ -329,7 +375,9 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     else ebase = ents + (h.x >> 1);
     const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
     if constexpr (DEPTH == 2) sell_gather2<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
-    else sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
+    else sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh, clk);
+    clk.count(nc * LGW);
+    clk.lap(2);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
     const int parts = 1 << lp;
     if (lp > 0) {

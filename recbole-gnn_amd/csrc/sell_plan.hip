@@ -36,7 +36,7 @@ namespace rbg {
 namespace {
 
 constexpr int kPast = 0x7ffffff0;  // = kSellPast (sell.hip)
-constexpr int kMaxSegs = 6;        // wide + parts LGW, LGW / 2, ..., 1 (LGW <= 8)
+constexpr int kMaxSegs = 6;        // wide + parts LGW, LGW / 2, ..., 1 (LGW <= 16)
 constexpr int kMaxPiece = 512;     // sell.py MAX_PIECE
 
 struct Seg {
@@ -242,7 +242,7 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
     };
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
-    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
+    if (W != 16 && W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (16, 32 or 64)", W);
     if (chunk == 0) chunk = 128;  // sell.py CHUNK
     if (chunk < 1 || chunk > (1 << 20)) return fail(RBG_EINVAL, "chunk = %d", chunk);
     if (g->base) return na("a re-weighted view borrows its base graph's plan (rbg_graph_refresh_values)");

@@ -65,7 +65,7 @@ def graphs(rbg, name):
 
 # ---- the planner ------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("W,chunk", [(32, 0), (32, 4), (32, 16), (64, 0), (64, 8)])
+@pytest.mark.parametrize("W,chunk", [(32, 0), (32, 4), (32, 16), (64, 0), (64, 8), (16, 0), (16, 8)])
 @pytest.mark.parametrize("name", ["toy", "ml-100k", "hubs", "duplicates"])
 def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
     """rbg_graph_plan_sell (rocPRIM sorts / scans + one-pass kernels) against sell.build_plan (torch ops) on the handle's own
@@ -93,9 +93,9 @@ def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
     assert torch.equal(arr["ent"][real, 1], val[src[real]].view(torch.int32))
     assert torch.equal(torch.sort(src[real]).values, torch.arange(h.nnz, device=cuda))
     # and the product through it
-    x = randn((nu + ni, 2 * W if W == 32 else 128), 4, cuda)
+    x = randn((nu + ni, {16: 64, 32: 64, 64: 128}[W]), 4, cuda)
     rp, cl, vl = C.build_norm_csr(uid, iid, nu, ni)
-    assert h.spmm_kernel_name(x.shape[1]).startswith(f"sell_spmm_kernel<{W}, 2, false")
+    assert h.spmm_kernel_name(x.shape[1]).startswith(f"sell_spmm_kernel<{W}, {x.shape[1] // W}, false")
     close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rp, cl, vl))
 
 
@@ -271,6 +271,63 @@ def test_launch_forms_are_bit_identical(rbg, cuda, d):
         rbg.set_option("sell_depth", 1)
         rbg.set_option("sell_class_serial", -1)
     assert names == {f"sell_spmm_kernel<32, {d // 32}, true, 1>", f"sell_spmm_kernel<32, {d // 32}, true, 2>"}
+
+
+@pytest.mark.parametrize("d,W", [(32, 32), (64, 32), (128, 32), (64, 16)])
+def test_resident_round_is_bit_identical(rbg, cuda, d, W):
+    """r05, option "sell_stream": one resident round of waves that WALK the plan's units in snake order (csrc/sell_stream.h)
+    instead of one wave per unit — the plan, the summation order and therefore every bit of the results are those of
+    sell_spmm_kernel: the propagation (K = 1..3, forward and backward), the row-major chain, the plain layer, Y += A X, the noise
+    epilogue; grids from one workgroup per CU (many tiers per wave) to eight, with and without the equal-tiers fit, one launch
+    per row class.  The W = 16 plan (four 64-byte slabs at d = 64: every XCD of a class owns one) against float64."""
+    uid, iid, nu, ni = hub_graph(rbg)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    if W != 32:
+        h.plan_sell(W=W)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    x = randn((nu + ni, d), 11, cuda)
+    gout = randn((nu + ni, d), 12, cuda)
+    noise = torch.rand(nu + ni, d, generator=torch.Generator().manual_seed(6)).to(cuda)
+    x64 = x.cpu().numpy().astype(np.float64)
+
+    def run():
+        res = []
+        for k in (1, 2, 3):
+            xg = x.clone().requires_grad_(True)
+            out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
+            out.backward(gout)
+            res += [out.detach().clone(), xg.grad.clone()]
+            res.append(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), k, keep_layers=True)[0].clone())
+        res.append(rbg.ops.spmm_raw(h, x).clone())
+        acc = x.clone()
+        rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
+        res.append(acc)
+        res.append(rbg.ops.spmm_noise_raw(h, x, noise, 0.1).clone())
+        return res
+
+    names = set()
+    try:
+        assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{W}, {d // W}, true, 1>"
+        base = run()
+        lay = _truth_layers(x64, rowptr, col, val, 3)
+        close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
+        close(base[9], lay[0])
+        rbg.set_option("sell_stream", 1)
+        for wgs, fit, serial in [(8, 0, -1), (7, 0, -1), (1, 0, -1), (2, 1, -1), (8, 1, 1), (3, 0, 1)]:
+            if serial == 1 and d // W > 4:
+                continue
+            rbg.set_option("sell_stream_wgs", wgs)
+            rbg.set_option("sell_stream_fit", fit)
+            rbg.set_option("sell_class_serial", serial)
+            names.add(h.propagation_kernel_name(d))
+            for j, (a, b) in enumerate(zip(run(), base)):
+                assert torch.equal(a, b), (wgs, fit, serial, j, float((a - b).abs().max()))
+    finally:
+        rbg.set_option("sell_stream", 0)
+        rbg.set_option("sell_stream_wgs", 8)
+        rbg.set_option("sell_stream_fit", 0)
+        rbg.set_option("sell_class_serial", -1)
+    assert names == {f"sell_stream_kernel<{W}, {d // W}, true, 8>", f"sell_stream_kernel<{W}, {d // W}, true, 7>"}
 
 
 @pytest.mark.parametrize("d", [32, 64, 128])
