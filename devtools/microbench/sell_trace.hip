@@ -7,3 +7,5 @@
 extern "C" int mb_sell_trace_set(unsigned long long *trace) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_sell_trace), &trace, sizeof(trace));
 }
+
+extern "C" int mb_sell_debug_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_sell_debug), &bits, sizeof(bits)); }

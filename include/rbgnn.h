@@ -252,6 +252,9 @@ int rbg_graph_sell_arrays(const rbg_graph *g, const int32_t **ent, const int32_t
  * `stream` (4 bytes read + 4 written per entry).  The view runs the column-slab kernel from its first refresh on; a caller
  * that never refreshes keeps the binned kernel, which reads `vals` at launch time.  A no-op without a plan. */
 int rbg_graph_refresh_values(rbg_graph *view, void *stream);
+/* Lifetime rule of borrowed plans: a view holds pointers INTO its base handle's plan arrays.  While a handle has live views that
+ * borrow its plan, rbg_graph_detach_sell / rbg_graph_plan_sell / rbg_graph_attach_sell on it return RBG_EUNSUPPORTED and leave the
+ * plan in place; destroy the views first (and, as for every view, before the base handle itself). */
 
 /* Column-slab propagation (r03; csrc/sell.hip): attach an EXTERNALLY built SELL-C-sigma plan of this graph for slab width W
  * (the executable specification recbole-gnn_amd/sell.py; the tests compare rbg_graph_plan_sell with it).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,

@@ -67,7 +67,8 @@ static std::atomic<int> g_sell_auto{1}, g_sell_depth{1}, g_sell_class_serial{-1}
 int opt_sell_auto() { return g_sell_auto.load(); }
 int opt_sell_depth() { return g_sell_depth.load(); }
 int opt_sell_class_serial() { return g_sell_class_serial.load(); }
-static std::atomic<int> g_sell_stream{0}, g_sell_stream_wgs{8}, g_sell_stream_fit{0};
+static std::atomic<int> g_sell_stream{0}, g_sell_stream_wgs{8}, g_sell_stream_fit{0}, g_sell_stream_sched{1};
+int opt_sell_stream_sched() { return g_sell_stream_sched.load(); }
 int opt_sell_stream() { return g_sell_stream.load(); }
 int opt_sell_stream_wgs() { return g_sell_stream_wgs.load(); }
 int opt_sell_stream_fit() { return g_sell_stream_fit.load(); }
@@ -331,6 +332,7 @@ static void free_device(rbg_graph *g) {
     if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
     for (SweepDev *sw : g->sweeps) free_sweep(sw);
     g->sweeps.clear();
+    if (g->base && g->sell && g->sell->borrowed) g->base->sell_views.fetch_sub(1);  // the view lets go of its base's plan
     free_sell(g->sell);
     g->sell = nullptr;
     if (g->base) {  // a view owns only its split-row scratch
@@ -562,12 +564,16 @@ int rbg_set_option(const char *key, int64_t value) {
         return RBG_OK;
     }
     if (!strcmp(key, "sell_stream_wgs")) {
-        if (value < 1 || value > 8) return fail(RBG_EINVAL, "sell_stream_wgs = %lld (1..8 workgroups per CU)", (long long)value);
+        if (value < 1 || value > 4096) return fail(RBG_EINVAL, "sell_stream_wgs = %lld (1..4096 workgroups per CU)", (long long)value);
         g_sell_stream_wgs = (int)value;
         return RBG_OK;
     }
     if (!strcmp(key, "sell_stream_fit")) {
         g_sell_stream_fit = value ? 1 : 0;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_sched")) {
+        g_sell_stream_sched = value ? 1 : 0;
         return RBG_OK;
     }
     if (!strcmp(key, "fail_alloc_after")) {
@@ -673,6 +679,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "sell_stream_fit")) {
         *value = g_sell_stream_fit.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_stream_sched")) {
+        *value = g_sell_stream_sched.load();
         return RBG_OK;
     }
     if (!strcmp(key, "sell_class_serial")) {
@@ -1211,7 +1221,16 @@ int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, floa
 
 void rbg_graph_destroy(rbg_graph *g) {
     if (!g) return;
+    // hipFree is an "unsafe" call while ANY stream of the process captures in the global mode (torch.cuda.graph's default): it
+    // fails and invalidates that capture, whichever stream this thread is on.  A dying handle's arrays are not part of a capture
+    // in progress (a captured graph that launches on the handle needs the handle alive anyway), so the frees run with this
+    // thread's capture mode relaxed, and the mode is put back.  (The Python owner additionally parks handles that die while its
+    // OWN current stream captures: graph.py GraphHandle.destroy.)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool swapped = g->device >= 0 && hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
     free_device(g);
+    if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    (void)hipGetLastError();
     delete g;
 }
 

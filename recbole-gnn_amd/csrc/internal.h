@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ int opt_sell_auto();     // rbg_graph_create*: plan the column-slab propagation 
 int opt_sell_depth();    // sell.hip: gather batches a wave keeps in flight (1 or 2)
 int opt_sell_stream();      // sell.hip: 1 = the resident-round launch (sell_stream.h), 0 = one wave per unit
 int opt_sell_stream_wgs();  // ... workgroups (four waves) per CU of its grid
+int opt_sell_stream_sched(); // ... 1 = units dealt longest-first by gather batches (a cached schedule), 0 = snake order
 int opt_sell_stream_fit();  // ... 1 = the fewest waves that give every wave the same number of units
 int opt_sell_class_serial();  // sell.hip: -1 = auto (by table size), 0 = both row classes in one launch, 1 = one launch per class
 // hipMalloc behind the fault-injection hook of the tests (option "fail_alloc_after"): every allocation of the plan code goes
@@ -141,6 +143,15 @@ struct SellDev {
     bool native = false;             // built by rbg_graph_plan_sell (the values are the graph's own)
     const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan
     bool view_fresh = false;         // a view's values have been refreshed at least once (rbg_graph_refresh_values)
+    // schedules of the resident-round launch (sell.hip sell_schedule): per (class, waves of a role) a longest-first deal of the
+    // class's units over the waves — permuted copies of the unit headers + every wave's slice; built on first use, outside captures
+    struct Sched {
+        int cls = 0, n_w = 0;
+        int32_t *head = nullptr;  // [n_units][4]
+        int32_t *off = nullptr;   // [n_w + 1]
+    };
+    mutable std::vector<Sched> scheds;
+    mutable std::mutex sched_mutex;
     float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain WITHOUT row-major entries (allocated by the first such backward)
     int64_t bwd_floats = 0;
     std::mutex bwd_mutex;
@@ -193,6 +204,9 @@ struct rbg_graph {
                                       // d_val borrowed from the caller; only partials / counters are its own
     std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
     rbg::SellDev *sell = nullptr;         // optional SELL plan of the column-slab propagation (rbg_graph_plan_sell / _attach_sell)
+    mutable std::atomic<int> sell_views{0};  // live re-weighted views that BORROW this handle's plan arrays: while > 0 the plan
+                                             // is neither detached nor replaced (rbg_graph_detach_sell / _plan_sell / _attach_sell
+                                             // return RBG_EUNSUPPORTED)
     std::string sell_note;                // why the handle has no plan (rbg_graph_sell_status)
 };
 

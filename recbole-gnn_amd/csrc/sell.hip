@@ -24,8 +24,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
+#include <queue>
+#include <vector>
 #include <type_traits>
 
 #include "internal.h"
@@ -192,6 +195,10 @@ void free_sell(SellDev *sw) {
     }
     if (sw->ent0) (void)hipFree(sw->ent0);
     if (sw->bwd) (void)hipFree(sw->bwd);
+    for (auto &sc : sw->scheds) {
+        if (sc.head) (void)hipFree(sc.head);
+        if (sc.off) (void)hipFree(sc.off);
+    }
     delete sw;
 }
 
@@ -209,15 +216,15 @@ static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_
 
 static int sell_depth() { return opt_sell_depth() == 2 ? 2 : 1; }
 
-static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int64_t *rounds_out, int *wgs_out);
+static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, bool snake, int64_t *rounds_out, int *wgs_out);
 const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
     static thread_local char buf[64];
     const int W = g->sell->W, ns = d / W;
     int64_t rounds = 0;
     int wgs = 0;
     const int c = opt_sell_class_serial() == 1 ? 0 : -1;
-    if (opt_sell_stream() && sell_stream_grid(g->sell, ns, c, compact, &rounds, &wgs))
-        snprintf(buf, sizeof buf, "sell_stream_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", (compact && wgs == 8) ? 8 : 7);
+    if (opt_sell_stream() && sell_stream_grid(g->sell, ns, c, compact, opt_sell_stream_sched() == 0, &rounds, &wgs))
+        snprintf(buf, sizeof buf, "sell_stream_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", (compact && wgs >= 8) ? 8 : 7);
     else
         snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", W == 32 ? sell_depth() : 1);
     return buf;
@@ -254,7 +261,7 @@ static int sell_cu_count() {
     return n;
 }
 // the grid of a resident-round launch: `rounds` workgroup indices (eight workgroups each, one per XCD); false = not this launch
-static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int64_t *rounds_out, int *wgs_out) {
+static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, bool snake, int64_t *rounds_out, int *wgs_out) {
     const int xr = (c < 0 ? 4 : 8) / NS;  // XCDs per (class, slab) role
     if (xr < 1) return false;
     int64_t units = 0;
@@ -263,7 +270,8 @@ static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int
     const int per = 4 * xr;  // waves one workgroup index adds to every role
     // workgroups (four waves) per CU: the valued form needs 72 registers (7 waves per SIMD), the compact one fits 64 with five
     // loop-invariant words in scratch or 69 without
-    const int wgs = std::min(opt_sell_stream_wgs(), compact ? 8 : 7);
+    // (more than the chip holds = a grid that covers the units: one unit per wave in the plan's order, dispatched by the hardware)
+    const int wgs = opt_sell_stream_wgs() > 8 ? opt_sell_stream_wgs() : std::min(opt_sell_stream_wgs(), compact ? 8 : 7);
     const int64_t cap = std::max<int64_t>(1, (int64_t)wgs * sell_cu_count() / 8);  // workgroup indices the chip holds at once
     int64_t rounds = std::min<int64_t>(cap, (units + per - 1) / per);
     if (opt_sell_stream_fit() && rounds > 0) {  // every wave the same number of units: T tiers, the fewest waves that cover them
@@ -271,17 +279,104 @@ static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, int
         rounds = (units + tiers * per - 1) / (tiers * per);
     }
     rounds = std::max<int64_t>(rounds, 1);
+    // (the snake deal keeps the four units of a wide row in one workgroup only inside its first tier; a schedule places them)
     for (int cls = 0; cls < 2; ++cls)
-        if ((c < 0 || c == cls) && sw->wide_end[cls] > rounds * per) return false;
+        if (snake && (c < 0 || c == cls) && sw->wide_end[cls] > rounds * per) return false;
     *rounds_out = rounds, *wgs_out = wgs;
     return true;
 }
+// The schedule of class `cls` over n_w waves: units dealt longest-first by their number of gather batches (a unit is a serial
+// chain of batches, each one trip through the CU's memory queue: a wave's time is its batch count, not its slot count).  Wide rows
+// first — row j of the class goes to workgroup j mod (n_w / 4), its four units to that workgroup's four waves in order, at the same
+// position of their lists (they meet at the workgroup barrier) —, then every other unit to the least loaded wave.  Built on the
+// host from the class's headers (one download), cached on the plan; NULL = not now (a capture is open, or out of memory): the
+// launch deals in snake order.
+static bool sell_schedule(const SellDev *sw, int cls, int n_w, hipStream_t s, SellDev::Sched *out) {
+    std::lock_guard<std::mutex> lock(sw->sched_mutex);
+    for (const auto &sc : sw->scheds)
+        if (sc.cls == cls && sc.n_w == n_w) {
+            *out = sc;
+            return true;
+        }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const int nu = sw->n_units[cls];
+    if (nu <= 0 || n_w < 4 || (n_w & 3)) return false;
+    std::vector<int4> h((size_t)nu);
+    if (hipMemcpy(h.data(), reinterpret_cast<const int4 *>(sw->head) + sw->unit_base[cls], sizeof(int4) * (size_t)nu, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    auto weight = [&](int u) { return 4 * (int64_t)((((unsigned)h[u].z >> 16) + 7) / 8) + 1; };  // batches (+ a quarter batch per unit)
+    std::vector<std::vector<int>> list((size_t)n_w);
+    std::vector<int64_t> load((size_t)n_w, 0);
+    const int n_wg = n_w / 4;
+    int u = 0, wide_rows = 0;
+    for (; u + 3 < nu && ((h[u].w >> 16) & 1); u += 4, ++wide_rows) {  // wide rows lead the class's list, four units each
+        const int g = wide_rows % n_wg;
+        for (int j = 0; j < 4; ++j) list[(size_t)4 * g + j].push_back(u + j), load[(size_t)4 * g + j] += weight(u + j);
+    }
+    std::vector<int> order;
+    order.reserve((size_t)(nu - u));
+    for (int v = u; v < nu; ++v) {
+        if ((h[v].w >> 16) & 1) return false;  // (a wide unit outside the leading block: not a plan of ours)
+        order.push_back(v);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(a) > weight(b); });
+    typedef std::pair<int64_t, int> Q;  // (load, wave): the least loaded wave, the lowest index among equals
+    std::priority_queue<Q, std::vector<Q>, std::greater<Q>> pq;
+    for (int w = 0; w < n_w; ++w) pq.push(Q(load[(size_t)w], w));
+    for (int v : order) {
+        Q q = pq.top();
+        pq.pop();
+        list[(size_t)q.second].push_back(v);
+        q.first += weight(v);
+        pq.push(q);
+    }
+    std::vector<int4> ph;
+    ph.reserve((size_t)nu);
+    std::vector<int32_t> off((size_t)n_w + 1, 0);
+    for (int w = 0; w < n_w; ++w) {
+        off[(size_t)w] = (int32_t)ph.size();
+        for (int v : list[(size_t)w]) ph.push_back(h[(size_t)v]);
+    }
+    off[(size_t)n_w] = (int32_t)ph.size();
+    SellDev::Sched sc;
+    sc.cls = cls, sc.n_w = n_w;
+    bool ok = dev_malloc(&sc.head, sizeof(int4) * ph.size()) == hipSuccess && dev_malloc(&sc.off, sizeof(int32_t) * off.size()) == hipSuccess;
+    ok = ok && hipMemcpy(sc.head, ph.data(), sizeof(int4) * ph.size(), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(sc.off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (sc.head) (void)hipFree(sc.head);
+        if (sc.off) (void)hipFree(sc.off);
+        return false;
+    }
+    sw->scheds.push_back(sc);
+    *out = sc;
+    return true;
+}
+
 template <int W, int NS>
 static bool sell_stream_launch(const SellDev *sw, const SellParams &p, int c, hipStream_t s) {
     int64_t rounds = 0;
     int wgs = 0;
-    if (!sell_stream_grid(sw, NS, c, p.compact != 0, &rounds, &wgs)) return false;
+    const bool lpt = opt_sell_stream_sched() != 0;
+    if (!sell_stream_grid(sw, NS, c, p.compact != 0, !lpt, &rounds, &wgs)) return false;
     const int xr = (c < 0 ? 4 : 8) / NS;
+    const int n_w = (int)(rounds * 4 * xr);
+    SellDev::Sched sc[2];
+    if (lpt)
+        for (int cls = 0; cls < 2; ++cls)
+            if ((c < 0 || c == cls) && sw->n_units[cls] > 0 && !sell_schedule(sw, cls, n_w, s, &sc[cls])) {
+                // no schedule now: the snake deal, under its own guard
+                if (!sell_stream_grid(sw, NS, c, p.compact != 0, true, &rounds, &wgs)) return false;
+                sc[0] = sc[1] = SellDev::Sched{};
+                break;
+            }
     SellStreamParams q;
     q.p = p;
     q.p.cls_only = c;
@@ -293,10 +388,11 @@ static bool sell_stream_launch(const SellDev *sw, const SellParams &p, int c, hi
         R.n_units = sw->n_units[cls], R.unit_base = sw->unit_base[cls];
         R.n_tab = sw->n_class[1 - cls], R.cbase = cls ? sw->n_class[0] : 0;
         R.ybase = p.slab_off[cls][R.s], R.xoff = p.slab_off[1 - cls][R.s];
+        if (sc[cls].off) R.sched_head = reinterpret_cast<const int4 *>(sc[cls].head), R.sched_off = sc[cls].off;
     }
     const unsigned grid = (unsigned)(8 * rounds);
     if (!p.compact) hipLaunchKernelGGL((sell_stream_kernel<W, NS, false, 7>), dim3(grid), dim3(256), 0, s, q);
-    else if (wgs == 8) hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 8>), dim3(grid), dim3(256), 0, s, q);
+    else if (wgs >= 8) hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 8>), dim3(grid), dim3(256), 0, s, q);
     else hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 7>), dim3(grid), dim3(256), 0, s, q);
     return true;
 }
@@ -777,6 +873,7 @@ int sell_make_view(rbg_graph *view, const rbg_graph *base) {
         return RBG_EUNSUPPORTED;  // (the view keeps the binned kernel)
     }
     view->sell = sw;
+    base->sell_views.fetch_add(1);  // (released by the view's destruction: graph_build.cpp free_device)
     return RBG_OK;
 }
 
@@ -792,6 +889,8 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
     if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
     if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan of its own (it borrows its base graph's)");
+    if (g->sell && !g->sell->borrowed && g->sell_views.load() > 0)
+        return fail(RBG_EUNSUPPORTED, "%d re-weighted view(s) borrow this handle's column-slab plan: destroy them before attaching another", g->sell_views.load());
     if (W != 16 && W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (16, 32 or 64)", W);
     if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
         return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
@@ -845,6 +944,10 @@ int rbg_graph_sell_set_factors(rbg_graph *g, const float *r) {
 
 int rbg_graph_detach_sell(rbg_graph *g) {
     if (!g) return fail(RBG_EINVAL, "graph is NULL");
+    // re-weighted views hold raw pointers into this plan (ent, entc, head, orig, src): it stays until they are destroyed
+    if (g->sell && !g->sell->borrowed && g->sell_views.load() > 0)
+        return fail(RBG_EUNSUPPORTED, "%d re-weighted view(s) borrow this handle's column-slab plan: destroy them before detaching or re-planning",
+                    g->sell_views.load());
     if (g->sell) {
         if (g->device >= 0) {
             int rc = set_device_for(g->device);

@@ -90,6 +90,11 @@ __device__ __forceinline__ SellLayer sell_layer_of(SellParamsK &p) {
 // every method is empty.
 #ifdef RBG_SELL_TRACE
 __device__ unsigned long long *g_sell_trace = nullptr;
+// what-if switches of the diagnostic build (results are wrong, timings tell what a part costs): 1 = every gather falls into the
+// first 16 KB of its table (an L1-resident table), 2 = no epilogue (no addend loads, no stores), 4 = entries are not loaded
+// (synthesised offsets), 8 = gathers out of range (the address units work, no cache access)
+__device__ int g_sell_debug = 0;
+#define RBG_SELL_DBG(bit) ((g_sell_debug & (bit)) != 0)
 struct SellClock {
     unsigned long long rt0, last, acc[6], units, slots;
     __device__ __forceinline__ void start() {
@@ -118,6 +123,7 @@ struct SellClock {
     }
 };
 #else
+#define RBG_SELL_DBG(bit) false
 struct SellClock {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void lap(int) {}
@@ -433,22 +439,32 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     }
     if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j
     if (L.last) {
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         const bool ntl = (p.nt & 2) != 0, nts = (p.nt & 1) != 0;
-        if (L.n_prev) sum = ld4(prev0, ntl);
-        if (L.prev_scaled) {  // the layers in between are stored scaled: E_k = z_k / r_i
-            float4 zs = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = 1; i < L.n_prev; ++i) {
-                const float4 q = ld4(p.prev[i] + o, ntl);
-                zs.x += q.x; zs.y += q.y; zs.z += q.z; zs.w += q.w;
+        // the addends are requested AG at a time (4; 2 in the valued kernel, which has no register to spare), not one per wait (r05: the per-wave clock showed the mean's epilogue at 4 500
+        // cycles per wave against 700 for a layer without addends), and summed in the old order: sum = prev0 (+ prev[1] + ...), or
+        // prev0 + (z_1 + z_2 + ...) / r_i when the layers in between are stored scaled
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), zs = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int np = L.n_prev;
+        const int64_t oprev = (L.prev_scaled || !p.prev_rm_all) ? o : orm;
+        constexpr int AG = COMPACT ? 4 : 2;
+        for (int i0 = 0; i0 < np; i0 += AG) {
+            float4 a[AG];
+#pragma unroll
+            for (int j = 0; j < AG; ++j) {
+                a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 + j < np) a[j] = ld4((i0 + j) == 0 ? prev0 : p.prev[i0 + j] + oprev, ntl);
             }
+#pragma unroll
+            for (int j = 0; j < AG; ++j) {
+                if (i0 + j >= np) continue;
+                if (i0 + j == 0) sum = a[j];
+                else if (L.prev_scaled) { zs.x += a[j].x; zs.y += a[j].y; zs.z += a[j].z; zs.w += a[j].w; }
+                else { sum.x += a[j].x; sum.y += a[j].y; sum.z += a[j].z; sum.w += a[j].w; }
+            }
+        }
+        if (L.prev_scaled) {  // E_k = z_k / r_i
             const float ir = p.irs[cbase + row];
             sum.x += zs.x * ir; sum.y += zs.y * ir; sum.z += zs.z * ir; sum.w += zs.w * ir;
-        } else {
-            for (int i = 1; i < L.n_prev; ++i) {
-                const float4 q = ld4(p.prev[i] + (p.prev_rm_all ? orm : o), ntl);
-                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
-            }
         }
         if (p.out2) st4(p.out2 + orm, y, nts);
         sum.x = (sum.x + y.x) / p.denom; sum.y = (sum.y + y.y) / p.denom;

@@ -33,7 +33,10 @@ struct SellRoleK {
     int32_t cbase;   // first row of the class in the plan's numbering (0 / n_class[0])
     int32_t cls, s;
     int32_t xi, xr;  // this XCD's index among the xr XCDs of the role
-    int32_t pad[4];
+    // the role's schedule (NULL: units dealt in snake order): wave w walks sched_head[sched_off[w] .. sched_off[w + 1]) — copies of
+    // the unit headers in the order of a longest-first deal by gather batches (the host's, sell.hip sell_schedule)
+    const int4 *sched_head;
+    const int32_t *sched_off;
 };
 static_assert(sizeof(SellRoleK) == 64, "one s_load_dwordx16 per role");
 
@@ -49,6 +52,11 @@ template <class WT>
 __device__ __forceinline__ WT sell_first_batch(const WT *ebase_all, const int4 h, const int lg, const int q4) {
     WT w = {};
     const int nc = (int)((unsigned)h.z >> 16), sb = min(8, nc);
+    if (RBG_SELL_DBG(4)) {
+        w.x = ((h.x * 37 + lg * 1031 + q4 * 7) & 0x7fff) << 7;
+        if constexpr (std::is_same<WT, v4i>::value) w.z = w.x ^ 0x5580; else w.y = w.x ^ 0x5580;
+        return w;
+    }
     if (2 * q4 < sb) w = (ebase_all + (h.x >> 1))[lg * (sb >> 1) + q4];
     return w;
 }
@@ -56,6 +64,21 @@ __device__ __forceinline__ WT sell_first_batch(const WT *ebase_all, const int4 h
 // (the unit loop's head would otherwise wait for vmcnt(0) — behind the previous unit's epilogue stores)
 template <class T>
 __device__ __forceinline__ void sell_pin(T &v) { asm volatile("" : "+v"(v)); }
+
+// the diagnostic build's what-if switches on a batch of entries (nothing in the product)
+template <class WT>
+__device__ __forceinline__ void sell_debug_entries(WT &e) {
+#ifdef RBG_SELL_TRACE
+    if (RBG_SELL_DBG(1)) {
+        e.x &= 0x3f80;
+        if constexpr (std::is_same<WT, v4i>::value) e.z &= 0x3f80; else e.y &= 0x3f80;
+    }
+    if (RBG_SELL_DBG(8)) {
+        e.x = kSellPast;
+        if constexpr (std::is_same<WT, v4i>::value) e.z = kSellPast; else e.y = kSellPast;
+    }
+#endif
+}
 
 // the row of lane-group lg in unit h (the plan's numbering, class-local)
 __device__ __forceinline__ int sell_row_of(const int4 h, const int lg) {
@@ -194,24 +217,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
     else ebase_all = L.x_rm ? p.ent0 : p.ent;
     const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
     const bool need_node = L.last || L.prev0_rm, need_r = COMPACT || L.store_scaled;
-    if (wi >= nun) {
+    // the units of this wave: a slice of the role's schedule, or every n_w-th unit of the plan's list in snake order
+    const bool sched = R.sched_off != nullptr;
+    if (!sched && wi >= nun) {
         clk.dump((COMPACT ? 2 : 0) + (L.last ? 1 : 0));
         return;
     }
-    SellHeadK *heads = (SellHeadK *)(p.head + R.unit_base);
-    auto head_of = [&](const unsigned t) __attribute__((always_inline)) {
-        const v4i v = heads[t];
+    unsigned t = wi, t_end = nun;
+    if (sched) {
+        const auto *off = (const __attribute__((address_space(4))) int32_t *)R.sched_off;
+        t = (unsigned)off[wi], t_end = (unsigned)off[wi + 1];
+        if (t >= t_end) {
+            clk.dump((COMPACT ? 2 : 0) + (L.last ? 1 : 0));
+            return;
+        }
+    }
+    SellHeadK *heads = sched ? (SellHeadK *)R.sched_head : (SellHeadK *)(p.head + R.unit_base);
+    auto head_of = [&](const unsigned u) __attribute__((always_inline)) {
+        const v4i v = heads[u];
         return make_int4(v.x, v.y, v.z, v.w);
     };
-    int4 h = head_of(wi);
+    int4 h = head_of(t);
     unsigned tier = 0;
-    unsigned tn = 2 * n_w - 1 - wi;  // tier 1
+    unsigned tn = sched ? t + 1 : 2 * n_w - 1 - wi;  // (snake: tier 1)
     WT w = sell_first_batch<WT>(ebase_all, h, lg, q4);
     sell_widen(w, sh);
     sell_pin(w);
     clk.lap(0);
     for (;;) {
-        const bool more = tn < nun;
+        const bool more = tn < t_end;
         int4 hn = h;
         if (more) hn = head_of(tn);  // scalar: back long before the last batch
         const int nc = (int)((unsigned)h.z >> 16);
@@ -242,13 +276,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
                 sell_issue_n(sb, x, w, rs, lane_off);
                 wn = WT{};
                 if (sbn > 0) {
-                    if (2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+                    if (RBG_SELL_DBG(4)) {
+                        wn.x = ((h.x * 37 + k * 131 + lg * 1031 + q4 * 7) & 0x7fff) << 7;
+                        if constexpr (std::is_same<WT, v4i>::value) wn.z = wn.x ^ 0x5580; else wn.y = wn.x ^ 0x5580;
+                    } else if (2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
                 } else {
                     tail_requests();
                 }
                 if (k == 0) clk.lap(1);
                 sell_consume_n(sb, acc, x, w);
                 sell_widen(wn, sh);
+                sell_debug_entries(wn);
                 w = wn;
                 sb = sbn;
             }
@@ -259,12 +297,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC))) void
         }
         sell_pin(w);  // (the next unit's first batch: it arrived right behind this unit's last gathers)
         clk.lap(2);
+        if (RBG_SELL_DBG(2)) {
+            if (acc.lo.x == 12345.678f && node == -77 && r_i == -3.f) L.ys[0] = acc.hi.y;  // (never: keeps the sums and the row scalars alive)
+        } else
         sell_finish<W, NS, COMPACT>(p, L, cls, cbase, s, h, acc, node, r_i, ybase, s_wide);
         clk.lap(3);
         if (!more) break;
         h = hn;
         ++tier;
-        tn = (tier + 1) * n_w + (((tier + 1) & 1) ? n_w - 1 - wi : wi);
+        tn = sched ? tn + 1 : (tier + 1) * n_w + (((tier + 1) & 1) ? n_w - 1 - wi : wi);
         clk.lap(4);
     }
     clk.dump((COMPACT ? 2 : 0) + (L.last ? 1 : 0));

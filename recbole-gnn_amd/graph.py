@@ -374,17 +374,28 @@ class GraphHandle:
         return m[: self.nnz]
 
     def reweighted(self, vals, symmetric=False):
-        """A view with this graph's structure and launch plan whose edge weights are read from ``vals`` (fp32 device
-        tensor [nnz], CSR entry order) at launch time — rewrite ``vals`` in place between launches (NGCF edge dropout,
-        ngcf.py:74-90, without rebuilding a sparse matrix).  The view keeps this handle and ``vals`` alive."""
+        """A view with this graph's structure and launch plan whose edge weights are ``vals`` (fp32 device tensor [nnz], CSR
+        entry order): NGCF edge dropout (ngcf.py:74-90) without rebuilding a sparse matrix.  RULE: after EVERY in-place rewrite
+        of ``vals`` call ``view.refresh_values()`` (or use ``view.update_values(new)``, which does both).  On a planned base
+        graph the view runs the column-slab kernel on a COPY of the values taken by the last refresh; only a view that was never
+        refreshed (or whose base has no plan) reads ``vals`` at launch time — a rewrite without a refresh trains on stale
+        weights with no error.  While views exist the base handle's plan can be neither detached nor re-planned (RbgError,
+        RBG_EUNSUPPORTED); destroy the views first.  The view keeps this handle and ``vals`` alive."""
         if not (vals.is_cuda and vals.dtype == torch.float32 and vals.is_contiguous() and vals.numel() == self.nnz):
             raise ValueError("vals must be a contiguous fp32 device tensor with one entry per edge")
         out = c_vp()
         check(lib.rbg_graph_create_reweighted(ctypes.byref(out), self.ptr, c_vp(vals.data_ptr())))
         view = GraphHandle(out.value, symmetric=symmetric, n_users=self.n_users)
         view._keep_alive = (self, vals)
-        view._is_view = True  # (the values are not the handle's own: no SELL plan, which carries values)
+        view._is_view = True  # (the values are the caller's: the view borrows the base's plan and owns a refreshed copy of them)
         return view
+
+    def update_values(self, new_vals):
+        """Re-weighted views: copy ``new_vals`` into the view's ``vals`` tensor and refresh the plan's copy, in one call."""
+        if not getattr(self, "_is_view", False):
+            raise ValueError("update_values: not a re-weighted view")
+        self._keep_alive[1].copy_(new_vals)
+        self.refresh_values()
 
     def to(self, device):
         """Mirror of ``SparseTensor.to(device)`` (abstract_recommender.py:18)."""

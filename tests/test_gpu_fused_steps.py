@@ -403,3 +403,28 @@ def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow, form):
                                         c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(loss.data_ptr()), st) != 0
     assert lib.rbg_concat_bpr_scatter_f32(None, 64, nu, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, reg, 0,
                                           c_vp(coef.data_ptr()), c_vp(sums.data_ptr()), c_vp(coef.data_ptr()), None, st) != 0
+
+
+def test_a_graph_handle_dying_while_another_stream_captures(rbg, cuda, golden):
+    """the capture is open on ANOTHER stream than the one the dying handle's thread is on (torch.cuda.graph
+    captures in the global mode: every "unsafe" call of the process — hipFree — would invalidate it).  Parking cannot see that
+    capture (torch only answers for the current stream); rbg_graph_destroy itself relaxes the thread's capture mode around its
+    frees.  The handle is destroyed at once, the capture survives and replays."""
+    from recbole_gnn_amd import graph as G
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    x = torch.ones(16, device=cuda)
+    a = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    other = torch.cuda.Stream(device=cuda)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        y = x * 2
+        with torch.cuda.stream(other):  # the current stream is not the capturing one
+            assert not torch.cuda.is_current_stream_capturing()
+            a.destroy()  # hipFree x N, now
+            assert len(G._PARKED) == 0
+        z = y + 1
+    gr.replay()
+    torch.cuda.synchronize()
+    assert float(z.sum()) == 48.0

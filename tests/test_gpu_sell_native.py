@@ -278,8 +278,8 @@ def test_resident_round_is_bit_identical(rbg, cuda, d, W):
     """r05, option "sell_stream": one resident round of waves that WALK the plan's units in snake order (csrc/sell_stream.h)
     instead of one wave per unit — the plan, the summation order and therefore every bit of the results are those of
     sell_spmm_kernel: the propagation (K = 1..3, forward and backward), the row-major chain, the plain layer, Y += A X, the noise
-    epilogue; grids from one workgroup per CU (many tiers per wave) to eight, with and without the equal-tiers fit, one launch
-    per row class.  The W = 16 plan (four 64-byte slabs at d = 64: every XCD of a class owns one) against float64."""
+    epilogue; grids from one workgroup per CU (many units per wave) to eight, units dealt longest-first by a cached schedule
+    (the default) or in snake order, with and without the equal-tiers fit, one launch per row class.  The W = 16 plan (four 64-byte slabs at d = 64: every XCD of a class owns one) against float64."""
     uid, iid, nu, ni = hub_graph(rbg)
     h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
     if W != 32:
@@ -313,17 +313,17 @@ def test_resident_round_is_bit_identical(rbg, cuda, d, W):
         close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
         close(base[9], lay[0])
         rbg.set_option("sell_stream", 1)
-        for wgs, fit, serial in [(8, 0, -1), (7, 0, -1), (1, 0, -1), (2, 1, -1), (8, 1, 1), (3, 0, 1)]:
-            if serial == 1 and d // W > 4:
-                continue
+        for wgs, fit, serial, sched in [(8, 0, -1, 1), (7, 0, -1, 1), (1, 0, -1, 1), (2, 1, -1, 0), (8, 1, 1, 0), (3, 0, 1, 1), (7, 0, -1, 0), (1, 0, -1, 0)]:
             rbg.set_option("sell_stream_wgs", wgs)
             rbg.set_option("sell_stream_fit", fit)
+            rbg.set_option("sell_stream_sched", sched)
             rbg.set_option("sell_class_serial", serial)
             names.add(h.propagation_kernel_name(d))
             for j, (a, b) in enumerate(zip(run(), base)):
-                assert torch.equal(a, b), (wgs, fit, serial, j, float((a - b).abs().max()))
+                assert torch.equal(a, b), (wgs, fit, serial, sched, j, float((a - b).abs().max()))
     finally:
         rbg.set_option("sell_stream", 0)
+        rbg.set_option("sell_stream_sched", 1)
         rbg.set_option("sell_stream_wgs", 8)
         rbg.set_option("sell_stream_fit", 0)
         rbg.set_option("sell_class_serial", -1)
@@ -456,6 +456,38 @@ def test_reweighted_view_runs_the_plan_after_a_refresh(rbg, cuda):
     close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x64, rowptr, col, val))  # the base graph's own values are untouched
     view.destroy()
     h.destroy()
+
+
+def test_a_borrowed_plan_outlives_its_views(rbg, cuda):
+    """a re-weighted view holds raw pointers into its base handle's plan.  While views live the base's plan is
+    neither detached nor replaced (RBG_EUNSUPPORTED, nothing freed); the views keep computing; once they are gone the base
+    re-plans."""
+    RBG_EUNSUPPORTED, RbgError = rbg._lib.RBG_EUNSUPPORTED, rbg.RbgError
+    uid, iid, nu, ni = hub_graph(rbg, seed=3)
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    vals = h.values() * 0.5
+    v1, v2 = h.reweighted(vals, symmetric=True), h.reweighted(vals, symmetric=True)
+    v1.refresh_values(), v2.refresh_values()
+    x = randn((nu + ni, 64), 2, cuda)
+    want = O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rowptr, col, val * 0.5)
+    assert v1.spmm_kernel_name(64).startswith("sell_")
+    close(rbg.ops.spmm_raw(v1, x), want)
+    for call in (h.detach_sell, lambda: h.plan_sell(W=64), lambda: h.attach_sell(64, planner="spec")):
+        with pytest.raises(RbgError) as ei:
+            call()
+        assert ei.value.code == RBG_EUNSUPPORTED and "view" in str(ei.value)
+        assert h.sell_status() == "planned"
+        close(rbg.ops.spmm_raw(v2, x), want)  # (the borrowed arrays are still there)
+    v1.destroy()
+    with pytest.raises(RbgError):
+        h.detach_sell()  # one view left
+    v2.update_values(h.values() * 0.25)  # write + refresh in one call
+    close(rbg.ops.spmm_raw(v2, x), want / 2)
+    v2.destroy()
+    assert h.plan_sell(W=64)["W"] == 64
+    h.detach_sell()
+    assert not h.has_sell(64)
 
 
 def test_per_layer_graphs_over_their_own_plans(rbg, cuda, golden):
