@@ -83,8 +83,6 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "nt_store"    : 1 = non-temporal output stores
  *   "col_split"   : SpMM column-half mode (even / odd XCDs own the lower / upper half of the columns of one row class,
  *                   halving the per-XCD gather working set): -1 = auto (d = 128 and a table <= 512 MB), 0 = off, 1 = on where eligible
- *   "sweep"       : 1 = SpMM launches use the column-sweep plan attached to the graph for that width (if any), 0 = binned kernel
- *   "sweep_lean"  : sweep kernel at d = 64: 1 (default) = DPP row broadcasts + buffer loads in the gather, 0 = the plain gather
  *   "bignn_dma"   : the NGCF configuration (d_in = 64; forward d_out in {16, 32, 48, 64}, backward d_out = 64): 1 (default) =
  *                   row tiles arrive by LDS-DMA (forward: weights in registers, one software-pipelined wave per SIMD,
  *                   16x16x4 fp32 MFMA on Y^T; backward: input AND weight gradients in one kernel); 0 = the general kernels
@@ -108,13 +106,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)
  *   "sell_auto"   : 1 (default) = rbg_graph_create* plans the column-slab propagation (rbg_graph_plan_sell) for every device graph
  *                   with a user / item boundary; 0 = no plan until rbg_graph_plan_sell / rbg_graph_attach_sell is called
- *   "sell_depth"  : gather batches a wave of the column-slab kernel keeps in flight: 1 (default) or 2 (two register sets;
- *                   measured +7 % time at the Gowalla shape, neutral elsewhere)
- *   "sell_class_serial" : 1 = one launch per row class (all eight XCDs gather from ONE table at a time); default (-1 / 0) = one
- *                   launch per layer (user rows on XCDs 0-3, item rows on 4-7).  Measured neutral (-0.4 % at 1.3 M nodes, +4 % at
- *                   the Amazon-Book shape)
  *   "fail_alloc_after" : test hook: the (n + 1)-th device allocation of the plan code from now fails once (-1 = off)
- *   "sell_units_per_wave" : units a wave of the column-slab kernel walks (default 1 = one wave per unit; more measured slower)
  *   "sell_nt"     : non-temporal hints in that kernel's epilogue (bit 0 stores, bit 1 the mean's addend loads; default 0, no effect measured)
  *   "slab"        : measured-and-off r03 variant of the binned kernel over column halves (default 0)
  *   "shard_single_stream" : 1 = the C-ABI sharded layer packs and exchanges on the caller's stream (capturable); default 0 */
@@ -206,26 +198,6 @@ int rbg_graph_export_csr(const rbg_graph *g, int64_t *rowptr, int32_t *col, floa
  * It synchronises the stream (called once per graph) and fails if the structure is not symmetric. */
 int rbg_graph_create_reweighted(rbg_graph **out, const rbg_graph *src, const float *vals);
 int rbg_graph_transpose_map(const rbg_graph *g, int32_t *map, void *stream);
-
-/* Column-sweep launch plan of rbg_spmm_f32 and every operator built on it (engine extension, no reference counterpart:
- * the reference's torch_sparse kernel has no launch plan).  The plan re-cuts the SAME CSR (every entry exactly once,
- * values unchanged) into per-lane-group streams of pieces ordered by column range, so that all rows of an XCD sweep
- * the gathered table range by range while their partial sums stay in LDS.  Arrays are HOST
- * pointers and are validated (bounds, every row finished exactly once) before they are copied to the device:
- *   lg_ptr      [n_wg * lgs + 1]  piece range of every lane-group, lgs = threads / (d / 4)
- *   pieces      [n_pieces][2]     {first entry, slot | cnt << 16 | flags << 24}; flags: 1 = first piece of its slot
- *                                 (store instead of add), 2 = columns index the workgroup's hot tile
- *   ent         [n_ent][2]        {column, bit pattern of the fp32 value}
- *   wg_row_ptr  [n_wg + 1], rows [n_desc][4] = {row, first slot, slots, 0}: the rows a workgroup finishes (sum of the
- *                                 slots in order; 0 slots = an empty row, written as zeros)
- *   wg_hot [n_wg][2] = {first, count} into hot_rows [n_hot] (or both NULL): rows of X copied to LDS at hot_base.
- * One plan per width d in {32, 64, 128}; attaching replaces the previous plan of that width.  Not to be called
- * concurrently with launches on the same handle.  The "sweep" option (default 1) selects the plan when present. */
-int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_floats, const int32_t *lg_ptr,
-                           const uint32_t *pieces, int64_t n_pieces, const int32_t *ent, int64_t n_ent,
-                           const int32_t *wg_row_ptr, const int32_t *rows, int64_t n_desc, const int32_t *wg_hot,
-                           const int32_t *hot_rows, int64_t n_hot, int hot_base);
-int rbg_graph_detach_sweep(rbg_graph *g, int d);  /* d <= 0: every width */
 
 /* Column-slab propagation: the planner inside the library (r04; csrc/sell_plan.hip).  Cuts this device graph's normalized CSR
  * (the product of get_norm_adj_mat, recbole_gnn/data/dataset.py:49-79, or of an SGL view rebuild, sgl.py:107-126) into the

@@ -44,9 +44,6 @@ SIGNATURES = {
     "rbg_graph_destroy": (None, [c_vp]),
     "rbg_graph_create_reweighted": (c_int, [P(c_vp), c_vp, c_vp]),
     "rbg_graph_transpose_map": (c_int, [c_vp, c_vp, c_vp]),
-    "rbg_graph_attach_sweep": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp,
-                                       c_i64, c_int]),
-    "rbg_graph_detach_sweep": (c_int, [c_vp, c_int]),
     "rbg_graph_attach_sell": (c_int, [c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rbg_graph_sell_set_factors": (c_int, [c_vp, c_vp]),
     "rbg_graph_plan_sell": (c_int, [c_vp, c_int, c_int]),

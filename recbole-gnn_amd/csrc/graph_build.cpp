@@ -38,7 +38,7 @@ void clear_error() { t_error.clear(); }
 
 static std::atomic<int> g_short_max{64}, g_wave_max{256}, g_seg_len{4096};
 
-static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_sweep{1}, g_mfma_split{1}, g_sweep_lean{1}, g_bignn_dma{1};
+static std::atomic<int> g_spmm_unroll{8}, g_xcd_split{4}, g_nt_store{1}, g_topk_sample{8192}, g_score_tiles{0}, g_col_split{-1}, g_mfma_split{1}, g_bignn_dma{1};
 int spmm_unroll() { return g_spmm_unroll.load(); }
 int opt_xcd_split() { return g_xcd_split.load(); }
 int opt_nt_store() { return g_nt_store.load(); }
@@ -55,23 +55,15 @@ static std::atomic<int> g_shard_single_stream{0};
 static std::atomic<int> g_slab{0};
 static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
-static std::atomic<int> g_sell_upw{1};
-int opt_sell_units_per_wave() { return g_sell_upw.load(); }
 static std::atomic<int> g_sell_nt{0};
 int opt_sell_nt() { return g_sell_nt.load(); }
 static std::atomic<int> g_sell_factored{1};
 int opt_sell_factored() { return g_sell_factored.load(); }
 static std::atomic<int> g_sell_rowmajor{1};
 int opt_sell_rowmajor() { return g_sell_rowmajor.load(); }
-static std::atomic<int> g_sell_auto{1}, g_sell_depth{1}, g_sell_class_serial{-1};
+static std::atomic<int> g_sell_auto{1};
 int opt_sell_auto() { return g_sell_auto.load(); }
-int opt_sell_depth() { return g_sell_depth.load(); }
-int opt_sell_class_serial() { return g_sell_class_serial.load(); }
-static std::atomic<int> g_sell_stream{0}, g_sell_stream_wgs{8}, g_sell_stream_fit{0}, g_sell_stream_sched{1};
-int opt_sell_stream_sched() { return g_sell_stream_sched.load(); }
-int opt_sell_stream() { return g_sell_stream.load(); }
-int opt_sell_stream_wgs() { return g_sell_stream_wgs.load(); }
-int opt_sell_stream_fit() { return g_sell_stream_fit.load(); }
+
 // fault injection for the tests: the (n + 1)-th dev_malloc from now fails once (option "fail_alloc_after" = n; -1 = off)
 static std::atomic<int64_t> g_fail_alloc_after{-1};
 hipError_t dev_malloc(void **p, size_t bytes) {
@@ -89,8 +81,6 @@ hipError_t dev_malloc(void **p, size_t bytes) {
 }
 int opt_slab() { return g_slab.load(); }
 int opt_shard_single_stream() { return g_shard_single_stream.load(); }
-int opt_sweep() { return g_sweep.load(); }
-int opt_sweep_lean() { return g_sweep_lean.load(); }
 int opt_bignn_dma() { return g_bignn_dma.load(); }
 int opt_mfma_split() { return g_mfma_split.load(); }
 
@@ -313,25 +303,11 @@ int plan_bins(const rbg_graph *g, BinPlan &plan) {
     return RBG_OK;
 }
 
-static void free_sweep(SweepDev *sw) {
-    if (!sw) return;
-    (void)hipFree(sw->lg_ptr);
-    (void)hipFree(sw->pieces);
-    (void)hipFree(sw->ent);
-    (void)hipFree(sw->wg_row_ptr);
-    (void)hipFree(sw->rows);
-    (void)hipFree(sw->wg_hot);
-    (void)hipFree(sw->hot_rows);
-    delete sw;
-}
-
 static void free_device(rbg_graph *g) {
     if (g->device < 0) return;
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return;
     if (cur != g->device && hipSetDevice(g->device) != hipSuccess) return;
-    for (SweepDev *sw : g->sweeps) free_sweep(sw);
-    g->sweeps.clear();
     if (g->base && g->sell && g->sell->borrowed) g->base->sell_views.fetch_sub(1);  // the view lets go of its base's plan
     free_sell(g->sell);
     g->sell = nullptr;
@@ -525,10 +501,6 @@ int rbg_set_option(const char *key, int64_t value) {
         g_col_split = (int)value;
         return RBG_OK;
     }
-    if (!strcmp(key, "sweep")) {
-        g_sweep = value ? 1 : 0;
-        return RBG_OK;
-    }
     if (!strcmp(key, "shard_single_stream")) {
         g_shard_single_stream = value ? 1 : 0;
         return RBG_OK;
@@ -549,33 +521,6 @@ int rbg_set_option(const char *key, int64_t value) {
         g_sell_auto = value ? 1 : 0;
         return RBG_OK;
     }
-    if (!strcmp(key, "sell_depth")) {
-        if (value != 1 && value != 2) return fail(RBG_EINVAL, "sell_depth must be 1 or 2");
-        g_sell_depth = (int)value;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_class_serial")) {
-        if (value < -1 || value > 1) return fail(RBG_EINVAL, "sell_class_serial must be -1 (auto), 0 or 1");
-        g_sell_class_serial = (int)value;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream")) {
-        g_sell_stream = value ? 1 : 0;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_wgs")) {
-        if (value < 1 || value > 4096) return fail(RBG_EINVAL, "sell_stream_wgs = %lld (1..4096 workgroups per CU)", (long long)value);
-        g_sell_stream_wgs = (int)value;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_fit")) {
-        g_sell_stream_fit = value ? 1 : 0;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_sched")) {
-        g_sell_stream_sched = value ? 1 : 0;
-        return RBG_OK;
-    }
     if (!strcmp(key, "fail_alloc_after")) {
         g_fail_alloc_after = value < 0 ? -1 : value;
         return RBG_OK;
@@ -586,15 +531,6 @@ int rbg_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "sell_nt")) {
         g_sell_nt = (int)(value & 3);
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_units_per_wave")) {
-        if (value < 1 || value > 64) return fail(RBG_EINVAL, "sell_units_per_wave = %lld (1..64)", (long long)value);
-        g_sell_upw = value;
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sweep_lean")) {
-        g_sweep_lean = value ? 1 : 0;
         return RBG_OK;
     }
     if (!strcmp(key, "bignn_dma")) {
@@ -665,30 +601,6 @@ int rbg_get_option(const char *key, int64_t *value) {
         *value = g_sell_auto.load();
         return RBG_OK;
     }
-    if (!strcmp(key, "sell_depth")) {
-        *value = g_sell_depth.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream")) {
-        *value = g_sell_stream.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_wgs")) {
-        *value = g_sell_stream_wgs.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_fit")) {
-        *value = g_sell_stream_fit.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_stream_sched")) {
-        *value = g_sell_stream_sched.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sell_class_serial")) {
-        *value = g_sell_class_serial.load();
-        return RBG_OK;
-    }
     if (!strcmp(key, "fail_alloc_after")) {
         *value = g_fail_alloc_after.load();
         return RBG_OK;
@@ -701,20 +613,8 @@ int rbg_get_option(const char *key, int64_t *value) {
         *value = g_sell_nt.load();
         return RBG_OK;
     }
-    if (!strcmp(key, "sell_units_per_wave")) {
-        *value = g_sell_upw.load();
-        return RBG_OK;
-    }
     if (!strcmp(key, "col_split")) {
         *value = g_col_split.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sweep")) {
-        *value = g_sweep.load();
-        return RBG_OK;
-    }
-    if (!strcmp(key, "sweep_lean")) {
-        *value = g_sweep_lean.load();
         return RBG_OK;
     }
     if (!strcmp(key, "bignn_dma")) {
@@ -965,161 +865,6 @@ int rbg_norm_edges(int64_t n_users, int64_t n_items, int64_t n_inter, const int6
     return RBG_OK;
 }
 
-int rbg_graph_detach_sweep(rbg_graph *g, int d) {
-    clear_error();
-    if (!g) return fail(RBG_EINVAL, "graph is NULL");
-    if (g->device < 0) return RBG_OK;
-    int rc = set_device_for(g->device);
-    if (rc) return rc;
-    RBG_HIP(hipDeviceSynchronize());
-    for (size_t i = 0; i < g->sweeps.size();) {
-        if (g->sweeps[i] && (d <= 0 || g->sweeps[i]->d == d)) {
-            free_sweep(g->sweeps[i]);
-            g->sweeps.erase(g->sweeps.begin() + (long)i);
-        } else {
-            ++i;
-        }
-    }
-    return RBG_OK;
-}
-
-int rbg_graph_attach_sweep(rbg_graph *g, int d, int threads, int n_wg, int lds_floats, const int32_t *lg_ptr,
-                           const uint32_t *pieces, int64_t n_pieces, const int32_t *ent, int64_t n_ent,
-                           const int32_t *wg_row_ptr, const int32_t *rows, int64_t n_desc, const int32_t *wg_hot,
-                           const int32_t *hot_rows, int64_t n_hot, int hot_base) {
-    clear_error();
-    if (!g) return fail(RBG_EINVAL, "graph is NULL");
-    if (g->device < 0) return fail(RBG_ENODEV, "sweep plans attach to device graphs");
-    if (d != 32 && d != 64 && d != 128) return fail(RBG_EUNSUPPORTED, "sweep plans exist for d in {32, 64, 128}, got %d", d);
-    if (threads != 256 && threads != 512 && threads != 1024) return fail(RBG_EINVAL, "threads = %d", threads);
-    if (n_wg <= 0 || n_pieces < 0 || n_ent < 0 || n_desc < 0 || n_hot < 0) return fail(RBG_EINVAL, "negative size");
-    if (lds_floats <= 0 || (size_t)lds_floats * 4 > 160 * 1024) return fail(RBG_EINVAL, "lds_floats = %d (at most 160 KiB)", lds_floats);
-    if (!lg_ptr || !wg_row_ptr || (n_pieces && (!pieces || !ent)) || (n_desc && !rows)) return fail(RBG_EINVAL, "NULL plan array");
-    if ((wg_hot != nullptr) != (hot_rows != nullptr)) return fail(RBG_EINVAL, "wg_hot and hot_rows come together");
-    const int lpr = d / 4, lgs = threads / lpr, pm = lpr < 16 ? lpr : 16;
-    const int64_t n_lg = (int64_t)n_wg * lgs;
-    // the plan is executed as given, so everything the kernel dereferences is bounds-checked here
-    const int n_slots_max = (wg_hot ? hot_base : lds_floats) / d;
-    if (wg_hot && (hot_base < 0 || hot_base % 4 || hot_base > lds_floats)) return fail(RBG_EINVAL, "hot_base = %d", hot_base);
-    const int hot_cap = wg_hot ? (lds_floats - hot_base) / d : 0;
-    if (lg_ptr[0] != 0 || lg_ptr[n_lg] != n_pieces) return fail(RBG_EINVAL, "lg_ptr does not span the pieces");
-    std::vector<int32_t> hot_of_wg;
-    if (wg_hot) {
-        for (int w = 0; w < n_wg; ++w) {
-            const int32_t hb = wg_hot[2 * w], hn = wg_hot[2 * w + 1];
-            if (hb < 0 || hn < 0 || hn > hot_cap || (int64_t)hb + hn > n_hot) return fail(RBG_EINVAL, "wg_hot[%d] out of range", w);
-        }
-        for (int64_t h = 0; h < n_hot; ++h)
-            if (hot_rows[h] < 0 || hot_rows[h] >= g->n_cols) return fail(RBG_EINVAL, "hot_rows[%lld] out of range", (long long)h);
-    }
-    for (int64_t l = 0; l < n_lg; ++l) {
-        if (lg_ptr[l + 1] < lg_ptr[l]) return fail(RBG_EINVAL, "lg_ptr not monotone at %lld", (long long)l);
-        const int w = (int)(l / lgs);
-        int64_t pos = lg_ptr[l] < lg_ptr[l + 1] ? (int64_t)pieces[2 * (int64_t)lg_ptr[l]] : 0;
-        for (int64_t q = lg_ptr[l]; q < lg_ptr[l + 1]; ++q) {
-            const uint32_t beg = pieces[2 * q], meta = pieces[2 * q + 1];
-            const int cnt = (int)((meta >> 16) & 0xffu), slot = (int)(meta & 0xffffu), flags = (int)(meta >> 24);
-            if ((int64_t)beg != pos) return fail(RBG_EINVAL, "piece %lld does not continue its lane-group's stream", (long long)q);
-            if (cnt < 1 || cnt > pm || (int64_t)beg + cnt > n_ent) return fail(RBG_EINVAL, "piece %lld: cnt = %d", (long long)q, cnt);
-            if (slot >= n_slots_max) return fail(RBG_EINVAL, "piece %lld: slot %d beyond the LDS accumulators", (long long)q, slot);
-            const bool hot = (flags & 2) != 0;
-            if (hot && !wg_hot) return fail(RBG_EINVAL, "piece %lld is HOT but the plan has no hot tile", (long long)q);
-            for (int j = 0; j < cnt; ++j) {
-                const int32_t c = ent[2 * ((int64_t)beg + j)];
-                if (hot ? (c < 0 || c >= wg_hot[2 * w + 1]) : (c < 0 || c >= g->n_cols))
-                    return fail(RBG_EINVAL, "piece %lld entry %d: column %d out of range", (long long)q, j, c);
-            }
-            pos += cnt;
-        }
-    }
-    if (wg_row_ptr[0] != 0 || wg_row_ptr[n_wg] != n_desc) return fail(RBG_EINVAL, "wg_row_ptr does not span the row descriptors");
-    std::vector<uint8_t> seen;
-    try {
-        seen.assign((size_t)g->n_rows, 0);
-    } catch (const std::bad_alloc &) {
-        return fail(RBG_ENOMEM, "host allocation failed");
-    }
-    for (int w = 0; w < n_wg; ++w) {
-        if (wg_row_ptr[w + 1] < wg_row_ptr[w]) return fail(RBG_EINVAL, "wg_row_ptr not monotone at %d", w);
-        for (int64_t r = wg_row_ptr[w]; r < wg_row_ptr[w + 1]; ++r) {
-            const int32_t row = rows[4 * r], s0 = rows[4 * r + 1], ns = rows[4 * r + 2];
-            if (row < 0 || row >= g->n_rows || seen[(size_t)row]) return fail(RBG_EINVAL, "row descriptor %lld: row %d invalid or repeated", (long long)r, row);
-            seen[(size_t)row] = 1;
-            if (s0 < 0 || ns < 0 || s0 + ns > n_slots_max) return fail(RBG_EINVAL, "row descriptor %lld: slots out of range", (long long)r);
-        }
-    }
-    for (int64_t r = 0; r < g->n_rows; ++r)
-        if (!seen[(size_t)r]) return fail(RBG_EINVAL, "row %lld is finished by no workgroup", (long long)r);
-    int rc = set_device_for(g->device);
-    if (rc) return rc;
-    if ((rc = rbg_graph_detach_sweep(g, d))) return rc;
-    SweepDev *sw = new (std::nothrow) SweepDev();
-    if (!sw) return fail(RBG_ENOMEM, "out of host memory");
-    sw->d = d;
-    sw->threads = threads;
-    sw->n_wg = n_wg;
-    sw->lds_floats = lds_floats;
-    sw->hot_base = hot_base;
-    sw->n_pieces = n_pieces;
-    sw->n_ent = n_ent;
-    sw->n_desc = n_desc;
-    sw->n_cols = g->n_cols;
-    // two row classes = no workgroup finishes rows on both sides of the user / item boundary (then all its gathers go to
-    // the other side's table, and the lean gather may address that table alone)
-    sw->class_split = 0;
-    if (g->n_users > 0 && g->n_users < g->n_rows) {
-        // ... and every column such a workgroup gathers lies on the OTHER side of the boundary (true for a bipartite graph;
-        // the lean gather addresses one table through a buffer resource, so a column on the wrong side would be read from
-        // outside it): checked entry by entry, otherwise the plan runs with the plain gather
-        bool pure = true;
-        std::vector<int8_t> wg_class((size_t)n_wg, -1);
-        for (int w = 0; w < n_wg && pure; ++w) {
-            bool lo = false, hi = false;
-            for (int64_t r = wg_row_ptr[w]; r < wg_row_ptr[w + 1]; ++r) (rows[4 * r] < g->n_users ? lo : hi) = true;
-            pure = !(lo && hi);
-            wg_class[(size_t)w] = lo ? 0 : (hi ? 1 : -1);
-        }
-        for (int64_t l = 0; l < n_lg && pure; ++l) {
-            const int cls = wg_class[(size_t)(l / lgs)];
-            for (int64_t q = lg_ptr[l]; q < lg_ptr[l + 1] && pure; ++q) {
-                const uint32_t beg = pieces[2 * q], meta = pieces[2 * q + 1];
-                if ((meta >> 24) & 2u) continue;  // HOT pieces index the LDS tile
-                const int cnt = (int)((meta >> 16) & 0xffu);
-                for (int j = 0; j < cnt && pure; ++j) {
-                    const int32_t c = ent[2 * ((int64_t)beg + j)];
-                    pure = cls < 0 || (cls == 0 ? c >= g->n_users : c < g->n_users);
-                }
-            }
-        }
-        if (pure) sw->class_split = g->n_users;
-    }
-    std::vector<int32_t> ent_pad;
-    try {
-        ent_pad.assign((size_t)(n_ent + 16) * 2, 0);
-    } catch (const std::bad_alloc &) {
-        delete sw;
-        return fail(RBG_ENOMEM, "host allocation failed");
-    }
-    if (n_ent) memcpy(ent_pad.data(), ent, sizeof(int32_t) * 2 * (size_t)n_ent);
-    rc = to_device(&sw->lg_ptr, lg_ptr, (size_t)n_lg + 1);
-    if (!rc) rc = to_device(&sw->pieces, pieces, (size_t)n_pieces * 2);
-    if (!rc) rc = to_device(&sw->ent, ent_pad.data(), ent_pad.size());
-    if (!rc) rc = to_device(&sw->wg_row_ptr, wg_row_ptr, (size_t)n_wg + 1);
-    if (!rc) rc = to_device(&sw->rows, rows, (size_t)n_desc * 4);
-    if (!rc && wg_hot) rc = to_device(&sw->wg_hot, wg_hot, (size_t)n_wg * 2);
-    if (!rc && wg_hot) rc = to_device(&sw->hot_rows, hot_rows, (size_t)n_hot);
-    if (rc) {
-        free_sweep(sw);
-        return rc;
-    }
-    try {
-        g->sweeps.push_back(sw);
-    } catch (const std::bad_alloc &) {
-        free_sweep(sw);
-        return fail(RBG_ENOMEM, "out of host memory");
-    }
-    return RBG_OK;
-}
 
 int rbg_graph_create_reweighted(rbg_graph **out, const rbg_graph *src, const float *vals) {
     clear_error();

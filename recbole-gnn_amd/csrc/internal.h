@@ -35,22 +35,13 @@ Tuning current_tuning();
 int spmm_unroll();
 int opt_xcd_split();
 int opt_nt_store();
-int opt_sweep();        // SpMM: use an attached column-sweep plan (1) or the binned kernel (0)
-int opt_sweep_lean();
-int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)   // sweep kernel: DPP broadcast + buffer-load gather (1) or the plain gather (0)
+int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
-int opt_sell_units_per_wave();  // sell.hip: units a wave walks (grid = units / this); 1 = one wave per unit
 int opt_sell_nt();         // sell.hip epilogue: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the mean's addends
 int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
 int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
 int opt_sell_auto();     // rbg_graph_create*: plan the column-slab propagation for every device graph with a user / item boundary
-int opt_sell_depth();    // sell.hip: gather batches a wave keeps in flight (1 or 2)
-int opt_sell_stream();      // sell.hip: 1 = the resident-round launch (sell_stream.h), 0 = one wave per unit
-int opt_sell_stream_wgs();  // ... workgroups (four waves) per CU of its grid
-int opt_sell_stream_sched(); // ... 1 = units dealt longest-first by gather batches (a cached schedule), 0 = snake order
-int opt_sell_stream_fit();  // ... 1 = the fewest waves that give every wave the same number of units
-int opt_sell_class_serial();  // sell.hip: -1 = auto (by table size), 0 = both row classes in one launch, 1 = one launch per class
 // hipMalloc behind the fault-injection hook of the tests (option "fail_alloc_after"): every allocation of the plan code goes
 // through it, so that a test can walk the error paths one allocation at a time
 hipError_t dev_malloc(void **p, size_t bytes);
@@ -102,27 +93,6 @@ struct GroupPlan {
     int32_t n_short, pos_short;  // lane-group rows  desc[pos_short .. +n_short)
 };
 
-// Column-sweep launch plan (spmm.hip, "sweep" kernel): a persistent grid in which every lane-group walks its own stream
-// of pieces (<= 16 CSR entries of one row, all inside one column range) in column-range order, adding each piece's
-// partial sum into an LDS accumulator slot; rows are finished from their slots after a workgroup barrier.  All device.
-struct SweepDev {
-    int d = 0;            // embedding width the plan was cut for (lane-groups per workgroup = threads / (d/4))
-    int threads = 0;      // workgroup size
-    int n_wg = 0;         // grid
-    int lds_floats = 0;   // dynamic LDS per workgroup: accumulator slots [+ hot rows]
-    int32_t *lg_ptr = nullptr;      // [n_wg * lgs + 1] piece range of every lane-group
-    uint32_t *pieces = nullptr;     // [n_pieces][2]: {first entry, slot | cnt << 16 | flags << 24}
-    int32_t *ent = nullptr;         // [n_ent + 16][2]: {col, bits of val}
-    int32_t *wg_row_ptr = nullptr;  // [n_wg + 1]
-    int32_t *rows = nullptr;        // [n_desc][4]: {row, first slot, slots, 0}
-    int32_t *wg_hot = nullptr;      // [n_wg][2]: {first hot row, hot rows} or NULL
-    int32_t *hot_rows = nullptr;    // source row of every hot-tile row
-    int hot_base = 0;               // float offset of the hot tile inside the workgroup's LDS
-    int64_t n_cols = 0;             // rows of the gathered operand
-    int64_t class_split = 0;        // > 0: rows [0, class_split) / the rest are separate workgroups' classes (two-table sources)
-    int64_t n_pieces = 0, n_ent = 0, n_desc = 0;
-};
-
 // SELL-C-sigma plan of the column-slab propagation (sell.hip; planner recbole-gnn_amd/sell.py).  All device.
 struct SellDev {
     int W = 0;                       // slab width (the plan serves d = 2 W)
@@ -138,20 +108,10 @@ struct SellDev {
     int32_t *src = nullptr;          // [n_ent]: CSR entry of every slot (-1 = padding): re-weighted views refresh their values through it; optional
     int64_t n_ent = 0;
     int64_t first_ent1 = 0;          // first entry of class 1's units
-    int32_t wide_end[2] = {0, 0};    // one past the last wide unit of class c (class-local): the resident-round launch's guard
     int chunk = 0;                   // the planner's chunk (0: an attached plan)
     bool native = false;             // built by rbg_graph_plan_sell (the values are the graph's own)
     const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan
     bool view_fresh = false;         // a view's values have been refreshed at least once (rbg_graph_refresh_values)
-    // schedules of the resident-round launch (sell.hip sell_schedule): per (class, waves of a role) a longest-first deal of the
-    // class's units over the waves — permuted copies of the unit headers + every wave's slice; built on first use, outside captures
-    struct Sched {
-        int cls = 0, n_w = 0;
-        int32_t *head = nullptr;  // [n_units][4]
-        int32_t *off = nullptr;   // [n_w + 1]
-    };
-    mutable std::vector<Sched> scheds;
-    mutable std::mutex sched_mutex;
     float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain WITHOUT row-major entries (allocated by the first such backward)
     int64_t bwd_floats = 0;
     std::mutex bwd_mutex;
@@ -202,7 +162,6 @@ struct rbg_graph {
     int32_t max_degree = 0;
     const rbg_graph *base = nullptr;  // a re-weighted view (rbg_graph_create_reweighted): structure + plan borrowed from base,
                                       // d_val borrowed from the caller; only partials / counters are its own
-    std::vector<rbg::SweepDev *> sweeps;  // optional column-sweep plans, one per width (rbg_graph_attach_sweep)
     rbg::SellDev *sell = nullptr;         // optional SELL plan of the column-slab propagation (rbg_graph_plan_sell / _attach_sell)
     mutable std::atomic<int> sell_views{0};  // live re-weighted views that BORROW this handle's plan arrays: while > 0 the plan
                                              // is neither detached nor replaced (rbg_graph_detach_sell / _plan_sell / _attach_sell

@@ -27,30 +27,25 @@
 #include <algorithm>
 #include <mutex>
 #include <new>
-#include <queue>
-#include <vector>
 #include <type_traits>
 
 #include "internal.h"
 #include "sell_kernel.h"
-#include "sell_stream.h"
 
 namespace rbg {
 
-// W = slab width (32).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows (or all eight
-// one class: cls_only), XCD x of a class owns slab x % NS; the 4 / NS (8 / NS) XCDs of a (class, slab) role share its units.
-template <int W, int NS, bool COMPACT, int DEPTH>
-__global__ __launch_bounds__(DEPTH == 2 ? 256 : 1024) __attribute__((amdgpu_waves_per_eu(DEPTH == 2 ? (COMPACT ? 5 : 4) : 8))) void sell_spmm_kernel(const SellParams p_) {
+// W = slab width (32).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows, XCD x of a class
+// owns slab x % NS; the 4 / NS XCDs of a (class, slab) role share its units.
+template <int W, int NS, bool COMPACT>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p_) {
     SellParamsK &p = sell_kernarg();  // (= p_, read in place)
     __shared__ float s_wide[4][W];
     SellClock clk;
     clk.start();
     const int x = blockIdx.x & 7;
-    const bool serial = p.cls_only >= 0;
-    const int cls = serial ? p.cls_only : x >> 2;
-    const int xr = serial ? x : (x & 3);
+    const int cls = x >> 2, xr = x & 3;
     const int s = xr & (NS - 1), xi = xr / NS;
-    const int XR = (serial ? 8 : 4) / NS;  // XCDs per role
+    constexpr int XR = 4 / NS;  // XCDs per role
     const int wave = threadIdx.x >> 6;
     // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
     // scalar-load round trips per wave — n_units, pointers, header, offsets)
@@ -60,11 +55,12 @@ __global__ __launch_bounds__(DEPTH == 2 ? 256 : 1024) __attribute__((amdgpu_wave
     const int4 *heads = p.head + p.unit_base[cls];
     const v4i *ents = p.x_rm ? p.ent0 : p.ent;
     const int64_t ybase = p.slab_off[cls][s];
-    const unsigned n_w = (gridDim.x >> 3) * 4 * XR;  // waves of this role: the grid covers the units, so the loop body runs at most once
-    for (unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave))); t < nun; t += n_w) {
+    // (the grid covers the units: one unit per wave, heaviest first, dealt by the hardware dispatcher)
+    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave)));
+    if (t < nun) {
         const int4 h = heads[t];
         clk.lap(0);
-        sell_unit<W, NS, COMPACT, DEPTH>(p, L, cls, s, h, rs, ents, ybase, s_wide, clk);
+        sell_unit<W, NS, COMPACT>(p, L, cls, s, h, rs, ents, ybase, s_wide, clk);
         clk.lap(3);
     }
     clk.dump((COMPACT ? 2 : 0) + (p.last ? 1 : 0));
@@ -136,17 +132,6 @@ __global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int6
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) entc[e] = ent[e].x;
 }
 
-// one past the last WIDE unit of either class (class-local index): the resident-round launch keeps the four units of a wide
-// row in one workgroup only inside its first tier
-__global__ void sell_wide_end_kernel(const int4 *head, int n_units_total, int unit_base1, int *wide_end) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_units_total) return;
-    if ((head[t].w >> 16) & 1) {
-        const int cls = t >= unit_base1;
-        atomicMax(wide_end + cls, t - (cls ? unit_base1 : 0) + 1);
-    }
-}
-
 // a re-weighted view's values: ent0v[pos].y = vals[src[pos]]
 __global__ void sell_refresh_values_kernel(int2 *ent, const int32_t *src, const float *vals, int64_t n_ent) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
@@ -195,14 +180,10 @@ void free_sell(SellDev *sw) {
     }
     if (sw->ent0) (void)hipFree(sw->ent0);
     if (sw->bwd) (void)hipFree(sw->bwd);
-    for (auto &sc : sw->scheds) {
-        if (sc.head) (void)hipFree(sc.head);
-        if (sc.off) (void)hipFree(sc.off);
-    }
     delete sw;
 }
 
-static bool sell_width_ok(const SellDev *sw, int d) { return (sw->W >= 32 && sw->W * 2 == d) || (sw->W == 32 && (d == 128 || d == 32)) || (sw->W == 16 && d == 64); }
+static bool sell_width_ok(const SellDev *sw, int d) { return sw->W * 2 == d || (sw->W == 32 && (d == 128 || d == 32)); }
 // a re-weighted view runs its plan only after the caller has refreshed it once (rbg_graph_refresh_values: the plan holds a COPY
 // of the values, the binned kernel reads the caller's array at launch time)
 static bool sell_usable(const rbg_graph *g) { return g && g->sell && (!g->sell->borrowed || g->sell->view_fresh); }
@@ -214,209 +195,27 @@ bool sell_applicable(const rbg_graph *g, int d) {
 // the chains run factored (compact entries from the second launch on) when the plan carries row factors
 static bool sell_factored(const SellDev *sw) { return sw->rs && sw->entc && opt_sell_factored() && !sw->borrowed; }
 
-static int sell_depth() { return opt_sell_depth() == 2 ? 2 : 1; }
-
-static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, bool snake, int64_t *rounds_out, int *wgs_out);
 const char *sell_kernel_name(const rbg_graph *g, int d, bool compact) {
     static thread_local char buf[64];
     const int W = g->sell->W, ns = d / W;
-    int64_t rounds = 0;
-    int wgs = 0;
-    const int c = opt_sell_class_serial() == 1 ? 0 : -1;
-    if (opt_sell_stream() && sell_stream_grid(g->sell, ns, c, compact, opt_sell_stream_sched() == 0, &rounds, &wgs))
-        snprintf(buf, sizeof buf, "sell_stream_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", (compact && wgs >= 8) ? 8 : 7);
-    else
-        snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s, %d>", W, ns, compact ? "true" : "false", W == 32 ? sell_depth() : 1);
+    snprintf(buf, sizeof buf, "sell_spmm_kernel<%d, %d, %s>", W, ns, compact ? "true" : "false");
     return buf;
 }
 bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_factored(g->sell); }
 
-// one launch per row class (all eight XCDs on one table at a time: the live gathered set is one table instead of two).  Measured
-// (profiles/r04_launch_forms.jsonl): G-1.3M 3 323 -> 3 310 us per propagation (-0.4 %), Amazon-Book 292 -> 304 us (+4 %): the
-// Infinity Cache is not what bounds the 1.3 M-node shape (its fabric traffic is: 7.3 TB/s) — off unless asked for.
-static bool sell_class_serial(const SellDev *, int) { return opt_sell_class_serial() == 1; }
-
-// one launch: both row classes (c = -1: user rows on XCDs 0-3, item rows on 4-7) or one class on all eight XCDs
-template <int W, int NS, int DEPTH>
-static void sell_launch_one(const SellDev *sw, SellParams &p, int c, hipStream_t s) {
-    const int64_t upw = std::max(1, opt_sell_units_per_wave());  // > 1: a wave walks units t, t + n_w, ... (fewer, longer waves)
-    p.cls_only = c;
-    const int64_t units = c < 0 ? std::max(sw->n_units[0], sw->n_units[1]) : sw->n_units[c];
-    const int per = 4 * ((c < 0 ? 4 : 8) / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
-    const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, ((units + per - 1) / per + upw - 1) / upw));
-    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true, DEPTH>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false, DEPTH>), dim3(grid), dim3(256), 0, s, p);
-}
-
-// The resident-round form (sell_stream.h): the grid is what the chip holds at once ("sell_stream_wgs" workgroups of four
-// waves per CU), a wave walks its role's units in snake order.  false = not this launch (a class has more wide units than a
-// role has waves: the four units of a wide row must meet in one workgroup's first tier) — the caller launches one wave per unit.
-static int sell_cu_count() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        (void)hipGetLastError();
-        return v;
-    }();
-    return n;
-}
-// the grid of a resident-round launch: `rounds` workgroup indices (eight workgroups each, one per XCD); false = not this launch
-static bool sell_stream_grid(const SellDev *sw, int NS, int c, bool compact, bool snake, int64_t *rounds_out, int *wgs_out) {
-    const int xr = (c < 0 ? 4 : 8) / NS;  // XCDs per (class, slab) role
-    if (xr < 1) return false;
-    int64_t units = 0;
-    for (int cls = 0; cls < 2; ++cls)
-        if (c < 0 || c == cls) units = std::max<int64_t>(units, sw->n_units[cls]);
-    const int per = 4 * xr;  // waves one workgroup index adds to every role
-    // workgroups (four waves) per CU: the valued form needs 72 registers (7 waves per SIMD), the compact one fits 64 with five
-    // loop-invariant words in scratch or 69 without
-    // (more than the chip holds = a grid that covers the units: one unit per wave in the plan's order, dispatched by the hardware)
-    const int wgs = opt_sell_stream_wgs() > 8 ? opt_sell_stream_wgs() : std::min(opt_sell_stream_wgs(), compact ? 8 : 7);
-    const int64_t cap = std::max<int64_t>(1, (int64_t)wgs * sell_cu_count() / 8);  // workgroup indices the chip holds at once
-    int64_t rounds = std::min<int64_t>(cap, (units + per - 1) / per);
-    if (opt_sell_stream_fit() && rounds > 0) {  // every wave the same number of units: T tiers, the fewest waves that cover them
-        const int64_t tiers = (units + rounds * per - 1) / (rounds * per);
-        rounds = (units + tiers * per - 1) / (tiers * per);
-    }
-    rounds = std::max<int64_t>(rounds, 1);
-    // (the snake deal keeps the four units of a wide row in one workgroup only inside its first tier; a schedule places them)
-    for (int cls = 0; cls < 2; ++cls)
-        if (snake && (c < 0 || c == cls) && sw->wide_end[cls] > rounds * per) return false;
-    *rounds_out = rounds, *wgs_out = wgs;
-    return true;
-}
-// The schedule of class `cls` over n_w waves: units dealt longest-first by their number of gather batches (a unit is a serial
-// chain of batches, each one trip through the CU's memory queue: a wave's time is its batch count, not its slot count).  Wide rows
-// first — row j of the class goes to workgroup j mod (n_w / 4), its four units to that workgroup's four waves in order, at the same
-// position of their lists (they meet at the workgroup barrier) —, then every other unit to the least loaded wave.  Built on the
-// host from the class's headers (one download), cached on the plan; NULL = not now (a capture is open, or out of memory): the
-// launch deals in snake order.
-static bool sell_schedule(const SellDev *sw, int cls, int n_w, hipStream_t s, SellDev::Sched *out) {
-    std::lock_guard<std::mutex> lock(sw->sched_mutex);
-    for (const auto &sc : sw->scheds)
-        if (sc.cls == cls && sc.n_w == n_w) {
-            *out = sc;
-            return true;
-        }
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return false;
-    }
-    const int nu = sw->n_units[cls];
-    if (nu <= 0 || n_w < 4 || (n_w & 3)) return false;
-    std::vector<int4> h((size_t)nu);
-    if (hipMemcpy(h.data(), reinterpret_cast<const int4 *>(sw->head) + sw->unit_base[cls], sizeof(int4) * (size_t)nu, hipMemcpyDeviceToHost) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    auto weight = [&](int u) { return 4 * (int64_t)((((unsigned)h[u].z >> 16) + 7) / 8) + 1; };  // batches (+ a quarter batch per unit)
-    std::vector<std::vector<int>> list((size_t)n_w);
-    std::vector<int64_t> load((size_t)n_w, 0);
-    const int n_wg = n_w / 4;
-    int u = 0, wide_rows = 0;
-    for (; u + 3 < nu && ((h[u].w >> 16) & 1); u += 4, ++wide_rows) {  // wide rows lead the class's list, four units each
-        const int g = wide_rows % n_wg;
-        for (int j = 0; j < 4; ++j) list[(size_t)4 * g + j].push_back(u + j), load[(size_t)4 * g + j] += weight(u + j);
-    }
-    std::vector<int> order;
-    order.reserve((size_t)(nu - u));
-    for (int v = u; v < nu; ++v) {
-        if ((h[v].w >> 16) & 1) return false;  // (a wide unit outside the leading block: not a plan of ours)
-        order.push_back(v);
-    }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight(a) > weight(b); });
-    typedef std::pair<int64_t, int> Q;  // (load, wave): the least loaded wave, the lowest index among equals
-    std::priority_queue<Q, std::vector<Q>, std::greater<Q>> pq;
-    for (int w = 0; w < n_w; ++w) pq.push(Q(load[(size_t)w], w));
-    for (int v : order) {
-        Q q = pq.top();
-        pq.pop();
-        list[(size_t)q.second].push_back(v);
-        q.first += weight(v);
-        pq.push(q);
-    }
-    std::vector<int4> ph;
-    ph.reserve((size_t)nu);
-    std::vector<int32_t> off((size_t)n_w + 1, 0);
-    for (int w = 0; w < n_w; ++w) {
-        off[(size_t)w] = (int32_t)ph.size();
-        for (int v : list[(size_t)w]) ph.push_back(h[(size_t)v]);
-    }
-    off[(size_t)n_w] = (int32_t)ph.size();
-    SellDev::Sched sc;
-    sc.cls = cls, sc.n_w = n_w;
-    bool ok = dev_malloc(&sc.head, sizeof(int4) * ph.size()) == hipSuccess && dev_malloc(&sc.off, sizeof(int32_t) * off.size()) == hipSuccess;
-    ok = ok && hipMemcpy(sc.head, ph.data(), sizeof(int4) * ph.size(), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(sc.off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) {
-        (void)hipGetLastError();
-        if (sc.head) (void)hipFree(sc.head);
-        if (sc.off) (void)hipFree(sc.off);
-        return false;
-    }
-    sw->scheds.push_back(sc);
-    *out = sc;
-    return true;
-}
-
-template <int W, int NS>
-static bool sell_stream_launch(const SellDev *sw, const SellParams &p, int c, hipStream_t s) {
-    int64_t rounds = 0;
-    int wgs = 0;
-    const bool lpt = opt_sell_stream_sched() != 0;
-    if (!sell_stream_grid(sw, NS, c, p.compact != 0, !lpt, &rounds, &wgs)) return false;
-    const int xr = (c < 0 ? 4 : 8) / NS;
-    const int n_w = (int)(rounds * 4 * xr);
-    SellDev::Sched sc[2];
-    if (lpt)
-        for (int cls = 0; cls < 2; ++cls)
-            if ((c < 0 || c == cls) && sw->n_units[cls] > 0 && !sell_schedule(sw, cls, n_w, s, &sc[cls])) {
-                // no schedule now: the snake deal, under its own guard
-                if (!sell_stream_grid(sw, NS, c, p.compact != 0, true, &rounds, &wgs)) return false;
-                sc[0] = sc[1] = SellDev::Sched{};
-                break;
-            }
-    SellStreamParams q;
-    q.p = p;
-    q.p.cls_only = c;
-    for (int x = 0; x < 8; ++x) {
-        SellRoleK &R = q.role[x];
-        const int cls = c < 0 ? x >> 2 : c, xl = c < 0 ? (x & 3) : x;
-        R = SellRoleK{};
-        R.cls = cls, R.s = xl & (NS - 1), R.xi = xl / NS, R.xr = xr;
-        R.n_units = sw->n_units[cls], R.unit_base = sw->unit_base[cls];
-        R.n_tab = sw->n_class[1 - cls], R.cbase = cls ? sw->n_class[0] : 0;
-        R.ybase = p.slab_off[cls][R.s], R.xoff = p.slab_off[1 - cls][R.s];
-        if (sc[cls].off) R.sched_head = reinterpret_cast<const int4 *>(sc[cls].head), R.sched_off = sc[cls].off;
-    }
-    const unsigned grid = (unsigned)(8 * rounds);
-    if (!p.compact) hipLaunchKernelGGL((sell_stream_kernel<W, NS, false, 7>), dim3(grid), dim3(256), 0, s, q);
-    else if (wgs >= 8) hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 8>), dim3(grid), dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((sell_stream_kernel<W, NS, true, 7>), dim3(grid), dim3(256), 0, s, q);
-    return true;
-}
-
-template <int W, int NS>
-static int sell_launch_class(const SellDev *sw, SellParams &p, int c, hipStream_t s) {
-    if (opt_sell_stream() && sell_stream_launch<W, NS>(sw, p, c, s)) {
-        RBG_HIP(hipGetLastError());
-        return RBG_OK;
-    }
-    if (W == 32 && sell_depth() == 2) {
-        if constexpr (W == 32) sell_launch_one<W, NS, 2>(sw, p, c, s);
-    } else {
-        sell_launch_one<W, NS, 1>(sw, p, c, s);
-    }
-    RBG_HIP(hipGetLastError());
-    return RBG_OK;
-}
-
+// one launch: both row classes (user rows on XCDs 0-3, item rows on 4-7), one wave per unit.
+// Measured and moved out of the product (DESIGN results log 6.9, 6.10, 6.12; devtools/experiments): two gather batches in flight per
+// wave (occupancy 5: +7 %), waves that walk several units (+7 .. +30 %), one launch per row class (+4 % at Amazon-Book, -0.4 % at
+// 1.3 M nodes), one resident round of waves with cross-unit prefetch and a longest-first schedule (+10 %), 64-byte slabs (+45 %).
 template <int W, int NS>
 static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
-    if (!sell_class_serial(sw, NS)) return sell_launch_class<W, NS>(sw, p, -1, s);
-    if (int rc = sell_launch_class<W, NS>(sw, p, 0, s)) return rc;
-    return sell_launch_class<W, NS>(sw, p, 1, s);
+    const int64_t units = std::max(sw->n_units[0], sw->n_units[1]);
+    const int per = 4 * (4 / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
+    const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, (units + per - 1) / per));
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(256), 0, s, p);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
 }
 
 static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
@@ -429,7 +228,6 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.nt = opt_sell_nt();
     p.rs = sw->rs;
     p.irs = sw->irs;
-    p.cls_only = -1;
     p.rm_ld = NS * W;
     p.rm_shift = NS == 4 ? 1 : (NS == 1 ? -1 : 0);
     for (int c = 0; c < 2; ++c) {
@@ -569,7 +367,6 @@ bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx) {
         if ((W_) == 32 && (d_) == 128) return CALL(32, 4);           \
         if ((W_) == 32 && (d_) == 32) return CALL(32, 1);            \
         if ((W_) == 64 && (d_) == 128) return CALL(64, 2);           \
-        if ((W_) == 16 && (d_) == 64) return CALL(16, 4);            \
     } while (0)
 
 int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,
@@ -788,21 +585,6 @@ int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
     if ((int64_t)std::max(n0, n1) * 2 * W * 4 < kSellPast && sell_opt_alloc(&sw->ent0, sizeof(int32_t) * 2 * (size_t)(n_ent + 128), true) && n_ent)
         hipLaunchKernelGGL(sell_first_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent),
                            reinterpret_cast<int2 *>(sw->ent0), n_ent, sw->first_ent1, sw->orig, n0, W);
-    // where the wide units end (the resident-round launch's guard)
-    int *d_we = nullptr;
-    bool we_ok = dev_malloc(&d_we, 2 * sizeof(int)) == hipSuccess && hipMemset(d_we, 0, 2 * sizeof(int)) == hipSuccess;
-    const int n_total = sw->n_units[0] + sw->n_units[1];
-    if (we_ok && n_total)
-        hipLaunchKernelGGL(sell_wide_end_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head), n_total,
-                           sw->n_units[0], d_we);
-    int h_we[2] = {INT32_MAX, INT32_MAX};  // (unknown = "never": the one-wave-per-unit launch)
-    if (we_ok) we_ok = hipMemcpy(h_we, d_we, sizeof h_we, hipMemcpyDeviceToHost) == hipSuccess;
-    if (d_we) (void)hipFree(d_we);
-    if (!we_ok) {
-        (void)hipGetLastError();
-        h_we[0] = h_we[1] = INT32_MAX;
-    }
-    sw->wide_end[0] = h_we[0], sw->wide_end[1] = h_we[1];
     if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
         free_sell(sw);
         return fail(RBG_EHIP, "building the derived arrays of the SELL plan failed");
@@ -864,7 +646,7 @@ int sell_make_view(rbg_graph *view, const rbg_graph *base) {
     sw->n_ent = b->n_ent;
     sw->first_ent1 = b->first_ent1;
     for (int c = 0; c < 2; ++c)
-        sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c], sw->wide_end[c] = b->wide_end[c];
+        sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c];
     sw->ent = b->ent, sw->entc = b->entc, sw->head = b->head, sw->orig = b->orig, sw->src = b->src;
     const size_t bytes = sizeof(int32_t) * 2 * (size_t)(b->n_ent + 128);
     if (dev_malloc(&sw->ent0, bytes) != hipSuccess || hipMemcpy(sw->ent0, b->ent0, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
@@ -891,7 +673,7 @@ int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent
     if (g->base) return fail(RBG_EUNSUPPORTED, "a re-weighted view cannot carry a SELL plan of its own (it borrows its base graph's)");
     if (g->sell && !g->sell->borrowed && g->sell_views.load() > 0)
         return fail(RBG_EUNSUPPORTED, "%d re-weighted view(s) borrow this handle's column-slab plan: destroy them before attaching another", g->sell_views.load());
-    if (W != 16 && W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (16, 32 or 64)", W);
+    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
     if (g->n_users <= 0 || g->n_users >= g->n_rows || g->n_rows != g->n_cols)
         return fail(RBG_EUNSUPPORTED, "a SELL plan needs a square graph with a user / item boundary");
     if (!ent || !head || !unit_base || !n_units || !orig || n_ent < 0 || (n_ent & 1)) return fail(RBG_EINVAL, "NULL or malformed plan array");

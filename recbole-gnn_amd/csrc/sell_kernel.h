@@ -1,5 +1,6 @@
-// sell_kernel.h — device code of the column-slab propagation shared by its two launch forms: one wave per unit, one launch per
-// layer (sell.hip) and the r04 experiment of a persistent K-layer launch (devtools/experiments/sell_persist.hip).  DESIGN 2.1c.
+// sell_kernel.h — device code of the column-slab propagation: one wave per unit, one launch per layer (sell.hip).  DESIGN 2.1c.
+// (Measured and moved out of the product: two gather batches in flight per wave, units walked by fewer / longer waves, one
+// launch per row class, a persistent K-layer launch, a resident round of waves with a longest-first schedule — devtools/experiments.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -47,9 +48,6 @@ struct SellParams {
     int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
     int32_t prev_scaled;     // 1 (last): prev[1..] are scaled slabs: their sum is multiplied by 1 / r_i
     int32_t nt;              // option "sell_nt"
-    // r04
-    int32_t cls_only;        // -1: XCDs 0-3 run class 0, 4-7 class 1; c: all eight XCDs run class c (one launch per class: the live
-                             // gathered set is ONE table — tables beyond the Infinity Cache)
     int32_t rm_ld;           // x_rm: floats between the rows of rm[] (NS W when contiguous; a column block of a wider buffer otherwise)
     int32_t rm_shift;        // x_rm: log2(rm_ld / (2 W)) (-1: rm_ld = W): ent0's offsets are rows of 2 W floats
     const float *noise;      // last (row-major out): out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps   (simgcl.py:30-33)
@@ -270,7 +268,7 @@ __device__ __forceinline__ void sell_widen(WT &e, const int sh) {
 }
 
 // The gathers of one unit: batches of 8 slots per lane-group (the last one of nc % 8, even); the pair of entries a lane holds
-// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  DEPTH = 1: one batch of gathers in flight per wave.
+// for batch k sits at base + (LGW k) / 2 + lg (sb / 2) + q4.  One batch of gathers in flight per wave.
 // (r04, measured and removed: the unit's first batch from a fixed-stride block requested together with the header instead of
 // after it — 93.4 vs 93.5 us per propagation at the Gowalla shape, 126.0 vs 126.2 at Yelp2018: the header -> entries round trip
 // is not on the critical path; profiles/r04_launch_forms.jsonl)
@@ -298,45 +296,6 @@ __device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const
     }
 }
 
-// DEPTH = 2: the gathers of batch b + 1 are issued before batch b is consumed (two register sets, the loop unrolled over
-// them): 16 wave-loads in flight per wave instead of 8 draining to 0 between batches (the wave's memory pipe
-// emptied at every s_waitcnt).  Same summation order as DEPTH = 1: bit-identical results.
-template <int W, int NS, class WT>
-__device__ __forceinline__ void sell_gather2(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
-                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh) {
-    constexpr int LGW = 64 / (W / 4);
-    if (nc <= 0) return;
-    const int nb = (nc + 7) >> 3;
-    auto size_of = [&](int b) __attribute__((always_inline)) { return min(8, nc - 8 * b); };
-    auto load = [&](int b, int sz) __attribute__((always_inline)) {
-        WT e = {};
-        if (2 * q4 < sz) e = base[((LGW * 8 * b) >> 1) + lg * (sz >> 1) + q4];
-        sell_widen(e, sh);
-        return e;
-    };
-    int szP = size_of(0), szQ = 0;
-    WT wP = load(0, szP), wQ = {};
-    SellRows xP, xQ;
-    sell_issue_n(szP, xP, wP, rs, lane_off);
-    if (nb > 1) wQ = load(1, size_of(1));
-    for (int b = 0; b < nb; b += 2) {
-        szQ = b + 1 < nb ? size_of(b + 1) : 0;
-        if (szQ) sell_issue_n(szQ, xQ, wQ, rs, lane_off);
-        WT wN = {};
-        if (b + 2 < nb) wN = load(b + 2, size_of(b + 2));
-        sell_consume_n(szP, acc, xP, wP);
-        if (!szQ) break;
-        szP = b + 2 < nb ? size_of(b + 2) : 0;
-        wP = wN;
-        if (szP) sell_issue_n(szP, xP, wP, rs, lane_off);
-        WT wN2 = {};
-        if (b + 3 < nb) wN2 = load(b + 3, size_of(b + 3));
-        sell_consume_n(szQ, acc, xQ, wQ);
-        wQ = wN2;
-        if (!szP) break;
-    }
-}
-
 __device__ __forceinline__ float sell_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
 
 // the buffer resource of the table a (class, slab) role gathers from
@@ -352,7 +311,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sell_table_rsrc(SellParamsK &p
 
 // One unit: the gathers of its lane-groups, the reduction of split rows, the epilogue.  h = the unit's header; rs = the buffer
 // resource of the gathered table (class 1 - cls, slab s); s_wide = the workgroup's [4][W] LDS scratch of wide rows.
-template <int W, int NS, bool COMPACT, int DEPTH>
+template <int W, int NS, bool COMPACT>
 __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, const int cls, const int s, const int4 h, const __amdgpu_buffer_rsrc_t rs,
                                           const v4i *ents, const int64_t ybase, float (*s_wide)[W], SellClock &clk) {
     constexpr int G = W / 4;      // lanes per lane-group
@@ -370,7 +329,7 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     const int cbase = cls ? p.n_class[0] : 0;
     int node = 0;
     float r_i = 1.f;
-    if constexpr (COMPACT || DEPTH == 2) {  // (the valued DEPTH-1 instantiation has no register to spare: it asks at the end)
+    if constexpr (COMPACT) {  // (the valued instantiation has no register to spare: it asks at the end)
         if (L.last || L.prev0_rm) node = p.orig[cbase + row];
         if (COMPACT || L.store_scaled) r_i = p.rs[cbase + row];
     }
@@ -380,8 +339,7 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     if constexpr (COMPACT) ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
     else ebase = ents + (h.x >> 1);
     const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
-    if constexpr (DEPTH == 2) sell_gather2<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh);
-    else sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh, clk);
+    sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh, clk);
     clk.count(nc * LGW);
     clk.lap(2);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
@@ -413,7 +371,7 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     float nsc = 0.f;
     float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
     if (L.last && p.noise) {
-        if constexpr (!(COMPACT || DEPTH == 2)) node = p.orig[cbase + row];
+        if constexpr (!COMPACT) node = p.orig[cbase + row];
         const float *nrow = p.noise + (int64_t)node * D + sl * 4;
         float ss = 0.f;
 #pragma unroll
@@ -428,13 +386,13 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     }
     if (owner) {
     const int64_t o = ybase + (int64_t)row * W + sl * 4;
-    if constexpr (!(COMPACT || DEPTH == 2)) {
+    if constexpr (!COMPACT) {
         if (L.last || L.prev0_rm) node = p.orig[cbase + row];
     }
     const int64_t orm = (int64_t)node * D + s * W + sl * 4;  // row-major [N, D], the reference's numbering
     const float *prev0 = L.prev0_rm ? p.prm[cls] + (orm - (int64_t)cbase * D) : p.prev[0] + o;
     float4 y = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-    if constexpr (!(COMPACT || DEPTH == 2)) {
+    if constexpr (!COMPACT) {
         if (L.store_scaled) r_i = p.rs[cbase + row];
     }
     if (COMPACT) { y.x *= r_i; y.y *= r_i; y.z *= r_i; y.w *= r_i; }  // y = r_i sum_j z_j

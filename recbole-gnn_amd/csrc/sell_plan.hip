@@ -244,7 +244,7 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
     if (g->device < 0) return fail(RBG_ENODEV, "a SELL plan needs a device graph");
     if (g && g->sell && !g->sell->borrowed && g->sell_views.load() > 0)
         return fail(RBG_EUNSUPPORTED, "%d re-weighted view(s) borrow this handle's column-slab plan: destroy them before re-planning", g->sell_views.load());
-    if (W != 16 && W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (16, 32 or 64)", W);
+    if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
     if (chunk == 0) chunk = 128;  // sell.py CHUNK
     if (chunk < 1 || chunk > (1 << 20)) return fail(RBG_EINVAL, "chunk = %d", chunk);
     if (g->base) return na("a re-weighted view borrows its base graph's plan (rbg_graph_refresh_values)");

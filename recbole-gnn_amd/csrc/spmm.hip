@@ -115,66 +115,6 @@ __device__ __forceinline__ float4 fma4(float s, float4 x, float4 a) {
     return make_float4(fmaf(s, x.x, a.x), fmaf(s, x.y, a.y), fmaf(s, x.z, a.z), fmaf(s, x.w, a.w));
 }
 
-// ---- lean gather (D = 64: a lane-group is exactly one 16-lane DPP row) ------------------------------------------------------
-// The ISA of the plain gather spends ~13 VALU / LDS instructions per gathered row (2 ds_bpermute broadcasts, a select
-// between the two tables, a 64-bit shift and two 64-bit adds, the load, the FMAs); with pieces of 3-9 entries and the
-// four lane-groups of a wave at different counts the sweep kernel is bound by instruction issue (r02: ~40 CU-cycles per
-// piece).  Here an entry's column becomes a BYTE OFFSET once per piece, the per-slot broadcast is a DPP row_newbcast (no
-// LDS crossbar), and the load is a buffer load (scalar base in a resource descriptor + 32-bit offset; reads past the
-// table return zero): 2 DPP moves + 1 add + 1 load + the FMAs per slot, slots beyond the wave's longest piece skipped.
-typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
-template <int J>
-__device__ __forceinline__ int row_bcast16(int x) {  // lane J of every 16-lane row, in all its lanes
-    return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xF, 0xF, true);
-}
-template <int J, int N>
-struct SlotLoop {
-    template <class F>
-    static __device__ __forceinline__ void run(F &&f) {
-        f(std::integral_constant<int, J>{});
-        SlotLoop<J + 1, N>::run(f);
-    }
-};
-template <int N>
-struct SlotLoop<N, N> {
-    template <class F>
-    static __device__ __forceinline__ void run(F &&) {}
-};
-
-// sum_{j < cnt} val_j * X[col_j][4 sl .. 4 sl + 3] for the piece whose entry j sits in lane j of this 16-lane row
-// (cb = col * 256 = byte offset of the row, v = val; lanes >= cnt hold finite leftovers).  Branch-free: a slot beyond the
-// piece gets an offset past the table, for which a buffer load returns zeros without touching memory, so the eight loads
-// of a batch issue back to back and the FMAs need no mask.
-__device__ __forceinline__ float4 lean_piece(__amdgpu_buffer_rsrc_t rs, int cb, float v, int cnt, int lane_off) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int vb = __builtin_bit_cast(int, v);
-    constexpr int kPast = 0x7ffffff0;  // >= num_records for every table this path accepts (< 2^31 bytes)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (__builtin_amdgcn_ballot_w64(half * 8 < cnt) == 0ull) break;  // no lane-group of the wave reaches this batch
-        v4u32 x[8];
-        float vv[8];
-        auto issue = [&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            const int off = (half ? row_bcast16<j + 8>(cb) : row_bcast16<j>(cb)) + lane_off;
-            vv[j] = __builtin_bit_cast(float, half ? row_bcast16<j + 8>(vb) : row_bcast16<j>(vb));
-            x[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (half * 8 + j < cnt) ? off : kPast, 0, 0);
-        };
-        SlotLoop<0, 8>::run(issue);
-        auto use = [&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            // (through scalar copies: __builtin_bit_cast applied to a vector ELEMENT reads element 0 for every index)
-            const unsigned x0 = x[j].x, x1 = x[j].y, x2 = x[j].z, x3 = x[j].w;
-            acc.x = fmaf(vv[j], __uint_as_float(x0), acc.x);
-            acc.y = fmaf(vv[j], __uint_as_float(x1), acc.y);
-            acc.z = fmaf(vv[j], __uint_as_float(x2), acc.z);
-            acc.w = fmaf(vv[j], __uint_as_float(x3), acc.w);
-        };
-        SlotLoop<0, 8>::run(use);
-    }
-    return acc;
-}
-
 // Sum of val[e] * X[col[e], 4*sl .. 4*sl+3] over the chunks of [beg,end) owned by lane-group g of G.
 // A chunk is LPR consecutive entries; lane sl of the group fetches entry sl of the chunk.
 // XS = compile-time row stride of a contiguous source (D, or 2 D in column-half mode); coff = first column of the slice.
@@ -286,7 +226,7 @@ __device__ __forceinline__ void finish_row(const SpmmParams &p, int row, float4 
 // HALF (column-half mode, "col_split" option): the launch covers rows of width W = 2 D; workgroups on even XCDs own
 // columns [0, D), on odd XCDs [D, 2 D), so an XCD's L2 holds half-width rows of one table (the per-XCD working set of
 // the gather halves; the CSR is read twice).  Only for graphs without split rows (the host checks).
-// (The DPP-broadcast + buffer-load gather of the sweep kernel, lean_piece, was also tried here at D = 64: parity holds
+// (The DPP-broadcast + buffer-load gather of the r02 sweep kernel (devtools/experiments/sweep) was also tried here at D = 64: parity holds
 // but the layer runs 43.0 us vs 39.5 us at the Gowalla shape — profiles/r02_binned_lean_gather.jsonl — because with one
 // row per 16 lanes the plain gather already has its 8 loads in flight and the OOB-padded slots cost issue cycles.)
 // SLAB (with HALF, option "slab"): the operands are stored as two column slabs [2][rows][D] instead of row-major [rows][2 D],
@@ -393,135 +333,10 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     finish_row(p, dsc.x, acc, sl, W, coff);
 }
 
-// ---- column-sweep kernel ("sweep" plan, rbg_graph_attach_sweep) --------------------------------------------------------
-// The binned kernel above is bound by L2 misses: an XCD's 4 MB L2 cannot hold the table its rows gather from, and rows
-// are dispatched in degree order, so a cold row of X crosses the fabric once per reference (r01: 4.8x the algorithmic
-// bytes).  Here ALL rows of an XCD are in flight at once (persistent grid, accumulators in LDS) and every lane-group
-// walks its rows' entries column range by column range — the plan stores them in that order — so at any moment the
-// whole XCD gathers from one L2-sized range of X, which is then fetched from the fabric once per XCD and launch.
-// A piece = up to 16 entries of one row inside one column range; its partial sum is added to the row's LDS slot by the
-// one lane-group that owns the slot (rows longer than a lane-group's share are cut over several lane-groups, one slot
-// each), so the summation order is fixed by the plan: results are bit-stable, no atomics.
-// Optional hot tile: the plan may name rows of X that every workgroup of a class copies into its LDS first; pieces
-// flagged HOT index that copy instead of global memory (the north_star's "LDS staging of embedding tiles").
-struct SweepArgs {
-    int table_bytes;  // LEAN: bound of the buffer resource (rows of X * D * 4)
-    const int32_t *lg_ptr;
-    const uint2 *pieces;
-    const int2 *ent;
-    const int32_t *wg_row_ptr;
-    const int4 *rows;
-    const int2 *wg_hot;
-    const int32_t *hot_rows;
-    int hot_base;
-};
+// (r02: a column-sweep kernel — persistent grid, LDS accumulators, entries walked column range by column range — lived here;
+//  measured slower than this kernel on every shape (DESIGN results log 6.5) and moved out of the product in r05:
+//  devtools/experiments/sweep/)
 
-enum { PIECE_FIRST = 1, PIECE_HOT = 2 };
-
-typedef int v2i __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int2 ld_ent(const int2 *p) {  // streamed once: non-temporal
-    const v2i w = __builtin_nontemporal_load(reinterpret_cast<const v2i *>(p));
-    return make_int2(w.x, w.y);
-}
-
-template <int D, int U, int THREADS, bool CONTIG, bool LEAN = false>
-__global__ __launch_bounds__(THREADS) void spmm_sweep_kernel(const SpmmParams p, const SweepArgs a) {
-    extern __shared__ __align__(16) float lds[];
-    constexpr int LPR = D / 4;
-    constexpr int LGS = THREADS / LPR;
-    constexpr int PM = LPR < 16 ? LPR : 16;  // entries per piece (the plan is cut for this width)
-    const int lg = threadIdx.x / LPR, sl = threadIdx.x % LPR;
-    const int wg = blockIdx.x;
-    if (a.wg_hot) {
-        const int2 hw = a.wg_hot[wg];
-        for (int h = lg; h < hw.y; h += LGS) {
-            const int r = a.hot_rows[hw.x + h];
-            st4(lds + a.hot_base + h * D + sl * 4, ld4((CONTIG ? src_row_c<D>(p.x, r) : src_row(p.x, r)) + sl * 4));
-        }
-        __syncthreads();
-    }
-    // LEAN: every gather of this workgroup goes to ONE table (the host checked: the plan's row classes are the source's
-    // two tables, or the source is a single array), whose base a buffer resource carries
-    __amdgpu_buffer_rsrc_t rs;
-    if constexpr (LEAN) {
-        const int first_row = a.rows[a.wg_row_ptr[wg] < a.wg_row_ptr[wg + 1] ? a.wg_row_ptr[wg] : 0].x;
-        const float *base = (first_row < p.x.split) ? p.x.p1 : p.x.p0;  // user rows gather the (pre-offset) item table
-        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, a.table_bytes, 0x00020000);
-    }
-    const int q0 = a.lg_ptr[wg * LGS + lg], q1 = a.lg_ptr[wg * LGS + lg + 1];
-    if (q0 < q1) {
-        uint2 pc = a.pieces[q0];
-        int pos = (int)pc.x;
-        int2 e = make_int2(0, 0);
-        if (sl < PM) e = ld_ent(a.ent + pos + sl);
-        for (int q = q0; q < q1; ++q) {
-            const int cnt = (int)((pc.y >> 16) & 0xffu), slot = (int)(pc.y & 0xffffu), flags = (int)(pc.y >> 24);
-            // the next piece's descriptor and entries are requested before this piece's gathers (the entry array is
-            // padded, so the read past the lane-group's last piece stays in bounds)
-            pos += cnt;
-            uint2 pc_n = pc;
-            int2 e_n = e;
-            if (q + 1 < q1) {
-                pc_n = a.pieces[q + 1];
-                if (sl < PM) e_n = ld_ent(a.ent + pos + sl);
-            }
-            const int c = e.x;
-            const float v = __int_as_float(e.y);
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (flags & PIECE_HOT) {
-                for (int j = 0; j < cnt; ++j) {
-                    const int cj = __shfl(c, j, LPR);
-                    const float vj = __shfl(v, j, LPR);
-                    acc = fma4(vj, ld4(lds + a.hot_base + cj * D + sl * 4), acc);
-                }
-            } else if constexpr (LEAN) {
-                acc = lean_piece(rs, c << 8, v, cnt, sl * 16);
-            } else {
-                int j = 0;
-                for (; j + U <= cnt; j += U) {
-                    float4 xv[U];
-                    float vv[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int cj = __shfl(c, j + u, LPR);
-                        vv[u] = __shfl(v, j + u, LPR);
-                        xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) acc = fma4(vv[u], xv[u], acc);
-                }
-                if (j < cnt) {
-                    float4 xv[U - 1];
-                    float vv[U - 1];
-#pragma unroll
-                    for (int u = 0; u < U - 1; ++u) {
-                        const int src = min(j + u, LPR - 1);
-                        const int cj = __shfl(c, src, LPR);
-                        const float vj = __shfl(v, src, LPR);
-                        const bool on = (j + u) < cnt;
-                        vv[u] = on ? vj : 0.f;
-                        xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (on) xv[u] = ld4((CONTIG ? src_row_c<D>(p.x, cj) : src_row(p.x, cj)) + sl * 4);
-                    }
-#pragma unroll
-                    for (int u = 0; u < U - 1; ++u) acc = fma4(vv[u], xv[u], acc);
-                }
-            }
-            float *dst = lds + slot * D + sl * 4;
-            if (!(flags & PIECE_FIRST)) acc = add4(ld4(dst), acc);
-            st4(dst, acc);
-            pc = pc_n;
-            e = e_n;
-        }
-    }
-    __syncthreads();
-    for (int r = a.wg_row_ptr[wg] + lg; r < a.wg_row_ptr[wg + 1]; r += LGS) {
-        const int4 rd = a.rows[r];
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < rd.z; ++i) s = add4(s, ld4(lds + (rd.y + i) * D + sl * 4));
-        finish_row(p, rd.x, s, sl, D);
-    }
-}
 
 // Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
 __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, int d) {
@@ -754,66 +569,6 @@ static int launch_binned(const rbg_graph *g, SpmmParams &p, hipStream_t s) {
     return RBG_OK;
 }
 
-// ---- sweep launch ----------------------------------------------------------------------------------------------------
-static const SweepDev *find_sweep(const rbg_graph *g, int d) {
-    for (const SweepDev *sw : g->sweeps)
-        if (sw && sw->d == d) return sw;
-    return nullptr;
-}
-
-template <int D, int THREADS, bool CONTIG, bool LEAN = false>
-static int launch_sweep_inst(const SweepDev *sw, const SpmmParams &p, const SweepArgs &a, hipStream_t s) {
-    auto kern = spmm_sweep_kernel<D, 8, THREADS, CONTIG, LEAN>;
-    const size_t lds_bytes = (size_t)sw->lds_floats * sizeof(float);
-    static std::atomic<size_t> configured[16] = {};  // per device: the largest dynamic-LDS size set for this instantiation
-    int dev = 0;
-    RBG_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 16 && configured[dev].load() < lds_bytes) {
-        RBG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured[dev].store(lds_bytes);
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)sw->n_wg), dim3(THREADS), lds_bytes, s, p, a);
-    RBG_HIP(hipGetLastError());
-    return RBG_OK;
-}
-
-static int64_t g_cols_of(const SweepDev *sw) { return sw->n_cols; }
-
-template <int D>
-static int launch_sweep(const SweepDev *sw, const SpmmParams &p, hipStream_t s) {
-    SweepArgs a{};
-    a.lg_ptr = sw->lg_ptr;
-    a.pieces = reinterpret_cast<const uint2 *>(sw->pieces);
-    a.ent = reinterpret_cast<const int2 *>(sw->ent);
-    a.wg_row_ptr = sw->wg_row_ptr;
-    a.rows = reinterpret_cast<const int4 *>(sw->rows);
-    a.wg_hot = reinterpret_cast<const int2 *>(sw->wg_hot);
-    a.hot_rows = sw->hot_rows;
-    a.hot_base = sw->hot_base;
-    const bool contig = (p.x.ld == D);
-    if constexpr (D == 64) {
-        // lean gather: contiguous rows, every workgroup's gathers inside one table (a single array, or the plan's two row
-        // classes = the source's two tables), offsets within 32 bits
-        const int64_t bytes = (int64_t)g_cols_of(sw) * D * 4;
-        const bool one_table = p.x.split == 0 || (sw->class_split > 0 && p.x.split == sw->class_split);
-        if (opt_sweep_lean() && contig && one_table && bytes < ((int64_t)1 << 31)) {
-            a.table_bytes = (int)bytes;
-            switch (sw->threads) {
-                case 256: return launch_sweep_inst<D, 256, true, true>(sw, p, a, s);
-                case 512: return launch_sweep_inst<D, 512, true, true>(sw, p, a, s);
-                case 1024: return launch_sweep_inst<D, 1024, true, true>(sw, p, a, s);
-                default: break;
-            }
-        }
-    }
-    switch (sw->threads) {
-        case 256: return contig ? launch_sweep_inst<D, 256, true>(sw, p, a, s) : launch_sweep_inst<D, 256, false>(sw, p, a, s);
-        case 512: return contig ? launch_sweep_inst<D, 512, true>(sw, p, a, s) : launch_sweep_inst<D, 512, false>(sw, p, a, s);
-        case 1024: return contig ? launch_sweep_inst<D, 1024, true>(sw, p, a, s) : launch_sweep_inst<D, 1024, false>(sw, p, a, s);
-        default: return fail(RBG_EINVAL, "sweep plan with %d threads per workgroup", sw->threads);
-    }
-}
-
 // One SpMM launch with the epilogue described by p (graph fields are filled here).
 static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) {
     fill_graph(g, p);
@@ -823,16 +578,6 @@ static int launch_spmm(const rbg_graph *g, SpmmParams &p, int d, hipStream_t s) 
     if (p.mode == MODE_MEAN) {
         vec = vec && vec_ok(p.e0) && aligned16(p.mean_out) && (!p.partial || aligned16(p.partial));
         for (int i = 0; i < p.n_prev; ++i) vec = vec && aligned16(p.prev[i]);
-    }
-    if (vec && opt_sweep()) {
-        if (const SweepDev *sw = find_sweep(g, d)) {
-            switch (d) {
-                case 32: return launch_sweep<32>(sw, p, s);
-                case 64: return launch_sweep<64>(sw, p, s);
-                case 128: return launch_sweep<128>(sw, p, s);
-                default: break;
-            }
-        }
     }
     if (vec) {
         switch (d) {
@@ -915,14 +660,6 @@ static int csr_kernel_name(const rbg_graph *g, int d, char *buf, int len) {
     if (d != 32 && d != 64 && d != 128 && d != 256) {
         snprintf(buf, (size_t)len, "spmm_generic_kernel");
         return RBG_OK;
-    }
-    if (opt_sweep() && d <= 128) {
-        if (const SweepDev *sw = find_sweep(g, d)) {
-            // the instantiation a single-array source gets (launch_sweep)
-            const bool lean = d == 64 && opt_sweep_lean() && (int64_t)sw->n_cols * d * 4 < ((int64_t)1 << 31);
-            snprintf(buf, (size_t)len, "spmm_sweep_kernel<%d, 8, %d, true, %s>", d, sw->threads, lean ? "true" : "false");
-            return RBG_OK;
-        }
     }
     const bool half = use_col_half(g, d, MODE_STORE, d);
     snprintf(buf, (size_t)len, "spmm_binned_kernel<%d, %d, true, %s>", half ? d / 2 : d, spmm_unroll(), half ? "true" : "false");

@@ -283,28 +283,15 @@ class GraphHandle:
             check(lib.rbg_graph_plan_sell(self.ptr, int(W), int(chunk)))
         return self.sell_info()
 
-    def attach_sell(self, d=64, chunk=None, W=32, planner="native"):
-        """Kept name of r03.  ``planner="native"`` = ``plan_sell``; ``planner="spec"`` builds the plan with the executable
-        specification ``sell.build_plan`` (torch ops) and attaches it through ``rbg_graph_attach_sell`` — the tests compare
-        the two bit for bit."""
+    def attach_sell(self, d=64, chunk=None, W=32):
+        """Kept name of r03 for ``plan_sell`` with a width check.  (The executable specification of the plan's layout — torch ops,
+        attached through ``rbg_graph_attach_sell`` — lives with the tests: ``tests/sell_spec.py``; the GPU tests compare the
+        library's planner with it bit for bit.)"""
         if not self.sell_eligible(d):
             raise ValueError("a SELL plan needs a device graph built from interactions and d in (32, 64, 128)")
         if W not in (32, 64) or (W == 64 and d != 128):
             raise ValueError(f"slab width {W} does not serve d = {d}")
-        if planner == "native":
-            return self.plan_sell(W, 0 if chunk is None else chunk)
-        from . import sell
-        rowptr, col, val = self.device_csr()
-        with torch.cuda.device(self.device):
-            plan = sell.build_plan(rowptr, col, val, self.n_users, self.n_rows - self.n_users, W=W,
-                                   chunk=sell.CHUNK if chunk is None else chunk)
-            ub = (ctypes.c_int32 * 2)(*plan["unit_base"])
-            nu = (ctypes.c_int32 * 2)(*plan["n_units"])
-            check(lib.rbg_graph_attach_sell(self.ptr, W, c_vp(plan["ent"].data_ptr()), plan["n_ent"], c_vp(plan["head"].data_ptr()),
-                                            ub, nu, c_vp(plan["orig"].data_ptr())))
-            if plan["factors"] is not None:  # val_ij = r_i r_j: the chains read 4-byte entries after their first launch
-                check(lib.rbg_graph_sell_set_factors(self.ptr, c_vp(plan["factors"].data_ptr())))
-        return self.sell_info()
+        return self.plan_sell(W, 0 if chunk is None else chunk)
 
     def detach_sell(self):
         check(lib.rbg_graph_detach_sell(self.ptr))

@@ -202,3 +202,21 @@ def emulate(plan, x):
                     yc[row0 + r] += (vals[ok, None] * x[orig[obase + cc]]).sum(axis=0)
         y[orig[base:base + n[c]]] = yc
     return y
+
+
+def attach(handle, W=32, chunk=None):
+    """Build the plan of ``handle`` (a device GraphHandle) with this specification and attach it through the C ABI
+    (``rbg_graph_attach_sell`` + ``rbg_graph_sell_set_factors``): what ``GraphHandle.attach_sell(planner="spec")`` did in r03/r04."""
+    import ctypes
+    import recbole_gnn_amd as rbg
+    lib, check, vp = rbg._lib.lib, rbg._lib.check, ctypes.c_void_p
+    rowptr, col, val = handle.device_csr()
+    with torch.cuda.device(handle.device):
+        plan = build_plan(rowptr, col, val, handle.n_users, handle.n_rows - handle.n_users, W=W, chunk=CHUNK if chunk is None else chunk)
+        ub = (ctypes.c_int32 * 2)(*plan["unit_base"])
+        nu = (ctypes.c_int32 * 2)(*plan["n_units"])
+        check(lib.rbg_graph_attach_sell(handle.ptr, W, vp(plan["ent"].data_ptr()), plan["n_ent"], vp(plan["head"].data_ptr()), ub, nu,
+                                        vp(plan["orig"].data_ptr())))
+        if plan["factors"] is not None:
+            check(lib.rbg_graph_sell_set_factors(handle.ptr, vp(plan["factors"].data_ptr())))
+    return handle.sell_info()

@@ -74,9 +74,10 @@ def test_ops_refuse_host_graphs_and_missing_gpu(rbg):
         g.attach_sell(64)
     for key in ("sell", "sell_rowmajor", "sell_factored"):
         assert rbg.get_option(key) == 1
-    assert rbg.get_option("sell_units_per_wave") == 1 and rbg.get_option("sell_nt") == 0
-    with pytest.raises(rbg.RbgError):
-        rbg.set_option("sell_units_per_wave", 0)
+    assert rbg.get_option("sell_nt") == 0
+    for gone in ("sell_units_per_wave", "sell_depth", "sell_class_serial", "sweep"):  # measured negatives, moved out of the product in r05
+        with pytest.raises(rbg.RbgError):
+            rbg.set_option(gone, 1)
     if rbg.device_count() == 0:
         with pytest.raises(rbg.RbgError) as ei:
             rbg.GraphHandle.from_interactions([1], [1], 2, 2, device=0)

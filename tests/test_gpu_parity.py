@@ -306,15 +306,14 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         assert not h.has_sell(d)
         info = h.attach_sell(d)
         assert h.has_sell(64) and h.has_sell(128) and h.has_sell(32) and info["padding"] < 1.2  # (W = 32 serves the three widths)
-        dep = rbg.get_option("sell_depth")
         # val_ij = r_i r_j (the symmetric normalisation): the chain's launches after the first read 4-byte entries
-        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true, {dep}>"
+        assert info["factored"] and h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true>"
         # a caller that reads the layers gets them row-major: the same kernel gathering / writing the reference's layout
-        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<32, {d // 32}, false, {dep}>" == h.spmm_kernel_name(d)
+        assert h.propagation_kernel_name(d, scratch_layers=False) == f"sell_spmm_kernel<32, {d // 32}, false>" == h.spmm_kernel_name(d)
         rbg.set_option("sell_rowmajor", 0)
         # without the row-major entries the per-layer outputs come from the binned kernel; the plain layer converts X to slabs
         assert "binned" in h.propagation_kernel_name(d, scratch_layers=False)
-        assert h.spmm_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false, {dep}>"
+        assert h.spmm_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
         rbg.set_option("sell_rowmajor", 1)
         for k in (1, 2, 3):
             out = torch.full((nu + ni, d), 7.0, device=cuda)
@@ -332,7 +331,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
             close(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0], tol=2e-6)  # (the slab chain runs factored)
             rbg.set_option("sell_factored", 0)
             assert torch.equal(mean, rbg.ops.lightgcn_forward_raw(h, uw, iw, k)[0])
-            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false, {dep}>"
+            assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
             rbg.set_option("sell_factored", 1)
             cur = x64
             for j in range(k):
@@ -392,7 +391,7 @@ def test_lightgcn_forward_column_slab_path(rbg, cuda, d):
         rbg.set_option("sell", 1)
         if d == 128:  # the two-slab form of d = 128 (256-byte slab rows): a plan of W = 64
             h.attach_sell(128, W=64)
-            assert h.has_sell(128) and not h.has_sell(64) and h.propagation_kernel_name(128) == "sell_spmm_kernel<64, 2, true, 1>"
+            assert h.has_sell(128) and not h.has_sell(64) and h.propagation_kernel_name(128) == "sell_spmm_kernel<64, 2, true>"
             close(rbg.ops.lightgcn_forward_raw(h, uw, iw, 3)[0], truth[2])
             close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x64, rowptr, col, val))
         h.detach_sell()
@@ -408,7 +407,7 @@ def test_sell_plan_is_range_checked_and_auto_attached(rbg, cuda, golden):
     """rbg_graph_attach_sell validates on the device every index the kernel would dereference; ops.lightgcn_forward attaches
     a plan on the first propagation of an eligible handle (option "sell"), never to a re-weighted view or a host graph."""
     import ctypes
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
     rbg.set_option("sell_auto", 0)  # (this handle is planned from outside: rbg_graph_attach_sell, the specification's arrays)
@@ -1206,72 +1205,6 @@ def test_ncl_model(rbg, cuda, golden):
     close(model.item_embedding.weight.grad, il.grad, tol=2e-5)
     scores = model.full_sort_predict({"user_id": torch.tensor([3, 4], device=cuda)})
     close(scores, O.full_sort_predict(u_ref, i_ref, [3, 4]))
-
-
-# ---- column-sweep launch plan (rbg_graph_attach_sweep) --------------------------------------------------------------------
-
-@pytest.mark.parametrize("cfg", [dict(d=64, threads=256, n_wg=16), dict(d=64, threads=512, n_wg=16, range_bytes=16 * 1024),
-                                 dict(d=32, threads=256, n_wg=16), dict(d=128, threads=512, n_wg=24),
-                                 dict(d=64, threads=256, n_wg=16, hot_rows_per_class=40),
-                                 dict(d=64, threads=1024, n_wg=24, hot_rows_per_class=64, range_bytes=32 * 1024)])
-def test_sweep_kernel(rbg, cuda, golden, cfg):
-    """The sweep kernel executes an attached plan: same operator as the binned kernel (1e-5 vs the oracle), bit-stable,
-    every epilogue (store, accumulate, the fused layer mean of lightgcn_forward, the backward chain), and the
-    "sweep" option switches back to the binned kernel."""
-    from recbole_gnn_amd import sweep
-    g = golden
-    nu, ni = int(g["n_users"]), int(g["n_items"])
-    n = nu + ni
-    cfg = dict(cfg)
-    d = cfg.pop("d")
-    cfg.setdefault("range_bytes", 64 * 1024)
-    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
-    plan = sweep.build_plan(g["rowptr"], g["col"], g["val"], nu, d, lds_bytes=64 * 1024, **cfg)
-    sweep.attach(h, plan)
-    x = randn((n, d), 3, cuda)
-    ref = C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], x.cpu().numpy())
-    y = rbg.ops.spmm_raw(h, x)
-    close(y, ref)
-    assert torch.equal(y, rbg.ops.spmm_raw(h, x))  # fixed summation order
-    acc = torch.ones_like(y)
-    rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
-    close(acc, ref + 1.0)
-    rbg.set_option("sweep", 0)
-    try:
-        y_binned = rbg.ops.spmm_raw(h, x)
-    finally:
-        rbg.set_option("sweep", 1)
-    close(y_binned, ref)
-    uw, iw = x[:nu].clone().requires_grad_(True), x[nu:].clone().requires_grad_(True)
-    mean = rbg.lightgcn_forward(h, uw, iw, 3)
-    close(mean, C.lightgcn_forward(g["rowptr"], g["col"].astype(np.int64), g["val"], x[:nu].cpu().numpy(), x[nu:].cpu().numpy(), 3))
-    mean.square().sum().backward()
-    sweep.detach(h, d)
-    uw2, iw2 = x[:nu].clone().requires_grad_(True), x[nu:].clone().requires_grad_(True)
-    rbg.lightgcn_forward(h, uw2, iw2, 3).square().sum().backward()
-    close(uw.grad, uw2.grad)
-    close(iw.grad, iw2.grad)
-
-
-def test_sweep_plan_is_validated(rbg, cuda, golden):
-    """rbg_graph_attach_sweep executes caller-built arrays, so it refuses plans that would read or write out of bounds or
-    that leave a row unfinished."""
-    from recbole_gnn_amd import sweep
-    g = golden
-    nu, ni = int(g["n_users"]), int(g["n_items"])
-    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
-    good = sweep.build_plan(g["rowptr"], g["col"], g["val"], nu, 64, n_wg=16, threads=256, range_bytes=64 * 1024, lds_bytes=64 * 1024)
-    import copy
-    for field, edit in [("ent", lambda a: a.__setitem__((0, 0), nu + ni + 5)), ("rows", lambda a: a.__setitem__((1, 0), int(a[0, 0]))),
-                        ("pieces", lambda a: a.__setitem__((0, 1), int(a[0, 1]) | 0xFFFF)), ("lg_ptr", lambda a: a.__setitem__(-1, int(a[-1]) - 1))]:
-        bad = copy.deepcopy(good)
-        edit(getattr(bad, field))
-        with pytest.raises(rbg.RbgError):
-            sweep.attach(h, bad)
-    sweep.attach(h, good)
-    host = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=None)
-    with pytest.raises(rbg.RbgError):
-        sweep.attach(host, good)
 
 
 # ---- NGCF -----------------------------------------------------------------------------------

@@ -1,12 +1,12 @@
 """r04: the column-slab plan as a property of the C ABI (csrc/sell_plan.hip: rbg_graph_plan_sell inside rbg_graph_create*).
 
-* the native planner's arrays equal the executable specification's (recbole-gnn_amd/sell.py) bit for bit;
+* the native planner's arrays equal the executable specification's (tests/sell_spec.py) bit for bit;
 * a caller that binds librbgnn.so with raw ctypes only (rbg_graph_create -> rbg_lightgcn_forward_f32,
   the sites layers.py:19-20 / lightgcn.py:74-76) runs sell_spmm_kernel and matches the oracle;
 * every caller of the plain product goes through the plan: the NGCF layer (layers.py:54-58) contiguous and as a column block
   of the concatenated buffer (ngcf.py:100), the SimGCL noise epilogue (simgcl.py:29-33), re-weighted views (ngcf.py:74-90),
   per-layer graph lists (sgl.py:89-91), d = 32;
-* the kernel's launch forms (two batches in flight, first-batch blocks, one launch per row class) are bit-identical;
+* every form of the propagation over the plan (slab chain, row-major chain, plain layer, accumulate, noise) against float64, bit-stable;
 * every allocation of the plan code can fail without leaving a dangling pointer (fault injection: option "fail_alloc_after");
 * parity at the north_star's named scale (1.3 M nodes) and at the single-GPU Amazon-Book shape through the plan.
 """
@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 import torch
 
+import sell_spec as sell
 from conftest import ROOT
 from oracle import coracle as C
 from oracle import oracle as O
@@ -65,13 +66,13 @@ def graphs(rbg, name):
 
 # ---- the planner ------------------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("W,chunk", [(32, 0), (32, 4), (32, 16), (64, 0), (64, 8), (16, 0), (16, 8)])
+@pytest.mark.parametrize("W,chunk", [(32, 0), (32, 4), (32, 16), (64, 0), (64, 8)])
 @pytest.mark.parametrize("name", ["toy", "ml-100k", "hubs", "duplicates"])
 def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
     """rbg_graph_plan_sell (rocPRIM sorts / scans + one-pass kernels) against sell.build_plan (torch ops) on the handle's own
     device CSR: entries (offsets AND value bits), unit headers, row numbering — bit for bit; the factors to one ulp (float64
     pow(-0.5) there, 1 / sqrt in double here); the slot -> CSR position map reproduces every entry."""
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     uid, iid, nu, ni = graphs(rbg, name)
     h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
     assert h.sell_status() == "planned"
@@ -93,7 +94,7 @@ def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
     assert torch.equal(arr["ent"][real, 1], val[src[real]].view(torch.int32))
     assert torch.equal(torch.sort(src[real]).values, torch.arange(h.nnz, device=cuda))
     # and the product through it
-    x = randn((nu + ni, {16: 64, 32: 64, 64: 128}[W]), 4, cuda)
+    x = randn((nu + ni, {32: 64, 64: 128}[W]), 4, cuda)
     rp, cl, vl = C.build_norm_csr(uid, iid, nu, ni)
     assert h.spmm_kernel_name(x.shape[1]).startswith(f"sell_spmm_kernel<{W}, {x.shape[1] // W}, false")
     close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rp, cl, vl))
@@ -228,10 +229,11 @@ def _truth_layers(x64, rowptr, col, val, k):
 
 
 @pytest.mark.parametrize("d", [32, 64, 128])
-def test_launch_forms_are_bit_identical(rbg, cuda, d):
-    """Options "sell_depth" (two gather batches in flight) and "sell_class_serial" (one launch per row class) change how a
-    launch is issued, not what it sums or in which order: the propagation (K = 1..3, forward and backward), the plain layer,
-    Y += A X and the noise epilogue — bit-identical to the default form, and equal to float64 within 1e-5."""
+def test_every_form_of_the_propagation_over_the_plan(rbg, cuda, d):
+    """The propagation (K = 1..3, forward and backward), the row-major chain, the plain layer, Y += A X and the noise epilogue on
+    a graph with split and wide rows: equal to float64 within 1e-5 and bit-stable run to run (the plan fixes the summation
+    order); the unfactored chain (option "sell_factored" = 0) too.  (r04's launch-form options — two batches in flight, one launch per row class — were measured slower and left the
+    product in r05.)"""
     uid, iid, nu, ni = hub_graph(rbg)
     h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
@@ -255,79 +257,24 @@ def test_launch_forms_are_bit_identical(rbg, cuda, d):
         res.append(rbg.ops.spmm_noise_raw(h, x, noise, 0.1).clone())
         return res
 
-    names = set()
-    try:
-        base = run()
-        lay = _truth_layers(x64, rowptr, col, val, 3)
-        close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
-        close(base[9], lay[0])
-        for depth, serial in [(2, 0), (1, 1), (2, 1)]:
-            rbg.set_option("sell_depth", depth)
-            rbg.set_option("sell_class_serial", serial)
-            names.add(h.propagation_kernel_name(d))
-            for a, b in zip(run(), base):
-                assert torch.equal(a, b), (depth, serial)
+    assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, true>"
+    base = run()
+    lay = _truth_layers(x64, rowptr, col, val, 3)
+    close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
+    close(base[8], (x64 + lay[0] + lay[1] + lay[2]) / 4)
+    close(base[9], lay[0])
+    close(base[10], x64 + lay[0])
+    g64 = gout.cpu().numpy().astype(np.float64)
+    gl = _truth_layers(g64, rowptr, col, val, 3)
+    close(base[7], (g64 + gl[0] + gl[1] + gl[2]) / 4)
+    for a, b in zip(run(), base):
+        assert torch.equal(a, b)
+    try:  # the unfactored chain differs by rounding only
+        rbg.set_option("sell_factored", 0)
+        assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
+        close(run()[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
     finally:
-        rbg.set_option("sell_depth", 1)
-        rbg.set_option("sell_class_serial", -1)
-    assert names == {f"sell_spmm_kernel<32, {d // 32}, true, 1>", f"sell_spmm_kernel<32, {d // 32}, true, 2>"}
-
-
-@pytest.mark.parametrize("d,W", [(32, 32), (64, 32), (128, 32), (64, 16)])
-def test_resident_round_is_bit_identical(rbg, cuda, d, W):
-    """r05, option "sell_stream": one resident round of waves that WALK the plan's units in snake order (csrc/sell_stream.h)
-    instead of one wave per unit — the plan, the summation order and therefore every bit of the results are those of
-    sell_spmm_kernel: the propagation (K = 1..3, forward and backward), the row-major chain, the plain layer, Y += A X, the noise
-    epilogue; grids from one workgroup per CU (many units per wave) to eight, units dealt longest-first by a cached schedule
-    (the default) or in snake order, with and without the equal-tiers fit, one launch per row class.  The W = 16 plan (four 64-byte slabs at d = 64: every XCD of a class owns one) against float64."""
-    uid, iid, nu, ni = hub_graph(rbg)
-    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
-    if W != 32:
-        h.plan_sell(W=W)
-    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
-    x = randn((nu + ni, d), 11, cuda)
-    gout = randn((nu + ni, d), 12, cuda)
-    noise = torch.rand(nu + ni, d, generator=torch.Generator().manual_seed(6)).to(cuda)
-    x64 = x.cpu().numpy().astype(np.float64)
-
-    def run():
-        res = []
-        for k in (1, 2, 3):
-            xg = x.clone().requires_grad_(True)
-            out = rbg.ops.lightgcn_forward(h, xg[:nu], xg[nu:], k)
-            out.backward(gout)
-            res += [out.detach().clone(), xg.grad.clone()]
-            res.append(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), k, keep_layers=True)[0].clone())
-        res.append(rbg.ops.spmm_raw(h, x).clone())
-        acc = x.clone()
-        rbg.ops.spmm_raw(h, x, out=acc, accumulate=True)
-        res.append(acc)
-        res.append(rbg.ops.spmm_noise_raw(h, x, noise, 0.1).clone())
-        return res
-
-    names = set()
-    try:
-        assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<{W}, {d // W}, true, 1>"
-        base = run()
-        lay = _truth_layers(x64, rowptr, col, val, 3)
-        close(base[6], (x64 + lay[0] + lay[1] + lay[2]) / 4)
-        close(base[9], lay[0])
-        rbg.set_option("sell_stream", 1)
-        for wgs, fit, serial, sched in [(8, 0, -1, 1), (7, 0, -1, 1), (1, 0, -1, 1), (2, 1, -1, 0), (8, 1, 1, 0), (3, 0, 1, 1), (7, 0, -1, 0), (1, 0, -1, 0)]:
-            rbg.set_option("sell_stream_wgs", wgs)
-            rbg.set_option("sell_stream_fit", fit)
-            rbg.set_option("sell_stream_sched", sched)
-            rbg.set_option("sell_class_serial", serial)
-            names.add(h.propagation_kernel_name(d))
-            for j, (a, b) in enumerate(zip(run(), base)):
-                assert torch.equal(a, b), (wgs, fit, serial, sched, j, float((a - b).abs().max()))
-    finally:
-        rbg.set_option("sell_stream", 0)
-        rbg.set_option("sell_stream_sched", 1)
-        rbg.set_option("sell_stream_wgs", 8)
-        rbg.set_option("sell_stream_fit", 0)
-        rbg.set_option("sell_class_serial", -1)
-    assert names == {f"sell_stream_kernel<{W}, {d // W}, true, 8>", f"sell_stream_kernel<{W}, {d // W}, true, 7>"}
+        rbg.set_option("sell_factored", 1)
 
 
 @pytest.mark.parametrize("d", [32, 64, 128])
@@ -473,7 +420,7 @@ def test_a_borrowed_plan_outlives_its_views(rbg, cuda):
     want = O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rowptr, col, val * 0.5)
     assert v1.spmm_kernel_name(64).startswith("sell_")
     close(rbg.ops.spmm_raw(v1, x), want)
-    for call in (h.detach_sell, lambda: h.plan_sell(W=64), lambda: h.attach_sell(64, planner="spec")):
+    for call in (h.detach_sell, lambda: h.plan_sell(W=64), lambda: sell.attach(h, W=32)):
         with pytest.raises(RbgError) as ei:
             call()
         assert ei.value.code == RBG_EUNSUPPORTED and "view" in str(ei.value)
@@ -525,7 +472,7 @@ def test_every_allocation_of_the_plan_code_may_fail(rbg, cuda):
     scratch one allocation at a time; after every failure the handle propagates correctly (with the plan it still has, or the
     binned kernel) and is destroyed cleanly — r03's attach freed entc / rs without clearing them when the row-major twin failed
     (ADVICE r03, medium)."""
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     uid, iid, nu, ni = rbg.synth.make("toy")
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
     x = randn((nu + ni, 64), 3, cuda)
@@ -569,7 +516,7 @@ def test_every_allocation_of_the_plan_code_may_fail(rbg, cuda):
             h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
             rbg.set_option("fail_alloc_after", n)
             try:
-                h.attach_sell(64, planner="spec")
+                sell.attach(h, W=32)
             except rbg.RbgError:
                 pass
             rbg.set_option("sell_rowmajor", 0)  # (the backward then needs the per-handle slab scratch)
@@ -632,18 +579,13 @@ def test_parity_at_scale_through_the_plan(rbg, cuda, name):
     deg = np.diff(rowptr)
     rows = np.unique(np.concatenate([np.random.default_rng(0).integers(0, n, 4000), np.argsort(deg)[-50:], [0, nu, n - 1]]))
     scale = float(np.abs(ref).max())
-    try:
-        for serial in (0, 1):
-            rbg.set_option("sell_class_serial", serial)
-            mean, _ = rbg.ops.lightgcn_forward_raw(h, uw.to(cuda), iw.to(cuda), 3)
-            err = float(np.abs(mean.cpu().numpy().astype(np.float64) - ref).max())
-            assert err <= 1e-5 and err <= 1e-5 * scale, (serial, err, scale)  # absolute AND normalized
-            y = rbg.ops.spmm_raw(h, torch.from_numpy(e0.astype(np.float32)).to(cuda))
-            r1 = a[rows] @ e0
-            e1 = float(np.abs(y[torch.from_numpy(rows).to(cuda)].cpu().numpy() - r1).max())
-            assert e1 <= 1e-5 * max(float(np.abs(r1).max()), 1e-30) * 4 and e1 <= 1e-5, e1
-    finally:
-        rbg.set_option("sell_class_serial", -1)
+    mean, _ = rbg.ops.lightgcn_forward_raw(h, uw.to(cuda), iw.to(cuda), 3)
+    err = float(np.abs(mean.cpu().numpy().astype(np.float64) - ref).max())
+    assert err <= 1e-5 and err <= 1e-5 * scale, (err, scale)  # absolute AND normalized
+    y = rbg.ops.spmm_raw(h, torch.from_numpy(e0.astype(np.float32)).to(cuda))
+    r1 = a[rows] @ e0
+    e1 = float(np.abs(y[torch.from_numpy(rows).to(cuda)].cpu().numpy() - r1).max())
+    assert e1 <= 1e-5 * max(float(np.abs(r1).max()), 1e-30) * 4 and e1 <= 1e-5, e1
     # fixed point: A sqrt(deg) = sqrt(deg) on every non-isolated row, N(0, 1)-scale check of the gather
     root = torch.from_numpy(np.sqrt(deg.astype(np.float64)).astype(np.float32)).to(cuda)
     xr = root[:, None].expand(n, d).contiguous()

@@ -1,4 +1,4 @@
-"""The planner of the column-slab propagation (recbole-gnn_amd/sell.py) on CPU tensors: the plan alone must reproduce
+"""The planner of the column-slab propagation (tests/sell_spec.py, moved out of the product package in r05) on CPU tensors: the plan alone must reproduce
 Y = A X (float64 emulation of exactly the layout csrc/sell.hip reads), cover every entry once, keep wide rows aligned to
 four units, and pad with {K_PAST, 0}.  The kernel itself is checked on the GPU (tests/test_gpu_parity.py)."""
 import numpy as np
@@ -19,7 +19,7 @@ def _graph(rbg, name):
 @pytest.mark.parametrize("chunk", [4, 16, 64])
 @pytest.mark.parametrize("name", ["toy", "ml-100k"])
 def test_plan_reproduces_the_product(rbg, name, W, chunk):
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     uid, iid, nu, ni, rowptr, col, val = _graph(rbg, name)
     plan = sell.build_plan(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), nu, ni, W=W, chunk=chunk)
     n = nu + ni
@@ -52,7 +52,7 @@ def test_plan_reproduces_the_product(rbg, name, W, chunk):
 
 
 def test_plan_is_deterministic_and_matches_the_heaviest_first_order(rbg):
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     uid, iid, nu, ni, rowptr, col, val = _graph(rbg, "ml-100k")
     t = [torch.from_numpy(a) for a in (rowptr, col, val)]
     p1, p2 = sell.build_plan(*t, nu, ni, W=32), sell.build_plan(*t, nu, ni, W=32)
@@ -74,7 +74,7 @@ def test_plan_is_deterministic_and_matches_the_heaviest_first_order(rbg):
 def test_row_factors_are_found_for_the_symmetric_normalisation_only(rbg):
     """val_ij = r_i r_j with r = deg^-1/2 (dataset.py:41-79): the planner returns r in the plan's numbering, and nothing for
     values that do not factor (a re-weighted graph) — rbg_graph_sell_set_factors re-checks every value on the device."""
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     uid, iid, nu, ni, rowptr, col, val = _graph(rbg, "ml-100k")
     t = [torch.from_numpy(a) for a in (rowptr, col, val)]
     plan = sell.build_plan(*t, nu, ni, W=32)
@@ -94,7 +94,7 @@ def test_hub_row_limit_scales_with_the_graph(rbg):
     """A row is summed serially by 4 LGW lane-groups: beyond 4 LGW x max(MAX_PIECE, nnz / 8192) entries the planner says
     NotApplicable (the caller keeps the binned kernel, which splits hub rows over workgroups) — a 20 000-entry hub is refused
     in a small graph and planned in a large one."""
-    from recbole_gnn_amd import sell
+    import sell_spec as sell
     lgw = 8
     hub = sell.MAX_PIECE * 4 * lgw + 1000
     nu, ni = 400, hub + 10
