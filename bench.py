@@ -163,6 +163,56 @@ def cpu_baseline_torch_sparse(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
                       f"torch {torch.__version__} CPU, {torch.get_num_threads()} intra-op threads"}
 
 
+def measured_hbm_peak(dev):
+    """what this box's HBM delivers to a plain streaming kernel, beside the 8 TB/s of the data sheet — a device-side
+    stream triad a = b + s c and a device-to-device copy over 1 GiB arrays (4x the Infinity Cache), torch's own elementwise
+    kernels (plumbing: nothing of the product is measured here), best of 5 after 2 warm-ups, HIP events."""
+    n = 1 << 28  # floats: 1 GiB per array
+    try:
+        a, b, c = torch.empty(n, device=dev), torch.ones(n, device=dev), torch.ones(n, device=dev)
+    except RuntimeError as ex:  # noqa: BLE001
+        return {"error": str(ex)[:120]}
+
+    def best(fn, nbytes):
+        ts = []
+        for i in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ts.append(e0.elapsed_time(e1))
+        return nbytes / (min(ts) * 1e-3) / 1e9
+
+    out = {"triad_GBps": best(lambda: torch.add(b, c, alpha=0.5, out=a), 3 * 4 * n), "copy_GBps": best(lambda: a.copy_(b), 2 * 4 * n),
+           "array_GiB": 1.0, "how": "torch.add(b, c, alpha, out=a) and a.copy_(b) on 1 GiB fp32 arrays, best of 5, HIP events"}
+    del a, b, c
+    torch.cuda.empty_cache()
+    return out
+
+
+# The gather path's own ceiling (r05, devtools/microbench/gather_rate.hip -> profiles/r05_gather_rate.jsonl): random 128-byte row
+# gathers — the propagation's access pattern with nothing else of it — sustain one 1 KiB wave-load per 17-19 clocks per CU from an
+# L2-resident table (55-60 B/clk/CU, ~30 TB/s over the chip at 2.1 GHz), 53 clocks from a 16 MB table, 77 from HBM.  A layer gathers
+# nnz x d x 4 bytes through that path whatever the kernel does with them.
+GATHER_PATH_GBPS = 30_000.0
+
+
+def gather_path_cap(n, nnz, d, k_layers):
+    b_layer, _ = rbg_algorithmic_bytes(n, nnz, d, k_layers)
+    t_min = nnz * d * 4 / (GATHER_PATH_GBPS * 1e9)
+    return {"frac": b_layer / t_min / 1e9 / HBM_PEAK_GBPS, "layer_us_min": t_min * 1e6,
+            "basis": "a layer gathers nnz x d x 4 B of 128-byte rows through the vector memory path, which sustains ~30 TB/s of random row "
+                     "gathers from an L2-resident table (1 KiB per 17-19 clk per CU; profiles/r05_gather_rate.jsonl): the cap of ANY "
+                     "gather formulation at this shape; larger tables are capped lower (53 clk at 16 MB, 77 from HBM)"}
+
+
+def rbg_algorithmic_bytes(n, nnz, d, k_layers):
+    b_layer = 4 * (n + 1) + 8 * nnz + 8 * n * d
+    return b_layer, k_layers * b_layer + 4 * n * d * (k_layers + 2)
+
+
 def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     """Non-headline measurements on the same graph (each: median of 3 x 50 iterations, HIP events)."""
     def time_us(fn, iters=50, warm=5):
@@ -234,6 +284,18 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         iw_all = model.restore_item_e if model.restore_item_e is not None else model.forward()[1]
         uq = torch.randn(4096, d, device=dev)
         ex["score_gemm_us(4096 users x all items)"] = time_us(lambda: rbg.score(uq, iw_all), iters=20, warm=3)
+        bq = 4096
+        sc_bytes = 4 * (bq * d + ni * d + bq * ni)  # the scoring GEMM at d = 64 is bound by writing S
+        sc_us = ex["score_gemm_us(4096 users x all items)"]
+        ex["score_roofline"] = {"bound": "hbm", "bytes": sc_bytes, "achieved": sc_bytes / (sc_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                "frac": sc_bytes / (sc_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                "note": "bytes = 4 (B d + n d + B n): the [B, n] score matrix written once"}
+        tk_us = ex["full_sort_topk_us(4096 users, k 10, history masked)"]
+        tk_flop = 2.0 * bq * ni * d  # the product the top-k needs; it runs as 3 bf16 x bf16 products on split operands (fp32-grade)
+        ex["topk_roofline"] = {"bound": "mfma", "flop": tk_flop, "achieved": tk_flop / (tk_us * 1e-6) / 1e12, "peak": 2500.0 / 3, "unit": "TFLOP/s",
+                               "frac": tk_flop / (tk_us * 1e-6) / 1e12 / (2500.0 / 3),
+                               "note": "fp32-equivalent flops 2 B n d against a third of the dense bf16 MFMA peak (each product is three bf16 "
+                                       "MFMA products on split operands); writes nothing but [B, k]: the [B, n] matrix never exists"}
     t0 = time.perf_counter()
     rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
     torch.cuda.synchronize()
@@ -255,7 +317,11 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             traffic, l2_hit = traffic_from_profiles(name, dd, kern)
             key = name if dd == d else f"{name}:d{dd}"
             ex[key] = {"nodes": gn, "nnz": gg.nnz, "us": us, "frac": gb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
-                       "l2_hit": l2_hit, "algorithmic_bytes_per_layer": gb, "kernel": kern}
+                       "l2_hit": l2_hit, "algorithmic_bytes_per_layer": gb, "kernel": kern,
+                       # what the 0.1-0.2 is read against: the gather path's ceiling at an L2-resident table, and — with the fabric
+                       # traffic this kernel has at this shape — the fabric's 7.3 TB/s (profiles/traffic.json, DESIGN results log 6.10)
+                       "cap": {"gather_path_frac": gather_path_cap(gn, gg.nnz, dd, k_layers)["frac"],
+                               "fabric_frac": (gb / (traffic / 7.3e12) / 1e9 / HBM_PEAK_GBPS) if traffic else None}}
             go, gl = torch.empty(gn, dd, device=dev), torch.empty(max(k_layers, 1), gn, dd, device=dev)
             pus = time_us(lambda: rbg.ops.lightgcn_forward_raw(gg, gx[:gnu], gx[gnu:], k_layers, out=go, layers=gl),
                           iters=5 if big else 20, warm=1 if big else 3)
@@ -948,6 +1014,12 @@ def main():
                                  "the kernel; rocprofv3's per-instantiation averages are in profiles/r04_bench_kernel_stats.csv"},
             "cpu_baseline": None,
         }
+        if world == 1:
+            pk = measured_hbm_peak(dev)
+            result["roofline"]["peak_measured"] = pk
+            if pk.get("triad_GBps"):
+                result["roofline"]["frac_of_measured"] = achieved / pk["triad_GBps"]
+            result["roofline"]["cap"] = gather_path_cap(nu + ni, graph.nnz, d, k_layers)
         result.update(extra)
         if world > 1 and args.shard == "columns" and isinstance(extra.get("column_sharding"), dict) and extra["column_sharding"].get("value"):
             cs_ = extra["column_sharding"]  # the column-sharded propagation becomes the headline, the node-range one is kept beside it

@@ -109,6 +109,14 @@ class BPRSampler:
         neg = draw()
         for _ in range(self.ROUNDS):
             neg = torch.where(self._is_positive(users, neg), draw(), neg)
+        # ROUNDS fixed redraws leave a positive with probability (degree / n_items)^(ROUNDS + 1) per draw: ~1e-25 at Gowalla's density,
+        # but not on a dense dataset with heavy users.  One check per epoch (one host sync) and a loop for what is left: like the host
+        # path and the reference's sampler, every returned item is a true negative.
+        bad = self._is_positive(users, neg)
+        while bool(bad.any()):
+            idx = bad.nonzero(as_tuple=True)[0]
+            neg[idx] = torch.randint(1, self.n_items, idx.shape, generator=self.gen, device=self.device)
+            bad = self._is_positive(users, neg)
         return neg
 
     def __iter__(self):
@@ -228,7 +236,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
     NGCF / SGL models use their autograd-free step (``train.fused_stepper``; ``fused=False`` forces the autograd path, whose
     gradients the fused steps are tested against); any other model goes through torch autograd + torch.optim.Adam, the
     whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly;
-    models whose loss has data-dependent shapes — SimGCL, XSimGCL — always run eagerly).  Batches come from ``BPRSampler`` on
+    SimGCL and XSimGCL are captured too since r04: their contrastive batches are masked, not ``unique``-d, on the device).  Batches come from ``BPRSampler`` on
     the model's GPU (``device_sampler``; False = the numpy sampler)."""
     on_gpu = next(model.parameters()).is_cuda
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed,

@@ -369,7 +369,9 @@ class ShardedPropagation:
     Which is faster depends on the machine: on one GPU with a world-size-1 RCCL group (r01, devtools/nccl1_probe.py) the
     second stream cost ~35 us of cross-stream event latency per layer and hid nothing (there was no link time to hide:
     325 vs 259 us per propagation); with real peers the single-stream layer exposes the whole collective.  ``autotune``
-    measures both on the actual group and keeps the faster.  Default (``overlap=None``): on under "nccl" with more than one rank.
+    measures both on the actual group and keeps the faster (``bench.py --gpus N`` does).  Default (``overlap=None``): the single-stream
+    layer — the overlapped form has never run between different GPUs (no multi-GPU box in five rounds: ADVICE r04), so it is
+    an explicit choice (``overlap=True`` / ``set_overlap``) or autotune's, not a default.
 
     r04: the INTERIOR block (square, user rows then item rows, bipartite) is planned by ``rbg_graph_create_csr_classes`` like any
     other handle and runs the column-slab kernel at d = 32 / 64 / 128; the rectangular halo block stays on the binned kernel.
@@ -382,10 +384,9 @@ class ShardedPropagation:
         return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
 
     def __init__(self, plan, backend, group=None, transport="nccl", overlap=None):
-        # overlap = None (default): on with real peers under the RCCL transport (the exchange hides behind the interior product),
-        # off otherwise (a one-rank group has no link time to hide: r01); ``autotune`` still measures both on the actual group
+        # overlap = None (default): off — unmeasured between real peers; ``autotune`` measures both forms on the actual group
         if overlap is None:
-            overlap = transport == "nccl" and plan.world > 1
+            overlap = False
         self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev

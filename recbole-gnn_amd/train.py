@@ -123,6 +123,7 @@ class _FusedStep:
     def _init_graphed(self, graphed):
         self.graphed = bool(graphed)
         self._graph, self._static, self._calls, self._key = None, None, 0, None
+        self._full = 0  # the batch size the graph is captured for: the largest seen so far (an epoch's last batch is shorter)
 
     def _handles(self):
         return (self.model.graph,)
@@ -141,9 +142,15 @@ class _FusedStep:
         key = tuple(id(h) for h in self._handles())
         if self._graph is not None and key != self._key:
             self._graph, self._calls = None, 1  # new views: their plans exist, one eager step re-warms
+        if self._graph is not None and user.shape[0] > self._full:  # (a larger batch than the captured one: capture again for it)
+            self._graph, self._calls = None, 1
+        self._full = max(self._full, int(user.shape[0]))
         if self._graph is None:
             self._calls += 1
-            if self._calls <= 2:
+            # warm-up steps — and any batch that is not of the full size (with three or fewer batches per epoch the
+            # third call could be the epoch's short last batch; the graph would then have been captured for the odd size and every
+            # full batch would have run eagerly for ever) — run eagerly on a side stream; the capture waits for a full batch
+            if self._calls <= 2 or user.shape[0] < self._full:
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
@@ -156,8 +163,12 @@ class _FusedStep:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._enqueue(*self._static)
-        if user.shape != self._static[0].shape:  # (an epoch's last, shorter batch: the same launches, not replayed)
-            self._enqueue(user, pos, neg)
+        if user.shape != self._static[0].shape:  # (an epoch's last, shorter batch: the same launches, not replayed —
+            side = torch.cuda.Stream(device=dev)  # on a side stream like the warm-up steps: its scratch is not the graph's)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._enqueue(user, pos, neg)
+            torch.cuda.current_stream(dev).wait_stream(side)
             return self.loss
         for dst, src in zip(self._static, (user, pos, neg)):
             dst.copy_(src)

@@ -139,20 +139,28 @@ def test_config3_ngcf_yelp2018_shape(rbg, cuda):
 
 # ---- #4 -------------------------------------------------------------------------------------------------------------
 
-def _shard_worker(rank, world, port, k_layers, d, out_q):
+def _shard_worker(rank, world, port, k_layers, d, out_q, peers=False):
     import sys
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # peers: one rank per GPU, halos over RCCL; else the ranks share cuda:0 and exchange through the host
+    dev = torch.device(f"cuda:{rank}" if peers else "cuda:0")
+    torch.cuda.set_device(dev)
+    if peers:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        gloo = dist.new_group(backend="gloo")
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        gloo = None
     try:
         import recbole_gnn_amd as rbg
         sh = rbg.sharded
-        dev = torch.device("cuda:0")
         uid, iid, nu, ni = rbg.synth.make("amazon-book")
         plan = sh.build_plans(uid, iid, nu, ni, world, ranks=[rank])[rank]  # default partition: nnz-balanced node ranges
         e0 = np.random.default_rng(1).standard_normal((nu + ni, d)).astype(np.float32)
-        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="staged")
+        prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="nccl" if peers else "staged")
         mean_local = prop.forward(torch.from_numpy(e0[plan.owned]).to(dev), k_layers)
         torch.cuda.synchronize()
         err = None
@@ -160,31 +168,38 @@ def _shard_worker(rank, world, port, k_layers, d, out_q):
             rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
             ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)
             np.save(os.path.join("/tmp", f"rbg_cfg4_ref_{port}.npy"), ref)
-        dist.barrier()
+        dist.barrier(group=gloo)
         ref = np.load(os.path.join("/tmp", f"rbg_cfg4_ref_{port}.npy"), mmap_mode="r")
         err = float(np.abs(mean_local.cpu().numpy() - ref[plan.owned]).max())
         scale = float(np.abs(ref).max())
         gathered = [None] * world
-        dist.all_gather_object(gathered, (rank, err, scale, plan.n_owned, plan.n_halo, int(plan.n_users_owned)))
+        dist.all_gather_object(gathered, (rank, err, scale, plan.n_owned, plan.n_halo, int(plan.n_users_owned)), group=gloo)
         if rank == 0:
             out_q.put(gathered)
-            dist.barrier()
+            dist.barrier(group=gloo)
             os.remove(os.path.join("/tmp", f"rbg_cfg4_ref_{port}.npy"))
         else:
-            dist.barrier()
+            dist.barrier(group=gloo)
     finally:
         dist.destroy_process_group()
 
 
-def test_config4_lightgcn_amazon_book_shape_four_ranks():
+_N_DEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
+_CFG4_MODE = "rccl-one-rank-per-gpu" if _N_DEV >= 4 else "staged-ranks-share-cuda0"
+
+
+@pytest.mark.parametrize("mode", [pytest.param(_CFG4_MODE, id=f"{_N_DEV}gpus-{_CFG4_MODE}")])
+def test_config4_lightgcn_amazon_book_shape_four_ranks(mode):
     """lightgcn.py:70-81 node-range sharded over 4 ranks on the Amazon-Book shape (52 644 / 91 600 / 2 984 108), 64-d, 3
-    layers: every rank's rows of the mean embedding against the single-process oracle forward.  The test box has one GPU:
-    the 4 processes share cuda:0 and exchange halos through the host (gloo); every kernel of the multi-GPU path runs."""
+    layers: every rank's rows of the mean embedding against the single-process oracle forward.  On a box with >= 4 GPUs (decided
+    at collection time, visible in the test id) every rank owns a GPU and the halos travel over RCCL; on the one-GPU test box the
+    4 processes share cuda:0 and exchange halos through the host (gloo) — every kernel of the multi-GPU path runs either way."""
     world = 4
+    peers = mode.startswith("rccl")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 33000 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, 3, 64, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, 3, 64, q, peers)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=900)

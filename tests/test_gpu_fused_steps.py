@@ -336,6 +336,9 @@ def test_a_graph_handle_dying_inside_a_capture_does_not_invalidate_it(rbg, cuda,
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
     x = torch.ones(16, device=cuda)
+    gc.collect()  # (earlier tests' dead cycles must not die inside THIS capture and be counted below)
+    G.flush_parked()
+    assert len(G._PARKED) == 0
     a = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
     b = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
     a._transpose, b._transpose = b, a  # a cycle: only the collector frees the pair

@@ -545,3 +545,124 @@ def test_ranks_column_sharded_training_step_hip_backend(ref_inter, world, d):
         assert abs(loss - ref) <= 1e-5 * max(1.0, abs(ref)), (rank, loss, ref)
         assert oerr <= 1e-5 and gerr <= 1e-5 * max(1.0, gscale) and serr <= 1e-5, (rank, oerr, gerr, serr)
         assert abs(v0 - loss) <= 1e-6 * max(1.0, abs(loss)) and v1 < v0, (rank, v0, v1)
+
+
+# ---- real peers: one rank per GPU over RCCL, whenever the box has more than one ------------------------------------
+# Every test above runs on ONE GPU (ranks sharing cuda:0 over the host-staged transport, RCCL on one-rank communicators).  The
+# tests below size themselves on torch.cuda.device_count() at collection time: with n >= 2 devices they run worlds 2, 4, 8 (<= n)
+# with one rank per device, transport "nccl" — both the torch.distributed path (ShardedPropagation: all_to_all_single, single
+# stream and overlapped on the comm stream) and the C-ABI path (rbg_comm_create + rbg_graph_create_sharded: library-issued grouped
+# ncclSend / ncclRecv) —, forward + backward + one sharded training step against the single-process oracle / model mirror.  With
+# one device they report a skip that names the device count, and the single-GPU tests above are what ran.
+
+_N_DEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
+_PEER_WORLDS = [w for w in (2, 4, 8) if w <= _N_DEV] or [0]
+_PEER_IDS = [f"{_N_DEV}gpus-world{w}" if w else f"{_N_DEV}gpu-no-peers" for w in _PEER_WORLDS]
+
+
+def _peers_worker(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device(f"cuda:{rank}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    gloo = dist.new_group(backend="gloo")
+    try:
+        import recbole_gnn_amd as rbg
+        from recbole_gnn_amd import sharded_train as st
+        sh = rbg.sharded
+        n = nu + ni
+        rng = np.random.default_rng(1)
+        e0 = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+        w = rng.standard_normal((n, d)).astype(np.float32)
+        owner = sh.degree_striped_partition(uid, iid, nu, ni, world)
+        plan = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank])[rank]
+        rp, cc, vv = C.build_norm_csr(uid, iid, nu, ni)
+        ref = C.lightgcn_forward(rp, cc, vv, e0[:nu], e0[nu:], k_layers)
+        gref = C.lightgcn_forward(rp, cc, vv, w[:nu], w[nu:], k_layers)  # the operator is symmetric: d<w, M e0>/d e0 = M w
+        out = {"device": torch.cuda.get_device_name(dev), "n_halo": int(plan.n_halo)}
+        # 1. torch.distributed path, both stream structures
+        means = {}
+        for overlap in (False, True):
+            prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="nccl", overlap=overlap)
+            x = torch.from_numpy(e0[plan.owned]).to(dev).requires_grad_(True)
+            for _ in range(2):  # buffers are reused: the second call must give the same result
+                mean = sh.sharded_lightgcn_forward(prop, x, k_layers)
+            (mean * torch.from_numpy(w[plan.owned]).to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            means[overlap] = mean.detach().clone()
+            out[f"dist_overlap{int(overlap)}"] = (float(np.abs(mean.detach().cpu().numpy() - ref[plan.owned]).max()),
+                                                  float(np.abs(x.grad.cpu().numpy() - gref[plan.owned]).max()))
+        out["overlap_bit_identical"] = bool(torch.equal(means[False], means[True]))
+        # 2. the C-ABI path: the library's own communicator (the id travels through the gloo group)
+        ids = [sh.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, group=gloo)
+        shard = sh.RcclShard(plan, ids[0], dev, nranks=world, rank=rank, d_max=d)
+        xo = torch.from_numpy(e0[plan.owned]).to(dev)
+        y = shard.spmm(xo)
+        got = shard.forward(xo, k_layers)
+        torch.cuda.synchronize()
+        out["cabi"] = (float(np.abs(y.cpu().numpy() - C.spmm(rp, cc, vv, e0)[plan.owned]).max()),
+                       float(np.abs(got.cpu().numpy() - ref[plan.owned]).max()))
+        dist.barrier(group=gloo)
+        shard.close()
+        # 3. one sharded LightGCN training step against the single-device model mirror (on this rank's own GPU)
+        b = 256
+        user, pos, neg = rng.integers(1, nu, b), rng.integers(1, ni, b), rng.integers(1, ni, b)
+        ds = rbg.InteractionDataset(uid, iid, nu, ni)
+        inter = {"user_id": torch.from_numpy(user).to(dev), "item_id": torch.from_numpy(pos).to(dev), "neg_item_id": torch.from_numpy(neg).to(dev)}
+        model = rbg.LightGCN({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-3,
+                              "require_pow": False}, ds)
+        with torch.no_grad():
+            model.user_embedding.weight.copy_(torch.from_numpy(e0[:nu]))
+            model.item_embedding.weight.copy_(torch.from_numpy(e0[nu:]))
+        ref_loss = model.calculate_loss(inter)
+        ref_loss.backward()
+        ref_grad = torch.cat([model.user_embedding.weight.grad, model.item_embedding.weight.grad]).cpu().numpy()
+        tr = st.ShardedTrainer(plan, sh.HipBackend(dev), torch.from_numpy(e0[plan.owned]).to(dev), nu, ni, k_layers, transport="nccl",
+                               lr=1e-2, reg_weight=1e-3)
+        loss = tr.loss(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        loss.backward()
+        torch.cuda.synchronize()
+        gerr = float(np.abs(tr.e0.grad.cpu().numpy() - ref_grad[plan.owned]).max())
+        v0 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        v1 = tr.step(inter["user_id"], inter["item_id"], inter["neg_item_id"])
+        out["train"] = (float(loss.detach()), float(ref_loss.detach()), gerr, float(np.abs(ref_grad).max()), v0, v1)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, out), group=gloo)
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", _PEER_WORLDS, ids=_PEER_IDS)
+def test_real_peers_over_rccl(world, ref_inter):
+    if world == 0:
+        pytest.skip(f"{_N_DEV} GPU on this box: exchanges between different devices run when device_count() >= 2 "
+                    "(the shared-GPU staged tests and the one-rank RCCL tests above are what ran)")
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 38000 + (os.getpid() % 1500) + world
+    procs = [ctx.Process(target=_peers_worker, args=(r, world, port, uid, iid, nu, ni, 3, 64, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert len(res) == world
+    for rank, out in res:
+        assert out["n_halo"] > 0, (rank, out)
+        for key in ("dist_overlap0", "dist_overlap1"):
+            err, gerr = out[key]
+            assert err <= 1e-5 and gerr <= 1e-5, (rank, key, out[key])
+        assert out["overlap_bit_identical"], rank
+        assert max(out["cabi"]) <= 1e-5, (rank, out["cabi"])
+        loss, ref, gerr, scale, v0, v1 = out["train"]
+        assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)) and gerr <= 1e-5 * max(1.0, scale), (rank, out["train"])
+        assert abs(v0 - loss) <= 1e-6 * max(1.0, abs(loss)) and v1 < v0, (rank, v0, v1)
