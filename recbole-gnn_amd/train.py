@@ -361,16 +361,195 @@ class FusedSGLAdam(_FusedStep):
             self.table_opt.step(self.ge[0])
 
 
+class _FusedContrastStep(_FusedStep):
+    """What the SimGCL / XSimGCL steps share: buffers over the [N, d] table, the perturbed pass (simgcl.py:25-36: one
+    ``rbg_spmm_noise_f32`` per layer on a fresh ``uniform_`` draw — the draws of ``torch.rand_like`` in the reference's order, so a
+    model trained by the autograd path from the same seed sees the same noise), the contrast on the batch's gathered rows
+    (``rbg_infonce_masked_f32`` with the one-occurrence mask: simgcl.py:38-57 over ``torch.unique`` without its data-dependent
+    shape) and the backward chain.  sign() has no gradient, so a perturbed layer's backward is the plain product — and EVERY
+    chain of a step is the same linear map of its incoming gradient: the gradients are summed first and ONE chain runs (autograd
+    runs one per propagation)."""
+
+    def _common_init(self, model, cls, lr, betas, eps, graphed):
+        from .models import BPRLoss
+        if not (type(model) is cls and isinstance(model.graph, ops.GraphHandle) and model.static_unique
+                and model.user_embedding.weight.shape[1] <= 128 and model.user_embedding.weight.shape[1] % 4 == 0
+                and type(model.mf_loss) is BPRLoss and model.mf_loss.gamma == 1e-10 and len(list(model.parameters())) == 2):
+            raise TypeError(f"{type(self).__name__} drives a plain {cls.__name__} model (static_unique form) on a device graph handle, "
+                            "embedding width <= 128 and a multiple of 4")
+        self.model = model
+        self._init_graphed(graphed)
+        dev, nu = model.device, model.n_users
+        n, d, k = nu + model.n_items, model.user_embedding.weight.shape[1], max(model.n_layers, 1)
+        f = dict(dtype=torch.float32, device=dev)
+        self.e0 = torch.empty((n, d), **f)
+        self.noise = torch.empty((n, d), **f)
+        self.gm = torch.empty((n, d), **f)     # dLoss / d(mean of the pass the BPR term reads); ends as the chain's input
+        self.ge = torch.empty((n, d), **f)     # dLoss / dE0
+        self.t0, self.t1, self.work = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
+        self.loss, self.reg_ws = torch.zeros((), **f), torch.zeros(3, **f)
+        self._scratch = {}
+        self.table_opt = _TableAdam(model, lr, betas, eps)
+        model.user_embedding.weight.grad = self.ge[:nu]  # (for inspection; the tables are updated from ge directly)
+        model.item_embedding.weight.grad = self.ge[nu:]
+        return n, d, k, f
+
+    @staticmethod
+    def _ptr(t):
+        return c_vp(t.data_ptr())
+
+    def _mean_of(self, layers, k, out):
+        srcs = (c_vp * k)(*[layers[i].data_ptr() for i in range(k)])
+        check(lib.rbg_mean_f32(srcs, k, out.numel(), 1.0 / k, self._ptr(out), c_vp(torch.cuda.current_stream(out.device).cuda_stream)))
+
+    def _perturbed_pass(self, layers, k):
+        m, st = self.model, c_vp(torch.cuda.current_stream(self.model.device).cuda_stream)
+        x = self.e0
+        for i in range(k):
+            self.noise.uniform_()  # (= torch.rand_like: the same draws in the same order as SimGCL._layers)
+            check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(self.noise), x.shape[1], float(m.eps), st))
+            x = layers[i]
+
+    def _contrast(self, ta, tb, ga, gb, ids, row0, rows, b, mean_form):
+        """cl_rate x InfoNCE between rows `ids` of tables ta and tb (rows [row0, row0 + rows) of the [N, d] buffers): the value is
+        added to self.loss, the gradients w.r.t. the two tables' rows are scattered onto ga / gb (either may be the same buffer)."""
+        from .models import _once_mask
+        m = self.model
+        d = ta.shape[1]
+        st = c_vp(torch.cuda.current_stream(m.device).cuda_stream)
+        if b not in self._scratch:
+            nbytes = _lib.c_i64()
+            check(lib.rbg_infonce_workspace(b, b, d, _lib.ctypes.byref(nbytes)))
+            self._scratch[b] = (torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device), torch.arange(b, device=m.device))
+        work, ar = self._scratch[b]
+        once = _once_mask(ids).to(torch.float32)
+        row_w = once / once.sum() if mean_form else once  # (xsimgcl.py:54: a mean over the distinct ids)
+        xa, xb = ta[row0:row0 + rows].index_select(0, ids), tb[row0:row0 + rows].index_select(0, ids)
+        gxa, gxb = torch.zeros_like(xa), torch.zeros_like(xb)
+        check(lib.rbg_infonce_masked_f32(self._ptr(xa), self._ptr(xb), b, d, self._ptr(ar), b, float(m.temperature), float(m.cl_rate),
+                                         self._ptr(row_w), self._ptr(once), self._ptr(self.loss), self._ptr(gxa), self._ptr(gxb), self._ptr(work), st))
+        # (rows of a repeated id carry zero weight but one: the scatter's float atomics add zeros — deterministic)
+        ga[row0:row0 + rows].index_add_(0, ids, gxa)
+        gb[row0:row0 + rows].index_add_(0, ids, gxb)
+
+    def _reg_and_adam(self, user, pos, neg, b, d):
+        m = self.model
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        st = c_vp(torch.cuda.current_stream(m.device).cuda_stream)
+        p = self._ptr
+        if m.require_pow:
+            check(lib.rbg_emb_reg_grad_f32(p(uw), p(iw), m.n_users, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge), p(self.loss), st))
+        else:
+            check(lib.rbg_emb_reg_grad_nopow_f32(p(uw), p(iw), m.n_users, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge),
+                                                 p(self.loss), p(self.reg_ws), st))
+        self.table_opt.step(self.ge)
+
+
+class FusedSimGCLAdam(_FusedContrastStep):
+    """SimGCL's training step (simgcl.py:45-61 + ``loss.backward()`` + Adam) as library calls, no autograd: the plain pass (K
+    products, mean of layers 1..K), two perturbed passes, BPR + EmbLoss, the two contrasts, ONE backward chain for the three
+    passes' summed gradients (K products), Adam on the two tables in one launch.  ``graphed=True`` replays it from a HIP graph."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
+        from .models import SimGCL
+        n, d, k, f = self._common_init(model, SimGCL, lr, betas, eps, graphed)
+        self.lay = [torch.empty((k, n, d), **f) for _ in range(3)]   # the plain pass, the two perturbed ones
+        self.mean = [torch.empty((n, d), **f) for _ in range(3)]
+        self.g12 = torch.empty((n, d), **f)                           # d(contrast) / d(mean of pass 1) + / d(mean of pass 2)
+
+    def _enqueue(self, user, pos, neg):
+        m = self.model
+        dev, nu, ni, b, k = m.device, m.n_users, m.n_items, user.shape[0], m.n_layers
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        d = uw.shape[1]
+        st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
+        p = self._ptr
+        with torch.cuda.device(dev):
+            torch.cat([uw, iw], dim=0, out=self.e0)
+            # simgcl.py:25-36 without noise: E_1 .. E_K row-major, their mean (no E_0)
+            ops.lightgcn_forward_raw(m.graph, uw, iw, k, keep_layers=True, out=self.work, layers=self.lay[0])
+            self._mean_of(self.lay[0], k, self.mean[0])
+            for v in (1, 2):
+                self._perturbed_pass(self.lay[v], k)
+                self._mean_of(self.lay[v], k, self.mean[v])
+            # lightgcn.py:93-100 on the plain pass (zeroes gm and the loss), then the contrasts between the perturbed passes
+            check(lib.rbg_bpr_grad_f32(p(self.mean[0]), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
+            self.g12.zero_()
+            # (the gradients w.r.t. the two perturbed means go through the same linear chain: they are added into ONE buffer)
+            self._contrast(self.mean[1], self.mean[2], self.g12, self.g12, user, 0, nu, b, False)
+            self._contrast(self.mean[1], self.mean[2], self.g12, self.g12, pos, nu, ni, b, False)
+            self.gm.add_(self.g12)
+            # out = (A + A^2 + .. + A^K) E0 / K for every pass  =>  dE0 = A (g + A g + .. + A^(K-1) g) / K
+            if k > 1:
+                arr = (c_vp * 1)(m.graph.transpose().ptr)
+                check(lib.rbg_lightgcn_backward_f32(arr, 1, p(self.gm), p(self.t0), p(self.work), d, k - 1, st))
+                src = self.t0
+            else:
+                src = self.gm
+            check(lib.rbg_spmm_f32(m.graph.transpose().ptr, p(src), p(self.ge), d, 0, st))
+            self._reg_and_adam(user, pos, neg, b, d)
+
+
+class FusedXSimGCLAdam(_FusedContrastStep):
+    """XSimGCL's training step (xsimgcl.py:56-90 + backward + Adam) as library calls, no autograd: ONE perturbed pass serves the
+    BPR term (its layer mean) and the contrast between that mean and the embedding after layer ``layer_cl``; the backward is one
+    Horner chain with the contrast's second gradient injected at that layer."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
+        from .models import XSimGCL
+        n, d, k, f = self._common_init(model, XSimGCL, lr, betas, eps, graphed)
+        self.lay = torch.empty((k, n, d), **f)
+        self.mean = torch.empty((n, d), **f)
+        self.gcl = torch.empty((n, d), **f)  # d(contrast) / d(the layer_cl embedding)
+
+    def _enqueue(self, user, pos, neg):
+        m = self.model
+        dev, nu, ni, b, k = m.device, m.n_users, m.n_items, user.shape[0], m.n_layers
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        d = uw.shape[1]
+        st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
+        p = self._ptr
+        lc = m.layer_cl if 1 <= m.layer_cl <= k else 0  # 0: the contrast's second view is E_0 itself (xsimgcl.py:29, 39-41)
+        with torch.cuda.device(dev):
+            torch.cat([uw, iw], dim=0, out=self.e0)
+            self._perturbed_pass(self.lay, k)
+            self._mean_of(self.lay, k, self.mean)
+            cl = self.lay[lc - 1] if lc else self.e0
+            check(lib.rbg_bpr_grad_f32(p(self.mean), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
+            self.gcl.zero_()
+            self._contrast(self.mean, cl, self.gm, self.gcl, user, 0, nu, b, True)
+            self._contrast(self.mean, cl, self.gm, self.gcl, pos, nu, ni, b, True)
+            # mean = (E_1 + .. + E_K) / K, E_j = A E_(j-1) (+ noise, no gradient): dE0 = A (g_1 + A (g_2 + .. A g_K)), g_j = gm / K
+            # (+ gcl at j = layer_cl); Horner from the top layer down
+            gt = m.graph.transpose().ptr
+            torch.mul(self.gm, 1.0 / k, out=self.gm)
+            cur, nxt = self.t0, self.t1
+            cur.copy_(self.gm)
+            if lc == k:
+                cur.add_(self.gcl)
+            for j in range(k - 1, 0, -1):
+                nxt.copy_(self.gm)
+                if lc == j:
+                    nxt.add_(self.gcl)
+                check(lib.rbg_spmm_f32(gt, p(cur), p(nxt), d, 1, st))  # nxt += A cur
+                cur, nxt = nxt, cur
+            check(lib.rbg_spmm_f32(gt, p(cur), p(self.ge), d, 0, st))
+            if lc == 0:
+                self.ge.add_(self.gcl)
+            self._reg_and_adam(user, pos, neg, b, d)
+
+
 def fused_stepper(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=True):
     """The autograd-free training step of `model` if this package has one — ``FusedBPRAdam`` (plain LightGCN),
-    ``FusedNGCFAdam`` (plain NGCF, fused layers, widths <= 128), ``FusedSGLAdam`` (plain SGL, d <= 128), all on device graph
-    handles — else None (``GraphedStep`` / an eager loop serve every other model).  ``graphed`` applies to the latter two."""
-    from .models import NGCF, SGL
+    ``FusedNGCFAdam`` (plain NGCF, fused layers, widths <= 128), ``FusedSGLAdam`` (plain SGL, d <= 128), ``FusedSimGCLAdam`` /
+    ``FusedXSimGCLAdam`` (their ``static_unique`` form), all on device graph handles — else None (``GraphedStep`` / an eager loop
+    serve every other model).  ``graphed`` applies to all but the first."""
+    from .models import NGCF, SGL, SimGCL, XSimGCL
     if not next(model.parameters()).is_cuda:
         return None
     if fused_step_applies(model) and isinstance(model.graph, ops.GraphHandle):
         return FusedBPRAdam(model, lr=lr, betas=betas, eps=eps)
-    for cls, step in ((NGCF, FusedNGCFAdam), (SGL, FusedSGLAdam)):
+    for cls, step in ((NGCF, FusedNGCFAdam), (SGL, FusedSGLAdam), (SimGCL, FusedSimGCLAdam), (XSimGCL, FusedXSimGCLAdam)):
         if type(model) is cls:
             try:
                 return step(model, lr=lr, betas=betas, eps=eps, graphed=graphed)

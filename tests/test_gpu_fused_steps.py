@@ -431,3 +431,71 @@ def test_a_graph_handle_dying_while_another_stream_captures(rbg, cuda, golden):
     gr.replay()
     torch.cuda.synchronize()
     assert float(z.sum()) == 48.0
+
+
+# ---- SimGCL / XSimGCL (r05) --------------------------------------------------------------------------------------------------
+
+def _contrastive(rbg, cuda, golden, kind, **cfg):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    torch.manual_seed(4)
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3, "enable_sparse": True, "reg_weight": 1e-3, "lambda": 0.3,
+              "eps": 0.15, "temperature": 0.2}
+    config.update(cfg)
+    return getattr(rbg, kind)(config, ds)
+
+
+@pytest.mark.parametrize("kind,cfg", [("SimGCL", {}), ("SimGCL", {"n_layers": 1, "require_pow": True}), ("XSimGCL", {"layer_cl": 1}),
+                                      ("XSimGCL", {"layer_cl": 3}), ("XSimGCL", {"layer_cl": 0, "n_layers": 2})])
+def test_fused_contrastive_step_takes_the_autograd_step(rbg, cuda, golden, kind, cfg):
+    """train.FusedSimGCLAdam / FusedXSimGCLAdam (simgcl.py:45-61, xsimgcl.py:56-90 + backward + Adam as library calls: the
+    perturbed passes by rbg_spmm_noise_f32, the contrasts by rbg_infonce_masked_f32 on the batch's rows, ONE backward chain for
+    all passes) against the model mirror's autograd step on the same parameters, batches (with repeated ids) and noise draws."""
+    model, twin = _contrastive(rbg, cuda, golden, kind, **cfg), _contrastive(rbg, cuda, golden, kind, **cfg)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    stepper = rbg.fused_stepper(model, lr=1e-3, graphed=False)
+    assert type(stepper).__name__ == f"Fused{kind}Adam"
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    total = lambda l: sum(l) if isinstance(l, tuple) else l  # noqa: E731  (XSimGCL returns its three terms, xsimgcl.py:90)
+    for step_no, batch in enumerate(_batches(golden, cuda, 3, 96)):
+        batch["user_id"][:7] = batch["user_id"][7:14]  # repeated ids: the one-occurrence mask matters
+        batch["item_id"][:5] = batch["item_id"][5:10]
+        torch.manual_seed(200 + step_no)  # the same noise draws on both sides (simgcl.py:31)
+        lf = float(stepper.step(batch))
+        torch.manual_seed(200 + step_no)
+        opt.zero_grad(set_to_none=True)
+        le = total(twin.calculate_loss(batch))
+        le.backward()
+        ref = float(le.detach())
+        if step_no == 0:
+            assert abs(lf - ref) <= 5e-6 * max(1.0, abs(ref)), (lf, ref)
+            for (name, pf), pe in zip(model.named_parameters(), twin.parameters()):
+                scale = max(float(pe.grad.abs().max()), 1e-12)
+                assert float((pf.grad - pe.grad).abs().max()) <= 2e-5 * scale, name
+        opt.step()
+        assert abs(lf - ref) <= 2e-4 * max(1.0, abs(ref)), (step_no, lf, ref)
+    for pf, pe in zip(model.parameters(), twin.parameters()):
+        assert float((pf.detach() - pe.detach()).abs().max()) <= 1e-4 * max(1.0, float(pe.detach().abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["SimGCL", "XSimGCL"])
+def test_fused_contrastive_step_replayed_from_a_hip_graph(rbg, cuda, golden, kind):
+    """graphed=True: the step is captured on its third full batch and replayed; the noise advances with every replay (the
+    generator's offset is part of the captured graph), a short batch runs eagerly and shares the optimizer state."""
+    model = _contrastive(rbg, cuda, golden, kind)
+    model.train()
+    a = rbg.fused_stepper(model, lr=1e-3, graphed=True)
+    losses = []
+    for n, batch in enumerate(_batches(golden, cuda, 8, 64)):
+        if n == 5:
+            batch = {k: v[:23] for k, v in batch.items()}
+        losses.append(float(a.step(batch)))
+    assert a._graph is not None and all(np.isfinite(x) for x in losses)
+    same = [float(a.step(_batches(golden, cuda, 1, 64)[0])) for _ in range(2)]
+    assert same[0] != same[1]  # (new noise and new parameters every replay)
+    with pytest.raises(TypeError):
+        rbg.FusedSimGCLAdam(_contrastive(rbg, cuda, golden, "XSimGCL"))
+    with pytest.raises(TypeError):
+        rbg.FusedXSimGCLAdam(_contrastive(rbg, cuda, golden, "SimGCL"))
+    assert rbg.fused_stepper(_contrastive(rbg, cuda, golden, "SimGCL", static_unique=False)) is None
