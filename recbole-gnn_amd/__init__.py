@@ -12,7 +12,7 @@ from .graph import (GraphHandle, InteractionDataset, device_count, find_communit
 from .models import NCL, NGCF, SGL, GeneralGraphRecommender, LightGCN, SimGCL, XSimGCL  # noqa: F401
 from .ops import BiGNNConv, LightGCNConv, full_sort_topk, gather_rows, lightgcn_forward, score, spmm  # noqa: F401
 
-from .train import (FusedBPRAdam, FusedNGCFAdam, FusedSGLAdam, FusedSimGCLAdam, FusedXSimGCLAdam, GraphedStep,  # noqa: F401,E402
+from .train import (FusedBPRAdam, FusedNCLAdam, FusedNGCFAdam, FusedSGLAdam, FusedSimGCLAdam, FusedXSimGCLAdam, GraphedStep,  # noqa: F401,E402
                     fused_stepper)
 
 __version__ = "0.1.0"

@@ -233,7 +233,7 @@ def evaluate(model, eval_uid, eval_iid, k=10, batch_users=4096, history=None, de
 def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=2020, fused=None, log=None, graphed=True,
         device_sampler=True):
     """``Trainer._train_epoch`` x epochs: zero_grad -> calculate_loss -> backward -> Adam step per batch.  Plain LightGCN /
-    NGCF / SGL models use their autograd-free step (``train.fused_stepper``; ``fused=False`` forces the autograd path, whose
+    NGCF / SGL / SimGCL / XSimGCL / NCL models use their autograd-free step (``train.fused_stepper``; ``fused=False`` forces the autograd path, whose
     gradients the fused steps are tested against); any other model goes through torch autograd + torch.optim.Adam, the
     whole step captured in a HIP graph and replayed (``graphed``; the odd-sized last batch of an epoch runs eagerly;
     SimGCL and XSimGCL are captured too since r04: their contrastive batches are masked, not ``unique``-d, on the device).  Batches come from ``BPRSampler`` on
@@ -241,7 +241,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
     on_gpu = next(model.parameters()).is_cuda
     sampler = BPRSampler(train_uid, train_iid, model.n_items, batch_size=batch_size, seed=seed,
                          device=model.device if (device_sampler and on_gpu) else None)
-    # the autograd-free steps (train.py): plain LightGCN, NGCF, SGL — subclasses with other losses (SimGCL, XSimGCL, NCL) do not qualify
+    # the autograd-free steps (train.py): plain LightGCN, NGCF, SGL, SimGCL, XSimGCL, NCL
     stepper = fused_stepper(model, lr=lr, graphed=graphed) if fused in (None, True) else None
     if fused and stepper is None:
         raise TypeError(f"no fused training step for {type(model).__name__} in this configuration")
@@ -255,6 +255,8 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
         if hasattr(model, "e_step") and epoch % max(int(getattr(model, "m_step", 1) or 1), 1) == 0:
             model.e_step()  # NCLTrainer.fit (trainer.py:38-40)
         model.train()
+        if fused and hasattr(stepper, "with_proto"):  # NCL: the prototype term joins after warm_up_step epochs (trainer.py:130-133)
+            stepper.with_proto = not (warm_up is not None and epoch < warm_up)
         total = torch.zeros((), device=model.device)
         for batch in sampler:
             batch = {k: v.to(model.device) for k, v in batch.items()}

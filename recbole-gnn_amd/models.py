@@ -18,10 +18,17 @@ import torch.nn.functional as F
 from . import ops
 
 
-def _once_mask(ids):
+def _once_mask(ids, n_ids=None):
     """mask[i] = True for exactly ONE occurrence of every distinct id in `ids` — what ``torch.unique`` selects, with static
-    shapes (a sort and a neighbour compare instead of a data-dependent output length), so a loss over the unique ids can be
-    written as a masked loss over the whole batch and the step stays capturable into a HIP graph."""
+    shapes, so a loss over the unique ids can be written as a masked loss over the whole batch and the step stays capturable
+    into a HIP graph.  With ``n_ids`` (an upper bound of the ids) on a GPU: every position writes its index into a table slot of
+    its id and the one that stays is the occurrence kept — three launches instead of a sort's dozen; WHICH occurrence survives
+    is not fixed, and no loss depends on it (the rows of equal ids are equal)."""
+    if n_ids is not None and ids.is_cuda:
+        ar = torch.arange(ids.shape[0], device=ids.device)
+        slot = torch.empty(int(n_ids), dtype=torch.int64, device=ids.device)  # (only slots written below are read)
+        slot.scatter_(0, ids, ar)
+        return slot.index_select(0, ids) == ar
     s, order = torch.sort(ids)
     first = torch.ones_like(s, dtype=torch.bool)
     first[1:] = s[1:] != s[:-1]
@@ -581,8 +588,8 @@ class SimGCL(LightGCN):
         u1, i1 = self.forward(perturbed=True)
         u2, i2 = self.forward(perturbed=True)
         if self.static_unique:
-            user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user), _once_mask(user))
-            item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item), _once_mask(pos_item))
+            user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user), _once_mask(user, self.n_users))
+            item_cl_loss = self.calculate_cl_loss(_rows(i1, pos_item), _rows(i2, pos_item), _once_mask(pos_item, self.n_items))
         else:
             user, pos_item = torch.unique(user), torch.unique(pos_item)
             user_cl_loss = self.calculate_cl_loss(_rows(u1, user), _rows(u2, user))
@@ -634,8 +641,8 @@ class XSimGCL(SimGCL):
             reg_term = self.reg_weight * self.reg_loss(_rows(self.user_embedding.weight, user), _rows(self.item_embedding.weight, pos_item),
                                                        _rows(self.item_embedding.weight, neg_item), require_pow=self.require_pow)
         if self.static_unique:
-            user_cl_loss = self.calculate_cl_loss(u_e, _rows(user_cl, user), _once_mask(user))
-            item_cl_loss = self.calculate_cl_loss(pos_e, _rows(item_cl, pos_item), _once_mask(pos_item))
+            user_cl_loss = self.calculate_cl_loss(u_e, _rows(user_cl, user), _once_mask(user, self.n_users))
+            item_cl_loss = self.calculate_cl_loss(pos_e, _rows(item_cl, pos_item), _once_mask(pos_item, self.n_items))
         else:
             user_u, item_u = torch.unique(user), torch.unique(pos_item)
             user_cl_loss = self.calculate_cl_loss(_rows(user_all, user_u), _rows(user_cl, user_u))

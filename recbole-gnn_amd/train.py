@@ -128,6 +128,10 @@ class _FusedStep:
     def _handles(self):
         return (self.model.graph,)
 
+    def _variant(self):
+        """What else a captured step has baked in (NCL: whether the prototype term is part of the loss)."""
+        return ()
+
     @torch.no_grad()
     def step(self, interaction):
         """One optimisation step on a batch of (user, pos item, neg item) triples; returns the loss (device scalar)."""
@@ -139,7 +143,7 @@ class _FusedStep:
         if not self.graphed:
             self._enqueue(user, pos, neg)
             return self.loss
-        key = tuple(id(h) for h in self._handles())
+        key = tuple(id(h) for h in self._handles()) + tuple(self._variant())
         if self._graph is not None and key != self._key:
             self._graph, self._calls = None, 1  # new views: their plans exist, one eager step re-warms
         if self._graph is not None and user.shape[0] > self._full:  # (a larger batch than the captured one: capture again for it)
@@ -422,7 +426,7 @@ class _FusedContrastStep(_FusedStep):
             check(lib.rbg_infonce_workspace(b, b, d, _lib.ctypes.byref(nbytes)))
             self._scratch[b] = (torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device), torch.arange(b, device=m.device))
         work, ar = self._scratch[b]
-        once = _once_mask(ids).to(torch.float32)
+        once = _once_mask(ids, rows).to(torch.float32)
         row_w = once / once.sum() if mean_form else once  # (xsimgcl.py:54: a mean over the distinct ids)
         xa, xb = ta[row0:row0 + rows].index_select(0, ids), tb[row0:row0 + rows].index_select(0, ids)
         gxa, gxb = torch.zeros_like(xa), torch.zeros_like(xb)
@@ -539,17 +543,124 @@ class FusedXSimGCLAdam(_FusedContrastStep):
             self._reg_and_adam(user, pos, neg, b, d)
 
 
+class FusedNCLAdam(_FusedStep):
+    """NCL's training step (ncl.py:167-199 + NCLTrainer._train_epoch's sum, trainer.py:130-133 + backward + Adam) without the
+    autograd graph of the propagation: the L = max(n_layers, 2 hyper_layers) layers in one chain call (every layer kept,
+    ncl.py:93-104), BPR + EmbLoss by the library, the structure contrast (ncl.py:137-165: layer 2 h against E_0 over ALL rows) by
+    ``rbg_infonce_f32`` with both table gradients, and ONE Horner chain of L products for the mean's gradient and the context
+    layer's injected at layer 2 h.  The prototype contrast (ncl.py:106-135: the batch's rows against k centroids) keeps the
+    model's own formula under ``torch.autograd.grad`` on E_0 — [B, d] x [k, d] work, no AccumulateGrad nodes.  ``with_proto``
+    (False during the trainer's warm-up epochs) is part of the captured step: toggling it re-captures."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=False):
+        from .models import NCL
+        d = model.user_embedding.weight.shape[1] if hasattr(model, "user_embedding") else 0
+        if not (type(model) is NCL and isinstance(model.graph, ops.GraphHandle) and d <= 128 and d % 4 == 0
+                and len(list(model.parameters())) == 2 and 1 <= 2 * model.hyper_layers):
+            raise TypeError("FusedNCLAdam drives a plain NCL model on a device graph handle, embedding width <= 128 and a multiple of 4")
+        self.model = model
+        self._init_graphed(graphed)
+        self.with_proto = True
+        dev, nu = model.device, model.n_users
+        n = nu + model.n_items
+        self.L = max(model.n_layers, 2 * model.hyper_layers)
+        if self.L > _lib.MAX_FUSED_LAYERS:
+            raise TypeError("too many layers for one chain call")
+        f = dict(dtype=torch.float32, device=dev)
+        self.e0 = torch.empty((n, d), **f)
+        self.lay = torch.empty((self.L, n, d), **f)
+        self.mean, self.chain_mean = torch.empty((n, d), **f), torch.empty((n, d), **f)
+        self.gm, self.gctx, self.g0 = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
+        self.ge, self.t0, self.t1 = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
+        self.loss, self.reg_ws = torch.zeros((), **f), torch.zeros(3, **f)
+        self._scratch = {}
+        self.table_opt = _TableAdam(model, lr, betas, eps)
+        model.user_embedding.weight.grad = self.ge[:nu]
+        model.item_embedding.weight.grad = self.ge[nu:]
+
+    def _variant(self):
+        return (bool(self.with_proto),)
+
+    def _enqueue(self, user, pos, neg):
+        m = self.model
+        dev, nu, ni, b, k, L = m.device, m.n_users, m.n_items, user.shape[0], m.n_layers, self.L
+        uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        d = uw.shape[1]
+        st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
+        p = lambda t, row=0: c_vp(t.data_ptr() + 4 * row * d)  # noqa: E731
+        if b not in self._scratch:
+            nbytes, need = _lib.c_i64(), 8
+            for rows in (nu, ni):
+                check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
+                need = max(need, nbytes.value)
+            self._scratch[b] = torch.empty(need, dtype=torch.uint8, device=dev)
+        work = self._scratch[b]
+        with torch.cuda.device(dev):
+            torch.cat([uw, iw], dim=0, out=self.e0)
+            # ncl.py:93-104: E_1 .. E_L row-major; the mean over E_0 .. E_K (the chain's own mean when K = L)
+            ops.lightgcn_forward_raw(m.graph, uw, iw, L, keep_layers=True, out=self.chain_mean, layers=self.lay)
+            if k == L:
+                mean = self.chain_mean
+            else:
+                srcs = (c_vp * (k + 1))(self.e0.data_ptr(), *[self.lay[i].data_ptr() for i in range(k)])
+                check(lib.rbg_mean_f32(srcs, k + 1, self.mean.numel(), 1.0 / (k + 1), p(self.mean), st))
+                mean = self.mean
+            check(lib.rbg_bpr_grad_f32(p(mean), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
+            # ncl.py:137-165: the context layer E_(2 h) against the center E_0, users then items (x alpha)
+            ctx = self.lay[2 * m.hyper_layers - 1]
+            self.gctx.zero_()
+            self.g0.zero_()
+            for row0, rows, idx, wgt in ((0, nu, user, m.ssl_reg), (nu, ni, pos, m.ssl_reg * m.alpha)):
+                check(lib.rbg_infonce_f32(p(ctx, row0), p(self.e0, row0), rows, d, p(idx), b, float(m.ssl_temp), float(wgt), p(self.loss),
+                                          p(self.gctx, row0), p(self.g0, row0), p(work), st))
+            if self.with_proto:  # ncl.py:106-135 on the batch's rows of E_0: the model's formula, differentiated by torch
+                with torch.enable_grad():
+                    leaf = self.e0.detach().requires_grad_(True)
+                    proto = m.ProtoNCE_loss(leaf, user, pos)
+                    (gp,) = torch.autograd.grad(proto, leaf)
+                self.g0.add_(gp)
+                self.loss.add_(proto.detach())
+            # mean = (E_0 + .. + E_K) / (K + 1), E_j = A E_(j-1):  dE0 = g_0 + A (g_1 + A (g_2 + .. A g_L)),
+            # g_j = gm / (K + 1) for j <= K  (+ gctx at j = 2 h),  g_0 = gm / (K + 1) + the direct gradients on E_0
+            gt = m.graph.transpose().ptr
+            torch.mul(self.gm, 1.0 / (k + 1), out=self.gm)
+            h2 = 2 * m.hyper_layers
+
+            def g_of(j, out):
+                if j <= k:
+                    out.copy_(self.gm)
+                else:
+                    out.zero_()
+                if j == h2:
+                    out.add_(self.gctx)
+
+            cur, nxt = self.t0, self.t1
+            g_of(L, cur)
+            for j in range(L - 1, 0, -1):
+                g_of(j, nxt)
+                check(lib.rbg_spmm_f32(gt, p(cur), p(nxt), d, 1, st))  # nxt += A cur
+                cur, nxt = nxt, cur
+            self.ge.copy_(self.gm)
+            self.ge.add_(self.g0)
+            check(lib.rbg_spmm_f32(gt, p(cur), p(self.ge), d, 1, st))
+            check(lib.rbg_emb_reg_grad_nopow_f32(p(uw), p(iw), nu, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge), p(self.loss),
+                                                 p(self.reg_ws), st))
+            self.table_opt.step(self.ge)
+
+
+
 def fused_stepper(model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, graphed=True):
     """The autograd-free training step of `model` if this package has one — ``FusedBPRAdam`` (plain LightGCN),
     ``FusedNGCFAdam`` (plain NGCF, fused layers, widths <= 128), ``FusedSGLAdam`` (plain SGL, d <= 128), ``FusedSimGCLAdam`` /
-    ``FusedXSimGCLAdam`` (their ``static_unique`` form), all on device graph handles — else None (``GraphedStep`` / an eager loop
+    ``FusedXSimGCLAdam`` (their ``static_unique`` form), ``FusedNCLAdam``, all on device graph handles — else None (``GraphedStep`` / an eager loop
     serve every other model).  ``graphed`` applies to all but the first."""
-    from .models import NGCF, SGL, SimGCL, XSimGCL
+    from .models import NCL, NGCF, SGL, SimGCL, XSimGCL
     if not next(model.parameters()).is_cuda:
         return None
     if fused_step_applies(model) and isinstance(model.graph, ops.GraphHandle):
         return FusedBPRAdam(model, lr=lr, betas=betas, eps=eps)
-    for cls, step in ((NGCF, FusedNGCFAdam), (SGL, FusedSGLAdam), (SimGCL, FusedSimGCLAdam), (XSimGCL, FusedXSimGCLAdam)):
+    for cls, step in ((NGCF, FusedNGCFAdam), (SGL, FusedSGLAdam), (SimGCL, FusedSimGCLAdam), (XSimGCL, FusedXSimGCLAdam),
+                      (NCL, FusedNCLAdam)):
         if type(model) is cls:
             try:
                 return step(model, lr=lr, betas=betas, eps=eps, graphed=graphed)

@@ -259,23 +259,24 @@ def test_static_unique_is_the_unique_loss(rbg, cuda, ref_inter, name):
 
 @pytest.mark.gpu
 def test_ncl_trains_through_a_replayed_step(rbg, cuda, ref_inter):
-    """NCL through driver.fit: the step is captured (e_step rewrites the prototypes in place; the prototype term joins after
-    warm_up_step epochs = one re-capture through GraphedStep.set_reduce) and gives the losses of the eager loop."""
+    """NCL through driver.fit: the autograd-free step (train.FusedNCLAdam, r05), captured and eager, and the autograd step
+    captured by GraphedStep (fused=False) — e_step rewrites the prototypes in place, the prototype term joins after warm_up_step
+    epochs (one re-capture) — give the same losses."""
     uid, iid, nu, ni = ref_inter
     ds = rbg.InteractionDataset(uid, iid, nu, ni)
     cfg = {"device": str(cuda), "enable_sparse": True, "embedding_size": 64, "n_layers": 2, "num_clusters": 8, "warm_up_step": 1, "m_step": 1,
            "proto_reg": 1e-3, "ssl_reg": 1e-5}
     out = []
-    for graphed in (True, False):
+    for graphed, fused in ((True, None), (False, None), (True, False)):
         torch.manual_seed(1)
         m = rbg.NCL(cfg, ds)
-        assert m.graph_capturable
-        hist = rbg.driver.fit(m, uid, iid, epochs=3, lr=1e-3, batch_size=500, seed=5, graphed=graphed)
+        assert m.graph_capturable and isinstance(rbg.fused_stepper(m), rbg.FusedNCLAdam)
+        hist = rbg.driver.fit(m, uid, iid, epochs=3, lr=1e-3, batch_size=500, seed=5, graphed=graphed, fused=fused)
         out.append((hist, m))
         cent = m.user_centroids
         m.e_step()
         assert m.user_centroids is cent  # rewritten in place
-    (ha, ma), (hb, mb) = out
-    for x, y in zip(ha, hb):
-        assert abs(x - y) <= 1e-2 * max(1.0, abs(y)), (ha, hb)
+    (ha, ma), (hb, mb), (hc, mc) = out
+    for x, y, z in zip(ha, hb, hc):
+        assert abs(x - z) <= 1e-2 * max(1.0, abs(z)) and abs(y - z) <= 1e-2 * max(1.0, abs(z)), (ha, hb, hc)
     assert ha[1] > 0 and np.isfinite(ha).all()

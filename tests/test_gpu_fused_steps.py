@@ -499,3 +499,75 @@ def test_fused_contrastive_step_replayed_from_a_hip_graph(rbg, cuda, golden, kin
     with pytest.raises(TypeError):
         rbg.FusedXSimGCLAdam(_contrastive(rbg, cuda, golden, "SimGCL"))
     assert rbg.fused_stepper(_contrastive(rbg, cuda, golden, "SimGCL", static_unique=False)) is None
+
+
+@pytest.mark.parametrize("cfg,with_proto", [({}, True), ({}, False), ({"n_layers": 2, "hyper_layers": 2}, True), ({"n_layers": 3, "hyper_layers": 1, "alpha": 1.5}, True)])
+def test_fused_ncl_step_takes_the_autograd_step(rbg, cuda, golden, cfg, with_proto):
+    """train.FusedNCLAdam (ncl.py:167-199 + trainer.py:130-133): one chain call for the L layers, rbg_infonce_f32 for the
+    structure contrast, one Horner chain for the mean's and the context layer's gradients, the prototype term by autograd.grad on
+    the batch's rows — against the model mirror's autograd step (the trainer's sum of the loss tuple, without the prototype term
+    during warm-up) on the same parameters, prototypes and batches."""
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 3, "enable_sparse": True, "reg_weight": 1e-3, "ssl_reg": 1e-3, "proto_reg": 1e-3,
+              "num_clusters": 7, "ssl_temp": 0.2}
+    config.update(cfg)
+    torch.manual_seed(4)
+    model, twin = rbg.NCL(config, ds), rbg.NCL(config, ds)
+    twin.load_state_dict(model.state_dict())
+    model.train(), twin.train()
+    model.e_step()
+    for name in ("user_centroids", "user_2cluster", "item_centroids", "item_2cluster"):
+        setattr(twin, name, getattr(model, name).clone())
+    stepper = rbg.fused_stepper(model, lr=1e-3, graphed=False)
+    assert isinstance(stepper, rbg.FusedNCLAdam)
+    stepper.with_proto = with_proto
+    opt = torch.optim.Adam(twin.parameters(), lr=1e-3)
+    for step_no, batch in enumerate(_batches(golden, cuda, 3, 96)):
+        lf = float(stepper.step(batch))
+        opt.zero_grad(set_to_none=True)
+        terms = twin.calculate_loss(batch)
+        le = sum(terms if with_proto else terms[:-1])
+        le.backward()
+        ref = float(le.detach())
+        if step_no == 0:
+            assert abs(lf - ref) <= 5e-6 * max(1.0, abs(ref)), (lf, ref)
+            for (name, pf), pe in zip(model.named_parameters(), twin.parameters()):
+                scale = max(float(pe.grad.abs().max()), 1e-12)
+                assert float((pf.grad - pe.grad).abs().max()) <= 2e-5 * scale, name
+        opt.step()
+        assert abs(lf - ref) <= 2e-4 * max(1.0, abs(ref)), (step_no, lf, ref)
+    for pf, pe in zip(model.parameters(), twin.parameters()):
+        assert float((pf.detach() - pe.detach()).abs().max()) <= 1e-4 * max(1.0, float(pe.detach().abs().max()))
+
+
+def test_fused_ncl_step_replayed_and_recaptured_when_the_prototype_term_joins(rbg, cuda, golden):
+    g = golden
+    ds = rbg.InteractionDataset(g["uid"], g["iid"], int(g["n_users"]), int(g["n_items"]))
+    torch.manual_seed(4)
+    model = rbg.NCL({"device": str(cuda), "embedding_size": 64, "n_layers": 3, "enable_sparse": True, "num_clusters": 7}, ds)
+    model.train()
+    model.e_step()
+    a = rbg.fused_stepper(model, lr=1e-3, graphed=True)
+    a.with_proto = False
+    batches = _batches(golden, cuda, 10, 64)
+    for batch in batches[:5]:
+        assert np.isfinite(float(a.step(batch)))
+    first = a._graph
+    assert first is not None
+    model.e_step()  # new prototypes, same storage: the captured step reads them
+    a.with_proto = True
+    for batch in batches[5:]:
+        assert np.isfinite(float(a.step(batch)))
+    assert a._graph is not None and a._graph is not first
+
+
+def test_once_mask_on_the_device_keeps_one_occurrence_per_id(rbg, cuda):
+    """models._once_mask with an id bound on a GPU (scatter + compare instead of a sort): exactly one position per distinct id."""
+    from recbole_gnn_amd import models
+    gen = torch.Generator().manual_seed(3)
+    for n_ids, b in ((50, 400), (30_000, 2048), (7, 7)):
+        ids = torch.randint(0, n_ids, (b,), generator=gen).to(cuda)
+        m = models._once_mask(ids, n_ids)
+        kept = ids[m]
+        assert m.dtype == torch.bool and kept.numel() == torch.unique(ids).numel() and torch.equal(torch.sort(kept).values, torch.unique(ids))
