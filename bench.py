@@ -67,10 +67,12 @@ def parse():
     ap.add_argument("--partition", choices=["auto", "ranges", "striped"], default="auto",
                     help="strong scaling: contiguous nnz-balanced id ranges, or degree-striped (degree order dealt round-robin); "
                          "auto = the one with the smaller max over ranks of (nnz + halo rows)")
-    ap.add_argument("--shard", choices=["rows", "columns"], default="rows",
+    ap.add_argument("--shard", choices=["rows", "columns", "hybrid"], default="rows",
                     help="N>1 headline: rows = node-range shards + halo exchange (the mode BASELINE.json's north_star names); columns = "
-                         "feature-column shards (colsharded.py: the K layers exchange nothing).  Both are measured in a strong-scaling "
-                         "run; this picks which one is `value`, the other is reported under `column_sharding` / `node_range_sharding`")
+                         "feature-column shards (colsharded.py: the K layers exchange nothing); hybrid = 2 column groups x N/2 node "
+                         "shards (hybrid.py: halos of d/2 floats inside a column group).  All are measured in a strong-scaling "
+                         "run; this picks which one is `value`, the others are reported under `column_sharding` / `hybrid_sharding` / "
+                         "`node_range_sharding`")
     ap.add_argument("--no-train-extra", action="store_true", help="N>1: skip the sharded SGL training-step measurement")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins a gloo group, rank 0 prints {\"launch_check\": world} (no GPU needed)")
@@ -108,6 +110,23 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
             coracle.lightgcn_forward(rowptr, col, val, uw, iw, k_layers, buffers=buffers)
             reps += 1
         probe[t] = reps / (time.perf_counter() - t1)
+    # The same arithmetic with thread-owned row blocks and first-touch placement (oracle/rbg_oracle.c ora_numa_*; effective with
+    # OMP_PROC_BIND / OMP_PLACES set before the first OpenMP region of the process — main() sets them when they are unset): what the
+    # reference's CPU path could reach on this box if it were NUMA-aware.  Reported beside the plain loop, never instead of it.
+    numa_probe = {}
+    for t in sorted({min(t, max_threads) for t in (16, 32, 64, 128, max_threads)}):
+        coracle.set_num_threads(t)
+        try:
+            nf = coracle.NumaForward(rowptr, col, val, nu, ni, d, k_layers)
+        except MemoryError:
+            break
+        nf(uw, iw, want_result=False)
+        reps, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 0.5:
+            nf(uw, iw, want_result=False)
+            reps += 1
+        numa_probe[t] = reps / (time.perf_counter() - t1)
+        nf.close()
     best = max(probe, key=probe.get)
     coracle.set_num_threads(best)
     samples, total_reps, total_s = [], 0, 0.0
@@ -128,6 +147,11 @@ def cpu_baseline(uid, iid, nu, ni, uw, iw, k_layers, budget_s):
                           f"{best} cores, not on all of them",
             "samples_prop_per_s": [round(v, 1) for v in samples],
             "thread_probe_prop_per_s": {str(k): round(v, 1) for k, v in probe.items()},
+            "numa_aware_variant": {"thread_probe_prop_per_s": {str(k): round(v, 1) for k, v in numa_probe.items()},
+                                   "best_prop_per_s": round(max(numa_probe.values()), 1) if numa_probe else None,
+                                   "best_threads": max(numa_probe, key=numa_probe.get) if numa_probe else None,
+                                   "note": "same arithmetic (bit-identical), static nnz-balanced row blocks per thread, col / val / layers first "
+                                           "touched by their thread (oracle/rbg_oracle.c ora_numa_*): context for the baseline, not the baseline"},
             "thread_pinning": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
             "sample": f"median of 3 samples, {total_reps} full propagations of the same workload in {total_s:.1f} s "
                       f"(oracle/rbg_oracle.c, gcc -O3 + AVX2 clone, OpenMP dynamic rows, buffers reused; {os.cpu_count()} logical cpus visible)"}
@@ -625,6 +649,10 @@ def self_launch(args):
 
 def main():
     args = parse()
+    # (for the CPU baseline's OpenMP runtime — the oracle library's own, loaded later: threads pinned one per core, spread over the
+    # sockets, so that first-touch placement means something; a caller's own setting wins)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         raise SystemExit(self_launch(args))  # no launcher around us: start the ranks here
@@ -863,6 +891,29 @@ def main():
                 extra["column_sharding"] = {"skipped": f"d / N = {d} / {world}: not a width the column-slab plan serves (32, 64, 128)"}
         except Exception as ex:  # noqa: BLE001
             extra["column_sharding"] = {"error": str(ex)[:200]}
+        # ... and their product (r05, hybrid.py): 2 column groups x N / 2 node shards — the mode that reaches 4 and 8 GPUs at d = 64
+        # with halos half as wide.  Collective construction (process subgroups): every rank runs this block.
+        try:
+            su, si, snu, sni = strong_graph[:4]
+            if world % 2 == 0 and d % 2 == 0 and (d // 2) in (32, 64, 128):
+                from recbole_gnn_amd import hybrid as hy
+                hprop = hy.HybridShardedPropagation(su, si, snu, sni, d, sh.HipBackend(dev), 2, rank=rank, world=world, transport=transport)
+                blk = xavier(hprop.plan.n_owned, hprop.width, gen).to(dev)
+                stepsh = max(10, min(args.steps, 100))
+                elh, evh = timed_loop(lambda: hprop.forward(blk, k_layers), stepsh, max(3, min(args.warmup, 10)), world, gloo_group)
+                extra["hybrid_sharding"] = {
+                    "value": stepsh / elh, "unit": "propagations/s", "ms_per_step": elh * 1e3 / stepsh, "steps": stepsh,
+                    "grid": f"2 column groups x {world // 2} node shards", "columns_per_rank": hprop.width,
+                    "halo_per_layer(rank 0)": hprop.halo_bytes_per_layer(), "interior_kernel": hprop.prop.g_int.propagation_kernel_name(hprop.width)
+                    if hasattr(hprop.prop.g_int, "propagation_kernel_name") else None,
+                    "note": "hybrid.py: a rank holds its node shard's rows and d / 2 columns; halos travel inside a column group as rows of "
+                            "d / 2 floats (half the pure node-range mode's bytes for the same node shards), the loss all-reduces partial "
+                            "dots over the two column groups"}
+                del hprop, blk
+            else:
+                extra["hybrid_sharding"] = {"skipped": f"needs an even rank count and d / 2 in (32, 64, 128); world {world}, d {d}"}
+        except Exception as ex:  # noqa: BLE001
+            extra["hybrid_sharding"] = {"error": str(ex)[:200]}
 
     if world > 1:
         # phase breakdown of one sharded layer (each phase alone, back to back; rank-0 view) so the scaling
@@ -1021,6 +1072,16 @@ def main():
                 result["roofline"]["frac_of_measured"] = achieved / pk["triad_GBps"]
             result["roofline"]["cap"] = gather_path_cap(nu + ni, graph.nnz, d, k_layers)
         result.update(extra)
+        if world > 1 and args.shard == "hybrid" and isinstance(extra.get("hybrid_sharding"), dict) and extra["hybrid_sharding"].get("value"):
+            hs_ = extra["hybrid_sharding"]  # the hybrid propagation becomes the headline, the node-range one is kept beside it
+            result["node_range_sharding"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "roofline_frac": result["roofline"]["frac"],
+                                             "sharding": result["config"]["sharding"]}
+            result["value"], result["ms_per_step"], result["steps"] = hs_["value"], hs_["ms_per_step"], hs_["steps"]
+            result["config"]["sharding"] = f"hybrid: {hs_['grid']}, {hs_['columns_per_rank']} columns per rank, halos of d / 2 floats inside a column group"
+            if "speedup_vs_one_gpu_same_workload" in result:
+                result["node_range_sharding"]["speedup_vs_one_gpu_same_workload"] = result.pop("speedup_vs_one_gpu_same_workload")
+                if one_gpu.get("value"):
+                    result["speedup_vs_one_gpu_same_workload"] = hs_["value"] / one_gpu["value"]
         if world > 1 and args.shard == "columns" and isinstance(extra.get("column_sharding"), dict) and extra["column_sharding"].get("value"):
             cs_ = extra["column_sharding"]  # the column-sharded propagation becomes the headline, the node-range one is kept beside it
             result["node_range_sharding"] = {"value": result["value"], "ms_per_step": result["ms_per_step"], "roofline_frac": result["roofline"]["frac"],

@@ -42,6 +42,12 @@ def lib():
         _lib.ora_lightgcn_forward_f32.restype = None
         _lib.ora_lightgcn_forward_f32.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int,
                                                   _i64p, _i64p, _f32p, _f32p, _f32p, _f32p, _f32p]
+        _lib.ora_numa_prepare.restype = ctypes.c_void_p
+        _lib.ora_numa_prepare.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, _i64p, _i64p, _f32p]
+        _lib.ora_numa_forward_f32.restype = None
+        _lib.ora_numa_forward_f32.argtypes = [ctypes.c_void_p, _f32p, _f32p, _f32p]
+        _lib.ora_numa_free.restype = None
+        _lib.ora_numa_free.argtypes = [ctypes.c_void_p]
     return _lib
 
 
@@ -105,3 +111,36 @@ def lightgcn_forward(rowptr, col, val, user_w, item_w, n_layers, return_layers=F
     if return_layers:
         return out, layers
     return out
+
+
+
+class NumaForward:
+    """The same propagation with thread-owned row blocks and first-touch placement of everything a thread streams (bench.py's
+    cpu_baseline on many-socket hosts; ora_numa_* in rbg_oracle.c).  Built for the CURRENT thread count; bit-identical results."""
+
+    def __init__(self, rowptr, col, val, n_users, n_items, d, n_layers):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        self.shape = (n_users + n_items, d)
+        self._h = lib().ora_numa_prepare(n_users, n_items, d, n_layers, _p(rowptr, _i64p), _p(col, _i64p), _p(val, _f32p))
+        if not self._h:
+            raise MemoryError("ora_numa_prepare failed")
+
+    def __call__(self, user_w, item_w, want_result=True):
+        user_w = np.ascontiguousarray(user_w, dtype=np.float32)
+        item_w = np.ascontiguousarray(item_w, dtype=np.float32)
+        out = np.empty(self.shape, dtype=np.float32) if want_result else None
+        lib().ora_numa_forward_f32(self._h, _p(user_w, _f32p), _p(item_w, _f32p), _p(out, _f32p))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().ora_numa_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -132,3 +132,106 @@ void ora_lightgcn_forward_f32(int64_t n_users, int64_t n_items, int64_t d, int n
         out_mean[i] = s / denom;
     }
 }
+
+/* ---- the same propagation with NUMA-aware placement (bench.py's cpu_baseline only; r05) -------------------
+ * The loop above hands rows out dynamically and reads arrays whose pages sit where the Python thread first touched them: on a
+ * two-socket host it stops scaling at 16 of 256 logical CPUs.  Here every thread owns ONE contiguous block of rows (blocks of
+ * equal entry counts), and the arrays it streams — its block of col / val, its rows of every layer and of the mean — are
+ * allocated untouched and first written by that thread, so their pages land on its NUMA node (run with OMP_PROC_BIND=spread /
+ * OMP_PLACES=cores).  The arithmetic is the loop's above, entry for entry: results are bit-identical. */
+typedef struct {
+    int64_t n_users, n_items, d;
+    int n_layers, n_threads;
+    int64_t *row_lo;  /* [n_threads + 1] */
+    int64_t *rowptr, *col;
+    float *val, *layers, *mean;
+} ora_numa;
+
+void ora_numa_free(ora_numa *h) {
+    if (!h) return;
+    free(h->row_lo); free(h->rowptr); free(h->col); free(h->val); free(h->layers); free(h->mean);
+    free(h);
+}
+
+ora_numa *ora_numa_prepare(int64_t n_users, int64_t n_items, int64_t d, int n_layers, const int64_t *rowptr, const int64_t *col,
+                           const float *val) {
+    const int64_t n = n_users + n_items, nnz = rowptr[n];
+    ora_numa *h = (ora_numa *)calloc(1, sizeof(ora_numa));
+    if (!h) return NULL;
+    h->n_users = n_users, h->n_items = n_items, h->d = d, h->n_layers = n_layers, h->n_threads = ora_num_threads();
+    const int T = h->n_threads;
+    h->row_lo = (int64_t *)malloc(sizeof(int64_t) * (size_t)(T + 1));
+    h->rowptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    h->col = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz ? nnz : 1));
+    h->val = (float *)malloc(sizeof(float) * (size_t)(nnz ? nnz : 1));
+    h->layers = (float *)malloc(sizeof(float) * (size_t)((n_layers + 1) * n * d + 1));
+    h->mean = (float *)malloc(sizeof(float) * (size_t)(n * d + 1));
+    if (!h->row_lo || !h->rowptr || !h->col || !h->val || !h->layers || !h->mean) { ora_numa_free(h); return NULL; }
+    h->row_lo[0] = 0;
+    for (int t = 1; t <= T; ++t) {  /* the first row whose entries start at or beyond t / T of all entries */
+        const int64_t target = (int64_t)((double)nnz * t / T);
+        int64_t lo = h->row_lo[t - 1], hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (rowptr[mid] < target) lo = mid + 1; else hi = mid; }
+        h->row_lo[t] = t == T ? n : lo;
+    }
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t r0 = h->row_lo[t], r1 = h->row_lo[t + 1];
+        for (int64_t r = r0; r < r1; ++r) h->rowptr[r] = rowptr[r];
+        if (t == T - 1) h->rowptr[n] = rowptr[n];
+        for (int64_t e = rowptr[r0]; e < rowptr[r1]; ++e) h->col[e] = col[e], h->val[e] = val[e];
+        for (int k = 0; k <= n_layers; ++k) memset(h->layers + ((int64_t)k * n + r0) * d, 0, sizeof(float) * (size_t)((r1 - r0) * d));
+        memset(h->mean + r0 * d, 0, sizeof(float) * (size_t)((r1 - r0) * d));
+    }
+    return h;
+}
+
+__attribute__((target_clones("avx2", "default")))
+static void ora_numa_rows(int64_t r0, int64_t r1, int64_t K, const int64_t *restrict rowptr, const int64_t *restrict col, const float *restrict val,
+                          const float *restrict mat, float *restrict out, float *restrict vals) {
+    for (int64_t m = r0; m < r1; ++m) {
+        for (int64_t k = 0; k < K; ++k) vals[k] = 0.0f;
+        for (int64_t e = rowptr[m]; e < rowptr[m + 1]; ++e) {
+            const int64_t c = col[e];
+            const float v = val[e];
+            const float *restrict src = mat + c * K;
+            for (int64_t k = 0; k < K; ++k) vals[k] += v * src[k];
+        }
+        memcpy(out + m * K, vals, sizeof(float) * (size_t)K);
+    }
+}
+
+/* out_mean may be NULL (the timing loop): the mean stays in the handle's own, thread-placed buffer */
+void ora_numa_forward_f32(ora_numa *h, const float *user_w, const float *item_w, float *out_mean) {
+    const int64_t n = h->n_users + h->n_items, d = h->d, nd = n * d;
+    const int T = h->n_threads, K = h->n_layers;
+    const float denom = (float)(K + 1);
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const int64_t r0 = h->row_lo[t], r1 = h->row_lo[t + 1];
+        float *vals = (float *)malloc(sizeof(float) * (size_t)(d ? d : 1));
+        for (int64_t r = r0; r < r1; ++r)
+            memcpy(h->layers + r * d, r < h->n_users ? user_w + r * d : item_w + (r - h->n_users) * d, sizeof(float) * (size_t)d);
+        for (int k = 0; k < K; ++k) {
+#pragma omp barrier
+            ora_numa_rows(r0, r1, d, h->rowptr, h->col, h->val, h->layers + (int64_t)k * nd, h->layers + (int64_t)(k + 1) * nd, vals);
+        }
+        for (int64_t i = r0 * d; i < r1 * d; ++i) {
+            float s = h->layers[i];
+            for (int k = 1; k <= K; ++k) s += h->layers[(int64_t)k * nd + i];
+            h->mean[i] = s / denom;
+        }
+        free(vals);
+    }
+    if (out_mean) memcpy(out_mean, h->mean, sizeof(float) * (size_t)nd);
+}

@@ -5,7 +5,7 @@ The package directory name carries a hyphen; import it as ``recbole_gnn_amd`` (t
 the repository root) or with ``importlib.import_module("recbole-gnn_amd")``.
 Importing fails loudly if librbgnn.so (the HIP extension) has not been built; there is no CPU path.
 """
-from . import _lib, colsharded, driver, graph, models, ops, sharded, sharded_train, synth, train  # noqa: F401
+from . import _lib, colsharded, driver, graph, hybrid, models, ops, sharded, sharded_train, synth, train  # noqa: F401
 from ._lib import LIB_PATH, RbgError  # noqa: F401
 from .graph import (GraphHandle, InteractionDataset, device_count, find_communities, get_option, get_tuning, norm_edges,  # noqa: F401
                     set_option, set_tuning)

@@ -435,10 +435,12 @@ class ShardedPropagation:
         for q in range(plan.world):
             sc, rc = int(plan.send_counts[q]), int(plan.recv_counts[q])
             if q != plan.rank:
+                # (the plan counts ranks inside ITS group — a column group of hybrid.py is a subgroup; P2POp names peers globally)
+                peer = q if self.group is None else dist.get_global_rank(self.group, q)
                 if sc:
-                    ops.append(dist.P2POp(dist.isend, send[so:so + sc].contiguous(), q, group=self.group))
+                    ops.append(dist.P2POp(dist.isend, send[so:so + sc].contiguous(), peer, group=self.group))
                 if rc:
-                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], q, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], peer, group=self.group))
             so += sc
             ro += rc
         if ops:

@@ -237,3 +237,24 @@ def test_ncl_restatements_known_answers():
     for j in range(4):
         if (a == j).any():
             assert np.allclose(c[j], pts[a == j].mean(0))
+
+
+def test_numa_aware_baseline_is_the_same_arithmetic(ref_inter):
+    """oracle/rbg_oracle.c ora_numa_* (bench.py's NUMA-aware CPU baseline variant: thread-owned row blocks, first-touch
+    placement): bit-identical to the plain restatement at several thread counts, also with more threads than rows per block."""
+    from oracle import coracle
+    uid, iid, nu, ni = ref_inter
+    rowptr, col, val = coracle.build_norm_csr(uid, iid, nu, ni)
+    rng = np.random.default_rng(0)
+    uw, iw = rng.standard_normal((nu, 64)).astype(np.float32), rng.standard_normal((ni, 64)).astype(np.float32)
+    ref = coracle.lightgcn_forward(rowptr, col, val, uw, iw, 3)
+    keep = coracle.num_threads()
+    try:
+        for t in (1, 3, 8):
+            coracle.set_num_threads(t)
+            nf = coracle.NumaForward(rowptr, col, val, nu, ni, 64, 3)
+            assert np.array_equal(nf(uw, iw), ref)
+            assert nf(uw, iw, want_result=False) is None
+            nf.close()
+    finally:
+        coracle.set_num_threads(keep)
