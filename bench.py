@@ -470,7 +470,7 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
                         "stepper": (type(rbg.fused_stepper(mm)).__name__ if name in ("LightGCN", "NGCF", "SGL") else "GraphedStep (autograd step as one HIP graph)")}
             del mm
         ep["batches_per_epoch"] = (len(uid) + 2047) // 2048
-        ex["driver_epoch(device sampler; fused steps for LightGCN / NGCF / SGL, replayed autograd steps for the others; model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep
+        ex["driver_epoch(device sampler; autograd-free fused steps for all six models (train.fused_stepper), replayed from HIP graphs; model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep
     except Exception as e:  # noqa: BLE001
         ex["driver_epoch_error"] = str(e)[:200]
     return ex
@@ -1062,7 +1062,7 @@ def main():
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean layer duration; duration = HIP-event "
                                  "time of the timed region / (steps x K layers), so inter-kernel gaps and (N>1) halo waits count against "
-                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r04_bench_kernel_stats.csv"},
+                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r05_bench_kernel_stats.csv"},
             "cpu_baseline": None,
         }
         if world == 1:

@@ -36,7 +36,7 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         table = json.load(open(tpath))
     except Exception:
         table = {}
-    key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:sell_spmm_kernel<32, 2, true, 1>"
+    key = sys.argv[2] if len(sys.argv) > 2 else "gowalla:d64:sell_spmm_kernel<32, 2, true>"
     rec = {"traffic": traffic, "fetch_size_kib": pmc["FETCH_SIZE"]["mean"], "write_size_kib": pmc["WRITE_SIZE"]["mean"]}
     if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
         rec["l2_hit"] = pmc["TCC_HIT_sum"]["mean"] / (pmc["TCC_HIT_sum"]["mean"] + pmc["TCC_MISS_sum"]["mean"])
