@@ -211,15 +211,28 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
 
     // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
     auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
-        // The not-passing case must be a compare and a branch per row: with the row / item validity folded into one bool per
-        // row hipcc kept 16 lane masks in (spilled) scalar registers and materialised every ballot through a VGPR — the
-        // phase clock (r02) had 2.2 k cycles per tile in here with NOTHING passing.
-        const unsigned long long item_mask = __builtin_amdgcn_ballot_w64(item < p.n_items && item != 0);
+        // r05: ONE branch per tile in the common case.  r04's form — a compare, a ballot and a branch per row — cost 1 320 cycles per
+        // tile with NOTHING passing (16 serial v_cmp -> SGPR -> s_cbranch chains beside the other wave's MFMAs: the phase clock had
+        // the matrix pipe 36 % busy).  Here every lane collects its rows' tests in a bit mask with vector instructions alone
+        // (v_cmp / v_cndmask / v_or: no scalar round trip), one ballot says whether any lane has a bit, and only then the rows
+        // that do are visited (their union comes from the few lanes that have one).  Same predicate, same visiting order:
+        // identical lists.  (r02's trap stays avoided: no per-row lane masks live in scalar registers.)
+        const bool item_ok = item < p.n_items && item != 0;
+        unsigned bits = 0u;
         RowLoop<0>::run([&](auto rc) {
             constexpr int r = decltype(rc)::value;
+            bits |= (acc[r] >= tau[r]) ? (1u << r) : 0u;
+        });
+        if (!item_ok) bits = 0u;
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(bits != 0u);
+        if (any == 0ull) return;  // the common case once the thresholds have risen
+        unsigned rows = 0u;
+        for (unsigned long long m = any; m; m &= m - 1ull) rows |= (unsigned)__builtin_amdgcn_readlane((int)bits, __builtin_ctzll(m));
+        RowLoop<0>::run([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            if (!(rows & (1u << r))) return;
             const float s = acc[r];
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(s >= tau[r]) & item_mask;
-            if (mask == 0ull) return;  // the common case once the thresholds have risen
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(((bits >> r) & 1u) != 0u);
             const bool pass = (mask >> lane) & 1ull;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {  // the two lane halves hold two different users
