@@ -20,4 +20,6 @@ timeout 600 python bench.py --no-extras > gpurun_out/final/bench_n1_default.json
 echo "default rc=$?"; head -c 500 gpurun_out/final/bench_n1_default.json; echo
 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/final/bench_n2.json 2> gpurun_out/final/bench_n2.err
 echo "n2 rc=$?"; head -c 500 gpurun_out/final/bench_n2.json; echo
+timeout 900 python bench.py --gpus 4 --steps 10 --warmup 3 --shard hybrid > gpurun_out/final/bench_n4_hybrid.json 2> gpurun_out/final/bench_n4_hybrid.err
+echo "n4 hybrid rc=$?"; head -c 400 gpurun_out/final/bench_n4_hybrid.json; echo
 find gpurun_out/prof gpurun_out/traffic -name "*.csv" -size +2M -delete

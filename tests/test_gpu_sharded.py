@@ -666,3 +666,62 @@ def test_real_peers_over_rccl(world, ref_inter):
         loss, ref, gerr, scale, v0, v1 = out["train"]
         assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)) and gerr <= 1e-5 * max(1.0, scale), (rank, out["train"])
         assert abs(v0 - loss) <= 1e-6 * max(1.0, abs(loss)) and v1 < v0, (rank, v0, v1)
+
+
+# ---- columns x node-ranges (hybrid.py, r05) through the product backend ---------------------------------------------------------------
+
+def _hybrid_worker(rank, world, col_shards, port, uid, iid, nu, ni, k_layers, d, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh, hy = rbg.sharded, rbg.hybrid
+        dev = torch.device("cuda:0")
+        n = nu + ni
+        rng = np.random.default_rng(1)
+        e0 = rng.standard_normal((n, d)).astype(np.float32)
+        w = rng.standard_normal((n, d)).astype(np.float32)
+        h = hy.HybridShardedPropagation(uid, iid, nu, ni, d, sh.HipBackend(dev), col_shards, transport="staged")
+        rp, cc, vv = C.build_norm_csr(uid, iid, nu, ni)
+        ref = C.lightgcn_forward(rp, cc, vv, e0[:nu], e0[nu:], k_layers)
+        gref = C.lightgcn_forward(rp, cc, vv, w[:nu], w[nu:], k_layers)
+        x = h.slab_of(torch.from_numpy(e0).to(dev)).requires_grad_(True)
+        out = h.propagate(x, k_layers)
+        (out * h.slab_of(torch.from_numpy(w).to(dev))).sum().backward()
+        torch.cuda.synchronize()
+        err = float(np.abs(out.detach().cpu().numpy() - ref[h.owned][:, h.lo:h.hi]).max())
+        gerr = float(np.abs(x.grad.cpu().numpy() - gref[h.owned][:, h.lo:h.hi]).max())
+        full = h.gather_columns(out.detach())
+        ferr = float(np.abs(full.cpu().numpy() - ref[h.owned]).max())
+        kern = h.prop.g_int.spmm_kernel_name(h.width)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, err, gerr, ferr, h.halo_bytes_per_layer(), kern))
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hybrid_grid_two_by_two_on_one_gpu(ref_inter):
+    """hybrid.py with the HIP backend: 2 column groups x 2 node shards, four processes sharing cuda:0 (host-staged halos inside
+    every column group): the interior product is the 32-column slab launch over the shard's own plan, the halo product the binned
+    kernel on rows of 32 floats; forward, backward and the column gather against the single-process oracle."""
+    uid, iid, nu, ni = ref_inter
+    world, col_shards, d = 4, 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_hybrid_worker, args=(r, world, col_shards, port, uid, iid, nu, ni, 3, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for rank, err, gerr, ferr, hb, kern in res:
+        assert err <= 1e-5 and gerr <= 1e-5 and ferr <= 1e-5, (rank, err, gerr, ferr)
+        assert hb["columns"] == 32 and hb["halo_rows"] > 0 and hb["recv_bytes"] == hb["halo_rows"] * 32 * 4
+        assert kern.startswith("sell_spmm_kernel<32, 1,"), kern
