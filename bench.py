@@ -467,7 +467,7 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
             t0 = time.perf_counter()
             rbg.driver.fit(mm, uid, iid, epochs=2, lr=1e-3, log=mark)
             ep[name] = {"epoch_s": round(marks[1] - marks[0], 4), "first_epoch_s(incl. warm-up and capture)": round(marks[0] - t0, 4),
-                        "stepper": (type(rbg.fused_stepper(mm)).__name__ if name in ("LightGCN", "NGCF", "SGL") else "GraphedStep (autograd step as one HIP graph)")}
+                        "stepper": type(rbg.fused_stepper(mm)).__name__}
             del mm
         ep["batches_per_epoch"] = (len(uid) + 2047) // 2048
         ex["driver_epoch(device sampler; autograd-free fused steps for all six models (train.fused_stepper), replayed from HIP graphs; model defaults: NGCF message_dropout 0.1, SGL ED views)"] = ep

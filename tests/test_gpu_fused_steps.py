@@ -193,7 +193,7 @@ def test_infonce_one_pass_form(rbg, cuda, n, b, d):
 def test_adam_with_the_step_count_on_the_device(rbg, cuda):
     """rbg_adam_step_dev_f32 == torch.optim.Adam over the two tables, also when ONE captured call is replayed: the bias
     corrections advance with the device-side count (a host-side count would repeat the captured step's)."""
-    from recbole_gnn_amd._lib import c_vp, check, lib
+    c_vp, check, lib = rbg._lib.c_vp, rbg._lib.check, rbg._lib.lib
     nu, ni, d = 37, 53, 64
     gen = torch.Generator().manual_seed(0)
     uw, iw = torch.randn(nu, d, generator=gen).to(cuda), torch.randn(ni, d, generator=gen).to(cuda)
@@ -256,7 +256,7 @@ def test_many_replays_of_a_captured_step(rbg, cuda, golden, name):
 def test_zero_fill_kernel_alignment_and_bounds(rbg, cuda):
     """The library zeroes through a fill kernel (csrc/train.hip zero_async — a captured hipMemsetAsync node writes garbage on later
     replays): any 4-byte alignment, any word count, nothing outside the range — and the same values on every replay of a graph."""
-    from recbole_gnn_amd._lib import c_vp, check, lib
+    c_vp, check, lib = rbg._lib.c_vp, rbg._lib.check, rbg._lib.lib
     tab = torch.zeros(4, 64, device=cuda)
     ptrs, wid = (c_vp * 1)(tab.data_ptr()), (ctypes.c_int * 1)(64)
     idx = torch.zeros(1, dtype=torch.int64, device=cuda)
@@ -368,7 +368,7 @@ def test_a_graph_handle_dying_inside_a_capture_does_not_invalidate_it(rbg, cuda,
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
 def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow, form):
     """BPRLoss + reg_weight * EmbLoss on the rows of cat(tables) (ngcf.py:113-126) and their gradient w.r.t. every table."""
-    from recbole_gnn_amd._lib import c_vp, check, lib
+    c_vp, check, lib = rbg._lib.c_vp, rbg._lib.check, rbg._lib.lib
     nu, ni, b, reg = 50, 70, 333, 0.37
     gen = torch.Generator().manual_seed(1)
     tabs = [torch.randn(nu + ni, w, generator=gen).to(cuda) for w in widths]
