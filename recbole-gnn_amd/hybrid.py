@@ -12,7 +12,7 @@ eighth: fewer, larger shards, fewer peers per exchange).
 What needs the other column groups is what ``colsharded.py`` lists (the loss: all-reduced partial dot products over the column
 group's peers with the same node shard) — ``gather_columns`` / ``reduce_over_columns`` here; the K layers use one process
 subgroup per column group.  UNMEASURED on more than one GPU (no multi-GPU box in five rounds); tested with gloo at 2 x 2 and
-2 x 4 ranks against the single-device oracle, forward and backward."""
+2 x 4 ranks against a single-device run of the same graph, forward and backward."""
 from __future__ import annotations
 
 import torch

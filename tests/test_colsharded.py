@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from oracle import coracle as C
 from test_sharded import CpuBackend
 
@@ -92,7 +92,7 @@ def test_gloo_column_sharded_training_step(ref_inter, world, d):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + 7 * world + d
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, uid, iid, nu, ni, d, 3, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from oracle import coracle as C
 from oracle import oracle as O
 
@@ -198,7 +198,7 @@ def test_config4_lightgcn_amazon_book_shape_four_ranks(mode):
     peers = mode.startswith("rccl")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33000 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_shard_worker, args=(r, world, port, 3, 64, q, peers)) for r in range(world)]
     for p in procs:
         p.start()

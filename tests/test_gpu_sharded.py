@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from oracle import coracle as C
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +47,7 @@ def test_two_ranks_share_one_gpu(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31000 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, uid, iid, nu, ni, 3, 64, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -180,7 +180,7 @@ def test_nccl_transport_on_a_world_size_one_group(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33000 + (os.getpid() % 2000)
+    port = free_port()
     p = ctx.Process(target=_nccl_world1_worker, args=(port, uid, iid, nu, ni, 3, 64, q))
     p.start()
     errs = q.get(timeout=600)
@@ -273,7 +273,7 @@ def test_two_ranks_device_planner_backward_view_scoring(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35000 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker_round2, args=(r, 2, port, uid, iid, nu, ni, 3, 64, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -440,7 +440,7 @@ def test_two_ranks_training_step_hip_backend(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 36500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker_train, args=(r, 2, port, uid, iid, nu, ni, 3, 64, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -532,7 +532,7 @@ def test_ranks_column_sharded_training_step_hip_backend(ref_inter, world, d):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37500 + (os.getpid() % 2000) + 5 * world + d
+    port = free_port()
     procs = [ctx.Process(target=_worker_columns, args=(r, world, port, uid, iid, nu, ni, 3, d, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -647,7 +647,7 @@ def test_real_peers_over_rccl(world, ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 38000 + (os.getpid() % 1500) + world
+    port = free_port()
     procs = [ctx.Process(target=_peers_worker, args=(r, world, port, uid, iid, nu, ni, 3, 64, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -713,7 +713,7 @@ def test_hybrid_grid_two_by_two_on_one_gpu(ref_inter):
     world, col_shards, d = 4, 2, 64
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + (os.getpid() % 1500)
+    port = free_port()
     procs = [ctx.Process(target=_hybrid_worker, args=(r, world, col_shards, port, uid, iid, nu, ni, 3, d, q)) for r in range(world)]
     for p in procs:
         p.start()

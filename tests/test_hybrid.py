@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from oracle import coracle as C
 from test_sharded import CpuBackend
 
@@ -59,7 +59,7 @@ def test_hybrid_grid_over_gloo(ref_inter, world, col_shards):
     d, k_layers = 64, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 27000 + (os.getpid() % 1500) + 11 * world + col_shards
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, col_shards, port, uid, iid, nu, ni, k_layers, d, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, free_port
 from oracle import coracle as C
 
 
@@ -153,7 +153,7 @@ def test_two_process_gloo_exchange(ref_inter, layout, world):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if layout == "striped" else 0) + 3 * world
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, uid, iid, nu, ni, 3, layout, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -330,7 +330,7 @@ def test_two_process_gloo_sgl_forward_shares_the_first_exchange(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 41
+    port = free_port()
     k_layers = 3
     procs = [ctx.Process(target=_worker3, args=(r, 2, port, uid, iid, nu, ni, k_layers, q)) for r in range(2)]
     for p in procs:
@@ -353,7 +353,7 @@ def test_two_process_gloo_backward_views_and_scoring(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 23
+    port = free_port()
     procs = [ctx.Process(target=_worker2, args=(r, 2, port, uid, iid, nu, ni, 3, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -464,7 +464,7 @@ def test_two_process_gloo_training_step(ref_inter, layout, world):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000) + (11 if layout == "striped" else 0) + 3 * world
+    port = free_port()
     procs = [ctx.Process(target=_worker_train, args=(r, world, port, uid, iid, nu, ni, 2, layout, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -537,7 +537,7 @@ def test_two_process_gloo_rw_views_have_one_plan_per_layer(ref_inter):
     uid, iid, nu, ni = ref_inter
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
+    port = free_port()
     procs = [ctx.Process(target=_worker_rw, args=(r, 2, port, uid, iid, nu, ni, 3, q)) for r in range(2)]
     for p in procs:
         p.start()
