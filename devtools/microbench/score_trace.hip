@@ -6,3 +6,5 @@ extern "C" int mb_score_trace(const float *U, const float *I, float *S, int64_t 
     (void)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_score_trace), &trace, sizeof(trace));
     return rbg_score_f32(U, d, I, d, S, B, n, d, stream);
 }
+
+extern "C" int mb_score_debug_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_score_debug), &bits, sizeof(bits)); }

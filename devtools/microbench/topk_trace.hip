@@ -8,3 +8,5 @@
 extern "C" int mb_topk_trace_set(unsigned long long *trace) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_topk_trace), &trace, sizeof(trace));
 }
+
+extern "C" int mb_topk_debug_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_topk_debug), &bits, sizeof(bits)); }

@@ -163,6 +163,8 @@ __global__ __launch_bounds__(256) void score_generic_kernel(const float *__restr
 // cycles spent up to each lap point, summed over the walk.
 #ifdef RBG_SCORE_TRACE
 __device__ unsigned long long *g_score_trace = nullptr;
+__device__ int g_score_debug = 0;  // what-if switches of the diagnostic build (results are wrong on purpose): 1 no product, 2 no stores, 4 no fetch / publish
+#define RBG_SCORE_DBG(bit) ((g_score_debug & (bit)) != 0)
 #define RBG_SCORE_T0() unsigned long long sc_last = clock64(), sc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define RBG_SCORE_LAP(k)                         \
     do {                                         \
@@ -177,6 +179,7 @@ __device__ unsigned long long *g_score_trace = nullptr;
                 g_score_trace[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = sc_acc[k];           \
     } while (0)
 #else
+#define RBG_SCORE_DBG(bit) false
 #define RBG_SCORE_T0() ((void)0)
 #define RBG_SCORE_LAP(k) ((void)0)
 #define RBG_SCORE_DUMP() ((void)0)
@@ -341,10 +344,10 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
     for (int64_t t = t0; t < t1; ++t) {
         const int buf = (int)(t - t0) & 1;
         f32x16 acc = zero;
-        if (wave_live) acc = tile_product(buf);
-        if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
-        if (t + 2 < t1) fetch(t + 2);
-        if (wave_live) emit(t, acc);
+        if (wave_live && !RBG_SCORE_DBG(1)) acc = tile_product(buf);
+        if (t + 1 < t1 && !RBG_SCORE_DBG(4)) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+        if (t + 2 < t1 && !RBG_SCORE_DBG(4)) fetch(t + 2);
+        if (wave_live && !(RBG_SCORE_DBG(2) && acc[0] != 12345.678f)) emit(t, acc);
         __syncthreads();
     }
 }

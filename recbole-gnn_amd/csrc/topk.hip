@@ -91,11 +91,10 @@ __device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t 
     return false;
 }
 
-// Prune one user's LDS list (<= 64 raw candidates) to its best k valid entries (sorted).  Returns the new
+// Prune one user's LDS list (n <= 64 raw candidates) to its best k valid entries (sorted; `kept` of them).  Returns the new
 // threshold: the k-th best (or -inf while fewer than k exist).
-__device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, float *lv, int *li, int *cnt, int lane) {
+__device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, float *lv, int *li, int n, int lane, int &kept) {
     __builtin_amdgcn_wave_barrier();  // lists are handed between lanes of ONE wave through LDS: keep program order
-    const int n = *cnt;
     float v = lane < n ? lv[lane] : kNegInf;
     int idx = lane < n ? li[lane] : 0x7fffffff;
     if (p.filter_history && lane < n && in_history(p.rowptr, p.col, p.n_users, user, idx)) {
@@ -108,8 +107,7 @@ __device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, f
         lv[lane] = v;
         li[lane] = idx;
     }
-    const int kept = valid < p.k ? valid : p.k;
-    if (lane == 0) *cnt = kept;
+    kept = valid < p.k ? valid : p.k;
     __builtin_amdgcn_wave_barrier();
     return __shfl(v, p.k - 1);
 }
@@ -142,6 +140,8 @@ using ItemTileMem = std::conditional_t<SPLIT, typename RowTile3<NCHUNK, (VEC ? R
 // Per-wave phase clock (devtools/microbench/topk_trace.hip builds this file with RBG_TOPK_TRACE; the product does not).
 #ifdef RBG_TOPK_TRACE
 __device__ unsigned long long *g_topk_trace = nullptr;
+__device__ int g_topk_debug = 0;  // what-if switches of the diagnostic build (results are wrong on purpose): 1 no product, 2 no filter, 4 no fetch / publish
+#define RBG_TOPK_DBG(bit) ((g_topk_debug & (bit)) != 0)
 #define RBG_TOPK_T0() unsigned long long tk_last = clock64(), tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define RBG_TOPK_LAP(k)                              \
     do {                                             \
@@ -156,10 +156,56 @@ __device__ unsigned long long *g_topk_trace = nullptr;
                 g_topk_trace[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + k] = tk_acc[k];      \
     } while (0)
 #else
+#define RBG_TOPK_DBG(bit) false
 #define RBG_TOPK_T0() ((void)0)
 #define RBG_TOPK_LAP(k) ((void)0)
 #define RBG_TOPK_DUMP() ((void)0)
 #endif
+
+// r05: the threshold test as ONE MORE MFMA.  tst = acc + (-tau) x 1 through three k-slots of a seventh / twenty-fifth product: the
+// A operand of user row i carries the three bf16 terms of -tau_i (lane half 0, slots 0-2; everything else zero), the B operand a
+// one in the same slots, and D is a second register block, so acc keeps the pure score.  The per-tile filter is then a v_max3
+// tree over tst (8 instructions) + one compare + one ballot instead of 16 x {compare, select, or} against 16 threshold registers
+// — every vector instruction of this kernel issues beside another wave's MFMA stream and costs 4 SIMD cycles, the extra MFMA 32.
+// The comparison is made conservative (tau lowered by 8 ulp: the matrix core's summation order is its own), so everything that
+// reaches the old test's threshold still passes; an entry that passes from just below it is dropped by the prunes / the merge
+// like any other non-winner.  -inf / +inf thresholds become -/+ 3e38.
+template <bool SPLIT>
+struct TauTest;
+template <>
+struct TauTest<true> {
+    bf16x8 a, one;
+    __device__ __forceinline__ void init(int h) {
+        const __bf16 z = (__bf16)0.0f, o = (__bf16)1.0f;
+        a = bf16x8{z, z, z, z, z, z, z, z};
+        one = h == 0 ? bf16x8{o, o, o, z, z, z, z, z} : bf16x8{z, z, z, z, z, z, z, z};
+    }
+    __device__ __forceinline__ void set(float tau, int h) {
+        float t = fminf(fmaxf(tau, -3.0e38f), 3.0e38f);
+        t = fabsf(t) * 4.8e-7f - t;  // -(tau - 8 ulp)
+        bf16x2 hh, mm, ll;
+        split2_bf16(t, 0.f, hh, mm, ll);
+        if (h == 0) {
+            a[0] = hh[0];
+            a[1] = mm[0];
+            a[2] = ll[0];
+        }
+    }
+    __device__ __forceinline__ f32x16 run(const f32x16 &acc) const { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, one, acc, 0, 0, 0); }
+};
+template <>
+struct TauTest<false> {  // the exact-fp32 chain: one v_mfma_f32_32x32x2_f32 (lane half h supplies k = h)
+    float a, one;
+    __device__ __forceinline__ void init(int h) {
+        a = 0.f;
+        one = h == 0 ? 1.f : 0.f;
+    }
+    __device__ __forceinline__ void set(float tau, int h) {
+        const float t = fminf(fmaxf(tau, -3.0e38f), 3.0e38f);
+        if (h == 0) a = fabsf(t) * 4.8e-7f - t;
+    }
+    __device__ __forceinline__ f32x16 run(const f32x16 &acc) const { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, one, acc, 0, 0, 0); }
+};
 
 // CAP = list capacity per user: a prune leaves <= k entries and one tile adds <= 32, so CAP >= k + 32 (48 for k <= 16,
 // which lets two workgroups share a CU's LDS; 64 otherwise).
@@ -173,12 +219,11 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     __shared__ float l_val[4][32][CAP];
     __shared__ int l_idx[4][32][CAP];
-    __shared__ int l_cnt[4][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;  // first batch slot of this wave's user tile
     const bool wave_live = b0 < p.B;                            // an idle wave still fetches and meets the barriers
-    if (lane < 32) l_cnt[wave][lane] = 0;
+    int my_cnt = 0;  // entries in the list of batch slot b0 + i (both lane halves keep it: read by v_readlane, no LDS round trip)
     // A operand: the embedding row of batch slot b0 + i
     const int64_t bi = b0 + i;
     const int64_t my_user = bi < p.B ? p.users[bi] : -1;
@@ -193,104 +238,108 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
         else return Tiles::product(s_it[buf], a, i, h);
     };
     // thresholds start at the pre-pass bound: an item scoring below the k-th best valid score of ANY item subset
-    // cannot be in the top k.  tau[r] belongs to the user of accumulator row (r&3) + 8*(r>>2) + 4h.
+    // cannot be in the top k.  Lane i (both halves) keeps the threshold of batch slot b0 + i; a slot past the end never passes.
 #ifdef RBG_TOPK_TRACE_NOPASS  // (diagnostic build only: nothing ever passes the threshold)
-    const float my_tau = __builtin_inff();
+    float my_tau = __builtin_inff();
 #else
-    const float my_tau = (p.tau0 && bi < p.B) ? p.tau0[bi] : kNegInf;
+    float my_tau = bi < p.B ? (p.tau0 ? p.tau0[bi] : kNegInf) : __builtin_inff();
 #endif
-    float tau[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float tv = __shfl(my_tau, src);
-        tau[r] = (b0 + src < p.B) ? tv : __builtin_inff();  // a row past the end never passes (thresholds only rise)
-    }
+    if (RBG_TOPK_DBG(8)) my_tau = __builtin_inff();
+    TauTest<SPLIT> tt;
+    tt.init(h);
+    tt.set(my_tau, h);
     const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
 
+    RBG_TOPK_T0();
     // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
     auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
-        // r05: ONE branch per tile in the common case.  r04's form — a compare, a ballot and a branch per row — cost 1 320 cycles per
-        // tile with NOTHING passing (16 serial v_cmp -> SGPR -> s_cbranch chains beside the other wave's MFMAs: the phase clock had
-        // the matrix pipe 36 % busy).  Here every lane collects its rows' tests in a bit mask with vector instructions alone
-        // (v_cmp / v_cndmask / v_or: no scalar round trip), one ballot says whether any lane has a bit, and only then the rows
-        // that do are visited (their union comes from the few lanes that have one).  Same predicate, same visiting order:
-        // identical lists.  (r02's trap stays avoided: no per-row lane masks live in scalar registers.)
+        // ONE branch per tile in the common case (r04's form — a compare, a ballot and a branch per row — cost 1 320 cycles per tile
+        // with NOTHING passing; r05 first collected per-lane row masks with 48 vector instructions).  Now: tst = score - tau from the
+        // matrix core (TauTest), a max3 tree, one compare, one ballot; only a tile with a passing entry builds the row masks and
+        // visits the rows that have one (their union comes from the few lanes that do).  Same visiting order as before.
         const bool item_ok = item < p.n_items && item != 0;
+        const f32x16 tst = tt.run(acc);
+        const float m01 = fmaxf(fmaxf(tst[0], tst[1]), tst[2]), m02 = fmaxf(fmaxf(tst[3], tst[4]), tst[5]);
+        const float m03 = fmaxf(fmaxf(tst[6], tst[7]), tst[8]), m04 = fmaxf(fmaxf(tst[9], tst[10]), tst[11]);
+        const float m05 = fmaxf(fmaxf(tst[12], tst[13]), tst[14]);
+        const float mx = fmaxf(fmaxf(fmaxf(fmaxf(m01, m02), m03), fmaxf(fmaxf(m04, m05), tst[15])), -1.f);  // (NaN rows never pass)
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(item_ok && mx >= 0.f);
+        RBG_TOPK_LAP(3);
+        if (any == 0ull) return;  // the common case once the thresholds have risen
         unsigned bits = 0u;
         RowLoop<0>::run([&](auto rc) {
             constexpr int r = decltype(rc)::value;
-            bits |= (acc[r] >= tau[r]) ? (1u << r) : 0u;
+            bits |= (tst[r] >= 0.f) ? (1u << r) : 0u;
         });
         if (!item_ok) bits = 0u;
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(bits != 0u);
-        if (any == 0ull) return;  // the common case once the thresholds have risen
         unsigned rows = 0u;
         for (unsigned long long m = any; m; m &= m - 1ull) rows |= (unsigned)__builtin_amdgcn_readlane((int)bits, __builtin_ctzll(m));
-        RowLoop<0>::run([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            if (!(rows & (1u << r))) return;
+        // r05: ONE copy of the list code, walked over the set bits (the score leaves the accumulator block by a register-indexed
+        // move).  Unrolled per row and lane half it was 32 copies, each with its own 64-lane bitonic sort: 23 000 instructions in this
+        // kernel, and a tile with a passing entry (70 % of them on propagated embeddings) ran a different copy each time — the
+        // instruction cache, not the vector unit, paid for the filter.
+#pragma clang loop unroll(disable)
+        while (rows != 0u) {
+            const int r = __builtin_ctz(rows);
+            rows &= rows - 1u;
             const float s = acc[r];
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(((bits >> r) & 1u) != 0u);
-            const bool pass = (mask >> lane) & 1ull;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {  // the two lane halves hold two different users
-                const unsigned m = hh ? (unsigned)(mask >> 32) : (unsigned)mask;
-                if (m == 0u) continue;
-                const int lu = (r & 3) + 8 * (r >> 2) + 4 * hh;  // user slot inside the tile
+            // the two lane halves hold two different users (list slots lu0 and lu0 + 4); both are served at once when both lists
+            // have room: two counter reads (v_readlane: the counts live in registers), one rank, two LDS writes — no LDS read, no
+            // inner loop, no wave barrier
+            const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+            const int lu0 = (r & 3) + 8 * (r >> 2);
+            const int base0 = __builtin_amdgcn_readlane(my_cnt, lu0), base1 = __builtin_amdgcn_readlane(my_cnt, lu0 + 4);
+            const int add0 = __popc(lo), add1 = __popc(hi);
+            if (base0 + add0 <= CAP && base1 + add1 <= CAP) {
+                const unsigned mh = h ? hi : lo;
+                if ((mh >> i) & 1u) {
+                    const int slot = (h ? base1 : base0) + __popc(mh & ((1u << i) - 1u));
+                    l_val[wave][lu0 + 4 * h][slot] = s;
+                    l_idx[wave][lu0 + 4 * h][slot] = (int)item;
+                }
+                my_cnt += (i == lu0 ? add0 : 0) + (i == lu0 + 4 ? add1 : 0);
+                continue;
+            }
+#pragma clang loop unroll(disable)
+            for (int hh = 0; hh < 2; ++hh) {  // a list overflows (rare: the thresholds start at the pre-pass bound): one half at a time
+                unsigned rem = hh ? hi : lo;
+                if (rem == 0u) continue;
+                const int lu = lu0 + 4 * hh;  // user slot inside the tile
                 float *lv = l_val[wave][lu];
                 int *li = l_idx[wave][lu];
-                int base = l_cnt[wave][lu];
-                if constexpr (CAP >= 48) {
-                    const int add = __popc(m);
-                    if (base + add > CAP) {  // full: prune to the best k valid ones (CAP >= k + 32, so 32 arrivals then fit)
-                        const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
-                        if (h == hh) tau[r] = fmaxf(tau[r], nt);
-                        base = l_cnt[wave][lu];
-                    }
-                    if (h == hh && pass) {
-                        const int slot = base + __popc(m & ((1u << i) - 1u));
-                        lv[slot] = s;
-                        li[slot] = (int)item;
-                    }
-                    if (lane == 0) l_cnt[wave][lu] = base + add;
-                    __builtin_amdgcn_wave_barrier();
-                } else {
-                    // short lists (three workgroups per CU): a tile's arrivals may not fit even after a prune — fill the list,
-                    // prune, go on with the rest (rare: the thresholds start at the pre-pass bound)
-                    unsigned rem = m;
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    while (true) {
-                        const int add = __popc(rem);
-                        const bool mine = h == hh && ((rem >> i) & 1u);
-                        const int rank = __popc(rem & ((1u << i) - 1u));
-                        if (base + add <= CAP) {
-                            if (mine) {
-                                lv[base + rank] = s;
-                                li[base + rank] = (int)item;
-                            }
-                            if (lane == 0) l_cnt[wave][lu] = base + add;
-                            __builtin_amdgcn_wave_barrier();
-                            break;
-                        }
-                        const int room = CAP - base;
-                        if (mine && rank < room) {
+                int base = hh ? base1 : base0;
+                // fill the list to CAP, prune it to its best k valid entries (that raises the user's threshold), go on with the rest
+                while (true) {
+                    const int add = __popc(rem);
+                    const bool mine = h == hh && ((rem >> i) & 1u);
+                    const int rank = __popc(rem & ((1u << i) - 1u));
+                    if (base + add <= CAP) {
+                        if (mine) {
                             lv[base + rank] = s;
                             li[base + rank] = (int)item;
                         }
-                        for (int q = 0; q < room; ++q) rem &= rem - 1u;  // those lanes are in
-                        if (lane == 0) l_cnt[wave][lu] = CAP;
-                        const float nt = prune_list(p, __shfl(my_user, lu), lv, li, &l_cnt[wave][lu], lane);
-                        if (h == hh) tau[r] = fmaxf(tau[r], nt);
-                        base = __builtin_amdgcn_readfirstlane(l_cnt[wave][lu]);
+                        base += add;
+                        break;
+                    }
+                    const int room = CAP - base;
+                    if (mine && rank < room) {
+                        lv[base + rank] = s;
+                        li[base + rank] = (int)item;
+                    }
+                    for (int q = 0; q < room; ++q) rem &= rem - 1u;  // those lanes are in
+                    const float nt = prune_list(p, __shfl(my_user, lu), lv, li, CAP, lane, base);
+                    if (i == lu) {  // (both halves keep the value; lane half 0 carries the operand)
+                        my_tau = fmaxf(my_tau, nt);
+                        tt.set(my_tau, h);
                     }
                 }
+                if (i == lu) my_cnt = base;
             }
-        });
+        }
     };
     Tiles tiles;
-    RBG_TOPK_T0();
     if (t_begin < t_end) {
         tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
         tiles.publish(s_it[0], tid);
@@ -299,18 +348,19 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     RBG_TOPK_LAP(0);
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
-        if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
+        if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
         RBG_TOPK_LAP(1);
         if (wave_live) {
-            const f32x16 acc = tile_product(buf);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!RBG_TOPK_DBG(1)) acc = tile_product(buf);
             RBG_TOPK_LAP(2);
-            filter_tile(acc, t * 32 + i);
+            if (!(RBG_TOPK_DBG(2) && acc[0] != 12345.678f)) filter_tile(acc, t * 32 + i);
         }
-        RBG_TOPK_LAP(3);
-        if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         RBG_TOPK_LAP(4);
-        __syncthreads();
+        if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         RBG_TOPK_LAP(5);
+        __syncthreads();
+        RBG_TOPK_LAP(6);
     }
     RBG_TOPK_DUMP();
     if (!wave_live) return;
@@ -320,9 +370,9 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     for (int lu = 0; lu < 32; ++lu) {
         const int64_t b = b0 + lu;
         if (b >= p.B) break;
+        int n = __builtin_amdgcn_readlane(my_cnt, lu);
+        if (n > kListStride) prune_list(p, __shfl(my_user, lu), l_val[wave][lu], l_idx[wave][lu], n, lane, n);
         __builtin_amdgcn_wave_barrier();
-        if (l_cnt[wave][lu] > kListStride) prune_list(p, __shfl(my_user, lu), l_val[wave][lu], l_idx[wave][lu], &l_cnt[wave][lu], lane);
-        const int n = l_cnt[wave][lu];
         const int64_t off = (b * lists + my_list) * kListStride;
         if (lane < n) {
             p.w_val[off + lane] = l_val[wave][lu][lane];
@@ -440,7 +490,10 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
 // them 32 at a time into the upper half-wave, masks history items (one 32-lane-parallel binary search per batch) and
 // bitonic-merges them into the running best 32 held by the lower half-wave.
 // tau_out != NULL (pre-pass): no mask while merging; afterwards the k-th VALID one of the 32 best becomes the bound.
-constexpr int kStage = 2048;
+// r05: 512 staged entries per wave (it was 2048: 64 KB of LDS per workgroup = 8 resident waves per CU and two rounds of them for
+// 4096 users, each wave a chain of dependent loads — 28 us); history items are masked while they are copied (every lane searches
+// the user's graph row for its own entries, once), not once per batch of 32 in the merge loop.
+constexpr int kStage = 512;
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ w_val, const int32_t *__restrict__ w_idx,
                                                         const int32_t *__restrict__ w_cnt, const int64_t *__restrict__ users,
                                                         const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -464,10 +517,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
                 const int e = base + lane - 32;
                 v = e < total ? s_val[wave][e] : kNegInf;
                 idx = e < total ? s_idx[wave][e] : 0x7fffffff;
-                if (mask_now && e < total && in_history(rowptr, col, n_users, user, idx)) {
-                    v = kNegInf;
-                    idx = 0x7fffffff;
-                }
             }
             wave_sort_desc(v, idx, lane);
             if (lane >= 32) {
@@ -477,24 +526,30 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
         }
         total = 0;
     };
-    for (int l0 = 0; l0 < lists; l0 += 32) {
-        // 32 lists per round: lane pair (2j, 2j+1) copies list l0 + j (entries e = lane&1, +2, ...)
-        const int l = l0 + (lane >> 1);
+    for (int l0 = 0; l0 < lists; l0 += 16) {
+        // 16 lists per round (at most 16 x 32 = kStage entries): lane quad 4j .. 4j + 3 copies list l0 + j (entries e = lane & 3, + 4, ...)
+        const int l = l0 + (lane >> 2);
         const int c = l < lists ? w_cnt[b * lists + l] : 0;
-        // exclusive prefix of the counts over the 32 lists (each list appears on two lanes: count it once)
-        int incl = (lane & 1) ? 0 : c;
+        // exclusive prefix of the counts over the 16 lists (each list appears on four lanes: count it once)
+        int incl = (lane & 3) ? 0 : c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int up = __shfl_up(incl, off);
             if (lane >= off) incl += up;
         }
         const int round_total = __shfl(incl, 63);
-        const int my_off = __shfl(incl, lane | 1) - c;  // start of this list inside the round
+        const int my_off = __shfl(incl, lane | 3) - c;  // start of this list inside the round
         if (total + round_total > kStage) flush();
         const int64_t src = (b * lists + l) * kListStride;
-        for (int e = lane & 1; e < c; e += 2) {
-            s_val[wave][total + my_off + e] = w_val[src + e];
-            s_idx[wave][total + my_off + e] = w_idx[src + e];
+        for (int e = lane & 3; e < c; e += 4) {
+            float ev = w_val[src + e];
+            int ei = w_idx[src + e];
+            if (mask_now && in_history(rowptr, col, n_users, user, ei)) {
+                ev = kNegInf;
+                ei = 0x7fffffff;
+            }
+            s_val[wave][total + my_off + e] = ev;
+            s_idx[wave][total + my_off + e] = ei;
         }
         total += round_total;
     }
