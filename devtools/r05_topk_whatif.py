@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """r05: what each part of score_topk_kernel costs on PROPAGATED embeddings (the bench's case) — the RBG_TOPK_TRACE build's what-if
-switches (results are wrong on purpose): 1 = no product, 2 = no filter, 4 = no fetch / publish after the first tile, 8 = nothing passes the threshold.
+switches (results are wrong on purpose): 1 = no product, 2 = no filter, 4 = no fetch / publish after the first tile, 8 = nothing passes the threshold, 16 = no raised priority between the product and the barrier.
 `prof` = five plain calls of the product library for rocprofv3.  -> gpurun_out/r05_topk_whatif.jsonl"""
 import json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -52,7 +52,7 @@ if plain:
            "random_us": [round(timeit(rnd), 1) for _ in range(3)]}
     print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n")
     sys.exit(0)
-for bits in (0, 1, 2, 8, 9, 10, 0):
+for bits in (0, 1, 2, 8, 16, 0):
     assert lib.mb_topk_debug_set(bits) == 0
     rec = {"what": "topk_whatif", "bits": bits, "us": round(timeit(call), 1)}
     print(json.dumps(rec), flush=True); log.write(json.dumps(rec) + "\n"); log.flush()

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) voi
 // ds_bpermute per tile in score_kernel, where a wave spent 53 % of its time), no carried half lines (16 registers), no
 // head / tail code beyond a column mask on the first and the last tile.  Used when every class holds >= 64 users
 // (B >= 64 q; the reference's own evaluation batches of a few users keep score_kernel).
-// (a fourth resident workgroup per CU — the 16 carry registers are gone — measured 161 vs 157 us: three it stays)
+// (a fourth resident workgroup per CU — the 16 carry registers are gone — measured 161 vs 157 us: three it stays;
+//  r05: raised priority between the product and the barrier, which pays in topk.hip, measured 167.4 vs 167.2-168.8 us here: not kept)
 template <int NCHUNK, bool VEC, bool FAST, bool SPLIT>
 __global__ __launch_bounds__(256, (NCHUNK == 1 ? 3 : (NCHUNK == 2 ? 2 : 1))) void score_uni_kernel(const float *__restrict__ U, int64_t ldu,
                                                     const float *__restrict__ I, int64_t ldi, float *__restrict__ S,

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
 
+    const bool opt_prio = !RBG_TOPK_DBG(16);
     RBG_TOPK_T0();
     // filter one finished tile: acc[r] is the score of (user row (r&3)+8(r>>2)+4h, item); the PAD item never qualifies
     auto filter_tile = [&](const f32x16 &acc, const int64_t item) __attribute__((always_inline)) {
@@ -354,12 +355,16 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (!RBG_TOPK_DBG(1)) acc = tile_product(buf);
             RBG_TOPK_LAP(2);
+            // everything between the product and the barrier is on the workgroup's critical path and made of short dependent
+            // vector <-> scalar chains: at raised priority its instructions win the issue slots between the other waves' MFMAs
+            if (opt_prio) __builtin_amdgcn_s_setprio(2);  // (r05: 241 -> 236 us per call in the diagnostic build; priority 3, or the fetch raised as well: no better / worse)
             if (!(RBG_TOPK_DBG(2) && acc[0] != 12345.678f)) filter_tile(acc, t * 32 + i);
         }
         RBG_TOPK_LAP(4);
         if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         RBG_TOPK_LAP(5);
         __syncthreads();
+        if (opt_prio) __builtin_amdgcn_s_setprio(0);
         RBG_TOPK_LAP(6);
     }
     RBG_TOPK_DUMP();
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
         if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
         if (wave_live) {
             const f32x16 acc = tile_product(buf);
+            if (!RBG_TOPK_DBG(16)) __builtin_amdgcn_s_setprio(2);
             const int64_t item = t * 32 + i;
             const bool item_ok = item < p.n_items && item != 0;
             RowLoop<0>::run([&](auto rc) {
@@ -442,6 +448,7 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
         }
         if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);
         __syncthreads();
+        if (!RBG_TOPK_DBG(16)) __builtin_amdgcn_s_setprio(0);
     }
     if (!wave_live) return;
     // lane (i, h) holds group i of user slot (r&3) + 8(r>>2) + 4h for r = 0..15
