@@ -301,6 +301,11 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
              "neg_item_id": torch.randint(1, ni, (2048,), generator=g).to(dev)}
     fused = rbg.FusedBPRAdam(model, lr=1e-3)
     ex["train_step_fused_us(batch 2048, fwd + BPR + bwd + Adam)"] = time_us(lambda: fused.step(batch))
+    rbg.set_option("deterministic", 1)  # the same step with ordered row scatters and one-workgroup sums (bit-stable; csrc/ordered.h)
+    try:
+        ex["train_step_fused_deterministic_us"] = time_us(lambda: fused.step(batch))
+    finally:
+        rbg.set_option("deterministic", 0)
     users = torch.randint(1, nu, (4096,), generator=g).to(dev)
     with torch.no_grad():
         model.full_sort_topk({"user_id": users}, 10)

@@ -27,6 +27,7 @@
 
 #include "internal.h"
 #include "mfma_common.h"
+#include "ordered.h"
 
 namespace rbg {
 
@@ -583,29 +584,49 @@ __global__ __launch_bounds__(256) void nce_loss_kernel(const float *__restrict__
 // Batch rows, backward: gA = dA[b] - weight*scale*C[r]  (lse term + positive term), pushed through normalize into
 // grad_T1[r]; the positive term's gradient on the table side, -weight*scale*A[b], is added to dC[r].  r = idx[b] may
 // repeat inside a batch: float atomics, like torch's GPU index_add.
-__global__ __launch_bounds__(256) void nce_batch_back_kernel(const float *__restrict__ dA, const float *__restrict__ A,
-                                                             const float *__restrict__ C, const float *__restrict__ inv1,
-                                                             const float *__restrict__ T1, const int64_t *__restrict__ idx, int64_t B,
-                                                             int d, float ws, float *__restrict__ dC, float *__restrict__ grad_T1) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int64_t r = idx[b];
+struct NceBackArgs {
+    const float *dA, *A, *C, *inv1;
+    const int64_t *idx;
+    int64_t B;
+    int d;
+    float ws;
+    float *dC, *grad_T1;
+};
+
+template <bool ORDERED>
+__device__ __forceinline__ void nce_batch_back_elem(const NceBackArgs &a, int64_t b, int lane) {
+    const int d = a.d;
+    const int64_t r = a.idx[b];
     float dot = 0.f;
     for (int c = lane; c < d; c += 64) {
-        const float g = dA[b * d + c] - ws * C[r * d + c];
-        dot = fmaf(g, A[b * d + c], dot);
+        const float g = a.dA[b * d + c] - a.ws * a.C[r * d + c];
+        dot = fmaf(g, a.A[b * d + c], dot);
     }
     dot = wave_sum(dot);
-    const float iv = inv1[b];
+    const float iv = a.inv1[b];
     const bool clamped = iv >= 1.0f / kNormEps;  // ||x|| < eps: normalize is x / eps, a plain scaling
     for (int c = lane; c < d; c += 64) {
-        const float a = A[b * d + c];
-        const float g = dA[b * d + c] - ws * C[r * d + c];
-        if (grad_T1) atomicAdd(grad_T1 + r * d + c, (clamped ? g : g - a * dot) * iv);
-        atomicAdd(dC + r * d + c, -ws * a);
+        const float av = a.A[b * d + c];
+        const float g = a.dA[b * d + c] - a.ws * a.C[r * d + c];
+        if (a.grad_T1) row_add<ORDERED>(a.grad_T1 + r * d + c, (clamped ? g : g - av * dot) * iv);
+        row_add<ORDERED>(a.dC + r * d + c, -a.ws * av);
     }
 }
+
+__global__ __launch_bounds__(256) void nce_batch_back_kernel(const NceBackArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    nce_batch_back_elem<false>(a, b, threadIdx.x & 63);
+}
+
+// option "deterministic" (ordered.h): the rows of a repeated id are written by the wavefront of its first occurrence, in batch order.
+// NOTE: an occurrence reads C[r] and writes dC[r] / grad_T1[r] — different buffers — so owners and non-owners never race.
+struct NceBackRows {
+    NceBackArgs a;
+    __device__ __forceinline__ int64_t key(int64_t m) const { return a.idx[m]; }
+    __device__ __forceinline__ void range(int64_t, int64_t &lo, int64_t &hi) const { lo = 0, hi = a.B; }
+    __device__ __forceinline__ void apply(int64_t m, int lane) const { nce_batch_back_elem<true>(a, m, lane); }
+};
 
 // Table rows, backward of C = normalize(T2): grad_T2[j] += (g - C[j] <g, C[j]>) * inv[j],  g = dC[j].
 __global__ __launch_bounds__(256) void nce_table_back_kernel(const float *__restrict__ dC, const float *__restrict__ C,
@@ -654,40 +675,61 @@ __global__ __launch_bounds__(256) void nce_sum_kernel(const float *__restrict__ 
 }
 
 // nce_batch_back_kernel with dA[b] = coef[b] * sum_c part_q[c][b] formed here (the chunk reduction of the batch-side gradient)
-__global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const float *__restrict__ part_q, int n_chunks, const float *__restrict__ coef,
-                                                                   const float *__restrict__ A, const float *__restrict__ C,
-                                                                   const float *__restrict__ inv1, const int64_t *__restrict__ idx,
-                                                                   const float *__restrict__ row_w, int64_t B, int d, float ws,
-                                                                   float *__restrict__ dC, float *__restrict__ grad_T1) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const int64_t r = idx[b];
-    const float cb = coef[b];
-    if (row_w) ws *= row_w[b];  // the positive term carries the row's weight too
+struct NceBackPartsArgs {
+    const float *part_q;
+    int n_chunks;
+    const float *coef, *A, *C, *inv1;
+    const int64_t *idx;
+    const float *row_w;
+    int64_t B;
+    int d;
+    float ws;
+    float *dC, *grad_T1;
+};
+
+template <bool ORDERED>
+__device__ __forceinline__ void nce_batch_back_parts_elem(const NceBackPartsArgs &a, int64_t b, int lane) {
+    const int d = a.d;
+    const int64_t B = a.B;
+    const int64_t r = a.idx[b];
+    const float cb = a.coef[b];
+    const float ws = a.row_w ? a.ws * a.row_w[b] : a.ws;  // the positive term carries the row's weight too
     float g0 = 0.f, g1 = 0.f;  // d <= 128: columns lane and lane + 64
     const bool in0 = lane < d, in1 = lane + 64 < d;
 #pragma unroll 8
-    for (int c = 0; c < n_chunks; ++c) {  // (unrolled: the chunks' loads go out together instead of one latency each)
-        const float *src = part_q + ((int64_t)c * B + b) * d;
+    for (int c = 0; c < a.n_chunks; ++c) {  // (unrolled: the chunks' loads go out together instead of one latency each)
+        const float *src = a.part_q + ((int64_t)c * B + b) * d;
         g0 += in0 ? src[lane] : 0.f;
         g1 += in1 ? src[lane + 64] : 0.f;
     }
-    g0 = lane < d ? g0 * cb - ws * C[r * d + lane] : 0.f;
-    g1 = lane + 64 < d ? g1 * cb - ws * C[r * d + lane + 64] : 0.f;
-    const float a0 = lane < d ? A[b * d + lane] : 0.f, a1 = lane + 64 < d ? A[b * d + lane + 64] : 0.f;
+    g0 = lane < d ? g0 * cb - ws * a.C[r * d + lane] : 0.f;
+    g1 = lane + 64 < d ? g1 * cb - ws * a.C[r * d + lane + 64] : 0.f;
+    const float a0 = lane < d ? a.A[b * d + lane] : 0.f, a1 = lane + 64 < d ? a.A[b * d + lane + 64] : 0.f;
     const float dot = wave_sum(fmaf(g0, a0, g1 * a1));
-    const float iv = inv1[b];
+    const float iv = a.inv1[b];
     const bool clamped = iv >= 1.0f / kNormEps;
     if (lane < d) {
-        if (grad_T1) atomicAdd(grad_T1 + r * d + lane, (clamped ? g0 : g0 - a0 * dot) * iv);
-        atomicAdd(dC + r * d + lane, -ws * a0);
+        if (a.grad_T1) row_add<ORDERED>(a.grad_T1 + r * d + lane, (clamped ? g0 : g0 - a0 * dot) * iv);
+        row_add<ORDERED>(a.dC + r * d + lane, -ws * a0);
     }
     if (lane + 64 < d) {
-        if (grad_T1) atomicAdd(grad_T1 + r * d + lane + 64, (clamped ? g1 : g1 - a1 * dot) * iv);
-        atomicAdd(dC + r * d + lane + 64, -ws * a1);
+        if (a.grad_T1) row_add<ORDERED>(a.grad_T1 + r * d + lane + 64, (clamped ? g1 : g1 - a1 * dot) * iv);
+        row_add<ORDERED>(a.dC + r * d + lane + 64, -ws * a1);
     }
 }
+
+__global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const NceBackPartsArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    nce_batch_back_parts_elem<false>(a, b, threadIdx.x & 63);
+}
+
+struct NceBackPartsRows {
+    NceBackPartsArgs a;
+    __device__ __forceinline__ int64_t key(int64_t m) const { return a.idx[m]; }
+    __device__ __forceinline__ void range(int64_t, int64_t &lo, int64_t &hi) const { lo = 0, hi = a.B; }
+    __device__ __forceinline__ void apply(int64_t m, int lane) const { nce_batch_back_parts_elem<true>(a, m, lane); }
+};
 
 // nce_table_back_kernel with g = sum_c part_c[c][j] formed here (the chunk reduction of the table-side gradient; the batch rows'
 // positive-term contributions were added onto chunk 0 by the kernel above)
@@ -772,8 +814,11 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
-    hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale,
-                       part_c, grad_T1);
+    {
+        const NceBackPartsArgs ba{part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale, part_c, grad_T1};
+        if (opt_deterministic()) launch_ordered_scatter(NceBackPartsRows{ba}, B, s);
+        else hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, ba);
+    }
     RBG_HIP(hipGetLastError());
     if (grad_T2) {
         hipLaunchKernelGGL(nce_table_back_parts_kernel, dim3(nb), dim3(256), 0, s, part_c, L.nc_c, C, inv2, n, d, grad_T2);
@@ -824,7 +869,11 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     if (!grads) return RBG_OK;
     rc = rbg_lse_rows_backward_f32(A, d, B, C, d, n, d, scale, scale, lse, gl, dA, dC, lse_ws, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(nce_batch_back_kernel, dim3(bb), dim3(256), 0, s, dA, A, C, inv1, T1, idx, B, d, weight * scale, dC, grad_T1);
+    {
+        const NceBackArgs ba{dA, A, C, inv1, idx, B, d, weight * scale, dC, grad_T1};
+        if (opt_deterministic()) launch_ordered_scatter(NceBackRows{ba}, B, s);
+        else hipLaunchKernelGGL(nce_batch_back_kernel, dim3(bb), dim3(256), 0, s, ba);
+    }
     RBG_HIP(hipGetLastError());
     if (grad_T2) {
         hipLaunchKernelGGL(nce_table_back_kernel, dim3(nb), dim3(256), 0, s, dC, C, inv2, n, d, grad_T2);

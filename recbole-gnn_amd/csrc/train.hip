@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "ordered.h"
 
 namespace rbg {
 
@@ -54,33 +55,60 @@ int zero_async(void *ptr, size_t bytes, hipStream_t s) {
     return RBG_OK;
 }
 
-constexpr int kElemsPerWave = 4;  // batch elements per wavefront: 16 per workgroup, ONE loss atomic per workgroup
+constexpr int kElemsPerWave = 4;  // batch elements per wavefront: 16 per 256-thread workgroup, ONE loss atomic per workgroup
 // (one atomic per element on the single loss word serialised the whole kernel: 80 us for 6 144 elements)
+// Every kernel below walks its elements with a grid-stride loop and sums them in a fixed order inside a workgroup, so launched as
+// ONE workgroup of 1024 threads it is reproducible bit for bit: that is how option "deterministic" takes the loss values and the
+// block norms (kOneBlock), while the row scatters go through ordered.h.
+constexpr int kMaxWaves = 16;
+static const dim3 kOneBlock(1024);
 
-__device__ __forceinline__ void block_add_loss(float part, float *loss) {
-    __shared__ float red[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// the workgroup's waves' partial sums, added in wave order (pairwise for the usual four)
+__device__ __forceinline__ float block_sum(float part, float *red) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
     if (lane == 0) red[wave] = part;
     __syncthreads();
+    float s = 0.f;
     if (threadIdx.x == 0) {
-        const float s = (red[0] + red[1]) + (red[2] + red[3]);
-        if (s != 0.f) atomicAdd(loss, s);
+        if (nw == 4) s = (red[0] + red[1]) + (red[2] + red[3]);
+        else
+            for (int w = 0; w < nw; ++w) s += red[w];
     }
+    return s;  // valid in thread 0
 }
 
-// one wavefront per kElemsPerWave batch elements
-__global__ __launch_bounds__(256) void bpr_grad_kernel(const float *__restrict__ mean, int64_t n_users,
-                                                       const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
-                                                       const int64_t *__restrict__ neg, int64_t B, int d, float gamma,
-                                                       float *__restrict__ grad_mean, float *__restrict__ loss) {
-    const int lane = threadIdx.x & 63;
-    float loss_part = 0.f;
-    for (int e = 0; e < kElemsPerWave; ++e) {
-    const int64_t b = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
-    if (b >= B) break;
-    const float *ue = mean + user[b] * d;
-    const float *pe = mean + (n_users + pos[b]) * d;
-    const float *ne = mean + (n_users + neg[b]) * d;
+__device__ __forceinline__ void block_add_loss(float part, float *loss) {
+    __shared__ float red[kMaxWaves];
+    const float s = block_sum(part, red);
+    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s);
+}
+
+// element groups of kElemsPerWave a wave walks: grp = first, first + stride, ...
+#define RBG_FOR_GROUPS(grp, n_elems)                                                                  \
+    for (int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); grp * kElemsPerWave < (n_elems); \
+         grp += (int64_t)gridDim.x * (blockDim.x >> 6))
+
+static inline dim3 grid_for(int64_t n_elems) { return dim3((unsigned)((n_elems + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))); }
+
+// ---- BPR on the layer mean (lightgcn.py:98-100) ---------------------------------------------------------------------------
+struct BprArgs {
+    const float *mean;
+    int64_t n_users;
+    const int64_t *user, *pos, *neg;
+    int64_t B;
+    int d;
+    float gamma;
+    float *grad_mean;
+};
+
+// triple b: its loss term; the gradient rows of `which` (0 user, 1 positive, 2 negative; -1 all three; -2 none)
+template <bool ORDERED>
+__device__ __forceinline__ float bpr_elem(const BprArgs &a, int64_t b, int which, int lane) {
+    const int d = a.d;
+    const float *ue = a.mean + a.user[b] * d;
+    const float *pe = a.mean + (a.n_users + a.pos[b]) * d;
+    const float *ne = a.mean + (a.n_users + a.neg[b]) * d;
     float sp = 0.f, sn = 0.f;
     for (int k = lane; k < d; k += 64) {
         const float u = ue[k];
@@ -92,107 +120,147 @@ __global__ __launch_bounds__(256) void bpr_grad_kernel(const float *__restrict__
     const float x = sp - sn;
     const float sig = 1.0f / (1.0f + expf(-x));
     // L = -mean(log(gamma + sig));  dL/dx = -(sig (1 - sig)) / (gamma + sig) / B
-    const float c = -(sig * (1.0f - sig)) / (gamma + sig) / (float)B;
-    float *gu = grad_mean + user[b] * d;
-    float *gp = grad_mean + (n_users + pos[b]) * d;
-    float *gn = grad_mean + (n_users + neg[b]) * d;
-    for (int k = lane; k < d; k += 64) {
-        const float u = ue[k], p = pe[k], n = ne[k];
-        atomicAdd(gu + k, c * (p - n));
-        atomicAdd(gp + k, c * u);
-        atomicAdd(gn + k, -c * u);
+    const float c = -(sig * (1.0f - sig)) / (a.gamma + sig) / (float)a.B;
+    if (which != -2) {
+        float *gu = a.grad_mean + a.user[b] * d;
+        float *gp = a.grad_mean + (a.n_users + a.pos[b]) * d;
+        float *gn = a.grad_mean + (a.n_users + a.neg[b]) * d;
+        for (int k = lane; k < d; k += 64) {
+            const float u = ue[k], p = pe[k], n = ne[k];
+            if (which < 0 || which == 0) row_add<ORDERED>(gu + k, c * (p - n));
+            if (which < 0 || which == 1) row_add<ORDERED>(gp + k, c * u);
+            if (which < 0 || which == 2) row_add<ORDERED>(gn + k, -c * u);
+        }
     }
-    loss_part += -logf(gamma + sig) / (float)B;
-    }
+    return -logf(a.gamma + sig) / (float)a.B;
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void bpr_grad_kernel(const BprArgs a, float *__restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    float loss_part = 0.f;
+    RBG_FOR_GROUPS(grp, a.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t b = grp * kElemsPerWave + e;
+            if (b >= a.B) break;
+            loss_part += bpr_elem<false>(a, b, SCATTER ? -1 : -2, lane);
+        }
     block_add_loss(loss_part, loss);
+}
+
+// occurrence m of [0, 3B): which = m / B of triple m % B.  Users share keys with users only, items with items.
+struct Triples {
+    const int64_t *user, *pos, *neg;
+    int64_t n_users, B;
+    __device__ __forceinline__ int64_t key(int64_t m) const {
+        const int64_t b = m % B;
+        const int which = (int)(m / B);
+        return which == 0 ? user[b] : n_users + (which == 1 ? pos[b] : neg[b]);
+    }
+    __device__ __forceinline__ void range(int64_t w, int64_t &lo, int64_t &hi) const {
+        lo = w < B ? 0 : B;
+        hi = w < B ? B : 3 * B;
+    }
+};
+
+struct BprRows : Triples {
+    BprArgs a;
+    __device__ __forceinline__ void apply(int64_t m, int lane) const { bpr_elem<true>(a, m % B, (int)(m / B), lane); }
+};
+
+// ---- EmbLoss on the ego embeddings (lightgcn.py:103-108) ------------------------------------------------------------------
+struct EmbRegArgs {
+    const float *user_emb, *item_emb;
+    int64_t n_users;
+    const int64_t *user, *pos, *neg;
+    int64_t B;
+    int d;
+    float *grad_e0;
+};
+
+// occurrence w of [0, 3B): grad_e0[row] += scale * row (if SCATTER); returns the row's sum of squares
+template <bool ORDERED, bool SCATTER>
+__device__ __forceinline__ float emb_reg_elem(const EmbRegArgs &a, int64_t w, float scale, int lane) {
+    const int64_t b = w % a.B;
+    const int which = (int)(w / a.B);  // 0 user, 1 pos item, 2 neg item
+    const int64_t id = which == 0 ? a.user[b] : (which == 1 ? a.pos[b] : a.neg[b]);
+    const float *row = which == 0 ? a.user_emb + id * a.d : a.item_emb + id * a.d;
+    float *g = a.grad_e0 + (which == 0 ? id : a.n_users + id) * a.d;
+    float sq = 0.f;
+    for (int k = lane; k < a.d; k += 64) {
+        const float e = row[k];
+        sq = fmaf(e, e, sq);
+        if (SCATTER) row_add<ORDERED>(g + k, scale * e);
+    }
+    return wave_sum(sq);
 }
 
 // EmbLoss(norm=2, require_pow=True): reg = (|U0[user]|^2 + |I0[pos]|^2 + |I0[neg]|^2) / B / 2
 // d(reg_weight * reg)/d(row) = reg_weight / B * row   per occurrence
-__global__ __launch_bounds__(256) void emb_reg_grad_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
-                                                           int64_t n_users, const int64_t *__restrict__ user,
-                                                           const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
-                                                           int64_t B, int d, float reg_weight, float *__restrict__ grad_e0,
-                                                           float *__restrict__ loss) {
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void emb_reg_grad_kernel(const EmbRegArgs a, float reg_weight, float *__restrict__ loss) {
     const int lane = threadIdx.x & 63;
     float loss_part = 0.f;
-    for (int e = 0; e < kElemsPerWave; ++e) {
-    const int64_t w = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
-    if (w >= 3 * B) break;
-    const int64_t b = w % B;
-    const int which = (int)(w / B);  // 0 user, 1 pos item, 2 neg item
-    const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
-    const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
-    float *g = grad_e0 + (which == 0 ? id : n_users + id) * d;
-    const float s = reg_weight / (float)B;
-    float sq = 0.f;
-    for (int k = lane; k < d; k += 64) {
-        const float e = row[k];
-        sq = fmaf(e, e, sq);
-        atomicAdd(g + k, s * e);
-    }
-    sq = wave_sum(sq);
-    loss_part += reg_weight * sq / (float)B * 0.5f;
-    }
+    RBG_FOR_GROUPS(grp, 3 * a.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t w = grp * kElemsPerWave + e;
+            if (w >= 3 * a.B) break;
+            loss_part += reg_weight * emb_reg_elem<false, SCATTER>(a, w, reg_weight / (float)a.B, lane) / (float)a.B * 0.5f;
+        }
     block_add_loss(loss_part, loss);
 }
 
 // EmbLoss(norm=2, require_pow=False): reg = (||U0[user]||_F + ||I0[pos]||_F + ||I0[neg]||_F) / B — torch.norm of each
 // gathered [B, d] block (RecBole's default; LightGCN.yaml switches to the squared form).  Pass 1: the three sums of squares.
-__global__ __launch_bounds__(256) void emb_sumsq_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
-                                                        const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
-                                                        const int64_t *__restrict__ neg, int64_t B, int d, float *__restrict__ sums) {
-    __shared__ float red[4][3];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void emb_sumsq_kernel(const EmbRegArgs a, float *__restrict__ sums) {
+    __shared__ float red[3][kMaxWaves];
+    const int lane = threadIdx.x & 63;
     float part[3] = {0.f, 0.f, 0.f};
-    for (int e = 0; e < kElemsPerWave; ++e) {
-        const int64_t w = ((int64_t)blockIdx.x * 4 + wave) * kElemsPerWave + e;
-        if (w >= 3 * B) break;
-        const int64_t b = w % B;
-        const int which = (int)(w / B);
-        const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
-        const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
-        float sq = 0.f;
-        for (int k = lane; k < d; k += 64) sq = fmaf(row[k], row[k], sq);
-        sq = wave_sum(sq);
-        part[0] += which == 0 ? sq : 0.f;
-        part[1] += which == 1 ? sq : 0.f;
-        part[2] += which == 2 ? sq : 0.f;
-    }
-    if (lane == 0) {
-        red[wave][0] = part[0];
-        red[wave][1] = part[1];
-        red[wave][2] = part[2];
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
+    RBG_FOR_GROUPS(grp, 3 * a.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t w = grp * kElemsPerWave + e;
+            if (w >= 3 * a.B) break;
+            const int which = (int)(w / a.B);
+            const float sq = emb_reg_elem<false, false>(a, w, 0.f, lane);
+            part[0] += which == 0 ? sq : 0.f;
+            part[1] += which == 1 ? sq : 0.f;
+            part[2] += which == 2 ? sq : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float t = block_sum(part[j], red[j]);
+        if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + j, t);
     }
 }
 
 // Pass 2: d(reg_weight * ||E||_F / B)/d(row) = reg_weight / B * row / ||E||_F per occurrence (torch: zero at ||E|| = 0).
-__global__ __launch_bounds__(256) void emb_reg_grad_nopow_kernel(const float *__restrict__ user_emb, const float *__restrict__ item_emb,
-                                                                 int64_t n_users, const int64_t *__restrict__ user,
-                                                                 const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
-                                                                 int64_t B, int d, float reg_weight, const float *__restrict__ sums,
-                                                                 float *__restrict__ grad_e0, float *__restrict__ loss) {
-    const int lane = threadIdx.x & 63;
-    const float nrm[3] = {sqrtf(sums[0]), sqrtf(sums[1]), sqrtf(sums[2])};
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss, reg_weight * ((nrm[0] + nrm[1]) + nrm[2]) / (float)B);
-    for (int e = 0; e < kElemsPerWave; ++e) {
-        const int64_t w = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
-        if (w >= 3 * B) break;
-        const int64_t b = w % B;
-        const int which = (int)(w / B);
-        const int64_t id = which == 0 ? user[b] : (which == 1 ? pos[b] : neg[b]);
-        const float *row = which == 0 ? user_emb + id * d : item_emb + id * d;
-        float *g = grad_e0 + (which == 0 ? id : n_users + id) * d;
-        const float nw = which == 0 ? nrm[0] : (which == 1 ? nrm[1] : nrm[2]);
-        const float s = nw > 0.f ? reg_weight / (float)B / nw : 0.f;
-        for (int k = lane; k < d; k += 64) atomicAdd(g + k, s * row[k]);
-    }
+__device__ __forceinline__ float nopow_scale(const float *sums, int which, float reg_weight, int64_t B) {
+    const float nw = sqrtf(sums[which]);
+    return nw > 0.f ? reg_weight / (float)B / nw : 0.f;
 }
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void emb_reg_grad_nopow_kernel(const EmbRegArgs a, float reg_weight, const float *__restrict__ sums,
+                                                                 float *__restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(loss, reg_weight * ((sqrtf(sums[0]) + sqrtf(sums[1])) + sqrtf(sums[2])) / (float)a.B);
+    if (!SCATTER) return;
+    RBG_FOR_GROUPS(grp, 3 * a.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t w = grp * kElemsPerWave + e;
+            if (w >= 3 * a.B) break;
+            emb_reg_elem<false, true>(a, w, nopow_scale(sums, (int)(w / a.B), reg_weight, a.B), lane);
+        }
+}
+
+struct EmbRegRows : Triples {
+    EmbRegArgs a;
+    float reg_weight;
+    const float *sums;  // NULL: the squared form
+    __device__ __forceinline__ void apply(int64_t m, int lane) const {
+        emb_reg_elem<true, true>(a, m, sums ? nopow_scale(sums, (int)(m / B), reg_weight, B) : reg_weight / (float)B, lane);
+    }
+};
 
 // ---- the mini-batch loss of NGCF on the CONCATENATION of its layer outputs (ngcf.py:100-126) without forming it ----------
 // u_e = cat_t(E_t[user]) etc.: a score is the sum over the tables of the per-table dots, a block norm the root of the sum over
@@ -205,15 +273,16 @@ struct ConcatTables {
     int n;
 };
 
-__global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
-                                                               const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
-                                                               int64_t B, float gamma, int form, float *__restrict__ coef,
-                                                               float *__restrict__ sums, float *__restrict__ loss) {
-    __shared__ float red[4][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
+                                                                const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                                int64_t B, float gamma, int form, float *__restrict__ coef,
+                                                                float *__restrict__ sums, float *__restrict__ loss) {
+    __shared__ float red[4][kMaxWaves];
+    const int lane = threadIdx.x & 63;
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss, |U|^2, |P|^2, |N|^2
+    RBG_FOR_GROUPS(grp, B)
     for (int e = 0; e < kElemsPerWave; ++e) {
-        const int64_t b = ((int64_t)blockIdx.x * 4 + wave) * kElemsPerWave + e;
+        const int64_t b = grp * kElemsPerWave + e;
         if (b >= B) break;
         const int64_t ru = user[b], rp = n_users + pos[b], rn = n_users + neg[b];
         float sp = 0.f, sn = 0.f, qu = 0.f, qp = 0.f, qn = 0.f;
@@ -242,55 +311,81 @@ __global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, i
         }
         part[1] += qu, part[2] += qp, part[3] += qn;
     }
-    if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][i] = part[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (t != 0.f) atomicAdd(threadIdx.x == 0 ? loss : sums + (threadIdx.x - 1), t);
+    for (int j = 0; j < 4; ++j) {
+        const float t = block_sum(part[j], red[j]);
+        if (threadIdx.x == 0 && t != 0.f) atomicAdd(j == 0 ? loss : sums + (j - 1), t);
     }
 }
 
 // EmbLoss(norm = 2) on the three concatenated blocks: require_pow False: (|U| + |P| + |N|) / B, d/d(row) = row / |block| / B;
 // True: (|U|^2 + |P|^2 + |N|^2) / B / 2, d/d(row) = row / B
-__global__ __launch_bounds__(256) void concat_bpr_scatter_kernel(const float *__restrict__ tab, int w, int64_t n_users,
-                                                                 const int64_t *__restrict__ user, const int64_t *__restrict__ pos,
-                                                                 const int64_t *__restrict__ neg, int64_t B, float reg_weight,
-                                                                 int require_pow, const float *__restrict__ coef,
-                                                                 const float *__restrict__ sums, float *__restrict__ grad,
-                                                                 float *__restrict__ loss_reg) {
-    const int lane = threadIdx.x & 63;
-    float s3[3];
-    if (require_pow) {
-        s3[0] = s3[1] = s3[2] = reg_weight / (float)B;
+struct ConcatArgs {
+    const float *tab;
+    int w;
+    int64_t n_users;
+    const int64_t *user, *pos, *neg;
+    int64_t B;
+    float reg_weight;
+    int require_pow;
+    const float *coef, *sums;
+    float *grad;
+};
+
+__device__ __forceinline__ void concat_scales(const ConcatArgs &a, float (&s3)[3]) {
+    if (a.require_pow) {
+        s3[0] = s3[1] = s3[2] = a.reg_weight / (float)a.B;
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float nrm = sqrtf(sums[i]);
-            s3[i] = nrm > 0.f ? reg_weight / (float)B / nrm : 0.f;
-        }
-    }
-    if (loss_reg && blockIdx.x == 0 && threadIdx.x == 0) {
-        const float r = require_pow ? ((sums[0] + sums[1]) + sums[2]) * 0.5f : (sqrtf(sums[0]) + sqrtf(sums[1])) + sqrtf(sums[2]);
-        atomicAdd(loss_reg, reg_weight * r / (float)B);
-    }
-    for (int e = 0; e < kElemsPerWave; ++e) {
-        const int64_t b = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kElemsPerWave + e;
-        if (b >= B) break;
-        const int64_t ru = user[b], rp = n_users + pos[b], rn = n_users + neg[b];
-        const float c = coef[b];
-        const float *ue = tab + ru * w, *pe = tab + rp * w, *ne = tab + rn * w;
-        float *gu = grad + ru * w, *gp = grad + rp * w, *gn = grad + rn * w;
-        for (int k = lane; k < w; k += 64) {
-            const float u = ue[k], p = pe[k], n = ne[k];
-            atomicAdd(gu + k, fmaf(c, p - n, s3[0] * u));
-            atomicAdd(gp + k, fmaf(c, u, s3[1] * p));
-            atomicAdd(gn + k, fmaf(-c, u, s3[2] * n));
+            const float nrm = sqrtf(a.sums[i]);
+            s3[i] = nrm > 0.f ? a.reg_weight / (float)a.B / nrm : 0.f;
         }
     }
 }
+
+// triple b: the gradient rows of `which` (-1: all three)
+template <bool ORDERED>
+__device__ __forceinline__ void concat_elem(const ConcatArgs &a, const float (&s3)[3], int64_t b, int which, int lane) {
+    const int w = a.w;
+    const int64_t ru = a.user[b], rp = a.n_users + a.pos[b], rn = a.n_users + a.neg[b];
+    const float c = a.coef[b];
+    const float *ue = a.tab + ru * w, *pe = a.tab + rp * w, *ne = a.tab + rn * w;
+    float *gu = a.grad + ru * w, *gp = a.grad + rp * w, *gn = a.grad + rn * w;
+    for (int k = lane; k < w; k += 64) {
+        const float u = ue[k], p = pe[k], n = ne[k];
+        if (which < 0 || which == 0) row_add<ORDERED>(gu + k, fmaf(c, p - n, s3[0] * u));
+        if (which < 0 || which == 1) row_add<ORDERED>(gp + k, fmaf(c, u, s3[1] * p));
+        if (which < 0 || which == 2) row_add<ORDERED>(gn + k, fmaf(-c, u, s3[2] * n));
+    }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void concat_bpr_scatter_kernel(const ConcatArgs a, float *__restrict__ loss_reg) {
+    const int lane = threadIdx.x & 63;
+    float s3[3];
+    concat_scales(a, s3);
+    if (loss_reg && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float r = a.require_pow ? ((a.sums[0] + a.sums[1]) + a.sums[2]) * 0.5f : (sqrtf(a.sums[0]) + sqrtf(a.sums[1])) + sqrtf(a.sums[2]);
+        atomicAdd(loss_reg, a.reg_weight * r / (float)a.B);
+    }
+    if (!SCATTER) return;
+    RBG_FOR_GROUPS(grp, a.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t b = grp * kElemsPerWave + e;
+            if (b >= a.B) break;
+            concat_elem<false>(a, s3, b, -1, lane);
+        }
+}
+
+struct ConcatRows : Triples {
+    ConcatArgs a;
+    __device__ __forceinline__ void apply(int64_t m, int lane) const {
+        float s3[3];
+        concat_scales(a, s3);
+        concat_elem<true>(a, s3, m % B, (int)(m / B), lane);
+    }
+};
 
 // torch.optim.Adam single step (foreach/fused semantics): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).   Rows [0,n_users) of the [N,d] state live in the
@@ -359,8 +454,15 @@ int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, co
     int zrc = zero_async(grad_mean, sizeof(float) * (size_t)(n_users + n_items) * d, s);
     if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
-    hipLaunchKernelGGL(bpr_grad_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, out_mean, n_users, user, pos, neg, B, d,
-                       1e-10f, grad_mean, loss);
+    const BprArgs a{out_mean, n_users, user, pos, neg, B, d, 1e-10f, grad_mean};
+    if (opt_deterministic()) {  // the loss by one workgroup in a fixed order, every gradient row by the wavefront that owns it
+        hipLaunchKernelGGL((bpr_grad_kernel<false>), dim3(1), kOneBlock, 0, s, a, loss);
+        BprRows r{};
+        r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a;
+        launch_ordered_scatter(r, 3 * B, s);
+    } else {
+        hipLaunchKernelGGL((bpr_grad_kernel<true>), grid_for(B), dim3(256), 0, s, a, loss);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -372,9 +474,16 @@ int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n
     if (n_users < 0 || B < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
     if (B == 0 || reg_weight == 0.f) return RBG_OK;
     if (!user_emb || !item_emb || !user || !pos || !neg || !grad_e0 || !loss) return fail(RBG_EINVAL, "NULL pointer");
-    hipLaunchKernelGGL(emb_reg_grad_kernel, dim3((unsigned)((3 * B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0,
-                       (hipStream_t)stream, user_emb,
-                       item_emb, n_users, user, pos, neg, B, d, reg_weight, grad_e0, loss);
+    hipStream_t s = (hipStream_t)stream;
+    const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
+    if (opt_deterministic()) {
+        hipLaunchKernelGGL((emb_reg_grad_kernel<false>), dim3(1), kOneBlock, 0, s, a, reg_weight, loss);
+        EmbRegRows r{};
+        r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = nullptr;
+        launch_ordered_scatter(r, 3 * B, s);
+    } else {
+        hipLaunchKernelGGL((emb_reg_grad_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -388,10 +497,17 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     if (!user_emb || !item_emb || !user || !pos || !neg || !grad_e0 || !loss || !workspace) return fail(RBG_EINVAL, "NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     if (int zrc = zero_async(workspace, 3 * sizeof(float), s)) return zrc;
-    const dim3 grid((unsigned)((3 * B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave)));
-    hipLaunchKernelGGL(emb_sumsq_kernel, grid, dim3(256), 0, s, user_emb, item_emb, user, pos, neg, B, d, workspace);
-    hipLaunchKernelGGL(emb_reg_grad_nopow_kernel, grid, dim3(256), 0, s, user_emb, item_emb, n_users, user, pos, neg, B, d, reg_weight,
-                       workspace, grad_e0, loss);
+    const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
+    if (opt_deterministic()) {
+        hipLaunchKernelGGL(emb_sumsq_kernel, dim3(1), kOneBlock, 0, s, a, workspace);
+        hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<false>), dim3(1), dim3(256), 0, s, a, reg_weight, workspace, loss);
+        EmbRegRows r{};
+        r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = workspace;
+        launch_ordered_scatter(r, 3 * B, s);
+    } else {
+        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace);
+        hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, workspace, loss);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -413,8 +529,10 @@ int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int 
     int zrc = zero_async(sums, 3 * sizeof(float), s);
     if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
-    hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0, s, T, n_users,
-                       user, pos, neg, B, 1e-10f, form, coef, sums, loss);
+    if (opt_deterministic())
+        hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3(1), kOneBlock, 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss);
+    else
+        hipLaunchKernelGGL(concat_bpr_begin_kernel, grid_for(B), dim3(256), 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -426,9 +544,16 @@ int rbg_concat_bpr_scatter_f32(const float *table, int width, int64_t n_users, c
     if (n_users < 0 || B < 0 || width <= 0) return fail(RBG_ESHAPE, "bad shape");
     if (B == 0) return RBG_OK;
     if (!table || !user || !pos || !neg || !coef || !sums || !grad_table) return fail(RBG_EINVAL, "NULL pointer");
-    hipLaunchKernelGGL(concat_bpr_scatter_kernel, dim3((unsigned)((B + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))), dim3(256), 0,
-                       (hipStream_t)stream, table, width, n_users, user, pos, neg, B, reg_weight, require_pow ? 1 : 0, coef, sums, grad_table,
-                       loss_reg);
+    hipStream_t s = (hipStream_t)stream;
+    const ConcatArgs a{table, width, n_users, user, pos, neg, B, reg_weight, require_pow ? 1 : 0, coef, sums, grad_table};
+    if (opt_deterministic()) {
+        hipLaunchKernelGGL((concat_bpr_scatter_kernel<false>), dim3(1), dim3(256), 0, s, a, loss_reg);
+        ConcatRows r{};
+        r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a;
+        launch_ordered_scatter(r, 3 * B, s);
+    } else {
+        hipLaunchKernelGGL((concat_bpr_scatter_kernel<true>), grid_for(B), dim3(256), 0, s, a, loss_reg);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

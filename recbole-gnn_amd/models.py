@@ -27,7 +27,12 @@ def _once_mask(ids, n_ids=None):
     if n_ids is not None and ids.is_cuda:
         ar = torch.arange(ids.shape[0], device=ids.device)
         slot = torch.empty(int(n_ids), dtype=torch.int64, device=ids.device)  # (only slots written below are read)
-        slot.scatter_(0, ids, ar)
+        if get_option("deterministic"):
+            # option "deterministic": the FIRST occurrence stays (an integer atomic minimum: order-free), so the masked sums run over
+            # the same positions in every run and the step is bit-stable
+            slot.scatter_reduce_(0, ids, ar, "amin", include_self=False)
+        else:
+            slot.scatter_(0, ids, ar)
         return slot.index_select(0, ids) == ar
     s, order = torch.sort(ids)
     first = torch.ones_like(s, dtype=torch.bool)
@@ -42,7 +47,7 @@ def _rows(table, idx):
     atomic ``index_add_`` launch instead of torch's sort-based index_put / embedding backward (115 us per lookup at
     batch 2048 on the Gowalla shape, r01 kernel stats of the SGL step)."""
     return table.index_select(0, idx)
-from .graph import GraphHandle, InteractionDataset
+from .graph import GraphHandle, InteractionDataset, get_option
 
 
 class _Config(dict):

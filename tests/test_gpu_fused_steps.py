@@ -159,7 +159,7 @@ def test_fused_sgl_step_replayed_and_recaptured(rbg, cuda, golden):
 
 
 @pytest.mark.parametrize("n,b,d", [(40_982, 2048, 64), (1500, 257, 64), (3000, 96, 128), (700, 33, 20)])
-def test_infonce_one_pass_form(rbg, cuda, n, b, d):
+def test_infonce_one_pass_form(rbg, cuda, scatter_mode, n, b, d):
     """rbg_infonce_f32 with gradients (option "lse_onepass", default): denominators and the batch rows' gradient out of one
     pass over the table — against the three-launch form and against sgl.py:191-199 in float64."""
     gen = torch.Generator().manual_seed(n)
@@ -182,7 +182,7 @@ def test_infonce_one_pass_form(rbg, cuda, n, b, d):
     ref.backward()
     for mode in (1, 0):
         loss, g1, g2 = res[mode]
-        assert abs(loss - float(ref)) <= 1e-5 * abs(float(ref))
+        assert abs(loss - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
         for got, want in ((g1, a.grad), (g2, c.grad)):
             assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
     assert abs(res[1][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
@@ -293,7 +293,7 @@ def test_zero_fill_kernel_alignment_and_bounds(rbg, cuda):
 
 
 @pytest.mark.parametrize("n,b,d", [(2048, 2048, 64), (300, 300, 64), (1000, 77, 128), (50, 200, 20)])
-def test_infonce_with_row_and_column_weights(rbg, cuda, n, b, d):
+def test_infonce_with_row_and_column_weights(rbg, cuda, scatter_mode, n, b, d):
     """rbg_infonce_masked_f32: weight * sum_b row_w[b] (log sum_j col_w[j] exp(<a_b, c_j> / tau) - <a_b, p_b> / tau) and its
     gradients against float64 — with 0 / 1 masks (SimGCL's contrast over the distinct ids of a batch) and with real weights;
     value-only calls; rows whose own column is masked."""
@@ -366,7 +366,7 @@ def test_a_graph_handle_dying_inside_a_capture_does_not_invalidate_it(rbg, cuda,
 @pytest.mark.parametrize("form", [0, 1])
 @pytest.mark.parametrize("require_pow", [False, True])
 @pytest.mark.parametrize("widths", [[64], [64, 32, 16, 128], [8, 100]])
-def test_concat_bpr_against_torch(rbg, cuda, widths, require_pow, form):
+def test_concat_bpr_against_torch(rbg, cuda, scatter_mode, widths, require_pow, form):
     """BPRLoss + reg_weight * EmbLoss on the rows of cat(tables) (ngcf.py:113-126) and their gradient w.r.t. every table."""
     c_vp, check, lib = rbg._lib.c_vp, rbg._lib.check, rbg._lib.lib
     nu, ni, b, reg = 50, 70, 333, 0.37
@@ -571,3 +571,92 @@ def test_once_mask_on_the_device_keeps_one_occurrence_per_id(rbg, cuda):
         m = models._once_mask(ids, n_ids)
         kept = ids[m]
         assert m.dtype == torch.bool and kept.numel() == torch.unique(ids).numel() and torch.equal(torch.sort(kept).values, torch.unique(ids))
+
+
+# ---- option "deterministic" (csrc/ordered.h): row scatters by owner wavefronts in batch order, sums by one workgroup ---------------
+@pytest.fixture(params=["atomic", "ordered"])
+def scatter_mode(request, rbg):
+    rbg.set_option("deterministic", 1 if request.param == "ordered" else 0)
+    yield request.param
+    rbg.set_option("deterministic", 0)
+
+
+def _any_model(rbg, cuda, golden, name):
+    ds = rbg.InteractionDataset(golden["uid"], golden["iid"], int(golden["n_users"]), int(golden["n_items"]))
+    torch.manual_seed(4)
+    config = {"device": str(cuda), "embedding_size": 64, "n_layers": 2, "enable_sparse": True, "reg_weight": 1e-3, "require_pow": name == "LightGCN",
+              "hidden_size_list": [64, 32], "message_dropout": 0.1, "node_dropout": 0.0, "type": "ED", "drop_ratio": 0.1, "ssl_tau": 0.5,
+              "ssl_weight": 0.05, "lambda": 0.3, "eps": 0.15, "temperature": 0.2, "layer_cl": 1}
+    return getattr(rbg, name)(config, ds)
+
+
+@pytest.mark.parametrize("name", ["LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL"])
+def test_fused_steps_are_bit_stable_in_deterministic_mode(rbg, cuda, golden, name):
+    """With option "deterministic" two runs of the autograd-free step — same parameters, same random draws, batches in which most ids
+    repeat (the tables are a few dozen rows) — end in bit-identical losses and parameters; and they stay within the usual
+    tolerance of the default (float-atomic) run."""
+    def run():
+        model = _any_model(rbg, cuda, golden, name)
+        model.train()
+        stepper = rbg.fused_stepper(model, lr=1e-2, graphed=False)
+        assert stepper is not None
+        losses = []
+        for step_no, batch in enumerate(_batches(golden, cuda, 5, 256)):
+            torch.manual_seed(300 + step_no)
+            losses.append(float(stepper.step(batch)))
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in model.parameters()]
+    default = run()
+    rbg.set_option("deterministic", 1)
+    try:
+        assert rbg.get_option("deterministic") == 1
+        a, b = run(), run()
+    finally:
+        rbg.set_option("deterministic", 0)
+    assert a[0] == b[0], (a[0], b[0])
+    for pa, pb in zip(a[1], b[1]):
+        assert torch.equal(pa, pb)
+    for x, y in zip(a[0], default[0]):
+        assert abs(x - y) <= 2e-4 * max(1.0, abs(y)), (a[0], default[0])
+
+
+@pytest.mark.parametrize("require_pow", [True, False])
+@pytest.mark.parametrize("b,d", [(2048, 64), (333, 20), (96, 128)])
+def test_bpr_and_embloss_scatters_in_both_modes(rbg, cuda, scatter_mode, b, d, require_pow):
+    """rbg_bpr_grad_f32 / rbg_emb_reg_grad[_nopow]_f32 on a batch whose ids repeat many times, against torch in float64 — with float
+    atomics and with the ordered scatters."""
+    lib, vp = rbg._lib.lib, ctypes.c_void_p
+    nu, ni = 37, 53
+    gen = torch.Generator().manual_seed(b + d)
+    mean = torch.randn(nu + ni, d, generator=gen).to(cuda)
+    user, pos, neg = (torch.randint(0, n, (b,), generator=gen).to(cuda) for n in (nu, ni, ni))
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    grad, loss = torch.full((nu + ni, d), 7.0, device=cuda), torch.full((1,), 7.0, device=cuda)  # (the call zeroes both)
+    rbg._lib.check(lib.rbg_bpr_grad_f32(vp(mean.data_ptr()), nu, ni, vp(user.data_ptr()), vp(pos.data_ptr()), vp(neg.data_ptr()), b, d,
+                                        vp(grad.data_ptr()), vp(loss.data_ptr()), st))
+    m64 = mean.double().requires_grad_(True)
+    u, p, n = m64[user], m64[nu + pos], m64[nu + neg]
+    ref = -torch.log(1e-10 + torch.sigmoid((u * p).sum(1) - (u * n).sum(1))).mean()
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((grad.double() - m64.grad).abs().max()) <= 2e-5 * max(float(m64.grad.abs().max()), 1e-12)
+    # EmbLoss on the ego tables, added onto an existing gradient and loss
+    uw, iw = mean[:nu].contiguous(), mean[nu:].contiguous()
+    g0 = torch.randn(nu + ni, d, generator=gen).to(cuda)
+    ge, le = g0.clone(), torch.full((1,), 0.25, device=cuda)
+    ws = torch.zeros(4, device=cuda)
+    args = (vp(uw.data_ptr()), vp(iw.data_ptr()), nu, vp(user.data_ptr()), vp(pos.data_ptr()), vp(neg.data_ptr()), b, d, ctypes.c_float(1e-2),
+            vp(ge.data_ptr()), vp(le.data_ptr()))
+    rbg._lib.check(lib.rbg_emb_reg_grad_f32(*args, st) if require_pow else lib.rbg_emb_reg_grad_nopow_f32(*args, vp(ws.data_ptr()), st))
+    u64, i64_ = uw.double().requires_grad_(True), iw.double().requires_grad_(True)
+    blocks = (u64[user], i64_[pos], i64_[neg])
+    reg = sum(x.pow(2).sum() for x in blocks) / b / 2 if require_pow else sum(x.norm() for x in blocks) / b
+    (1e-2 * reg).backward()
+    assert abs(float(le) - 0.25 - 1e-2 * float(reg)) <= 2e-6 * max(1.0, abs(float(reg)))
+    want = g0.double() + torch.cat([u64.grad, i64_.grad])
+    assert float((ge.double() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1e-12)  # (dozens of fp32 adds onto rows of size ~ 3)
+    if scatter_mode == "ordered":  # and a second run gives the same bits
+        ge2, le2 = g0.clone(), torch.full((1,), 0.25, device=cuda)
+        args2 = args[:-2] + (vp(ge2.data_ptr()), vp(le2.data_ptr()))
+        rbg._lib.check(lib.rbg_emb_reg_grad_f32(*args2, st) if require_pow else lib.rbg_emb_reg_grad_nopow_f32(*args2, vp(ws.data_ptr()), st))
+        assert torch.equal(ge, ge2) and torch.equal(le, le2)
