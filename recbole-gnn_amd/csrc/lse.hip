@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     // so the fetch a publish consumes was issued one whole iteration earlier.  (r03 fetched tile t + 1 at the top of
     // iteration t and published it at the bottom: with the products knocked out the loop still ran at one memory latency
     // per tile.  Measured neutral (399 vs 397 us): the gradient kernel is not bound by the fetch but by the missing overlap of its
-    // phases at two workgroups per CU — profiles/r04_lse_phase_probe.jsonl.)
+    // phases at two workgroups per CU — profiles/r04_lse_phase_probe.jsonl.  r05: raised priority between the first product and
+    // the barrier, which pays 3 % in topk.hip: 390-395 vs 394-401 us per InfoNCE with gradients at 2048 x 40 982 — inside the noise, not kept.)
     if (t0 < t1) {
         fetch(t0);
         publish(0);
