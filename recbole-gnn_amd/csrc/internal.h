@@ -53,7 +53,7 @@ int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 ma
 // train.hip: zero `bytes` (4-byte units) at ptr by a fill kernel — NOT hipMemsetAsync, whose node writes garbage on a captured graph's later replays
 int zero_async(void *ptr, size_t bytes, hipStream_t s);
 int opt_topk_short_lists();  // rbg_full_sort_topk_f32: 24-entry LDS lists (three workgroups per CU) at k <= 12, d <= 64: 0 never, 1 from 2048 users (default), 2 always
-int opt_deterministic();  // train.hip / lse.hip: row scatters by owner wavefronts in batch order (ordered.h), sums by one workgroup: bit-stable
+int opt_deterministic();  // train.hip / lse.hip: row scatters by owner wavefronts in batch order (ordered.h), sums in fixed point: bit-stable
 int opt_lse_onepass();    // rbg_infonce_f32: denominators and the batch rows' gradient out of one pass over the table (1, default)
 int opt_score_uniform();  // rbg_score_f32: workgroups take users of one alignment class and store whole lines without shuffles (1, default)
 int opt_score_tiles();  // item tiles one workgroup of rbg_score_f32 walks (0 = auto)

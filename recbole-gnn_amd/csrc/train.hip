@@ -15,6 +15,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "internal.h"
 #include "ordered.h"
@@ -57,11 +58,18 @@ int zero_async(void *ptr, size_t bytes, hipStream_t s) {
 
 constexpr int kElemsPerWave = 4;  // batch elements per wavefront: 16 per 256-thread workgroup, ONE loss atomic per workgroup
 // (one atomic per element on the single loss word serialised the whole kernel: 80 us for 6 144 elements)
-// Every kernel below walks its elements with a grid-stride loop and sums them in a fixed order inside a workgroup, so launched as
-// ONE workgroup of 1024 threads it is reproducible bit for bit: that is how option "deterministic" takes the loss values and the
-// block norms (kOneBlock), while the row scatters go through ordered.h.
+// Sums over the batch (loss values, block norms): every workgroup reduces its elements in a fixed order (block_sum); across
+// workgroups the default is one float atomic per workgroup and value — order-dependent in the last bits.  Option "deterministic":
+// the workgroups add their partial sums as 31.32 FIXED-POINT integers into a slot of g_fix_acc (integer addition is associative:
+// any order gives the same bits), the last workgroup to arrive converts the total and adds it to the caller's cell, and leaves the
+// slot zeroed.  No scratch memory from the caller, nothing allocated, capturable; |sum| < 2^31.  Slots are handed out round-robin
+// per launch, so up to kFixSlots such launches may be in flight on different streams.
 constexpr int kMaxWaves = 16;
-static const dim3 kOneBlock(1024);
+constexpr int kFixSlots = 64;
+__device__ unsigned long long g_fix_acc[kFixSlots][4];
+__device__ unsigned g_fix_cnt[kFixSlots];
+static std::atomic<unsigned> g_fix_next{0};
+static int fix_slot() { return opt_deterministic() ? (int)(g_fix_next.fetch_add(1) % kFixSlots) : -1; }
 
 // the workgroup's waves' partial sums, added in wave order (pairwise for the usual four)
 __device__ __forceinline__ float block_sum(float part, float *red) {
@@ -78,10 +86,39 @@ __device__ __forceinline__ float block_sum(float part, float *red) {
     return s;  // valid in thread 0
 }
 
-__device__ __forceinline__ void block_add_loss(float part, float *loss) {
-    __shared__ float red[kMaxWaves];
-    const float s = block_sum(part, red);
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(loss, s);
+// dst[j] += the sum over all workgroups of part[j] (each lane-0-of-wave partial, summed per workgroup first); slot < 0: float atomics
+template <int NV>
+__device__ __forceinline__ void commit_sums(const float (&part)[NV], float *const (&dst)[NV], int slot) {
+    __shared__ float red[NV][kMaxWaves];
+    float tot[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) tot[j] = block_sum(part[j], red[j]);
+    if (threadIdx.x != 0) return;
+    if (slot < 0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (tot[j] != 0.f) atomicAdd(dst[j], tot[j]);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) atomicAdd(&g_fix_acc[slot][j], (unsigned long long)__float2ll_rn(tot[j] * 4294967296.0f));
+    __threadfence();
+    if (atomicAdd(&g_fix_cnt[slot], 1u) == gridDim.x - 1) {  // the last workgroup: every partial sum is in
+        __threadfence();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const long long t = (long long)atomicExch(&g_fix_acc[slot][j], 0ull);
+            const float f = (float)((double)t * 2.3283064365386963e-10);
+            if (f != 0.f) atomicAdd(dst[j], f);
+        }
+        atomicExch(&g_fix_cnt[slot], 0u);
+    }
+}
+
+__device__ __forceinline__ void block_add_loss(float part, float *loss, int slot) {
+    const float p1[1] = {part};
+    float *const d1[1] = {loss};
+    commit_sums<1>(p1, d1, slot);
 }
 
 // element groups of kElemsPerWave a wave walks: grp = first, first + stride, ...
@@ -136,7 +173,7 @@ __device__ __forceinline__ float bpr_elem(const BprArgs &a, int64_t b, int which
 }
 
 template <bool SCATTER>
-__global__ __launch_bounds__(1024) void bpr_grad_kernel(const BprArgs a, float *__restrict__ loss) {
+__global__ __launch_bounds__(256) void bpr_grad_kernel(const BprArgs a, float *__restrict__ loss, int slot) {
     const int lane = threadIdx.x & 63;
     float loss_part = 0.f;
     RBG_FOR_GROUPS(grp, a.B)
@@ -145,18 +182,18 @@ __global__ __launch_bounds__(1024) void bpr_grad_kernel(const BprArgs a, float *
             if (b >= a.B) break;
             loss_part += bpr_elem<false>(a, b, SCATTER ? -1 : -2, lane);
         }
-    block_add_loss(loss_part, loss);
+    block_add_loss(loss_part, loss, slot);
 }
 
 // occurrence m of [0, 3B): which = m / B of triple m % B.  Users share keys with users only, items with items.
 struct Triples {
     const int64_t *user, *pos, *neg;
     int64_t n_users, B;
-    __device__ __forceinline__ int64_t key(int64_t m) const {
-        const int64_t b = m % B;
-        const int which = (int)(m / B);
-        return which == 0 ? user[b] : n_users + (which == 1 ? pos[b] : neg[b]);
+    __device__ __forceinline__ int64_t key(int64_t m) const {  // (compares, not a 64-bit division: every wavefront evaluates this n times)
+        return m < B ? user[m] : n_users + (m < 2 * B ? pos[m - B] : neg[m - 2 * B]);
     }
+    __device__ __forceinline__ int which_of(int64_t m) const { return m < B ? 0 : (m < 2 * B ? 1 : 2); }
+    __device__ __forceinline__ int64_t triple_of(int64_t m) const { return m < B ? m : (m < 2 * B ? m - B : m - 2 * B); }
     __device__ __forceinline__ void range(int64_t w, int64_t &lo, int64_t &hi) const {
         lo = w < B ? 0 : B;
         hi = w < B ? B : 3 * B;
@@ -165,7 +202,7 @@ struct Triples {
 
 struct BprRows : Triples {
     BprArgs a;
-    __device__ __forceinline__ void apply(int64_t m, int lane) const { bpr_elem<true>(a, m % B, (int)(m / B), lane); }
+    __device__ __forceinline__ void apply(int64_t m, int lane) const { bpr_elem<true>(a, triple_of(m), which_of(m), lane); }
 };
 
 // ---- EmbLoss on the ego embeddings (lightgcn.py:103-108) ------------------------------------------------------------------
@@ -198,7 +235,7 @@ __device__ __forceinline__ float emb_reg_elem(const EmbRegArgs &a, int64_t w, fl
 // EmbLoss(norm=2, require_pow=True): reg = (|U0[user]|^2 + |I0[pos]|^2 + |I0[neg]|^2) / B / 2
 // d(reg_weight * reg)/d(row) = reg_weight / B * row   per occurrence
 template <bool SCATTER>
-__global__ __launch_bounds__(1024) void emb_reg_grad_kernel(const EmbRegArgs a, float reg_weight, float *__restrict__ loss) {
+__global__ __launch_bounds__(256) void emb_reg_grad_kernel(const EmbRegArgs a, float reg_weight, float *__restrict__ loss, int slot) {
     const int lane = threadIdx.x & 63;
     float loss_part = 0.f;
     RBG_FOR_GROUPS(grp, 3 * a.B)
@@ -207,13 +244,12 @@ __global__ __launch_bounds__(1024) void emb_reg_grad_kernel(const EmbRegArgs a, 
             if (w >= 3 * a.B) break;
             loss_part += reg_weight * emb_reg_elem<false, SCATTER>(a, w, reg_weight / (float)a.B, lane) / (float)a.B * 0.5f;
         }
-    block_add_loss(loss_part, loss);
+    block_add_loss(loss_part, loss, slot);
 }
 
 // EmbLoss(norm=2, require_pow=False): reg = (||U0[user]||_F + ||I0[pos]||_F + ||I0[neg]||_F) / B — torch.norm of each
 // gathered [B, d] block (RecBole's default; LightGCN.yaml switches to the squared form).  Pass 1: the three sums of squares.
-__global__ __launch_bounds__(1024) void emb_sumsq_kernel(const EmbRegArgs a, float *__restrict__ sums) {
-    __shared__ float red[3][kMaxWaves];
+__global__ __launch_bounds__(256) void emb_sumsq_kernel(const EmbRegArgs a, float *__restrict__ sums, int slot) {
     const int lane = threadIdx.x & 63;
     float part[3] = {0.f, 0.f, 0.f};
     RBG_FOR_GROUPS(grp, 3 * a.B)
@@ -226,11 +262,8 @@ __global__ __launch_bounds__(1024) void emb_sumsq_kernel(const EmbRegArgs a, flo
             part[1] += which == 1 ? sq : 0.f;
             part[2] += which == 2 ? sq : 0.f;
         }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const float t = block_sum(part[j], red[j]);
-        if (threadIdx.x == 0 && t != 0.f) atomicAdd(sums + j, t);
-    }
+    float *const dst[3] = {sums, sums + 1, sums + 2};
+    commit_sums<3>(part, dst, slot);
 }
 
 // Pass 2: d(reg_weight * ||E||_F / B)/d(row) = reg_weight / B * row / ||E||_F per occurrence (torch: zero at ||E|| = 0).
@@ -258,7 +291,7 @@ struct EmbRegRows : Triples {
     float reg_weight;
     const float *sums;  // NULL: the squared form
     __device__ __forceinline__ void apply(int64_t m, int lane) const {
-        emb_reg_elem<true, true>(a, m, sums ? nopow_scale(sums, (int)(m / B), reg_weight, B) : reg_weight / (float)B, lane);
+        emb_reg_elem<true, true>(a, m, sums ? nopow_scale(sums, which_of(m), reg_weight, B) : reg_weight / (float)B, lane);
     }
 };
 
@@ -273,11 +306,10 @@ struct ConcatTables {
     int n;
 };
 
-__global__ __launch_bounds__(1024) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
-                                                                const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
-                                                                int64_t B, float gamma, int form, float *__restrict__ coef,
-                                                                float *__restrict__ sums, float *__restrict__ loss) {
-    __shared__ float red[4][kMaxWaves];
+__global__ __launch_bounds__(256) void concat_bpr_begin_kernel(ConcatTables T, int64_t n_users, const int64_t *__restrict__ user,
+                                                               const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+                                                               int64_t B, float gamma, int form, float *__restrict__ coef,
+                                                               float *__restrict__ sums, float *__restrict__ loss, int slot) {
     const int lane = threadIdx.x & 63;
     float part[4] = {0.f, 0.f, 0.f, 0.f};  // loss, |U|^2, |P|^2, |N|^2
     RBG_FOR_GROUPS(grp, B)
@@ -311,11 +343,8 @@ __global__ __launch_bounds__(1024) void concat_bpr_begin_kernel(ConcatTables T, 
         }
         part[1] += qu, part[2] += qp, part[3] += qn;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float t = block_sum(part[j], red[j]);
-        if (threadIdx.x == 0 && t != 0.f) atomicAdd(j == 0 ? loss : sums + (j - 1), t);
-    }
+    float *const dst[4] = {loss, sums, sums + 1, sums + 2};
+    commit_sums<4>(part, dst, slot);
 }
 
 // EmbLoss(norm = 2) on the three concatenated blocks: require_pow False: (|U| + |P| + |N|) / B, d/d(row) = row / |block| / B;
@@ -383,7 +412,7 @@ struct ConcatRows : Triples {
     __device__ __forceinline__ void apply(int64_t m, int lane) const {
         float s3[3];
         concat_scales(a, s3);
-        concat_elem<true>(a, s3, m % B, (int)(m / B), lane);
+        concat_elem<true>(a, s3, triple_of(m), which_of(m), lane);
     }
 };
 
@@ -455,13 +484,13 @@ int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, co
     if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
     const BprArgs a{out_mean, n_users, user, pos, neg, B, d, 1e-10f, grad_mean};
-    if (opt_deterministic()) {  // the loss by one workgroup in a fixed order, every gradient row by the wavefront that owns it
-        hipLaunchKernelGGL((bpr_grad_kernel<false>), dim3(1), kOneBlock, 0, s, a, loss);
+    if (opt_deterministic()) {  // the loss summed in fixed point (order-free), every gradient row by the wavefront that owns it
+        hipLaunchKernelGGL((bpr_grad_kernel<false>), grid_for(B), dim3(256), 0, s, a, loss, fix_slot());
         BprRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a;
         launch_ordered_scatter(r, 3 * B, s);
     } else {
-        hipLaunchKernelGGL((bpr_grad_kernel<true>), grid_for(B), dim3(256), 0, s, a, loss);
+        hipLaunchKernelGGL((bpr_grad_kernel<true>), grid_for(B), dim3(256), 0, s, a, loss, -1);
     }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
@@ -477,12 +506,12 @@ int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n
     hipStream_t s = (hipStream_t)stream;
     const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
     if (opt_deterministic()) {
-        hipLaunchKernelGGL((emb_reg_grad_kernel<false>), dim3(1), kOneBlock, 0, s, a, reg_weight, loss);
+        hipLaunchKernelGGL((emb_reg_grad_kernel<false>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss, fix_slot());
         EmbRegRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = nullptr;
         launch_ordered_scatter(r, 3 * B, s);
     } else {
-        hipLaunchKernelGGL((emb_reg_grad_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss);
+        hipLaunchKernelGGL((emb_reg_grad_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss, -1);
     }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
@@ -499,13 +528,13 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     if (int zrc = zero_async(workspace, 3 * sizeof(float), s)) return zrc;
     const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
     if (opt_deterministic()) {
-        hipLaunchKernelGGL(emb_sumsq_kernel, dim3(1), kOneBlock, 0, s, a, workspace);
+        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, fix_slot());
         hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<false>), dim3(1), dim3(256), 0, s, a, reg_weight, workspace, loss);
         EmbRegRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = workspace;
         launch_ordered_scatter(r, 3 * B, s);
     } else {
-        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace);
+        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, -1);
         hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, workspace, loss);
     }
     RBG_HIP(hipGetLastError());
@@ -529,10 +558,7 @@ int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int 
     int zrc = zero_async(sums, 3 * sizeof(float), s);
     if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
-    if (opt_deterministic())
-        hipLaunchKernelGGL(concat_bpr_begin_kernel, dim3(1), kOneBlock, 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss);
-    else
-        hipLaunchKernelGGL(concat_bpr_begin_kernel, grid_for(B), dim3(256), 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss);
+    hipLaunchKernelGGL(concat_bpr_begin_kernel, grid_for(B), dim3(256), 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss, fix_slot());
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

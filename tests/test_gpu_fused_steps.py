@@ -573,7 +573,7 @@ def test_once_mask_on_the_device_keeps_one_occurrence_per_id(rbg, cuda):
         assert m.dtype == torch.bool and kept.numel() == torch.unique(ids).numel() and torch.equal(torch.sort(kept).values, torch.unique(ids))
 
 
-# ---- option "deterministic" (csrc/ordered.h): row scatters by owner wavefronts in batch order, sums by one workgroup ---------------
+# ---- option "deterministic" (csrc/ordered.h): row scatters by owner wavefronts in batch order, sums in fixed point ---------------
 @pytest.fixture(params=["atomic", "ordered"])
 def scatter_mode(request, rbg):
     rbg.set_option("deterministic", 1 if request.param == "ordered" else 0)
