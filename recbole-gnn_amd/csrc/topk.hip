@@ -91,6 +91,39 @@ __device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t 
     return false;
 }
 
+// The same test against a copy of the row's head in LDS (r05, the merge and threshold kernels: one wavefront per user).  The
+// binary search of in_history() is a chain of ~ log2(degree) dependent global loads (~ 0.5 us each) paid by every kernel that
+// masks; staged, the chain is two loads (rowptr, the row) and the search runs at LDS latency.  Columns past the staged head are
+// still read from global memory.
+constexpr int kHistStage = 512;
+struct HistRow {
+    const int32_t *col;
+    const int *lds;
+    int lo, hi, staged;
+    int64_t n_users;
+    __device__ __forceinline__ void stage(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf, int lane) {
+        col = col_, lds = buf, n_users = n_users_;
+        lo = hi = staged = 0;
+        if (!rowptr || user < 0) return;
+        lo = rowptr[user], hi = rowptr[user + 1];
+        staged = hi - lo < kHistStage ? hi - lo : kHistStage;
+        for (int e = lane; e < staged; e += 64) buf[e] = col_[lo + e];
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ bool has(int item) const {
+        if (item < 0) return false;
+        int a = lo, b = hi;
+        const int target = (int)(item + n_users);
+        while (a < b) {
+            const int mid = (a + b) >> 1;
+            const int c = (mid - lo < staged) ? lds[mid - lo] : col[mid];
+            if (c == target) return true;
+            if (c < target) a = mid + 1; else b = mid;
+        }
+        return false;
+    }
+};
+
 // Prune one user's LDS list (n <= 64 raw candidates) to its best k valid entries (sorted; `kept` of them).  Returns the new
 // threshold: the k-th best (or -inf while fewer than k exist).
 __device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, float *lv, int *li, int n, int lane, int &kept) {
@@ -470,23 +503,37 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
                                                        const int64_t *__restrict__ users, const int32_t *__restrict__ rowptr,
                                                        const int32_t *__restrict__ col, int64_t n_users, int64_t B, int splits,
                                                        int k, float *__restrict__ tau_out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int s_hist[4][kHistStage];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
+    HistRow hist;
+    hist.stage(rowptr, col, n_users, users[b], s_hist[wave], lane);  // (its loads go out with the maxima's)
+    // lane (i, half) folds the splits of its parity, four loads in flight (r05: one at a time it was a chain of `splits` latencies)
     float v = kNegInf;
     int idx = 0x7fffffff;
-    if (lane < 32) {
-        for (int sp = 0; sp < splits; ++sp) {
-            const float ov = g_val[(b * splits + sp) * 32 + lane];
-            const int oi = g_idx[(b * splits + sp) * 32 + lane];
-            if (better(ov, oi, v, idx)) {
-                v = ov;
-                idx = oi;
-            }
+    const int i = lane & 31, half = lane >> 5;
+    for (int sp = half; sp < splits; sp += 8) {
+        float ov[4];
+        int oi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = sp + 2 * u;
+            ov[u] = q < splits ? g_val[(b * splits + q) * 32 + i] : kNegInf;
+            oi[u] = q < splits ? g_idx[(b * splits + q) * 32 + i] : 0x7fffffff;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (better(ov[u], oi[u], v, idx)) v = ov[u], idx = oi[u];
+    }
+    {
+        const float pv = __shfl_xor(v, 32);
+        const int pi = __shfl_xor(idx, 32);
+        if (better(pv, pi, v, idx)) v = pv, idx = pi;
+        if (half) v = kNegInf, idx = 0x7fffffff;  // the 32 slot maxima live in the lower half
     }
     wave_sort_desc(v, idx, lane);
-    const bool ok = lane < 32 && idx != 0x7fffffff && !in_history(rowptr, col, n_users, users[b], idx);
+    const bool ok = lane < 32 && idx != 0x7fffffff && !hist.has(idx);
     const unsigned long long m = __ballot(ok);
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0 && __popcll(m) < k) tau_out[b] = kNegInf;
@@ -497,10 +544,10 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
 // them 32 at a time into the upper half-wave, masks history items (one 32-lane-parallel binary search per batch) and
 // bitonic-merges them into the running best 32 held by the lower half-wave.
 // tau_out != NULL (pre-pass): no mask while merging; afterwards the k-th VALID one of the 32 best becomes the bound.
-// r05: 512 staged entries per wave (it was 2048: 64 KB of LDS per workgroup = 8 resident waves per CU and two rounds of them for
+// r05: 1024 staged entries per wave (it was 2048: 64 KB of LDS per workgroup = 8 resident waves per CU and two rounds of them for
 // 4096 users, each wave a chain of dependent loads — 28 us); history items are masked while they are copied (every lane searches
-// the user's graph row for its own entries, once), not once per batch of 32 in the merge loop.
-constexpr int kStage = 512;
+// the user's graph row — its head staged in LDS, HistRow — for its own entries, once), not once per batch of 32 in the merge loop.
+constexpr int kStage = 1024;
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ w_val, const int32_t *__restrict__ w_idx,
                                                         const int32_t *__restrict__ w_cnt, const int64_t *__restrict__ users,
                                                         const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -509,11 +556,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
                                                         float *__restrict__ tau_out) {
     __shared__ float s_val[4][kStage];
     __shared__ int s_idx[4][kStage];
+    __shared__ int s_hist[4][kHistStage];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
     const int64_t user = users[b];
     const bool mask_now = (tau_out == nullptr);
+    HistRow hist;
+    hist.stage(rowptr, col, n_users, user, s_hist[wave], lane);
     float v = kNegInf;  // lanes 0..31: best so far; lanes 32..63: incoming batch
     int idx = 0x7fffffff;
     int total = 0;
@@ -533,25 +583,26 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
         }
         total = 0;
     };
-    for (int l0 = 0; l0 < lists; l0 += 16) {
-        // 16 lists per round (at most 16 x 32 = kStage entries): lane quad 4j .. 4j + 3 copies list l0 + j (entries e = lane & 3, + 4, ...)
-        const int l = l0 + (lane >> 2);
+    for (int l0 = 0; l0 < lists; l0 += 32) {
+        // 32 lists per round (at most 32 x 32 = kStage entries; the usual 24 lists: ONE round): lane pair (2j, 2j + 1) copies list
+        // l0 + j (entries e = lane & 1, + 2, ...)
+        const int l = l0 + (lane >> 1);
         const int c = l < lists ? w_cnt[b * lists + l] : 0;
-        // exclusive prefix of the counts over the 16 lists (each list appears on four lanes: count it once)
-        int incl = (lane & 3) ? 0 : c;
+        // exclusive prefix of the counts over the 32 lists (each list appears on two lanes: count it once)
+        int incl = (lane & 1) ? 0 : c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int up = __shfl_up(incl, off);
             if (lane >= off) incl += up;
         }
         const int round_total = __shfl(incl, 63);
-        const int my_off = __shfl(incl, lane | 3) - c;  // start of this list inside the round
+        const int my_off = __shfl(incl, lane | 1) - c;  // start of this list inside the round
         if (total + round_total > kStage) flush();
         const int64_t src = (b * lists + l) * kListStride;
-        for (int e = lane & 3; e < c; e += 4) {
+        for (int e = lane & 1; e < c; e += 2) {
             float ev = w_val[src + e];
             int ei = w_idx[src + e];
-            if (mask_now && in_history(rowptr, col, n_users, user, ei)) {
+            if (mask_now && hist.has(ei)) {
                 ev = kNegInf;
                 ei = 0x7fffffff;
             }
@@ -564,7 +615,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     if (tau_out) {
         // lanes 0..31 hold the 32 best UNMASKED sample scores; the k-th one that is not a history item bounds the
         // user's k-th best valid score from below (-inf if the sample cannot tell)
-        const bool ok = lane < 32 && idx != 0x7fffffff && !in_history(rowptr, col, n_users, user, idx);
+        const bool ok = lane < 32 && idx != 0x7fffffff && !hist.has(idx);
         const unsigned long long m = __ballot(ok);
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0 && __popcll(m) < k) tau_out[b] = kNegInf;

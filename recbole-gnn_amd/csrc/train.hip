@@ -527,14 +527,13 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     hipStream_t s = (hipStream_t)stream;
     if (int zrc = zero_async(workspace, 3 * sizeof(float), s)) return zrc;
     const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
+    hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, fix_slot());
     if (opt_deterministic()) {
-        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, fix_slot());
         hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<false>), dim3(1), dim3(256), 0, s, a, reg_weight, workspace, loss);
         EmbRegRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = workspace;
         launch_ordered_scatter(r, 3 * B, s);
     } else {
-        hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, -1);
         hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<true>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, workspace, loss);
     }
     RBG_HIP(hipGetLastError());
