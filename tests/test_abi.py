@@ -75,6 +75,10 @@ def test_ops_refuse_host_graphs_and_missing_gpu(rbg):
     for key in ("sell", "sell_rowmajor", "sell_factored"):
         assert rbg.get_option(key) == 1
     assert rbg.get_option("sell_nt") == 0
+    assert rbg.get_option("deterministic") == 0  # float atomics by default; 1 = ordered row scatters + fixed-point sums (csrc/ordered.h)
+    rbg.set_option("deterministic", 1)
+    assert rbg.get_option("deterministic") == 1
+    rbg.set_option("deterministic", 0)
     for gone in ("sell_units_per_wave", "sell_depth", "sell_class_serial", "sweep"):  # measured negatives, moved out of the product in r05
         with pytest.raises(rbg.RbgError):
             rbg.set_option(gone, 1)
