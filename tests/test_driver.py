@@ -127,7 +127,7 @@ def test_fit_trains_the_subclass_objective(rbg, cuda, ref_inter, name):
     assert abs(lc[0] - total) <= 1e-4 * max(1.0, abs(total))
     assert abs(la[0] - total) <= 1e-3 * max(1.0, abs(total))
     for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
-        assert float((pc - pb).abs().max()) <= 1e-6                                             # the autograd path: the same launches
+        assert float((pc - pb).abs().max()) <= 5e-6                                             # the autograd path: the same launches (torch float-atomic index_add_: 1.3e-6 seen once)
         assert float((pa - pb).abs().max()) <= 2e-3 * max(1.0, float(pb.abs().max()))           # the fused step: rounding order
 
 
