@@ -262,7 +262,10 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     // iteration t and published it at the bottom: with the products knocked out the loop still ran at one memory latency
     // per tile.  Measured neutral (399 vs 397 us): the gradient kernel is not bound by the fetch but by the missing overlap of its
     // phases at two workgroups per CU — profiles/r04_lse_phase_probe.jsonl.  r05: raised priority between the first product and
-    // the barrier, which pays 3 % in topk.hip: 390-395 vs 394-401 us per InfoNCE with gradients at 2048 x 40 982 — inside the noise, not kept.)
+    // the barrier, which pays 3 % in topk.hip: 390-395 vs 394-401 us per InfoNCE with gradients at 2048 x 40 982 — inside the noise, not kept.
+    // Three workgroups per CU for the split gradient kernel (transposed planes at row stride 34: 54.0 KB of LDS; launch bounds 3 force
+    // 192 -> 168 registers with 20-27 spilled, whatever the order of the second product's loops): 434 / 300 us against 395 / 262 at
+    // 40 982 / 29 858 table rows, 479 / 351 with the chunking re-tuned for three — the scratch traffic costs more than the third wave hides.)
     if (t0 < t1) {
         fetch(t0);
         publish(0);
