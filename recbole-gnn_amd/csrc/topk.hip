@@ -252,11 +252,12 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     __shared__ float l_val[4][32][CAP];
     __shared__ int l_idx[4][32][CAP];
+    __shared__ int l_cnt[4][32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;  // first batch slot of this wave's user tile
     const bool wave_live = b0 < p.B;                            // an idle wave still fetches and meets the barriers
-    int my_cnt = 0;  // entries in the list of batch slot b0 + i (both lane halves keep it: read by v_readlane, no LDS round trip)
+    if (lane < 32) l_cnt[wave][lane] = 0;  // entries in the list of batch slot b0 + lane (LDS atomics hand out the slots)
     // A operand: the embedding row of batch slot b0 + i
     const int64_t bi = b0 + i;
     const int64_t my_user = bi < p.B ? p.users[bi] : -1;
@@ -307,43 +308,51 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
             bits |= (tst[r] >= 0.f) ? (1u << r) : 0u;
         });
         if (!item_ok) bits = 0u;
+        // r05, the appends: every lane with a passing entry serves ITSELF — the score out of its accumulator block by a select tree,
+        // the slot from an LDS atomic on the user's counter, two LDS writes; no ballot, no readlane, no scalar branch per row.  (The
+        // per-row form — one ballot + two counter reads + ranks per row — cost ~ 1 000 cycles per passing tile for ~ 100
+        // instructions: a chain of vector -> scalar -> vector hops, each waiting for a gap in the other waves' MFMA streams;
+        // 237 -> 221 us per call in the diagnostic build.)  A lane that finds its list full stops and keeps its bits.
+        unsigned pend = bits;
+        while (pend != 0u) {  // (divergent: one or two rounds)
+            const int r = __builtin_ctz(pend);
+            const bool r0 = r & 1, r1 = r & 2, r2 = r & 4, r3 = r & 8;
+            const float t0 = r0 ? acc[1] : acc[0], t1 = r0 ? acc[3] : acc[2], t2 = r0 ? acc[5] : acc[4], t3 = r0 ? acc[7] : acc[6];
+            const float t4 = r0 ? acc[9] : acc[8], t5 = r0 ? acc[11] : acc[10], t6 = r0 ? acc[13] : acc[12], t7 = r0 ? acc[15] : acc[14];
+            const float u0 = r1 ? t1 : t0, u1 = r1 ? t3 : t2, u2 = r1 ? t5 : t4, u3 = r1 ? t7 : t6;
+            const float v0 = r2 ? u1 : u0, v1 = r2 ? u3 : u2;
+            const float sv = r3 ? v1 : v0;
+            const int lu = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pos = atomicAdd(&l_cnt[wave][lu], 1);
+            if (pos >= CAP) break;  // full: this entry and the lane's later ones stay pending
+            l_val[wave][lu][pos] = sv;
+            l_idx[wave][lu][pos] = (int)item;
+            pend &= pend - 1u;
+        }
+        const unsigned long long left = __builtin_amdgcn_ballot_w64(pend != 0u);
+        if (left == 0ull) return;  // the common case: every list had room
+        // A list overflowed (rare: the thresholds start at the pre-pass bound; always in the first tiles when they do not).  The failed
+        // attempts pushed counters past CAP: clamp them, then the pending entries go row by row through the fill / prune / refill
+        // code below (one looped copy: the score leaves the accumulator block by a register-indexed move).
+        if (lane < 32 && l_cnt[wave][lane] > CAP) l_cnt[wave][lane] = CAP;
+        __builtin_amdgcn_wave_barrier();
         unsigned rows = 0u;
-        for (unsigned long long m = any; m; m &= m - 1ull) rows |= (unsigned)__builtin_amdgcn_readlane((int)bits, __builtin_ctzll(m));
-        // r05: ONE copy of the list code, walked over the set bits (the score leaves the accumulator block by a register-indexed
-        // move).  Unrolled per row and lane half it was 32 copies, each with its own 64-lane bitonic sort: 23 000 instructions in this
-        // kernel, and a tile with a passing entry (70 % of them on propagated embeddings) ran a different copy each time — the
-        // instruction cache, not the vector unit, paid for the filter.
+        for (unsigned long long m = left; m; m &= m - 1ull) rows |= (unsigned)__builtin_amdgcn_readlane((int)pend, __builtin_ctzll(m));
 #pragma clang loop unroll(disable)
         while (rows != 0u) {
             const int r = __builtin_ctz(rows);
             rows &= rows - 1u;
             const float s = acc[r];
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(((bits >> r) & 1u) != 0u);
-            // the two lane halves hold two different users (list slots lu0 and lu0 + 4); both are served at once when both lists
-            // have room: two counter reads (v_readlane: the counts live in registers), one rank, two LDS writes — no LDS read, no
-            // inner loop, no wave barrier
-            const unsigned lo = (unsigned)mask, hi = (unsigned)(mask >> 32);
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(((pend >> r) & 1u) != 0u);
             const int lu0 = (r & 3) + 8 * (r >> 2);
-            const int base0 = __builtin_amdgcn_readlane(my_cnt, lu0), base1 = __builtin_amdgcn_readlane(my_cnt, lu0 + 4);
-            const int add0 = __popc(lo), add1 = __popc(hi);
-            if (base0 + add0 <= CAP && base1 + add1 <= CAP) {
-                const unsigned mh = h ? hi : lo;
-                if ((mh >> i) & 1u) {
-                    const int slot = (h ? base1 : base0) + __popc(mh & ((1u << i) - 1u));
-                    l_val[wave][lu0 + 4 * h][slot] = s;
-                    l_idx[wave][lu0 + 4 * h][slot] = (int)item;
-                }
-                my_cnt += (i == lu0 ? add0 : 0) + (i == lu0 + 4 ? add1 : 0);
-                continue;
-            }
 #pragma clang loop unroll(disable)
-            for (int hh = 0; hh < 2; ++hh) {  // a list overflows (rare: the thresholds start at the pre-pass bound): one half at a time
-                unsigned rem = hh ? hi : lo;
+            for (int hh = 0; hh < 2; ++hh) {  // the two lane halves hold two different users: one half at a time
+                unsigned rem = hh ? (unsigned)(mask >> 32) : (unsigned)mask;
                 if (rem == 0u) continue;
                 const int lu = lu0 + 4 * hh;  // user slot inside the tile
                 float *lv = l_val[wave][lu];
                 int *li = l_idx[wave][lu];
-                int base = hh ? base1 : base0;
+                int base = __builtin_amdgcn_readfirstlane(l_cnt[wave][lu]);
                 // fill the list to CAP, prune it to its best k valid entries (that raises the user's threshold), go on with the rest
                 while (true) {
                     const int add = __popc(rem);
@@ -369,7 +378,8 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
                         tt.set(my_tau, h);
                     }
                 }
-                if (i == lu) my_cnt = base;
+                if (lane == 0) l_cnt[wave][lu] = base;
+                __builtin_amdgcn_wave_barrier();
             }
         }
     };
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     for (int lu = 0; lu < 32; ++lu) {
         const int64_t b = b0 + lu;
         if (b >= p.B) break;
-        int n = __builtin_amdgcn_readlane(my_cnt, lu);
+        int n = __builtin_amdgcn_readfirstlane(l_cnt[wave][lu]);
         if (n > kListStride) prune_list(p, __shfl(my_user, lu), l_val[wave][lu], l_idx[wave][lu], n, lane, n);
         __builtin_amdgcn_wave_barrier();
         const int64_t off = (b * lists + my_list) * kListStride;
