@@ -8,8 +8,9 @@
 //
 // Kernel 1 (score_topk_kernel): same MFMA tiling as score.hip (wave = 32 users x 32 items).  Lane i keeps the threshold tau of
 // batch slot i; after a tile ONE more MFMA forms score - tau in a second register block (TauTest), a max3 tree + one compare + one
-// ballot says whether anything passes (the common case costs 12 instructions); otherwise the passing lanes append
-// (score, item) to the user's LDS list (capacity 24, 48 or 64, raw: no history lookups in the hot loop; counts in registers).  A full
+// ballot says whether anything passes (the common case costs 12 instructions); otherwise every passing lane appends its
+// (score, item) to the user's LDS list itself (capacity 24, 48 or 64, raw: no history lookups in the hot loop; an LDS atomic on the
+// user's counter hands out the slot).  A full
 // list is pruned to its best k valid entries by a 64-lane bitonic sort, its history items dropped by ONE 64-lane-parallel binary
 // search in the user's graph row (a chain of dependent loads paid per batch, not per candidate); that raises tau.
 // A workgroup covers four 32-user tiles (one per wave) x one chunk of item tiles, which it fetches once, coalesced,
