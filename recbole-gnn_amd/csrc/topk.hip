@@ -96,20 +96,27 @@ __device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t 
 // binary search of in_history() is a chain of ~ log2(degree) dependent global loads (~ 0.5 us each) paid by every kernel that
 // masks; staged, the chain is two loads (rowptr, the row) and the search runs at LDS latency.  Columns past the staged head are
 // still read from global memory.
-constexpr int kHistStage = 512;
+constexpr int kHistStage = 128;  // (merge kernel: 32 KB of staged lists + 2 KB of history per workgroup = four workgroups per CU, all 4 096 users in one round)
 struct HistRow {
     const int32_t *col;
     const int *lds;
     int lo, hi, staged;
     int64_t n_users;
-    __device__ __forceinline__ void stage(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf, int lane) {
+    // two steps, so that a caller can put its own loads between them (they then travel with the row's)
+    __device__ __forceinline__ void begin(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf) {
         col = col_, lds = buf, n_users = n_users_;
         lo = hi = staged = 0;
         if (!rowptr || user < 0) return;
         lo = rowptr[user], hi = rowptr[user + 1];
+    }
+    __device__ __forceinline__ void finish(int *buf, int lane) {
         staged = hi - lo < kHistStage ? hi - lo : kHistStage;
-        for (int e = lane; e < staged; e += 64) buf[e] = col_[lo + e];
+        for (int e = lane; e < staged; e += 64) buf[e] = col[lo + e];
         __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void stage(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf, int lane) {
+        begin(rowptr, col_, n_users_, user, buf);
+        finish(buf, lane);
     }
     __device__ __forceinline__ bool has(int item) const {
         if (item < 0) return false;
@@ -573,8 +580,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     if (b >= B) return;
     const int64_t user = users[b];
     const bool mask_now = (tau_out == nullptr);
+    // three dependent round trips instead of five: {user, counts} -> {row bounds, first entries} -> {the row's head}
+    const int c_first = (lane >> 1) < lists ? w_cnt[b * lists + (lane >> 1)] : 0;
     HistRow hist;
-    hist.stage(rowptr, col, n_users, user, s_hist[wave], lane);
+    hist.begin(rowptr, col, n_users, user, s_hist[wave]);
+    const int64_t src_first = (b * lists + (lane >> 1)) * kListStride + (lane & 1);
+    const float pre_v = (lane & 1) < c_first ? w_val[src_first] : kNegInf;
+    const int pre_i = (lane & 1) < c_first ? w_idx[src_first] : 0x7fffffff;
+    hist.finish(s_hist[wave], lane);
     float v = kNegInf;  // lanes 0..31: best so far; lanes 32..63: incoming batch
     int idx = 0x7fffffff;
     int total = 0;
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
         // 32 lists per round (at most 32 x 32 = kStage entries; the usual 24 lists: ONE round): lane pair (2j, 2j + 1) copies list
         // l0 + j (entries e = lane & 1, + 2, ...)
         const int l = l0 + (lane >> 1);
-        const int c = l < lists ? w_cnt[b * lists + l] : 0;
+        const int c = l0 == 0 ? c_first : (l < lists ? w_cnt[b * lists + l] : 0);
         // exclusive prefix of the counts over the 32 lists (each list appears on two lanes: count it once)
         int incl = (lane & 1) ? 0 : c;
 #pragma unroll
@@ -611,8 +624,9 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
         if (total + round_total > kStage) flush();
         const int64_t src = (b * lists + l) * kListStride;
         for (int e = lane & 1; e < c; e += 2) {
-            float ev = w_val[src + e];
-            int ei = w_idx[src + e];
+            const bool first = l0 == 0 && e == (lane & 1);  // (requested above)
+            float ev = first ? pre_v : w_val[src + e];
+            int ei = first ? pre_i : w_idx[src + e];
             if (mask_now && hist.has(ei)) {
                 ev = kNegInf;
                 ei = 0x7fffffff;
