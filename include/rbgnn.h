@@ -96,6 +96,9 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "lse_onepass" : 1 (default) = rbg_infonce_f32 with gradients takes the denominators and the batch rows' gradient out of ONE
  *                   pass over the table (the unnormalised gradient accumulates beside the denominator; no separate forward
  *                   launch); 0 = forward launch + two gradient launches
+ *   "sell_c16"    : 1 (default) = the launches of the factored chain read their entries as 16-bit slab-row numbers where the plan
+ *                   has them (both row classes below 65 536 rows: 2 instead of 4 bytes per entry; r05: 91.6 -> 89.6 us per
+ *                   propagation at the Gowalla shape, 124.7 -> 121.1 at Yelp2018); 0 = 32-bit offsets.  Same bits.
  *   "deterministic" : 0 (default) = the mini-batch kernels (rbg_bpr_grad_f32, rbg_emb_reg_grad[_nopow]_f32, rbg_concat_bpr_*_f32,
  *                   rbg_infonce[_masked]_f32 with gradients) add the rows of repeated ids with float atomics, like torch's GPU
  *                   index_put_(accumulate=True): the low bits of those rows and of the loss sums vary from run to run;

@@ -50,6 +50,8 @@ static std::atomic<int> g_topk_short{1};
 int opt_topk_short_lists() { return g_topk_short.load(); }
 static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
+static std::atomic<int> g_sell_c16{1};
+int opt_sell_c16() { return g_sell_c16.load(); }
 static std::atomic<int> g_deterministic{0};
 int opt_deterministic() { return g_deterministic.load(); }
 int opt_col_split() { return g_col_split.load(); }
@@ -555,6 +557,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_deterministic = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_c16")) {
+        g_sell_c16 = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "topk_short_lists")) {
         if (value < 0 || value > 2) return fail(RBG_EINVAL, "topk_short_lists must be 0, 1 or 2");
         g_topk_short = (int)value;
@@ -637,6 +643,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "deterministic")) {
         *value = g_deterministic.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_c16")) {
+        *value = g_sell_c16.load();
         return RBG_OK;
     }
     if (!strcmp(key, "lse_onepass")) {

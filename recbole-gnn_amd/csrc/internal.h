@@ -38,6 +38,7 @@ int opt_nt_store();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
 int opt_sell_nt();         // sell.hip epilogue: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the mean's addends
+int opt_sell_c16();       // sell.hip: compact launches read 16-bit slab-row numbers where the plan has them (1, default)
 int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
 int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)
 int opt_sell();          // rbg_lightgcn_forward_f32: use an attached SELL plan (column-slab propagation, sell.hip)
@@ -103,6 +104,7 @@ struct SellDev {
     int32_t *ent = nullptr;          // [n_ent + 128][2]: {internal column * W * 4, bits of val}
     int32_t *ent0 = nullptr;         // same, column = original class-local row * 2 W * 4 (a launch that gathers row-major tables); optional
     int32_t *entc = nullptr;         // [n_ent + 256]: the offsets column of ent alone (launches of the factored chain)
+    uint16_t *entc16 = nullptr;      // [n_ent + 512]: the same as slab-ROW numbers (0xffff = padding), when both classes have < 65 536 rows
     float *rs = nullptr, *irs = nullptr;  // [n_rows] each (one allocation): r_i with val_ij = r_i r_j, and 1 / r_i; the plan's numbering; optional
     int32_t *head = nullptr;         // [n_units][4]
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)

@@ -131,6 +131,13 @@ __global__ void sell_first_entries_kernel(const int2 *ent, int2 *ent0, int64_t n
 __global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int64_t n) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) entc[e] = ent[e].x;
 }
+// ... and as 16-bit slab-row numbers (offset / (W 4); padding = 0xffff), [n, n_alloc) filled with padding
+__global__ void sell_compact16_kernel(const int2 *ent, uint16_t *entc16, int64_t n, int64_t n_alloc, int shift) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_alloc; e += (int64_t)gridDim.x * blockDim.x) {
+        const int off = e < n ? ent[e].x : kSellPast;
+        entc16[e] = off == kSellPast ? (uint16_t)0xffff : (uint16_t)(off >> shift);
+    }
+}
 
 // a re-weighted view's values: ent0v[pos].y = vals[src[pos]]
 __global__ void sell_refresh_values_kernel(int2 *ent, const int32_t *src, const float *vals, int64_t n_ent) {
@@ -173,6 +180,7 @@ void free_sell(SellDev *sw) {
     if (!sw->borrowed) {  // (a view owns its valued row-major entries and their first-batch block only)
         if (sw->ent) (void)hipFree(sw->ent);
         if (sw->entc) (void)hipFree(sw->entc);
+        if (sw->entc16) (void)hipFree(sw->entc16);
         if (sw->rs) (void)hipFree(sw->rs);  // (irs is its second half)
         if (sw->head) (void)hipFree(sw->head);
         if (sw->orig) (void)hipFree(sw->orig);
@@ -225,6 +233,8 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.head = reinterpret_cast<const int4 *>(sw->head);
     p.orig = sw->orig;
     p.entc = sw->entc;
+    p.entc16 = (sw->entc16 && opt_sell_c16()) ? reinterpret_cast<const int32_t *>(sw->entc16) : nullptr;
+    p.c16_shift = W == 64 ? 8 : 7;
     p.nt = opt_sell_nt();
     p.rs = sw->rs;
     p.irs = sw->irs;
@@ -579,6 +589,10 @@ int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
     // the offsets column alone (the factored chain's launches read 4 bytes per entry)
     if (sell_opt_alloc(&sw->entc, sizeof(int32_t) * (size_t)(n_ent + 256), true) && n_ent)
         hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc, n_ent);
+    // r05: the same column as 16-bit slab-row numbers when both classes are small enough (Gowalla, Yelp2018: yes; Amazon-Book: no)
+    if (sw->entc && std::max(n0, n1) < 65535 && sell_opt_alloc(&sw->entc16, sizeof(uint16_t) * (size_t)(n_ent + 512), true))
+        hipLaunchKernelGGL(sell_compact16_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc16, n_ent, n_ent + 512,
+                           W == 64 ? 8 : 7);
     // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per
     // propagation).  A failed allocation leaves the plan without the twin — and touches nothing else (r03: this branch freed
     // entc and rs without clearing them)

@@ -43,6 +43,8 @@ struct SellParams {
     // factored chain (val_ij = r_i r_j, the symmetric normalisation): the slabs between the layers hold z = r (.) y, a launch that
     // gathers z reads COLUMN OFFSETS ONLY (entc: 4 bytes per entry instead of 8) and scales its row sums by r_i
     const int32_t *entc;     // compact: the offsets column of ent
+    const int32_t *entc16;   // compact, or NULL: the same as PAIRS of 16-bit slab-row numbers (r05: half the entry bytes again)
+    int32_t c16_shift;       // log2(W * 4): row number -> byte offset
     const float *rs, *irs;   // r_i and 1 / r_i (0 for an empty row), the plan's numbering
     int32_t compact;         // 1: gather through entc (the operand is a scaled slab), acc *= r_i
     int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
@@ -272,22 +274,32 @@ __device__ __forceinline__ void sell_widen(WT &e, const int sh) {
 // (r04, measured and removed: the unit's first batch from a fixed-stride block requested together with the header instead of
 // after it — 93.4 vs 93.5 us per propagation at the Gowalla shape, 126.0 vs 126.2 at Yelp2018: the header -> entries round trip
 // is not on the critical path; profiles/r04_launch_forms.jsonl)
+// (c16: the unit's entries as pairs of 16-bit slab-row numbers, or NULL — uniform over the launch)
 template <int W, int NS, class WT>
-__device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const int nc, const int lg, const int q4,
-                                             const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh, SellClock &clk) {
+__device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const int32_t *c16, const int c16_shift, const int nc, const int lg,
+                                             const int q4, const __amdgpu_buffer_rsrc_t rs, const int lane_off, const int sh, SellClock &clk) {
     constexpr int LGW = 64 / (W / 4);
     if (nc <= 0) return;
     int sb = min(8, nc);
+    auto entries = [&](const int idx) __attribute__((always_inline)) -> WT {
+        if constexpr (std::is_same<WT, v2i>::value) {
+            if (c16) {  // 0xffff (padding) << shift is past every table with < 65 536 rows
+                const unsigned t = (unsigned)c16[idx];
+                return WT{(int)((t & 0xffffu) << c16_shift), (int)((t >> 16) << c16_shift)};
+            }
+        }
+        return base[idx];
+    };
     // (plain loads: with the non-temporal hint on the entry stream the layer measured 38.6 us instead of 31)
     WT w = {};
-    if (2 * q4 < sb) w = base[lg * (sb >> 1) + q4];
+    if (2 * q4 < sb) w = entries(lg * (sb >> 1) + q4);
     sell_widen(w, sh);
     for (int k = 0; k < nc; k += 8) {
         const int sbn = min(8, nc - k - 8);  // slots of the next batch (<= 0: none)
         WT wn = {};
         SellRows x;
         sell_issue_n(sb, x, w, rs, lane_off);
-        if (sbn > 0 && 2 * q4 < sbn) wn = base[((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4];
+        if (sbn > 0 && 2 * q4 < sbn) wn = entries(((LGW * (k + 8)) >> 1) + lg * (sbn >> 1) + q4);
         if (k == 0) clk.lap(1);
         sell_consume_n(sb, acc, x, w);
         sell_widen(wn, sh);
@@ -336,10 +348,15 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     SellAcc acc = {{0.f, 0.f}, {0.f, 0.f}};
     // (ent0's offsets are rows of 2 W floats: a 4 W or a W row-major operand rescales them)
     const WT *ebase;
-    if constexpr (COMPACT) ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
-    else ebase = ents + (h.x >> 1);
+    const int32_t *e16 = nullptr;
+    if constexpr (COMPACT) {
+        ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
+        if (p.entc16) e16 = p.entc16 + (h.x >> 1);
+    } else {
+        ebase = ents + (h.x >> 1);
+    }
     const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
-    sell_gather1<W, NS, WT>(acc, ebase, nc, lg, q4, rs, lane_off, sh, clk);
+    sell_gather1<W, NS, WT>(acc, ebase, e16, p.c16_shift, nc, lg, q4, rs, lane_off, sh, clk);
     clk.count(nc * LGW);
     clk.lap(2);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order

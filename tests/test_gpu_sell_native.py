@@ -269,6 +269,13 @@ def test_every_form_of_the_propagation_over_the_plan(rbg, cuda, d):
     close(base[7], (g64 + gl[0] + gl[1] + gl[2]) / 4)
     for a, b in zip(run(), base):
         assert torch.equal(a, b)
+    try:  # r05: the compact launches read 16-bit slab-row numbers (both classes < 65 536 rows); 32-bit offsets give the same bits
+        assert rbg.get_option("sell_c16") == 1
+        rbg.set_option("sell_c16", 0)
+        for a, b in zip(run(), base):
+            assert torch.equal(a, b)
+    finally:
+        rbg.set_option("sell_c16", 1)
     try:  # the unfactored chain differs by rounding only
         rbg.set_option("sell_factored", 0)
         assert h.propagation_kernel_name(d) == f"sell_spmm_kernel<32, {d // 32}, false>"
