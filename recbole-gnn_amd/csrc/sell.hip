@@ -135,7 +135,7 @@ __global__ void sell_compact_entries_kernel(const int2 *ent, int32_t *entc, int6
 __global__ void sell_compact16_kernel(const int2 *ent, uint16_t *entc16, int64_t n, int64_t n_alloc, int shift) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_alloc; e += (int64_t)gridDim.x * blockDim.x) {
         const int off = e < n ? ent[e].x : kSellPast;
-        entc16[e] = off == kSellPast ? (uint16_t)0xffff : (uint16_t)(off >> shift);
+        entc16[e] = (off == kSellPast || (off >> shift) >= 0xffff) ? (uint16_t)0xffff : (uint16_t)(off >> shift);  // (a class too large for 16 bits never reads its half)
     }
 }
 
@@ -235,6 +235,7 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.entc = sw->entc;
     p.entc16 = (sw->entc16 && opt_sell_c16()) ? reinterpret_cast<const int32_t *>(sw->entc16) : nullptr;
     p.c16_shift = W == 64 ? 8 : 7;
+    p.c16_ok[0] = sw->n_class[1] < 65535, p.c16_ok[1] = sw->n_class[0] < 65535;
     p.nt = opt_sell_nt();
     p.rs = sw->rs;
     p.irs = sw->irs;
@@ -589,8 +590,9 @@ int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
     // the offsets column alone (the factored chain's launches read 4 bytes per entry)
     if (sell_opt_alloc(&sw->entc, sizeof(int32_t) * (size_t)(n_ent + 256), true) && n_ent)
         hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc, n_ent);
-    // r05: the same column as 16-bit slab-row numbers when both classes are small enough (Gowalla, Yelp2018: yes; Amazon-Book: no)
-    if (sw->entc && std::max(n0, n1) < 65535 && sell_opt_alloc(&sw->entc16, sizeof(uint16_t) * (size_t)(n_ent + 512), true))
+    // r05: the same column as 16-bit slab-row numbers; the rows of class c use them when class 1 - c has < 65 535 rows (Gowalla,
+    // Yelp2018: both classes; Amazon-Book: the item rows, which gather the 52 644 user rows)
+    if (sw->entc && std::min(n0, n1) < 65535 && sell_opt_alloc(&sw->entc16, sizeof(uint16_t) * (size_t)(n_ent + 512), true))
         hipLaunchKernelGGL(sell_compact16_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc16, n_ent, n_ent + 512,
                            W == 64 ? 8 : 7);
     // the row-major twin of the entries (used under option 'sell_rowmajor', default 1; without it E0 is converted to slabs per

@@ -45,6 +45,7 @@ struct SellParams {
     const int32_t *entc;     // compact: the offsets column of ent
     const int32_t *entc16;   // compact, or NULL: the same as PAIRS of 16-bit slab-row numbers (r05: half the entry bytes again)
     int32_t c16_shift;       // log2(W * 4): row number -> byte offset
+    int32_t c16_ok[2];       // rows of class c gather class 1 - c: 16-bit numbers serve them when THAT class has < 65 535 rows
     const float *rs, *irs;   // r_i and 1 / r_i (0 for an empty row), the plan's numbering
     int32_t compact;         // 1: gather through entc (the operand is a scaled slab), acc *= r_i
     int32_t store_scaled;    // 1: ys = r_i * (...): the next launch is compact
@@ -351,7 +352,7 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     const int32_t *e16 = nullptr;
     if constexpr (COMPACT) {
         ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
-        if (p.entc16) e16 = p.entc16 + (h.x >> 1);
+        if (p.entc16 && p.c16_ok[cls]) e16 = p.entc16 + (h.x >> 1);
     } else {
         ebase = ents + (h.x >> 1);
     }
