@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     // the barrier, which pays 3 % in topk.hip: 390-395 vs 394-401 us per InfoNCE with gradients at 2048 x 40 982 — inside the noise, not kept.
     // Three workgroups per CU for the split gradient kernel (transposed planes at row stride 34: 54.0 KB of LDS; launch bounds 3 force
     // 192 -> 168 registers with 20-27 spilled, whatever the order of the second product's loops): 434 / 300 us against 395 / 262 at
-    // 40 982 / 29 858 table rows, 479 / 351 with the chunking re-tuned for three — the scratch traffic costs more than the third wave hides.)
+    // 40 982 / 29 858 table rows, 479 / 351 with the chunking re-tuned for three — the scratch traffic costs more than the third wave hides.
+    // The transposed planes at stride 34 alone (two workgroups per CU): SQ_LDS_BANK_CONFLICT 11.8 M -> 3.9 M cycles per launch (the 2-byte
+    // transposed stores of publish() are 4-way conflicted at stride 36), launch time unchanged (398 vs 395 us): not on the critical path.)
     if (t0 < t1) {
         fetch(t0);
         publish(0);
