@@ -101,7 +101,10 @@ __device__ __forceinline__ void commit_sums(const float (&part)[NV], float *cons
         return;
     }
 #pragma unroll
-    for (int j = 0; j < NV; ++j) atomicAdd(&g_fix_acc[slot][j], (unsigned long long)__float2ll_rn(tot[j] * 4294967296.0f));
+    for (int j = 0; j < NV; ++j) {
+        if (fabsf(tot[j]) < 1.0e9f) atomicAdd(&g_fix_acc[slot][j], (unsigned long long)__float2ll_rn(tot[j] * 4294967296.0f));
+        else atomicAdd(dst[j], tot[j]);  // beyond the 31.32 range (a diverged run; NaN): still summed, no longer order-free
+    }
     __threadfence();
     if (atomicAdd(&g_fix_cnt[slot], 1u) == gridDim.x - 1) {  // the last workgroup: every partial sum is in
         __threadfence();
