@@ -629,8 +629,11 @@ __global__ __launch_bounds__(256) void nce_batch_back_kernel(const NceBackArgs a
 // NOTE: an occurrence reads C[r] and writes dC[r] / grad_T1[r] — different buffers — so owners and non-owners never race.
 struct NceBackRows {
     NceBackArgs a;
-    __device__ __forceinline__ int64_t key(int64_t m) const { return a.idx[m]; }
-    __device__ __forceinline__ void range(int64_t, int64_t &lo, int64_t &hi) const { lo = 0, hi = a.B; }
+    __device__ __forceinline__ int segments(int64_t w, KeySeg (&seg)[2], int64_t &mine) const {
+        mine = a.idx[w];
+        seg[0] = KeySeg{a.idx, a.B, 0};
+        return 1;
+    }
     __device__ __forceinline__ void apply(int64_t m, int lane) const { nce_batch_back_elem<true>(a, m, lane); }
 };
 
@@ -732,8 +735,11 @@ __global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const NceBack
 
 struct NceBackPartsRows {
     NceBackPartsArgs a;
-    __device__ __forceinline__ int64_t key(int64_t m) const { return a.idx[m]; }
-    __device__ __forceinline__ void range(int64_t, int64_t &lo, int64_t &hi) const { lo = 0, hi = a.B; }
+    __device__ __forceinline__ int segments(int64_t w, KeySeg (&seg)[2], int64_t &mine) const {
+        mine = a.idx[w];
+        seg[0] = KeySeg{a.idx, a.B, 0};
+        return 1;
+    }
     __device__ __forceinline__ void apply(int64_t m, int lane) const { nce_batch_back_parts_elem<true>(a, m, lane); }
 };
 

@@ -192,15 +192,19 @@ __global__ __launch_bounds__(256) void bpr_grad_kernel(const BprArgs a, float *_
 struct Triples {
     const int64_t *user, *pos, *neg;
     int64_t n_users, B;
-    __device__ __forceinline__ int64_t key(int64_t m) const {  // (compares, not a 64-bit division: every wavefront evaluates this n times)
-        return m < B ? user[m] : n_users + (m < 2 * B ? pos[m - B] : neg[m - 2 * B]);
+    __device__ __forceinline__ int segments(int64_t w, KeySeg (&seg)[2], int64_t &mine) const {
+        if (w < B) {
+            mine = user[w];
+            seg[0] = KeySeg{user, B, 0};
+            return 1;
+        }
+        mine = w < 2 * B ? pos[w - B] : neg[w - 2 * B];
+        seg[0] = KeySeg{pos, B, B};
+        seg[1] = KeySeg{neg, B, 2 * B};
+        return 2;
     }
     __device__ __forceinline__ int which_of(int64_t m) const { return m < B ? 0 : (m < 2 * B ? 1 : 2); }
     __device__ __forceinline__ int64_t triple_of(int64_t m) const { return m < B ? m : (m < 2 * B ? m - B : m - 2 * B); }
-    __device__ __forceinline__ void range(int64_t w, int64_t &lo, int64_t &hi) const {
-        lo = w < B ? 0 : B;
-        hi = w < B ? B : 3 * B;
-    }
 };
 
 struct BprRows : Triples {
