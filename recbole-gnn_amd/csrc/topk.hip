@@ -98,13 +98,13 @@ __device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t 
 // still read from global memory.
 constexpr int kHistStage = 128;  // (merge kernel: 32 KB of staged lists + 2 KB of history per workgroup = four workgroups per CU, all 4 096 users in one round)
 struct HistRow {
-    const int32_t *col;
+    const __attribute__((address_space(1))) int32_t *col;  // (global, not generic: a flat load in the search loop would make every wait a full one)
     const int *lds;
     int lo, hi, staged;
     int64_t n_users;
     // two steps, so that a caller can put its own loads between them (they then travel with the row's)
     __device__ __forceinline__ void begin(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf) {
-        col = col_, lds = buf, n_users = n_users_;
+        col = (const __attribute__((address_space(1))) int32_t *)col_, lds = buf, n_users = n_users_;
         lo = hi = staged = 0;
         if (!rowptr || user < 0) return;
         lo = rowptr[user], hi = rowptr[user + 1];
