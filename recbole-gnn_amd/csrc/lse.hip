@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     constexpr bool kPlT = SPLIT && GRAD;
     __shared__ __attribute__((aligned(16))) __bf16 s_plt[kPlT ? 2 : 1][3][kPlT ? NC * 64 : 1][kPlT ? LDT : 4];
     __shared__ float s_coef[2][32];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
     const int i = lane & 31, h = lane >> 5;
     const int64_t j = (int64_t)(blockIdx.x & 7) * p.blocks_per_xcd + (blockIdx.x >> 3);
     if (j >= p.total_blocks) return;  // whole workgroup

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
     __shared__ float l_val[4][32][CAP];
     __shared__ int l_idx[4][32][CAP];
     __shared__ int l_cnt[4][32];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;  // first batch slot of this wave's user tile
     const bool wave_live = b0 < p.B;                            // an idle wave still fetches and meets the barriers
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
                                                            int32_t *__restrict__ g_idx) {
     using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
     const bool wave_live = b0 < p.B;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
                                                        const int32_t *__restrict__ col, int64_t n_users, int64_t B, int splits,
                                                        int k, float *__restrict__ tau_out) {
     __shared__ int s_hist[4][kHistStage];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
     HistRow hist;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     __shared__ float s_val[4][kStage];
     __shared__ int s_idx[4][kStage];
     __shared__ int s_hist[4][kHistStage];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= B) return;
     const int64_t user = users[b];
