@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, (NT <= 2 ? 3 : 1)) void bignn_dense_kernel(con
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     constexpr int DP = 32 * NT;
     const int nch = (p.d_in + 63) / 64;  // k chunks per part
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (p.n_rows + 31) / 32;
     const int64_t tile_first = (int64_t)blockIdx.x * 4 + wave;

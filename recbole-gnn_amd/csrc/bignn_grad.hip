@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void bignn_wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // layout per buffer: g[32][DO] | s[32][DI] | h[32][DI]
     constexpr int BUF = 32 * (DO + 2 * DI);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (p.n_rows + 31) / 32;
 
@@ -264,7 +264,7 @@ template <int TI, int NCO, bool FAST>
 __global__ __launch_bounds__(256, (TI <= 2 && NCO == 1 ? 2 : 1)) void bignn_dgrad_kernel(const DgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float Wl[];
     constexpr int DP = 32 * TI, KP = 64 * NCO + 4;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (p.n_rows + 31) / 32;
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;

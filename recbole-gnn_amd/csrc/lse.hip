@@ -535,7 +535,7 @@ __device__ __forceinline__ float wave_sum(float x) {
 __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__restrict__ T, int64_t n, int d, float *__restrict__ C,
                                                              float *__restrict__ inv) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= n) return;
     const float *row = T + j * d;
     float ss = 0.f;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__rest
                                                              const int64_t *__restrict__ idx, int64_t B, int d,
                                                              float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= B) return;
     const int64_t r = idx[b];
     const float *row = T1 + r * d;
@@ -620,7 +620,7 @@ __device__ __forceinline__ void nce_batch_back_elem(const NceBackArgs &a, int64_
 }
 
 __global__ __launch_bounds__(256) void nce_batch_back_kernel(const NceBackArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= a.B) return;
     nce_batch_back_elem<false>(a, b, threadIdx.x & 63);
 }
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void nce_table_back_kernel(const float *__rest
                                                              const float *__restrict__ inv, int64_t n, int d,
                                                              float *__restrict__ grad_T2) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= n) return;
     float dot = 0.f;
     for (int c = lane; c < d; c += 64) dot = fmaf(dC[j * d + c], C[j * d + c], dot);
@@ -728,7 +728,7 @@ __device__ __forceinline__ void nce_batch_back_parts_elem(const NceBackPartsArgs
 }
 
 __global__ __launch_bounds__(256) void nce_batch_back_parts_kernel(const NceBackPartsArgs a) {
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= a.B) return;
     nce_batch_back_parts_elem<false>(a, b, threadIdx.x & 63);
 }
@@ -748,7 +748,7 @@ struct NceBackPartsRows {
 __global__ __launch_bounds__(256) void nce_table_back_parts_kernel(const float *__restrict__ part_c, int n_chunks, const float *__restrict__ C,
                                                                    const float *__restrict__ inv, int64_t n, int d, float *__restrict__ grad_T2) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= n) return;
     float g0 = 0.f, g1 = 0.f;
     const bool in0 = lane < d, in1 = lane + 64 < d;

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
     constexpr int W = (HALF && !SLAB) ? 2 * D : D;
     const int hoff = HALF ? (int)(blockIdx.x & 1) * D : 0;  // column offset of this half inside a full-width row
     const int64_t coff = SLAB ? (int64_t)(blockIdx.x & 1) * p.n_rows * D : hoff;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR;
     const int sl = lane % LPR;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void spmm_binned_kernel(const SpmmParams p) {
 
 // Any d / any alignment: one wavefront per row, lanes stride the feature dimension.
 __global__ __launch_bounds__(256) void spmm_generic_kernel(const SpmmParams p, int d) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= p.n_rows) return;
     const int beg = p.rowptr[row], end = p.rowptr[row + 1];

@@ -126,7 +126,7 @@ __device__ __forceinline__ void block_add_loss(float part, float *loss, int slot
 
 // element groups of kElemsPerWave a wave walks: grp = first, first + stride, ...
 #define RBG_FOR_GROUPS(grp, n_elems)                                                                  \
-    for (int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); grp * kElemsPerWave < (n_elems); \
+    for (int64_t grp = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); grp * kElemsPerWave < (n_elems); \
          grp += (int64_t)gridDim.x * (blockDim.x >> 6))
 
 static inline dim3 grid_for(int64_t n_elems) { return dim3((unsigned)((n_elems + 4 * kElemsPerWave - 1) / (4 * kElemsPerWave))); }
