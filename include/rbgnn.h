@@ -120,7 +120,11 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "fail_alloc_after" : test hook: the (n + 1)-th device allocation of the plan code from now fails once (-1 = off)
  *   "sell_nt"     : non-temporal hints in that kernel's epilogue (bit 0 stores, bit 1 the mean's addend loads; default 0, no effect measured)
  *   "slab"        : measured-and-off r03 variant of the binned kernel over column halves (default 0)
- *   "shard_single_stream" : 1 = the C-ABI sharded layer packs and exchanges on the caller's stream (capturable); default 0 */
+ *   "shard_single_stream" : 1 = the C-ABI sharded layer packs and exchanges on the caller's stream (capturable); default 0
+ *   "shard_fused" : 1 (default) = rbg_graph_create_sharded builds the rank's block [A_interior | A_halo] as ONE rectangular handle
+ *                   planned for the column-slab kernel; a layer is pack -> exchange -> ONE launch over the table [owned rows | halo
+ *                   rows] on the caller's stream (no accumulate pass, every entry on sell_spmm_kernel); 0 = two handles (interior
+ *                   product beside the exchange on the shard's stream, then Y += A_halo X_halo).  Read at creation. */
 int rbg_set_option(const char *key, int64_t value);
 int rbg_get_option(const char *key, int64_t *value);
 
@@ -240,12 +244,12 @@ int rbg_graph_refresh_values(rbg_graph *view, void *stream);
  * plan in place; destroy the views first (and, as for every view, before the base handle itself). */
 
 /* Column-slab propagation (r03; csrc/sell.hip): attach an EXTERNALLY built SELL-C-sigma plan of this graph for slab width W
- * (the executable specification recbole-gnn_amd/sell.py; the tests compare rbg_graph_plan_sell with it).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
+ * (the executable specification tests/sell_spec.py; the tests compare rbg_graph_plan_sell with it).  rbg_lightgcn_forward_f32 then runs the slab kernel whenever it is called with ONE graph,
  * RBG_FWD_LAYERS_SCRATCH and without RBG_FWD_KEEP_LAST_LAYER (option "sell", default 1); with the layers kept row-major the
  * same kernel serves the other flag combinations, rbg_lightgcn_backward_f32 and rbg_spmm_f32 at that width (option
  * "sell_rowmajor", default 1: E0 / the gradient / X are gathered where they lie through a twin of the entry array in the
  * reference's numbering, built at attach time, +8 bytes per entry).  The planner is
- * recbole-gnn_amd/sell.py (torch ops on the handle's device CSR); `ent` [n_ent][2], `head` [n_units][4] and `orig` [n_rows] are
+ * tests/sell_spec.py (torch ops on the handle's device CSR); `ent` [n_ent][2], `head` [n_units][4] and `orig` [n_rows] are
  * DEVICE arrays on the graph's device, `unit_base` / `n_units` host arrays of 2.  Every index the kernel dereferences is
  * range-checked on the device before the plan is adopted (copied: the caller keeps its arrays).  Graphs built from
  * interactions (a user / item boundary, square) only; a re-weighted view cannot carry a plan. */
@@ -526,14 +530,21 @@ int rbg_graph_create_sharded(rbg_shard **out, rbg_comm *comm, int64_t n_owned, i
                              const int64_t *recv_counts, int d_max);
 void rbg_shard_destroy(rbg_shard *shard);
 
+/* What the shard runs, as text: "fused: <plan status of the [interior | halo] handle>" or "two handles: interior <status>, halo
+ * <status>" (the statuses of rbg_graph_sell_status). */
+int rbg_shard_status(const rbg_shard *shard, char *buf, int len);
+
 /* One sharded layer, collective over the communicator: Y[owned] = Â[owned, :] X with X = this rank's owned rows [n_owned, d].
- * The halo rows are packed and exchanged (grouped ncclSend / ncclRecv) on the shard's own high-priority stream while the
- * interior product runs on `stream`; then Y += Â_halo X_halo.  Also the backward of itself (the global Â is symmetric). */
+ * Fused shards (option "shard_fused", r06): the halo rows are packed and exchanged (grouped ncclSend / ncclRecv) on `stream` into
+ * the tail of the shard's [owned | halo] table, then ONE launch computes Y.  Two-handle shards: the exchange runs on the shard's
+ * own high-priority stream while the interior product runs on `stream`; then Y += Â_halo X_halo.
+ * Also the backward of itself (the global Â is symmetric). */
 int rbg_spmm_sharded_f32(rbg_shard *shard, const float *X, float *Y, int d, void *stream);
 
 /* lightgcn.py:70-81 over the shard: out_mean [n_owned, d] = mean(E_0 .. E_K) of the owned rows, K exchanges; the layer
- * mean rides in the last halo product's epilogue.  layers: [K][n_owned][d] (E_1 .. E_{K-1} are kept there; the last slice
- * is scratch).  1 <= K <= RBG_MAX_FUSED_LAYERS + 1. */
+ * mean rides in the last product's epilogue.  layers: [K][n_owned][d] scratch (two-handle shards keep E_1 .. E_{K-1} there; a
+ * fused shard keeps its layers in its own [owned | halo] tables — K of them, grown by the first call, which must therefore run
+ * outside a stream capture — and leaves `layers` untouched).  1 <= K <= RBG_MAX_FUSED_LAYERS + 1. */
 int rbg_lightgcn_forward_sharded_f32(rbg_shard *shard, const float *E0, float *out_mean, float *layers, int d, int K, void *stream);
 
 /* out[t] = scale * (srcs[0][t] + srcs[1][t] + ...), added left to right: the layer mean of lightgcn.py:80-81 over

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rbg_comm_destroy": (None, [c_vp]),
     "rbg_graph_create_sharded": (c_int, [P(c_vp), c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int]),
     "rbg_shard_destroy": (None, [c_vp]),
+    "rbg_shard_status": (c_int, [c_vp, ctypes.c_char_p, c_int]),
     "rbg_spmm_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "rbg_lightgcn_forward_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "rbg_mean_f32": (c_int, [c_vp, c_int, c_i64, c_f32, c_vp, c_vp]),

@@ -56,6 +56,8 @@ static std::atomic<int> g_deterministic{0};
 int opt_deterministic() { return g_deterministic.load(); }
 int opt_col_split() { return g_col_split.load(); }
 static std::atomic<int> g_shard_single_stream{0};
+static std::atomic<int> g_shard_fused{1};
+int opt_shard_fused() { return g_shard_fused.load(); }
 static std::atomic<int> g_slab{0};
 static std::atomic<int> g_sell{1};
 int opt_sell() { return g_sell.load(); }
@@ -426,7 +428,14 @@ static void auto_plan(rbg_graph *g) {
         g->sell_note = "rows are pinned to XCDs by the caller's community partition";
         return;
     }
-    const int rc = plan_sell(g, 32, 0);
+    // a rectangular block with two row classes (a shard's [owned | halo] product or its halo block): the rectangular form;
+    // a square one that is not the bipartite adjacency (a halo block with as many slots as rows): the same
+    int rc = g->n_rows != g->n_cols ? plan_sell(g, 32, 0, true) : plan_sell(g, 32, 0, false);
+    if (rc == RBG_EUNSUPPORTED && g->n_rows == g->n_cols && g->n_users < 0 && g->row_split > 0 && g->row_split < g->n_rows &&
+        g->sell_note.find("not the bipartite") != std::string::npos) {
+        clear_error();
+        rc = plan_sell(g, 32, 0, true);
+    }
     if (rc != RBG_OK) {
         if (g->sell_note.empty() || rc != RBG_EUNSUPPORTED) g->sell_note = t_error;
         clear_error();
@@ -507,6 +516,10 @@ int rbg_set_option(const char *key, int64_t value) {
     }
     if (!strcmp(key, "shard_single_stream")) {
         g_shard_single_stream = value ? 1 : 0;
+        return RBG_OK;
+    }
+    if (!strcmp(key, "shard_fused")) {
+        g_shard_fused = value ? 1 : 0;
         return RBG_OK;
     }
     if (!strcmp(key, "slab")) {
@@ -591,6 +604,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "nt_store")) {
         *value = g_nt_store.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "shard_fused")) {
+        *value = g_shard_fused.load();
         return RBG_OK;
     }
     if (!strcmp(key, "shard_single_stream")) {

@@ -37,6 +37,7 @@ int opt_xcd_split();
 int opt_nt_store();
 int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA kernel (1) or the general kernel (0)
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
+int opt_shard_fused();  // rbg_graph_create_sharded: the rank's [interior | halo] block as ONE planned handle, a layer = exchange + one launch (1, default)
 int opt_sell_nt();         // sell.hip epilogue: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the mean's addends
 int opt_sell_c16();       // sell.hip: compact launches read 16-bit slab-row numbers where the plan has them (1, default)
 int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
@@ -95,7 +96,7 @@ struct GroupPlan {
     int32_t n_short, pos_short;  // lane-group rows  desc[pos_short .. +n_short)
 };
 
-// SELL-C-sigma plan of the column-slab propagation (sell.hip; planner recbole-gnn_amd/sell.py).  All device.
+// SELL-C-sigma plan of the column-slab propagation (sell.hip; planner sell_plan.hip, specification tests/sell_spec.py).  All device.
 struct SellDev {
     int W = 0;                       // slab width (the plan serves d = 2 W)
     int32_t unit_base[2] = {0, 0};   // first unit of row class c
@@ -113,6 +114,10 @@ struct SellDev {
     int64_t first_ent1 = 0;          // first entry of class 1's units
     int chunk = 0;                   // the planner's chunk (0: an attached plan)
     bool native = false;             // built by rbg_graph_plan_sell (the values are the graph's own)
+    bool rect = false;               // a RECTANGULAR block (r06: a shard's [owned | halo] product, sharded.py): the columns index ONE
+                                     // row-major table of n_tab rows, ent holds row-major offsets (col * 2 W * 4) and ent0 aliases it;
+                                     // no slab chain (entc / rs stay NULL): every launch gathers row-major
+    int32_t n_tab = 0;               // rect: rows of the gathered table (= the handle's n_cols)
     const SellDev *borrowed = nullptr;  // a re-weighted view: everything but ent0 / fb0 belongs to the base graph's plan
     bool view_fresh = false;         // a view's values have been refreshed at least once (rbg_graph_refresh_values)
     float *bwd = nullptr;            // [3][n_rows][2 W] slab scratch of the backward chain WITHOUT row-major entries (allocated by the first such backward)
@@ -125,7 +130,7 @@ void free_sell(SellDev *sw);
 int sell_adopt(rbg_graph *g, SellDev *sw, bool validate);
 int sell_set_factors(rbg_graph *g, const float *r);  // rbg_graph_sell_set_factors without the error reset
 // sell_plan.hip
-int plan_sell(rbg_graph *g, int W, int chunk);
+int plan_sell(rbg_graph *g, int W, int chunk, bool rect = false);  // rect: the rectangular form (SellDev::rect)
 
 
 }  // namespace rbg
@@ -205,6 +210,8 @@ bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact e
 // (X: row stride ldx floats — d, or a column block of a wider buffer when sell_stride_ok; Y contiguous)
 bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx);  // the plain layer runs on the plan (row-major entries, or the slab scratch)
 int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s);
+// rbg_spmm_mean_f32 over the plan: out = (srcs[0] + ... + srcs[n - 1] + (partial +) A X) / (n + 1), everything row-major [n_rows, d]
+int sell_spmm_mean(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean, int d, hipStream_t s);
 bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx);
 // every layer row-major (the caller reads `layers`, or one graph per layer)
 int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,

@@ -1,6 +1,6 @@
 // sell.hip — the propagation of LightGCN.forward / SGL.forward (lightgcn.py:70-81, sgl.py:128-145) over COLUMN SLABS with a
 // sliced-ELL graph (r03).  Used by rbg_lightgcn_forward_f32 at d = 64 when a plan is attached
-// (rbg_graph_attach_sell; planner recbole-gnn_amd/sell.py) and the caller does not read the intermediate layers.
+// (rbg_graph_attach_sell; planner sell_plan.hip, specification tests/sell_spec.py) and the caller does not read the intermediate layers.
 //
 // Why: the binned kernel (spmm.hip) is bound by L2 misses — an XCD's 4 MB L2 cannot hold the table its rows gather from, and
 // a layer moves 230 MB over the fabric for 53 MB of algorithmic bytes at the Gowalla shape.  Here
@@ -102,11 +102,12 @@ __global__ void sell_check_units_kernel(const int4 *head, int n_units_total, int
     }
     if (bad) atomicExch(err, 1 + t);
 }
-__global__ void sell_check_entries_kernel(const int2 *ent, int64_t n_ent, int64_t first_ent1, int n0, int n1, int W, int *err) {
+// (stride = W 4, the rows of a slab; a rectangular plan: n0 = n1 = the table's rows, stride = 2 W 4)
+__global__ void sell_check_entries_kernel(const int2 *ent, int64_t n_ent, int64_t first_ent1, int n0, int n1, int stride, int *err) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x) {
         const int off = ent[e].x;
-        const int64_t lim = (int64_t)(e >= first_ent1 ? n0 : n1) * W * 4;  // class 0 rows gather the class 1 table and vice versa
-        if (off != kSellPast && (off < 0 || off >= lim || off % (W * 4) != 0)) atomicExch(err, -1);
+        const int64_t lim = (int64_t)(e >= first_ent1 ? n0 : n1) * stride;  // class 0 rows gather the class 1 table and vice versa
+        if (off != kSellPast && (off < 0 || off >= lim || off % stride != 0)) atomicExch(err, -1);
     }
 }
 __global__ void sell_check_orig_kernel(const int32_t *orig, int n, int n_users, int n0, int *err) {
@@ -186,7 +187,7 @@ void free_sell(SellDev *sw) {
         if (sw->orig) (void)hipFree(sw->orig);
         if (sw->src) (void)hipFree(sw->src);
     }
-    if (sw->ent0) (void)hipFree(sw->ent0);
+    if (sw->ent0 && sw->ent0 != sw->ent) (void)hipFree(sw->ent0);  // (a rectangular plan's ent0 IS its ent)
     if (sw->bwd) (void)hipFree(sw->bwd);
     delete sw;
 }
@@ -196,8 +197,8 @@ static bool sell_width_ok(const SellDev *sw, int d) { return sw->W * 2 == d || (
 // of the values, the binned kernel reads the caller's array at launch time)
 static bool sell_usable(const rbg_graph *g) { return g && g->sell && (!g->sell->borrowed || g->sell->view_fresh); }
 
-bool sell_applicable(const rbg_graph *g, int d) {
-    return opt_sell() && sell_usable(g) && !g->sell->borrowed && sell_width_ok(g->sell, d);
+bool sell_applicable(const rbg_graph *g, int d) {  // the slab chains (never a rectangular block: it has no slab layout)
+    return opt_sell() && sell_usable(g) && !g->sell->borrowed && !g->sell->rect && sell_width_ok(g->sell, d);
 }
 
 // the chains run factored (compact entries from the second launch on) when the plan carries row factors
@@ -241,6 +242,8 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.irs = sw->irs;
     p.rm_ld = NS * W;
     p.rm_shift = NS == 4 ? 1 : (NS == 1 ? -1 : 0);
+    p.rm_rows[0] = sw->rect ? sw->n_tab : sw->n_class[0];
+    p.rm_rows[1] = sw->rect ? sw->n_tab : sw->n_class[1];
     for (int c = 0; c < 2; ++c) {
         p.unit_base[c] = sw->unit_base[c];
         p.n_units[c] = sw->n_units[c];
@@ -430,7 +433,7 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, int64_t ldx, float *Y
         p.xs = sw->bwd;
     } else {
         p.rm[0] = X;
-        p.rm[1] = X + (int64_t)n0 * ldx;
+        p.rm[1] = sw->rect ? X : X + (int64_t)n0 * ldx;  // (rect: both classes gather the one table)
         p.x_rm = 1;
     }
     if (ldx != NS * W) {  // X is a column block of a wider row-major buffer (NGCF's concatenated output, ngcf.py:100)
@@ -453,13 +456,48 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, int64_t ldx, float *Y
     return sell_launch<W, NS>(sw, p, s);
 }
 
+// out = (srcs[0] + ... + srcs[n - 1] (+ partial) + A X) / (n + 1): the last layer of a propagation whose layers the caller keeps
+// row-major (rbg_spmm_mean_f32: the sharded forward's last launch — lightgcn.py:76-78 on a rank's rows)
+template <int W, int NS>
+static int sell_spmm_mean_w(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean,
+                            hipStream_t s) {
+    const SellDev *sw = g->sell;
+    const int n0 = sw->n_class[0];
+    SellParams p{};
+    sell_fill(sw, W, NS, p);
+    p.rm[0] = X;
+    p.rm[1] = sw->rect ? X : X + (int64_t)n0 * NS * W;
+    p.x_rm = 1;
+    p.last = 1;
+    p.prev0_rm = 1;
+    p.prev_rm_all = 1;
+    p.prm[0] = srcs[0];
+    p.prm[1] = srcs[0] + (int64_t)n0 * NS * W;
+    for (int i = 1; i < n_srcs; ++i) p.prev[i] = srcs[i];
+    p.n_prev = n_srcs;
+    if (partial) p.prev[p.n_prev++] = partial;
+    p.denom = (float)(n_srcs + 1);
+    p.out = out_mean;
+    return sell_launch<W, NS>(sw, p, s);
+}
+
+int sell_spmm_mean(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean, int d,
+                   hipStream_t s) {
+    if (n_srcs + (partial ? 1 : 0) > RBG_MAX_FUSED_LAYERS + 1 || !g->sell->ent0 || !opt_sell_rowmajor()) return RBG_EUNSUPPORTED;
+    const int W = g->sell->W;
+#define CALL(W_, NS_) sell_spmm_mean_w<W_, NS_>(g, X, partial, srcs, n_srcs, out_mean, s)
+    RBG_SELL_DISPATCH(W, d, CALL);
+#undef CALL
+    return RBG_EUNSUPPORTED;
+}
+
 // the row strides of X the plan's row-major entries reach: d itself, or 2 W << k (k <= 3) while 32-bit offsets hold every row
 bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx) {
-    if (ldx == d) return true;
     const SellDev *sw = g->sell;
+    if (ldx == d) return !sw->rect || (int64_t)sw->n_tab * d * 4 < kSellPast;  // (rect plans are cut for 2 W; 4 W doubles the offsets)
     const int64_t w2 = 2 * sw->W;
     if (ldx < d || ldx % w2 || ldx / w2 > 8 || ((ldx / w2) & (ldx / w2 - 1))) return false;
-    return (int64_t)std::max(sw->n_class[0], sw->n_class[1]) * ldx * 4 < kSellPast;
+    return (int64_t)(sw->rect ? sw->n_tab : std::max(sw->n_class[0], sw->n_class[1])) * ldx * 4 < kSellPast;
 }
 
 int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s) {
@@ -553,7 +591,7 @@ static int sell_validate(const rbg_graph *g, const SellDev *sw) {
     if (n_total) hipLaunchKernelGGL(sell_check_units_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head),
                                     n_total, sw->n_units[0], n0, n1, sw->n_ent, lgw, d_err);
     if (sw->n_ent) hipLaunchKernelGGL(sell_check_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->n_ent,
-                                      sw->first_ent1, n0, n1, sw->W, d_err);
+                                      sw->first_ent1, sw->rect ? sw->n_tab : n0, sw->rect ? sw->n_tab : n1, sw->rect ? 2 * sw->W * 4 : sw->W * 4, d_err);
     hipLaunchKernelGGL(sell_check_orig_kernel, dim3((unsigned)((g->n_rows + 255) / 256)), dim3(256), 0, 0, sw->orig, (int)g->n_rows, n0, n0, d_err);
     int h_err = 0;
     if (ce == hipSuccess) ce = hipMemcpy(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost);
@@ -587,6 +625,11 @@ int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
     }
     const int n0 = sw->n_class[0], n1 = sw->n_class[1], W = sw->W;
     const int64_t n_ent = sw->n_ent;
+    if (sw->rect) {  // row-major offsets already: the entries are their own row-major twin; no compact / 16-bit forms (no slab chain)
+        sw->ent0 = sw->ent;
+        g->sell = sw;
+        return RBG_OK;
+    }
     // the offsets column alone (the factored chain's launches read 4 bytes per entry)
     if (sell_opt_alloc(&sw->entc, sizeof(int32_t) * (size_t)(n_ent + 256), true) && n_ent)
         hipLaunchKernelGGL(sell_compact_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->entc, n_ent);
@@ -657,6 +700,8 @@ int sell_make_view(rbg_graph *view, const rbg_graph *base) {
     SellDev *sw = new (std::nothrow) SellDev();
     if (!sw) return fail(RBG_ENOMEM, "out of host memory");
     sw->borrowed = b;
+    sw->rect = b->rect;
+    sw->n_tab = b->n_tab;
     sw->W = b->W;
     sw->chunk = b->chunk;
     sw->n_ent = b->n_ent;

@@ -53,6 +53,7 @@ struct SellParams {
     int32_t nt;              // option "sell_nt"
     int32_t rm_ld;           // x_rm: floats between the rows of rm[] (NS W when contiguous; a column block of a wider buffer otherwise)
     int32_t rm_shift;        // x_rm: log2(rm_ld / (2 W)) (-1: rm_ld = W): ent0's offsets are rows of 2 W floats
+    int32_t rm_rows[2];      // x_rm: rows of rm[c] (n_class[c]; a rectangular plan: both = the one table's rows)
     const float *noise;      // last (row-major out): out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps   (simgcl.py:30-33)
     float eps;
 };
@@ -317,7 +318,7 @@ __device__ __forceinline__ float sell_sgn(float x) { return x > 0.f ? 1.f : (x <
 template <int W, int NS>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sell_table_rsrc(SellParamsK &p, const SellLayer &L, const int cls, const int s) {
     const float *xtab = L.x_rm ? p.rm[1 - cls] + s * W : L.xs + p.slab_off[1 - cls][s];
-    const int n_tab = p.n_class[1 - cls];
+    const int n_tab = L.x_rm ? p.rm_rows[1 - cls] : p.n_class[1 - cls];
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0,
                                              L.x_rm ? (unsigned)n_tab * (unsigned)(p.rm_ld * 4) - s * W * 4 : n_tab * W * 4, 0x00020000);
 }

@@ -6,7 +6,7 @@
 // rbg_graph_create* itself (option "sell_auto", default 1) for every device graph with a user / item boundary, so a caller that
 // binds the C ABI alone (rbg_graph_create -> rbg_lightgcn_forward_f32) runs the column-slab kernel.
 //
-// The layout is specified by recbole-gnn_amd/sell.py (torch ops; kept as the executable specification: the tests compare this
+// The layout is specified by tests/sell_spec.py (torch ops; kept as the executable specification: the tests compare this
 // planner's arrays with it bit for bit).  Per row class (user rows / item rows):
 //   1. rows sorted by degree, descending, stable (= (parts, degree) descending: parts is monotone in the degree)
 //      -> the plan's row numbering `orig`; rocPRIM radix_sort_pairs_desc
@@ -18,6 +18,12 @@
 //   5. per sorted entry: (unit, lane-group, batch, slot) in closed form -> ent[pos] = {column offset, val}, src[pos] = CSR position
 // No step is proportional to N or nnz on the host; at the config-#5 shape (15 M rows, 400 M entries) the temporaries are
 // two 2.4 GB key / payload double buffers per class, freed before the next class is cut.
+//
+// r06 — the RECTANGULAR form (plan_sell(..., rect = true); SellDev::rect): a block whose rows are cut into the two classes at
+// row_split but whose columns index ONE row-major table of n_cols rows — a shard's [owned | halo] product, or its halo block
+// alone (sharded.py / shard.hip: rows = the rank's nodes, the same operator as layers.py:19-20 restricted to them).  Same
+// steps; the sort key's column is the table row itself, the entries hold row-major offsets (col * 2 W * 4) and there is no
+// slab chain: every launch gathers the table where it lies.
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,7 +43,7 @@ namespace {
 
 constexpr int kPast = 0x7ffffff0;  // = kSellPast (sell.hip)
 constexpr int kMaxSegs = 6;        // wide + parts LGW, LGW / 2, ..., 1 (LGW <= 16)
-constexpr int kMaxPiece = 512;     // sell.py MAX_PIECE
+constexpr int kMaxPiece = 512;     // sell_spec.py MAX_PIECE
 
 struct Seg {
     int32_t pp;      // pieces per row (4 LGW for wide rows)
@@ -184,19 +190,19 @@ __global__ void plan_keys_kernel(const int32_t *__restrict__ rowptr, const int32
             if (rowptr[mid + 1] <= e) lo = mid + 1; else hi = mid;
         }
         int c = col[e] - obase;
-        if (c < 0 || c >= n_o) {  // a user row that lists a user (or an item row an item): not the bipartite adjacency
+        if (c < 0 || c >= n_o) {  // a user row that lists a user (or an item row an item): not the bipartite adjacency (rect: out of the table)
             atomicExch(bad, 1);
             c = 0;
         }
-        keys[i] = ((unsigned long long)(uint32_t)inv_c[lo - row_b] << shift) | (unsigned long long)(uint32_t)inv_o[c];
+        keys[i] = ((unsigned long long)(uint32_t)inv_c[lo - row_b] << shift) | (unsigned long long)(uint32_t)(inv_o ? inv_o[c] : c);
         pay[i] = (uint32_t)e;
     }
 }
 
-// one thread per sorted entry: its slot in closed form (sell.py: pos = u_off + LGW 8 k + lg sb + j)
+// one thread per sorted entry: its slot in closed form (sell_spec.py: pos = u_off + LGW 8 k + lg sb + j)
 __global__ void plan_scatter_kernel(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ pay, int64_t n_e, int shift,
                                     const ClassSegs segs, int lgw, const int32_t *__restrict__ ptr, const int32_t *__restrict__ rdeg,
-                                    const int4 *__restrict__ head, int W, const float *__restrict__ val, int2 *__restrict__ ent,
+                                    const int4 *__restrict__ head, int stride, const float *__restrict__ val, int2 *__restrict__ ent,
                                     int32_t *__restrict__ src) {
     const unsigned long long mask = (1ull << shift) - 1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_e; i += (int64_t)gridDim.x * blockDim.x) {
@@ -219,7 +225,7 @@ __global__ void plan_scatter_kernel(const unsigned long long *__restrict__ keys,
         const int sb = min(8, nc - 8 * k);
         const int64_t pos = (int64_t)h.x + (int64_t)lgw * 8 * k + lg * sb + j;
         const uint32_t e = pay[i];
-        ent[pos] = make_int2(ci * (W * 4), __float_as_int(val[e]));
+        ent[pos] = make_int2(ci * stride, __float_as_int(val[e]));  // stride = W 4 (a slab row) or 2 W 4 (rect: a row-major table row)
         src[pos] = (int32_t)e;
     }
 }
@@ -235,7 +241,7 @@ unsigned grid_for_n(int64_t n, int cap = 16384) { return (unsigned)std::max<int6
 }  // namespace
 
 // RBG_EUNSUPPORTED = the graph is outside what the slab path serves (g->sell_note says why); the caller keeps the binned kernel.
-int plan_sell(rbg_graph *g, int W, int chunk) {
+int plan_sell(rbg_graph *g, int W, int chunk, bool rect) {
     auto na = [&](const char *why) {
         g->sell_note = why;
         return fail(RBG_EUNSUPPORTED, "SELL plan not applicable: %s", why);
@@ -245,15 +251,22 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
     if (g && g->sell && !g->sell->borrowed && g->sell_views.load() > 0)
         return fail(RBG_EUNSUPPORTED, "%d re-weighted view(s) borrow this handle's column-slab plan: destroy them before re-planning", g->sell_views.load());
     if (W != 32 && W != 64) return fail(RBG_EINVAL, "W = %d (32 or 64)", W);
-    if (chunk == 0) chunk = 128;  // sell.py CHUNK
+    if (chunk == 0) chunk = 128;  // sell_spec.py CHUNK
     if (chunk < 1 || chunk > (1 << 20)) return fail(RBG_EINVAL, "chunk = %d", chunk);
     if (g->base) return na("a re-weighted view borrows its base graph's plan (rbg_graph_refresh_values)");
     const int64_t split = g->n_users >= 0 ? g->n_users : g->row_split;
-    if (g->n_rows != g->n_cols || split <= 0 || split >= g->n_rows) return na("no user / item boundary (a square bipartite graph is needed)");
+    if (rect) {
+        if (split <= 0 || split >= g->n_rows) return na("a rectangular block without two row classes (rbg_graph_create_csr_classes)");
+        if (g->n_cols <= 0 || g->n_cols > INT32_MAX) return na("no columns, or more than 2^31");
+        if (W != 32) return na("rectangular blocks are planned at W = 32");
+    } else if (g->n_rows != g->n_cols || split <= 0 || split >= g->n_rows) {
+        return na("no user / item boundary (a square bipartite graph is needed)");
+    }
     if (g->n_rows > INT32_MAX) return na("more than 2^31 rows");
     const int n[2] = {(int)split, (int)(g->n_rows - split)}, base[2] = {0, (int)split};
     const int lgw = 64 / (W / 4), lp_full = lgw == 8 ? 3 : (lgw == 4 ? 2 : 4);
-    if ((int64_t)std::max(n[0], n[1]) * W * 4 >= kPast) return na("table too large for 32-bit slab offsets");
+    if (!rect && (int64_t)std::max(n[0], n[1]) * W * 4 >= kPast) return na("table too large for 32-bit slab offsets");
+    if (rect && g->n_cols * 2 * W * 4 >= kPast) return na("table too large for 32-bit row offsets");
     int rc = set_device_for(g->device);
     if (rc) return rc;
     hipStream_t s = nullptr;
@@ -340,6 +353,8 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
     sw->W = W;
     sw->chunk = chunk;
     sw->native = true;
+    sw->rect = rect;
+    sw->n_tab = rect ? (int32_t)g->n_cols : 0;
     for (int c = 0; c < 2; ++c) {
         sw->unit_base[c] = c ? n_units[0] : 0;
         sw->n_units[c] = n_units[c];
@@ -397,14 +412,15 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
     const int64_t e_b[2] = {0, ent_split}, e_n[2] = {ent_split, g->nnz - ent_split};
     for (int c = 0; c < 2; ++c) {
         if (e_n[c] <= 0) continue;
-        const int shift = bits_for(std::max(n[1 - c], 2)), key_bits = shift + bits_for(std::max(n[c], 2));
+        const int n_o = rect ? (int)g->n_cols : n[1 - c];  // rect: the key's column is the table row itself
+        const int shift = bits_for(std::max(n_o, 2)), key_bits = shift + bits_for(std::max(n[c], 2));
         Buf k_in, k_out, p_in, p_out;
         if ((rc = k_in.alloc(8 * (size_t)e_n[c])) || (rc = k_out.alloc(8 * (size_t)e_n[c])) || (rc = p_in.alloc(4 * (size_t)e_n[c])) ||
             (rc = p_out.alloc(4 * (size_t)e_n[c])))
             return rc;
-        hipLaunchKernelGGL(plan_keys_kernel, dim3(grid_for_n(e_n[c])), dim3(256), 0, s, g->d_rowptr, g->d_col, e_b[c], e_n[c], base[c], n[c], base[1 - c],
-                           n[1 - c], b_inv.as<int32_t>() + base[c], b_inv.as<int32_t>() + base[1 - c], shift, k_in.as<unsigned long long>(),
-                           p_in.as<uint32_t>(), b_flag.as<int>() + 1);
+        hipLaunchKernelGGL(plan_keys_kernel, dim3(grid_for_n(e_n[c])), dim3(256), 0, s, g->d_rowptr, g->d_col, e_b[c], e_n[c], base[c], n[c],
+                           rect ? 0 : base[1 - c], n_o, b_inv.as<int32_t>() + base[c], rect ? (const int32_t *)nullptr : b_inv.as<int32_t>() + base[1 - c],
+                           shift, k_in.as<unsigned long long>(), p_in.as<uint32_t>(), b_flag.as<int>() + 1);
         size_t t4 = 0;
         RBG_HIP(rocprim::radix_sort_pairs(nullptr, t4, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), p_in.as<uint32_t>(),
                                           p_out.as<uint32_t>(), (size_t)e_n[c], 0, (unsigned)key_bits, s));
@@ -416,15 +432,23 @@ int plan_sell(rbg_graph *g, int W, int chunk) {
         RBG_HIP(rocprim::radix_sort_pairs(b_tmp.p, t4, k_in.as<unsigned long long>(), k_out.as<unsigned long long>(), p_in.as<uint32_t>(),
                                           p_out.as<uint32_t>(), (size_t)e_n[c], 0, (unsigned)key_bits, s));
         hipLaunchKernelGGL(plan_scatter_kernel, dim3(grid_for_n(e_n[c])), dim3(256), 0, s, k_out.as<unsigned long long>(), p_out.as<uint32_t>(), e_n[c],
-                           shift, segs[c], lgw, b_ptr.as<int32_t>() + rb[c], b_rdeg.as<int32_t>() + rb[c], head + sw->unit_base[c], W, g->d_val,
+                           shift, segs[c], lgw, b_ptr.as<int32_t>() + rb[c], b_rdeg.as<int32_t>() + rb[c], head + sw->unit_base[c],
+                           rect ? 2 * W * 4 : W * 4, g->d_val,
                            reinterpret_cast<int2 *>(sw->ent), sw->src);
         RBG_HIP(hipGetLastError());
         RBG_HIP(hipStreamSynchronize(s));  // (the temporaries of this class are freed here)
     }
     RBG_HIP(hipMemcpy(flag, b_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag[1]) return na("a user row lists a user or an item row an item: not the bipartite adjacency");
+    if (flag[1]) return na(rect ? "a column index outside the table" : "a user row lists a user or an item row an item: not the bipartite adjacency");
 
     // ---- 5. r = deg^-1/2 in the plan's numbering, then adopt: validation, derived arrays, factors ------------------------------
+    if (rect) {  // (no slab chain on a rectangular block: no factors — a shard's rows do not even hold their columns' degrees)
+        SellDev *adopt = sw;
+        sw = nullptr;
+        if ((rc = sell_adopt(g, adopt, true))) return rc;
+        g->sell_note = "planned";
+        return RBG_OK;
+    }
     Buf b_r;
     if ((rc = b_r.alloc(sizeof(float) * (size_t)N))) return rc;
     for (int c = 0; c < 2; ++c)
@@ -447,7 +471,8 @@ extern "C" {
 
 int rbg_graph_plan_sell(rbg_graph *g, int W, int chunk) {
     clear_error();
-    return plan_sell(g, W, chunk);
+    if (g && g->n_rows != g->n_cols) return plan_sell(g, W, chunk, true);
+    return plan_sell(g, W, chunk, false);
 }
 
 int rbg_graph_sell_status(const rbg_graph *g, char *buf, int len) {

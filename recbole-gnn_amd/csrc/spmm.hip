@@ -675,7 +675,7 @@ int rbg_lightgcn_forward_kernel_name(const rbg_graph *g, int d, uint32_t flags, 
         snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, sell_chain_factored(g)));
         return RBG_OK;
     }
-    if (sell_rowmajor_applicable(g, d)) {
+    if (sell_rowmajor_applicable(g, d) && !g->sell->rect) {
         snprintf(buf, (size_t)len, "%s", sell_kernel_name(g, d, false));
         return RBG_OK;
     }
@@ -748,6 +748,14 @@ int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, 
         if (!srcs[i]) return fail(RBG_EINVAL, "srcs[%d] is NULL", i);
     if (out_mean == X || out_mean == partial) return fail(RBG_EINVAL, "out_mean aliases an input");
     if ((rc = set_device_for(g->device))) return rc;
+    if (sell_plain_applicable(g, d, d) && aligned16(X) && aligned16(out_mean) && (!partial || aligned16(partial))) {
+        bool al = true;
+        for (int i = 0; i < n_srcs; ++i) al = al && aligned16(srcs[i]);
+        if (al) {
+            rc = sell_spmm_mean(g, X, partial, srcs, n_srcs, out_mean, d, (hipStream_t)stream);
+            if (rc != RBG_EUNSUPPORTED) return rc;
+        }
+    }
     SpmmParams p{};
     p.x = make_src(X, X, 0, d);
     p.y = nullptr;
@@ -836,7 +844,7 @@ int rbg_lightgcn_forward_f32(const rbg_graph *const *graphs, int n_graphs, int64
     // the same plan with every layer row-major where the caller reads them (NCL, keep_layers)
     // ... and with one graph per layer (SGL's RW views, sgl.py:89-91: every plan has its own row numbering)
     bool all_rm = fused && aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);
-    for (int i = 0; i < n_graphs && all_rm; ++i) all_rm = sell_rowmajor_applicable(graphs[i], d) && graphs[i]->sell->n_class[0] == n_users;
+    for (int i = 0; i < n_graphs && all_rm; ++i) all_rm = sell_rowmajor_applicable(graphs[i], d) && !graphs[i]->sell->rect && graphs[i]->sell->n_class[0] == n_users;
     if (all_rm) return sell_forward_rowmajor(graphs, n_graphs, user_emb, item_emb, out_mean, layers, d, K, (flags & RBG_FWD_KEEP_LAST_LAYER) != 0, s);
     bool slab = opt_slab() && fused && layers && (flags & RBG_FWD_LAYERS_SCRATCH) && !(flags & RBG_FWD_KEEP_LAST_LAYER) &&
                 aligned16(user_emb) && aligned16(item_emb) && aligned16(layers) && aligned16(out_mean);

@@ -116,6 +116,25 @@ class ShardPlan:
     def n_halo(self):
         return len(self.halo_ids)
 
+    def cat_csr(self):
+        """[A_interior | A_halo] as ONE rectangular CSR over the table [owned rows | halo rows] (r06, the fused layer): row r's
+        interior entries, then its halo entries with the column moved past the owned rows.  (rowptr, col, val); n_cols =
+        n_owned + n_halo."""
+        ip, ic, iv = (np.asarray(a) for a in self.int_csr)
+        hp, hc, hv = (np.asarray(a) for a in self.halo_csr)
+        n = self.n_owned
+        ip, hp = ip.astype(np.int64), hp.astype(np.int64)
+        rp = ip + hp
+        col = np.empty(int(rp[-1]), dtype=np.int32)
+        val = np.empty(int(rp[-1]), dtype=np.float32)
+        rows_i = np.repeat(np.arange(n), np.diff(ip))
+        rows_h = np.repeat(np.arange(n), np.diff(hp))
+        pos_i = rp[rows_i] + (np.arange(len(ic)) - ip[rows_i])
+        pos_h = rp[rows_h] + (ip[rows_h + 1] - ip[rows_h]) + (np.arange(len(hc)) - hp[rows_h])
+        col[pos_i], val[pos_i] = ic, iv
+        col[pos_h], val[pos_h] = np.asarray(hc, dtype=np.int64) + n, hv
+        return rp, col, val
+
 
 def _csr_from_sorted(rows_local, cols, vals, n_rows):
     rowptr = np.zeros(n_rows + 1, dtype=np.int64)
@@ -373,8 +392,13 @@ class ShardedPropagation:
     layer — the overlapped form has never run between different GPUs (no multi-GPU box in five rounds: ADVICE r04), so it is
     an explicit choice (``overlap=True`` / ``set_overlap``) or autotune's, not a default.
 
-    r04: the INTERIOR block (square, user rows then item rows, bipartite) is planned by ``rbg_graph_create_csr_classes`` like any
-    other handle and runs the column-slab kernel at d = 32 / 64 / 128; the rectangular halo block stays on the binned kernel.
+    r06 — ``fused`` (default whenever ``overlap`` is off and the rank has a halo): the rank's block [A_interior | A_halo] is ONE
+    rectangular handle over the table [owned rows | halo rows] (``ShardPlan.cat_csr``), planned for the column-slab kernel like any
+    other handle (rectangular form, csrc/sell_plan.hip).  A layer = pack -> exchange into the table's tail -> ONE launch that
+    writes the next layer's table head: no accumulate pass over Y, every entry on ``sell_spmm_kernel`` (r05: the halo block —
+    (P - 1) / P of the entries on an unstructured graph — ran the binned kernel and re-read Y).  ``overlap=True`` keeps the
+    two-handle form (interior product beside the exchange); its halo block is planned too (r06) — only widths other than
+    32 / 64 / 128 stay on the binned kernel.
     ``halo_bytes_per_layer`` says what a rank receives per layer — on an unstructured power-law graph almost the whole table
     (Amazon-Book shape, P = 4: 106 056 of 108 183 foreign rows): see ``colsharded.py`` for the sharding that exchanges nothing."""
 
@@ -383,24 +407,62 @@ class ShardedPropagation:
         n_total = sum(int(c) for c in self.plan.recv_counts)
         return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
 
-    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None):
+    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None):
         # overlap = None (default): off — unmeasured between real peers; ``autotune`` measures both forms on the actual group
         if overlap is None:
             overlap = False
         self.plan, self.backend, self.group, self.transport = plan, backend, group, transport
         dev = getattr(backend, "device", torch.device("cpu"))
         self.device = dev
-        self.g_int = self._make_graph(plan.int_csr, plan.n_owned)
-        self.g_halo = self._make_graph(plan.halo_csr, max(plan.n_halo, 1)) if plan.n_halo else None
+        self._g_int = self._g_halo = self._g_cat = None   # handles are built on first use: a fused rank never builds the pair
+        self._want_fused = (not overlap) if fused is None else bool(fused)
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
         self.comm_stream, self._comm_h, self._ctx = None, None, None
         self.overlap = False
         self.set_overlap(overlap)
+        if self.fused:
+            _ = self.g_cat
+        else:
+            _ = self.g_int, self.g_halo
         self._n_send = len(plan.send_idx)
         self._buf_d = None  # per-width buffers, allocated on first use: halo, send, ping-pong outputs
         self._recv_splits = [int(c) for c in plan.recv_counts]
         self._send_splits = [int(c) for c in plan.send_counts]
         self.tuned = None  # filled by autotune(): {"single_stream_us", "overlap_us", "chosen"}
+
+    @property
+    def fused(self):
+        """One handle, one launch per layer (no interior / halo split): whenever asked for, the rank has a halo and the
+        overlapped two-stream form is off."""
+        return self._want_fused and self.plan.n_halo > 0 and self.plan.n_owned > 0 and not self.overlap
+
+    def set_fused(self, fused):
+        self._want_fused = bool(fused)
+
+    @property
+    def g_int(self):
+        if self._g_int is None:
+            self._g_int = self._make_graph(self.plan.int_csr, self.plan.n_owned)
+        return self._g_int
+
+    @property
+    def g_halo(self):
+        if self._g_halo is None and self.plan.n_halo:
+            self._g_halo = self._make_graph(self.plan.halo_csr, max(self.plan.n_halo, 1))
+        return self._g_halo
+
+    @property
+    def g_cat(self):
+        if self._g_cat is None:
+            self._g_cat = self._make_graph(self.plan.cat_csr(), self.plan.n_owned + self.plan.n_halo)
+        return self._g_cat
+
+    def kernel_status(self):
+        """What the handles of the active form run: {"form", "cat" | "interior" / "halo": plan status} (HIP backend)."""
+        st = lambda g: g.sell_status() if (g is not None and hasattr(g, "sell_status")) else None  # noqa: E731
+        if self.fused:
+            return {"form": "fused", "cat": st(self.g_cat)}
+        return {"form": "two handles", "interior": st(self.g_int), "halo": st(self.g_halo)}
 
     def set_overlap(self, overlap):
         self.overlap = bool(overlap) and self.transport == "nccl" and self.device.type == "cuda"
@@ -419,7 +481,10 @@ class ShardedPropagation:
             f = dict(dtype=x.dtype, device=x.device)
             self._halo = torch.empty((max(plan.n_halo, 1), d), **f)
             self._send = torch.empty((max(len(plan.send_idx), 1), d), **f)
-            self._y = [torch.empty((plan.n_owned, d), **f) for _ in range(2)]
+            # layer tables [owned rows | halo rows]: a fused layer gathers one and writes the head of the next; the two-handle
+            # form uses their heads as its ping-pong outputs
+            self._cat = [torch.empty((plan.n_owned + plan.n_halo, d), **f) for _ in range(2)]
+            self._y = [c[: plan.n_owned] for c in self._cat]
             self._mean = torch.empty((plan.n_owned, d), **f)
             self._halo_view = self._halo[: plan.n_halo]
             self._flip = 0
@@ -514,6 +579,61 @@ class ShardedPropagation:
             return self.backend.spmm_mean(self.g_halo, halo, y, srcs, out, **kw)
         return self.backend.mean(list(srcs) + [y], out, **kw)  # no halo on this rank: plain mean of the kept layers
 
+    def _more_tables(self, n):
+        while len(self._cat) < n:
+            self._cat.append(torch.empty_like(self._cat[0]))
+            self._y.append(self._cat[-1][: self.plan.n_owned])
+
+    def _table_of(self, x, avoid=None):
+        """The layer table whose head holds x: x itself when it already is one (a previous layer's output), else a table
+        (not the one `avoid` lives in) it is copied into."""
+        n = self.plan.n_owned
+        for c in self._cat:
+            if c.data_ptr() == x.data_ptr() and x.shape[0] == n and x.is_contiguous():
+                return c
+        for c in self._cat:
+            if avoid is None or c.data_ptr() != avoid.data_ptr():
+                c[:n].copy_(x)
+                return c
+        raise RuntimeError("no free layer table")
+
+    def _spmm_fused(self, x, out, main, finish, halo_rows):
+        """One fused layer: the halo of x lands behind x's rows in its layer table, then ONE launch over [A_int | A_halo]."""
+        plan = self.plan
+        n, d = plan.n_owned, x.shape[1]
+        if x.device.type == "cuda":
+            self._buffers(x)
+            main_h = (main or torch.cuda.current_stream(x.device)).cuda_stream
+            kw = {"stream": main_h}
+            xcat = self._table_of(x, avoid=out)
+        else:  # injected CPU backend (tests): fresh tensors
+            main_h, kw = None, {}
+            xcat = torch.empty((n + plan.n_halo, d), dtype=x.dtype)
+            xcat[:n] = x
+        tail = xcat[n:]
+        if halo_rows is not None:
+            if halo_rows.shape[0] < max(plan.n_halo, 1):
+                raise ValueError("halo_rows has fewer rows than this plan's halo")
+            if halo_rows.data_ptr() != tail.data_ptr():
+                tail.copy_(halo_rows[: plan.n_halo])
+        elif self.transport == "nccl":
+            if self._n_send:
+                self.backend.gather_rows(xcat[:n], self.send_idx, out=self._send[: self._n_send], stream=main_h)
+            dist.all_to_all_single(tail, self._send[: self._n_send], output_split_sizes=self._recv_splits,
+                                   input_split_sizes=self._send_splits, group=self.group)
+        else:
+            self._exchange_staged(xcat[:n], tail)
+        if finish is not None:
+            srcs, mean_out = finish
+            return self.backend.spmm_mean(self.g_cat, xcat, None, srcs, mean_out, **kw)
+        if out is not None:
+            y = out
+        elif x.device.type == "cuda":
+            y = next(c for c in self._cat if c.data_ptr() != xcat.data_ptr())[:n]
+        else:
+            y = torch.empty((n, d), dtype=x.dtype)
+        return self.backend.spmm(self.g_cat, xcat, y, False, **kw)
+
     def spmm(self, x, out=None, main=None, finish=None, halo_rows=None):
         """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows.  `main`: the torch stream the caller runs on
         (looked up once per propagation by forward()).  `finish` = (srcs, out_mean): this is the last layer of a
@@ -521,6 +641,10 @@ class ShardedPropagation:
         `halo_rows` ([n_halo, d], from halo_of / remap_halo): the halo of x is already here — no exchange, no collective."""
         plan = self.plan
         d = x.shape[1]
+        if self.fused and plan.world > 1:
+            return self._spmm_fused(x, out, main, finish, halo_rows)
+        if not x.is_contiguous():
+            x = x.contiguous()
         if halo_rows is not None and plan.world > 1:
             if halo_rows.shape[0] < max(plan.n_halo, 1):
                 raise ValueError("halo_rows has fewer rows than this plan's halo")
@@ -596,14 +720,18 @@ class ShardedPropagation:
         if hasattr(self.backend, "spmm_mean") and e0.device.type == "cuda" and 1 <= n_layers <= 8:
             # keep the K - 1 first layer outputs; the K-th product carries the layer mean in its epilogue
             self._buffers(e0)
-            while len(self._y) < n_layers:
-                self._y.append(torch.empty_like(self._y[0]))
+            self._more_tables(n_layers + 1)
             main = torch.cuda.current_stream(e0.device) if e0.device.type == "cuda" else None
+            # (fused: E0 is copied behind nothing — into table 0's head, its halo lands in that table's tail; layer k writes
+            # table k + 1's head, so the mean's addends E_1 .. E_{K-1} stay where the layers left them)
             srcs, x = [e0], e0
+            if self.fused and self.plan.world > 1:
+                self._cat[0][: self.plan.n_owned].copy_(e0)
+                x = self._cat[0][: self.plan.n_owned]
             for k in range(n_layers - 1):
-                x = self.spmm(x, out=self._y[k], main=main, halo_rows=first_halo if k == 0 else None)
+                x = self.spmm(x, out=self._y[k + 1], main=main, halo_rows=first_halo if k == 0 else None)
                 srcs.append(x)
-            return self.spmm(x, out=self._y[n_layers - 1], main=main, finish=(srcs, self._mean if out is None else out),
+            return self.spmm(x, out=self._y[n_layers], main=main, finish=(srcs, self._mean if out is None else out),
                              halo_rows=first_halo if n_layers == 1 else None)
         acc = e0.clone()
         x = e0
@@ -626,7 +754,7 @@ class ShardedPropagation:
         off = 0
         for (w1, b1, w2, b2), d_in, d_out in zip(layer_params, widths[:-1], widths[1:]):
             x = out[:, off: off + d_in]
-            p = self.spmm(x.contiguous())
+            p = self.spmm(x)   # (a column block: the two-handle form makes it contiguous, the fused one copies it into a layer table)
             y = out[:, off + d_in: off + d_in + d_out]
             if hasattr(self.backend, "bignn_dense"):
                 self.backend.bignn_dense(p, x, w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous(), y, True, slope)
@@ -645,7 +773,10 @@ class ShardedPropagation:
         x = g
         for i in range(n_layers):
             x = self.spmm(x)
-            x = x + g  # a fresh tensor: the ping-pong buffer is free again
+            if self.fused and x.device.type == "cuda" and self.plan.world > 1:
+                x.add_(g)   # the layer table's head (ours): the next step gathers it where it lies
+            else:
+                x = x + g  # a fresh tensor: the ping-pong buffer is free again
         return x / float(n_layers + 1)
 
     def autotune(self, e0, n_layers, iters=10):
@@ -654,7 +785,7 @@ class ShardedPropagation:
         if not (self.transport == "nccl" and self.plan.world > 1 and e0.device.type == "cuda"):
             return None
         res = {}
-        for ov in (False, True):
+        for ov in (False, True):   # False: the fused one-launch layer (when asked for); True: two handles, two streams
             self.set_overlap(ov)
             for _ in range(3):
                 self.forward(e0, n_layers)
@@ -724,14 +855,14 @@ class LayeredShardedPropagation:
     ShardedPropagation where ``sharded_sgl_forward`` / ``ShardedTrainer`` use them; the halo of E0 (first_halo) is the
     FIRST layer's."""
 
-    def __init__(self, layer_plans, backend, group=None, transport="nccl", overlap=False):
+    def __init__(self, layer_plans, backend, group=None, transport="nccl", overlap=False, fused=None):
         if not layer_plans:
             raise ValueError("at least one layer plan")
         owned = layer_plans[0].owned
         for pl in layer_plans[1:]:
             if not np.array_equal(pl.owned, owned):
                 raise ValueError("the layer plans must share one partition")
-        self.layers = [ShardedPropagation(pl, backend, group=group, transport=transport, overlap=overlap) for pl in layer_plans]
+        self.layers = [ShardedPropagation(pl, backend, group=group, transport=transport, overlap=overlap, fused=fused) for pl in layer_plans]
         self.plan, self.backend = layer_plans[0], backend
         self.device = self.layers[0].device
 
