@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample budget (0 = skip)")
     ap.add_argument("--seed", type=int, default=2020)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra (non-headline) measurements at N = 1")
+    ap.add_argument("--shard-ceiling-only", action="store_true",
+                    help="N = 1: print only the shard_compute_ceiling extra (per-rank layer products of P = 2 / 4 / 8 shards, alone on the GPU)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N>1 headline: strong = ONE fixed graph (BASELINE.json's configuration for N: gowalla / amazon-book / "
                          "config5) cut into node shards, no planted locality (value = global forwards/s); weak = one "
@@ -396,6 +398,11 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         ex["strong_scaling_reference(single-GPU propagations/s of the --scaling strong graphs)"] = ref
     except Exception as e:  # noqa: BLE001
         ex["shapes_error"] = str(e)[:200]
+    # the node-range shards' compute ceiling on this one GPU: per-rank layer product alone, P = 2 / 4 / 8
+    try:
+        ex["shard_compute_ceiling"] = shard_compute_ceiling(rbg, dev, d, time_us)
+    except Exception as e:  # noqa: BLE001
+        ex["shard_compute_ceiling_error"] = str(e)[:300]
     # the other two model families of the path (NGCF bi-interaction layers, SGL views + InfoNCE), one training step each
     try:
         cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "reg_weight": 1e-5,
@@ -503,6 +510,71 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     except Exception as e:  # noqa: BLE001
         ex["driver_epoch_error"] = str(e)[:200]
     return ex
+
+
+def shard_compute_ceiling(rbg, dev, d, time_us, shapes=("amazon-book", "g-1.3m"), worlds=(2, 4, 8)):
+    """the COMPUTE ceiling of the node-range shards on the one GPU there is — per shape and P, rank r's plan
+    is cut out of the global CSR (sharded.plan_from_csr, degree-striped partition), its layer product is timed ALONE on the GPU
+    (nothing else running, no exchange) in three forms: `fused` = ONE launch over [A_int | A_halo] (r06, the default),
+    `two_handles` = interior + halo accumulate, both on the column-slab kernel (r06), `r05_form` = the same with the halo block on
+    the binned kernel (option "sell" off for that launch: what r05 ran).  ceiling = T_1 / max_r T_{P,r} with T_1 = the same
+    layer (rbg_spmm_f32) on the whole graph.  All ranks at the Amazon-Book shape, ranks 0 and P - 1 at 1.3 M nodes (the
+    degree-striped ranks are near-identical by construction; the plan of one rank of that graph takes ~1 s)."""
+    sh = rbg.sharded
+    be = sh.HipBackend(dev)
+    out = {}
+    for name in shapes:
+        uid, iid, nu, ni = rbg.synth.make(name)
+        g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
+        n = nu + ni
+        big = n > 1_000_000
+        it, wm = (10, 2) if big else (50, 5)
+        x, y = torch.randn(n, d, device=dev), torch.empty(n, d, device=dev)
+        t1 = time_us(lambda: rbg.ops.spmm_raw(g, x, out=y), iters=it, warm=wm)
+        rowptr, col, val = g.device_csr()
+        rec = {"nodes": n, "nnz": g.nnz, "T1_layer_us": t1, "T1_kernel": g.spmm_kernel_name(d)}
+        del x, y
+        for world in worlds:
+            owner = sh.degree_striped_partition(uid, iid, nu, ni, world)
+            ranks = list(range(world)) if not big else sorted({0, world - 1})
+            per = []
+            for r in ranks:
+                plan = sh.plan_from_csr(rowptr, col, val, nu, owner, r, world)
+                prop = sh.ShardedPropagation(plan, be, transport="staged", fused=True)
+                no, nh = plan.n_owned, plan.n_halo
+                xc, yo = torch.randn(no + nh, d, device=dev), torch.empty(no, d, device=dev)
+                row = {"rank": r, "owned_rows": no, "halo_rows": nh, "nnz": int(plan.int_csr[0][-1] + plan.halo_csr[0][-1]),
+                       "status": prop.kernel_status()["cat"]}
+                row["fused_us"] = time_us(lambda: be.spmm(prop.g_cat, xc, yo, False), iters=it, warm=wm)
+                gi_, gh_ = prop.g_int, prop.g_halo
+
+                def two():
+                    be.spmm(gi_, xc[:no], yo, False)
+                    be.spmm(gh_, xc[no:], yo, True)
+
+                row["two_handles_us"] = time_us(two, iters=it, warm=wm)
+
+                def r05():
+                    be.spmm(gi_, xc[:no], yo, False)
+                    rbg.set_option("sell", 0)
+                    be.spmm(gh_, xc[no:], yo, True)
+                    rbg.set_option("sell", 1)
+
+                try:
+                    row["r05_form_us"] = time_us(r05, iters=it, warm=wm)
+                finally:
+                    rbg.set_option("sell", 1)
+                per.append(row)
+                del prop, xc, yo, plan, gi_, gh_
+            worst = {k: max(q[k] for q in per) for k in ("fused_us", "two_handles_us", "r05_form_us")}
+            rec[f"P{world}"] = {"partition": "degree-striped", "ranks_timed": ranks,
+                                "max_rank_us": worst,
+                                "ceiling(T1 / max_r T_P,r)": {k[:-3]: t1 / v for k, v in worst.items()},
+                                "ceiling_over_P": {k[:-3]: t1 / v / world for k, v in worst.items()},
+                                "per_rank": per}
+        out[name] = rec
+        del g, rowptr, col, val
+    return out
 
 
 def capture_steps(step, steps):
@@ -730,6 +802,24 @@ def main():
     k_layers = args.layers
     gen = torch.Generator().manual_seed(args.seed + rank)
     extra = {}
+
+    if world == 1 and args.shard_ceiling_only:
+        def _time_us(fn, iters=50, warm=5):
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(iters):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3 / iters)
+            return sorted(ts)[1]
+        print(json.dumps({"shard_compute_ceiling": shard_compute_ceiling(rbg, dev, args.dim or 64, _time_us)}), file=json_out, flush=True)
+        return
 
     if world == 1:
         wl_name, d = args.workload or "gowalla", args.dim or 64
