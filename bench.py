@@ -1174,6 +1174,9 @@ def main():
                        f"{'exchange overlapped on a second stream' if extra['overlap'] else 'single-stream layers'}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
+                         # SURVEY 8(d) quotes its 60 % target (19 227 prop/s) on the PER-PROPAGATION bytes B_prop = K B_layer + 4 N d (K + 2):
+                         # the same timed region read against that figure
+                         "frac_prop": (b_prop / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS) if world == 1 else None,
                          "traffic": traffic, "l2_hit": l2_hit,
                          "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT,TCC_MISS, separate "
                                            "passes, devtools/traffic_session.sh; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 B per the gfx950 correction)",
@@ -1181,7 +1184,7 @@ def main():
                          "launches_per_step": launches_per_step,
                          "note": "achieved = B_layer (4(N+1) + 8 nnz + 8 N d) / mean layer duration; duration = HIP-event "
                                  "time of the timed region / (steps x K layers), so inter-kernel gaps and (N>1) halo waits count against "
-                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r05_bench_kernel_stats.csv"},
+                                 "the kernel; rocprofv3's per-instantiation averages are in profiles/r06_bench_kernel_stats.csv"},
             "cpu_baseline": None,
         }
         if world == 1:

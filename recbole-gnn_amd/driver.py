@@ -75,6 +75,7 @@ class BPRSampler:
     at the Gowalla shape a draw hits with probability 8e-4, so a positive survives 8 rounds with probability 2e-25."""
 
     ROUNDS = 8
+    MAX_REDRAWS = 64  # checked redraws after the unconditional rounds; then the sampler raises instead of spinning
 
     def __init__(self, uid, iid, n_items, batch_size=2048, seed=2020, device=None):
         self.n_items, self.batch_size = int(n_items), int(batch_size)
@@ -100,11 +101,12 @@ class BPRSampler:
     def _negatives(self, users):
         if self.device is None:
             neg = self.rng.integers(1, self.n_items, len(users))
-            while True:
+            for _ in range(self.MAX_REDRAWS):
                 bad = self._is_positive(users, neg)
                 if not bad.any():
                     return neg
                 neg[bad] = self.rng.integers(1, self.n_items, int(bad.sum()))
+            raise RuntimeError(f"BPRSampler: draws still positive after {self.MAX_REDRAWS} redraws (a user who interacted with every item has no negative item)")
         draw = lambda: torch.randint(1, self.n_items, users.shape, generator=self.gen, device=self.device)  # noqa: E731
         neg = draw()
         for _ in range(self.ROUNDS):
@@ -113,10 +115,15 @@ class BPRSampler:
         # but not on a dense dataset with heavy users.  One check per epoch (one host sync) and a loop for what is left: like the host
         # path and the reference's sampler, every returned item is a true negative.
         bad = self._is_positive(users, neg)
-        while bool(bad.any()):
+        for _ in range(self.MAX_REDRAWS):  # (bounded: a user who has interacted with EVERY item has no negative — ADVICE r05)
+            if not bool(bad.any()):
+                return neg
             idx = bad.nonzero(as_tuple=True)[0]
             neg[idx] = torch.randint(1, self.n_items, idx.shape, generator=self.gen, device=self.device)
             bad = self._is_positive(users, neg)
+        if bool(bad.any()):
+            raise RuntimeError(f"BPRSampler: {int(bad.sum())} draws still positive after {self.MAX_REDRAWS} redraws "
+                               "(a user who interacted with every item has no negative item)")
         return neg
 
     def __iter__(self):

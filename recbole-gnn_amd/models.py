@@ -18,6 +18,9 @@ import torch.nn.functional as F
 from . import ops
 
 
+_ONCE_CACHE = {}
+
+
 def _once_mask(ids, n_ids=None):
     """mask[i] = True for exactly ONE occurrence of every distinct id in `ids` — what ``torch.unique`` selects, with static
     shapes, so a loss over the unique ids can be written as a masked loss over the whole batch and the step stays capturable
@@ -25,8 +28,20 @@ def _once_mask(ids, n_ids=None):
     its id and the one that stays is the occurrence kept — three launches instead of a sort's dozen; WHICH occurrence survives
     is not fixed, and no loss depends on it (the rows of equal ids are equal)."""
     if n_ids is not None and ids.is_cuda:
-        ar = torch.arange(ids.shape[0], device=ids.device)
-        slot = torch.empty(int(n_ids), dtype=torch.int64, device=ids.device)  # (only slots written below are read)
+        # the slot table and the position vector are kept per (device, stream, n_ids, batch): four calls per SimGCL / XSimGCL step
+        # otherwise allocate 8-16 MB each on million-node catalogs (ADVICE r05).  The table needs no reset (only slots written
+        # below are read) and the calls of one stream are ordered; tensors made while a stream is capturing belong to the graph's
+        # pool and are not kept
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (ids.device.index, torch.cuda.current_stream(ids.device).cuda_stream, int(n_ids), int(ids.shape[0]))
+        hit = None if capturing else _ONCE_CACHE.get(key)
+        if hit is None:
+            hit = (torch.arange(ids.shape[0], device=ids.device), torch.empty(int(n_ids), dtype=torch.int64, device=ids.device))
+            if not capturing:
+                if len(_ONCE_CACHE) >= 16:
+                    _ONCE_CACHE.clear()
+                _ONCE_CACHE[key] = hit
+        ar, slot = hit
         if get_option("deterministic"):
             # option "deterministic": the FIRST occurrence stays (an integer atomic minimum: order-free), so the masked sums run over
             # the same positions in every run and the step is bit-stable

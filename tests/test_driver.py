@@ -36,6 +36,17 @@ def test_split_and_sampler(rbg, ref_inter):
     assert seen == len(tr_u) and len(sampler) == (len(tr_u) + 511) // 512
 
 
+def test_sampler_gives_up_on_a_user_without_negatives(rbg):
+    """a user who interacted with EVERY item has no negative; the redraw loop is bounded and raises."""
+    ni = 6
+    uid = np.array([1] * (ni - 1) + [2], dtype=np.int64)
+    iid = np.array(list(range(1, ni)) + [3], dtype=np.int64)
+    sampler = rbg.driver.BPRSampler(uid, iid, ni, batch_size=4, seed=0)
+    with pytest.raises(RuntimeError, match="no negative"):
+        for _ in sampler:
+            pass
+
+
 def test_metrics_known_answers(rbg):
     topk = np.array([[5, 7, 9, 2], [1, 2, 3, 4], [8, 1, 2, 3]])
     truth = [{7, 2, 100}, {9}, {8}]

@@ -547,3 +547,33 @@ def test_two_process_gloo_rw_views_have_one_plan_per_layer(ref_inter):
         assert p.exitcode == 0
     for rank, (err, gerr, ferr) in res:
         assert err <= 1e-5 and gerr <= 1e-5 and ferr <= 1e-5, (rank, err, gerr, ferr)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_fused_block_equals_the_two_handle_form(rbg, ref_inter, world):
+    """r06: ShardPlan.cat_csr() is [A_interior | A_halo] over the table [owned rows | halo rows]; the fused layer (one product)
+    and the two-handle layer (interior + halo accumulate) agree row by row, and both equal the rows of the global product."""
+    uid, iid, nu, ni = ref_inter
+    sh = rbg.sharded
+    plans = sh.build_plans(uid, iid, nu, ni, world, owner=sh.degree_striped_partition(uid, iid, nu, ni, world))
+    x = np.random.default_rng(1).standard_normal((nu + ni, 16)).astype(np.float32)
+    rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+    y_ref = C.spmm(rowptr, col, val, x)
+    be = CpuBackend()
+    for p, plan in plans.items():
+        rp, cc, vv = plan.cat_csr()
+        ip, ic, iv = plan.int_csr
+        hp, hc, hv = plan.halo_csr
+        assert rp[-1] == ip[-1] + hp[-1] and np.all(np.diff(rp) == np.diff(ip) + np.diff(hp))
+        for r in (0, plan.n_owned // 2, plan.n_owned - 1):   # a row = its interior entries, then its halo entries moved past the owned rows
+            a, b = rp[r], rp[r + 1]
+            ni_r = ip[r + 1] - ip[r]
+            assert np.array_equal(cc[a:a + ni_r], ic[ip[r]:ip[r + 1]]) and np.array_equal(cc[a + ni_r:b], np.asarray(hc[hp[r]:hp[r + 1]]) + plan.n_owned)
+        halo = torch.from_numpy(x[plan.halo_ids]) if plan.n_halo else torch.zeros((1, 16))
+        xo = torch.from_numpy(x[plan.owned])
+        fused = sh.ShardedPropagation(plan, be, transport="staged", fused=True)
+        pair = sh.ShardedPropagation(plan, be, transport="staged", fused=False)
+        assert fused.fused == (plan.n_halo > 0) and not pair.fused
+        y1 = fused.spmm(xo, halo_rows=halo).numpy()
+        y2 = pair.spmm(xo, halo_rows=halo).numpy()
+        assert np.abs(y1 - y_ref[plan.owned]).max() <= 1e-5 and np.abs(y2 - y_ref[plan.owned]).max() <= 1e-5
