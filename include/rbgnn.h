@@ -104,9 +104,13 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   index_put_(accumulate=True): the low bits of those rows and of the loss sums vary from run to run;
  *                   1 = every such row is written by ONE wavefront (the one of the id's first occurrence) that applies the
  *                   occurrences in batch order, and loss values / block norms are summed across workgroups as 31.32 fixed-point
- *                   integers (integer addition does not depend on the order; |sum| < 2^31): bit-identical from run to run,
- *                   no scratch memory, capturable; costs a scan of the batch's ids per wavefront (csrc/ordered.h).  At most
- *                   64 such launches may be in flight on different streams of one device at a time.  The propagation, scoring and top-k kernels are bit-stable in either mode.
+ *                   integers (integer addition does not depend on the order; |sum| < 2^31, absolute resolution 2^-32 of the
+ *                   sum before its weight — a regulariser's reg_weight / B multiplies the total, not the addends): bit-identical from
+ *                   run to run, no scratch memory, capturable; costs a scan of the batch's ids per wavefront (csrc/ordered.h).
+ *                   The sums use one slot of a device table per stream and one per stream capture (a captured step keeps its own
+ *                   for every replay); 256 such streams / captured graphs are live at a time, the oldest slot is recycled after
+ *                   that.  A captured step has the mode it was captured in (train.py re-captures on a toggle).
+ *                   The propagation, scoring and top-k kernels are bit-stable in either mode.
  *   "score_tiles" : item tiles one workgroup of rbg_score_f32 walks (0 = auto: whole rounds of resident workgroups)
  *   "topk_short_lists" : rbg_full_sort_topk_f32 at k <= 12, d <= 64 keeps 24-entry candidate lists (three workgroups per CU instead of
  *                   two; a tile's arrivals that do not fit are appended in rounds with a prune between): 1 (default) from

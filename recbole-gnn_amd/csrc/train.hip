@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 
 #include "internal.h"
 #include "ordered.h"
@@ -62,14 +64,42 @@ constexpr int kElemsPerWave = 4;  // batch elements per wavefront: 16 per 256-th
 // workgroups the default is one float atomic per workgroup and value — order-dependent in the last bits.  Option "deterministic":
 // the workgroups add their partial sums as 31.32 FIXED-POINT integers into a slot of g_fix_acc (integer addition is associative:
 // any order gives the same bits), the last workgroup to arrive converts the total and adds it to the caller's cell, and leaves the
-// slot zeroed.  No scratch memory from the caller, nothing allocated, capturable; |sum| < 2^31.  Slots are handed out round-robin
-// per launch, so up to kFixSlots such launches may be in flight on different streams.
+// slot zeroed.  No scratch memory from the caller, nothing allocated, capturable.  A workgroup's partial enters the fixed-point
+// sum only while |partial| < 2^31 / gridDim.x (so the total cannot wrap the 64-bit accumulator: beyond it — a diverged run —
+// the partial is added with a float atomic, still summed, no longer order-free); resolution 2^-32 of the value BEFORE its
+// `post` factor (r06, ADVICE r05: a weighted regulariser of 1e-9 per workgroup is summed unweighted and scaled once at the end).
+// Slots (r06): one per STREAM — launches of one stream are ordered, so they can share it — and one per stream
+// CAPTURE (hipStreamGetCaptureInfo's id: a captured step keeps its slot for every replay, whatever stream replays it, and never
+// meets the eager launches of the stream it was captured on).  kFixSlots keys are live at a time; the oldest key's slot is
+// recycled after that (a graph captured more than kFixSlots captures / streams ago may then share its slot with a new one:
+// only concurrent use would collide).
 constexpr int kMaxWaves = 16;
-constexpr int kFixSlots = 64;
+constexpr int kFixSlots = 256;
 __device__ unsigned long long g_fix_acc[kFixSlots][4];
 __device__ unsigned g_fix_cnt[kFixSlots];
-static std::atomic<unsigned> g_fix_next{0};
-static int fix_slot() { return opt_deterministic() ? (int)(g_fix_next.fetch_add(1) % kFixSlots) : -1; }
+static std::mutex g_fix_mutex;
+static std::unordered_map<unsigned long long, int> g_fix_key_slot;
+static unsigned long long g_fix_slot_key[kFixSlots];
+static unsigned g_fix_next = 0;
+static int fix_slot(hipStream_t stream) {
+    if (!opt_deterministic()) return -1;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    unsigned long long key;
+    if (hipStreamGetCaptureInfo(stream, &st, &id) == hipSuccess && st == hipStreamCaptureStatusActive) key = (id << 1) | 1ull;
+    else {
+        (void)hipGetLastError();
+        key = (unsigned long long)(uintptr_t)stream << 1;  // (pointers are at least 2-byte aligned: no clash with the capture keys' low bit)
+    }
+    std::lock_guard<std::mutex> lock(g_fix_mutex);
+    auto it = g_fix_key_slot.find(key);
+    if (it != g_fix_key_slot.end()) return it->second;
+    const int slot = (int)(g_fix_next++ % kFixSlots);
+    if (g_fix_next > (unsigned)kFixSlots) g_fix_key_slot.erase(g_fix_slot_key[slot]);  // the slot's previous key
+    g_fix_slot_key[slot] = key;
+    g_fix_key_slot[key] = slot;
+    return slot;
+}
 
 // the workgroup's waves' partial sums, added in wave order (pairwise for the usual four)
 __device__ __forceinline__ float block_sum(float part, float *red) {
@@ -87,8 +117,9 @@ __device__ __forceinline__ float block_sum(float part, float *red) {
 }
 
 // dst[j] += the sum over all workgroups of part[j] (each lane-0-of-wave partial, summed per workgroup first); slot < 0: float atomics
+// (post: a factor applied to the sum, not to the addends — the fixed-point sum keeps its 2^-32 resolution on values of order 1)
 template <int NV>
-__device__ __forceinline__ void commit_sums(const float (&part)[NV], float *const (&dst)[NV], int slot) {
+__device__ __forceinline__ void commit_sums(const float (&part)[NV], float *const (&dst)[NV], int slot, const float post = 1.f) {
     __shared__ float red[NV][kMaxWaves];
     float tot[NV];
 #pragma unroll
@@ -97,13 +128,14 @@ __device__ __forceinline__ void commit_sums(const float (&part)[NV], float *cons
     if (slot < 0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-            if (tot[j] != 0.f) atomicAdd(dst[j], tot[j]);
+            if (tot[j] != 0.f) atomicAdd(dst[j], tot[j] * post);
         return;
     }
+    const float bound = 2147483648.0f / (float)gridDim.x;  // gridDim.x partials below it cannot wrap the signed 64-bit sum
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        if (fabsf(tot[j]) < 1.0e9f) atomicAdd(&g_fix_acc[slot][j], (unsigned long long)__float2ll_rn(tot[j] * 4294967296.0f));
-        else atomicAdd(dst[j], tot[j]);  // beyond the 31.32 range (a diverged run; NaN): still summed, no longer order-free
+        if (fabsf(tot[j]) < bound) atomicAdd(&g_fix_acc[slot][j], (unsigned long long)__float2ll_rn(tot[j] * 4294967296.0f));
+        else atomicAdd(dst[j], tot[j] * post);  // beyond the range (a diverged run; NaN): still summed, no longer order-free
     }
     __threadfence();
     if (atomicAdd(&g_fix_cnt[slot], 1u) == gridDim.x - 1) {  // the last workgroup: every partial sum is in
@@ -111,17 +143,17 @@ __device__ __forceinline__ void commit_sums(const float (&part)[NV], float *cons
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const long long t = (long long)atomicExch(&g_fix_acc[slot][j], 0ull);
-            const float f = (float)((double)t * 2.3283064365386963e-10);
+            const float f = (float)((double)t * 2.3283064365386963e-10 * (double)post);
             if (f != 0.f) atomicAdd(dst[j], f);
         }
         atomicExch(&g_fix_cnt[slot], 0u);
     }
 }
 
-__device__ __forceinline__ void block_add_loss(float part, float *loss, int slot) {
+__device__ __forceinline__ void block_add_loss(float part, float *loss, int slot, const float post = 1.f) {
     const float p1[1] = {part};
     float *const d1[1] = {loss};
-    commit_sums<1>(p1, d1, slot);
+    commit_sums<1>(p1, d1, slot, post);
 }
 
 // element groups of kElemsPerWave a wave walks: grp = first, first + stride, ...
@@ -249,9 +281,9 @@ __global__ __launch_bounds__(256) void emb_reg_grad_kernel(const EmbRegArgs a, f
         for (int e = 0; e < kElemsPerWave; ++e) {
             const int64_t w = grp * kElemsPerWave + e;
             if (w >= 3 * a.B) break;
-            loss_part += reg_weight * emb_reg_elem<false, SCATTER>(a, w, reg_weight / (float)a.B, lane) / (float)a.B * 0.5f;
+            loss_part += emb_reg_elem<false, SCATTER>(a, w, reg_weight / (float)a.B, lane) * 0.5f;  // (unweighted: reg_weight / B multiplies the SUM)
         }
-    block_add_loss(loss_part, loss, slot);
+    block_add_loss(loss_part, loss, slot, reg_weight / (float)a.B);
 }
 
 // EmbLoss(norm=2, require_pow=False): reg = (||U0[user]||_F + ||I0[pos]||_F + ||I0[neg]||_F) / B — torch.norm of each
@@ -492,7 +524,7 @@ int rbg_bpr_grad_f32(const float *out_mean, int64_t n_users, int64_t n_items, co
     if (B == 0) return RBG_OK;
     const BprArgs a{out_mean, n_users, user, pos, neg, B, d, 1e-10f, grad_mean};
     if (opt_deterministic()) {  // the loss summed in fixed point (order-free), every gradient row by the wavefront that owns it
-        hipLaunchKernelGGL((bpr_grad_kernel<false>), grid_for(B), dim3(256), 0, s, a, loss, fix_slot());
+        hipLaunchKernelGGL((bpr_grad_kernel<false>), grid_for(B), dim3(256), 0, s, a, loss, fix_slot(s));
         BprRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a;
         launch_ordered_scatter(r, 3 * B, s);
@@ -513,7 +545,7 @@ int rbg_emb_reg_grad_f32(const float *user_emb, const float *item_emb, int64_t n
     hipStream_t s = (hipStream_t)stream;
     const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
     if (opt_deterministic()) {
-        hipLaunchKernelGGL((emb_reg_grad_kernel<false>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss, fix_slot());
+        hipLaunchKernelGGL((emb_reg_grad_kernel<false>), grid_for(3 * B), dim3(256), 0, s, a, reg_weight, loss, fix_slot(s));
         EmbRegRows r{};
         r.user = user, r.pos = pos, r.neg = neg, r.n_users = n_users, r.B = B, r.a = a, r.reg_weight = reg_weight, r.sums = nullptr;
         launch_ordered_scatter(r, 3 * B, s);
@@ -534,7 +566,7 @@ int rbg_emb_reg_grad_nopow_f32(const float *user_emb, const float *item_emb, int
     hipStream_t s = (hipStream_t)stream;
     if (int zrc = zero_async(workspace, 3 * sizeof(float), s)) return zrc;
     const EmbRegArgs a{user_emb, item_emb, n_users, user, pos, neg, B, d, grad_e0};
-    hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, fix_slot());
+    hipLaunchKernelGGL(emb_sumsq_kernel, grid_for(3 * B), dim3(256), 0, s, a, workspace, fix_slot(s));
     if (opt_deterministic()) {
         hipLaunchKernelGGL((emb_reg_grad_nopow_kernel<false>), dim3(1), dim3(256), 0, s, a, reg_weight, workspace, loss);
         EmbRegRows r{};
@@ -564,7 +596,7 @@ int rbg_concat_bpr_begin_f32(const float *const *tables, const int *widths, int 
     int zrc = zero_async(sums, 3 * sizeof(float), s);
     if (zrc || (zrc = zero_async(loss, sizeof(float), s))) return zrc;
     if (B == 0) return RBG_OK;
-    hipLaunchKernelGGL(concat_bpr_begin_kernel, grid_for(B), dim3(256), 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss, fix_slot());
+    hipLaunchKernelGGL(concat_bpr_begin_kernel, grid_for(B), dim3(256), 0, s, T, n_users, user, pos, neg, B, 1e-10f, form, coef, sums, loss, fix_slot(s));
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
