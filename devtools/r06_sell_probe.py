@@ -49,18 +49,21 @@ def main():
     ap.add_argument("--tag", default="")
     ap.add_argument("--shapes", default="gowalla,yelp2018,amazon-book")
     ap.add_argument("--no-shards", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="re-plan every graph with this chunk (0: the creation-time plan)")
     ap.add_argument("--options", default="", help="key=value,... passed to rbg.set_option before the graphs are built")
     args = ap.parse_args()
     for kv in filter(None, args.options.split(",")):
         k, v = kv.split("=")
         rbg.set_option(k, int(v))
     dev = torch.device("cuda:0")
-    rec = {"tag": args.tag, "lib": os.environ.get("RBGNN_LIB", "product"), "options": args.options}
+    rec = {"tag": args.tag, "lib": os.environ.get("RBGNN_LIB", "product"), "options": args.options, "chunk": args.chunk}
     d, K = 64, 3
     for name in args.shapes.split(","):
         uid, iid, nu, ni = rbg.synth.make(name)
         g = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=dev)
         n = nu + ni
+        if args.chunk:
+            g.plan_sell(32, args.chunk)
         gen = torch.Generator().manual_seed(7)
         e0 = (torch.randn(n, d, generator=gen) * 0.1).to(dev)
         y = torch.empty(n, d, device=dev)

@@ -256,7 +256,13 @@ int rbg_graph_refresh_values(rbg_graph *view, void *stream);
  * tests/sell_spec.py (torch ops on the handle's device CSR); `ent` [n_ent][2], `head` [n_units][4] and `orig` [n_rows] are
  * DEVICE arrays on the graph's device, `unit_base` / `n_units` host arrays of 2.  Every index the kernel dereferences is
  * range-checked on the device before the plan is adopted (copied: the caller keeps its arrays).  Graphs built from
- * interactions (a user / item boundary, square) only; a re-weighted view cannot carry a plan. */
+ * interactions (a user / item boundary, square) only; a re-weighted view cannot carry a plan.
+ * Unit header (r06) = {first entry, first row, slots << 16 | j, log2(parts) | rows << 8 | wide << 16 | U << 17}: a row of more
+ * than chunk x LGW entries ("wide") is U consecutive units at the FRONT of its class (unit j of U); their partial sums meet
+ * in a scratch slot per unit that belongs to the handle (every re-weighted view has its own) and the last unit to arrive adds
+ * them in unit order — the result is bit-stable, but launches on ONE handle must be stream-ordered (two streams running the
+ * same handle at once would share that scratch; the binned kernel's split rows have the same rule).  Rows of any length are
+ * served (r03-r05: four units per wide row, longer hub rows kept the binned kernel). */
 int rbg_graph_attach_sell(rbg_graph *g, int W, const int32_t *ent, int64_t n_ent, const int32_t *head, const int32_t *unit_base,
                           const int32_t *n_units, const int32_t *orig);
 /* Row factors of an attached plan: r [n_rows] (device, the PLAN's row numbering = orig[]) with val_ij = r_i * r_j — the symmetric

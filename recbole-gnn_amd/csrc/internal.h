@@ -108,6 +108,11 @@ struct SellDev {
     uint16_t *entc16 = nullptr;      // [n_ent + 512]: the same as slab-ROW numbers (0xffff = padding), when both classes have < 65 536 rows
     float *rs = nullptr, *irs = nullptr;  // [n_rows] each (one allocation): r_i with val_ij = r_i r_j, and 1 / r_i; the plan's numbering; optional
     int32_t *head = nullptr;         // [n_units][4]
+    int32_t n_wide_units[2] = {0, 0};  // the class's leading units that belong to wide rows (rows of several units, r06)
+    float *wide_part = nullptr;      // [n_wide_units total][128]: a wide unit's partial sums, one 128-float slot per unit (NS W <= 128)
+    uint32_t *wide_ctr = nullptr;    // [n_wide_units total][4]: arrivals per (row's first unit, slab); zero between launches.
+                                     // Scratch of the LAUNCH: a handle's launches must be stream-ordered (as for the binned kernel's
+                                     // split rows); every re-weighted view has its own
     int32_t *orig = nullptr;         // [n_rows]: original node id of (class, internal row)
     int32_t *src = nullptr;          // [n_ent]: CSR entry of every slot (-1 = padding): re-weighted views refresh their values through it; optional
     int64_t n_ent = 0;

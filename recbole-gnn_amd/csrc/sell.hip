@@ -37,30 +37,29 @@ namespace rbg {
 // W = slab width (32).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows, XCD x of a class
 // owns slab x % NS; the 4 / NS XCDs of a (class, slab) role share its units.
 template <int W, int NS, bool COMPACT>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellParams p_) {
-    SellParamsK &p = sell_kernarg();  // (= p_, read in place)
-    __shared__ float s_wide[4][W];
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellLaunch a_) {
+    SellLaunchK &A = sell_kernarg();  // (= a_, read in place)
+    SellParamsK &p = A.p;
     SellClock clk;
     clk.start();
     const int x = blockIdx.x & 7;
     const int cls = x >> 2, xr = x & 3;
     const int s = xr & (NS - 1), xi = xr / NS;
     constexpr int XR = 4 / NS;  // XCDs per role
-    const int wave = threadIdx.x >> 6;
-    // (kernel arguments first, all of them, then the unit test: an early exit in front of them serialises four dependent
-    // scalar-load round trips per wave — n_units, pointers, header, offsets)
+    // the role record (one scalar load, indexed by blockIdx alone) and the layer's switches: everything a wave needs before its
+    // header, requested together
+    const float *xtab = A.role[x].xtab;
+    const unsigned tab_bytes = A.role[x].tab_bytes;
+    const SellRole R{A.role[x].heads, A.role[x].ents, A.role[x].ybase, A.role[x].n_units, A.role[x].cbase, A.role[x].c16, A.role[x].wbase};
     const SellLayer L = sell_layer_of(p);
-    const __amdgpu_buffer_rsrc_t rs = sell_table_rsrc<W, NS>(p, L, cls, s);
-    const unsigned nun = (unsigned)p.n_units[cls];
-    const int4 *heads = p.head + p.unit_base[cls];
-    const v4i *ents = p.x_rm ? p.ent0 : p.ent;
-    const int64_t ybase = p.slab_off[cls][s];
-    // (the grid covers the units: one unit per wave, heaviest first, dealt by the hardware dispatcher)
-    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)((((blockIdx.x >> 3) * XR + xi) * 4 + wave)));
-    if (t < nun) {
-        const int4 h = heads[t];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, (int)tab_bytes, 0x00020000);
+    // (the grid covers the units: one unit per single-wave workgroup — a retired wave's slot is refilled on its own (r06; r03-r05:
+    // four-wave workgroups, because a wide row's four units met in LDS) — heaviest first, dealt by the hardware dispatcher)
+    const unsigned t = (blockIdx.x >> 3) * XR + xi;
+    if (t < (unsigned)R.n_units) {
+        const int4 h = R.heads[t];
         clk.lap(0);
-        sell_unit<W, NS, COMPACT>(p, L, cls, s, h, rs, ents, ybase, s_wide, clk);
+        sell_unit<W, NS, COMPACT>(p, L, R, cls, s, t, h, rs, clk);
         clk.lap(3);
     }
     clk.dump((COMPACT ? 2 : 0) + (p.last ? 1 : 0));
@@ -84,21 +83,31 @@ __global__ __launch_bounds__(256) void sell_to_slab_kernel(const float *user_emb
 }
 
 // memory safety of a plan (its content is the planner's business: parity tests pin it): every index the kernel dereferences
-__global__ void sell_check_units_kernel(const int4 *head, int n_units_total, int unit_base1, int n0, int n1, int64_t n_ent, int lgw,
-                                        int *err) {
+// wide units of each class (a plan the caller attached: the planner knows its own)
+__global__ void sell_count_wide_kernel(const int4 *head, int n_units_total, int unit_base1, int *n_wide) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_units_total && ((head[t].w >> 16) & 1)) atomicAdd(&n_wide[t >= unit_base1], 1);
+}
+__global__ void sell_check_units_kernel(const int4 *head, int n_units_total, int unit_base1, int n0, int n1, int64_t n_ent, int lgw, int nw0,
+                                        int nw1, int *err) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_units_total) return;
     const int4 h = head[t];
     const int cls = t >= unit_base1, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff, wide = (h.w >> 16) & 1;
-    const int n_c = cls ? n1 : n0;
-    bool bad = h.x < 0 || (h.x & 1) || (h.z & 0xffff) != 0 || (nc & 1) || nc > 65534 || (int64_t)h.x + (int64_t)lgw * nc > n_ent;
-    bad = bad || lp < 0 || (1 << lp) > lgw || nrows < 0 || nrows > (lgw >> lp) || h.y < 0 || h.y + nrows > n_c || (h.w >> 17) != 0;
+    const int n_c = cls ? n1 : n0, nw = cls ? nw1 : nw0;
+    const int U = (int)((unsigned)h.w >> 17), j = h.z & 0xffff;
+    bool bad = h.x < 0 || (h.x & 1) || (nc & 1) || nc > 65534 || (int64_t)h.x + (int64_t)lgw * nc > n_ent;
+    bad = bad || lp < 0 || (1 << lp) > lgw || nrows < 0 || nrows > (lgw >> lp) || h.y < 0 || h.y + nrows > n_c;
     const int tl = t - (cls ? unit_base1 : 0);
-    if (wide) {  // a wide row = units 4 j .. 4 j + 3 of its class, all flagged, one row
-        const int4 h0 = head[t - (tl & 3)];
-        bad = bad || !((h0.w >> 16) & 1) || h0.y != h.y || nrows != 1 || (1 << lp) != lgw;
-    } else if (tl & 3) {
-        bad = bad || ((head[t - (tl & 3)].w >> 16) & 1);
+    bad = bad || (wide != 0) != (tl < nw);  // the wide units are the first units of their class: their number is their scratch slot
+    if (wide) {  // a wide row = U consecutive units, all flagged, one row; unit j of it knows j and U
+        bad = bad || U < 1 || j >= U || tl - j < 0 || tl - j + U > nw || nrows != 1 || (1 << lp) != lgw;
+        if (!bad) {
+            const int4 h0 = head[t - j];
+            bad = !((h0.w >> 16) & 1) || h0.y != h.y || (h0.z & 0xffff) != 0 || (int)((unsigned)h0.w >> 17) != U;
+        }
+    } else {
+        bad = bad || j != 0 || U != 0;
     }
     if (bad) atomicExch(err, 1 + t);
 }
@@ -188,6 +197,8 @@ void free_sell(SellDev *sw) {
         if (sw->src) (void)hipFree(sw->src);
     }
     if (sw->ent0 && sw->ent0 != sw->ent) (void)hipFree(sw->ent0);  // (a rectangular plan's ent0 IS its ent)
+    if (sw->wide_part) (void)hipFree(sw->wide_part);
+    if (sw->wide_ctr) (void)hipFree(sw->wide_ctr);
     if (sw->bwd) (void)hipFree(sw->bwd);
     delete sw;
 }
@@ -219,10 +230,30 @@ bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_facto
 template <int W, int NS>
 static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
     const int64_t units = std::max(sw->n_units[0], sw->n_units[1]);
-    const int per = 4 * (4 / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role, four waves each
+    const int per = 4 / NS;  // units per 8 workgroups: the XCDs of a (class, slab) role, one wave each
     const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, (units + per - 1) / per));
-    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(256), 0, s, p);
+    SellLaunch a;
+    a.p = p;
+    for (int x = 0; x < 8; ++x) {  // what sell_spmm_kernel's workgroups on XCD x work on (x = blockIdx & 7)
+        const int cls = x >> 2, sl = (x & 3) & (NS - 1);
+        SellRoleK &r = a.role[x];
+        r = SellRoleK{};
+        r.xtab = p.x_rm ? p.rm[1 - cls] + sl * W : p.xs + p.slab_off[1 - cls][sl];
+        r.tab_bytes = p.x_rm ? (uint32_t)p.rm_rows[1 - cls] * (uint32_t)(p.rm_ld * 4) - (uint32_t)(sl * W * 4) : (uint32_t)p.n_class[1 - cls] * (uint32_t)(W * 4);
+        r.heads = p.head + p.unit_base[cls];
+        r.n_units = p.n_units[cls];
+        r.cbase = cls ? p.n_class[0] : 0;
+        r.wbase = cls ? sw->n_wide_units[0] : 0;
+        r.ybase = p.slab_off[cls][sl];
+        if (p.compact) {
+            r.c16 = (p.entc16 && p.c16_ok[cls]) ? 1 : 0;
+            r.ents = r.c16 ? (const void *)p.entc16 : (const void *)p.entc;
+        } else {
+            r.ents = p.x_rm ? (const void *)p.ent0 : (const void *)p.ent;
+        }
+    }
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(64), 0, s, a);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -244,6 +275,8 @@ static void sell_fill(const SellDev *sw, int W, int NS, SellParams &p) {
     p.rm_shift = NS == 4 ? 1 : (NS == 1 ? -1 : 0);
     p.rm_rows[0] = sw->rect ? sw->n_tab : sw->n_class[0];
     p.rm_rows[1] = sw->rect ? sw->n_tab : sw->n_class[1];
+    p.wide_part = sw->wide_part;
+    p.wide_ctr = sw->wide_ctr;
     for (int c = 0; c < 2; ++c) {
         p.unit_base[c] = sw->unit_base[c];
         p.n_units[c] = sw->n_units[c];
@@ -589,7 +622,7 @@ static int sell_validate(const rbg_graph *g, const SellDev *sw) {
     }
     hipError_t ce = hipMemset(d_err, 0, sizeof(int));
     if (n_total) hipLaunchKernelGGL(sell_check_units_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head),
-                                    n_total, sw->n_units[0], n0, n1, sw->n_ent, lgw, d_err);
+                                    n_total, sw->n_units[0], n0, n1, sw->n_ent, lgw, sw->n_wide_units[0], sw->n_wide_units[1], d_err);
     if (sw->n_ent) hipLaunchKernelGGL(sell_check_entries_kernel, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const int2 *>(sw->ent), sw->n_ent,
                                       sw->first_ent1, sw->rect ? sw->n_tab : n0, sw->rect ? sw->n_tab : n1, sw->rect ? 2 * sw->W * 4 : sw->W * 4, d_err);
     hipLaunchKernelGGL(sell_check_orig_kernel, dim3((unsigned)((g->n_rows + 255) / 256)), dim3(256), 0, 0, sw->orig, (int)g->n_rows, n0, n0, d_err);
@@ -616,8 +649,36 @@ static bool sell_opt_alloc(T **p, size_t bytes, bool zero) {
     return true;
 }
 
+// the launch scratch of the wide rows' units (one 128-float slot and four arrival counters per unit)
+static int sell_wide_scratch(SellDev *sw) {
+    const int64_t nw = (int64_t)sw->n_wide_units[0] + sw->n_wide_units[1];
+    if (!nw) return RBG_OK;
+    if (dev_malloc(&sw->wide_part, sizeof(float) * 128 * (size_t)nw) != hipSuccess || dev_malloc(&sw->wide_ctr, sizeof(uint32_t) * 4 * (size_t)nw) != hipSuccess ||
+        hipMemset(sw->wide_ctr, 0, sizeof(uint32_t) * 4 * (size_t)nw) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RBG_ENOMEM, "device allocation of the wide rows' scratch (%lld units) failed", (long long)nw);
+    }
+    return RBG_OK;
+}
+
 int sell_adopt(rbg_graph *g, SellDev *sw, bool validate) {
-    int rc = validate ? sell_validate(g, sw) : RBG_OK;
+    int rc = RBG_OK;
+    if (!sw->native) {  // an attached plan: count its wide units (the planner knows its own)
+        int *d_nw = nullptr, h_nw[2] = {0, 0};
+        const int n_total = sw->n_units[0] + sw->n_units[1];
+        if (dev_malloc(&d_nw, sizeof(int) * 2) != hipSuccess || hipMemset(d_nw, 0, sizeof(int) * 2) != hipSuccess) {
+            (void)hipGetLastError();
+            rc = fail(RBG_ENOMEM, "device allocation failed");
+        } else {
+            if (n_total) hipLaunchKernelGGL(sell_count_wide_kernel, dim3((n_total + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const int4 *>(sw->head),
+                                            n_total, sw->n_units[0], d_nw);
+            if (hipMemcpy(h_nw, d_nw, sizeof(h_nw), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(RBG_EHIP, "reading the plan failed");
+            sw->n_wide_units[0] = h_nw[0], sw->n_wide_units[1] = h_nw[1];
+        }
+        if (d_nw) (void)hipFree(d_nw);
+    }
+    if (rc == RBG_OK && validate) rc = sell_validate(g, sw);
+    if (rc == RBG_OK) rc = sell_wide_scratch(sw);
     if (rc == RBG_OK) rc = rbg_graph_detach_sell(g);
     if (rc) {
         free_sell(sw);
@@ -709,6 +770,12 @@ int sell_make_view(rbg_graph *view, const rbg_graph *base) {
     for (int c = 0; c < 2; ++c)
         sw->unit_base[c] = b->unit_base[c], sw->n_units[c] = b->n_units[c], sw->n_class[c] = b->n_class[c];
     sw->ent = b->ent, sw->entc = b->entc, sw->head = b->head, sw->orig = b->orig, sw->src = b->src;
+    sw->n_wide_units[0] = b->n_wide_units[0], sw->n_wide_units[1] = b->n_wide_units[1];
+    if (sell_wide_scratch(sw) != RBG_OK) {  // (the view's own launch scratch: it may run beside its base graph)
+        clear_error();
+        free_sell(sw);
+        return RBG_EUNSUPPORTED;
+    }
     const size_t bytes = sizeof(int32_t) * 2 * (size_t)(b->n_ent + 128);
     if (dev_malloc(&sw->ent0, bytes) != hipSuccess || hipMemcpy(sw->ent0, b->ent0, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
         (void)hipGetLastError();

@@ -56,14 +56,46 @@ struct SellParams {
     int32_t rm_rows[2];      // x_rm: rows of rm[c] (n_class[c]; a rectangular plan: both = the one table's rows)
     const float *noise;      // last (row-major out): out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps   (simgcl.py:30-33)
     float eps;
+    float *wide_part;        // [wide units][128]: partial sums of the units of wide rows (the plan's scratch)
+    uint32_t *wide_ctr;      // [wide units][4]: arrivals per (row, slab)
+};
+
+// What the waves of XCD x need to know about their (class, slab) role, worked out on the host (sell.hip sell_launch): ONE
+// 64-byte scalar load indexed by blockIdx alone (r06).  Read out of the parameter block the same values took a chain of
+// dependent scalar round trips — x_rm -> table pointer -> slab offset -> row count -> stride -> unit count -> header — because
+// every choice between the row-major and the slab operand became a branch around a load.
+struct alignas(64) SellRoleK {
+    const float *xtab;     // the table this role gathers, at its column piece (slab s of class 1 - cls, or rm[1 - cls] + s W)
+    const int4 *heads;     // unit headers of the role's row class
+    const void *ents;      // the entries this launch reads for the class: ent / ent0 (valued), entc or entc16 (compact)
+    int64_t ybase;         // float offset of the role's result slab
+    uint32_t tab_bytes;    // the table's extent: gathers past it return zeros
+    int32_t n_units;
+    int32_t cbase;         // first row of the class in the plan's numbering (0 / n_class[0])
+    int32_t c16;           // compact: the entries are 16-bit slab-row numbers
+    int32_t wbase;         // first scratch slot of the class's wide units (0 / n_wide_units[0])
+    int32_t pad[3];
+};
+static_assert(sizeof(SellRoleK) == 64, "one s_load_dwordx16 per role");
+struct SellLaunch {
+    SellParams p;
+    SellRoleK role[8];
 };
 
 // The parameter block is read where the launch put it — the kernel-argument segment (constant address space) — through this
 // reference type: a by-value copy handed to an inlined function by reference stayed in scratch memory (432 bytes per lane).
 typedef const __attribute__((address_space(4))) SellParams SellParamsK;
-__device__ __forceinline__ SellParamsK &sell_kernarg() {
-    return *(SellParamsK *)__builtin_amdgcn_kernarg_segment_ptr();
+typedef const __attribute__((address_space(4))) SellLaunch SellLaunchK;
+__device__ __forceinline__ SellLaunchK &sell_kernarg() {
+    return *(SellLaunchK *)__builtin_amdgcn_kernarg_segment_ptr();
 }
+// the role record in registers (wave-uniform: scalar)
+struct SellRole {
+    const int4 *heads;
+    const void *ents;
+    int64_t ybase;
+    int32_t n_units, cbase, c16, wbase;
+};
 
 // One layer of a chain as the host describes it (sell.hip's chain builders)
 struct SellChainLayer {
@@ -312,35 +344,25 @@ __device__ __forceinline__ void sell_gather1(SellAcc &acc, const WT *base, const
 
 __device__ __forceinline__ float sell_sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }  // torch.sign
 
-// the buffer resource of the table a (class, slab) role gathers from
-// (a row-major table is read as its column piece s: 128-byte (W = 32) pieces at an NS W stride — whole L2 lines, the same
-// footprint per XCD as a slab)
-template <int W, int NS>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sell_table_rsrc(SellParamsK &p, const SellLayer &L, const int cls, const int s) {
-    const float *xtab = L.x_rm ? p.rm[1 - cls] + s * W : L.xs + p.slab_off[1 - cls][s];
-    const int n_tab = L.x_rm ? p.rm_rows[1 - cls] : p.n_class[1 - cls];
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0,
-                                             L.x_rm ? (unsigned)n_tab * (unsigned)(p.rm_ld * 4) - s * W * 4 : n_tab * W * 4, 0x00020000);
-}
-
-// One unit: the gathers of its lane-groups, the reduction of split rows, the epilogue.  h = the unit's header; rs = the buffer
-// resource of the gathered table (class 1 - cls, slab s); s_wide = the workgroup's [4][W] LDS scratch of wide rows.
+// One unit: the gathers of its lane-groups, the reduction of split rows, the epilogue.  h = the unit's header (unit t of its
+// class); rs = the buffer resource of the gathered table (class 1 - cls, slab s).
 template <int W, int NS, bool COMPACT>
-__device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, const int cls, const int s, const int4 h, const __amdgpu_buffer_rsrc_t rs,
-                                          const v4i *ents, const int64_t ybase, float (*s_wide)[W], SellClock &clk) {
+__device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, const SellRole &R, const int cls, const int s, const unsigned t,
+                                          const int4 h, const __amdgpu_buffer_rsrc_t rs, SellClock &clk) {
     constexpr int G = W / 4;      // lanes per lane-group
     constexpr int LGW = 64 / G;   // lane-groups per wave = pieces per unit
     constexpr int D = NS * W;     // row width: NS slabs
     using WT = std::conditional_t<COMPACT, v2i, v4i>;
-    const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3, wave = (threadIdx.x >> 6) & 3;
+    const int lane = threadIdx.x & 63, lg = lane / G, sl = lane % G, q4 = lane & 3;
     const int lane_off = sl * 16;
     const int row0 = h.y, nc = (int)((unsigned)h.z >> 16), lp = h.w & 0xff, nrows = (h.w >> 8) & 0xff;
-    const bool wide = (h.w >> 16) & 1;  // uniform over the workgroup: the plan aligns a wide row to four units
+    const bool wide = (h.w >> 16) & 1;  // one of the U units of a wide row (wave-uniform)
     // the epilogue's row-indexed scalars are requested before the gathers (they would otherwise be two dependent round trips
     // at the end of the wave: orig[] -> the row-major addend)
     const int r = lg >> lp;
     const int row = row0 + (r < nrows ? r : 0);
-    const int cbase = cls ? p.n_class[0] : 0;
+    const int cbase = R.cbase;
+    const int64_t ybase = R.ybase;
     int node = 0;
     float r_i = 1.f;
     if constexpr (COMPACT) {  // (the valued instantiation has no register to spare: it asks at the end)
@@ -352,13 +374,17 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
     const WT *ebase;
     const int32_t *e16 = nullptr;
     if constexpr (COMPACT) {
-        ebase = reinterpret_cast<const v2i *>(p.entc) + (h.x >> 1);
-        if (p.entc16 && p.c16_ok[cls]) e16 = p.entc16 + (h.x >> 1);
+        ebase = reinterpret_cast<const v2i *>(R.ents) + (h.x >> 1);
+        if (R.c16) e16 = reinterpret_cast<const int32_t *>(R.ents) + (h.x >> 1);
     } else {
-        ebase = ents + (h.x >> 1);
+        ebase = reinterpret_cast<const v4i *>(R.ents) + (h.x >> 1);
     }
     const int sh = (!COMPACT && L.x_rm) ? p.rm_shift : 0;
     sell_gather1<W, NS, WT>(acc, ebase, e16, p.c16_shift, nc, lg, q4, rs, lane_off, sh, clk);
+    // "these values are in their registers HERE": the row scalars requested above are waited for behind the gathers — hipcc
+    // otherwise sign-extends `node` right behind its load and the wave sits out a whole vector round trip (s_waitcnt vmcnt(0))
+    // before it has requested its first entries (r06; the per-wave clock's 5 200-cycle prologue)
+    if constexpr (COMPACT) asm volatile("" : "+v"(node), "+v"(r_i));
     clk.count(nc * LGW);
     clk.lap(2);
     // the pieces of a split row sit in adjacent lane-groups: butterfly, fixed order
@@ -371,21 +397,43 @@ __device__ __forceinline__ void sell_unit(SellParamsK &p, const SellLayer &L, co
             if (off < parts) { acc.lo.x += a0; acc.lo.y += a1; acc.hi.x += a2; acc.hi.y += a3; }
         }
     }
-    if (wide) {  // 4 waves x LGW pieces of ONE row: per-wave partial sums through LDS, added in wave order
-        if (lg == 0) *reinterpret_cast<float4 *>(&s_wide[wave][sl * 4]) = make_float4(acc.lo.x, acc.lo.y, acc.hi.x, acc.hi.y);
-        __syncthreads();
-        if (wave == 0 && lg == 0) {
-            float4 tsum = *reinterpret_cast<const float4 *>(&s_wide[0][sl * 4]);
-#pragma unroll
-            for (int q = 1; q < 4; ++q) {
-                const float4 o4 = *reinterpret_cast<const float4 *>(&s_wide[q][sl * 4]);
-                tsum.x += o4.x; tsum.y += o4.y; tsum.z += o4.z; tsum.w += o4.w;
-            }
-            acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
+    // A wide row = U units (waves anywhere on the role's XCDs).  Every unit publishes its sum WRITE-THROUGH (agent-scope relaxed
+    // stores: sc1, no L2-flushing release fence), drains, and bumps the row's arrival counter; the LAST to arrive re-reads the U
+    // partials with agent-scope loads and adds them in unit order, so the result does not depend on the arrival order (the
+    // idiom of spmm.hip's split rows; MI355X guide 6 G16, form R1).  It leaves the counter at zero for the next launch.
+    bool emit = true;
+    if (wide) {
+        const int U = (int)((unsigned)h.w >> 17), j = h.z & 0xffff;
+        const int64_t slot0 = (int64_t)R.wbase + (int64_t)t - j;  // the row's first unit
+        if (lg == 0) {
+            float *dst = p.wide_part + (slot0 + j) * 128 + s * W + sl * 4;
+            __hip_atomic_store(dst + 0, acc.lo.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, acc.lo.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 2, acc.hi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 3, acc.hi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();  // (a wave that walks on to another wide unit must not overwrite s_wide under wave 0's reads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t *arrivals = p.wide_ctr + slot0 * 4 + s;
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        emit = old == (unsigned)(U - 1);
+        if (emit) {
+            if (lane == 0) __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-cleaning
+            if (lg == 0) {
+                float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = 0; i < U; ++i) {
+                    const float *src = p.wide_part + (slot0 + i) * 128 + s * W + sl * 4;
+                    tsum.x += __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tsum.y += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tsum.z += __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tsum.w += __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                acc.lo.x = tsum.x; acc.lo.y = tsum.y; acc.hi.x = tsum.z; acc.hi.y = tsum.w;
+            }
+        }
     }
-    const bool owner = (lg & (parts - 1)) == 0 && r < nrows && (!wide || wave == 0);
+    const bool owner = (lg & (parts - 1)) == 0 && r < nrows && emit;
     // the noise row's norm spans all NS slabs: every lane-group reads the whole row (all lanes take part in the shuffles)
     float nsc = 0.f;
     float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -13,7 +13,10 @@
 //   2. every entry (row, col) -> key (internal row, internal column of the OTHER class), payload = its CSR position; one
 //      radix_sort_pairs over the class's entries: a row's entries by ascending internal column
 //   3. rows with equal `parts` form segments (counts by binary search in the sorted degrees: the one host round trip); a
-//      segment's units are consecutive groups of LGW / parts rows (wide rows: 4 units per row)
+//      segment's units are consecutive groups of LGW / parts rows; a WIDE row (more than chunk LGW entries) has
+//      U = ceil(degree / (chunk LGW)) units of its own (r06: any number — their partial sums meet in the plan's scratch and the
+//      last to arrive adds them in unit order; r03-r05: exactly four, one workgroup, and longer hub rows were refused); the
+//      first unit of every wide row comes from an exclusive scan of U over the class's wide rows (`woff`)
 //   4. per unit: longest piece -> slots (rounded to 2); exclusive scan -> the unit's first entry
 //   5. per sorted entry: (unit, lane-group, batch, slot) in closed form -> ent[pos] = {column offset, val}, src[pos] = CSR position
 // No step is proportional to N or nnz on the host; at the config-#5 shape (15 M rows, 400 M entries) the temporaries are
@@ -43,7 +46,7 @@ namespace {
 
 constexpr int kPast = 0x7ffffff0;  // = kSellPast (sell.hip)
 constexpr int kMaxSegs = 6;        // wide + parts LGW, LGW / 2, ..., 1 (LGW <= 16)
-constexpr int kMaxPiece = 512;     // sell_spec.py MAX_PIECE
+constexpr int kMaxUnits = 32767;   // sell_spec.py MAX_UNITS: units of one wide row (15 bits of the header)
 
 struct Seg {
     int32_t pp;      // pieces per row (4 LGW for wide rows)
@@ -56,6 +59,10 @@ struct Seg {
 };
 struct ClassSegs {
     int32_t n, n_units;
+    int32_t n_wide_rows, n_wide_units;  // the wide segment (always s[0] when there is one)
+    const int32_t *woff;                // [n_wide_rows + 1]: first unit of wide row r (class-local)
+    int32_t cw;                         // chunk * lgw: entries per wide unit (at most)
+    int32_t pad;
     Seg s[kMaxSegs];
 };
 
@@ -142,12 +149,20 @@ __global__ void plan_units_kernel(const ClassSegs segs, int lgw, const int32_t *
                                   int64_t *__restrict__ slots, int *__restrict__ max_nc) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= segs.n_units) return;
-    const Seg sg = segs.s[seg_of_unit(segs, u)];
-    int row0, nrows, pbase;
-    if (sg.wide) {
-        row0 = sg.row_b + (u - sg.unit_b) / 4;
+    Seg sg = segs.s[seg_of_unit(segs, u)];
+    int row0, nrows, pbase, wj = 0, wu = 0;
+    if (sg.wide) {  // the row whose units include u: woff[row] <= u < woff[row + 1]
+        int lo = 0, hi = segs.n_wide_rows;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (segs.woff[mid + 1] <= u) lo = mid + 1; else hi = mid;
+        }
+        row0 = lo;
         nrows = 1;
-        pbase = ((u - sg.unit_b) & 3) * lgw;
+        wj = u - segs.woff[lo];
+        wu = segs.woff[lo + 1] - segs.woff[lo];
+        pbase = wj * lgw;
+        sg.pp = wu * lgw;
     } else {
         row0 = sg.row_b + (u - sg.unit_b) * sg.per;
         nrows = min(sg.per, sg.row_e - row0);
@@ -161,9 +176,16 @@ __global__ void plan_units_kernel(const ClassSegs segs, int lgw, const int32_t *
         mx = max(mx, (int)(dg * (part + 1) / sg.pp - dg * part / sg.pp));
     }
     const int nc = (mx + 1) / 2 * 2;
-    head[u] = make_int4(0, row0, (int)((unsigned)nc << 16), sg.lp | (nrows << 8) | (sg.wide << 16));
+    head[u] = make_int4(0, row0, (int)(((unsigned)nc << 16) | (unsigned)wj), sg.lp | (nrows << 8) | (sg.wide << 16) | (wu << 17));
     slots[u] = (int64_t)lgw * nc;
     if (nc > 32767) atomicMax(max_nc, nc);  // (rare: only then is the atomic worth issuing)
+}
+
+// U of every wide row (rdeg: the class's degrees, descending; the first n_wide are the wide rows)
+__global__ void plan_wide_units_kernel(const int32_t *__restrict__ rdeg, int n_wide, int cw, int32_t *__restrict__ u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_wide) u[i] = (int32_t)(((int64_t)rdeg[i] + cw - 1) / cw);
+    else if (i == n_wide) u[i] = 0;
 }
 
 __global__ void plan_head_offsets_kernel(int4 *__restrict__ head, const int64_t *__restrict__ uoff, int n_units) {
@@ -209,11 +231,12 @@ __global__ void plan_scatter_kernel(const unsigned long long *__restrict__ keys,
         const unsigned long long key = keys[i];
         const int ir = (int)(key >> shift), ci = (int)(key & mask);
         const int64_t t = i - ptr[ir], dg = rdeg[ir];
-        const Seg sg = segs.s[seg_of_row(segs, ir)];
+        Seg sg = segs.s[seg_of_row(segs, ir)];
+        if (sg.wide) sg.pp = (segs.woff[ir + 1] - segs.woff[ir]) * lgw;
         const int64_t q = ((t + 1) * sg.pp + dg - 1) / dg - 1;  // the piece that holds entry t: floor(dg q / pp) <= t < floor(dg (q + 1) / pp)
         int u, lg;
         if (sg.wide) {
-            u = sg.unit_b + 4 * (ir - sg.row_b) + (int)(q / lgw);
+            u = segs.woff[ir] + (int)(q / lgw);
             lg = (int)(q % lgw);
         } else {
             u = sg.unit_b + (ir - sg.row_b) / sg.per;
@@ -316,13 +339,34 @@ int plan_sell(rbg_graph *g, int W, int chunk, bool rect) {
     b_order.release();
 
     // ---- 2. segments and units (host: a handful of integers) -------------------------------------------------------------------
-    const int64_t max_piece = std::max<int64_t>(kMaxPiece, g->nnz / 8192);
     const int64_t max_deg = std::max(info[thr.n], info[16 + thr.n]);
-    if (max_deg > max_piece * 4 * lgw) {
+    const int64_t cw = (int64_t)chunk * lgw;  // entries per wide unit (at most)
+    if (max_deg > kMaxUnits * cw) {
         char why[160];
-        snprintf(why, sizeof why, "a row of %lld entries is longer than the %d pieces of %lld the slab path sums per row", (long long)max_deg,
-                 4 * lgw, (long long)max_piece);
+        snprintf(why, sizeof why, "a row of %lld entries is longer than %d units of %lld", (long long)max_deg, kMaxUnits, (long long)cw);
         return na(why);
+    }
+    // the wide rows' units: U = ceil(degree / cw) per row, exclusive scan -> woff (device); the totals come back with one copy
+    Buf b_woff[2], b_wu;
+    int32_t n_wide_units[2] = {0, 0};
+    {
+        const int nw_max = std::max(info[0], info[16]);
+        if ((rc = b_wu.alloc(sizeof(int32_t) * ((size_t)nw_max + 1)))) return rc;
+        for (int c = 0; c < 2; ++c) {
+            const int nw = info[16 * c];
+            if ((rc = b_woff[c].alloc(sizeof(int32_t) * ((size_t)nw + 1)))) return rc;
+            hipLaunchKernelGGL(plan_wide_units_kernel, dim3((nw + 256) / 256), dim3(256), 0, s, b_rdeg.as<int32_t>() + rb[c], nw, (int)cw, b_wu.as<int32_t>());
+            size_t tb = 0;
+            RBG_HIP(rocprim::exclusive_scan(nullptr, tb, b_wu.as<int32_t>(), b_woff[c].as<int32_t>(), 0, (size_t)nw + 1, rocprim::plus<int32_t>(), s));
+            if (tb > tmp_bytes) {
+                RBG_HIP(hipStreamSynchronize(s));
+                if ((rc = b_tmp.alloc(tb))) return rc;
+                tmp_bytes = tb;
+            }
+            RBG_HIP(rocprim::exclusive_scan(b_tmp.p, tb, b_wu.as<int32_t>(), b_woff[c].as<int32_t>(), 0, (size_t)nw + 1, rocprim::plus<int32_t>(), s));
+            RBG_HIP(hipMemcpyAsync(&n_wide_units[c], b_woff[c].as<int32_t>() + nw, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            RBG_HIP(hipStreamSynchronize(s));  // (b_wu is reused by the next class)
+        }
     }
     const int64_t ent_split = info[thr.n + 1];  // rowptr[split]
     ClassSegs segs[2] = {};
@@ -333,10 +377,19 @@ int plan_sell(rbg_graph *g, int W, int chunk, bool rect) {
             if (row_e <= row) return;
             Seg &sg = segs[c].s[segs[c].n++];
             sg.pp = pp, sg.lp = lp, sg.row_b = row, sg.row_e = row_e, sg.unit_b = unit, sg.per = per, sg.wide = wide;
-            unit += wide ? 4 * (row_e - row) : (row_e - row + per - 1) / per;
+            unit += (row_e - row + per - 1) / per;
             row = row_e;
         };
-        push(4 * lgw, lp_full, 1, 1, cnt[0]);                                    // degree > chunk lgw: 4 lgw pieces over a workgroup
+        segs[c].n_wide_rows = cnt[0];
+        segs[c].n_wide_units = n_wide_units[c];
+        segs[c].woff = b_woff[c].as<int32_t>();
+        segs[c].cw = (int32_t)cw;
+        if (cnt[0] > 0) {  // degree > chunk lgw: U units of lgw pieces per row (pp is the row's own: U lgw, set where a row is looked at)
+            Seg &sg = segs[c].s[segs[c].n++];
+            sg.pp = 0, sg.lp = lp_full, sg.row_b = 0, sg.row_e = cnt[0], sg.unit_b = 0, sg.per = 1, sg.wide = 1;
+            unit = n_wide_units[c];
+            row = cnt[0];
+        }
         for (int j = 1; j < thr.n; ++j) push(lgw >> (j - 1), lp_full - (j - 1), 1 << (j - 1), 0, cnt[j]);  // parts = lgw >> (j - 1)
         push(1, 0, lgw, 0, n[c]);                                                 // degree <= chunk: whole rows
         segs[c].n_units = unit;
@@ -359,6 +412,7 @@ int plan_sell(rbg_graph *g, int W, int chunk, bool rect) {
         sw->unit_base[c] = c ? n_units[0] : 0;
         sw->n_units[c] = n_units[c];
         sw->n_class[c] = n[c];
+        sw->n_wide_units[c] = n_wide_units[c];
     }
     sw->orig = b_orig.as<int32_t>();
     b_orig.p = nullptr;  // (owned by the plan from here on)

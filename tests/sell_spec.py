@@ -6,15 +6,18 @@ the graph handle's device CSR with torch ops (on the handle's GPU: ~10 ms at the
 (``rbg_graph_attach_sell``).  Per row class (user rows / item rows):
 
 * a row longer than ``chunk`` entries is cut into ``parts`` equal pieces (a power of two <= the LGW = 64 / (W/4) lane-groups
-  of a wave); a row longer than ``chunk * LGW`` into 4 LGW pieces over the four waves of a workgroup ("wide" rows: without
-  them the longest row is one wave's serial chain of 48 gather batches, which alone set the kernel's duration);
+  of a wave); a row longer than ``chunk * LGW`` into U = ceil(degree / (chunk LGW)) UNITS of LGW pieces each ("wide" rows;
+  r06: any number of units — their partial sums meet in a scratch slot per unit and the last unit to arrive adds them in unit
+  order — where r03-r05 had exactly four, the four waves of a workgroup, and refused graphs with longer hub rows);
 * rows are renumbered in PROCESSING order — (parts, degree) descending — so the rows of a unit (= the lane-groups of one
   wave) are consecutive and of similar length, heaviest first (the hardware dispatcher then balances the load);
 * a unit's entries are stored unit-major and padded to its longest piece (rounded up to 2): batches of 8 slots,
   ``[batch][lane-group][slot]``, so one wave-wide 16-byte load fetches a batch and no lane masks anything.
 
 Entry = {byte offset of the slab row (internal column * W * 4), bits of val}; padding = {K_PAST, 0.0} (a buffer load past
-the table returns zeros).  ``factors`` = r with val_ij = r_i r_j when the values are the symmetric normalisation (else None).  Unit header = {first entry, first row, slots << 16, log2(parts) | rows << 8 | wide << 16}.
+the table returns zeros).  ``factors`` = r with val_ij = r_i r_j when the values are the symmetric normalisation (else None).
+Unit header = {first entry, first row, slots << 16 | j, log2(parts) | rows << 8 | wide << 16 | U << 17}: j = the unit's index
+among the U units of its wide row (0, 0 otherwise).  The wide units are the FIRST units of their class.
 The same planner runs on CPU tensors (tests)."""
 from __future__ import annotations
 
@@ -22,13 +25,12 @@ import torch
 
 K_PAST = 0x7FFFFFF0
 CHUNK = 128  # (sweep, profiles/r03_sell_chunk_probe.jsonl: 24..192 within 4 %, best 128-192; from 256 on the longest piece is the critical path again)
-MAX_PIECE = 512  # longest piece a plan accepts (or nnz / 8192 if that is more): a wide row has 4 LGW pieces, each summed
-                 # serially by one lane-group at ~20 entries per us — beyond this the hub row's chain would outlast the launch
+MAX_UNITS = 32767  # units of one wide row (15 bits of the header)
 
 
 class NotApplicable(ValueError):
-    """The graph is outside what the slab path serves (a hub row longer than 4 LGW x max(MAX_PIECE, nnz / 8192) entries, a table beyond 32-bit
-    slab offsets): the caller keeps the binned kernel, which splits such rows over workgroups."""
+    """The graph is outside what the slab path serves (a table beyond 32-bit slab offsets, a row of more than
+    MAX_UNITS x chunk x LGW entries): the caller keeps the binned kernel."""
 
 
 def _round2(x):
@@ -50,9 +52,8 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
     if max(n) * W * 4 >= K_PAST:
         raise NotApplicable("table too large for 32-bit slab offsets")
     max_deg = int(deg.max()) if deg.numel() else 0
-    max_piece = max(MAX_PIECE, int(col.numel()) // 8192)
-    if max_deg > max_piece * 4 * lgw:
-        raise NotApplicable(f"a row of {max_deg} entries is longer than the {4 * lgw} pieces of {max_piece} the slab path sums per row")
+    if max_deg > MAX_UNITS * chunk * lgw:
+        raise NotApplicable(f"a row of {max_deg} entries is longer than {MAX_UNITS} units of {chunk * lgw}")
     order, inv, parts_of = [], [], []
     for c in (0, 1):
         d = deg[base[c]:base[c] + n[c]]
@@ -61,7 +62,8 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
         need = (d[big] + chunk - 1) // chunk
         p[big] = torch.clamp(2 ** torch.ceil(torch.log2(need.to(torch.float64))).to(torch.int64), max=lgw)
         if wide:
-            p[d > chunk * lgw] = 4 * lgw
+            w = d > chunk * lgw
+            p[w] = (d[w] + chunk * lgw - 1) // (chunk * lgw) * lgw  # U units of lgw pieces
         o = torch.argsort(-d, stable=True)
         o = o[torch.argsort(-p[o], stable=True)]  # parts descending, then degree descending, then id
         i = torch.empty(n[c], **i64)
@@ -92,12 +94,12 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
         b = 0
         for pb, cnt in zip(vals_p.tolist(), counts.tolist()):
             e = b + cnt
-            if pb > lgw:  # wide rows: one row = 4 units (one workgroup); unit j holds parts [j lgw, (j + 1) lgw)
-                rows_w = torch.repeat_interleave(torch.arange(b, e, **i64), 4)
+            if pb > lgw:  # wide rows: one row = U = pb / lgw units; unit j holds parts [j lgw, (j + 1) lgw)
+                rows_w = torch.repeat_interleave(torch.arange(b, e, **i64), pb // lgw)
                 u_row0.append(rows_w)
                 u_nrows.append(torch.ones(len(rows_w), **i64))
                 u_lp.append(torch.full((len(rows_w),), lgw.bit_length() - 1, **i64))
-                u_pbase.append((torch.arange(4, **i64) * lgw).repeat(cnt))
+                u_pbase.append((torch.arange(pb // lgw, **i64) * lgw).repeat(cnt))
                 u_pp.append(torch.full((len(rows_w),), pb, **i64))
             else:
                 per = lgw // pb
@@ -145,7 +147,8 @@ def build_plan(rowptr, col, val, n_users, n_items, W=32, chunk=CHUNK, wide=True)
         pos = u_off[un] + lgw * 8 * k + flg[piece] * sb + j
         e[pos, 0] = (ci[eidx] * (W * 4)).to(torch.int32)
         e[pos, 1] = v[eidx].contiguous().view(torch.int32)
-        head = torch.stack([u_off[:-1] + ent_off, u_row0, u_nc << 16, u_lp | (u_nrows << 8) | (u_wide << 16)], dim=1)
+        head = torch.stack([u_off[:-1] + ent_off, u_row0, (u_nc << 16) | (u_wide * (u_pbase // lgw)),
+                            u_lp | (u_nrows << 8) | (u_wide << 16) | ((u_wide * (u_pp // lgw)) << 17)], dim=1)
         unit_base.append(sum(n_units))
         n_units.append(nu_)
         heads.append(head)
@@ -186,7 +189,7 @@ def emulate(plan, x):
         obase, base = (n[0], 0) if c == 0 else (0, n[0])
         yc = np.zeros((n[c], x.shape[1]))
         for off, row0, hc, lr in head[plan["unit_base"][c]:plan["unit_base"][c] + plan["n_units"][c]]:
-            nc, lp, nrows = hc >> 16, lr & 0xFF, (lr >> 8) & 0xFF
+            nc, lp, nrows = (hc >> 16) & 0xFFFF, lr & 0xFF, (lr >> 8) & 0xFF
             for k in range(0, nc, 8):
                 sb = min(8, nc - k)
                 blk = ent[off + lgw * k: off + lgw * k + lgw * sb].reshape(lgw, sb, 2)

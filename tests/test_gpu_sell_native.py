@@ -101,8 +101,9 @@ def test_native_plan_equals_the_specification(rbg, cuda, name, W, chunk):
 
 
 def test_plan_reasons_are_visible(rbg, cuda):
-    """A graph outside the plan's reach keeps the binned kernel and says why (rbg_graph_sell_status): a hub row beyond
-    4 LGW x max(512, nnz / 8192) entries; a CSR without a user / item boundary; a host graph; planning switched off."""
+    """r06: a hub row of any length is planned (U units; r03-r05 refused a hub beyond 4 LGW x max(512, nnz / 8192) entries and
+    kept the binned kernel).  A graph outside the plan's reach keeps the binned kernel and says why (rbg_graph_sell_status):
+    a CSR without a user / item boundary; a host graph; planning switched off."""
     lgw = 8
     hub = 512 * 4 * lgw + 1000
     nu, ni = 400, hub + 10
@@ -111,18 +112,21 @@ def test_plan_reasons_are_visible(rbg, cuda):
     key = np.unique(u * ni + i)
     u, i = key // ni, key % ni
     h = rbg.GraphHandle.from_interactions(u, i, nu, ni, device=cuda)
-    assert not h.has_sell(64) and "longer than" in h.sell_status() and "binned" in h.propagation_kernel_name(64)
-    with pytest.raises(rbg.RbgError) as ei:
-        h.plan_sell()
-    assert ei.value.code == rbg._lib.RBG_EUNSUPPORTED
+    assert h.has_sell(64) and h.sell_status() == "planned" and "sell_spmm_kernel" in h.propagation_kernel_name(64)
     x = randn((nu + ni, 64), 1, cuda)
     rp, cl, vl = C.build_norm_csr(u, i, nu, ni)
     x64 = x.cpu().numpy().astype(np.float64)  # (float64: the hub row is a sum of 17 384 terms, the fp32 restatement itself is 1e-4 off)
     l1 = O.conv_csr_f64(x64, rp, cl, vl)
-    close(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), 2)[0], (x64 + l1 + O.conv_csr_f64(l1, rp, cl, vl)) / 3)
-    # a square CSR / COO without stated classes: the bipartite boundary is detected (r04) — here the hub still rules the plan out
+    want = (x64 + l1 + O.conv_csr_f64(l1, rp, cl, vl)) / 3
+    got = rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), 2)[0]
+    close(got, want)
+    for _ in range(3):  # the hub's 17 units arrive in any order: the last one adds them in unit order — the same bits every time
+        assert torch.equal(rbg.ops.lightgcn_forward_raw(h, x[:nu].contiguous(), x[nu:].contiguous(), 2)[0], got)
+    close(rbg.ops.spmm_raw(h, x), l1)
+    # a square CSR / COO without stated classes: the bipartite boundary is detected (r04)
     hc = rbg.GraphHandle.from_csr(rp, cl, vl, nu + ni, device=cuda)
-    assert not hc.has_sell(64) and "longer than" in hc.sell_status()
+    assert hc.has_sell(64) and hc.sell_status() == "planned"
+    close(rbg.ops.spmm_raw(hc, x), l1)
     # ... and a graph that is NOT bipartite (a triangle among the users) has no boundary
     tri_rp = np.array([0, 2, 4, 6, 6], dtype=np.int64)
     tri = rbg.GraphHandle.from_csr(tri_rp, np.array([1, 2, 0, 2, 0, 1], dtype=np.int32), np.full(6, 0.5, dtype=np.float32), 4, device=cuda)
