@@ -913,7 +913,8 @@ def main():
 
         launches_per_step = k_layers
         units_per_step = world if scaling == "weak" else 1
-        kernel_name = prop.g_int.spmm_kernel_name(d)
+        kernel_name = (prop.g_cat if prop.fused else prop.g_int).spmm_kernel_name(d)
+        extra["layer_form"] = prop.kernel_status()  # r06: "fused" = one planned handle over [owned | halo], one launch per layer
         extra.update(p_in=args.p_in if scaling == "weak" else None, halo_rows_rank0=int(plan.n_halo),
                      owned_rows_rank0=int(plan.n_owned), halo_bytes_per_layer_rank0=int(plan.n_halo) * d * 4,
                      overlap=bool(prop.overlap), transport=transport,
@@ -1058,9 +1059,14 @@ def main():
             extra["phase_us"] = {
                 "halo_exchange(pack + all_to_all)": phase_us(
                     lambda: (prop._exchange_nccl if transport == "nccl" else prop._exchange_staged)(e0, halo_buf[: plan.n_halo])),
-                "interior_spmm": phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False)),
-                "halo_spmm": phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0,
             }
+            if prop.fused:  # one launch over the table [owned rows | halo rows]
+                cat_buf = torch.empty((plan.n_owned + plan.n_halo, d), device=dev)
+                extra["phase_us"]["fused_layer_spmm"] = phase_us(lambda: prop.backend.spmm(prop.g_cat, cat_buf, y_buf, False))
+                del cat_buf
+            else:
+                extra["phase_us"]["interior_spmm"] = phase_us(lambda: prop.backend.spmm(prop.g_int, e0, y_buf, False))
+                extra["phase_us"]["halo_spmm"] = phase_us(lambda: prop.backend.spmm(prop.g_halo, halo_buf, y_buf, True)) if prop.g_halo else 0.0
             del halo_buf, y_buf
         except Exception as ex:  # noqa: BLE001
             extra["phase_us_error"] = str(ex)[:200]
