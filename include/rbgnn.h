@@ -557,6 +557,24 @@ int rbg_spmm_sharded_f32(rbg_shard *shard, const float *X, float *Y, int d, void
  * outside a stream capture — and leaves `layers` untouched).  1 <= K <= RBG_MAX_FUSED_LAYERS + 1. */
 int rbg_lightgcn_forward_sharded_f32(rbg_shard *shard, const float *E0, float *out_mean, float *layers, int d, int K, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * multi-GPU: halo PUSH without a collective (r06; csrc/ipc.hip).  A rank keeps its layer tables [owned rows | halo rows] in
+ * memory it exports; its peers map that memory and their pack kernels (rbg_gather_rows_f32 with dst inside the mapping) store
+ * the rows the owner needs straight into the owner's table tail — over xGMI between GPUs, in the same HBM when two processes
+ * share a GPU.  Ordering: after its pushes a sender release-stores a sequence number into the receiver's flag word
+ * (rbg_ipc_signal, on the sender's stream); the receiver's stream waits for all its senders' words (rbg_ipc_wait: a bounded
+ * spin — after timeout_ms it sets *err (device int, 1 + the index of the late word) instead of hanging) and its layer launch
+ * follows in stream order.  sharded.py::PushExchange drives it; the collective transports remain the default.
+ * ------------------------------------------------------------------------------------------- */
+#define RBG_IPC_HANDLE_BYTES 64
+int rbg_ipc_alloc(void **ptr, int64_t bytes, int device);       /* zero-filled device memory that can be exported */
+void rbg_ipc_free(void *ptr);
+int rbg_ipc_export(void *ptr, void *handle);                      /* hipIpcGetMemHandle: RBG_IPC_HANDLE_BYTES bytes for the peers */
+int rbg_ipc_open(const void *handle, void **ptr, int device);    /* hipIpcOpenMemHandle in a peer process */
+int rbg_ipc_close(void *ptr);
+int rbg_ipc_signal(void *flag, uint64_t value, void *stream);    /* *flag = value (8-byte word, possibly in a peer's memory), release */
+int rbg_ipc_wait(const void *flags, int n, uint64_t value, int timeout_ms, int *err, void *stream);  /* until flags[0..n) >= value */
+
 /* out[t] = scale * (srcs[0][t] + srcs[1][t] + ...), added left to right: the layer mean of lightgcn.py:80-81 over
  * separately held layer outputs (the sharded propagation) in one launch.  n_srcs <= RBG_MAX_FUSED_LAYERS + 1. */
 int rbg_mean_f32(const float *const *srcs, int n_srcs, int64_t n_floats, float scale, float *out, void *stream);

@@ -84,6 +84,13 @@ SIGNATURES = {
     "rbg_shard_status": (c_int, [c_vp, ctypes.c_char_p, c_int]),
     "rbg_spmm_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "rbg_lightgcn_forward_sharded_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "rbg_ipc_alloc": (c_int, [P(c_vp), c_i64, c_int]),
+    "rbg_ipc_free": (None, [c_vp]),
+    "rbg_ipc_export": (c_int, [c_vp, c_vp]),
+    "rbg_ipc_open": (c_int, [c_vp, P(c_vp), c_int]),
+    "rbg_ipc_close": (c_int, [c_vp]),
+    "rbg_ipc_signal": (c_int, [c_vp, ctypes.c_uint64, c_vp]),
+    "rbg_ipc_wait": (c_int, [c_vp, c_int, ctypes.c_uint64, c_int, c_vp, c_vp]),
     "rbg_mean_f32": (c_int, [c_vp, c_int, c_i64, c_f32, c_vp, c_vp]),
     "rbg_gather_rows_f32": (c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_vp]),
     "rbg_bignn_layer_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_int, c_f32, c_vp]),

@@ -376,6 +376,135 @@ class HipBackend:
         return out
 
 
+# ---- halo push without a collective (r06) ------------------------------------------------------------
+
+class PushExchange:
+    """Peer-to-peer halo PUSH (csrc/ipc.hip): this rank's layer tables [owned rows | halo rows] live in memory it exports
+    (hipIpcGetMemHandle); every peer maps them and its pack kernel stores the rows this rank needs straight into the table's
+    tail — no send buffer, no collective, no receive-side copy.  Ordering by flag words in the same exported block:
+
+    * ``ready[k][p]``  (mine, written by sender p after its pushes into my table k): my stream waits for all of them before the
+      layer launch;
+    * ``free[k][q]``   (mine, written by receiver q after ITS launch consumed its table k): my stream waits for it before it
+      pushes into q's table k again.
+
+    Values are the exchange's sequence number (monotone: no reset).  Waits are bounded spins on the GPU (``timeout_ms``; a
+    time-out sets an error word that ``check()`` raises on).  Set-up is collective over ``group`` (handles and geometry travel
+    by ``all_gather_object``); a layer afterwards is launches on the rank's own stream only.  Exercised by two processes on ONE
+    GPU (tests); between different GPUs the mapping goes over xGMI — never run in this project (no multi-GPU box)."""
+
+    def __init__(self, plan, device, d, n_tables, group=None, timeout_ms=2000):
+        import ctypes
+        from . import _lib
+        self._lib, self.plan, self.device, self.d, self.n_tables = _lib, plan, torch.device(device), int(d), int(n_tables)
+        self.world, self.rank, self.timeout_ms = plan.world, plan.rank, int(timeout_ms)
+        lib, vp = _lib.lib, _lib.c_vp
+        dev_i = self.device.index or 0
+        self.rows = plan.n_owned + plan.n_halo
+        self.table_bytes = -(-self.rows * self.d * 4 // 256) * 256
+        nf = self.n_tables * self.world
+        self.flag_bytes = -(-(2 * nf * 8 + 64) // 4096) * 4096     # ready[k][p], free[k][q] (uint64), one error word
+        self._base = vp()
+        _lib.check(lib.rbg_ipc_alloc(ctypes.byref(self._base), self.flag_bytes + self.n_tables * self.table_bytes, dev_i))
+        h = ctypes.create_string_buffer(64)
+        _lib.check(lib.rbg_ipc_export(self._base, h))
+        meta = {"handle": h.raw, "n_owned": int(plan.n_owned), "recv_counts": [int(c) for c in plan.recv_counts],
+                "table_bytes": self.table_bytes, "flag_bytes": self.flag_bytes, "d": self.d, "n_tables": self.n_tables}
+        metas = [None] * self.world
+        dist.all_gather_object(metas, meta, group=group)
+        for m in metas:
+            if m["d"] != self.d or m["n_tables"] != self.n_tables:
+                raise ValueError("PushExchange: the ranks disagree on d / n_tables")
+        self._metas = metas
+        self._peer = {}
+        for q, m in enumerate(metas):
+            if q == self.rank:
+                continue
+            ptr = vp()
+            _lib.check(lib.rbg_ipc_open(m["handle"], ctypes.byref(ptr), dev_i))
+            self._peer[q] = ptr.value
+        # what I push to q: my rows send_idx[so_q : so_q + sc_q]; where they land in q's tail: after the rows of the ranks before me
+        self._send = []
+        so = 0
+        for q in range(self.world):
+            sc = int(plan.send_counts[q])
+            if sc and q != self.rank:
+                row_off = metas[q]["n_owned"] + sum(metas[q]["recv_counts"][:self.rank])
+                self._send.append((q, so, sc, row_off))
+            so += sc
+        self._senders = [p for p in range(self.world) if p != self.rank and int(plan.recv_counts[p]) > 0]
+        self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=self.device)
+        self._seq = 0
+        self._last_use = [0] * self.n_tables
+        self._tables = [self._view(self._base.value + self.flag_bytes + k * self.table_bytes, (self.rows, self.d)) for k in range(self.n_tables)]
+        # every rank has mapped everyone before anyone pushes
+        dist.barrier(group=group)
+
+    def _view(self, ptr, shape):
+        owner = self
+
+        class _V:
+            def __init__(self):
+                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (ptr, False), "version": 2}
+                self._owner = owner
+        return torch.as_tensor(_V(), device=self.device)
+
+    def table(self, k):
+        return self._tables[k]
+
+    def _flag(self, base, kind, k, who):
+        """address of ready (kind 0) / free (kind 1) word [k][who] in the block at `base`"""
+        return base + ((kind * self.n_tables + k) * self.world + who) * 8
+
+    @property
+    def _err_ptr(self):
+        return self._base.value + 2 * self.n_tables * self.world * 8
+
+    def exchange(self, k, stream):
+        """Push the rows my peers need of table k's head into THEIR table k, then wait until mine has everyone's rows."""
+        lib, vp, chk = self._lib.lib, self._lib.c_vp, self._lib.check
+        self._seq += 1
+        seq, st = self._seq, vp(stream)
+        x = self._tables[k]
+        # the receivers have consumed what I pushed into their table k last time
+        if self._last_use[k] and self._send:
+            # (one wait per receiver word: they are not adjacent — free[k][q] for the q I send to)
+            for q, _, _, _ in self._send:
+                chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 1, k, q)), 1, self._last_use[k], self.timeout_ms, vp(self._err_ptr), st))
+        for q, so, sc, row_off in self._send:
+            dst = self._peer[q] + self._metas[q]["flag_bytes"] + k * self._metas[q]["table_bytes"] + row_off * self.d * 4
+            chk(lib.rbg_gather_rows_f32(vp(x.data_ptr()), self.d, vp(self.send_idx.data_ptr() + so * 8), vp(dst), sc, self.d, st))
+            chk(lib.rbg_ipc_signal(vp(self._flag(self._peer[q], 0, k, self.rank)), seq, st))
+        for p in self._senders:
+            chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 0, k, p)), 1, seq, self.timeout_ms, vp(self._err_ptr), st))
+        self._last_use[k] = seq
+
+    def consumed(self, k, stream):
+        """After the launch that read table k: its senders may overwrite the tail."""
+        lib, vp, chk = self._lib.lib, self._lib.c_vp, self._lib.check
+        for p in self._senders:
+            chk(lib.rbg_ipc_signal(vp(self._flag(self._peer[p], 1, k, self.rank)), self._last_use[k], vp(stream)))
+
+    def check(self):
+        """Synchronise and raise if a wait timed out (a peer that never pushed)."""
+        torch.cuda.synchronize(self.device)
+        err = torch.as_tensor(type("_E", (), {"__cuda_array_interface__": {"shape": (1,), "typestr": "<i4", "data": (self._err_ptr, False), "version": 2}})(),
+                              device=self.device)
+        e = int(err[0])
+        if e:
+            raise RuntimeError(f"PushExchange: rank {self.rank} timed out waiting for flag word {e - 1} ({self.timeout_ms} ms)")
+
+    def close(self):
+        if getattr(self, "_base", None) is not None and self._base.value:
+            torch.cuda.synchronize(self.device)
+            for ptr in self._peer.values():
+                self._lib.lib.rbg_ipc_close(self._lib.c_vp(ptr))
+            self._peer = {}
+            self._tables = []
+            self._lib.lib.rbg_ipc_free(self._base)
+            self._base = None
+
+
 # ---- the sharded propagation ---------------------------------------------------------------------
 
 class ShardedPropagation:
@@ -407,7 +536,7 @@ class ShardedPropagation:
         n_total = sum(int(c) for c in self.plan.recv_counts)
         return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
 
-    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None):
+    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None, push_tables=4, push_timeout_ms=2000):
         # overlap = None (default): off — unmeasured between real peers; ``autotune`` measures both forms on the actual group
         if overlap is None:
             overlap = False
@@ -416,6 +545,11 @@ class ShardedPropagation:
         self.device = dev
         self._g_int = self._g_halo = self._g_cat = None   # handles are built on first use: a fused rank never builds the pair
         self._want_fused = (not overlap) if fused is None else bool(fused)
+        # transport "push" (r06): no collective — the peers' pack kernels store into this rank's exported layer tables
+        # (PushExchange); the fused layer only, forward / spmm / backward (halo_of and the staged helpers are not served)
+        self.push, self._push_tables, self._push_timeout_ms = None, int(push_tables), int(push_timeout_ms)
+        if transport == "push" and (overlap or fused is False):
+            raise ValueError('transport "push" is the fused single-stream layer')
         self.send_idx = torch.as_tensor(plan.send_idx, dtype=torch.int64, device=dev)
         self.comm_stream, self._comm_h, self._ctx = None, None, None
         self.overlap = False
@@ -434,6 +568,8 @@ class ShardedPropagation:
     def fused(self):
         """One handle, one launch per layer (no interior / halo split): whenever asked for, the rank has a halo and the
         overlapped two-stream form is off."""
+        if self.transport == "push":  # (every rank runs the table form, also one without a halo of its own: its peers push and wait)
+            return self.plan.world > 1 and self.plan.n_owned > 0
         return self._want_fused and self.plan.n_halo > 0 and self.plan.n_owned > 0 and not self.overlap
 
     def set_fused(self, fused):
@@ -483,7 +619,13 @@ class ShardedPropagation:
             self._send = torch.empty((max(len(plan.send_idx), 1), d), **f)
             # layer tables [owned rows | halo rows]: a fused layer gathers one and writes the head of the next; the two-handle
             # form uses their heads as its ping-pong outputs
-            self._cat = [torch.empty((plan.n_owned + plan.n_halo, d), **f) for _ in range(2)]
+            if self.transport == "push" and plan.world > 1:   # (collective set-up: every rank reaches its first layer together)
+                if self.push is not None:
+                    self.push.close()
+                self.push = PushExchange(plan, x.device, d, self._push_tables, group=self.group, timeout_ms=self._push_timeout_ms)
+                self._cat = [self.push.table(k) for k in range(self._push_tables)]
+            else:
+                self._cat = [torch.empty((plan.n_owned + plan.n_halo, d), **f) for _ in range(2)]
             self._y = [c[: plan.n_owned] for c in self._cat]
             self._mean = torch.empty((plan.n_owned, d), **f)
             self._halo_view = self._halo[: plan.n_halo]
@@ -580,6 +722,8 @@ class ShardedPropagation:
         return self.backend.mean(list(srcs) + [y], out, **kw)  # no halo on this rank: plain mean of the kept layers
 
     def _more_tables(self, n):
+        if self.push is not None and n > len(self._cat):
+            raise ValueError(f"transport \"push\" was set up with {len(self._cat)} layer tables; this call needs {n} (push_tables=)")
         while len(self._cat) < n:
             self._cat.append(torch.empty_like(self._cat[0]))
             self._y.append(self._cat[-1][: self.plan.n_owned])
@@ -616,6 +760,9 @@ class ShardedPropagation:
                 raise ValueError("halo_rows has fewer rows than this plan's halo")
             if halo_rows.data_ptr() != tail.data_ptr():
                 tail.copy_(halo_rows[: plan.n_halo])
+        elif self.transport == "push":
+            pk = next(k for k, c in enumerate(self._cat) if c.data_ptr() == xcat.data_ptr())
+            self.push.exchange(pk, main_h)
         elif self.transport == "nccl":
             if self._n_send:
                 self.backend.gather_rows(xcat[:n], self.send_idx, out=self._send[: self._n_send], stream=main_h)
@@ -623,16 +770,21 @@ class ShardedPropagation:
                                    input_split_sizes=self._send_splits, group=self.group)
         else:
             self._exchange_staged(xcat[:n], tail)
+        pushed = self.transport == "push" and halo_rows is None
         if finish is not None:
             srcs, mean_out = finish
-            return self.backend.spmm_mean(self.g_cat, xcat, None, srcs, mean_out, **kw)
-        if out is not None:
-            y = out
-        elif x.device.type == "cuda":
-            y = next(c for c in self._cat if c.data_ptr() != xcat.data_ptr())[:n]
+            res = self.backend.spmm_mean(self.g_cat, xcat, None, srcs, mean_out, **kw)
         else:
-            y = torch.empty((n, d), dtype=x.dtype)
-        return self.backend.spmm(self.g_cat, xcat, y, False, **kw)
+            if out is not None:
+                y = out
+            elif x.device.type == "cuda":
+                y = next(c for c in self._cat if c.data_ptr() != xcat.data_ptr())[:n]
+            else:
+                y = torch.empty((n, d), dtype=x.dtype)
+            res = self.backend.spmm(self.g_cat, xcat, y, False, **kw)
+        if pushed:
+            self.push.consumed(pk, main_h)  # the table's senders may overwrite its tail from here on (stream order)
+        return res
 
     def spmm(self, x, out=None, main=None, finish=None, halo_rows=None):
         """Y[owned] = Â[owned,:]·X with X given as this rank's owned rows.  `main`: the torch stream the caller runs on

@@ -725,3 +725,69 @@ def test_hybrid_grid_two_by_two_on_one_gpu(ref_inter):
         assert err <= 1e-5 and gerr <= 1e-5 and ferr <= 1e-5, (rank, err, gerr, ferr)
         assert hb["columns"] == 32 and hb["halo_rows"] > 0 and hb["recv_bytes"] == hb["halo_rows"] * 32 * 4
         assert kern.startswith("sell_spmm_kernel<32, 1,"), kern
+
+
+def _push_worker(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import recbole_gnn_amd as rbg
+        sh = rbg.sharded
+        dev = torch.device("cuda:0")
+        owner = sh.degree_striped_partition(uid, iid, nu, ni, world)
+        plan = sh.build_plans(uid, iid, nu, ni, world, owner=owner, ranks=[rank])[rank]
+        e0 = np.random.default_rng(1).standard_normal((nu + ni, d)).astype(np.float32)
+        x0 = torch.from_numpy(e0[plan.owned]).to(dev)
+        staged = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="staged")
+        want = staged.forward(x0, k_layers).clone()
+        push = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="push", push_tables=k_layers + 1)
+        outs = []
+        for _ in range(3):  # the tables and flag words are reused: three propagations back to back, no host synchronisation between
+            outs.append(push.forward(x0, k_layers).clone())
+        push.push.check()
+        bit_equal = all(bool(torch.equal(o, want)) for o in outs)
+        # the plain layer and the backward chain (ping-pong tables) as well
+        y_s, y_p = staged.spmm(x0).clone(), push.spmm(x0).clone()
+        g_s, g_p = staged.backward(x0, k_layers).clone(), push.backward(x0, k_layers).clone()
+        push.push.check()
+        rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
+        ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)
+        err = float(np.abs(outs[-1].cpu().numpy() - ref[plan.owned]).max())
+        res = (rank, bit_equal, bool(torch.equal(y_s, y_p)), bool(torch.equal(g_s, g_p)), err, push.kernel_status())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        push.push.close()
+        if rank == 0:
+            out_q.put(gathered)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_push_between_processes_on_one_gpu(ref_inter, world):
+    """r06, transport "push" (csrc/ipc.hip, sharded.PushExchange): every rank exports its layer tables, the peers' pack kernels
+    store the halo rows straight into them, flag words order it — no collective.  Two / three processes on cuda:0: bit-equal to
+    the staged transport (forward x 3 without a host synchronisation in between, plain layer, backward chain) and within 1e-5
+    of the single-graph oracle."""
+    uid, iid, nu, ni = ref_inter
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_push_worker, args=(r, world, port, uid, iid, nu, ni, 3, 64, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = q.get(timeout=300)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0
+    for rank, fwd_equal, layer_equal, bwd_equal, err, status in res:
+        assert fwd_equal and layer_equal and bwd_equal, (rank, fwd_equal, layer_equal, bwd_equal)
+        assert err <= 1e-5 and status["form"] == "fused", (rank, err, status)
