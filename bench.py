@@ -1070,6 +1070,39 @@ def main():
             del halo_buf, y_buf
         except Exception as ex:  # noqa: BLE001
             extra["phase_us_error"] = str(ex)[:200]
+        # r06: the same propagation with the halo PUSHED into the peers' exported layer tables instead of a collective
+        # (sharded.PushExchange, csrc/ipc.hip): us per propagation (max over ranks) and its exchange alone.  Collective set-up:
+        # every rank tries, a failure anywhere is voted on, so nobody waits on a peer that gave up.
+        try:
+            pp, perr = None, None
+            try:
+                if k_layers + 1 > 9 or not prop.fused:
+                    raise RuntimeError("push serves the fused layer")
+                pp = sh.ShardedPropagation(plan, prop.backend, group=gloo_group, transport="push", push_tables=k_layers + 1)
+                pp._g_cat = prop.g_cat  # (the same planned handle)
+            except Exception as ex:  # noqa: BLE001
+                perr = str(ex)[:160]
+            ok = torch.tensor([0.0 if perr else 1.0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
+            if float(ok) == 1.0:
+                pp.forward(e0, k_layers)  # (set-up of the exchange: collective over the gloo group)
+                torch.cuda.synchronize()
+                ref_mean = prop.forward(e0, k_layers).clone()
+                same = bool(torch.equal(pp.forward(e0, k_layers), ref_mean))
+                t_push = phase_us(lambda: pp.forward(e0, k_layers), iters=10)
+                t_ex = phase_us(lambda: (pp.push.exchange(0, torch.cuda.current_stream().cuda_stream), pp.push.consumed(0, torch.cuda.current_stream().cuda_stream)), iters=10)
+                pp.push.check()
+                tt = torch.tensor([t_push, t_ex])
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=gloo_group)
+                extra["halo_push"] = {"propagation_us(max over ranks)": float(tt[0]), "exchange_alone_us(push + flags, one layer)": float(tt[1]),
+                                      "bit_equal_to_the_timed_transport": same,
+                                      "note": "no collective: peers' pack kernels store into this rank's exported tables (hipIpc), flag words order it"
+                                              + ("" if torch.cuda.device_count() >= world else "; ranks share one GPU here: functional, not a measurement")}
+                pp.push.close()
+            else:
+                extra["halo_push"] = {"error": perr or "a peer could not set the exchange up"}
+        except Exception as ex:  # noqa: BLE001
+            extra["halo_push_error"] = str(ex)[:200]
         # BASELINE config #5 is "SGL ... 8 x MI355X": one sharded SGL TRAINING step on the strong graph (sharded_train.py: three
         # propagations over the full graph and two edge-drop views, BPR + reg + InfoNCE with distributed denominators, the
         # transposed chains, Adam on the owned rows), batch 2048 — a few steps, reported beside the propagation figure

@@ -437,15 +437,25 @@ class PushExchange:
         self._seq = 0
         self._last_use = [0] * self.n_tables
         self._tables = [self._view(self._base.value + self.flag_bytes + k * self.table_bytes, (self.rows, self.d)) for k in range(self.n_tables)]
-        # every rank has mapped everyone before anyone pushes
+        # the words of ranks that never signal me (no rows exchanged in that direction, and my own) are born satisfied, so ONE
+        # wait launch covers a table's row of words
+        flags = self._view(self._base.value, (2, self.n_tables, self.world), typestr="<i8")
+        never_ready = [p for p in range(self.world) if p not in self._senders]
+        never_free = [q for q in range(self.world) if q not in [t[0] for t in self._send]]
+        if never_ready:
+            flags[0][:, never_ready] = -1   # (= 2^64 - 1 as the unsigned word the kernels compare)
+        if never_free:
+            flags[1][:, never_free] = -1
+        torch.cuda.synchronize(self.device)
+        # every rank has mapped everyone (and initialised its words) before anyone pushes
         dist.barrier(group=group)
 
-    def _view(self, ptr, shape):
+    def _view(self, ptr, shape, typestr="<f4"):
         owner = self
 
         class _V:
             def __init__(self):
-                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (ptr, False), "version": 2}
+                self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
                 self._owner = owner
         return torch.as_tensor(_V(), device=self.device)
 
@@ -468,15 +478,13 @@ class PushExchange:
         x = self._tables[k]
         # the receivers have consumed what I pushed into their table k last time
         if self._last_use[k] and self._send:
-            # (one wait per receiver word: they are not adjacent — free[k][q] for the q I send to)
-            for q, _, _, _ in self._send:
-                chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 1, k, q)), 1, self._last_use[k], self.timeout_ms, vp(self._err_ptr), st))
+            chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 1, k, 0)), self.world, self._last_use[k], self.timeout_ms, vp(self._err_ptr), st))
         for q, so, sc, row_off in self._send:
             dst = self._peer[q] + self._metas[q]["flag_bytes"] + k * self._metas[q]["table_bytes"] + row_off * self.d * 4
             chk(lib.rbg_gather_rows_f32(vp(x.data_ptr()), self.d, vp(self.send_idx.data_ptr() + so * 8), vp(dst), sc, self.d, st))
             chk(lib.rbg_ipc_signal(vp(self._flag(self._peer[q], 0, k, self.rank)), seq, st))
-        for p in self._senders:
-            chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 0, k, p)), 1, seq, self.timeout_ms, vp(self._err_ptr), st))
+        if self._senders:
+            chk(lib.rbg_ipc_wait(vp(self._flag(self._base.value, 0, k, 0)), self.world, seq, self.timeout_ms, vp(self._err_ptr), st))
         self._last_use[k] = seq
 
     def consumed(self, k, stream):
@@ -931,9 +939,10 @@ class ShardedPropagation:
                 x = x + g  # a fresh tensor: the ping-pong buffer is free again
         return x / float(n_layers + 1)
 
-    def autotune(self, e0, n_layers, iters=10):
-        """nccl transport, N > 1: time a few propagations with each stream structure on the real group, take the MAX over
-        ranks, keep the faster one on every rank.  Returns the record it also stores in ``self.tuned``."""
+    def autotune(self, e0, n_layers, iters=10, try_push=True):
+        """nccl transport, N > 1: time a few propagations with each stream structure on the real group — and (r06) with the halo
+        PUSH that needs no collective — take the MAX over ranks, keep the fastest on every rank.  Returns the record it also
+        stores in ``self.tuned``."""
         if not (self.transport == "nccl" and self.plan.world > 1 and e0.device.type == "cuda"):
             return None
         res = {}
@@ -955,6 +964,41 @@ class ShardedPropagation:
         choice = res[True] < res[False]
         self.set_overlap(choice)
         self.tuned = {"single_stream_us": res[False], "overlap_us": res[True], "chosen": "overlap" if choice else "single_stream"}
+        # r06: the halo push without a collective (PushExchange) as a third candidate; every rank tries, a failure anywhere (IPC
+        # not available between these devices) is voted on, so nobody waits on a peer that gave up
+        if try_push and self._want_fused and n_layers + 1 <= 9:
+            sib, err = None, None
+            try:
+                sib = ShardedPropagation(self.plan, self.backend, group=self.group, transport="push", push_tables=n_layers + 1)
+                sib._g_cat = self._g_cat
+            except Exception as ex:  # noqa: BLE001
+                err = str(ex)[:160]
+            ok = torch.tensor([0.0 if err else 1.0], device=e0.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok[0]) == 1.0:
+                for _ in range(3):
+                    sib.forward(e0, n_layers)
+                torch.cuda.synchronize(e0.device)
+                dist.barrier(group=self.group)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(iters):
+                    sib.forward(e0, n_layers)
+                b.record()
+                torch.cuda.synchronize(e0.device)
+                t = torch.tensor([a.elapsed_time(b) * 1e3 / iters], device=e0.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                self.tuned["push_us"] = float(t[0])
+                if float(t[0]) < min(res.values()):  # adopt the sibling's transport and tables
+                    self.set_overlap(False)
+                    self.transport, self.push, self._push_tables = "push", sib.push, sib._push_tables
+                    self._cat, self._y, self._mean, self._buf_d = sib._cat, sib._y, sib._mean, sib._buf_d
+                    self._halo, self._send, self._halo_view, self._flip = sib._halo, sib._send, sib._halo_view, sib._flip
+                    self.tuned["chosen"] = "push"
+                else:
+                    sib.push.close()
+            else:
+                self.tuned["push_error"] = err or "a peer could not set the exchange up"
         return self.tuned
 
     # -- full-sort scoring over a sharded table (lightgcn.py:123-133: scores = u @ item_all.T) -------------------------------
