@@ -1078,15 +1078,21 @@ def main():
             try:
                 if k_layers + 1 > 9 or not prop.fused:
                     raise RuntimeError("push serves the fused layer")
-                pp = sh.ShardedPropagation(plan, prop.backend, group=gloo_group, transport="push", push_tables=k_layers + 1)
+                pp = sh.ShardedPropagation(plan, prop.backend, group=gloo_group, transport="push", push_tables=k_layers + 1, push_timeout_ms=500)
                 pp._g_cat = prop.g_cat  # (the same planned handle)
             except Exception as ex:  # noqa: BLE001
                 perr = str(ex)[:160]
             ok = torch.tensor([0.0 if perr else 1.0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
             if float(ok) == 1.0:
-                pp.forward(e0, k_layers)  # (set-up of the exchange: collective over the gloo group)
-                torch.cuda.synchronize()
+                try:
+                    pp.forward(e0, k_layers)  # (set-up of the exchange: collective over the gloo group)
+                    pp.push.check()           # (flag words that never arrive time out here, once, not in the timed loops)
+                except Exception as ex:  # noqa: BLE001
+                    perr = str(ex)[:160]
+                ok = torch.tensor([0.0 if perr else 1.0])
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=gloo_group)
+            if float(ok) == 1.0:
                 ref_mean = prop.forward(e0, k_layers).clone()
                 same = bool(torch.equal(pp.forward(e0, k_layers), ref_mean))
                 t_push = phase_us(lambda: pp.forward(e0, k_layers), iters=10)

@@ -969,14 +969,24 @@ class ShardedPropagation:
         if try_push and self._want_fused and n_layers + 1 <= 9:
             sib, err = None, None
             try:
-                sib = ShardedPropagation(self.plan, self.backend, group=self.group, transport="push", push_tables=n_layers + 1)
+                sib = ShardedPropagation(self.plan, self.backend, group=self.group, transport="push", push_tables=n_layers + 1, push_timeout_ms=500)
                 sib._g_cat = self._g_cat
             except Exception as ex:  # noqa: BLE001
                 err = str(ex)[:160]
             ok = torch.tensor([0.0 if err else 1.0], device=e0.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
             if float(ok[0]) == 1.0:
-                for _ in range(3):
+                # one propagation first, checked: flag words that never arrive (a mapping this machine does not keep coherent) time
+                # out in a few seconds instead of being timed ten times over
+                try:
+                    sib.forward(e0, n_layers)
+                    sib.push.check()
+                except Exception as ex:  # noqa: BLE001
+                    err = str(ex)[:160]
+                ok = torch.tensor([0.0 if err else 1.0], device=e0.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok[0]) == 1.0:
+                for _ in range(2):
                     sib.forward(e0, n_layers)
                 torch.cuda.synchronize(e0.device)
                 dist.barrier(group=self.group)
