@@ -116,6 +116,11 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   two; a tile's arrivals that do not fit are appended in rounds with a prune between): 1 (default) from
  *                   2048 users, 2 always, 0 never.  Same results.
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
+ *   "topk_image"  : 1 (default) = rbg_full_sort_topk_f32 at 64 < d <= 128, B >= 1024 splits the item table ONCE per call into three
+ *                   bf16 planes stored tile by tile in the LDS layout (in the workspace) and both passes take their item tiles from
+ *                   it by LDS-DMA (r06: 430 -> 394 us per call at 4096 users x 40 982 items x 128; at d <= 64 the per-workgroup
+ *                   fetch + split was already hidden: 191.5 vs 192.0 us); 2 = at d <= 64 as well; 0 = every workgroup fetches,
+ *                   splits and publishes its tiles itself.  Same results bit for bit.
  *   "sell"        : 1 (default) = rbg_lightgcn_forward_f32 / _backward_f32 / rbg_spmm_f32 use an attached column-slab plan
  *                   (rbg_graph_attach_sell) where it applies; 0 = the binned kernel
  *   "sell_rowmajor", "sell_factored" : see rbg_graph_attach_sell / rbg_graph_sell_set_factors (both default 1)

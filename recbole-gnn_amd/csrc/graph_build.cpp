@@ -48,6 +48,8 @@ static std::atomic<int> g_score_uniform{1};
 int opt_score_uniform() { return g_score_uniform.load(); }
 static std::atomic<int> g_topk_short{1};
 int opt_topk_short_lists() { return g_topk_short.load(); }
+static std::atomic<int> g_topk_image{1};
+int opt_topk_image() { return g_topk_image.load(); }
 static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 static std::atomic<int> g_sell_c16{1};
@@ -518,6 +520,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_shard_single_stream = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "topk_image")) {
+        g_topk_image = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        return RBG_OK;
+    }
     if (!strcmp(key, "shard_fused")) {
         g_shard_fused = value ? 1 : 0;
         return RBG_OK;
@@ -604,6 +610,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "nt_store")) {
         *value = g_nt_store.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "topk_image")) {
+        *value = g_topk_image.load();
         return RBG_OK;
     }
     if (!strcmp(key, "shard_fused")) {

@@ -54,6 +54,7 @@ int opt_col_split();    // SpMM: even / odd XCDs own the lower / upper half of t
 int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 matrix cores (1) or the exact-fp32 MFMA (0)
 // train.hip: zero `bytes` (4-byte units) at ptr by a fill kernel — NOT hipMemsetAsync, whose node writes garbage on a captured graph's later replays
 int zero_async(void *ptr, size_t bytes, hipStream_t s);
+int opt_topk_image();  // rbg_full_sort_topk_f32: split the item table once per call into a plane image the passes take by LDS-DMA (1, default)
 int opt_topk_short_lists();  // rbg_full_sort_topk_f32: 24-entry LDS lists (three workgroups per CU) at k <= 12, d <= 64: 0 never, 1 from 2048 users (default), 2 always
 int opt_deterministic();  // train.hip / lse.hip: row scatters by owner wavefronts in batch order (ordered.h), sums in fixed point: bit-stable
 int opt_lse_onepass();    // rbg_infonce_f32: denominators and the batch rows' gradient out of one pass over the table (1, default)

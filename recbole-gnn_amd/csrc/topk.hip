@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "lds_dma.h"
 #include "mfma_common.h"
 
 namespace rbg {
@@ -52,7 +53,42 @@ struct TopkParams {
     float *w_val;              // workspace [B][n_chunks*4][kListStride]
     int32_t *w_idx;
     int32_t *w_cnt;            // [B][n_chunks*4]
+    const char *image;         // r06: the item table as bf16 planes, tile by tile in the LDS layout (topk_image_kernel); NULL: fetch + split per workgroup
 };
+
+// r06 — the PLANE IMAGE.  Every workgroup of the main pass and of the pre-pass used to fetch each 32-item tile as fp32, split it
+// into three bf16 planes and publish them to LDS: per tile and wave ~ 1 000 cycles of fetch issue + ~ 800 of split / LDS writes
+// (profiles/r05_topk_clock.jsonl) — 40 % of the loop once the filter had become cheap (r05) — repeated by all 32 workgroup rows
+// of a 4 096-user call on the same 10 MB table.  Now one small kernel splits the table ONCE per call into an image that IS the
+// LDS layout (tile t = 3 planes x 32 rows x (64 NCHUNK + 8) bf16, contiguous), and a workgroup takes a tile by LDS-DMA
+// (global_load_lds_dwordx4: 16 bytes per lane, lane-linear — no registers, no VALU, no LDS-write instructions), one tile ahead.
+// Same planes, same products: bit-identical results.  (r02 had tried this when the filter and the list code dominated the loop:
+// no gain then.)
+template <int NCHUNK>
+struct PlaneImage {
+    static constexpr int LDH = NCHUNK * 64 + 8;
+    static constexpr int kTileBytes = 3 * 32 * LDH * 2;  // 13 824 (d <= 64), 26 112 (d <= 128): multiples of 16
+    static constexpr int kRounds = (kTileBytes + 4095) / 4096;
+    // all 256 threads: tile t of the image -> the LDS tile at lds_dst (byte address), 16 bytes per lane per round
+    static __device__ __forceinline__ void dma(const char *image, int64_t t, unsigned lds_dst, int tid, int wave) {
+        const char *src = image + t * (int64_t)kTileBytes;
+#pragma unroll
+        for (int k = 0; k < kRounds; ++k) {
+            const int chunk = tid + 256 * k;
+            if (chunk * 16 < kTileBytes) lds_dma16(src + chunk * 16, lds_dst + (unsigned)(k * 4096 + wave * 1024));
+        }
+    }
+};
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int NCHUNK, bool VEC>
+__global__ __launch_bounds__(256) void topk_image_kernel(const float *__restrict__ I, int64_t n_items, int d, char *__restrict__ image) {
+    using Tiles = RowTile3<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>;
+    Tiles tiles;
+    const int64_t t = blockIdx.x;
+    tiles.fetch(I, d, n_items, d, t, threadIdx.x);
+    tiles.publish(*reinterpret_cast<typename Tiles::Planes *>(image + t * (int64_t)PlaneImage<NCHUNK>::kTileBytes), threadIdx.x);
+}
 
 // (va, ia) "better than" (vb, ib): higher score first, lower item id on ties (a total order -> deterministic)
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
@@ -254,8 +290,9 @@ struct TauTest<false> {  // the exact-fp32 chain: one v_mfma_f32_32x32x2_f32 (la
 //  layout, built once per call — instead of fetch + split + publish in every workgroup.  Bit-identical results, but no
 //  faster: 231.0 vs 229.5 us at d = 64, 437 vs 457 us at d = 128 (4096 users), +13 us at 128 users for the extra pass: the
 //  fetch and the publish were already hidden behind the other resident workgroup's product and filter.  Removed.)
-template <int NCHUNK, bool VEC, int CAP, bool SPLIT>
+template <int NCHUNK, bool VEC, int CAP, bool SPLIT, bool IMG = false>
 __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(const TopkParams p) {
+    static_assert(!IMG || (SPLIT && NCHUNK <= 2), "the plane image serves the split product at d <= 128");
     using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     __shared__ float l_val[4][32][CAP];
@@ -392,15 +429,25 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
         }
     };
     Tiles tiles;
+    const unsigned lds_it[2] = {(unsigned)(uintptr_t)&s_it[0], (unsigned)(uintptr_t)&s_it[1]};  // (LDS byte addresses: the DMA's destination)
     if (t_begin < t_end) {
-        tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
-        tiles.publish(s_it[0], tid);
+        if constexpr (IMG) {
+            PlaneImage<NCHUNK>::dma(p.image, t_begin, lds_it[0], tid, wave);
+            dma_drain();
+        } else {
+            tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
+            tiles.publish(s_it[0], tid);
+        }
     }
     __syncthreads();
     RBG_TOPK_LAP(0);
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
-        if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);  // in flight while this tile feeds the matrix core
+        if (t + 1 < t_end && !RBG_TOPK_DBG(4)) {
+            // tile t + 1 into the other buffer (last read before the previous barrier), in flight while this tile feeds the matrix core
+            if constexpr (IMG) PlaneImage<NCHUNK>::dma(p.image, t + 1, lds_it[buf ^ 1], tid, wave);
+            else tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
+        }
         RBG_TOPK_LAP(1);
         if (wave_live) {
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -412,7 +459,8 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
             if (!(RBG_TOPK_DBG(2) && acc[0] != 12345.678f)) filter_tile(acc, t * 32 + i);
         }
         RBG_TOPK_LAP(4);
-        if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
+        if constexpr (IMG) dma_drain();  // (this wave's requests have landed; the barrier makes that true of all four)
+        else if (t + 1 < t_end && !RBG_TOPK_DBG(4)) tiles.publish(s_it[buf ^ 1], tid);  // the other buffer was last read before the previous barrier
         RBG_TOPK_LAP(5);
         __syncthreads();
         if (opt_prio) __builtin_amdgcn_s_setprio(0);
@@ -444,9 +492,10 @@ __global__ __launch_bounds__(256, (CAP < 48 ? 3 : 1)) void score_topk_kernel(con
 // group maximum that is neither PAD nor a history item is <= the k-th best valid score overall, and with k << 32 it is
 // nearly as tight as the exact k-th best of the sample.  Same workgroup shape as the main pass (4 user tiles sharing the
 // item tiles of one split of the sample); topk_tau_kernel folds the splits and selects.
-template <int NCHUNK, bool VEC, bool SPLIT>
+template <int NCHUNK, bool VEC, bool SPLIT, bool IMG = false>
 __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, float *__restrict__ g_val,
                                                            int32_t *__restrict__ g_idx) {
+    static_assert(!IMG || (SPLIT && NCHUNK <= 2), "the plane image serves the split product at d <= 128");
     using Tiles = ItemTiles<NCHUNK, VEC, SPLIT>;
     __shared__ __attribute__((aligned(16))) ItemTileMem<NCHUNK, VEC, SPLIT> s_it[2];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
@@ -475,14 +524,23 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
     const int64_t t_begin = p.tile_lo + (int64_t)blockIdx.x * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     Tiles tiles;
+    const unsigned lds_it[2] = {(unsigned)(uintptr_t)&s_it[0], (unsigned)(uintptr_t)&s_it[1]};
     if (t_begin < t_end) {
-        tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
-        tiles.publish(s_it[0], tid);
+        if constexpr (IMG) {
+            PlaneImage<NCHUNK>::dma(p.image, t_begin, lds_it[0], tid, wave);
+            dma_drain();
+        } else {
+            tiles.fetch(p.I, p.d, p.n_items, p.d, t_begin, tid);
+            tiles.publish(s_it[0], tid);
+        }
     }
     __syncthreads();
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int buf = (int)(t - t_begin) & 1;
-        if (t + 1 < t_end) tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
+        if (t + 1 < t_end) {
+            if constexpr (IMG) PlaneImage<NCHUNK>::dma(p.image, t + 1, lds_it[buf ^ 1], tid, wave);
+            else tiles.fetch(p.I, p.d, p.n_items, p.d, t + 1, tid);
+        }
         if (wave_live) {
             const f32x16 acc = tile_product(buf);
             if (!RBG_TOPK_DBG(16)) __builtin_amdgcn_s_setprio(2);
@@ -497,7 +555,8 @@ __global__ __launch_bounds__(256) void topk_prepass_kernel(const TopkParams p, f
                 }
             });
         }
-        if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);
+        if constexpr (IMG) dma_drain();
+        else if (t + 1 < t_end) tiles.publish(s_it[buf ^ 1], tid);
         __syncthreads();
         if (!RBG_TOPK_DBG(16)) __builtin_amdgcn_s_setprio(0);
     }
@@ -672,6 +731,12 @@ static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s)
     constexpr bool kSplitFits = !(NCHUNK == 4 && CAP > 48);
     const bool split = kSplitFits && opt_mfma_split() != 0;
     if constexpr (kSplitFits) {
+        if constexpr (NCHUNK <= 2) {
+            if (split && p.image) {
+                hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP, true, true>), grid, dim3(256), 0, s, p);
+                return;
+            }
+        }
         if (vec && split) {
             hipLaunchKernelGGL((score_topk_kernel<NCHUNK, true, CAP, true>), grid, dim3(256), 0, s, p);
             return;
@@ -690,6 +755,12 @@ static void launch_topk(const TopkParams &p, bool vec, dim3 grid, hipStream_t s)
 template <int NCHUNK>
 static void launch_prepass(const TopkParams &p, bool vec, dim3 grid, float *gv, int32_t *gi, hipStream_t s) {
     const bool split = opt_mfma_split() != 0 && !(NCHUNK == 4 && p.k > 16);  // the same product as the main pass (launch_topk)
+    if constexpr (NCHUNK <= 2) {
+        if (split && p.image) {
+            hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true, true, true>), grid, dim3(256), 0, s, p, gv, gi);
+            return;
+        }
+    }
     if (vec && split)
         hipLaunchKernelGGL((topk_prepass_kernel<NCHUNK, true, true>), grid, dim3(256), 0, s, p, gv, gi);
     else if (vec)
@@ -723,7 +794,8 @@ static bool topk_short_lists(int k, int d, int64_t B) {
 
 static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t s) {
     if (topk_short_lists(p.k, p.d, p.B)) {
-        if (vec) hipLaunchKernelGGL((score_topk_kernel<1, true, 24, true>), grid, dim3(256), 0, s, p);
+        if (p.image) hipLaunchKernelGGL((score_topk_kernel<1, true, 24, true, true>), grid, dim3(256), 0, s, p);
+        else if (vec) hipLaunchKernelGGL((score_topk_kernel<1, true, 24, true>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((score_topk_kernel<1, false, 24, true>), grid, dim3(256), 0, s, p);
         return;
     }
@@ -736,7 +808,9 @@ static void launch_topk_d(const TopkParams &p, bool vec, dim3 grid, hipStream_t 
 struct TopkLayout {
     int tpc, nc, max_splits, splits, tpc_s;
     int64_t n_tiles, sample_tiles, main_lists, bytes;
+    int64_t image_off, image_bytes;  // the plane image (sized for d <= 128; 0 when it would pass kImageCap: the per-workgroup fetch then)
 };
+constexpr int64_t kImageCap = 1ll << 30;
 static TopkLayout topk_layout(int64_t B, int64_t n_items, int64_t want_blocks) {
     TopkLayout L{};
     L.n_tiles = (n_items + 31) / 32;
@@ -751,6 +825,10 @@ static TopkLayout topk_layout(int64_t B, int64_t n_items, int64_t want_blocks) {
     L.tpc_s = tpc_s;
     L.splits = splits;
     L.bytes = L.main_lists * (kListStride * 8 + 4) + B * (int64_t)L.max_splits * 32 * 8 + B * 4 + 256;
+    L.image_off = (L.bytes + 255) / 256 * 256;
+    L.image_bytes = L.n_tiles * (int64_t)PlaneImage<2>::kTileBytes;
+    if (L.image_bytes > kImageCap) L.image_bytes = 0;
+    if (L.image_bytes) L.bytes = L.image_off + L.image_bytes;
     return L;
 }
 
@@ -808,6 +886,22 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     hipStream_t s = (hipStream_t)stream;
     const unsigned merge_blocks = (unsigned)((B + 3) / 4);
     const bool prepass = L.n_tiles > 2 * L.sample_tiles;  // small item sets: one pass
+    // r06: the item table as bf16 planes in the LDS layout, once per call (both passes take their tiles from it by LDS-DMA)
+    // (measured, profiles/r06_topk_image.jsonl, 4096 users x 40 982 items: d = 128 429.7 -> 393.7 us per call; d = 64 191.5 -> 192.0 —
+    // there the fetch and the split were already hidden behind the other resident workgroups' products, as r02 had found: the image
+    // is built for 64 < d <= 128 only; option "topk_image" = 2 forces it at d <= 64 as well)
+    if (opt_topk_image() && opt_mfma_split() != 0 && d <= 128 && (d > 64 || opt_topk_image() == 2) && L.image_bytes && B >= 1024) {
+        char *image = w + L.image_off;
+        if (d <= 64) {
+            if (vec) hipLaunchKernelGGL((topk_image_kernel<1, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+            else hipLaunchKernelGGL((topk_image_kernel<1, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+        } else {
+            if (vec) hipLaunchKernelGGL((topk_image_kernel<2, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+            else hipLaunchKernelGGL((topk_image_kernel<2, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+        }
+        RBG_HIP(hipGetLastError());
+        p.image = image;
+    }
     if (prepass) {
         // pass 1: group maxima over the first "topk_sample" (default 8192) items -> tau0[b], a lower bound of the user's k-th best valid score
         p.k = k;
