@@ -1200,6 +1200,13 @@ class RcclShard:
     def _stream(self):
         return self._lib.c_vp(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def status(self):
+        """"fused: <plan status>" (one handle over [owned | halo], one launch per layer) or "two handles: interior ..., halo ..."."""
+        import ctypes
+        buf = ctypes.create_string_buffer(512)
+        self._lib.check(self._lib.lib.rbg_shard_status(self._shard, buf, 512))
+        return buf.value.decode()
+
     def spmm(self, x, out=None):
         out = torch.empty_like(x) if out is None else out
         self._lib.check(self._lib.lib.rbg_spmm_sharded_f32(self._shard, self._lib.c_vp(x.data_ptr()), self._lib.c_vp(out.data_ptr()),

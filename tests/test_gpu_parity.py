@@ -1757,6 +1757,33 @@ def test_full_sort_topk_short_lists(rbg, cuda, golden):
         rbg.set_option("topk_short_lists", 3)
 
 
+def test_full_sort_topk_plane_image(rbg, cuda, golden):
+    """r06, option "topk_image": the item table split once per call into bf16 planes in the LDS layout, tiles taken by LDS-DMA in
+    the pre-pass and the main pass — the same planes and products as the per-workgroup fetch + split: identical output bit for
+    bit (d = 128 by default from 1024 users; forced at d = 64 and d = 33 (ragged rows) with option value 2; history masks,
+    repeated users, an item count that is not a multiple of the tile), and equal to the reference top-k."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    cases = [(h, randn((nu, 128), 5, cuda), randn((ni, 128), 6, cuda), torch.from_numpy(np.random.default_rng(1).integers(0, nu, 1100)).to(cuda), 10),
+             (None, randn((3000, 64), 7, cuda), randn((40_991, 64), 8, cuda), torch.arange(2999, -1, -1, device=cuda), 12),
+             (None, randn((300, 33), 9, cuda), randn((5003, 33), 10, cuda), torch.arange(300, device=cuda).repeat(8), 20),
+             (None, randn((1500, 100), 11, cuda), randn((20_000, 100), 12, cuda), torch.arange(1500, device=cuda), 3)]
+    try:
+        for hist, ua, it, users, k in cases:
+            out = {}
+            for mode in (0, 2):
+                rbg.set_option("topk_image", mode)
+                out[mode] = rbg.full_sort_topk(hist, ua, it, users, k)
+            assert torch.equal(out[0][1], out[2][1]) and torch.equal(out[0][0], out[2][0])
+        hist, ua, it, users, k = cases[0]
+        scores, (rv, ri) = reference_topk(ua.cpu(), it.cpu(), users.cpu(), k, g["uid"], g["iid"])
+        rbg.set_option("topk_image", 1)  # the default: on at d = 128
+        close(rbg.full_sort_topk(hist, ua, it, users, k)[0], rv.float(), tol=2e-5)
+    finally:
+        rbg.set_option("topk_image", 1)
+
+
 def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])

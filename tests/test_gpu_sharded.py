@@ -355,8 +355,20 @@ def _cabi_world1_worker(uid, iid, nu, ni, k_layers, d, out_q):
     one = shard.forward(x, 1)
     torch.cuda.synchronize()
     err1 = float(np.abs(one.cpu().numpy() - (e0 + ref_layer) / 2).max())
+    status = shard.status()
     shard.close()
-    out_q.put((err_layer, errs, err1))
+    # r06: the same shard as TWO handles (option "shard_fused" = 0 at creation): interior product + halo accumulate, both planned
+    rbg.set_option("shard_fused", 0)
+    try:
+        pair = sh.RcclShard(plan, sh.comm_unique_id(), dev, nranks=1, rank=0, d_max=d)
+    finally:
+        rbg.set_option("shard_fused", 1)
+    got2 = pair.forward(x, k_layers)
+    torch.cuda.synchronize()
+    err_pair = float(np.abs(got2.cpu().numpy() - ref).max())
+    status2 = pair.status()
+    pair.close()
+    out_q.put((err_layer, errs, err1, status, err_pair, status2))
 
 
 def test_c_abi_sharded_path_on_a_one_rank_communicator(ref_inter):
@@ -365,10 +377,12 @@ def test_c_abi_sharded_path_on_a_one_rank_communicator(ref_inter):
     q = ctx.Queue()
     p = ctx.Process(target=_cabi_world1_worker, args=(uid, iid, nu, ni, 3, 64, q))
     p.start()
-    err_layer, errs, err1 = q.get(timeout=600)
+    err_layer, errs, err1, status, err_pair, status2 = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
     assert err_layer <= 1e-5 and max(errs) <= 1e-5 and err1 <= 1e-5, (err_layer, errs, err1)
+    assert status == "fused: planned", status  # r06: [interior | halo] as ONE planned handle, one launch per layer
+    assert err_pair <= 1e-5 and status2 == "two handles: interior planned, halo planned", (err_pair, status2)
 
 
 # ---- round 3: the sharded training step through the HIP backend ------------------------------------------------------------------
