@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins a gloo group, rank 0 prints {\"launch_check\": world} (no GPU needed)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the other scaling mode's measurement")
+    ap.add_argument("--halo-push", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: also time the propagation with the halo PUSHED into the peers' exported tables (no collective; "
+                         "sharded.PushExchange).  auto = only when the ranks share GPUs (the configuration the tests cover): between "
+                         "different GPUs it has never run, and a faulting peer mapping would cost the run its JSON line")
     ap.add_argument("--transport", choices=["nccl", "staged"], default=None,
                     help="N>1 halo transport: RCCL all_to_all (default) or host-staged gloo send/recv (self-test: lets "
                          "several ranks share one GPU)")
@@ -906,7 +910,7 @@ def main():
                 transport = "staged"
                 prop = sh.ShardedPropagation(plan, sh.HipBackend(dev), group=gloo_group, transport="staged")
         if transport == "nccl":  # pick the stream structure on the real group: both are timed, the faster is kept
-            extra["overlap_autotune"] = prop.autotune(e0, k_layers)
+            extra["overlap_autotune"] = prop.autotune(e0, k_layers, try_push=(args.halo_push == "on"))
 
         def step():
             prop.forward(e0, k_layers)
@@ -1075,6 +1079,9 @@ def main():
         # every rank tries, a failure anywhere is voted on, so nobody waits on a peer that gave up.
         try:
             pp, perr = None, None
+            shared_gpus = torch.cuda.device_count() < world
+            if args.halo_push == "off" or (args.halo_push == "auto" and not shared_gpus):
+                raise RuntimeError("not requested (--halo-push on): untested between different GPUs")
             try:
                 if k_layers + 1 > 9 or not prop.fused:
                     raise RuntimeError("push serves the fused layer")

@@ -939,10 +939,11 @@ class ShardedPropagation:
                 x = x + g  # a fresh tensor: the ping-pong buffer is free again
         return x / float(n_layers + 1)
 
-    def autotune(self, e0, n_layers, iters=10, try_push=True):
+    def autotune(self, e0, n_layers, iters=10, try_push=False):
         """nccl transport, N > 1: time a few propagations with each stream structure on the real group — and (r06) with the halo
-        PUSH that needs no collective — take the MAX over ranks, keep the fastest on every rank.  Returns the record it also
-        stores in ``self.tuned``."""
+        PUSH that needs no collective when ``try_push`` is set — take the MAX over ranks, keep the fastest on every rank.  Returns
+        the record it also stores in ``self.tuned``.  (``try_push`` is opt-in: the push has only ever run between processes that
+        share ONE GPU; a flag word that never arrives is caught by a time-out, a peer mapping that faults is not.)"""
         if not (self.transport == "nccl" and self.plan.world > 1 and e0.device.type == "cuda"):
             return None
         res = {}
