@@ -563,8 +563,13 @@ class ShardedPropagation:
         self.overlap = False
         self.set_overlap(overlap)
         if self.fused:
-            _ = self.g_cat
-        else:
+            # a table the planner cannot address (n_cols x d x 4 bytes beyond 32-bit offsets: config #5's shards) would put EVERY
+            # entry on the binned kernel; the two-handle form keeps the interior block on the column-slab kernel (the r05 state)
+            g = self.g_cat
+            if transport != "push" and hasattr(g, "sell_status") and g.sell_status() != "planned":
+                self._want_fused, self._g_cat = False, None
+                del g
+        if not self.fused:
             _ = self.g_int, self.g_halo
         self._n_send = len(plan.send_idx)
         self._buf_d = None  # per-width buffers, allocated on first use: halo, send, ping-pong outputs
