@@ -133,6 +133,14 @@ class _FusedStep:
         """What else a captured step has baked in (NCL: whether the prototype term is part of the loss)."""
         return ()
 
+    def _side_stream(self, dev):
+        """ONE side stream per stepper for the eager steps beside a captured graph (warm-up, an epoch's short last batch) — a fresh
+        stream per such batch was a stream creation per epoch and model."""
+        st = getattr(self, "_eager_side", None)
+        if st is None:  # (a stepper lives on one device)
+            st = self._eager_side = torch.cuda.Stream(device=dev)
+        return st
+
     @torch.no_grad()
     def step(self, interaction):
         """One optimisation step on a batch of (user, pos item, neg item) triples; returns the loss (device scalar)."""
@@ -158,7 +166,7 @@ class _FusedStep:
             # third call could be the epoch's short last batch; the graph would then have been captured for the odd size and every
             # full batch would have run eagerly for ever) — run eagerly on a side stream; the capture waits for a full batch
             if self._calls <= 2 or user.shape[0] < self._full:
-                side = torch.cuda.Stream(device=dev)
+                side = self._side_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     self._enqueue(user, pos, neg)
@@ -171,7 +179,7 @@ class _FusedStep:
             with torch.cuda.graph(self._graph):
                 self._enqueue(*self._static)
         if user.shape != self._static[0].shape:  # (an epoch's last, shorter batch: the same launches, not replayed —
-            side = torch.cuda.Stream(device=dev)  # on a side stream like the warm-up steps: its scratch is not the graph's)
+            side = self._side_stream(dev)  # on a side stream like the warm-up steps: its scratch is not the graph's)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 self._enqueue(user, pos, neg)
