@@ -646,3 +646,48 @@ def test_score_uniform_phase_store_stream(rbg, cuda):
     finally:
         rbg.set_option("score_tiles", 0)
         rbg.set_option("score_uniform", 1)
+
+
+def test_attached_plan_with_wide_rows_is_validated_and_runs(rbg, cuda):
+    """r06 header format: a wide row is U consecutive units at the front of its class, unit j of U.  rbg_graph_attach_sell (the
+    specification's arrays) counts them, checks every unit's (j, U) against its row's first unit and the class's wide range, and
+    the attached plan then runs like the native one; a plan with a wrong index / count / a wide unit behind a narrow one is refused."""
+    import ctypes
+    import sell_spec as sell
+    hub = 5000
+    nu, ni = 300, hub + 50
+    u = np.concatenate([np.full(hub, 1), np.full(2500, 2), np.arange(3000) % (nu - 3) + 3]).astype(np.int64)
+    i = np.concatenate([np.arange(hub) + 1, np.arange(2500) * 2 + 1, (np.arange(3000) * 7919) % (ni - 1) + 1]).astype(np.int64)
+    key = np.unique(u * ni + i)
+    u, i = key // ni, key % ni
+    rbg.set_option("sell_auto", 0)
+    try:
+        h = rbg.GraphHandle.from_interactions(u, i, nu, ni, device=cuda)
+    finally:
+        rbg.set_option("sell_auto", 1)
+    lib, vp = rbg._lib.lib, ctypes.c_void_p
+    plan = sell.build_plan(*h.device_csr(), nu, ni, W=32)
+    head = plan["head"]
+    wide = ((head[:, 3] >> 16) & 1).bool()
+    assert int(wide.sum()) >= 5 + 3          # user 1: ceil(5000 / 1024) = 5 units, user 2: 3
+
+    def attach(hd):
+        ub, nun = (ctypes.c_int32 * 2)(*plan["unit_base"]), (ctypes.c_int32 * 2)(*plan["n_units"])
+        return lib.rbg_graph_attach_sell(h.ptr, 32, vp(plan["ent"].data_ptr()), plan["n_ent"], vp(hd.data_ptr()), ub, nun, vp(plan["orig"].data_ptr()))
+
+    for field, delta in ((2, 1), (3, 1 << 17)):      # unit 1 of the first row: a wrong index j, a wrong count U
+        bad = head.clone()
+        bad[1, field] += delta
+        assert attach(bad) == rbg._lib.RBG_EINVAL and b"unit" in lib.rbg_last_error()
+    bad = head.clone()
+    bad[int(wide.sum()), 3] |= (1 << 16) | (1 << 17)  # a "wide" unit behind the class's wide range
+    assert attach(bad) == rbg._lib.RBG_EINVAL
+    bad = head.clone()
+    bad[0, 3] &= ~(1 << 16)                           # the first unit of a wide row loses its flag: the row's other units point at it
+    assert attach(bad) == rbg._lib.RBG_EINVAL
+    assert attach(head) == 0 and h.has_sell(64) and h.sell_status() == "attached"
+    x = randn((nu + ni, 64), 3, cuda)
+    rp, cl, vl = C.build_norm_csr(u, i, nu, ni)
+    close(rbg.ops.spmm_raw(h, x), O.conv_csr_f64(x.cpu().numpy().astype(np.float64), rp, cl, vl))
+    native = rbg.GraphHandle.from_interactions(u, i, nu, ni, device=cuda)
+    assert torch.equal(rbg.ops.spmm_raw(h, x), rbg.ops.spmm_raw(native, x))  # the same plan, the same bits
