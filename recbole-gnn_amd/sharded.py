@@ -562,6 +562,8 @@ class ShardedPropagation:
         self.comm_stream, self._comm_h, self._ctx = None, None, None
         self.overlap = False
         self.set_overlap(overlap)
+        if self._want_fused and transport != "push" and (plan.n_owned + plan.n_halo) * 256 >= 0x7ffffff0:
+            self._want_fused = False  # (config #5's shards: beyond the rectangular plan's 32-bit row offsets — not even tried)
         if self.fused:
             # a table the planner cannot address (n_cols x d x 4 bytes beyond 32-bit offsets: config #5's shards) would put EVERY
             # entry on the binned kernel; the two-handle form keeps the interior block on the column-slab kernel (the r05 state)
