@@ -135,6 +135,24 @@ class ShardPlan:
         col[pos_h], val[pos_h] = np.asarray(hc, dtype=np.int64) + n, hv
         return rp, col, val
 
+    def cat_windows(self, window_rows):
+        """cat_csr() cut into COLUMN windows of at most ``window_rows`` table rows: [(row_lo, row_hi, (rowptr, col - row_lo, val))].
+        A rectangular plan addresses its table with 32-bit byte offsets (4 M rows at d = 128); config #5's 8-rank shards gather
+        a 15 M-row table, so their layer is one launch per window, the later ones accumulating into Y (r06)."""
+        rp, col, val = self.cat_csr()
+        n_cols = self.n_owned + self.n_halo
+        if n_cols <= window_rows:
+            return [(0, n_cols, (rp, col, val))]
+        rows = np.repeat(np.arange(self.n_owned), np.diff(rp))
+        out = []
+        for lo in range(0, n_cols, window_rows):
+            hi = min(lo + window_rows, n_cols)
+            m = (col >= lo) & (col < hi)
+            ptr = np.zeros(self.n_owned + 1, dtype=np.int64)
+            ptr[1:] = np.cumsum(np.bincount(rows[m], minlength=self.n_owned))
+            out.append((lo, hi, (ptr, (col[m] - lo).astype(np.int32), val[m])))
+        return out
+
 
 def _csr_from_sorted(rows_local, cols, vals, n_rows):
     rowptr = np.zeros(n_rows + 1, dtype=np.int64)
@@ -544,7 +562,8 @@ class ShardedPropagation:
         n_total = sum(int(c) for c in self.plan.recv_counts)
         return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
 
-    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None, push_tables=4, push_timeout_ms=2000):
+    def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None, push_tables=4, push_timeout_ms=2000,
+                 cat_window_rows=4_000_000):
         # overlap = None (default): off — unmeasured between real peers; ``autotune`` measures both forms on the actual group
         if overlap is None:
             overlap = False
@@ -562,15 +581,17 @@ class ShardedPropagation:
         self.comm_stream, self._comm_h, self._ctx = None, None, None
         self.overlap = False
         self.set_overlap(overlap)
-        if self._want_fused and transport != "push" and (plan.n_owned + plan.n_halo) * 256 >= 0x7ffffff0:
-            self._want_fused = False  # (config #5's shards: beyond the rectangular plan's 32-bit row offsets — not even tried)
+        # a rectangular plan addresses its table with 32-bit byte offsets (4.19 M rows at d = 128): a longer table — config #5's
+        # 8-rank shards gather 15 M rows — is cut into column windows, one planned handle and one launch each (r06)
+        self._cat_window_rows = int(cat_window_rows)
+        self._g_cats = None
         if self.fused:
-            # a table the planner cannot address (n_cols x d x 4 bytes beyond 32-bit offsets: config #5's shards) would put EVERY
-            # entry on the binned kernel; the two-handle form keeps the interior block on the column-slab kernel (the r05 state)
-            g = self.g_cat
-            if transport != "push" and hasattr(g, "sell_status") and g.sell_status() != "planned":
-                self._want_fused, self._g_cat = False, None
-                del g
+            # blocks the planner does not serve (no two row classes, ...) would put EVERY entry on the binned kernel; the two-handle
+            # form keeps at least the interior block on the column-slab kernel (the r05 state)
+            gs = self.g_cats
+            if transport != "push" and any(hasattr(g, "sell_status") and g.sell_status() != "planned" for _, _, g in gs):
+                self._want_fused, self._g_cat, self._g_cats = False, None, None
+            del gs
         if not self.fused:
             _ = self.g_int, self.g_halo
         self._n_send = len(plan.send_idx)
@@ -603,16 +624,27 @@ class ShardedPropagation:
         return self._g_halo
 
     @property
+    def g_cats(self):
+        """[(row_lo, row_hi, handle)]: the [interior | halo] block per column window of the layer table (one window unless the
+        table is beyond the rectangular plan's 32-bit offsets)."""
+        if self._g_cats is None:
+            if self._g_cat is not None:  # (a handle handed over by a sibling propagation of the same plan)
+                self._g_cats = [(0, self.plan.n_owned + self.plan.n_halo, self._g_cat)]
+            else:
+                self._g_cats = [(lo, hi, self._make_graph(csr, hi - lo)) for lo, hi, csr in self.plan.cat_windows(self._cat_window_rows)]
+                self._g_cat = self._g_cats[0][2]
+        return self._g_cats
+
+    @property
     def g_cat(self):
-        if self._g_cat is None:
-            self._g_cat = self._make_graph(self.plan.cat_csr(), self.plan.n_owned + self.plan.n_halo)
-        return self._g_cat
+        return self.g_cats[0][2]
 
     def kernel_status(self):
         """What the handles of the active form run: {"form", "cat" | "interior" / "halo": plan status} (HIP backend)."""
         st = lambda g: g.sell_status() if (g is not None and hasattr(g, "sell_status")) else None  # noqa: E731
         if self.fused:
-            return {"form": "fused", "cat": st(self.g_cat)}
+            gs = self.g_cats
+            return {"form": "fused", "cat": st(gs[0][2])} if len(gs) == 1 else {"form": "fused", "cat": [st(g) for _, _, g in gs], "windows": len(gs)}
         return {"form": "two handles", "interior": st(self.g_int), "halo": st(self.g_halo)}
 
     def set_overlap(self, overlap):
@@ -786,17 +818,25 @@ class ShardedPropagation:
         else:
             self._exchange_staged(xcat[:n], tail)
         pushed = self.transport == "push" and halo_rows is None
+        wins = self.g_cats
+        if out is not None:
+            y = out
+        elif x.device.type == "cuda":
+            y = next(c for c in self._cat if c.data_ptr() != xcat.data_ptr())[:n]
+        else:
+            y = torch.empty((n, d), dtype=x.dtype)
+        for w, (lo, hi, g) in enumerate(wins[:-1]):  # (column windows of a table beyond 32-bit offsets: the later ones accumulate)
+            self.backend.spmm(g, xcat[lo:hi], y, w > 0, **kw)
+        lo, hi, g = wins[-1]
         if finish is not None:
             srcs, mean_out = finish
-            res = self.backend.spmm_mean(self.g_cat, xcat, None, srcs, mean_out, **kw)
+            if hasattr(self.backend, "spmm_mean"):
+                res = self.backend.spmm_mean(g, xcat[lo:hi], y if len(wins) > 1 else None, srcs, mean_out, **kw)
+            else:  # injected CPU backend (tests)
+                self.backend.spmm(g, xcat[lo:hi], y, len(wins) > 1)
+                res = mean_out.copy_((sum(srcs) + y) / float(len(srcs) + 1))
         else:
-            if out is not None:
-                y = out
-            elif x.device.type == "cuda":
-                y = next(c for c in self._cat if c.data_ptr() != xcat.data_ptr())[:n]
-            else:
-                y = torch.empty((n, d), dtype=x.dtype)
-            res = self.backend.spmm(self.g_cat, xcat, y, False, **kw)
+            res = self.backend.spmm(g, xcat[lo:hi], y, len(wins) > 1, **kw)
         if pushed:
             self.push.consumed(pk, main_h)  # the table's senders may overwrite its tail from here on (stream order)
         return res

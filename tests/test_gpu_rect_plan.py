@@ -85,7 +85,7 @@ def test_halo_block_alone_is_planned(rbg, cuda):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "windows"])
 def test_virtual_ranks_on_one_gpu_equal_the_single_graph_forward(rbg, cuda, world, fused):
     """P ShardedPropagation objects in ONE process; the exchange is played by indexing the assembled global layer
     (``halo_rows``), so every launch of the fused (or two-handle) layer runs as on P GPUs.  3 layers + mean."""
@@ -93,11 +93,16 @@ def test_virtual_ranks_on_one_gpu_equal_the_single_graph_forward(rbg, cuda, worl
     sh = rbg.sharded
     d, K = 64, 3
     be = sh.HipBackend(cuda)
-    props = [sh.ShardedPropagation(plans[p], be, transport="staged", fused=fused) for p in range(world)]
+    # "windows": the layer table cut into column windows of ~ a third (what a table beyond 32-bit offsets gets): 3+ launches per layer
+    kw = {"cat_window_rows": (plans[0].n_owned + plans[0].n_halo) // 3} if fused == "windows" else {}
+    props = [sh.ShardedPropagation(plans[p], be, transport="staged", fused=bool(fused), **kw) for p in range(world)]
     for pr in props:
         st = pr.kernel_status()
         assert st["form"] == ("fused" if fused else "two handles")
-        assert all(v == "planned" for k, v in st.items() if k != "form" and v is not None), st
+        if fused == "windows":
+            assert st["windows"] >= 3 and all(v == "planned" for v in st["cat"]), st
+        else:
+            assert all(v == "planned" for k, v in st.items() if k != "form" and v is not None), st
     e0 = np.random.default_rng(11).standard_normal((nu + ni, d)).astype(np.float32)
     rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
     ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], K)

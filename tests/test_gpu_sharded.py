@@ -757,6 +757,11 @@ def _push_worker(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
         x0 = torch.from_numpy(e0[plan.owned]).to(dev)
         staged = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="staged")
         want = staged.forward(x0, k_layers).clone()
+        # the same forward with the layer table cut into three column windows (a table beyond 32-bit offsets): 3 launches per layer,
+        # the mean rides in the last one with the accumulated partial
+        windowed = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="staged", cat_window_rows=(plan.n_owned + plan.n_halo) // 3)
+        err_win = float((windowed.forward(x0, k_layers) - want).abs().max())
+        n_win = len(windowed.g_cats)
         push = sh.ShardedPropagation(plan, sh.HipBackend(dev), transport="push", push_tables=k_layers + 1)
         outs = []
         for _ in range(3):  # the tables and flag words are reused: three propagations back to back, no host synchronisation between
@@ -770,7 +775,7 @@ def _push_worker(rank, world, port, uid, iid, nu, ni, k_layers, d, out_q):
         rowptr, col, val = C.build_norm_csr(uid, iid, nu, ni)
         ref = C.lightgcn_forward(rowptr, col, val, e0[:nu], e0[nu:], k_layers)
         err = float(np.abs(outs[-1].cpu().numpy() - ref[plan.owned]).max())
-        res = (rank, bit_equal, bool(torch.equal(y_s, y_p)), bool(torch.equal(g_s, g_p)), err, push.kernel_status())
+        res = (rank, bit_equal, bool(torch.equal(y_s, y_p)), bool(torch.equal(g_s, g_p)), err, push.kernel_status(), err_win, n_win)
         gathered = [None] * world
         dist.all_gather_object(gathered, res)
         push.push.close()
@@ -802,6 +807,7 @@ def test_halo_push_between_processes_on_one_gpu(ref_inter, world):
                 p.kill()
     for p in procs:
         assert p.exitcode == 0
-    for rank, fwd_equal, layer_equal, bwd_equal, err, status in res:
+    for rank, fwd_equal, layer_equal, bwd_equal, err, status, err_win, n_win in res:
         assert fwd_equal and layer_equal and bwd_equal, (rank, fwd_equal, layer_equal, bwd_equal)
         assert err <= 1e-5 and status["form"] == "fused", (rank, err, status)
+        assert n_win >= 3 and err_win <= 2e-6, (rank, n_win, err_win)

@@ -577,3 +577,11 @@ def test_fused_block_equals_the_two_handle_form(rbg, ref_inter, world):
         y1 = fused.spmm(xo, halo_rows=halo).numpy()
         y2 = pair.spmm(xo, halo_rows=halo).numpy()
         assert np.abs(y1 - y_ref[plan.owned]).max() <= 1e-5 and np.abs(y2 - y_ref[plan.owned]).max() <= 1e-5
+        # column windows (a table beyond the rectangular plan's 32-bit offsets: config #5's shards): the same rows from 3+ launches
+        wins = plan.cat_windows(max((plan.n_owned + plan.n_halo) // 3, 1))
+        assert len(wins) >= 3 and wins[0][0] == 0 and wins[-1][1] == plan.n_owned + plan.n_halo
+        assert sum(len(w[2][1]) for w in wins) == rp[-1] and all(a[1] == b_[0] for a, b_ in zip(wins, wins[1:]))
+        windowed = sh.ShardedPropagation(plan, be, transport="staged", fused=True, cat_window_rows=max((plan.n_owned + plan.n_halo) // 3, 1))
+        assert windowed.fused == (plan.n_halo > 0) and (len(windowed.g_cats) >= 3 or plan.n_halo == 0)
+        y3 = windowed.spmm(xo, halo_rows=halo).numpy()
+        assert np.abs(y3 - y_ref[plan.owned]).max() <= 1e-5
