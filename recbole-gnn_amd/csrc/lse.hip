@@ -73,7 +73,7 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // split into three bf16 terms (mfma_common.h: the accuracy of the fp32 chain, 24 x 32 instead of 32 x 64 cycles per
 // 64 k); the oth tile is then published as three bf16 planes, and — for the gradients, whose second product reads the
 // tile as fp32 columns — as the fp32 tile too.
-template <int NC, bool GRAD, bool VEC, bool SPLIT>
+template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
@@ -86,8 +86,12 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     // (r03) the gradients' second product reads the tile by COLUMN (8 oth rows of one feature column per lane): a transposed
     // copy of the planes [plane][column][row], row stride 36 bf16 (8-byte aligned, 18 dwords: b64 reads of 32 columns land in
     // 32 different bank pairs), makes a B fragment two 8-byte reads instead of eight 2-byte reads plus their packing
+    // r06: the transposed copy is gone — gfx950's LDS transpose read (ds_read_b64_tr_b16) takes the second product's B fragments
+    // straight out of the row-major planes: a 16-lane group reads a [4 rows][16 columns] block (each lane supplies the address of
+    // one 8-byte piece of it) and every lane receives its column's four rows.  Saves the 24 two-byte, 4-way bank-conflicted LDS
+    // stores per thread and tile of the transposed publish and 27.6 KB of LDS per workgroup (option "lse_tr_read" = 0 keeps the copy).
     constexpr int LDT = 36;
-    constexpr bool kPlT = SPLIT && GRAD;
+    constexpr bool kPlT = SPLIT && GRAD && !TRR;
     __shared__ __attribute__((aligned(16))) __bf16 s_plt[kPlT ? 2 : 1][3][kPlT ? NC * 64 : 1][kPlT ? LDT : 4];
     __shared__ float s_coef[2][32];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
@@ -233,9 +237,21 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
                         // rows rowmap(8 u + j, h), j = 0..7 = 16 u + 4 h + {0..3} and 16 u + 8 + 4 h + {0..3}: two runs of the transposed planes
                         bf16x8 bh, bm, bl;
                         auto col8 = [&](const int pl) __attribute__((always_inline)) {
-                            const __bf16 *src = &s_plt[buf][pl][q * 32 + i][16 * u + 4 * h];
-                            const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(src), hi = *reinterpret_cast<const bf16x4 *>(src + 8);
-                            return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            if constexpr (TRR) {
+                                // lane t of a 16-lane group addresses piece (row t / 4, columns 4 (t % 4) ..) of the block
+                                // [rows 16 u + 4 h (+ 8) .. + 3][columns q 32 + 16 (i / 16) .. + 15]; it receives column q 32 + i, rows .. + 3
+                                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                                const int t = lane & 15;
+                                const __bf16 *src = &s_pl[buf][pl][16 * u + 4 * h + (t >> 2)][q * 32 + (i & 16) + 4 * (t & 3)];
+                                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(src + 8 * LDH));
+                                const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+                                return (bf16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                            } else {
+                                const __bf16 *src = &s_plt[buf][pl][q * 32 + i][16 * u + 4 * h];
+                                const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(src), hi = *reinterpret_cast<const bf16x4 *>(src + 8);
+                                return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            }
                         };
                         bh = col8(0), bm = col8(1), bl = col8(2);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh, g[q], 0, 0, 0);
@@ -387,6 +403,13 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     p.blocks_per_xcd = (p.total_blocks + 7) / 8;
     dim3 grid((unsigned)(p.blocks_per_xcd * 8));
     const bool split = opt_mfma_split() != 0;
+    if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
+        if (split && opt_lse_tr_read()) {
+            if (vec) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((lse_tile_kernel<NC, true, false, true, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
+    }
     if (vec && split)
         hipLaunchKernelGGL((lse_tile_kernel<NC, GRAD, true, true>), grid, dim3(256), 0, s, p);
     else if (vec)
