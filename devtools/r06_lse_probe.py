@@ -1,4 +1,4 @@
-"""r06: rbg_infonce_f32 with gradients, LDS transpose reads (option "lse_tr_read") on / off: us per forward + backward and
+"""r06: rbg_infonce_f32 with gradients: transposed tile copy (tr0) / LDS transpose reads (tr1) / + plane images by LDS-DMA (tr2): us per forward + backward and
 bit-identity of loss and gradients (2048 batch rows against 40 982 / 29 858 table rows, d = 64; 91 600 rows at d = 128)."""
 import json, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +13,9 @@ for n, d in ((40982, 64), (29858, 64), (91600, 128)):
     idx = torch.randint(1, n, (B,), generator=g).to(dev)
     rec = {"n": n, "d": d}
     res = {}
-    for mode in (0, 1, 0, 1):
-        rbg.set_option("lse_tr_read", mode)
+    for mode in (0, 1, 2, 0, 1, 2):   # 0: transposed copy; 1: LDS transpose reads; 2: + plane images taken by LDS-DMA
+        rbg.set_option("lse_tr_read", 1 if mode else 0)
+        rbg.set_option("lse_image", 1 if mode == 2 else 0)
         def step():
             t1.grad = t2.grad = None
             loss = rbg.ops.info_nce(t1, t2, idx, 0.2)
@@ -32,7 +33,8 @@ for n, d in ((40982, 64), (29858, 64), (91600, 128)):
         rec.setdefault(f"tr{mode}_us", []).append(round(sorted(ts)[2], 1))
         loss = step()
         res[mode] = (loss.detach().clone(), t1.grad.clone(), t2.grad.clone())
-    rec["bit_identical"] = all(bool(torch.equal(a, b)) for a, b in zip(res[0], res[1]))
-    rec["max_grad_diff"] = max(float((a - b).abs().max()) for a, b in zip(res[0][1:], res[1][1:]))
+    rec["bit_identical"] = all(bool(torch.equal(a, b)) for m in (1, 2) for a, b in zip(res[0], res[m]))
+    rec["max_grad_diff"] = max(float((a - b).abs().max()) for m in (1, 2) for a, b in zip(res[0][1:], res[m][1:]))
     print(json.dumps(rec), flush=True)
 rbg.set_option("lse_tr_read", 1)
+rbg.set_option("lse_image", 0)

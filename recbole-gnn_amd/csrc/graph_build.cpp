@@ -54,6 +54,8 @@ static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 static std::atomic<int> g_lse_tr_read{1};
 int opt_lse_tr_read() { return g_lse_tr_read.load(); }
+static std::atomic<int> g_lse_image{0};  // (measured neutral to slightly slower, profiles/r06_lse_image.jsonl: off)
+int opt_lse_image() { return g_lse_image.load(); }
 static std::atomic<int> g_sell_c16{1};
 int opt_sell_c16() { return g_sell_c16.load(); }
 static std::atomic<int> g_deterministic{0};
@@ -522,6 +524,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_shard_single_stream = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "lse_image")) {
+        g_lse_image = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "lse_tr_read")) {
         g_lse_tr_read = value ? 1 : 0;
         return RBG_OK;
@@ -616,6 +622,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "nt_store")) {
         *value = g_nt_store.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "lse_image")) {
+        *value = g_lse_image.load();
         return RBG_OK;
     }
     if (!strcmp(key, "lse_tr_read")) {

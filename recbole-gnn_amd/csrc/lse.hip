@@ -28,6 +28,7 @@
 #include "internal.h"
 #include "mfma_common.h"
 #include "ordered.h"
+#include "plane_image.h"
 
 namespace rbg {
 
@@ -45,6 +46,7 @@ struct LseParams {
     float *den_out;         // gradients only, or NULL: [n_chunks][n_own] row sums of the weights (the forward's output) from the same pass
     int tiles_per_chunk, n_chunks;
     int64_t own_blocks, total_blocks, blocks_per_xcd;  // workgroup j = chunk * own_blocks + own_block, j < total_blocks
+    const char *oth_image;  // r06: `oth` as bf16 planes in the LDS layout (plane_image.h), taken by LDS-DMA; NULL: fetch + split per workgroup
 };
 
 template <int R>
@@ -73,8 +75,9 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // split into three bf16 terms (mfma_common.h: the accuracy of the fp32 chain, 24 x 32 instead of 32 x 64 cycles per
 // 64 k); the oth tile is then published as three bf16 planes, and — for the gradients, whose second product reads the
 // tile as fp32 columns — as the fp32 tile too.
-template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false>
+template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
+    static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
     // who reads s_oth: the exact-fp32 products.  (r03: with split operands the gradients' second product takes its B
@@ -284,6 +287,31 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
     // 40 982 / 29 858 table rows, 479 / 351 with the chunking re-tuned for three — the scratch traffic costs more than the third wave hides.
     // The transposed planes at stride 34 alone (two workgroups per CU): SQ_LDS_BANK_CONFLICT 11.8 M -> 3.9 M cycles per launch (the 2-byte
     // transposed stores of publish() are 4-way conflicted at stride 36), launch time unchanged (398 vs 395 us): not on the critical path.)
+    if constexpr (IMG) {
+        // r06: the oth tiles come from the plane image by LDS-DMA, one tile ahead; only the tile's 32 weights (gradient of the table
+        // side) still travel through registers
+        const unsigned lds_pl[2] = {(unsigned)(uintptr_t)&s_pl[0], (unsigned)(uintptr_t)&s_pl[1]};
+        auto coef_of = [&](const int64_t t) __attribute__((always_inline)) {
+            return (GRAD && p.coef_oth && tid < 32 && t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] : 0.f;
+        };
+        if (t0 < t1) {
+            PlaneImage<NC>::dma(p.oth_image, t0, lds_pl[0], tid, wave);
+            if (GRAD && p.coef_oth && tid < 32) s_coef[0][tid] = coef_of(t0);
+            dma_drain();
+        }
+        __syncthreads();
+        for (int64_t t = t0; t < t1; ++t) {
+            const int buf = (int)(t - t0) & 1;
+            if (t + 1 < t1) {
+                PlaneImage<NC>::dma(p.oth_image, t + 1, lds_pl[buf ^ 1], tid, wave);  // (the other buffer was last read before the previous barrier)
+                stage_coef = coef_of(t + 1);
+            }
+            if (wave_live) compute(buf, t);
+            if (GRAD && p.coef_oth && tid < 32 && t + 1 < t1) s_coef[buf ^ 1][tid] = stage_coef;
+            dma_drain();
+            __syncthreads();
+        }
+    } else {
     if (t0 < t1) {
         fetch(t0);
         publish(0);
@@ -296,6 +324,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC 
         if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
         if (t + 2 < t1) fetch(t + 2);
         __syncthreads();
+    }
     }
     if (!wave_live) return;
     if constexpr (!GRAD) {
@@ -405,7 +434,8 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     const bool split = opt_mfma_split() != 0;
     if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
         if (split && opt_lse_tr_read()) {
-            if (vec) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true>), grid, dim3(256), 0, s, p);
+            if (p.oth_image) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true>), grid, dim3(256), 0, s, p);
+            else if (vec) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((lse_tile_kernel<NC, true, false, true, true>), grid, dim3(256), 0, s, p);
             return;
         }
@@ -791,7 +821,11 @@ __global__ __launch_bounds__(256) void nce_table_back_parts_kernel(const float *
 
 struct NceLayout {
     int64_t off_C, off_inv2, off_A, off_inv1, off_pos, off_lse, off_gl, off_dA, off_dC, off_lse_ws, bytes;
+    int64_t off_imgC, off_imgA;  // r06: plane images of the normalised table and batch rows (d <= 128)
 };
+static int64_t nce_image_bytes(int64_t rows, int d) {
+    return (rows + 31) / 32 * (int64_t)(d <= 64 ? PlaneImage<1>::kTileBytes : PlaneImage<2>::kTileBytes);
+}
 static NceLayout nce_layout(int64_t B, int64_t n, int d) {
     auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
     NceLayout L{};
@@ -805,7 +839,9 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
     L.off_gl = o, o += up(B * 4);
     L.off_dA = o, o += up(B * d * 4);
     L.off_dC = o, o += up(n * d * 4);
-    L.off_lse_ws = o, o += lse_layout(B, n, d).bytes;
+    L.off_lse_ws = o, o += up(lse_layout(B, n, d).bytes);
+    L.off_imgC = o, o += up(nce_image_bytes(n, d));
+    L.off_imgA = o, o += up(nce_image_bytes(B, d));
     L.bytes = o + 256;
     return L;
 }
@@ -816,12 +852,26 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 // into the consumers of the chunk partials, which also absorb the chunk reductions: 8 launches per half instead of 13.
 static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
                            const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
-                           float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s) {
+                           float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr) {
     const LseLayout L = lse_layout(B, n, d);
     char *w = reinterpret_cast<char *>(lse_ws);
     float *coef = reinterpret_cast<float *>(w + L.off_coef), *part_q = reinterpret_cast<float *>(w + L.off_q);
     float *part_c = L.nc_c > 1 ? reinterpret_cast<float *>(w + L.off_c) : dC, *den = reinterpret_cast<float *>(w + L.off_den);
     const bool vec = lse_vec(A, d, C, d, d);
+    // r06: the normalised table and batch rows as plane images (plane_image.h), built once per call: both gradient passes take their
+    // oth tiles by LDS-DMA instead of fetching, splitting and publishing them in every workgroup
+    const bool img = imgC && imgA && d <= 128 && opt_mfma_split() != 0 && opt_lse_tr_read() && opt_lse_image();
+    if (img) {
+        const unsigned tc = (unsigned)((n + 31) / 32), ta = (unsigned)((B + 31) / 32);
+        if (d <= 64) {
+            hipLaunchKernelGGL((plane_image_kernel<1, false>), dim3(tc), dim3(256), 0, s, C, (int64_t)d, n, d, imgC);
+            hipLaunchKernelGGL((plane_image_kernel<1, false>), dim3(ta), dim3(256), 0, s, A, (int64_t)d, B, d, imgA);
+        } else {
+            hipLaunchKernelGGL((plane_image_kernel<2, false>), dim3(tc), dim3(256), 0, s, C, (int64_t)d, n, d, imgC);
+            hipLaunchKernelGGL((plane_image_kernel<2, false>), dim3(ta), dim3(256), 0, s, A, (int64_t)d, B, d, imgA);
+        }
+        RBG_HIP(hipGetLastError());
+    }
     LseParams p{};
     p.d = d;
     p.s2 = scale * kLog2e;
@@ -829,6 +879,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 1 (own = the batch rows): denominators' and gradient's partials per chunk
     p.own = A, p.ld_own = d, p.n_own = B;
     p.oth = C, p.ld_oth = d, p.n_oth = n;
+    p.oth_image = img ? imgC : nullptr;
     p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
     p.out = part_q;
     p.den_out = den;
@@ -842,6 +893,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 2 (own = the table rows): needs the finished denominators (coef)
     p.own = C, p.n_own = n;
     p.oth = A, p.n_oth = B;
+    p.oth_image = img ? imgA : nullptr;
     p.coef_own = col_w, p.coef_oth = coef;
     p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
     p.out = part_c;
@@ -896,7 +948,8 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     const bool grads = grad_T1 || grad_T2;
     const bool masked = row_w || col_w;
     const bool onepass = masked || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
-    if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s);
+    if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s,
+                                        grads ? w + L.off_imgC : nullptr, grads ? w + L.off_imgA : nullptr);
     int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);

@@ -27,8 +27,8 @@
 #include <type_traits>
 
 #include "internal.h"
-#include "lds_dma.h"
 #include "mfma_common.h"
+#include "plane_image.h"
 
 namespace rbg {
 
@@ -53,43 +53,16 @@ struct TopkParams {
     float *w_val;              // workspace [B][n_chunks*4][kListStride]
     int32_t *w_idx;
     int32_t *w_cnt;            // [B][n_chunks*4]
-    const char *image;         // r06: the item table as bf16 planes, tile by tile in the LDS layout (topk_image_kernel); NULL: fetch + split per workgroup
+    const char *image;         // r06: the item table as bf16 planes, tile by tile in the LDS layout (plane_image.h); NULL: fetch + split per workgroup
 };
 
 // r06 — the PLANE IMAGE.  Every workgroup of the main pass and of the pre-pass used to fetch each 32-item tile as fp32, split it
 // into three bf16 planes and publish them to LDS: per tile and wave ~ 1 000 cycles of fetch issue + ~ 800 of split / LDS writes
 // (profiles/r05_topk_clock.jsonl) — 40 % of the loop once the filter had become cheap (r05) — repeated by all 32 workgroup rows
 // of a 4 096-user call on the same 10 MB table.  Now one small kernel splits the table ONCE per call into an image that IS the
-// LDS layout (tile t = 3 planes x 32 rows x (64 NCHUNK + 8) bf16, contiguous), and a workgroup takes a tile by LDS-DMA
-// (global_load_lds_dwordx4: 16 bytes per lane, lane-linear — no registers, no VALU, no LDS-write instructions), one tile ahead.
+// LDS layout (plane_image.h), and a workgroup takes a tile by LDS-DMA, one tile ahead.
 // Same planes, same products: bit-identical results.  (r02 had tried this when the filter and the list code dominated the loop:
 // no gain then.)
-template <int NCHUNK>
-struct PlaneImage {
-    static constexpr int LDH = NCHUNK * 64 + 8;
-    static constexpr int kTileBytes = 3 * 32 * LDH * 2;  // 13 824 (d <= 64), 26 112 (d <= 128): multiples of 16
-    static constexpr int kRounds = (kTileBytes + 4095) / 4096;
-    // all 256 threads: tile t of the image -> the LDS tile at lds_dst (byte address), 16 bytes per lane per round
-    static __device__ __forceinline__ void dma(const char *image, int64_t t, unsigned lds_dst, int tid, int wave) {
-        const char *src = image + t * (int64_t)kTileBytes;
-#pragma unroll
-        for (int k = 0; k < kRounds; ++k) {
-            const int chunk = tid + 256 * k;
-            if (chunk * 16 < kTileBytes) lds_dma16(src + chunk * 16, lds_dst + (unsigned)(k * 4096 + wave * 1024));
-        }
-    }
-};
-__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <int NCHUNK, bool VEC>
-__global__ __launch_bounds__(256) void topk_image_kernel(const float *__restrict__ I, int64_t n_items, int d, char *__restrict__ image) {
-    using Tiles = RowTile3<NCHUNK, (VEC ? RUN_VEC : RUN_ANY)>;
-    Tiles tiles;
-    const int64_t t = blockIdx.x;
-    tiles.fetch(I, d, n_items, d, t, threadIdx.x);
-    tiles.publish(*reinterpret_cast<typename Tiles::Planes *>(image + t * (int64_t)PlaneImage<NCHUNK>::kTileBytes), threadIdx.x);
-}
-
 // (va, ia) "better than" (vb, ib): higher score first, lower item id on ties (a total order -> deterministic)
 __device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
 
@@ -893,11 +866,11 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     if (opt_topk_image() && opt_mfma_split() != 0 && d <= 128 && (d > 64 || opt_topk_image() == 2) && L.image_bytes && B >= 1024) {
         char *image = w + L.image_off;
         if (d <= 64) {
-            if (vec) hipLaunchKernelGGL((topk_image_kernel<1, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
-            else hipLaunchKernelGGL((topk_image_kernel<1, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+            if (vec) hipLaunchKernelGGL((plane_image_kernel<1, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, (int64_t)d, n_items, d, image);
+            else hipLaunchKernelGGL((plane_image_kernel<1, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, (int64_t)d, n_items, d, image);
         } else {
-            if (vec) hipLaunchKernelGGL((topk_image_kernel<2, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
-            else hipLaunchKernelGGL((topk_image_kernel<2, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, n_items, d, image);
+            if (vec) hipLaunchKernelGGL((plane_image_kernel<2, true>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, (int64_t)d, n_items, d, image);
+            else hipLaunchKernelGGL((plane_image_kernel<2, false>), dim3((unsigned)L.n_tiles), dim3(256), 0, s, item_all, (int64_t)d, n_items, d, image);
         }
         RBG_HIP(hipGetLastError());
         p.image = image;
