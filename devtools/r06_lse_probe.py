@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import recbole_gnn_amd as rbg
 dev = torch.device("cuda:0")
-for n, d in ((40982, 64), (29858, 64), (91600, 128)):
+for n, d in ((29858, 64), (31669, 64), (38049, 64), (40982, 64), (52644, 64), (91600, 64)):
     B = 2048
     g = torch.Generator().manual_seed(n)
     t1 = torch.randn(n, d, generator=g).to(dev).requires_grad_(True)

@@ -101,8 +101,9 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   publishing a transposed copy of every tile (r06: InfoNCE forward + backward at 2048 x 40 982 x 64
  *                   354 -> 330 us, at 2048 x 91 600 x 128 1 790 -> 1 396 us; same results bit for bit); 0 = the transposed copy
  *   "lse_image"   : 0 (default) ; 1 = the gradient launches of rbg_infonce*_f32 take the tiles of the normalised table / batch rows from
- *                   plane images (built once per call, as "topk_image") by LDS-DMA.  Bit-identical; measured neutral to 1 % slower
- *                   (the per-workgroup split is hidden behind the products), so it is off
+ *                   plane images (built once per call, as "topk_image") by LDS-DMA, three workgroups per CU at d <= 64 with the
+ *                   chunking tuned for three.  Same values to the last chunk-summation bit; measured -4 % at 40 982 / 91 600 table
+ *                   rows, +3 % at 29 858 / 31 669 (profiles/r06_lse_image_3wg.jsonl): off
  *   "sell_c16"    : 1 (default) = the launches of the factored chain read their entries as 16-bit slab-row numbers where the plan
  *                   has them (both row classes below 65 536 rows: 2 instead of 4 bytes per entry; r05: 91.6 -> 89.6 us per
  *                   propagation at the Gowalla shape, 124.7 -> 121.1 at Yelp2018); 0 = 32-bit offsets.  Same bits.

@@ -76,7 +76,7 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // 64 k); the oth tile is then published as three bf16 planes, and — for the gradients, whose second product reads the
 // tile as fp32 columns — as the fp32 tile too.
 template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false>
-__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? 2 : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
+__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
@@ -408,7 +408,10 @@ struct LseLayout {
 static LseLayout lse_layout(int64_t B, int64_t n, int d) {
     LseLayout L{};
     const bool split = opt_mfma_split() != 0;  // (the split kernels hold 48 instead of 32 own registers per chunk)
-    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = d <= 64 ? (split ? 2 : 3) : 1;  // resident workgroups per CU (register-limited)
+    // resident workgroups per CU (register-limited; r06: the gradient kernel that takes its tiles from plane images and its column
+    // fragments by transpose reads fits three at d <= 64: 168 registers, 28 KB of LDS)
+    const bool img3 = split && opt_lse_image() && opt_lse_tr_read();
+    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = d <= 64 ? (split ? (img3 ? 3 : 2) : 3) : 1;
     // one partial array per chunk: own rows x d x 8 bytes (write + read) at ~5 TB/s, in units of a ~1.2 us tile
     auto partial_cost = [&](int64_t rows) { return (double)rows * d * 8.0 / 5e6 / 1.2; };
     lse_geometry(B, n, res_f, 0.02, L.tpc_f, L.nc_f);
