@@ -514,9 +514,7 @@ class PushExchange:
     def check(self):
         """Synchronise and raise if a wait timed out (a peer that never pushed)."""
         torch.cuda.synchronize(self.device)
-        err = torch.as_tensor(type("_E", (), {"__cuda_array_interface__": {"shape": (1,), "typestr": "<i4", "data": (self._err_ptr, False), "version": 2}})(),
-                              device=self.device)
-        e = int(err[0])
+        e = int(self._view(self._err_ptr, (1,), typestr="<i4")[0])
         if e:
             raise RuntimeError(f"PushExchange: rank {self.rank} timed out waiting for flag word {e - 1} ({self.timeout_ms} ms)")
 
@@ -529,6 +527,13 @@ class PushExchange:
             self._tables = []
             self._lib.lib.rbg_ipc_free(self._base)
             self._base = None
+
+    def __del__(self):
+        try:
+            if not torch.cuda.is_current_stream_capturing():  # (close() synchronises and frees: never inside a capture)
+                self.close()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 # ---- the sharded propagation ---------------------------------------------------------------------
