@@ -321,6 +321,8 @@ class HipBackend:
         return ctx
 
     def __del__(self):
+        if torch is None or torch.cuda is None:  # (interpreter shutdown: the modules are already gone)
+            return
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return  # (collected inside somebody's stream capture: leaked rather than invalidating it — see GraphHandle.destroy)
         for ctx in getattr(self, "_ctxs", []):
@@ -568,7 +570,7 @@ class ShardedPropagation:
         return {"recv_bytes": n_total * d * 4, "halo_rows": int(self.plan.n_halo), "owned_rows": int(self.plan.n_owned)}
 
     def __init__(self, plan, backend, group=None, transport="nccl", overlap=None, fused=None, push_tables=4, push_timeout_ms=2000,
-                 cat_window_rows=4_000_000):
+                 cat_window_rows=None):
         # overlap = None (default): off — unmeasured between real peers; ``autotune`` measures both forms on the actual group
         if overlap is None:
             overlap = False
@@ -586,9 +588,14 @@ class ShardedPropagation:
         self.comm_stream, self._comm_h, self._ctx = None, None, None
         self.overlap = False
         self.set_overlap(overlap)
-        # a rectangular plan addresses its table with 32-bit byte offsets (4.19 M rows at d = 128): a longer table — config #5's
-        # 8-rank shards gather 15 M rows — is cut into column windows, one planned handle and one launch each (r06)
-        self._cat_window_rows = int(cat_window_rows)
+        # a rectangular plan addresses its table with 32-bit byte offsets (4.19 M rows at d = 128).  A longer table — config #5's
+        # 8-rank shards gather 12 M rows — CAN be cut into column windows, one planned handle and one launch each
+        # (``cat_window_rows``), but measured at that scale the windows lose to the two-handle form (4.93 vs 4.24 ms per layer,
+        # profiles/r06_config5_shard.json: every extra launch re-reads and re-writes the rank's 0.96 GB of Y and the gathers are
+        # fabric-bound on either kernel), so by default such a rank keeps two handles: interior on the column-slab kernel, halo binned
+        self._cat_window_rows = int(cat_window_rows) if cat_window_rows else None
+        if self._want_fused and transport != "push" and self._cat_window_rows is None and (plan.n_owned + plan.n_halo) * 256 >= 0x7ffffff0:
+            self._want_fused = False
         self._g_cats = None
         if self.fused:
             # blocks the planner does not serve (no two row classes, ...) would put EVERY entry on the binned kernel; the two-handle
@@ -636,7 +643,8 @@ class ShardedPropagation:
             if self._g_cat is not None:  # (a handle handed over by a sibling propagation of the same plan)
                 self._g_cats = [(0, self.plan.n_owned + self.plan.n_halo, self._g_cat)]
             else:
-                self._g_cats = [(lo, hi, self._make_graph(csr, hi - lo)) for lo, hi, csr in self.plan.cat_windows(self._cat_window_rows)]
+                self._g_cats = [(lo, hi, self._make_graph(csr, hi - lo))
+                                for lo, hi, csr in self.plan.cat_windows(self._cat_window_rows or (self.plan.n_owned + self.plan.n_halo))]
                 self._g_cat = self._g_cats[0][2]
         return self._g_cats
 
