@@ -104,6 +104,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   plane images (built once per call, as "topk_image") by LDS-DMA, three workgroups per CU at d <= 64 with the
  *                   chunking tuned for three.  Same values to the last chunk-summation bit; measured -4 % at 40 982 / 91 600 table
  *                   rows, +3 % at 29 858 / 31 669 (profiles/r06_lse_image_3wg.jsonl): off
+ *   "sell_wpb"    : waves per workgroup of the column-slab launch: 1 (default), 2 or 4 — same results, 1 measured best everywhere (r06)
  *   "sell_c16"    : 1 (default) = the launches of the factored chain read their entries as 16-bit slab-row numbers where the plan
  *                   has them (both row classes below 65 536 rows: 2 instead of 4 bytes per entry; r05: 91.6 -> 89.6 us per
  *                   propagation at the Gowalla shape, 124.7 -> 121.1 at Yelp2018); 0 = 32-bit offsets.  Same bits.

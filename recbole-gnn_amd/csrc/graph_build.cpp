@@ -58,6 +58,8 @@ static std::atomic<int> g_lse_image{0};  // (measured neutral to slightly slower
 int opt_lse_image() { return g_lse_image.load(); }
 static std::atomic<int> g_sell_c16{1};
 int opt_sell_c16() { return g_sell_c16.load(); }
+static std::atomic<int> g_sell_wpb{1};
+int opt_sell_wpb() { return g_sell_wpb.load(); }
 static std::atomic<int> g_deterministic{0};
 int opt_deterministic() { return g_deterministic.load(); }
 int opt_col_split() { return g_col_split.load(); }
@@ -524,6 +526,11 @@ int rbg_set_option(const char *key, int64_t value) {
         g_shard_single_stream = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "sell_wpb")) {
+        if (value != 1 && value != 2 && value != 4) return fail(RBG_EINVAL, "sell_wpb must be 1, 2 or 4 waves per workgroup");
+        g_sell_wpb = (int)value;
+        return RBG_OK;
+    }
     if (!strcmp(key, "lse_image")) {
         g_lse_image = value ? 1 : 0;
         return RBG_OK;
@@ -622,6 +629,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "nt_store")) {
         *value = g_nt_store.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "sell_wpb")) {
+        *value = g_sell_wpb.load();
         return RBG_OK;
     }
     if (!strcmp(key, "lse_image")) {

@@ -39,6 +39,7 @@ int opt_bignn_dma();     // BiGNN dense layer at d_in = 64, d_out <= 64: LDS-DMA
 int opt_shard_single_stream();  // C-ABI sharded layer: pack + exchange on the caller's stream (1) or on the shard's comm stream (0)
 int opt_shard_fused();  // rbg_graph_create_sharded: the rank's [interior | halo] block as ONE planned handle, a layer = exchange + one launch (1, default)
 int opt_sell_nt();         // sell.hip epilogue: bit 0 = non-temporal stores, bit 1 = non-temporal loads of the mean's addends
+int opt_sell_wpb();       // sell.hip: waves per workgroup of the layer launch (1, 2 or 4)
 int opt_sell_c16();       // sell.hip: compact launches read 16-bit slab-row numbers where the plan has them (1, default)
 int opt_sell_factored();  // sell.hip: factored chains (val_ij = r_i r_j): compact entries, scaled slabs
 int opt_sell_rowmajor();  // sell.hip: gather E0 / the incoming gradient row-major where they lie (no conversion to slabs)

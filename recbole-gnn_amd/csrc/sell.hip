@@ -37,7 +37,7 @@ namespace rbg {
 // W = slab width (32).  One wave per unit; workgroup b runs on XCD b & 7: XCDs 0-3 take user rows, 4-7 item rows, XCD x of a class
 // owns slab x % NS; the 4 / NS XCDs of a (class, slab) role share its units.
 template <int W, int NS, bool COMPACT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellLaunch a_) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void sell_spmm_kernel(const SellLaunch a_) {
     SellLaunchK &A = sell_kernarg();  // (= a_, read in place)
     SellParamsK &p = A.p;
     SellClock clk;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void se
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xtab), 0, (int)tab_bytes, 0x00020000);
     // (the grid covers the units: one unit per single-wave workgroup — a retired wave's slot is refilled on its own (r06; r03-r05:
     // four-wave workgroups, because a wide row's four units met in LDS) — heaviest first, dealt by the hardware dispatcher)
-    const unsigned t = (blockIdx.x >> 3) * XR + xi;
+    const unsigned t = ((blockIdx.x >> 3) * XR + xi) * (blockDim.x >> 6) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (t < (unsigned)R.n_units) {
         const int4 h = R.heads[t];
         clk.lap(0);
@@ -230,7 +230,8 @@ bool sell_chain_factored(const rbg_graph *g) { return g && g->sell && sell_facto
 template <int W, int NS>
 static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
     const int64_t units = std::max(sw->n_units[0], sw->n_units[1]);
-    const int per = 4 / NS;  // units per 8 workgroups: the XCDs of a (class, slab) role, one wave each
+    const int wpb = opt_sell_wpb();  // waves per workgroup (1, 2 or 4: nothing in the kernel is workgroup-wide)
+    const int per = wpb * (4 / NS);  // units per 8 workgroups: the XCDs of a (class, slab) role
     const unsigned grid = (unsigned)(8 * std::max<int64_t>(1, (units + per - 1) / per));
     SellLaunch a;
     a.p = p;
@@ -252,8 +253,8 @@ static int sell_launch(const SellDev *sw, SellParams &p, hipStream_t s) {
             r.ents = p.x_rm ? (const void *)p.ent0 : (const void *)p.ent;
         }
     }
-    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(64), 0, s, a);
+    if (p.compact) hipLaunchKernelGGL((sell_spmm_kernel<W, NS, true>), dim3(grid), dim3(64 * wpb), 0, s, a);
+    else hipLaunchKernelGGL((sell_spmm_kernel<W, NS, false>), dim3(grid), dim3(64 * wpb), 0, s, a);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
