@@ -50,6 +50,8 @@ static std::atomic<int> g_topk_short{1};
 int opt_topk_short_lists() { return g_topk_short.load(); }
 static std::atomic<int> g_topk_image{1};
 int opt_topk_image() { return g_topk_image.load(); }
+static std::atomic<int> g_topk_screen{1};
+int opt_topk_screen() { return g_topk_screen.load(); }
 static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 static std::atomic<int> g_lse_tr_read{1};
@@ -543,6 +545,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_topk_image = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         return RBG_OK;
     }
+    if (!strcmp(key, "topk_screen")) {
+        g_topk_screen = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        return RBG_OK;
+    }
     if (!strcmp(key, "shard_fused")) {
         g_shard_fused = value ? 1 : 0;
         return RBG_OK;
@@ -645,6 +651,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "topk_image")) {
         *value = g_topk_image.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "topk_screen")) {
+        *value = g_topk_screen.load();
         return RBG_OK;
     }
     if (!strcmp(key, "shard_fused")) {

@@ -29,11 +29,12 @@
 #include "internal.h"
 #include "mfma_common.h"
 #include "plane_image.h"
+#include "topk_common.h"
+#include "topk_screen.h"
 
 namespace rbg {
 
 
-constexpr float kNegInf = -__builtin_inff();
 
 constexpr int kListStride = 32;  // entries a wave hands over per user (workspace row)
 
@@ -63,84 +64,6 @@ struct TopkParams {
 // LDS layout (plane_image.h), and a workgroup takes a tile by LDS-DMA, one tile ahead.
 // Same planes, same products: bit-identical results.  (r02 had tried this when the filter and the list code dominated the loop:
 // no gain then.)
-// (va, ia) "better than" (vb, ib): higher score first, lower item id on ties (a total order -> deterministic)
-__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
-
-// 64-lane bitonic sort, best first.
-__device__ __forceinline__ void wave_sort_desc(float &v, int &idx, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const float ov = __shfl_xor(v, j);
-            const int oi = __shfl_xor(idx, j);
-            const bool up = (lane & k) == 0;        // this block sorts best-first
-            const bool lower = (lane & j) == 0;     // I hold the earlier position of the pair
-            const bool other_better = better(ov, oi, v, idx);
-            const bool take = (up == lower) ? other_better : !other_better;
-            if (take) {
-                v = ov;
-                idx = oi;
-            }
-        }
-    }
-}
-
-// Is `item` in the training history of `user` (= a column of the user's graph row)?  Binary search; called by
-// up to 64 lanes at once so the chain of dependent loads is paid once per batch, not once per candidate.
-__device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t *col, int64_t n_users, int64_t user, int item) {
-    if (!rowptr || user < 0 || item < 0) return false;
-    int lo = rowptr[user], hi = rowptr[user + 1];
-    const int target = (int)(item + n_users);
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const int c = col[mid];
-        if (c == target) return true;
-        if (c < target) lo = mid + 1; else hi = mid;
-    }
-    return false;
-}
-
-// The same test against a copy of the row's head in LDS (r05, the merge and threshold kernels: one wavefront per user).  The
-// binary search of in_history() is a chain of ~ log2(degree) dependent global loads (~ 0.5 us each) paid by every kernel that
-// masks; staged, the chain is two loads (rowptr, the row) and the search runs at LDS latency.  Columns past the staged head are
-// still read from global memory.
-constexpr int kHistStage = 128;  // (merge kernel: 32 KB of staged lists + 2 KB of history per workgroup = four workgroups per CU, all 4 096 users in one round)
-struct HistRow {
-    const __attribute__((address_space(1))) int32_t *col;  // (global, not generic: a flat load in the search loop would make every wait a full one)
-    const int *lds;
-    int lo, hi, staged;
-    int64_t n_users;
-    // two steps, so that a caller can put its own loads between them (they then travel with the row's)
-    __device__ __forceinline__ void begin(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf) {
-        col = (const __attribute__((address_space(1))) int32_t *)col_, lds = buf, n_users = n_users_;
-        lo = hi = staged = 0;
-        if (!rowptr || user < 0) return;
-        lo = rowptr[user], hi = rowptr[user + 1];
-    }
-    __device__ __forceinline__ void finish(int *buf, int lane) {
-        staged = hi - lo < kHistStage ? hi - lo : kHistStage;
-        for (int e = lane; e < staged; e += 64) buf[e] = col[lo + e];
-        __builtin_amdgcn_wave_barrier();
-    }
-    __device__ __forceinline__ void stage(const int32_t *rowptr, const int32_t *col_, int64_t n_users_, int64_t user, int *buf, int lane) {
-        begin(rowptr, col_, n_users_, user, buf);
-        finish(buf, lane);
-    }
-    __device__ __forceinline__ bool has(int item) const {
-        if (item < 0) return false;
-        int a = lo, b = hi;
-        const int target = (int)(item + n_users);
-        while (a < b) {
-            const int mid = (a + b) >> 1;
-            const int c = (mid - lo < staged) ? lds[mid - lo] : col[mid];
-            if (c == target) return true;
-            if (c < target) a = mid + 1; else b = mid;
-        }
-        return false;
-    }
-};
-
 // Prune one user's LDS list (n <= 64 raw candidates) to its best k valid entries (sorted; `kept` of them).  Returns the new
 // threshold: the k-th best (or -inf while fewer than k exist).
 __device__ __forceinline__ float prune_list(const TopkParams &p, int64_t user, float *lv, int *li, int n, int lane, int &kept) {
@@ -814,6 +737,8 @@ extern "C" {
 int rbg_full_sort_topk_workspace(int64_t B, int64_t n_items, int k, int64_t *bytes) {
     if (!bytes || B < 0 || n_items < 0 || k < 1) return fail(RBG_EINVAL, "bad argument");
     *bytes = std::max(topk_layout(B, n_items, 512).bytes, topk_layout(B, n_items, 768).bytes);  // (either residency of the main pass)
+    const ScreenLayout S = screen_layout(B, n_items);  // r06: the screen's image and candidate pool behind the exact passes' part
+    if (S.fits) *bytes = (*bytes + 255) / 256 * 256 + S.bytes;
     return RBG_OK;
 }
 
@@ -859,6 +784,23 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     hipStream_t s = (hipStream_t)stream;
     const unsigned merge_blocks = (unsigned)((B + 3) / 4);
     const bool prepass = L.n_tiles > 2 * L.sample_tiles;  // small item sets: one pass
+    // r06: ONE bf16 product per pair screens the call, the survivors are rescored exactly (topk_screen.hip; measured:
+    // profiles/r06_topk_screen.jsonl); the exact passes below stay for what it does not take (small batches and item sets,
+    // d > 128, option "topk_screen" 0)
+    if (prepass && L.tpc_s <= 256 && screen_applicable(B, n_items, d, k)) {  // (the pre-pass keeps a tile index in 8 bits)
+        ScreenCall c{};
+        c.U = user_all, c.I = item_all, c.users = users, c.rowptr = rp, c.col = cl;
+        c.n_users = n_users, c.n_items = n_items, c.B = B, c.d = d, c.k = k;
+        c.w = w + (L.bytes + 255) / 256 * 256;
+        c.pre_val = pre_val, c.pre_idx = pre_idx, c.splits = L.splits, c.tpc_s = L.tpc_s, c.sample_tiles = L.sample_tiles;
+        c.tau0 = tau0, c.out_val = out_val, c.out_idx = out_idx;
+        int rc = screen_prepass(c, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(topk_tau_kernel, dim3(merge_blocks), dim3(256), 0, s, pre_val, pre_idx, users, rp, cl, n_users, B,
+                           L.splits, k, tau0);
+        RBG_HIP(hipGetLastError());
+        return screen_main(c, s);
+    }
     // r06: the item table as bf16 planes in the LDS layout, once per call (both passes take their tiles from it by LDS-DMA)
     // (measured, profiles/r06_topk_image.jsonl, 4096 users x 40 982 items: d = 128 429.7 -> 393.7 us per call; d = 64 191.5 -> 192.0 —
     // there the fetch and the split were already hidden behind the other resident workgroups' products, as r02 had found: the image

@@ -1784,6 +1784,91 @@ def test_full_sort_topk_plane_image(rbg, cuda, golden):
         rbg.set_option("topk_image", 1)
 
 
+def _random_history(n_users, n_items, per_user, seed, hub=None):
+    rng = np.random.default_rng(seed)
+    uid = np.repeat(np.arange(1, n_users), per_user)
+    iid = rng.integers(1, n_items, uid.shape[0])
+    if hub is not None:
+        u, items = hub
+        uid = np.concatenate([uid, np.full(len(items), u)])
+        iid = np.concatenate([iid, items])
+    pairs = np.unique(np.stack([uid, iid], 1), axis=0)
+    return pairs[:, 0], pairs[:, 1]
+
+
+def _check_topk_against_reference(vals, idx, user_all, item_all, users, k, uid, iid, tol):
+    scores, (rv, ri) = reference_topk(user_all.cpu(), item_all.cpu(), users.cpu(), k, uid, iid)
+    close(vals, rv.float(), tol=tol)
+    idx_c, vals_c = idx.cpu(), vals.cpu()
+    srt = torch.sort(scores, dim=1, descending=True).values
+    gap = (srt[:, k - 1] - srt[:, k]) > 1e-3 * max(1.0, float(srt[:, 0].abs().max()))
+    for r in range(users.shape[0]):
+        row = idx_c[r].tolist()
+        assert len(set(row)) == k and 0 not in row
+        assert torch.all(torch.isfinite(scores[r, idx_c[r]]))      # no history item, no PAD
+        assert torch.all(vals_c[r, :-1] >= vals_c[r, 1:])
+        if gap[r]:
+            assert set(row) == set(ri[r].tolist())
+    assert int(gap.sum()) > users.shape[0] // 2
+
+
+def test_full_sort_topk_screen(rbg, cuda):
+    """r06, option "topk_screen" (csrc/topk_screen.hip): ONE bf16 product per (user, item) with a rigorous error bound on the matrix
+    core screens the call, the survivors are rescored exactly in fp32 — the same top-k as the exact passes (option 0) and as the
+    float64 reference (lightgcn.py:123-133 + _full_sort_batch_eval): history masks incl. a hub user whose 2 500 history items all
+    score high, repeated users, ragged rows (d = 33: scalar loads), d = 100 / 128 (eight product fragments), an item count that is
+    not a multiple of the tile; and the two cases in which candidate regions overflow and the merge takes every pair of the
+    region's chunk instead: all scores equal (every pair passes) and a user whose history covers the whole pre-pass sample (no
+    threshold: every item is its candidate)."""
+    nu, ni = 3000, 9003
+    hub_items = np.random.default_rng(3).choice(np.arange(1, ni), 2500, replace=False)
+    uid, iid = _random_history(nu, ni, 20, 1, hub=(7, hub_items))
+    h = rbg.GraphHandle.from_interactions(uid, iid, nu, ni, device=cuda)
+    ua, it = randn((nu, 64), 5, cuda), randn((ni, 64), 6, cuda)
+    it[torch.from_numpy(hub_items).to(cuda)] += 0.5 * ua[7]     # the hub's history items are its best items: all must be dropped
+    users_h = torch.cat([torch.tensor([7, 7, 1, nu - 1]), torch.from_numpy(np.random.default_rng(1).integers(1, nu, 2100))]).to(cuda)
+    cases = [("history", h, ua, it, users_h, 10, uid, iid),
+             ("d128", None, randn((1500, 128), 11, cuda), randn((20_000, 128), 12, cuda), torch.arange(1500, device=cuda), 3, [], []),
+             ("d33", None, randn((300, 33), 9, cuda), randn((5003, 33), 10, cuda), torch.arange(300, device=cuda).repeat(8), 20, [], []),
+             ("d100k32", h, randn((nu, 100), 13, cuda), randn((ni, 100), 14, cuda), torch.arange(1, 1300, device=cuda), 32, uid, iid)]
+    rbg.set_option("topk_sample", 1024)
+    try:
+        for name, hist, u, i, users, k, hu, hi in cases:
+            out = {}
+            for mode in (0, 2):
+                rbg.set_option("topk_screen", mode)
+                out[mode] = rbg.full_sort_topk(hist, u, i, users, k)
+            close(out[2][0], out[0][0], tol=2e-6)
+            same = (out[0][1] == out[2][1]).all(dim=1)
+            assert float(same.float().mean()) > 0.99, name      # (a last-bit tie may swap two neighbours)
+            _check_topk_against_reference(out[2][0], out[2][1], u, i, users, k, np.asarray(hu), np.asarray(hi), tol=1e-5 * max(1, u.shape[1] / 64))
+        # every score equal: the screen passes every pair, every region overflows
+        flat_u, flat_i = torch.ones((1200, 64), device=cuda), torch.ones((5000, 64), device=cuda)
+        users = torch.arange(1200, device=cuda)
+        res = {}
+        for mode in (0, 2):
+            rbg.set_option("topk_screen", mode)
+            res[mode] = rbg.full_sort_topk(None, flat_u, flat_i, users, 10)
+        assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1])
+        assert torch.equal(res[2][1][0].cpu(), torch.arange(1, 11))  # ties by item id, PAD masked
+        # a user whose history is the whole sample: no bound for it
+        cover = np.arange(1, 1100)
+        uid2, iid2 = _random_history(nu, ni, 20, 2, hub=(9, cover))
+        h2 = rbg.GraphHandle.from_interactions(uid2, iid2, nu, ni, device=cuda)
+        users = torch.arange(1, 1201, device=cuda)
+        for mode in (0, 2):
+            rbg.set_option("topk_screen", mode)
+            res[mode] = rbg.full_sort_topk(h2, ua, it, users, 10)
+        close(res[2][0], res[0][0], tol=2e-6)
+        assert torch.equal(res[0][1][8], res[2][1][8])  # (user 9; its candidates are every item: they fit the regions at this size)
+        _check_topk_against_reference(res[2][0], res[2][1], ua, it, users, 10, uid2, iid2, tol=1e-5)
+    finally:
+        rbg.set_option("topk_screen", 1)
+        rbg.set_option("topk_sample", 8192)
+    with pytest.raises(rbg.RbgError):
+        rbg.set_option("topk_nonexistent", 1)
+
+
 def test_full_sort_topk_model_and_few_candidates(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
