@@ -1,0 +1,8 @@
+// What-if build of the screened top-k: the product source with its diagnostic switches compiled in (results are wrong on purpose).
+#define RBG_SCREEN_DBG 1
+#include "../../recbole-gnn_amd/csrc/topk_screen.hip"
+
+extern "C" int mb_screen_debug_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_screen_debug), &bits, sizeof(bits)); }
+extern "C" int mb_screen_trace_set(unsigned long long *trace) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_screen_trace), &trace, sizeof(trace));
+}

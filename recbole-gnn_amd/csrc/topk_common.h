@@ -32,6 +32,44 @@ __device__ __forceinline__ void wave_sort_desc(float &v, int &idx, int lane) {
     }
 }
 
+// The same network with the partner's value taken by DPP where a lane's partner sits in its row of 16 (strides 1, 2: quad_perm;
+// 4: row_shr / row_shl + select; 8: row_ror) — 18 of the 21 stages — instead of ds_bpermute: no LDS round trip per stage (r06: the
+// fold phase of topk_screen.hip's merge kernel was bound by them with 16 waves per CU sorting at once).  Same comparisons, same result.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+template <int J>
+__device__ __forceinline__ int lane_xor(int x, int lane) {
+    if constexpr (J == 1) return dpp_mov<0xB1>(x);        // quad_perm [1, 0, 3, 2]
+    else if constexpr (J == 2) return dpp_mov<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+    else if constexpr (J == 4) {
+        const int up = dpp_mov<0x114>(x), dn = dpp_mov<0x104>(x);  // row_shr:4 (from lane - 4), row_shl:4 (from lane + 4)
+        return (lane & 4) ? up : dn;
+    } else if constexpr (J == 8) return dpp_mov<0x128>(x);  // row_ror:8
+    else return __shfl_xor(x, J);
+}
+template <int K, int J>
+__device__ __forceinline__ void sort_stage(float &v, int &idx, int lane) {
+    const float ov = __int_as_float(lane_xor<J>(__float_as_int(v), lane));
+    const int oi = lane_xor<J>(idx, lane);
+    const bool up = (lane & K) == 0;
+    const bool lower = (lane & J) == 0;
+    const bool other_better = ov > v || (ov == v && oi < idx);
+    const bool take = (up == lower) ? other_better : !other_better;
+    if (take) {
+        v = ov;
+        idx = oi;
+    }
+    if constexpr (J > 1) sort_stage<K, J / 2>(v, idx, lane);
+}
+__device__ __forceinline__ void wave_sort_desc_dpp(float &v, int &idx, int lane) {
+    sort_stage<2, 1>(v, idx, lane);
+    sort_stage<4, 2>(v, idx, lane);
+    sort_stage<8, 4>(v, idx, lane);
+    sort_stage<16, 8>(v, idx, lane);
+    sort_stage<32, 16>(v, idx, lane);
+    sort_stage<64, 32>(v, idx, lane);
+}
+
 // Is `item` in the training history of `user` (= a column of the user's graph row)?  Binary search; called by
 // up to 64 lanes at once so the chain of dependent loads is paid once per batch, not once per candidate.
 __device__ __forceinline__ bool in_history(const int32_t *rowptr, const int32_t *col, int64_t n_users, int64_t user, int item) {

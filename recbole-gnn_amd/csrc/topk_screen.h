@@ -10,7 +10,7 @@ struct ScreenLayout {
     bool fits;                       // the screen's workspace exists for this (B, n_items)
     int64_t n_tiles;                 // 32-item tiles
     int ut, n_ublocks, tpc, nc;      // main pass: user tiles per wave, user blocks (ut x 32 users), item tiles per chunk, chunks
-    int64_t image_off, pool_off, cnt_off, bytes;  // byte offsets inside the screen's part of the workspace
+    int64_t image_off, uimage_off, pool_off, cnt_off, bytes;  // byte offsets inside the screen's part of the workspace
 };
 ScreenLayout screen_layout(int64_t B, int64_t n_items);
 bool screen_applicable(int64_t B, int64_t n_items, int d, int k);

@@ -20,8 +20,8 @@
 //          halves (= two sets of 16 users) fill a region from its two ends.
 //   pass 3 (screen_merge_kernel): one workgroup per 16 users (one lane half of a tile) gathers its regions, rescoring every
 //          candidate exactly in fp32 (16 lanes per candidate, eight candidates in flight, the item row read from the fp32 table),
-//          buckets them by user, drops history / PAD items and folds them into the user's best 32 by the same bitonic network
-//          and the same total order as topk.hip.
+//          buckets them by user, drops history items (one 64-lane-parallel search of the staged graph row per batch) and folds
+//          them into the user's best 32 by the same bitonic network and the same total order as topk.hip, one wave per user.
 // No workgroup shares anything in passes 1 and 2: a wave keeps the bf16 rows of UT x 32 users as A fragments (16 registers per
 // 32 users at d <= 64 — the split operands of the exact pass take 48) and reads its B fragments straight from an image of the
 // item table laid out per tile as [fragment][lane][16 bytes] (1 KiB coalesced wave loads, L1 / L2 resident: 5 KiB per tile), so
@@ -44,10 +44,11 @@
 namespace rbg {
 
 constexpr float kScreenEps = 0.00390625f * 1.03f;
+constexpr float kPreEps = kScreenEps + 6.2e-5f;  // (the pre-pass: see screen_pre_kernel)
 constexpr int kRegion = 512;   // entries of one (user block, chunk, user tile) region of the pool
 constexpr int kSlab = 4096;    // candidates a merge workgroup holds in LDS at a time
 constexpr int kMaxChunks = 64;
-constexpr int kHS = 64;        // history columns staged per user in the merge kernel
+constexpr int kHS = 512;       // history columns staged per user in the merge kernel (longer rows: the tail is searched in global memory)
 constexpr int kUStride = 132;  // floats per staged user row (d <= 128)
 constexpr int kUt64 = 2, kUt128 = 2;  // 32-user tiles a wave of the main pass keeps (d <= 64 / d <= 128)
 constexpr int kWantWaves = 4096;      // waves the main pass aims for (user blocks x item chunks)
@@ -96,11 +97,37 @@ __device__ __forceinline__ float sumsq8(const f32x8v &v) {
 // elements 16 s + 8 h + [0, 8) of item 32 t + i — exactly a lane's B operand of v_mfma_f32_32x32x16_bf16 -------------------------
 template <int S, bool VEC>
 __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restrict__ I, int64_t n_items, int64_t n_tiles, int d,
-                                                           char *__restrict__ image) {
+                                                           char *__restrict__ image, const float *__restrict__ U,
+                                                           const int64_t *__restrict__ users, int64_t B, char *__restrict__ uimage) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    if (t >= n_tiles) return;
     const int i = lane & 31, h = lane >> 5;
+    const __bf16 z = (__bf16)0.0f, o = (__bf16)1.0f;
+    if (t >= n_tiles) {
+        // the waves behind the item tiles convert the batch's user rows: the same layout, tile ut = 32 batch slots, the bound
+        // fragment (eps ||u|| rounded up, 1); both passes then start with five coalesced loads instead of a gather behind an
+        // index load (their prologue was ~ 8 of the pre-pass's 17 us)
+        const int64_t ut = t - n_tiles;
+        if (ut * 32 >= B) return;
+        const int64_t bi = ut * 32 + i;
+        const int64_t user = bi < B ? users[bi] : -1;
+        const float *row = U + (user < 0 ? 0 : user) * (int64_t)d;
+        bf16x8 *dst = reinterpret_cast<bf16x8 *>(uimage + ut * (int64_t)(S + 1) * 1024) + lane;
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const f32x8v v = load8<VEC>(row, user >= 0, 16 * s + 8 * h, d);
+            ss += sumsq8(v);
+            dst[s * 64] = __builtin_convertvector(v, bf16x8);
+        }
+        ss += __shfl_xor(ss, 32);
+        const float nrm = sqrtf(ss) * 1.00001f;
+        // slot 3: the main pass's margin, slot 5: the pre-pass's (wider: its packed maxima lose 8 mantissa bits); the passes pick one
+        bf16x8 f = {z, z, z, z, z, z, z, z};
+        if (h == 0) f = bf16x8{z, z, z, bf16_up(fminf(kScreenEps * nrm, 1.0e38f)), o, bf16_up(fminf(kPreEps * nrm, 1.0e38f)), z, z};
+        dst[S * 64] = f;
+        return;
+    }
     const int64_t item = t * 32 + i;
     const bool ok = item < n_items;
     const float *row = I + (ok ? item : 0) * (int64_t)d;
@@ -114,19 +141,34 @@ __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restri
     }
     ss += __shfl_xor(ss, 32);
     const float nrm = fminf(sqrtf(ss) * 1.00001f, 1.0e38f);
-    const __bf16 z = (__bf16)0.0f, o = (__bf16)1.0f;
     const bool valid = ok && item != 0;  // the PAD item and the rows past the end never pass
     bf16x8 f = {z, z, z, z, z, z, z, z};
     if (h == 0) f = bf16x8{o, o, o, bf16_up(nrm), valid ? z : (__bf16)-3.0e38f, z, z, z};
     dst[S * 64] = f;
 }
 
+// What-if switches of the diagnostic build (devtools/microbench/topk_screen_trace.hip defines RBG_SCREEN_DBG; results are wrong on
+// purpose): 1 main pass appends nothing, 2 main pass tests one accumulator row of 16, 4 main pass loads no tile after its first,
+// 8 main pass stops after its prologue, 16 merge scores nothing, 32 merge sorts nothing, 64 merge stops after staging, 128 merge tests no history, 256 merge runs no sorting network.
+#ifdef RBG_SCREEN_DBG
+__device__ int g_screen_debug = 0;
+__device__ unsigned long long *g_screen_trace = nullptr;  // [workgroup][16] phase clock of the merge kernel (thread 0)
+#define RBG_SCREEN_LAP(k)                                                                                       \
+    do {                                                                                                        \
+        if (g_screen_trace && threadIdx.x == 0) g_screen_trace[(int64_t)blockIdx.x * 16 + (k)] = clock64();    \
+    } while (0)
+#define RBG_SCREEN_DBG_LOAD() const int screen_dbg_bits = g_screen_debug  // (once per kernel: a load per use would stall the loop it is meant to probe)
+#define RBG_SCREEN_DBGBIT(bit) ((screen_dbg_bits & (bit)) != 0)
+#else
+#define RBG_SCREEN_LAP(k) ((void)0)
+#define RBG_SCREEN_DBG_LOAD() ((void)0)
+#define RBG_SCREEN_DBGBIT(bit) false
+#endif
+
 struct ScreenParams {
-    const float *U;
-    const int64_t *users;
     int64_t B;
-    int d;
-    const char *image;
+    const char *image;   // item tiles
+    const char *uimage;  // the batch's user tiles, same layout
     int tiles_per_chunk, n_chunks;
     int64_t tile_lo, tile_hi;
     const float *tau0;
@@ -136,40 +178,25 @@ struct ScreenParams {
     int32_t *g_idx;
 };
 
-// a lane's A operand: the bf16 row of batch slot b0 + i (elements 16 s + 8 h + [0, 8) per fragment); returns ||row||
-template <int S, bool VEC>
-__device__ __forceinline__ float load_a(const ScreenParams &p, int64_t bi, int h, bf16x8 (&A)[S]) {
-    const int64_t user = bi < p.B ? p.users[bi] : -1;
-    const float *row = p.U + (user < 0 ? 0 : user) * (int64_t)p.d;
-    float ss = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const f32x8v v = load8<VEC>(row, user >= 0, 16 * s + 8 * h, p.d);
-        ss += sumsq8(v);
-        A[s] = __builtin_convertvector(v, bf16x8);
-    }
-    ss += __shfl_xor(ss, 32);
-    return sqrtf(ss) * 1.00001f;
-}
-
 // ---- pass 1: lower bounds s^ - m^ of the first tile_hi tiles; per lane and accumulator row the running maximum ----------------
 // One 32-user tile per wave, two item tiles per iteration.  The maximum and its item travel in ONE register: the low 8 mantissa
 // bits of the bound are replaced by the tile's index inside the chunk (< 256), so a row costs v_and_or x 2 + v_max3 per two tiles
 // (topk.hip's pre-pass: compare + two selects per tile).  Truncating moves a bound by < 2^-15 |bound| either way; the margin of this
 // pass is widened by 2^-14 ||u|| ||i|| to stay a lower bound.
-constexpr float kPreEps = kScreenEps + 6.2e-5f;
-template <int S, bool VEC>
+template <int S>
 __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
     if (b0 >= p.B) return;  // (no barrier in this kernel)
-    const __bf16 z = (__bf16)0.0f, o = (__bf16)1.0f;
+    const __bf16 z = (__bf16)0.0f;
+    const bf16x8 *uimg = reinterpret_cast<const bf16x8 *>(p.uimage) + ((b0 >> 5) * (S + 1)) * 64 + lane;
     bf16x8 A[S];
-    const float nu = load_a<S, VEC>(p, b0 + i, h, A);
-    const __bf16 au = bf16_up(fminf(kPreEps * nu, 1.0e38f));
-    bf16x8 At = {z, z, z, z, z, z, z, z};
-    if (h == 0) At = bf16x8{z, z, z, bf16_neg(au), o, z, z, z};  // acc = s^ - m^ (+ -3e38 for an invalid item)
+#pragma unroll
+    for (int s = 0; s < S; ++s) A[s] = uimg[s * 64];
+    bf16x8 At = uimg[S * 64];
+    At[3] = bf16_neg(At[5]);  // acc = s^ - m^ (+ -3e38 for an invalid item): the wider margin, negated
+    At[5] = z;
     float best[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) best[r] = kNegInf;
@@ -178,11 +205,22 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
     const int64_t t_last = t_end - 1;
+    i32x4v N0[S + 1], N1[S + 1];  // the next pair of tiles, in flight while this pair feeds the matrix core
+    if (t_begin < t_end) {
+        const int64_t t1 = t_begin + 1 < t_end ? t_begin + 1 : t_last;
+#pragma unroll
+        for (int s = 0; s <= S; ++s) N0[s] = img[(t_begin * (S + 1) + s) * 64], N1[s] = img[(t1 * (S + 1) + s) * 64];
+    }
     for (int64_t t = t_begin; t < t_end; t += 2) {
         const int64_t t1 = t + 1 < t_end ? t + 1 : t_last;  // (an odd tail repeats its tile: the maximum does not change)
         i32x4v B0[S + 1], B1[S + 1];
 #pragma unroll
-        for (int s = 0; s <= S; ++s) B0[s] = img[(t * (S + 1) + s) * 64], B1[s] = img[(t1 * (S + 1) + s) * 64];
+        for (int s = 0; s <= S; ++s) B0[s] = N0[s], B1[s] = N1[s];
+        if (t + 2 < t_end) {
+            const int64_t u1 = t + 3 < t_end ? t + 3 : t_last;
+#pragma unroll
+            for (int s = 0; s <= S; ++s) N0[s] = img[((t + 2) * (S + 1) + s) * 64], N1[s] = img[(u1 * (S + 1) + s) * 64];
+        }
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, as_frag(B0[S]), zero, 0, 0, 0);
         f32x16 a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, as_frag(B1[S]), zero, 0, 0, 0);
@@ -213,28 +251,40 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
 }
 
 // ---- pass 2: every item against tau; passing (item, row) pairs go to the wave's regions -----------------------------------------
-template <int S, int UT, bool VEC>
+template <int S, int UT>
 __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) {
+    RBG_SCREEN_DBG_LOAD();
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int64_t ublock = (int64_t)blockIdx.y * 4 + wave;
     const int64_t b0 = ublock * (UT * 32);
     if (b0 >= p.B) return;  // (no barrier in this kernel)
-    const __bf16 z = (__bf16)0.0f, o = (__bf16)1.0f;
+    const __bf16 z = (__bf16)0.0f;
     bf16x8 A[UT][S], At[UT];
+    float tau[UT];
 #pragma unroll
     for (int j = 0; j < UT; ++j) {
         const int64_t bi = b0 + 32 * j + i;
-        const float nu = load_a<S, VEC>(p, bi, h, A[j]);
-        const __bf16 au = bf16_up(fminf(kScreenEps * nu, 1.0e38f));
-        float t = bi < p.B ? p.tau0[bi] : __builtin_inff();
-        t = fminf(fmaxf(t, -3.0e38f), 3.0e38f);
+        tau[j] = bi < p.B ? p.tau0[bi] : __builtin_inff();
+        const bf16x8 *uimg = reinterpret_cast<const bf16x8 *>(p.uimage) + (((b0 >> 5) + j) * (S + 1)) * 64 + lane;
+        if (b0 + 32 * j < p.B) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) A[j][s] = uimg[s * 64];
+            At[j] = uimg[S * 64];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s) A[j][s] = bf16x8{z, z, z, z, z, z, z, z};
+            At[j] = bf16x8{z, z, z, z, z, z, z, z};
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < UT; ++j) {
+        float t = fminf(fmaxf(tau[j], -3.0e38f), 3.0e38f);
         t = fabsf(t) * 1.0e-5f + 1.0e-30f - t;  // -(tau lowered): a pair with s >= tau has tst > 0
         bf16x2 hh, mm, ll;
         split2_bf16(t, 0.f, hh, mm, ll);
-        bf16x8 f = {z, z, z, z, z, z, z, z};
-        if (h == 0) f = bf16x8{hh[0], mm[0], ll[0], au, o, z, z, z};
-        At[j] = f;
+        if (h == 0) At[j][0] = hh[0], At[j][1] = mm[0], At[j][2] = ll[0];
+        At[j][5] = z;
     }
     int n_lo[UT], n_hi[UT];  // entries of the two lane halves in region j (wave-uniform: scalar registers)
 #pragma unroll
@@ -243,6 +293,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
     const int64_t t_begin = p.tile_lo + (int64_t)chunk * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
+    if (RBG_SCREEN_DBGBIT(8)) return;
     uint32_t *const reg0 = p.pool + ((ublock * p.n_chunks + chunk) * UT) * (int64_t)kRegion;
     i32x4v Bn[S + 1];
     if (t_begin < t_end) {
@@ -253,7 +304,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
         i32x4v Bc[S + 1];
 #pragma unroll
         for (int s = 0; s <= S; ++s) Bc[s] = Bn[s];
-        if (t + 1 < t_end) {
+        if (t + 1 < t_end && !RBG_SCREEN_DBGBIT(4)) {
 #pragma unroll
             for (int s = 0; s <= S; ++s) Bn[s] = img[((t + 1) * (S + 1) + s) * 64];
         }
@@ -273,8 +324,9 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
             // bit (15 - r) of x = sign of acc[r]: one v_alignbit per register shifts it in
             unsigned x = 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x = __builtin_amdgcn_alignbit(x, __float_as_uint(acc[j][r]), 31);
+            for (int r = 0; r < 16; ++r) x = __builtin_amdgcn_alignbit(x, __float_as_uint(acc[j][RBG_SCREEN_DBGBIT(2) ? 0 : r]), 31);
             unsigned bits = ~x & 0xffffu;  // 1 = tst > 0 (a NaN may pass: the merge drops it)
+            if (RBG_SCREEN_DBGBIT(1)) bits = 0u;
             unsigned long long act = __builtin_amdgcn_ballot_w64(bits != 0u);
             uint32_t *reg = reg0 + j * kRegion;
             while (act != 0ull) {  // one round per entry of the lane with the most (usually one)
@@ -314,14 +366,19 @@ struct MergeParams {
     int64_t n_tiles;
     const uint32_t *pool;
     const int32_t *cnt;
+    const float *tau0;
     float *out_val;
     int64_t *out_idx;
 };
 
-// One workgroup (8 waves) per lane half of a 32-user tile = the 16 users rowmap(r, half), r = 0..15.
-template <bool VEC>
-__global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) {
-    __shared__ uint32_t s_ent[kSlab];  // item << 4 | r
+// One workgroup (16 waves) per lane half of a 32-user tile = the 16 users rowmap(r, half), r = 0..15; wave r folds user r.
+// D4 = float4 pieces of a row per lane of a 16-lane group (1: d <= 64, 2: d <= 128); E = candidates a lane group has in flight.
+constexpr int kMergeThreads = 1024;
+template <bool VEC, int D4, int E>
+__global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const MergeParams q) {
+    RBG_SCREEN_DBG_LOAD();
+    constexpr int kGroups = kMergeThreads / 16;
+    __shared__ uint32_t s_ent[kSlab];  // item << 4 | r   (~0: dropped — a history or PAD item, a row past the end)
     __shared__ float s_val[kSlab];
     __shared__ unsigned short s_perm[kSlab];
     __shared__ __attribute__((aligned(16))) float s_u[16][kUStride];
@@ -329,14 +386,16 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
     __shared__ int s_ucnt[16], s_ustart[17], s_ucur[16];
     __shared__ float s_bv[16][32];
     __shared__ int s_bi[16][32];
-    __shared__ int s_hist[16][kHS];
+    __shared__ __attribute__((aligned(16))) int s_hist[16][kHS];
     __shared__ int s_hlo[16], s_hhi[16];
+    __shared__ float s_tau[16];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int64_t tile = blockIdx.x >> 1;
     const int half = blockIdx.x & 1;
     const int64_t ublock = tile / q.ut;
     const int j = (int)(tile % q.ut);
     const int64_t b0 = tile * 32;
+    RBG_SCREEN_LAP(0);
     // candidates per chunk (an overflowed region: every pair of its chunk) -> exclusive prefix (one lane per chunk)
     if (wave == 0) {
         int c = lane < q.n_chunks ? q.cnt[((ublock * q.n_chunks + lane) * q.ut + j) * 2 + half] : 0;
@@ -354,37 +413,40 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
         s_pref[lane + 1] = incl;
         if (lane == 0) s_pref[0] = 0;
     }
-    // the 16 user rows, their history bounds, empty result lists
-    for (int f = tid; f < 16 * q.d; f += 512) {
-        const int r = f / q.d, k = f % q.d;
+    // the 16 user rows, their history rows' heads, empty result lists
+    for (int f = tid; f < 16 * 128; f += kMergeThreads) {  // (zero past d: the row walk below is guarded on the table's side only)
+        const int r = f >> 7, k = f & 127;
         const int64_t b = b0 + mfma_rowmap(r, half);
         const int64_t user = b < q.B ? q.users[b] : -1;
-        s_u[r][k] = user >= 0 ? q.U[user * (int64_t)q.d + k] : 0.f;
+        s_u[r][k] = (user >= 0 && k < q.d) ? q.U[user * (int64_t)q.d + k] : 0.f;
     }
-    s_bv[tid >> 5][tid & 31] = kNegInf, s_bi[tid >> 5][tid & 31] = 0x7fffffff;
+    if (tid < 512) s_bv[tid >> 5][tid & 31] = kNegInf, s_bi[tid >> 5][tid & 31] = 0x7fffffff;
     {
-        const int r = tid >> 5, l32 = tid & 31;  // 32 lanes per user
+        // one wave per user: its graph row's head (a probe of the binary search that leaves the staged head is a global round trip)
+        const int r = wave;
         const int64_t b = b0 + mfma_rowmap(r, half);
         const int64_t user = b < q.B ? q.users[b] : -1;
         int lo = 0, hi = 0;
         if (q.rowptr && user >= 0) lo = q.rowptr[user], hi = q.rowptr[user + 1];
         const int staged = hi - lo < kHS ? hi - lo : kHS;
-        for (int e = l32; e < staged; e += 32) s_hist[r][e] = q.col[lo + e];
-        if (l32 == 0) s_hlo[r] = lo, s_hhi[r] = hi;
+        for (int e = lane; e < staged; e += 64) s_hist[r][e] = q.col[lo + e];
+        if (lane == 0) s_hlo[r] = lo, s_hhi[r] = hi, s_tau[r] = b < q.B ? q.tau0[b] : kNegInf;
     }
     __syncthreads();
+    RBG_SCREEN_LAP(1);
+    if (RBG_SCREEN_DBGBIT(64)) return;
     const int n_ent = s_pref[kMaxChunks];
     const int grp = tid >> 4, l16 = tid & 15;
     for (int base = 0; base < n_ent; base += kSlab) {
         const int n = n_ent - base < kSlab ? n_ent - base : kSlab;
-        // a. this slab's candidates: eight threads per chunk copy (or synthesise) the entries that fall into the slab
+        // a. this slab's candidates: sixteen threads per chunk copy (or synthesise) the entries that fall into the slab
         {
-            const int c = tid >> 3, sub = tid & 7;
+            const int c = tid >> 4, sub = tid & 15;
             const int cc = s_cnt[c], cn = cc < 0 ? -cc : cc, pf = s_pref[c];
             const int o_lo = base - pf > 0 ? base - pf : 0, o_hi = base + kSlab - pf < cn ? base + kSlab - pf : cn;
             const uint32_t *reg = q.pool + ((ublock * q.n_chunks + c) * q.ut + j) * (int64_t)kRegion;
             const int64_t item_lo = (int64_t)c * q.tiles_per_chunk * 32;
-            for (int o = o_lo + sub; o < o_hi; o += 8) {
+            for (int o = o_lo + sub; o < o_hi; o += 16) {
                 uint32_t e;
                 if (cc >= 0) {
                     const uint32_t raw = reg[half ? kRegion - 1 - o : o];
@@ -397,33 +459,69 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
         }
         if (tid < 16) s_ucnt[tid] = 0;
         __syncthreads();
-        // b. exact scores: 16 lanes per candidate, eight candidates in flight per lane group
-        for (int e0 = grp * 8; e0 < n; e0 += 32 * 8) {
-            float part[8];
+        RBG_SCREEN_LAP(2);
+        // b. exact scores: 16 lanes per candidate, E candidates per lane group and round — every load of a round is issued before
+        //    the first is used (a row walk with a run-time trip count made the rows dependent round trips); the PAD item, rows
+        //    past the end and NaN scores never reach the buckets
+        for (int e0 = grp * E; e0 < n && !RBG_SCREEN_DBGBIT(16); e0 += kGroups * E) {
+            uint32_t ent[E];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const int e = e0 + x;
-                const uint32_t ent = e < n ? s_ent[e] : 0u;
-                const int64_t item = ent >> 4;
-                const int r = ent & 15u;
-                const float *row = q.I + (item < q.n_items ? item : 0) * (int64_t)q.d;
-                float a = 0.f;
-                if constexpr (VEC) {
-                    for (int c4 = l16 * 4; c4 < q.d; c4 += 64) {
-                        const float4 iv = *reinterpret_cast<const float4 *>(row + c4);
-                        const float4 uv = *reinterpret_cast<const float4 *>(&s_u[r][c4]);
-                        a = fmaf(iv.x, uv.x, a);
-                        a = fmaf(iv.y, uv.y, a);
-                        a = fmaf(iv.z, uv.z, a);
-                        a = fmaf(iv.w, uv.w, a);
-                    }
-                } else {
-                    for (int c = l16; c < q.d; c += 16) a = fmaf(row[c], s_u[r][c], a);
+            for (int x = 0; x < E; ++x) ent[x] = e0 + x < n ? s_ent[e0 + x] : 0u;
+            float part[E];
+            bool drop[E];
+            auto history = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int x = 0; x < E; ++x) {
+                    const int item = (int)(ent[x] >> 4);
+                    drop[x] = item == 0 || item >= q.n_items;
                 }
-                part[x] = a;
+            };
+            if constexpr (VEC) {
+                float4 iv[E][D4];
+#pragma unroll
+                for (int x = 0; x < E; ++x) {
+                    const int64_t item = ent[x] >> 4;
+                    const float *row = q.I + (item < q.n_items ? item : 0) * (int64_t)q.d;
+#pragma unroll
+                    for (int m = 0; m < D4; ++m) {
+                        const int c4 = l16 * 4 + 64 * m;
+                        iv[x][m] = c4 < q.d ? *reinterpret_cast<const float4 *>(row + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+                history();
+#pragma unroll
+                for (int x = 0; x < E; ++x) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int m = 0; m < D4; ++m) {
+                        const float4 uv = *reinterpret_cast<const float4 *>(&s_u[ent[x] & 15u][l16 * 4 + 64 * m]);  // (zero past d)
+                        a = fmaf(iv[x][m].x, uv.x, a);
+                        a = fmaf(iv[x][m].y, uv.y, a);
+                        a = fmaf(iv[x][m].z, uv.z, a);
+                        a = fmaf(iv[x][m].w, uv.w, a);
+                    }
+                    part[x] = a;
+                }
+            } else {
+                float iv[E][D4 * 4];
+#pragma unroll
+                for (int x = 0; x < E; ++x) {
+                    const int64_t item = ent[x] >> 4;
+                    const float *row = q.I + (item < q.n_items ? item : 0) * (int64_t)q.d;
+#pragma unroll
+                    for (int m = 0; m < D4 * 4; ++m) iv[x][m] = l16 + 16 * m < q.d ? row[l16 + 16 * m] : 0.f;
+                }
+                history();
+#pragma unroll
+                for (int x = 0; x < E; ++x) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int m = 0; m < D4 * 4; ++m) a = fmaf(iv[x][m], s_u[ent[x] & 15u][l16 + 16 * m], a);
+                    part[x] = a;
+                }
             }
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < E; ++x) {
                 float a = part[x];
                 a += __shfl_xor(a, 8);
                 a += __shfl_xor(a, 4);
@@ -431,12 +529,18 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
                 a += __shfl_xor(a, 1);
                 const int e = e0 + x;
                 if (l16 == 0 && e < n) {
-                    s_val[e] = a;
-                    atomicAdd(&s_ucnt[s_ent[e] & 15u], 1);
+                    // tau <= the user's k-th best valid exact score: what the margins let in below it is not sorted
+                    if (drop[x] || !(a >= s_tau[ent[x] & 15u])) {
+                        s_ent[e] = ~0u;
+                    } else {
+                        s_val[e] = a;
+                        atomicAdd(&s_ucnt[ent[x] & 15u], 1);
+                    }
                 }
             }
         }
         __syncthreads();
+        RBG_SCREEN_LAP(3);
         // c. buckets by user
         if (wave == 0) {
             const int c = lane < 16 ? s_ucnt[lane] : 0;
@@ -453,47 +557,54 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
             if (lane == 0) s_ustart[0] = 0;
         }
         __syncthreads();
-        for (int e = tid; e < n; e += 512) {
-            const int pos = atomicAdd(&s_ucur[s_ent[e] & 15u], 1);
-            s_perm[pos] = (unsigned short)e;
-        }
-        __syncthreads();
-        // d. every wave folds the buckets of its two users into their best 32 (lower half-wave: best so far; upper: arrivals;
-        //    a user's first batch fills all 64 lanes)
-        for (int x = 0; x < 2; ++x) {
-            const int r = wave * 2 + x;
-            const int r_lo = s_ustart[r], r_hi = s_ustart[r + 1];
-            if (r_lo == r_hi) continue;
-            HistRow hist;
-            hist.col = (const __attribute__((address_space(1))) int32_t *)q.col;
-            hist.lds = s_hist[r];
-            hist.lo = s_hlo[r], hist.hi = s_hhi[r];
-            hist.staged = hist.hi - hist.lo < kHS ? hist.hi - hist.lo : kHS;
-            hist.n_users = q.n_users;
-            float v = lane < 32 ? s_bv[r][lane] : kNegInf;
-            int idx = lane < 32 ? s_bi[r][lane] : 0x7fffffff;
-            int first = base == 0 ? 0 : 32;  // lanes >= first take arrivals in the first round
-            for (int r0 = r_lo; r0 < r_hi; r0 += 64 - first, first = 32) {
-                if (lane >= first) {
-                    const int rr = r0 + lane - first;
-                    if (rr < r_hi) {
-                        const int e = s_perm[rr];
-                        const int item = (int)(s_ent[e] >> 4);
-                        const float sc = s_val[e];
-                        const bool drop = item == 0 || item >= q.n_items || !(sc == sc) || hist.has(item);
-                        v = drop ? kNegInf : sc;
-                        idx = drop ? 0x7fffffff : item;
-                    }
-                }
-                wave_sort_desc(v, idx, lane);
-                if (lane >= 32) v = kNegInf, idx = 0x7fffffff;
+        for (int e = tid; e < n; e += kMergeThreads) {
+            const uint32_t ent = s_ent[e];
+            if (ent != ~0u) {
+                const int pos = atomicAdd(&s_ucur[ent & 15u], 1);
+                s_perm[pos] = (unsigned short)e;
             }
-            if (lane < 32) s_bv[r][lane] = v, s_bi[r][lane] = idx;
         }
         __syncthreads();
+        RBG_SCREEN_LAP(4);
+        // d. wave r folds the bucket of user r into its best 32 (lower half-wave: best so far; upper: arrivals; a user's first
+        //    batch fills all 64 lanes)
+        {
+            const int r = wave;
+            const int r_lo = s_ustart[r], r_hi = s_ustart[r + 1];
+            if (r_lo != r_hi && !RBG_SCREEN_DBGBIT(32)) {
+                HistRow hist;
+                hist.col = (const __attribute__((address_space(1))) int32_t *)q.col;
+                hist.lds = s_hist[r];
+                hist.lo = s_hlo[r], hist.hi = s_hhi[r];
+                hist.staged = hist.hi - hist.lo < kHS ? hist.hi - hist.lo : kHS;
+                hist.n_users = q.n_users;
+                float v = lane < 32 ? s_bv[r][lane] : kNegInf;
+                int idx = lane < 32 ? s_bi[r][lane] : 0x7fffffff;
+                int first = base == 0 ? 0 : 32;  // lanes >= first take arrivals in the first round
+                for (int r0 = r_lo; r0 < r_hi; r0 += 64 - first, first = 32) {
+                    if (lane >= first) {
+                        const int rr = r0 + lane - first;
+                        if (rr < r_hi) {
+                            const int e = s_perm[rr];
+                            const int item = (int)(s_ent[e] >> 4);
+                            // (every arrival of the round searches at once.  Scanning short rows whole with independent broadcast
+                            //  reads instead was measured slower: 37.6 vs 30.7 us per launch)
+                            const bool hdrop = !RBG_SCREEN_DBGBIT(128) && hist.has(item);
+                            v = hdrop ? kNegInf : s_val[e];
+                            idx = hdrop ? 0x7fffffff : item;
+                        }
+                    }
+                    if (!RBG_SCREEN_DBGBIT(256)) wave_sort_desc_dpp(v, idx, lane);
+                    if (lane >= 32) v = kNegInf, idx = 0x7fffffff;
+                }
+                if (lane < 32) s_bv[r][lane] = v, s_bi[r][lane] = idx;
+            }
+        }
+        __syncthreads();
+        RBG_SCREEN_LAP(5);
     }
-    for (int x = 0; x < 2; ++x) {
-        const int r = wave * 2 + x;
+    {
+        const int r = wave;
         const int64_t b = b0 + mfma_rowmap(r, half);
         if (b < q.B && lane < q.k) {
             const int idx = s_bi[r][lane];
@@ -501,6 +612,11 @@ __global__ __launch_bounds__(512) void screen_merge_kernel(const MergeParams q) 
             q.out_idx[b * q.k + lane] = idx == 0x7fffffff ? -1 : (int64_t)idx;
         }
     }
+    RBG_SCREEN_LAP(6);
+    if (threadIdx.x == 0 && RBG_SCREEN_DBGBIT(512)) ((volatile int *)s_cnt)[0] = n_ent;
+#ifdef RBG_SCREEN_DBG
+    if (g_screen_trace && threadIdx.x == 0) g_screen_trace[(int64_t)blockIdx.x * 16 + 7] = (unsigned long long)n_ent;
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -518,7 +634,9 @@ static ScreenLayout layout_for(int64_t B, int64_t n_items, int ut) {
     L.nc = (int)((L.n_tiles + L.tpc - 1) / std::max(L.tpc, 1));
     L.image_off = 0;
     const int64_t image_bytes = L.n_tiles * 9 * 1024;  // (sized for d <= 128: eight product fragments + the bound fragment)
-    L.pool_off = L.image_off + (image_bytes + 255) / 256 * 256;
+    L.uimage_off = L.image_off + (image_bytes + 255) / 256 * 256;
+    const int64_t uimage_bytes = ((B + 31) / 32 + 8) * 9 * 1024;  // (+ the tiles a partial last user block reads past the batch)
+    L.pool_off = L.uimage_off + uimage_bytes;
     const int64_t regions = (int64_t)L.n_ublocks * L.nc * ut;
     L.cnt_off = L.pool_off + regions * kRegion * 4;
     L.bytes = (L.cnt_off + regions * 8 + 255) / 256 * 256;
@@ -549,22 +667,20 @@ static bool rows_vec(const ScreenCall &c) {
 int screen_prepass(const ScreenCall &c, hipStream_t s) {
     const ScreenLayout L = layout_for(c.B, c.n_items, screen_ut(c.d));
     const bool vec = rows_vec(c);
-    char *image = c.w + L.image_off;
-    const unsigned img_blocks = (unsigned)((L.n_tiles + 3) / 4);
+    char *image = c.w + L.image_off, *uimage = c.w + L.uimage_off;
+    const unsigned img_blocks = (unsigned)((L.n_tiles + (c.B + 31) / 32 + 3) / 4);  // item tiles, then the batch's user tiles
     if (c.d <= 64) {
-        if (vec) hipLaunchKernelGGL((screen_image_kernel<4, true>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image);
-        else hipLaunchKernelGGL((screen_image_kernel<4, false>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image);
+        if (vec) hipLaunchKernelGGL((screen_image_kernel<4, true>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image, c.U, c.users, c.B, uimage);
+        else hipLaunchKernelGGL((screen_image_kernel<4, false>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image, c.U, c.users, c.B, uimage);
     } else {
-        if (vec) hipLaunchKernelGGL((screen_image_kernel<8, true>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image);
-        else hipLaunchKernelGGL((screen_image_kernel<8, false>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image);
+        if (vec) hipLaunchKernelGGL((screen_image_kernel<8, true>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image, c.U, c.users, c.B, uimage);
+        else hipLaunchKernelGGL((screen_image_kernel<8, false>), dim3(img_blocks), dim3(256), 0, s, c.I, c.n_items, L.n_tiles, c.d, image, c.U, c.users, c.B, uimage);
     }
     RBG_HIP(hipGetLastError());
     ScreenParams p{};
-    p.U = c.U;
-    p.users = c.users;
     p.B = c.B;
-    p.d = c.d;
     p.image = image;
+    p.uimage = uimage;
     p.tiles_per_chunk = c.tpc_s;
     p.n_chunks = c.splits;
     p.tile_lo = 0;
@@ -572,13 +688,8 @@ int screen_prepass(const ScreenCall &c, hipStream_t s) {
     p.g_val = c.pre_val;
     p.g_idx = c.pre_idx;
     const dim3 grid((unsigned)c.splits, (unsigned)(((c.B + 31) / 32 + 3) / 4));
-    if (c.d <= 64) {
-        if (vec) hipLaunchKernelGGL((screen_pre_kernel<4, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((screen_pre_kernel<4, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((screen_pre_kernel<8, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((screen_pre_kernel<8, false>), grid, dim3(256), 0, s, p);
-    }
+    if (c.d <= 64) hipLaunchKernelGGL((screen_pre_kernel<4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((screen_pre_kernel<8>), grid, dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
@@ -587,11 +698,9 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     const ScreenLayout L = layout_for(c.B, c.n_items, screen_ut(c.d));
     const bool vec = rows_vec(c);
     ScreenParams p{};
-    p.U = c.U;
-    p.users = c.users;
     p.B = c.B;
-    p.d = c.d;
     p.image = c.w + L.image_off;
+    p.uimage = c.w + L.uimage_off;
     p.tiles_per_chunk = L.tpc;
     p.n_chunks = L.nc;
     p.tile_lo = 0;
@@ -600,13 +709,8 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     p.pool = reinterpret_cast<uint32_t *>(c.w + L.pool_off);
     p.cnt = reinterpret_cast<int32_t *>(c.w + L.cnt_off);
     const dim3 grid((unsigned)L.nc, (unsigned)((L.n_ublocks + 3) / 4));
-    if (c.d <= 64) {
-        if (vec) hipLaunchKernelGGL((screen_main_kernel<4, kUt64, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((screen_main_kernel<4, kUt64, false>), grid, dim3(256), 0, s, p);
-    } else {
-        if (vec) hipLaunchKernelGGL((screen_main_kernel<8, kUt128, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((screen_main_kernel<8, kUt128, false>), grid, dim3(256), 0, s, p);
-    }
+    if (c.d <= 64) hipLaunchKernelGGL((screen_main_kernel<4, kUt64>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((screen_main_kernel<8, kUt128>), grid, dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
     MergeParams q{};
     q.U = c.U;
@@ -625,11 +729,17 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     q.n_tiles = L.n_tiles;
     q.pool = p.pool;
     q.cnt = p.cnt;
+    q.tau0 = c.tau0;
     q.out_val = c.out_val;
     q.out_idx = c.out_idx;
     const unsigned halves = 2u * (unsigned)((c.B + 31) / 32);
-    if (vec) hipLaunchKernelGGL((screen_merge_kernel<true>), dim3(halves), dim3(512), 0, s, q);
-    else hipLaunchKernelGGL((screen_merge_kernel<false>), dim3(halves), dim3(512), 0, s, q);
+    if (c.d <= 64) {
+        if (vec) hipLaunchKernelGGL((screen_merge_kernel<true, 1, 8>), dim3(halves), dim3(kMergeThreads), 0, s, q);
+        else hipLaunchKernelGGL((screen_merge_kernel<false, 1, 8>), dim3(halves), dim3(kMergeThreads), 0, s, q);
+    } else {
+        if (vec) hipLaunchKernelGGL((screen_merge_kernel<true, 2, 4>), dim3(halves), dim3(kMergeThreads), 0, s, q);
+        else hipLaunchKernelGGL((screen_merge_kernel<false, 2, 4>), dim3(halves), dim3(kMergeThreads), 0, s, q);
+    }
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }
