@@ -339,11 +339,25 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
         tk_us = ex["full_sort_topk_us(4096 users, k 10, history masked)"]
         if isinstance(ex.get("full_sort_topk_graph_replay_us"), float):
             tk_us = min(tk_us, ex["full_sort_topk_graph_replay_us"])  # (the device's share is what the roofline prices)
-        tk_flop = 2.0 * bq * ni * d  # the product the top-k needs; it runs as 3 bf16 x bf16 products on split operands (fp32-grade)
-        ex["topk_roofline"] = {"bound": "mfma", "flop": tk_flop, "achieved": tk_flop / (tk_us * 1e-6) / 1e12, "peak": 2500.0 / 3, "unit": "TFLOP/s",
-                               "frac": tk_flop / (tk_us * 1e-6) / 1e12 / (2500.0 / 3),
-                               "note": "fp32-equivalent flops 2 B n d against a third of the dense bf16 MFMA peak (each product is three bf16 "
-                                       "MFMA products on split operands); writes nothing but [B, k]: the [B, n] matrix never exists"}
+        tk_flop = 2.0 * bq * ni * d  # the product the top-k needs
+        screened = bool(rbg.get_option("topk_screen")) and d <= 128
+        # r06: behind the screen (csrc/topk_screen.hip) every pair costs ONE bf16 product (+ 1/4 of one for the bound): the peak is the
+        # dense bf16 MFMA peak; the exact passes ran three products on split operands per fp32-grade product (peak / 3)
+        tk_peak = 2500.0 if screened else 2500.0 / 3
+        ex["topk_roofline"] = {"bound": "mfma", "flop": tk_flop, "achieved": tk_flop / (tk_us * 1e-6) / 1e12, "peak": tk_peak, "unit": "TFLOP/s",
+                               "frac": tk_flop / (tk_us * 1e-6) / 1e12 / tk_peak, "screened": screened,
+                               "note": ("one bf16 x bf16 product per (user, item) pair with a rigorous error bound screens the call, the ~ 75 survivors "
+                                        "per user are rescored exactly in fp32 (option topk_screen); flops 2 B n d against the dense bf16 MFMA peak; "
+                                        "the call is five launches (image, pre-pass, thresholds, screen, rescoring merge) of which the screen is ~ 40 %"
+                                        if screened else
+                                        "fp32-equivalent flops 2 B n d against a third of the dense bf16 MFMA peak (each product is three bf16 "
+                                        "MFMA products on split operands)") + "; writes nothing but [B, k]: the [B, n] matrix never exists"}
+        if screened:  # the exact passes beside it (what r05 measured as the top-k)
+            rbg.set_option("topk_screen", 0)
+            try:
+                ex["full_sort_topk_exact_passes_us"] = time_us(lambda: model.full_sort_topk({"user_id": users}, 10), iters=10, warm=2)
+            finally:
+                rbg.set_option("topk_screen", 1)
     fused = rbg.FusedBPRAdam(model, lr=1e-3)
     ex["train_step_fused_us(batch 2048, fwd + BPR + bwd + Adam)"] = time_us(lambda: fused.step(batch))
     rbg.set_option("deterministic", 1)  # the same step with ordered row scatters and fixed-point sums (bit-stable; csrc/ordered.h)

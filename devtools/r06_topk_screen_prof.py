@@ -22,7 +22,8 @@ with torch.no_grad():
     ue, ie = model.forward()
 if BITS:
     assert rbg._lib.lib.mb_screen_debug_set(BITS) == 0
-users = torch.randint(1, nu, (4096,), generator=torch.Generator().manual_seed(1)).to(dev)
+NB = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+users = torch.randint(1, nu, (NB,), generator=torch.Generator().manual_seed(1)).to(dev)
 for _ in range(20):
     rbg.full_sort_topk(model.graph, ue, ie, users, 10)
 torch.cuda.synchronize()

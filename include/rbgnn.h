@@ -125,6 +125,13 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   two; a tile's arrivals that do not fit are appended in rounds with a prune between): 1 (default) from
  *                   2048 users, 2 always, 0 never.  Same results.
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
+ *   "topk_screen" : 1 (default) = rbg_full_sort_topk_f32 at d <= 128, B >= 1024, more than 2 x "topk_sample" items screens every
+ *                   (user, item) pair with ONE bf16 x bf16 product and a rigorous bound of its error on the matrix core
+ *                   (|s - s^| <= 1.03 x 2^-8 ||u|| ||i||: no pair that can be in the top k is dropped) and rescoring the ~ k n /
+ *                   sample survivors per user exactly in fp32 (csrc/topk_screen.hip; r06: 4096 users x 40 982 items 188 -> 92 us
+ *                   per call at d = 64, 394 -> 128 us at d = 128); 2 = for any batch size; 0 = the exact passes on 3-way split
+ *                   operands for every pair.  Same items wherever two scores are not equal to the last bit; values agree to
+ *                   ~ 1e-7 relative (the rescoring sums in a different order than the split products).
  *   "topk_image"  : 1 (default) = rbg_full_sort_topk_f32 at 64 < d <= 128, B >= 1024 splits the item table ONCE per call into three
  *                   bf16 planes stored tile by tile in the LDS layout (in the workspace) and both passes take their item tiles from
  *                   it by LDS-DMA (r06: 430 -> 394 us per call at 4096 users x 40 982 items x 128; at d <= 64 the per-workgroup
@@ -504,7 +511,8 @@ int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, c
  * `history` is the TRAINING graph handle (a user's history = its graph row; NULL = no history mask).
  * out_val [B, k] fp32 descending, out_idx [B, k] int64 item ids (-1 / -inf when fewer than k items remain).
  * Ties are broken towards the smaller item id.  k <= 32, d <= 256.  `workspace`: device buffer of at least
- * rbg_full_sort_topk_workspace(B, n_items, k) bytes. */
+ * rbg_full_sort_topk_workspace(B, n_items, k) bytes (r06: includes the screen's bf16 image of the item table, 288 bytes per
+ * item, and its candidate pool, ~ 4 KB per user — option "topk_screen"). */
 int rbg_full_sort_topk_workspace(int64_t B, int64_t n_items, int k, int64_t *bytes);
 int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, const float *item_all, const int64_t *users,
                            int64_t B, int64_t n_users, int64_t n_items, int d, int k, float *out_val, int64_t *out_idx,

@@ -787,18 +787,19 @@ int rbg_full_sort_topk_f32(const rbg_graph *history, const float *user_all, cons
     // r06: ONE bf16 product per pair screens the call, the survivors are rescored exactly (topk_screen.hip; measured:
     // profiles/r06_topk_screen.jsonl); the exact passes below stay for what it does not take (small batches and item sets,
     // d > 128, option "topk_screen" 0)
-    if (prepass && L.tpc_s <= 256 && screen_applicable(B, n_items, d, k)) {  // (the pre-pass keeps a tile index in 8 bits)
+    if (prepass && L.sample_tiles <= 16 * 256 && screen_applicable(B, n_items, d, k)) {  // (the pre-pass keeps a tile index in 8 bits)
         ScreenCall c{};
         c.U = user_all, c.I = item_all, c.users = users, c.rowptr = rp, c.col = cl;
         c.n_users = n_users, c.n_items = n_items, c.B = B, c.d = d, c.k = k;
         c.w = w + (L.bytes + 255) / 256 * 256;
-        c.pre_val = pre_val, c.pre_idx = pre_idx, c.splits = L.splits, c.tpc_s = L.tpc_s, c.sample_tiles = L.sample_tiles;
-        c.tau0 = tau0, c.out_val = out_val, c.out_idx = out_idx;
+        // (the screen's threshold kernel folds at most 16 x 32 slot maxima per user)
+        c.splits = std::min(L.splits, 16);
+        c.tpc_s = (int)((L.sample_tiles + c.splits - 1) / c.splits);
+        c.splits = (int)((L.sample_tiles + c.tpc_s - 1) / c.tpc_s);
+        c.pre_val = pre_val, c.pre_idx = pre_idx, c.sample_tiles = L.sample_tiles;
+        c.tau0 = tau0, c.out_val = out_val, c.out_idx = out_idx;  // (tau0: the screen's own threshold kernel writes it)
         int rc = screen_prepass(c, s);
         if (rc) return rc;
-        hipLaunchKernelGGL(topk_tau_kernel, dim3(merge_blocks), dim3(256), 0, s, pre_val, pre_idx, users, rp, cl, n_users, B,
-                           L.splits, k, tau0);
-        RBG_HIP(hipGetLastError());
         return screen_main(c, s);
     }
     // r06: the item table as bf16 planes in the LDS layout, once per call (both passes take their tiles from it by LDS-DMA)

@@ -26,13 +26,13 @@ struct ScreenCall {
     int32_t *pre_idx;     // ... and their items
     int splits, tpc_s;    // pre-pass geometry: `splits` chunks of `tpc_s` tiles over the first sample_tiles tiles
     int64_t sample_tiles;
-    const float *tau0;    // [B] the bound the main pass screens against (written by the caller's threshold kernel between the two calls)
+    float *tau0;          // [B] the bound the main pass screens against (workspace: screen_main's threshold kernel writes it)
     float *out_val;
     int64_t *out_idx;
 };
 // image + pre-pass (fills pre_val / pre_idx)
 int screen_prepass(const ScreenCall &c, hipStream_t s);
-// main pass + rescoring merge (fills out_val / out_idx)
+// thresholds + main pass + rescoring merge (fills out_val / out_idx)
 int screen_main(const ScreenCall &c, hipStream_t s);
 
 }  // namespace rbg

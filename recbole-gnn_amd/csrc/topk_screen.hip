@@ -20,8 +20,8 @@
 //          halves (= two sets of 16 users) fill a region from its two ends.
 //   pass 3 (screen_merge_kernel): one workgroup per 16 users (one lane half of a tile) gathers its regions, rescoring every
 //          candidate exactly in fp32 (16 lanes per candidate, eight candidates in flight, the item row read from the fp32 table),
-//          buckets them by user, drops history items (one 64-lane-parallel search of the staged graph row per batch) and folds
-//          them into the user's best 32 by the same bitonic network and the same total order as topk.hip, one wave per user.
+//          drops history items (one thread per candidate searches the user's graph row, staged in LDS), buckets the rest by
+//          user and folds them into the user's best 32 by the same bitonic network and the same total order as topk.hip, one wave per user.
 // No workgroup shares anything in passes 1 and 2: a wave keeps the bf16 rows of UT x 32 users as A fragments (16 registers per
 // 32 users at d <= 64 — the split operands of the exact pass take 48) and reads its B fragments straight from an image of the
 // item table laid out per tile as [fragment][lane][16 bytes] (1 KiB coalesced wave loads, L1 / L2 resident: 5 KiB per tile), so
@@ -48,7 +48,7 @@ constexpr float kPreEps = kScreenEps + 6.2e-5f;  // (the pre-pass: see screen_pr
 constexpr int kRegion = 512;   // entries of one (user block, chunk, user tile) region of the pool
 constexpr int kSlab = 4096;    // candidates a merge workgroup holds in LDS at a time
 constexpr int kMaxChunks = 64;
-constexpr int kHS = 512;       // history columns staged per user in the merge kernel (longer rows: the tail is searched in global memory)
+constexpr int kHPool = 8192;   // history columns the merge kernel stages for its 16 users together (256 each, the rest to the long rows in turn)
 constexpr int kUStride = 132;  // floats per staged user row (d <= 128)
 constexpr int kUt64 = 2, kUt128 = 2;  // 32-user tiles a wave of the main pass keeps (d <= 64 / d <= 128)
 constexpr int kWantWaves = 4096;      // waves the main pass aims for (user blocks x item chunks)
@@ -250,6 +250,74 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     }
 }
 
+// ---- thresholds: tau_u = the k-th largest slot maximum of user u that is not a history item, over ALL splits x 32 slots -------
+// (topk.hip's threshold kernel folds the splits to 32 slot maxima first and searches the user's history for those 32: a user whose
+// best sample items ARE its history — every trained model has them — loses slots to history items and ends without a bound; the
+// exact passes then start at -inf and prune their way up, the screen cannot.)  Here the history is walked instead: a history item
+// inside the sample belongs to exactly one slot (its split and its lane), so one look-up says whether it is that slot's maximum.
+// Every lane then folds its eight slots and the k-th largest of the 64 lane maxima is the bound (one sort).  Fewer than k lanes with
+// a valid slot: tau = +inf = "no bound" (the merge takes every item for that user).
+__global__ __launch_bounds__(256) void screen_tau_kernel(const float *__restrict__ g_val, const int32_t *__restrict__ g_idx,
+                                                         const int64_t *__restrict__ users, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ col, int64_t n_users, int64_t B, int splits,
+                                                         int tpc_s, int64_t sample_items, int k, float *__restrict__ tau_out) {
+    __shared__ unsigned s_bad[4][16];  // one bit per slot (splits <= 16)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const int total = splits * 32;
+    if (lane < 16) s_bad[wave][lane] = 0u;
+    const int64_t user = users[b];
+    int lo = 0, hi = 0;
+    if (rowptr && user >= 0) lo = rowptr[user], hi = rowptr[user + 1];
+    float val[8];
+    int idx[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int e = lane + 64 * t;
+        val[t] = e < total ? g_val[b * total + e] : kNegInf;
+        idx[t] = e < total ? g_idx[b * total + e] : 0x7fffffff;
+    }
+    // the row is sorted: its history items inside the sample are a prefix; four loads in flight, stop at the first batch past it
+    for (int e0 = lo; e0 < hi; e0 += 256) {
+        int64_t it[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 64 * u + lane;
+            it[u] = e < hi ? (int64_t)col[e] - n_users : sample_items;
+        }
+        int hit[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = it[u] >= 0 && it[u] < sample_items;
+            const int slot = in ? (int)((it[u] >> 5) / tpc_s) * 32 + (int)(it[u] & 31) : 0;
+            hit[u] = (in && slot < total) ? g_idx[b * total + slot] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int slot = (int)((it[u] >> 5) / tpc_s) * 32 + (int)(it[u] & 31);
+            if (hit[u] >= 0 && hit[u] == (int)it[u]) atomicOr(&s_bad[wave][slot >> 5], 1u << (slot & 31));
+        }
+        if (__ballot(it[3] < sample_items) == 0ull) break;  // (every lane's last column is past the sample)
+    }
+    __builtin_amdgcn_wave_barrier();
+    // every lane folds its (up to) eight valid slots; the k-th largest of the 64 lane maxima — distinct items, a subset of the valid
+    // slot maxima — is <= the k-th largest of them all: one 64-lane sort instead of a selection over 512 values
+    float m = kNegInf;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int e = lane + 64 * t;
+        const bool bad = e >= total || idx[t] == 0x7fffffff || !(val[t] > -1.0e37f) || ((s_bad[wave][(e >> 5) & 15] >> (e & 31)) & 1u);
+        if (!bad && better(val[t], idx[t], m, mi)) m = val[t], mi = idx[t];
+    }
+    wave_sort_desc_dpp(m, mi, lane);
+    const float kth = __shfl(m, k - 1);
+    const int kth_i = __shfl(mi, k - 1);
+    const float tau = kth_i == 0x7fffffff ? __builtin_inff() : kth;  // fewer than k lanes with a valid slot: no bound
+    if (lane == 0) tau_out[b] = tau;
+}
+
 // ---- pass 2: every item against tau; passing (item, row) pairs go to the wave's regions -----------------------------------------
 template <int S, int UT>
 __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) {
@@ -289,9 +357,11 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
     int n_lo[UT], n_hi[UT];  // entries of the two lane halves in region j (wave-uniform: scalar registers)
 #pragma unroll
     for (int j = 0; j < UT; ++j) n_lo[j] = n_hi[j] = 0;
+    // chunk c takes the item tiles c, c + n_chunks, c + 2 n_chunks, ... : item ids are often ordered by popularity, and the popular
+    // items are most users' candidates — in contiguous chunks they all met in the first chunk's regions, which overflowed
+    // (the bench's trained tables: 12 regions, each a 10 752-pair exhaustive scan in the merge)
     const int chunk = blockIdx.x;
-    const int64_t t_begin = p.tile_lo + (int64_t)chunk * p.tiles_per_chunk;
-    const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
+    const int64_t t_begin = chunk, t_end = p.tile_hi, t_step = p.n_chunks;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
     if (RBG_SCREEN_DBGBIT(8)) return;
     uint32_t *const reg0 = p.pool + ((ublock * p.n_chunks + chunk) * UT) * (int64_t)kRegion;
@@ -300,13 +370,13 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
 #pragma unroll
         for (int s = 0; s <= S; ++s) Bn[s] = img[(t_begin * (S + 1) + s) * 64];
     }
-    for (int64_t t = t_begin; t < t_end; ++t) {
+    for (int64_t t = t_begin; t < t_end; t += t_step) {
         i32x4v Bc[S + 1];
 #pragma unroll
         for (int s = 0; s <= S; ++s) Bc[s] = Bn[s];
-        if (t + 1 < t_end && !RBG_SCREEN_DBGBIT(4)) {
+        if (t + t_step < t_end && !RBG_SCREEN_DBGBIT(4)) {
 #pragma unroll
-            for (int s = 0; s <= S; ++s) Bn[s] = img[((t + 1) * (S + 1) + s) * 64];
+            for (int s = 0; s <= S; ++s) Bn[s] = img[((t + t_step) * (S + 1) + s) * 64];
         }
         f32x16 acc[UT];
 #pragma unroll
@@ -386,9 +456,10 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
     __shared__ int s_ucnt[16], s_ustart[17], s_ucur[16];
     __shared__ float s_bv[16][32];
     __shared__ int s_bi[16][32];
-    __shared__ __attribute__((aligned(16))) int s_hist[16][kHS];
-    __shared__ int s_hlo[16], s_hhi[16];
+    __shared__ int s_hpool[kHPool];
+    __shared__ int s_hlo[16], s_hhi[16], s_hoff[16], s_hstaged[16];
     __shared__ float s_tau[16];
+    __shared__ int s_exh[16], s_nexh;  // users without a bound (tau = +inf from the threshold kernel): every item is their candidate
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int64_t tile = blockIdx.x >> 1;
     const int half = blockIdx.x & 1;
@@ -400,8 +471,8 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
     if (wave == 0) {
         int c = lane < q.n_chunks ? q.cnt[((ublock * q.n_chunks + lane) * q.ut + j) * 2 + half] : 0;
         if (c < 0) {
-            const int64_t lo = (int64_t)lane * q.tiles_per_chunk, hi = lo + q.tiles_per_chunk < q.n_tiles ? lo + q.tiles_per_chunk : q.n_tiles;
-            c = -(int)((hi - lo) * 32 * 16);  // (kept negative: the loader below synthesises the pairs)
+            const int64_t tiles_c = (q.n_tiles - lane + q.n_chunks - 1) / q.n_chunks;  // tiles lane, lane + n_chunks, ...
+            c = -(int)(tiles_c * 32 * 16);  // (kept negative: the loader below synthesises the pairs)
         }
         s_cnt[lane] = c;
         int incl = c < 0 ? -c : c;
@@ -421,21 +492,51 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
         s_u[r][k] = (user >= 0 && k < q.d) ? q.U[user * (int64_t)q.d + k] : 0.f;
     }
     if (tid < 512) s_bv[tid >> 5][tid & 31] = kNegInf, s_bi[tid >> 5][tid & 31] = 0x7fffffff;
-    {
-        // one wave per user: its graph row's head (a probe of the binary search that leaves the staged head is a global round trip)
-        const int r = wave;
-        const int64_t b = b0 + mfma_rowmap(r, half);
-        const int64_t user = b < q.B ? q.users[b] : -1;
+    if (wave == 0) {
+        // the 16 history rows share one pool: 256 columns each, what is left goes to the long rows in turn (a hub's whole row is
+        // searched in LDS; only beyond the pool does a probe of the search leave for global memory)
         int lo = 0, hi = 0;
-        if (q.rowptr && user >= 0) lo = q.rowptr[user], hi = q.rowptr[user + 1];
-        const int staged = hi - lo < kHS ? hi - lo : kHS;
-        for (int e = lane; e < staged; e += 64) s_hist[r][e] = q.col[lo + e];
-        if (lane == 0) s_hlo[r] = lo, s_hhi[r] = hi, s_tau[r] = b < q.B ? q.tau0[b] : kNegInf;
+        if (lane < 16) {
+            const int64_t b = b0 + mfma_rowmap(lane, half);
+            const int64_t user = b < q.B ? q.users[b] : -1;
+            if (q.rowptr && user >= 0) lo = q.rowptr[user], hi = q.rowptr[user + 1];
+            s_tau[lane] = b < q.B ? q.tau0[b] : kNegInf;
+        }
+        const int len = hi - lo;
+        int st = len < 256 ? len : 256;
+        int left = kHPool - 16 * 256;
+        for (int r = 0; r < 16; ++r) {  // (wave-uniform: 16 short rounds)
+            const int want = __shfl(len - st, r);
+            const int give = want < left ? want : left;
+            left -= give;
+            if (lane == r) st += give;
+        }
+        int incl = lane < 16 ? st : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane < 16) s_hlo[lane] = lo, s_hhi[lane] = hi, s_hstaged[lane] = st, s_hoff[lane] = incl - st;
+    }
+    __syncthreads();
+    {
+        const int r = wave;  // one wave per user
+        const int lo = s_hlo[r], st = s_hstaged[r], off = s_hoff[r];
+        for (int e = lane; e < st; e += 64) s_hpool[off + e] = q.col[lo + e];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int ne = 0;
+        for (int r = 0; r < 16; ++r)
+            if (s_tau[r] == __builtin_inff()) s_exh[ne++] = r, s_tau[r] = kNegInf;
+        s_nexh = ne;
     }
     __syncthreads();
     RBG_SCREEN_LAP(1);
     if (RBG_SCREEN_DBGBIT(64)) return;
-    const int n_ent = s_pref[kMaxChunks];
+    const int n_reg = s_pref[kMaxChunks];  // candidates of the regions; behind them: every item for each user without a bound
+    const int n_ent = n_reg + s_nexh * (int)q.n_items;
     const int grp = tid >> 4, l16 = tid & 15;
     for (int base = 0; base < n_ent; base += kSlab) {
         const int n = n_ent - base < kSlab ? n_ent - base : kSlab;
@@ -445,17 +546,22 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
             const int cc = s_cnt[c], cn = cc < 0 ? -cc : cc, pf = s_pref[c];
             const int o_lo = base - pf > 0 ? base - pf : 0, o_hi = base + kSlab - pf < cn ? base + kSlab - pf : cn;
             const uint32_t *reg = q.pool + ((ublock * q.n_chunks + c) * q.ut + j) * (int64_t)kRegion;
-            const int64_t item_lo = (int64_t)c * q.tiles_per_chunk * 32;
+
             for (int o = o_lo + sub; o < o_hi; o += 16) {
                 uint32_t e;
                 if (cc >= 0) {
                     const uint32_t raw = reg[half ? kRegion - 1 - o : o];
                     e = ((raw >> 5) << 4) | (raw & 15u);
                 } else {
-                    e = ((uint32_t)(item_lo + (o >> 4)) << 4) | (uint32_t)(o & 15);
+                    const int p = o >> 4;  // pair p of the chunk: tile c + (p >> 5) n_chunks, item p & 31 of it
+                    e = ((uint32_t)(((int64_t)c + (int64_t)(p >> 5) * q.n_chunks) * 32 + (p & 31)) << 4) | (uint32_t)(o & 15);
                 }
                 s_ent[pf + o - base] = e;
             }
+        }
+        for (int g = (base > n_reg ? base : n_reg) + tid; g < base + n; g += kMergeThreads) {
+            const int o = g - n_reg, x = o / (int)q.n_items;
+            s_ent[g - base] = ((uint32_t)(o - x * (int)q.n_items) << 4) | (uint32_t)s_exh[x];
         }
         if (tid < 16) s_ucnt[tid] = 0;
         __syncthreads();
@@ -530,14 +636,27 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
                 const int e = e0 + x;
                 if (l16 == 0 && e < n) {
                     // tau <= the user's k-th best valid exact score: what the margins let in below it is not sorted
-                    if (drop[x] || !(a >= s_tau[ent[x] & 15u])) {
-                        s_ent[e] = ~0u;
-                    } else {
-                        s_val[e] = a;
-                        atomicAdd(&s_ucnt[ent[x] & 15u], 1);
-                    }
+                    if (drop[x] || !(a >= s_tau[ent[x] & 15u])) s_ent[e] = ~0u;
+                    else s_val[e] = a;
                 }
             }
+        }
+        __syncthreads();
+        // b2. history: one thread per surviving candidate searches its user's row in the pool (a hub's thousands of history items
+        //     — all of them candidates of a trained model — are spread over the whole workgroup, not searched by the one wave that
+        //     folds the user)
+        for (int e = tid; e < n; e += kMergeThreads) {
+            const uint32_t ent = s_ent[e];
+            if (ent == ~0u) continue;
+            const int r = (int)(ent & 15u);
+            HistRow hist;
+            hist.col = (const __attribute__((address_space(1))) int32_t *)q.col;
+            hist.lds = s_hpool + s_hoff[r];
+            hist.lo = s_hlo[r], hist.hi = s_hhi[r];
+            hist.staged = s_hstaged[r];
+            hist.n_users = q.n_users;
+            if (!RBG_SCREEN_DBGBIT(128) && hist.has((int)(ent >> 4))) s_ent[e] = ~0u;
+            else atomicAdd(&s_ucnt[r], 1);
         }
         __syncthreads();
         RBG_SCREEN_LAP(3);
@@ -572,12 +691,6 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
             const int r = wave;
             const int r_lo = s_ustart[r], r_hi = s_ustart[r + 1];
             if (r_lo != r_hi && !RBG_SCREEN_DBGBIT(32)) {
-                HistRow hist;
-                hist.col = (const __attribute__((address_space(1))) int32_t *)q.col;
-                hist.lds = s_hist[r];
-                hist.lo = s_hlo[r], hist.hi = s_hhi[r];
-                hist.staged = hist.hi - hist.lo < kHS ? hist.hi - hist.lo : kHS;
-                hist.n_users = q.n_users;
                 float v = lane < 32 ? s_bv[r][lane] : kNegInf;
                 int idx = lane < 32 ? s_bi[r][lane] : 0x7fffffff;
                 int first = base == 0 ? 0 : 32;  // lanes >= first take arrivals in the first round
@@ -586,15 +699,17 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
                         const int rr = r0 + lane - first;
                         if (rr < r_hi) {
                             const int e = s_perm[rr];
-                            const int item = (int)(s_ent[e] >> 4);
-                            // (every arrival of the round searches at once.  Scanning short rows whole with independent broadcast
-                            //  reads instead was measured slower: 37.6 vs 30.7 us per launch)
-                            const bool hdrop = !RBG_SCREEN_DBGBIT(128) && hist.has(item);
-                            v = hdrop ? kNegInf : s_val[e];
-                            idx = hdrop ? 0x7fffffff : item;
+                            v = s_val[e];
+                            idx = (int)(s_ent[e] >> 4);
                         }
                     }
-                    if (!RBG_SCREEN_DBGBIT(256)) wave_sort_desc_dpp(v, idx, lane);
+                    // a round whose arrivals are all below the k-th best so far changes nothing (a user without a bound brings
+                    // every item: ~ k ln(n / k) rounds sort instead of n / 32)
+                    const float kth = __shfl(v, q.k - 1);
+                    const bool news = lane >= 32 && (v > kth || (v == kth && v > kNegInf));
+                    if (first == 0 || __ballot(news) != 0ull) {
+                        if (!RBG_SCREEN_DBGBIT(256)) wave_sort_desc_dpp(v, idx, lane);
+                    }
                     if (lane >= 32) v = kNegInf, idx = 0x7fffffff;
                 }
                 if (lane < 32) s_bv[r][lane] = v, s_bi[r][lane] = idx;
@@ -615,7 +730,22 @@ __global__ __launch_bounds__(kMergeThreads) void screen_merge_kernel(const Merge
     RBG_SCREEN_LAP(6);
     if (threadIdx.x == 0 && RBG_SCREEN_DBGBIT(512)) ((volatile int *)s_cnt)[0] = n_ent;
 #ifdef RBG_SCREEN_DBG
-    if (g_screen_trace && threadIdx.x == 0) g_screen_trace[(int64_t)blockIdx.x * 16 + 7] = (unsigned long long)n_ent;
+    if (g_screen_trace && threadIdx.x == 0) {
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 7] = (unsigned long long)n_ent;
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 8] = (unsigned long long)n_reg;
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 9] = (unsigned long long)s_nexh;
+        int over = 0;
+        int first_over = -1;
+        for (int c = 0; c < kMaxChunks; ++c) {
+            over += s_cnt[c] < 0;
+            if (s_cnt[c] < 0 && first_over < 0) first_over = c;
+        }
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 10] = (unsigned long long)over;
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 11] = (unsigned long long)(long long)first_over;
+        float tmin = __builtin_inff();
+        for (int r = 0; r < 16; ++r) tmin = fminf(tmin, s_tau[r]);
+        g_screen_trace[(int64_t)blockIdx.x * 16 + 12] = (unsigned long long)__float_as_uint(tmin);
+    }
 #endif
 }
 
@@ -696,6 +826,9 @@ int screen_prepass(const ScreenCall &c, hipStream_t s) {
 
 int screen_main(const ScreenCall &c, hipStream_t s) {
     const ScreenLayout L = layout_for(c.B, c.n_items, screen_ut(c.d));
+    hipLaunchKernelGGL(screen_tau_kernel, dim3((unsigned)((c.B + 3) / 4)), dim3(256), 0, s, c.pre_val, c.pre_idx, c.users, c.rowptr, c.col,
+                       c.n_users, c.B, c.splits, c.tpc_s, c.sample_tiles * 32, c.k, c.tau0);
+    RBG_HIP(hipGetLastError());
     const bool vec = rows_vec(c);
     ScreenParams p{};
     p.B = c.B;

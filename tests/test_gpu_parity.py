@@ -1816,8 +1816,9 @@ def test_full_sort_topk_screen(rbg, cuda):
     """r06, option "topk_screen" (csrc/topk_screen.hip): ONE bf16 product per (user, item) with a rigorous error bound on the matrix
     core screens the call, the survivors are rescored exactly in fp32 — the same top-k as the exact passes (option 0) and as the
     float64 reference (lightgcn.py:123-133 + _full_sort_batch_eval): history masks incl. a hub user whose 2 500 history items all
-    score high, repeated users, ragged rows (d = 33: scalar loads), d = 100 / 128 (eight product fragments), an item count that is
-    not a multiple of the tile; and the two cases in which candidate regions overflow and the merge takes every pair of the
+    score high (its slot maxima in the pre-pass sample are history items: the threshold kernel walks the history), repeated users,
+    ragged rows (d = 33: scalar loads), d = 100 / 128 (eight product fragments), an item count that is not a multiple of the tile,
+    item ids ordered by popularity (the candidates of every user in the same few item tiles); and the two cases in which candidate regions overflow and the merge takes every pair of the
     region's chunk instead: all scores equal (every pair passes) and a user whose history covers the whole pre-pass sample (no
     threshold: every item is its candidate)."""
     nu, ni = 3000, 9003
@@ -1831,6 +1832,13 @@ def test_full_sort_topk_screen(rbg, cuda):
              ("d128", None, randn((1500, 128), 11, cuda), randn((20_000, 128), 12, cuda), torch.arange(1500, device=cuda), 3, [], []),
              ("d33", None, randn((300, 33), 9, cuda), randn((5003, 33), 10, cuda), torch.arange(300, device=cuda).repeat(8), 20, [], []),
              ("d100k32", h, randn((nu, 100), 13, cuda), randn((ni, 100), 14, cuda), torch.arange(1, 1300, device=cuda), 32, uid, iid)]
+    # item ids ordered by popularity (the bench's synthetic graphs, many real ones): the first few hundred items are most users' best
+    # items — every user's candidates would meet in the regions of the first item chunk if the chunks were contiguous ranges
+    pu, pi = randn((2048, 64), 21, cuda), randn((30_011, 64), 22, cuda)
+    mean_dir = pu.mean(dim=0) / pu.mean(dim=0).norm()
+    pu += 2.0 * mean_dir
+    pi[:700] += 3.0 * mean_dir
+    cases.append(("popular", None, pu, pi, torch.arange(2048, device=cuda), 10, [], []))
     rbg.set_option("topk_sample", 1024)
     try:
         for name, hist, u, i, users, k, hu, hi in cases:
