@@ -6,3 +6,6 @@ extern "C" int mb_screen_debug_set(int bits) { return (int)hipMemcpyToSymbol(HIP
 extern "C" int mb_screen_trace_set(unsigned long long *trace) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_screen_trace), &trace, sizeof(trace));
 }
+extern "C" int mb_screen_trace_main_set(unsigned long long *trace) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(rbg::g_screen_trace_main), &trace, sizeof(trace));
+}

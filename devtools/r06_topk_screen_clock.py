@@ -35,10 +35,22 @@ trace = torch.zeros((2 * ((NB + 31) // 32), 16), dtype=torch.int64, device=dev)
 for _ in range(3):
     rbg.full_sort_topk(model.graph, ue, ie, users, 10)
 torch.cuda.synchronize()
+tmain = torch.zeros((1024, 4), dtype=torch.int64, device=dev)
+assert lib.mb_screen_trace_main_set(ctypes.c_void_p(tmain.data_ptr())) == 0
+assert lib.mb_screen_debug_set(int(os.environ.get("SCREEN_DBG", "0"))) == 0
 assert lib.mb_screen_trace_set(ctypes.c_void_p(trace.data_ptr())) == 0
 rbg.full_sort_topk(model.graph, ue, ie, users, 10)
 torch.cuda.synchronize()
 lib.mb_screen_trace_set(ctypes.c_void_p(0))
+lib.mb_screen_trace_main_set(ctypes.c_void_p(0))
+tm = tmain.cpu().numpy().astype("float64")
+tm = tm[tm[:, 0] > 0]
+main_rec = {"what": "screen_main_kernel clock (wave 0 of every workgroup)", "workgroups": int(tm.shape[0]),
+            "prologue_ticks_mean": float((tm[:, 1] - tm[:, 0]).mean()), "loop_ticks_mean": float((tm[:, 2] - tm[:, 1]).mean()),
+            "loop_ticks_p90": float(sorted(tm[:, 2] - tm[:, 1])[int(0.9 * tm.shape[0])]),
+            "span_ticks": float(tm[:, 2].max() - tm[:, 0].min()), "start_spread_ticks": float(tm[:, 0].max() - tm[:, 0].min()),
+            "dbg_bits": int(os.environ.get("SCREEN_DBG", "0"))}
+print(json.dumps(main_rec))
 t = trace.cpu().numpy().astype("float64")
 names = ["stage", "load entries", "score + history", "bucket", "sort", "out"]
 span = t[:, 6].max() - t[:, 0].min()

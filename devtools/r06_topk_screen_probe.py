@@ -40,28 +40,33 @@ def replay_us(fn, calls=10, reps=5):
     return sorted(out)[len(out) // 2]
 
 
-uid, iid, nu, ni = rbg.synth.make("gowalla")
-ds = rbg.InteractionDataset(uid, iid, nu, ni)
-for d in (64, 128):
-    torch.manual_seed(0)
-    model = rbg.LightGCN({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": 3}, ds)
-    with torch.no_grad():
-        ue, ie = model.forward()
-    ue2, ie2 = ue.clone(), ie.clone()
-    g = torch.Generator().manual_seed(5)
-    ue2[torch.randint(1, nu, (2048,), generator=g).to(dev)] *= 30.0
-    ie2[torch.randint(1, ni, (4096,), generator=g).to(dev)] *= 30.0
-    for state, (u, i) in (("fresh", (ue, ie)), ("skewed", (ue2, ie2))):
-        for nb in (4096, 1024):
-            users = torch.randint(1, nu, (nb,), generator=torch.Generator().manual_seed(1)).to(dev)
-            rec = {"d": d, "users": nb, "k": 10, "tables": state}
-            res = {}
-            for scr in (0, 1, 0, 1):
-                rbg.set_option("topk_screen", scr)
-                v, ix = rbg.full_sort_topk(model.graph, u, i, users, 10)
-                res[scr] = (v.clone(), ix.clone())
-                rec.setdefault(f"screen{scr}_us", []).append(round(replay_us(lambda: rbg.full_sort_topk(model.graph, u, i, users, 10)), 2))
-            rec["same_items"] = float((res[0][1] == res[1][1]).all(dim=1).float().mean())
-            rec["max_rel_diff"] = float(((res[0][0] - res[1][0]).abs() / res[0][0].abs().clamp_min(1e-30)).max())
-            print(json.dumps(rec), flush=True)
-rbg.set_option("topk_screen", 1)
+def main():
+    uid, iid, nu, ni = rbg.synth.make("gowalla")
+    ds = rbg.InteractionDataset(uid, iid, nu, ni)
+    for d in (64, 128):
+        torch.manual_seed(0)
+        model = rbg.LightGCN({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": 3}, ds)
+        with torch.no_grad():
+            ue, ie = model.forward()
+        ue2, ie2 = ue.clone(), ie.clone()
+        g = torch.Generator().manual_seed(5)
+        ue2[torch.randint(1, nu, (2048,), generator=g).to(dev)] *= 30.0
+        ie2[torch.randint(1, ni, (4096,), generator=g).to(dev)] *= 30.0
+        for state, (u, i) in (("fresh", (ue, ie)), ("skewed", (ue2, ie2))):
+            for nb in (4096, 1024):
+                users = torch.randint(1, nu, (nb,), generator=torch.Generator().manual_seed(1)).to(dev)
+                rec = {"d": d, "users": nb, "k": 10, "tables": state}
+                res = {}
+                for scr in (0, 1, 0, 1):
+                    rbg.set_option("topk_screen", scr)
+                    v, ix = rbg.full_sort_topk(model.graph, u, i, users, 10)
+                    res[scr] = (v.clone(), ix.clone())
+                    rec.setdefault(f"screen{scr}_us", []).append(round(replay_us(lambda: rbg.full_sort_topk(model.graph, u, i, users, 10)), 2))
+                rec["same_items"] = float((res[0][1] == res[1][1]).all(dim=1).float().mean())
+                rec["max_rel_diff"] = float(((res[0][0] - res[1][0]).abs() / res[0][0].abs().clamp_min(1e-30)).max())
+                print(json.dumps(rec), flush=True)
+    rbg.set_option("topk_screen", 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -56,7 +56,7 @@ int opt_mfma_split();   // score / top-k: 3 x bf16 split operands on the bf16 ma
 // train.hip: zero `bytes` (4-byte units) at ptr by a fill kernel — NOT hipMemsetAsync, whose node writes garbage on a captured graph's later replays
 int zero_async(void *ptr, size_t bytes, hipStream_t s);
 int opt_topk_image();  // rbg_full_sort_topk_f32: split the item table once per call into a plane image the passes take by LDS-DMA (1, default)
-int opt_topk_screen();  // rbg_full_sort_topk_f32: one bf16 product per pair screens the call, survivors rescored exactly (topk_screen.hip): 0 never, 1 from 1024 users (default), 2 always
+int opt_topk_screen();  // rbg_full_sort_topk_f32: one bf16 product per pair screens the call, survivors rescored exactly (topk_screen.hip): 0 never, 1 from 256 users (default), 2 always
 int opt_topk_short_lists();  // rbg_full_sort_topk_f32: 24-entry LDS lists (three workgroups per CU) at k <= 12, d <= 64: 0 never, 1 from 2048 users (default), 2 always
 int opt_deterministic();  // train.hip / lse.hip: row scatters by owner wavefronts in batch order (ordered.h), sums in fixed point: bit-stable
 int opt_lse_tr_read();    // lse.hip gradients: the second product's B fragments by ds_read_b64_tr_b16 from the row-major planes (1, default)

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restri
 #ifdef RBG_SCREEN_DBG
 __device__ int g_screen_debug = 0;
 __device__ unsigned long long *g_screen_trace = nullptr;  // [workgroup][16] phase clock of the merge kernel (thread 0)
+__device__ unsigned long long *g_screen_trace_main = nullptr;  // [workgroup][4] clock of the main pass (wave 0): entry, loop entry, loop exit
+#define RBG_SCREEN_MAIN_LAP(k)                                                                                            \
+    do {                                                                                                                  \
+        if (g_screen_trace_main && threadIdx.x == 0) g_screen_trace_main[(int64_t)blockIdx.x * 4 + (k)] = clock64();     \
+    } while (0)
 #define RBG_SCREEN_LAP(k)                                                                                       \
     do {                                                                                                        \
         if (g_screen_trace && threadIdx.x == 0) g_screen_trace[(int64_t)blockIdx.x * 16 + (k)] = clock64();    \
@@ -160,6 +165,7 @@ __device__ unsigned long long *g_screen_trace = nullptr;  // [workgroup][16] pha
 #define RBG_SCREEN_DBG_LOAD() const int screen_dbg_bits = g_screen_debug  // (once per kernel: a load per use would stall the loop it is meant to probe)
 #define RBG_SCREEN_DBGBIT(bit) ((screen_dbg_bits & (bit)) != 0)
 #else
+#define RBG_SCREEN_MAIN_LAP(k) ((void)0)
 #define RBG_SCREEN_LAP(k) ((void)0)
 #define RBG_SCREEN_DBG_LOAD() ((void)0)
 #define RBG_SCREEN_DBGBIT(bit) false
@@ -187,7 +193,17 @@ template <int S>
 __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t b0 = ((int64_t)blockIdx.y * 4 + wave) * 32;
+    // (XCD-aware like the main pass when the splits allow it: XCD x takes the splits x, x + 8)
+    int chunk, yb;
+    if ((p.n_chunks & 7) == 0) {
+        const int cpx = p.n_chunks >> 3, wg_slot = (int)(blockIdx.x >> 3);
+        chunk = (int)(blockIdx.x & 7) + 8 * (wg_slot % cpx);
+        yb = wg_slot / cpx;
+    } else {
+        chunk = (int)(blockIdx.x % p.n_chunks);
+        yb = (int)(blockIdx.x / p.n_chunks);
+    }
+    const int64_t b0 = ((int64_t)yb * 4 + wave) * 32;
     if (b0 >= p.B) return;  // (no barrier in this kernel)
     const __bf16 z = (__bf16)0.0f;
     const bf16x8 *uimg = reinterpret_cast<const bf16x8 *>(p.uimage) + ((b0 >> 5) * (S + 1)) * 64 + lane;
@@ -200,7 +216,6 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     float best[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) best[r] = kNegInf;
-    const int chunk = blockIdx.x;
     const int64_t t_begin = p.tile_lo + (int64_t)chunk * p.tiles_per_chunk;
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(256) void screen_tau_kernel(const float *__restrict
         idx[t] = e < total ? g_idx[b * total + e] : 0x7fffffff;
     }
     // the row is sorted: its history items inside the sample are a prefix; four loads in flight, stop at the first batch past it
+    const float inv_tpc = 1.0f / (float)tpc_s;
     for (int e0 = lo; e0 < hi; e0 += 256) {
         int64_t it[4];
 #pragma unroll
@@ -286,18 +302,17 @@ __global__ __launch_bounds__(256) void screen_tau_kernel(const float *__restrict
             const int e = e0 + 64 * u + lane;
             it[u] = e < hi ? (int64_t)col[e] - n_users : sample_items;
         }
-        int hit[4];
+        int hit[4], slot[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bool in = it[u] >= 0 && it[u] < sample_items;
-            const int slot = in ? (int)((it[u] >> 5) / tpc_s) * 32 + (int)(it[u] & 31) : 0;
-            hit[u] = (in && slot < total) ? g_idx[b * total + slot] : -1;
+            // split of the item's tile: tile / tpc_s by a float reciprocal (tile < 4096, tpc_s <= 256: exact with the half offset)
+            slot[u] = in ? (int)(((float)(int)(it[u] >> 5) + 0.5f) * inv_tpc) * 32 + (int)(it[u] & 31) : total;
+            hit[u] = slot[u] < total ? g_idx[b * total + slot[u]] : -1;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int slot = (int)((it[u] >> 5) / tpc_s) * 32 + (int)(it[u] & 31);
-            if (hit[u] >= 0 && hit[u] == (int)it[u]) atomicOr(&s_bad[wave][slot >> 5], 1u << (slot & 31));
-        }
+        for (int u = 0; u < 4; ++u)
+            if (hit[u] >= 0 && hit[u] == (int)it[u]) atomicOr(&s_bad[wave][slot[u] >> 5], 1u << (slot[u] & 31));
         if (__ballot(it[3] < sample_items) == 0ull) break;  // (every lane's last column is past the sample)
     }
     __builtin_amdgcn_wave_barrier();
@@ -324,7 +339,14 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
     RBG_SCREEN_DBG_LOAD();
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int64_t ublock = (int64_t)blockIdx.y * 4 + wave;
+    // workgroup w runs on XCD w & 7 (round-robin dispatch): XCD x takes the chunks x, x + 8, ... for every user block, so the
+    // image tiles one XCD's L2 serves are 1/8 of the image (0.8 MB of 6.5 MB at the Gowalla shape: resident, instead of the
+    // whole image streaming through every L2 for every user block)
+    RBG_SCREEN_MAIN_LAP(0);
+    const int cpx = p.n_chunks >> 3;  // chunks per XCD (n_chunks is a multiple of 8)
+    const int wg_slot = (int)(blockIdx.x >> 3);
+    const int chunk = (int)(blockIdx.x & 7) + 8 * (wg_slot % cpx);
+    const int64_t ublock = (int64_t)(wg_slot / cpx) * 4 + wave;
     const int64_t b0 = ublock * (UT * 32);
     if (b0 >= p.B) return;  // (no barrier in this kernel)
     const __bf16 z = (__bf16)0.0f;
@@ -360,7 +382,6 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
     // chunk c takes the item tiles c, c + n_chunks, c + 2 n_chunks, ... : item ids are often ordered by popularity, and the popular
     // items are most users' candidates — in contiguous chunks they all met in the first chunk's regions, which overflowed
     // (the bench's trained tables: 12 regions, each a 10 752-pair exhaustive scan in the merge)
-    const int chunk = blockIdx.x;
     const int64_t t_begin = chunk, t_end = p.tile_hi, t_step = p.n_chunks;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
     if (RBG_SCREEN_DBGBIT(8)) return;
@@ -370,6 +391,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
 #pragma unroll
         for (int s = 0; s <= S; ++s) Bn[s] = img[(t_begin * (S + 1) + s) * 64];
     }
+    RBG_SCREEN_MAIN_LAP(1);
     for (int64_t t = t_begin; t < t_end; t += t_step) {
         i32x4v Bc[S + 1];
 #pragma unroll
@@ -415,6 +437,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
             }
         }
     }
+    RBG_SCREEN_MAIN_LAP(2);
     if (lane < UT * 2) {
         int c = 0;
 #pragma unroll
@@ -758,10 +781,12 @@ static ScreenLayout layout_for(int64_t B, int64_t n_items, int ut) {
     L.n_tiles = (n_items + 31) / 32;
     L.ut = ut;
     L.n_ublocks = (int)((B + ut * 32 - 1) / (ut * 32));
+    // chunk c = the item tiles c, c + nc, ...; nc a multiple of 8 (one residue class of chunks per XCD), at most kMaxChunks
     int64_t want = std::max<int64_t>(1, kWantWaves / std::max(L.n_ublocks, 1));
-    want = std::min<int64_t>(want, std::min<int64_t>(kMaxChunks, std::max<int64_t>(1, L.n_tiles / 4)));
-    L.tpc = (int)((L.n_tiles + want - 1) / want);
-    L.nc = (int)((L.n_tiles + L.tpc - 1) / std::max(L.tpc, 1));
+    want = std::min<int64_t>((want + 7) / 8 * 8, kMaxChunks);
+    while (want > 8 && want * 4 > L.n_tiles) want -= 8;
+    L.nc = (int)want;
+    L.tpc = (int)((L.n_tiles + L.nc - 1) / L.nc);
     L.image_off = 0;
     const int64_t image_bytes = L.n_tiles * 9 * 1024;  // (sized for d <= 128: eight product fragments + the bound fragment)
     L.uimage_off = L.image_off + (image_bytes + 255) / 256 * 256;
@@ -786,7 +811,7 @@ bool screen_applicable(int64_t B, int64_t n_items, int d, int k) {
     if (!opt_topk_screen()) return false;
     if (d > 128 || k > 32) return false;
     if (n_items >= (1ll << 26)) return false;  // (item << 5 | accumulator row) in 32 bits
-    if (B < 1024 && opt_topk_screen() != 2) return false;
+    if (B < 256 && opt_topk_screen() != 2) return false;  // (measured, profiles/r06_topk_screen_small.jsonl: ahead from 256 users, level at 128)
     return screen_layout(B, n_items).fits;
 }
 
@@ -817,7 +842,7 @@ int screen_prepass(const ScreenCall &c, hipStream_t s) {
     p.tile_hi = c.sample_tiles;
     p.g_val = c.pre_val;
     p.g_idx = c.pre_idx;
-    const dim3 grid((unsigned)c.splits, (unsigned)(((c.B + 31) / 32 + 3) / 4));
+    const dim3 grid((unsigned)(c.splits * (((c.B + 31) / 32 + 3) / 4)));
     if (c.d <= 64) hipLaunchKernelGGL((screen_pre_kernel<4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((screen_pre_kernel<8>), grid, dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
@@ -841,7 +866,7 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     p.tau0 = c.tau0;
     p.pool = reinterpret_cast<uint32_t *>(c.w + L.pool_off);
     p.cnt = reinterpret_cast<int32_t *>(c.w + L.cnt_off);
-    const dim3 grid((unsigned)L.nc, (unsigned)((L.n_ublocks + 3) / 4));
+    const dim3 grid((unsigned)(L.nc * ((L.n_ublocks + 3) / 4)));
     if (c.d <= 64) hipLaunchKernelGGL((screen_main_kernel<4, kUt64>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((screen_main_kernel<8, kUt128>), grid, dim3(256), 0, s, p);
     RBG_HIP(hipGetLastError());
