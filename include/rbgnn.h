@@ -128,8 +128,8 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "topk_screen" : 1 (default) = rbg_full_sort_topk_f32 at d <= 128, B >= 256, more than 2 x "topk_sample" items screens every
  *                   (user, item) pair with ONE bf16 x bf16 product and a rigorous bound of its error on the matrix core
  *                   (|s - s^| <= 1.03 x 2^-8 ||u|| ||i||: no pair that can be in the top k is dropped) and rescoring the ~ k n /
- *                   sample survivors per user exactly in fp32 (csrc/topk_screen.hip; r06: 4096 users x 40 982 items 192 -> 98 us
- *                   per call at d = 64, 394 -> 133 us at d = 128, 242 -> 97 us on trained tables); 2 = for any batch size; 0 = the exact passes on 3-way split
+ *                   sample survivors per user exactly in fp32 (csrc/topk_screen.hip; r06: 4096 users x 40 982 items 188 -> 91 us
+ *                   per call at d = 64, 394 -> 122 us at d = 128, 242 -> 97 us on trained tables); 2 = for any batch size; 0 = the exact passes on 3-way split
  *                   operands for every pair.  Same items wherever two scores are not equal to the last bit; values agree to
  *                   ~ 1e-7 relative (the rescoring sums in a different order than the split products).
  *   "topk_image"  : 1 (default) = rbg_full_sort_topk_f32 at 64 < d <= 128, B >= 1024 splits the item table ONCE per call into three

@@ -392,15 +392,10 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
         for (int s = 0; s <= S; ++s) Bn[s] = img[(t_begin * (S + 1) + s) * 64];
     }
     RBG_SCREEN_MAIN_LAP(1);
-    for (int64_t t = t_begin; t < t_end; t += t_step) {
-        i32x4v Bc[S + 1];
-#pragma unroll
-        for (int s = 0; s <= S; ++s) Bc[s] = Bn[s];
-        if (t + t_step < t_end && !RBG_SCREEN_DBGBIT(4)) {
-#pragma unroll
-            for (int s = 0; s <= S; ++s) Bn[s] = img[((t + t_step) * (S + 1) + s) * 64];
-        }
-        f32x16 acc[UT];
+    // Software pipeline over the tiles: the sign words of tile t - 1 are formed and its candidates appended while the matrix core
+    // works on tile t (a wave issues in order: with the filter behind its own products it filtered OR multiplied, and the pipe
+    // idled whenever the SIMD's waves filtered at the same time — 2 640 cycles per tile and SIMD against 1 280 of MFMA time).
+    auto product = [&](f32x16 (&acc)[UT], const i32x4v (&Bc)[S + 1]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < UT; ++j) {
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -410,22 +405,34 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int j = 0; j < UT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][s], as_frag(Bc[s]), acc[j], 0, 0, 0);
+    };
+    auto fetch = [&](int64_t t, i32x4v (&Bx)[S + 1]) __attribute__((always_inline)) {
+        if (t < t_end && !RBG_SCREEN_DBGBIT(4)) {
+#pragma unroll
+            for (int s = 0; s <= S; ++s) Bx[s] = img[(t * (S + 1) + s) * 64];
+        }
+    };
+    auto sift = [&](const f32x16 (&acc)[UT], int64_t t) __attribute__((always_inline)) {
         const uint32_t code = ((uint32_t)(t * 32 + i) << 5) | ((uint32_t)h << 4);
+        unsigned bits[UT];
 #pragma unroll
         for (int j = 0; j < UT; ++j) {
             // bit (15 - r) of x = sign of acc[r]: one v_alignbit per register shifts it in
             unsigned x = 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x = __builtin_amdgcn_alignbit(x, __float_as_uint(acc[j][RBG_SCREEN_DBGBIT(2) ? 0 : r]), 31);
-            unsigned bits = ~x & 0xffffu;  // 1 = tst > 0 (a NaN may pass: the merge drops it)
-            if (RBG_SCREEN_DBGBIT(1)) bits = 0u;
-            unsigned long long act = __builtin_amdgcn_ballot_w64(bits != 0u);
+            bits[j] = ~x & 0xffffu;  // 1 = tst > 0 (a NaN may pass: the merge drops it)
+            if (RBG_SCREEN_DBGBIT(1)) bits[j] = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < UT; ++j) {
+            unsigned long long act = __builtin_amdgcn_ballot_w64(bits[j] != 0u);
             uint32_t *reg = reg0 + j * kRegion;
             while (act != 0ull) {  // one round per entry of the lane with the most (usually one)
                 const int c_lo = __popc((unsigned)act), c_hi = __popc((unsigned)(act >> 32));
-                if (bits != 0u) {
-                    const int q = 31 - __builtin_clz(bits);  // the lowest row first
-                    bits &= ~(1u << q);
+                if (bits[j] != 0u) {
+                    const int q = 31 - __builtin_clz(bits[j]);  // the lowest row first
+                    bits[j] &= ~(1u << q);
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
                     // the lower half fills the region from its start, the upper half from its end
                     const int pos = h ? (kRegion - 1 - n_hi[j] + c_lo) - rank : n_lo[j] + rank;
@@ -433,8 +440,32 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
                 }
                 n_lo[j] += c_lo;
                 n_hi[j] += c_hi;
-                act = __builtin_amdgcn_ballot_w64(bits != 0u);
+                act = __builtin_amdgcn_ballot_w64(bits[j] != 0u);
             }
+        }
+    };
+    f32x16 accA[UT], accB[UT];
+    i32x4v Bm[S + 1];  // the second fragment set: the tiles alternate between Bn and Bm (no register copies)
+#pragma unroll
+    for (int s = 0; s <= S; ++s) Bm[s] = Bn[s];
+    int64_t t = t_begin;
+    if (t < t_end) {
+        fetch(t + t_step, Bm);
+        product(accA, Bn);
+        for (t += t_step; t + t_step < t_end; t += 2 * t_step) {  // two tiles per round: accumulators and fragments swap roles without copies
+            fetch(t + t_step, Bn);
+            product(accB, Bm);
+            sift(accA, t - t_step);
+            fetch(t + 2 * t_step, Bm);
+            product(accA, Bn);
+            sift(accB, t);
+        }
+        if (t < t_end) {  // an even count of tiles: one more product
+            product(accB, Bm);
+            sift(accA, t - t_step);
+            sift(accB, t);
+        } else {
+            sift(accA, t - t_step);
         }
     }
     RBG_SCREEN_MAIN_LAP(2);
@@ -795,7 +826,9 @@ static ScreenLayout layout_for(int64_t B, int64_t n_items, int ut) {
     const int64_t regions = (int64_t)L.n_ublocks * L.nc * ut;
     L.cnt_off = L.pool_off + regions * kRegion * 4;
     L.bytes = (L.cnt_off + regions * 8 + 255) / 256 * 256;
-    L.fits = image_bytes <= (1ll << 30) && L.bytes <= (3ll << 30);
+    // (never for item sets the pre-pass cannot sample — its smallest sample is 1024 items and the main pass needs more than two
+    //  samples: a million-row nearest-centroid call must not be handed a 4 KB-per-row candidate pool)
+    L.fits = L.n_tiles > 64 && n_items < (1ll << 22) && image_bytes <= (1ll << 30) && L.bytes <= (3ll << 30);
     return L;
 }
 
@@ -810,7 +843,7 @@ ScreenLayout screen_layout(int64_t B, int64_t n_items) {
 bool screen_applicable(int64_t B, int64_t n_items, int d, int k) {
     if (!opt_topk_screen()) return false;
     if (d > 128 || k > 32) return false;
-    if (n_items >= (1ll << 26)) return false;  // (item << 5 | accumulator row) in 32 bits
+    if (n_items >= (1ll << 22)) return false;  // (the merge counts candidates in 32 bits even when every region overflows: 64 chunks x n_tiles / 64 x 512 pairs + 16 x n_items)
     if (B < 256 && opt_topk_screen() != 2) return false;  // (measured, profiles/r06_topk_screen_small.jsonl: ahead from 256 users, level at 128)
     return screen_layout(B, n_items).fits;
 }
