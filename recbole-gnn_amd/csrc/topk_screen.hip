@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restri
 
 // What-if switches of the diagnostic build (devtools/microbench/topk_screen_trace.hip defines RBG_SCREEN_DBG; results are wrong on
 // purpose): 1 main pass appends nothing, 2 main pass tests one accumulator row of 16, 4 main pass loads no tile after its first,
-// 8 main pass stops after its prologue, 16 merge scores nothing, 32 merge sorts nothing, 64 merge stops after staging, 128 merge tests no history, 256 merge runs no sorting network.
+// 8 main pass stops after its prologue, 16 merge scores nothing, 32 merge sorts nothing, 64 merge stops after staging, 128 merge tests no history, 256 merge runs no sorting network, 1024 the pre-pass is clocked instead of the main pass.
 #ifdef RBG_SCREEN_DBG
 __device__ int g_screen_debug = 0;
 __device__ unsigned long long *g_screen_trace = nullptr;  // [workgroup][16] phase clock of the merge kernel (thread 0)
@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     // (XCD-aware like the main pass when the splits allow it: XCD x takes the splits x, x + 8)
+    RBG_SCREEN_DBG_LOAD();
+    if (RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(0);
     int chunk, yb;
     if ((p.n_chunks & 7) == 0) {
         const int cpx = p.n_chunks >> 3, wg_slot = (int)(blockIdx.x >> 3);
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int64_t t_end = (t_begin + p.tiles_per_chunk < p.tile_hi) ? t_begin + p.tiles_per_chunk : p.tile_hi;
     const i32x4v *img = reinterpret_cast<const i32x4v *>(p.image) + lane;
     const int64_t t_last = t_end - 1;
+    if (RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(1);
     i32x4v N0[S + 1], N1[S + 1];  // the next pair of tiles, in flight while this pair feeds the matrix core
     if (t_begin < t_end) {
         const int64_t t1 = t_begin + 1 < t_end ? t_begin + 1 : t_last;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
             best[r] = fmaxf(fmaxf(best[r], p0), p1);
         }
     }
+    if (RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(2);
     // lane (i, h) holds group i of user slot rowmap(r, h) (the layout topk.hip's threshold kernel reads)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
     // workgroup w runs on XCD w & 7 (round-robin dispatch): XCD x takes the chunks x, x + 8, ... for every user block, so the
     // image tiles one XCD's L2 serves are 1/8 of the image (0.8 MB of 6.5 MB at the Gowalla shape: resident, instead of the
     // whole image streaming through every L2 for every user block)
-    RBG_SCREEN_MAIN_LAP(0);
+    if (!RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(0);
     const int cpx = p.n_chunks >> 3;  // chunks per XCD (n_chunks is a multiple of 8)
     const int wg_slot = (int)(blockIdx.x >> 3);
     const int chunk = (int)(blockIdx.x & 7) + 8 * (wg_slot % cpx);
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
 #pragma unroll
         for (int s = 0; s <= S; ++s) Bn[s] = img[(t_begin * (S + 1) + s) * 64];
     }
-    RBG_SCREEN_MAIN_LAP(1);
+    if (!RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(1);
     // Software pipeline over the tiles: the sign words of tile t - 1 are formed and its candidates appended while the matrix core
     // works on tile t (a wave issues in order: with the filter behind its own products it filtered OR multiplied, and the pipe
     // idled whenever the SIMD's waves filtered at the same time — 2 640 cycles per tile and SIMD against 1 280 of MFMA time).
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
             sift(accA, t - t_step);
         }
     }
-    RBG_SCREEN_MAIN_LAP(2);
+    if (!RBG_SCREEN_DBGBIT(1024)) RBG_SCREEN_MAIN_LAP(2);
     if (lane < UT * 2) {
         int c = 0;
 #pragma unroll
