@@ -459,6 +459,26 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
                       float *exp_avg, float *exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                       void *stream);
 
+/* r06 — LightGCN's training step (lightgcn.py:83-110 + Adam) without its glue launches: two calls around the backward propagation
+ * replace rbg_bpr_grad_f32 (and the 18 MB fill of grad_mean it starts with), rbg_emb_reg_grad_f32 (require_pow = True) and
+ * rbg_adam_step_dev_f32 — 221 -> 207 us per step, 0.113 -> 0.105 s per epoch at the Gowalla shape (profiles/r06_lean_step.jsonl);
+ * same arithmetic.
+ *   head: grad_mean += dBPR/d(out_mean) (rows of the batch; float atomics), *loss = BPR + reg_weight x EmbLoss (stored, not added:
+ *         nothing to zero; also added to *loss_total when non-NULL), and how often every node occurs in the batch -> row_count.
+ *         Counts the step (*step += 1) and leaves Adam's bias corrections of it in scratch.
+ *   tail: Adam on both tables with gradient grad_e0 + reg_weight / B x occurrences x row; zeroes the rows of grad_mean the head
+ *         wrote.
+ * State the caller keeps between steps, all zero before the first: grad_mean [N, d], row_count [2][N] int32 (two tables used
+ * alternately by the step's parity), step (device int64), scratch (8 floats; the head leaves Adam's bias corrections of the step
+ * there for the tail: lr, beta1, beta2 must be the same in both calls).  Not in deterministic mode (RBG_EUNSUPPORTED). */
+int rbg_lightgcn_step_head_f32(const float *out_mean, const float *user_emb, const float *item_emb, int64_t n_users, int64_t n_items,
+                               const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight,
+                               float *grad_mean, int32_t *row_count, int64_t *step, float *scratch, float *loss, float *loss_total,
+                               float lr, float beta1, float beta2, void *stream);
+int rbg_lightgcn_step_tail_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad_e0,
+                               float *grad_mean, int32_t *row_count, float reg_weight, int64_t B, float *exp_avg, float *exp_avg_sq,
+                               const int64_t *step, float *scratch, float lr, float beta1, float beta2, float eps, void *stream);
+
 /* The same update with the step count in device memory, for callers that replay the step from a HIP graph (a host-side count
  * would bake the bias corrections of the captured step into every replay): `step` is a DEVICE int64 (0 before the first
  * call; incremented by the call), `factors` 2 floats of device scratch.  d must be a multiple of 4. */

@@ -507,6 +507,173 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ user_
     }
 }
 
+// ---- r06: LightGCN's step without its glue launches --------------------------------------------------------------------------
+// The fused step was 6 propagation launches + 7 small ones: zero(grad_mean, 18 MB), zero(loss), bpr_grad, emb_reg_grad, adam_tick,
+// adam, and the driver's loss accumulation — 59 of its 231 us at the Gowalla shape (rocprofv3 of an epoch).  Two launches do the
+// same arithmetic:
+//   head: bpr_grad + the regulariser's VALUE + how often every node occurs in the batch (row_count; the regulariser's gradient is
+//         reg_weight / B x occurrences x row: the tail adds it where it applies Adam).  The loss is summed in a scratch cell and
+//         the last workgroup to arrive stores it (and adds it to a running total): nothing to zero beforehand.
+//   tail: Adam over both tables with that gradient term; it zeroes the grad_mean rows the head wrote (so grad_mean is all-zero
+//         again: no 18 MB fill per step), clears the OTHER occurrence table (the tables alternate with the step's parity: the one
+//         it reads cannot be cleared while other lanes still read it), derives Adam's bias corrections from the device step count
+//         in every workgroup and lets the last workgroup to finish increment it.
+struct LeanHeadArgs {
+    BprArgs bpr;
+    const float *user_emb, *item_emb;
+    int64_t n_nodes;
+    float reg_weight;
+    int32_t *row_count;        // [2][n_nodes]
+    int64_t *step;
+    float *scratch;            // [0]: the loss sum, [1] (as unsigned): workgroups done, [2]: the tail's count, [4], [5]: Adam's factors of this step
+    float *loss, *loss_total;  // stored / accumulated by the last workgroup
+    float lr, beta1, beta2;
+};
+
+__global__ __launch_bounds__(256) void lgcn_head_kernel(const LeanHeadArgs a) {
+    __shared__ float red[kMaxWaves];
+    const int lane = threadIdx.x & 63;
+    const int64_t parity = *a.step & 1;
+    int32_t *cnt = a.row_count + parity * a.n_nodes;
+    const BprArgs &b = a.bpr;
+    float loss_part = 0.f, reg_part = 0.f;
+    if (b.d <= 64) {
+        // one column per lane: the wave's four triples side by side — all their row loads are issued before the first is used (one
+        // after the other they were four dependent chains of id -> rows -> sums -> atomics: 17.5 us for 2 048 triples)
+        RBG_FOR_GROUPS(grp, b.B) {
+            const bool col = lane < b.d;
+            int64_t u[kElemsPerWave], ip[kElemsPerWave], in[kElemsPerWave];
+            bool live[kElemsPerWave];
+#pragma unroll
+            for (int e = 0; e < kElemsPerWave; ++e) {
+                const int64_t t = grp * kElemsPerWave + e;
+                live[e] = t < b.B;
+                u[e] = live[e] ? b.user[t] : 0, ip[e] = live[e] ? b.pos[t] : 0, in[e] = live[e] ? b.neg[t] : 0;
+            }
+            float ue[kElemsPerWave], pe[kElemsPerWave], ne[kElemsPerWave], ru[kElemsPerWave], rp[kElemsPerWave], rn[kElemsPerWave];
+#pragma unroll
+            for (int e = 0; e < kElemsPerWave; ++e) {
+                const bool on = live[e] && col;
+                ue[e] = on ? b.mean[u[e] * b.d + lane] : 0.f;
+                pe[e] = on ? b.mean[(b.n_users + ip[e]) * b.d + lane] : 0.f;
+                ne[e] = on ? b.mean[(b.n_users + in[e]) * b.d + lane] : 0.f;
+                ru[e] = on ? a.user_emb[u[e] * b.d + lane] : 0.f;
+                rp[e] = on ? a.item_emb[ip[e] * b.d + lane] : 0.f;
+                rn[e] = on ? a.item_emb[in[e] * b.d + lane] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < kElemsPerWave; ++e) {
+                const float x = wave_sum(ue[e] * (pe[e] - ne[e]));  // sp - sn
+                const float sq = wave_sum(fmaf(ru[e], ru[e], fmaf(rp[e], rp[e], rn[e] * rn[e])));
+                if (!live[e]) continue;
+                const float sig = 1.0f / (1.0f + expf(-x));
+                const float c = -(sig * (1.0f - sig)) / (b.gamma + sig) / (float)b.B;
+                loss_part += -logf(b.gamma + sig) / (float)b.B;
+                reg_part += sq * 0.5f;
+                if (col) {
+                    atomicAdd(b.grad_mean + u[e] * b.d + lane, c * (pe[e] - ne[e]));
+                    atomicAdd(b.grad_mean + (b.n_users + ip[e]) * b.d + lane, c * ue[e]);
+                    atomicAdd(b.grad_mean + (b.n_users + in[e]) * b.d + lane, -c * ue[e]);
+                }
+                if (lane == 0) {
+                    atomicAdd(&cnt[u[e]], 1);
+                    atomicAdd(&cnt[b.n_users + ip[e]], 1);
+                    atomicAdd(&cnt[b.n_users + in[e]], 1);
+                }
+            }
+        }
+    } else {
+    RBG_FOR_GROUPS(grp, b.B)
+        for (int e = 0; e < kElemsPerWave; ++e) {
+            const int64_t t = grp * kElemsPerWave + e;
+            if (t >= b.B) break;
+            loss_part += bpr_elem<false>(b, t, -1, lane);
+            const int64_t u = b.user[t], ip = b.pos[t], in = b.neg[t];
+            const float *ru = a.user_emb + u * b.d, *rp = a.item_emb + ip * b.d, *rn = a.item_emb + in * b.d;
+            float sq = 0.f;
+            for (int k = lane; k < b.d; k += 64) {
+                const float x = ru[k], y = rp[k], z = rn[k];
+                sq = fmaf(x, x, fmaf(y, y, fmaf(z, z, sq)));
+            }
+            reg_part += wave_sum(sq) * 0.5f;
+            if (lane == 0) {
+                atomicAdd(&cnt[u], 1);
+                atomicAdd(&cnt[b.n_users + ip], 1);
+                atomicAdd(&cnt[b.n_users + in], 1);
+            }
+        }
+    }
+    const float tot = block_sum(loss_part + reg_part * (a.reg_weight / (float)b.B), red);
+    if (threadIdx.x != 0) return;
+    // no __threadfence here (an L2 write-back per workgroup): the arrival count is bumped only after this workgroup's sum has
+    // RETURNED from the atomic unit (its old value feeds the increment), so the last arrival's exchange sees every sum
+    const float before = atomicAdd(&a.scratch[0], tot);
+    unsigned *done = reinterpret_cast<unsigned *>(a.scratch) + 1;
+    const unsigned one = __float_as_uint(before) == 0xffffffffu ? 3u : 1u;  // (always 1 for a finite sum: the data dependency is the point)
+    if (atomicAdd(done, one) == gridDim.x - 1) {  // the last workgroup: every partial sum is in
+        const float total = atomicExch(&a.scratch[0], 0.f);
+        *a.loss = total;
+        if (a.loss_total) *a.loss_total += total;
+        // Adam's bias corrections of THIS step for the tail (two double-precision pow: once per step, not once per workgroup there)
+        const int64_t t1 = *a.step + 1;
+        const double t = (double)t1;
+        a.scratch[4] = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
+        a.scratch[5] = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, t)));
+        // the step is counted HERE (every workgroup of this launch has read the old count — its parity — before it arrived): the
+        // tail needs no arrival counter of its own (8 192 atomics on one word were 38 of its 58 us)
+        *a.step = t1;
+        atomicExch(done, 0u);
+    }
+}
+
+struct LeanTailArgs {
+    float *user_emb, *item_emb;
+    int64_t n_users_d, nd, n_nodes;
+    int d;
+    const float *grad_e0;
+    float *grad_mean;
+    int32_t *row_count;
+    float reg_over_b;
+    float *m, *v;
+    const int64_t *step;
+    const float *factors;
+    float beta1, beta2, eps;
+    int quads_shift;  // log2(d / 4) when d / 4 is a power of two, else -1
+};
+
+__global__ __launch_bounds__(256) void lgcn_tail_kernel(const LeanTailArgs a) {
+    const int64_t t0 = *a.step - 1;  // (the head counted the step already)
+    const float lr_over_bc1 = a.factors[0], inv_sqrt_bc2 = a.factors[1];  // (the head's last workgroup wrote them for this step)
+    const int32_t *cnt = a.row_count + (t0 & 1) * a.n_nodes;
+    int32_t *other = a.row_count + ((t0 & 1) ^ 1) * a.n_nodes;
+    const float beta1 = a.beta1, beta2 = a.beta2, eps = a.eps;
+    const int64_t n4 = a.nd >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = q << 2;
+        const int64_t row = a.quads_shift >= 0 ? (q >> a.quads_shift) : (int64_t)((uint64_t)q / (unsigned)(a.d >> 2));
+        const int c = cnt[row];
+        float4 g = *reinterpret_cast<const float4 *>(a.grad_e0 + i);
+        float4 mi = *reinterpret_cast<const float4 *>(a.m + i), vi = *reinterpret_cast<const float4 *>(a.v + i);
+        float *pp = i < a.n_users_d ? a.user_emb + i : a.item_emb + (i - a.n_users_d);
+        float4 pv = *reinterpret_cast<const float4 *>(pp);
+        if (c) {  // EmbLoss(require_pow): reg_weight / B x row per occurrence; the head's rows of grad_mean back to zero
+            const float w = a.reg_over_b * (float)c;
+            g.x = fmaf(w, pv.x, g.x), g.y = fmaf(w, pv.y, g.y), g.z = fmaf(w, pv.z, g.z), g.w = fmaf(w, pv.w, g.w);
+            *reinterpret_cast<float4 *>(a.grad_mean + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (i - row * a.d == 0) other[row] = 0;
+#define RBG_ADAM1(c)                                                        \
+        mi.c = beta1 * mi.c + (1.0f - beta1) * g.c;                         \
+        vi.c = beta2 * vi.c + (1.0f - beta2) * g.c * g.c;                   \
+        pv.c = pv.c - lr_over_bc1 * (mi.c / (sqrtf(vi.c) * inv_sqrt_bc2 + eps));
+        RBG_ADAM1(x) RBG_ADAM1(y) RBG_ADAM1(z) RBG_ADAM1(w)
+#undef RBG_ADAM1
+        *reinterpret_cast<float4 *>(a.m + i) = mi;
+        *reinterpret_cast<float4 *>(a.v + i) = vi;
+        *reinterpret_cast<float4 *>(pp) = pv;
+    }
+}
+
 }  // namespace rbg
 
 using namespace rbg;
@@ -655,6 +822,48 @@ int rbg_adam_step_dev_f32(float *user_emb, float *item_emb, int64_t n_users, int
     const unsigned blocks = (unsigned)std::min<int64_t>((nd / 4 + 255) / 256, 8192);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, s, user_emb, item_emb, n_users * d, grad, exp_avg, exp_avg_sq, nd,
                        factors, beta1, beta2, eps);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_lightgcn_step_head_f32(const float *out_mean, const float *user_emb, const float *item_emb, int64_t n_users, int64_t n_items,
+                               const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int d, float reg_weight,
+                               float *grad_mean, int32_t *row_count, int64_t *step, float *scratch, float *loss, float *loss_total,
+                               float lr, float beta1, float beta2, void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || B <= 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (!out_mean || !user_emb || !item_emb || !user || !pos || !neg || !grad_mean || !row_count || !step || !scratch || !loss)
+        return fail(RBG_EINVAL, "NULL pointer");
+    if (opt_deterministic()) return fail(RBG_EUNSUPPORTED, "the lean LightGCN step adds repeated rows with float atomics: use the separate calls in deterministic mode");
+    LeanHeadArgs a{};
+    a.bpr = BprArgs{out_mean, n_users, user, pos, neg, B, d, 1e-10f, grad_mean};
+    a.user_emb = user_emb, a.item_emb = item_emb, a.n_nodes = n_users + n_items, a.reg_weight = reg_weight;
+    a.row_count = row_count, a.step = step, a.scratch = scratch, a.loss = loss, a.loss_total = loss_total;
+    a.lr = lr, a.beta1 = beta1, a.beta2 = beta2;
+    hipLaunchKernelGGL(lgcn_head_kernel, grid_for(B), dim3(256), 0, (hipStream_t)stream, a);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_lightgcn_step_tail_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad_e0,
+                               float *grad_mean, int32_t *row_count, float reg_weight, int64_t B, float *exp_avg, float *exp_avg_sq,
+                               const int64_t *step, float *scratch, float lr, float beta1, float beta2, float eps, void *stream) {
+    clear_error();
+    if (n_users < 0 || n_items < 0 || d <= 0 || B <= 0) return fail(RBG_ESHAPE, "bad shape");
+    if (d % 4) return fail(RBG_EUNSUPPORTED, "rbg_lightgcn_step_tail_f32: d = %d is not a multiple of 4", d);
+    if (!user_emb || !item_emb || !grad_e0 || !grad_mean || !row_count || !exp_avg || !exp_avg_sq || !step || !scratch)
+        return fail(RBG_EINVAL, "NULL pointer");
+    LeanTailArgs a{};
+    a.user_emb = user_emb, a.item_emb = item_emb, a.n_users_d = n_users * d, a.nd = (n_users + n_items) * d, a.n_nodes = n_users + n_items;
+    a.d = d, a.grad_e0 = grad_e0, a.grad_mean = grad_mean, a.row_count = row_count, a.reg_over_b = reg_weight / (float)B;
+    a.m = exp_avg, a.v = exp_avg_sq, a.step = step;
+    a.factors = scratch + 4, a.beta1 = beta1, a.beta2 = beta2, a.eps = eps;
+    (void)lr;  // (in the factors the head wrote)
+    const int quads = d >> 2;
+    a.quads_shift = (quads & (quads - 1)) == 0 ? __builtin_ctz((unsigned)quads) : -1;
+    if (a.nd == 0) return RBG_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((a.nd / 4 + 255) / 256, 8192);
+    hipLaunchKernelGGL(lgcn_tail_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

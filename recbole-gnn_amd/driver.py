@@ -265,9 +265,14 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
         if fused and hasattr(stepper, "with_proto"):  # NCL: the prototype term joins after warm_up_step epochs (trainer.py:130-133)
             stepper.with_proto = not (warm_up is not None and epoch < warm_up)
         total = torch.zeros((), device=model.device)
+        own_total = fused and hasattr(stepper, "loss_total")  # (the stepper sums its losses itself: no add launch per step)
+        if own_total:
+            stepper.loss_total.zero_()
         for batch in sampler:
             batch = {k: v.to(model.device) for k, v in batch.items()}
-            if fused:
+            if own_total:
+                stepper.step(batch)
+            elif fused:
                 total += stepper.step(batch)
             elif graphed:
                 reduce = total_without_last if (warm_up is not None and epoch < warm_up) else None
@@ -290,7 +295,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
                 loss.backward()
                 opt.step()
                 total += loss.detach().reshape(())
-        history.append(float(total))
+        history.append(float(stepper.loss_total if own_total else total))
         if log:
             log(f"epoch {epoch}: train loss {history[-1]:.4f}")
     return history

@@ -38,7 +38,15 @@ class FusedBPRAdam:
         f = dict(dtype=torch.float32, device=dev)
         self.out_mean = torch.empty((n, d), **f)
         self.layers = torch.empty((max(model.n_layers, 1), n, d), **f)
-        self.grad_mean = torch.empty((n, d), **f)
+        self.grad_mean = torch.zeros((n, d), **f)
+        # r06, the lean step (rbg_lightgcn_step_head_f32 / _tail_f32: two launches instead of seven around the backward
+        # propagation): grad_mean stays all-zero between steps (the tail zeroes the rows the head wrote), the batch's node
+        # occurrences alternate between two tables by the step's parity, the loss is stored by the last workgroup to arrive
+        self.lean = True
+        self.row_count = torch.zeros((2, n), dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(8, **f)
+        self.loss_total = torch.zeros((), **f)  # the running sum of the steps' losses (the driver reads it once per epoch)
+        self._lean_state_clean = True
         self.grad_e0 = torch.empty((n, d), **f)
         self.work = torch.empty((n, d), **f)
         self.exp_avg = torch.zeros((n, d), **f)
@@ -62,6 +70,30 @@ class FusedBPRAdam:
         d, k_layers, b = m.latent_dim, m.n_layers, user.shape[0]
         st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
         g = m.graph
+        lean = self.lean and m.require_pow and d % 4 == 0 and b > 0 and not _get_option("deterministic")
+        if lean:
+            with torch.cuda.device(dev):
+                if not self._lean_state_clean:  # (a step of the other form left its gradient rows behind)
+                    self.grad_mean.zero_()
+                    self.row_count.zero_()
+                    self._lean_state_clean = True
+                ops.lightgcn_forward_raw(g, uw, iw, k_layers, out=self.out_mean, layers=self.layers)
+                check(lib.rbg_lightgcn_step_head_f32(c_vp(self.out_mean.data_ptr()), c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users,
+                                                     m.n_items, c_vp(user.data_ptr()), c_vp(pos.data_ptr()), c_vp(neg.data_ptr()), b, d,
+                                                     float(m.reg_weight), c_vp(self.grad_mean.data_ptr()), c_vp(self.row_count.data_ptr()),
+                                                     c_vp(self.step_dev.data_ptr()), c_vp(self.scratch.data_ptr()), c_vp(self.loss.data_ptr()),
+                                                     c_vp(self.loss_total.data_ptr()), self.lr, self.betas[0], self.betas[1], st))
+                arr = (c_vp * 1)(g.transpose().ptr)
+                check(lib.rbg_lightgcn_backward_f32(arr, 1, c_vp(self.grad_mean.data_ptr()), c_vp(self.grad_e0.data_ptr()),
+                                                    c_vp(self.work.data_ptr()), d, k_layers, st))
+                self.step_count += 1
+                check(lib.rbg_lightgcn_step_tail_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, d,
+                                                     c_vp(self.grad_e0.data_ptr()), c_vp(self.grad_mean.data_ptr()),
+                                                     c_vp(self.row_count.data_ptr()), float(m.reg_weight), b, c_vp(self.exp_avg.data_ptr()),
+                                                     c_vp(self.exp_avg_sq.data_ptr()), c_vp(self.step_dev.data_ptr()),
+                                                     c_vp(self.scratch.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps, st))
+            return self.loss
+        self._lean_state_clean = False
         with torch.cuda.device(dev):
             ops.lightgcn_forward_raw(g, uw, iw, k_layers, out=self.out_mean, layers=self.layers)
             check(lib.rbg_bpr_grad_f32(c_vp(self.out_mean.data_ptr()), m.n_users, m.n_items, c_vp(user.data_ptr()),
@@ -90,6 +122,7 @@ class FusedBPRAdam:
                                             c_vp(self.grad_e0.data_ptr()), c_vp(self.exp_avg.data_ptr()),
                                             c_vp(self.exp_avg_sq.data_ptr()), self.step_count, self.lr, self.betas[0],
                                             self.betas[1], self.eps, st))
+        self.loss_total += self.loss
         return self.loss
 
 

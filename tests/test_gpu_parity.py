@@ -793,6 +793,43 @@ def test_fused_training_step_matches_torch_adam(rbg, cuda, golden, require_pow):
     close(model3.item_embedding.weight, model2.item_embedding.weight, tol=2e-5)
 
 
+def test_lean_lightgcn_step_equals_the_separate_calls(rbg, cuda, golden):
+    """r06: FusedBPRAdam's lean form (rbg_lightgcn_step_head_f32 / _tail_f32: BPR + the regulariser's value + node occurrences in
+    one launch, Adam + the regulariser's gradient + the clean-up in another) against its separate calls (rbg_bpr_grad_f32,
+    rbg_emb_reg_grad_f32, rbg_adam_step_dev_f32) over six steps with repeated ids — incl. switching between the two forms on ONE
+    stepper (the lean form's state: grad_mean all-zero, the occurrence tables alternating with the step's parity, the device step
+    count) — and the running loss total the driver reads once per epoch."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    ma, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    mb, _ = make_model(rbg, rbg.LightGCN, cuda, golden, enable_sparse=True, require_pow=True, reg_weight=1e-2)
+    mb.load_state_dict(ma.state_dict())
+    lean, sep = rbg.FusedBPRAdam(ma, lr=1e-2), rbg.FusedBPRAdam(mb, lr=1e-2)
+    sep.lean = False
+    rng = np.random.default_rng(7)
+    total = 0.0
+    for step in range(6):
+        batch = {"user_id": torch.from_numpy(rng.integers(1, nu, 96)).to(cuda), "item_id": torch.from_numpy(rng.integers(1, min(ni, 40), 96)).to(cuda),
+                 "neg_item_id": torch.from_numpy(rng.integers(1, ni, 96)).to(cuda)}
+        lean.lean = step not in (2, 3)  # steps 2 and 3 in the separate form on the same stepper, then back
+        la, lb = lean.step(batch), sep.step(batch)
+        close(la.reshape(()), lb.reshape(()), tol=1e-6)
+        total += float(la)
+        close(ma.user_embedding.weight, mb.user_embedding.weight, tol=1e-6)
+        close(ma.item_embedding.weight, mb.item_embedding.weight, tol=1e-6)
+    assert abs(float(lean.loss_total) - total) <= 1e-5 * max(1.0, abs(total))
+    assert int(lean.step_dev) == 6 and int(sep.step_dev) == 6
+    assert float(lean.grad_mean.abs().max()) == 0.0 and int(lean.row_count[int(lean.step_dev) & 1].abs().max()) == 0
+    rbg.set_option("deterministic", 1)  # the lean form adds repeated rows with float atomics: the stepper takes the separate calls
+    try:
+        lean.lean = True
+        l1, l2 = lean.step(batch), sep.step(batch)
+        close(l1.reshape(()), l2.reshape(()), tol=1e-6)
+        close(ma.user_embedding.weight, mb.user_embedding.weight, tol=1e-6)
+    finally:
+        rbg.set_option("deterministic", 0)
+
+
 def test_sgl_model_views(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
