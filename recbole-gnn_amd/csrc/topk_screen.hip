@@ -9,27 +9,32 @@
 // threshold of topk.hip's TauTest: one more MFMA whose A operand carries (-tau_u in three bf16 terms, eps ||u|| rounded UP, 1) and
 // whose B operand carries (1, 1, 1, ||i|| rounded UP, -3e38 for the PAD item and rows past the end), so the accumulator holds
 //     tst = s^ + m^_ui - tau_u      (m^ >= m, tau lowered by 1e-5 |tau|)
-// and "tst >= 0" is one v_max3 tree, one compare, one ballot per 32 x 32 tile.  No pair with s >= tau_u is ever dropped.
-//   pass 1 (screen_pass_kernel<PRE>): over the first "topk_sample" items the accumulator holds the LOWER bound s^ - m^; per-lane
-//          running maxima as in topk.hip's pre-pass; topk.hip's threshold kernel turns them into tau_u <= the k-th best valid
-//          exact score.
-//   pass 2 (screen_main_kernel): every item; the sign bits of the 16 accumulator registers are shifted into one word per lane
+// and "tst > 0" is the accumulator's sign bit.  No pair with s >= tau_u is ever dropped.
+//   launch 1 (screen_image_kernel): the item table AND the batch's user rows as bf16 fragments in the MFMA operand layout
+//          ([tile][fragment][lane][16 bytes]: a wave's operand is a coalesced 1 KiB load), norms in a bound fragment per tile.
+//   launch 2 (screen_pre_kernel): over the first "topk_sample" items the accumulator holds the LOWER bound s^ - m^; per lane and
+//          accumulator row the running maximum and its tile index in one register (slot maxima, as topk.hip's pre-pass keeps them).
+//   launch 3 (screen_tau_kernel): tau_u = the k-th largest slot maximum that is not a history item, over all splits x 32 slots, the
+//          user's history walked (a history item belongs to exactly one slot) — tau_u <= the k-th best valid exact score.
+//   launch 4 (screen_main_kernel): every item; the sign bits of the 16 accumulator registers are shifted into one word per lane
 //          (v_alignbit: 16 instructions), one ballot says whether anything passed; a lane whose entry passes appends
 //          (item, accumulator row) to its wave's private region of a candidate pool — the slot is a wave-uniform counter + the
 //          lane's rank in the ballot (v_mbcnt): no atomic, no LDS, no exact score, no list pruning, no barrier.  The two lane
-//          halves (= two sets of 16 users) fill a region from its two ends.
-//   pass 3 (screen_merge_kernel): one workgroup per 16 users (one lane half of a tile) gathers its regions, rescoring every
+//          halves (= two sets of 16 users) fill a region from its two ends.  Software-pipelined over the tiles; chunk c = the
+//          tiles c, c + n_chunks, ... (popular items spread over the chunks); one residue class of chunks per XCD.
+//   launch 5 (screen_merge_kernel): one workgroup per 16 users (one lane half of a tile) gathers its regions, rescoring every
 //          candidate exactly in fp32 (16 lanes per candidate, eight candidates in flight, the item row read from the fp32 table),
-//          drops history items (one thread per candidate searches the user's graph row, staged in LDS), buckets the rest by
-//          user and folds them into the user's best 32 by the same bitonic network and the same total order as topk.hip, one wave per user.
-// No workgroup shares anything in passes 1 and 2: a wave keeps the bf16 rows of UT x 32 users as A fragments (16 registers per
-// 32 users at d <= 64 — the split operands of the exact pass take 48) and reads its B fragments straight from an image of the
-// item table laid out per tile as [fragment][lane][16 bytes] (1 KiB coalesced wave loads, L1 / L2 resident: 5 KiB per tile), so
-// there is no LDS tile, no split, no publish and no barrier in the loop.
-// A candidate region that overflows (scores that are all equal, a user whose history covers the whole sample: no threshold) is
-// not lost: the merge takes EVERY (user, item) pair of that region's chunk as a candidate instead — slow and exact, no host round
-// trip, no second code path.  Results: the same items as the exact passes wherever scores are not tied to the last bit (the
-// rescoring sums in a different order: values agree to ~ 1e-7 relative; tests/test_gpu_parity.py::test_full_sort_topk_screen).
+//          drops what the exact score puts below tau_u and the history items (one thread per candidate searches the user's graph
+//          row, staged in an LDS pool), buckets the rest by user and folds them into the user's best 32 by topk.hip's bitonic
+//          network (DPP exchanges inside a row of 16) and total order, one wave per user.
+// No workgroup shares anything in launches 2 and 4: a wave keeps the bf16 rows of its 32-user tiles as A fragments (16 registers
+// per tile at d <= 64 — the split operands of the exact pass take 48) and reads its B fragments straight from the image (L2
+// resident: 5 KiB per tile), so there is no LDS tile, no split, no publish and no barrier in the loop.
+// What the screen cannot hold is not lost: a candidate region that overflows (scores that are all equal) is replaced in the merge
+// by EVERY (user, item) pair of its chunk, a user without a bound (fewer than k valid slots: tau = +inf) by every item — slow and
+// exact, no host round trip, no second code path.  Results: the same items as the exact passes wherever scores are not tied to the
+// last bit (the rescoring sums in a different order: values agree to ~ 5e-7 relative; tests/test_gpu_parity.py::
+// test_full_sort_topk_screen).  Measurements and what was tried: DESIGN.md 2.4a, profiles/r06_topk_screen*.
 //
 // Replaces (with topk.hip): lightgcn.py:123-133 + Trainer._full_sort_batch_eval [recbole==1.1.1].
 
