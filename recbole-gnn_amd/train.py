@@ -345,7 +345,8 @@ class FusedSGLAdam(_FusedStep):
         n, d = nu + model.n_items, model.user_embedding.weight.shape[1]
         f = dict(dtype=torch.float32, device=dev)
         self.mean = [torch.empty((n, d), **f) for _ in range(3)]   # the full graph, view 1, view 2
-        self.gm = [torch.empty((n, d), **f) for _ in range(3)]     # dLoss/d(mean)
+        self._gm3 = torch.empty((3, n, d), **f)                    # (one allocation: ONE fill launch per step zeroes the three)
+        self.gm = [self._gm3[0], self._gm3[1], self._gm3[2]]       # dLoss/d(mean)
         self.ge = [torch.empty((n, d), **f) for _ in range(3)]     # dLoss/dE0 through each propagation; ge[0] ends as the total
         self.layers = torch.empty((max(model.n_layers, 1), n, d), **f)
         self.work = torch.empty((n, d), **f)
@@ -390,8 +391,7 @@ class FusedSGLAdam(_FusedStep):
             # sgl.py:147-162 on the full graph's mean: value, then the rows' gradients onto zeros
             check(lib.rbg_concat_bpr_begin_f32(self._tab, self._wid, 1, nu, ni, ptr(user), ptr(pos), ptr(neg), b, 1, ptr(self.coef),
                                                ptr(self.sums), ptr(self.loss), st))
-            for g in self.gm:
-                g.zero_()
+            self._gm3.zero_()
             check(lib.rbg_concat_bpr_scatter_f32(ptr(self.mean[0]), d, nu, ptr(user), ptr(pos), ptr(neg), b, 0.0, 0, ptr(self.coef),
                                                  ptr(self.sums), ptr(self.gm[0]), None, st))
             # sgl.py:176-209: users, then items, between the two views
@@ -614,7 +614,8 @@ class FusedNCLAdam(_FusedStep):
         self.e0 = torch.empty((n, d), **f)
         self.lay = torch.empty((self.L, n, d), **f)
         self.mean, self.chain_mean = torch.empty((n, d), **f), torch.empty((n, d), **f)
-        self.gm, self.gctx, self.g0 = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
+        self._gz = torch.empty((2, n, d), **f)  # (gctx and g0 side by side: ONE fill launch per step zeroes both)
+        self.gm, self.gctx, self.g0 = torch.empty((n, d), **f), self._gz[0], self._gz[1]
         self.ge, self.t0, self.t1 = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
         self.loss, self.reg_ws = torch.zeros((), **f), torch.zeros(3, **f)
         self._scratch = {}
@@ -652,8 +653,7 @@ class FusedNCLAdam(_FusedStep):
             check(lib.rbg_bpr_grad_f32(p(mean), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
             # ncl.py:137-165: the context layer E_(2 h) against the center E_0, users then items (x alpha)
             ctx = self.lay[2 * m.hyper_layers - 1]
-            self.gctx.zero_()
-            self.g0.zero_()
+            self._gz.zero_()  # gctx, g0
             for row0, rows, idx, wgt in ((0, nu, user, m.ssl_reg), (nu, ni, pos, m.ssl_reg * m.alpha)):
                 check(lib.rbg_infonce_f32(p(ctx, row0), p(self.e0, row0), rows, d, p(idx), b, float(m.ssl_temp), float(wgt), p(self.loss),
                                           p(self.gctx, row0), p(self.g0, row0), p(work), st))
