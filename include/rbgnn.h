@@ -127,7 +127,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *   "topk_sample" : items the pre-pass of rbg_full_sort_topk_f32 looks at (multiple of 128, default 8192)
  *   "topk_screen" : 1 (default) = rbg_full_sort_topk_f32 at d <= 128, B >= 256, more than 2 x "topk_sample" items screens every
  *                   (user, item) pair with ONE bf16 x bf16 product and a rigorous bound of its error on the matrix core
- *                   (|s - s^| <= 1.03 x 2^-8 ||u|| ||i||: no pair that can be in the top k is dropped) and rescoring the ~ k n /
+ *                   (|s - s^| <= ||du|| ||i^|| + ||u|| ||di|| from the rows' actual rounding errors: no pair that can be in the top k is dropped) and rescoring the ~ k n /
  *                   sample survivors per user exactly in fp32 (csrc/topk_screen.hip; r06: 4096 users x 40 982 items 188 -> 91 us
  *                   per call at d = 64, 394 -> 122 us at d = 128, 242 -> 97 us on trained tables); 2 = for any batch size; 0 = the exact passes on 3-way split
  *                   operands for every pair.  Same items wherever two scores are not equal to the last bit; values agree to

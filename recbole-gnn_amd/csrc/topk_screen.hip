@@ -2,12 +2,14 @@
 //
 // The exact passes of topk.hip pay six bf16 MFMA products on 3-way split operands, a split / publish of every item tile and a
 // workgroup barrier per 32 items for EVERY (user, item) pair, although > 99.8 % of the pairs are nowhere near a user's top k.
-// Here every pair gets one bf16 x bf16 product  s^ = bf16(u) . bf16(i)  and a RIGOROUS bound of what that lost:
-//     |s - s^|  <=  (2^-8 + 2^-18) sum_k |u_k i_k|  <=  m_ui := eps ||u|| ||i||,  eps = 1.03 x 2^-8
-// (round-to-nearest bf16 is off by <= 2^-9 relative per operand; Cauchy-Schwarz; the 3 % slack covers the matrix core's fp32
-// accumulation, the norms' rounding and the fp32 rescoring: all < 1e-5 ||u|| ||i||).  The bound rides on the matrix core like the
-// threshold of topk.hip's TauTest: one more MFMA whose A operand carries (-tau_u in three bf16 terms, eps ||u|| rounded UP, 1) and
-// whose B operand carries (1, 1, 1, ||i|| rounded UP, -3e38 for the PAD item and rows past the end), so the accumulator holds
+// Here every pair gets one bf16 x bf16 product  s^ = u^ . i^  (u^ = bf16(u), i^ = bf16(i), round to nearest) and a RIGOROUS bound
+// of what that lost, from the rounding errors the two rows ACTUALLY have (du = u^ - u, di = i^ - i are known when the fragments are built):
+//     u^ . i^ - u . i  =  du . i^ + u . di      =>      |s - s^|  <=  ||du|| ||i^|| + ||u|| ||di||  =:  m_ui        (Cauchy-Schwarz)
+// (~ 0.5 x 2^-8 ||u|| ||i|| on average; the worst case of round-to-nearest bf16 — 2^-8 per operand — would be 2^-7 ||u|| ||i||.  The
+// fp32 accumulation of the matrix core, the fp32 rescoring and the norms' own rounding, together < 2e-5 ||u|| ||i||, are added to
+// ||di||.)  The bound rides on the matrix core like the threshold of topk.hip's TauTest: one more MFMA whose A operand carries
+// (-tau_u in three bf16 terms, ||du||, 1, ||u||) and whose B operand carries (1, 1, 1, ||i^||, -3e38 for the PAD item and rows past
+// the end, ||di|| + 2e-5 ||i||), every norm rounded UP to bf16, so the accumulator holds
 //     tst = s^ + m^_ui - tau_u      (m^ >= m, tau lowered by 1e-5 |tau|)
 // and "tst > 0" is the accumulator's sign bit.  No pair with s >= tau_u is ever dropped.
 //   launch 1 (screen_image_kernel): the item table AND the batch's user rows as bf16 fragments in the MFMA operand layout
@@ -48,8 +50,8 @@
 
 namespace rbg {
 
-constexpr float kScreenEps = 0.00390625f * 1.03f;
-constexpr float kPreEps = kScreenEps + 6.2e-5f;  // (the pre-pass: see screen_pre_kernel)
+constexpr float kFpSlack = 2.0e-5f;   // x ||u|| ||i||: the matrix core's fp32 accumulation, the fp32 rescoring, the norms' rounding (d <= 128: < 1e-5)
+constexpr float kPackSlack = 6.2e-5f;  // x ||u|| ||i||: the pre-pass's packed maxima lose 8 mantissa bits (< 2^-15 of the value either way)
 constexpr int kRegion = 512;   // entries of one (user block, chunk, user tile) region of the pool
 constexpr int kSlab = 4096;    // candidates a merge workgroup holds in LDS at a time
 constexpr int kMaxChunks = 64;
@@ -118,18 +120,20 @@ __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restri
         const int64_t user = bi < B ? users[bi] : -1;
         const float *row = U + (user < 0 ? 0 : user) * (int64_t)d;
         bf16x8 *dst = reinterpret_cast<bf16x8 *>(uimage + ut * (int64_t)(S + 1) * 1024) + lane;
-        float ss = 0.f;
+        float ss = 0.f, sd = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const f32x8v v = load8<VEC>(row, user >= 0, 16 * s + 8 * h, d);
+            const bf16x8 r = __builtin_convertvector(v, bf16x8);
             ss += sumsq8(v);
-            dst[s * 64] = __builtin_convertvector(v, bf16x8);
+            sd += sumsq8(__builtin_convertvector(r, f32x8v) - v);  // (exact in fp32: the rounding error of every element)
+            dst[s * 64] = r;
         }
         ss += __shfl_xor(ss, 32);
-        const float nrm = sqrtf(ss) * 1.00001f;
-        // slot 3: the main pass's margin, slot 5: the pre-pass's (wider: its packed maxima lose 8 mantissa bits); the passes pick one
+        sd += __shfl_xor(sd, 32);
+        // slot 3: ||du||, slot 4: 1 (the invalid-item flag's multiplier), slot 5: ||u|| — rounded up; the passes add tau / negate
         bf16x8 f = {z, z, z, z, z, z, z, z};
-        if (h == 0) f = bf16x8{z, z, z, bf16_up(fminf(kScreenEps * nrm, 1.0e38f)), o, bf16_up(fminf(kPreEps * nrm, 1.0e38f)), z, z};
+        if (h == 0) f = bf16x8{z, z, z, bf16_up(fminf(sqrtf(sd) * 1.00001f, 1.0e38f)), o, bf16_up(fminf(sqrtf(ss) * 1.00001f, 1.0e38f)), z, z};
         dst[S * 64] = f;
         return;
     }
@@ -137,18 +141,29 @@ __global__ __launch_bounds__(256) void screen_image_kernel(const float *__restri
     const bool ok = item < n_items;
     const float *row = I + (ok ? item : 0) * (int64_t)d;
     bf16x8 *dst = reinterpret_cast<bf16x8 *>(image + t * (int64_t)(S + 1) * 1024) + lane;
-    float ss = 0.f;
+    float ss = 0.f, sh = 0.f, sd = 0.f;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const f32x8v v = load8<VEC>(row, ok, 16 * s + 8 * h, d);
+        const bf16x8 r = __builtin_convertvector(v, bf16x8);
+        const f32x8v rf = __builtin_convertvector(r, f32x8v);
         ss += sumsq8(v);
-        dst[s * 64] = __builtin_convertvector(v, bf16x8);
+        sh += sumsq8(rf);
+        sd += sumsq8(rf - v);
+        dst[s * 64] = r;
     }
     ss += __shfl_xor(ss, 32);
-    const float nrm = fminf(sqrtf(ss) * 1.00001f, 1.0e38f);
+    sh += __shfl_xor(sh, 32);
+    sd += __shfl_xor(sd, 32);
+    const float ni = sqrtf(ss) * 1.00001f;
+    const float nh = fminf(sqrtf(sh) * 1.00001f, 1.0e38f);                                // ||i^||
+    const float nd = fminf(sqrtf(sd) * 1.00001f + kFpSlack * ni, 1.0e38f);                // ||di|| + the fp32 slack
+    const float np = fminf(sqrtf(sd) * 1.00001f + (kFpSlack + kPackSlack) * ni, 1.0e38f);  // the pre-pass's: + its packing slack
     const bool valid = ok && item != 0;  // the PAD item and the rows past the end never pass
+    // slots 0-2: 1 (x -tau), 3: ||i^|| (x ||du||), 4: the invalid flag (x 1), 5: ||di|| + slack (x ||u||, main pass), 6: the same + the
+    // packing slack (x ||u||, pre-pass)
     bf16x8 f = {z, z, z, z, z, z, z, z};
-    if (h == 0) f = bf16x8{o, o, o, bf16_up(nrm), valid ? z : (__bf16)-3.0e38f, z, z, z};
+    if (h == 0) f = bf16x8{o, o, o, bf16_up(nh), valid ? z : (__bf16)-3.0e38f, bf16_up(nd), bf16_up(np), z};
     dst[S * 64] = f;
 }
 
@@ -180,7 +195,7 @@ struct ScreenParams {
     int64_t B;
     const char *image;   // item tiles
     const char *uimage;  // the batch's user tiles, same layout
-    int tiles_per_chunk, n_chunks;
+    int tiles_per_chunk, n_chunks;  // pre-pass: chunk c = tiles_per_chunk tiles from tile_lo + c tiles_per_chunk; main pass: see there
     int64_t tile_lo, tile_hi;
     const float *tau0;
     uint32_t *pool;
@@ -193,7 +208,7 @@ struct ScreenParams {
 // One 32-user tile per wave, two item tiles per iteration.  The maximum and its item travel in ONE register: the low 8 mantissa
 // bits of the bound are replaced by the tile's index inside the chunk (< 256), so a row costs v_and_or x 2 + v_max3 per two tiles
 // (topk.hip's pre-pass: compare + two selects per tile).  Truncating moves a bound by < 2^-15 |bound| either way; the margin of this
-// pass is widened by 2^-14 ||u|| ||i|| to stay a lower bound.
+// pass is wider by 6.2e-5 ||u|| ||i|| (> 2^-14: kPackSlack, in the item fragment's slot 6) to stay a lower bound.
 template <int S>
 __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -217,8 +232,9 @@ __global__ __launch_bounds__(256) void screen_pre_kernel(const ScreenParams p) {
     bf16x8 A[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) A[s] = uimg[s * 64];
-    bf16x8 At = uimg[S * 64];
-    At[3] = bf16_neg(At[5]);  // acc = s^ - m^ (+ -3e38 for an invalid item): the wider margin, negated
+    bf16x8 At = uimg[S * 64];  // (.., ||du||, 1, ||u||, 0, 0): acc = s^ - m^_pre (+ -3e38 for an invalid item) takes both margins negated,
+    At[3] = bf16_neg(At[3]);   // ||u|| against the item fragment's slot 6 (its slack includes the packed maxima's)
+    At[6] = bf16_neg(At[5]);
     At[5] = z;
     float best[16];
 #pragma unroll
@@ -382,8 +398,7 @@ __global__ __launch_bounds__(256) void screen_main_kernel(const ScreenParams p) 
         t = fabsf(t) * 1.0e-5f + 1.0e-30f - t;  // -(tau lowered): a pair with s >= tau has tst > 0
         bf16x2 hh, mm, ll;
         split2_bf16(t, 0.f, hh, mm, ll);
-        if (h == 0) At[j][0] = hh[0], At[j][1] = mm[0], At[j][2] = ll[0];
-        At[j][5] = z;
+        if (h == 0) At[j][0] = hh[0], At[j][1] = mm[0], At[j][2] = ll[0];  // (slots 3-5: ||du||, 1, ||u|| from the image)
     }
     int n_lo[UT], n_hi[UT];  // entries of the two lane halves in region j (wave-uniform: scalar registers)
 #pragma unroll
@@ -495,7 +510,7 @@ struct MergeParams {
     const int64_t *users;
     const int32_t *rowptr, *col;
     int64_t n_users, n_items, B;
-    int d, k, ut, n_chunks, tiles_per_chunk;
+    int d, k, ut, n_chunks;
     int64_t n_tiles;
     const uint32_t *pool;
     const int32_t *cnt;
@@ -901,9 +916,7 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     p.B = c.B;
     p.image = c.w + L.image_off;
     p.uimage = c.w + L.uimage_off;
-    p.tiles_per_chunk = L.tpc;
-    p.n_chunks = L.nc;
-    p.tile_lo = 0;
+    p.n_chunks = L.nc;  // (chunk c = the tiles c, c + nc, ... below tile_hi)
     p.tile_hi = L.n_tiles;
     p.tau0 = c.tau0;
     p.pool = reinterpret_cast<uint32_t *>(c.w + L.pool_off);
@@ -925,7 +938,6 @@ int screen_main(const ScreenCall &c, hipStream_t s) {
     q.k = c.k;
     q.ut = L.ut;
     q.n_chunks = L.nc;
-    q.tiles_per_chunk = L.tpc;
     q.n_tiles = L.n_tiles;
     q.pool = p.pool;
     q.cnt = p.cnt;
