@@ -1,6 +1,6 @@
 """The error bound the screened top-k (csrc/topk_screen.hip) rests on, checked on the CPU in numpy:
 
-    |s - s^| <= ||du|| ||i^|| + ||u|| (||di|| + 2e-5 ||i||),   u^ = bf16(u), du = u^ - u (likewise i),   s^ = u^ . i^ in fp32,
+    |s - s^| <= ||du|| ||i^|| + ||u|| (||di|| + 4e-5 ||i||),   u^ = bf16(u), du = u^ - u (likewise i),   s^ = u^ . i^ in fp32,
 
 for the exact product s (float64), the fp32 rescoring s_r the merge kernel sorts by, and the quantities as the kernels form them
 (norms in fp32 scaled by 1.00001 and rounded UP to bf16) — random rows of several scales and distributions, and adversarial rows
@@ -11,7 +11,7 @@ covers, and the threshold's lowering by 1e-5 |tau|.  No GPU: this pins the arith
 import numpy as np
 import pytest
 
-FP_SLACK = np.float32(2.0e-5)
+FP_SLACK = np.float32(4.0e-5)
 PACK_SLACK = np.float32(6.2e-5)
 
 
