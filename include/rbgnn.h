@@ -324,6 +324,12 @@ int rbg_spmm_f32(const rbg_graph *g, const float *X, float *Y, int d, int accumu
 int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs,
                       float *out_mean, int d, void *stream);
 
+/* Y = Z + Â X  (r06): one step of a Horner chain whose addend changes from layer to layer — the backward of a propagation whose
+ * layers receive different incoming gradients (XSimGCL's contrast at layer_cl, xsimgcl.py:39-41; NCL's context layer, ncl.py:137-165):
+ * dE_0 = g_0 + Â (g_1 + Â (g_2 + ...)).  Replaces "copy the addend into Y, then rbg_spmm_f32(accumulate = 1)": one 18 MB copy per
+ * layer less at the Gowalla shape.  X, Z, Y: [n, d]; Y must alias neither input. */
+int rbg_spmm_add_f32(const rbg_graph *g, const float *X, const float *Z, float *Y, int d, void *stream);
+
 /* One perturbed layer of SimGCL / XSimGCL (simgcl.py:29-34, xsimgcl.py:34-38):
  *   Y = Â X;   Y += sign(Y) * F.normalize(noise, dim=-1) * eps        (noise [N, d]: the caller's torch.rand_like draw)
  * as the SpMM's epilogue.  sign() has zero gradient, so the backward of this op is the plain Â^T product. */

@@ -221,7 +221,7 @@ bool sell_chain_factored(const rbg_graph *g);  // the slab chains read compact e
 bool sell_plain_applicable(const rbg_graph *g, int d, int64_t ldx);  // the plain layer runs on the plan (row-major entries, or the slab scratch)
 int sell_spmm(const rbg_graph *g, const float *X, int64_t ldx, float *Y, int d, int accumulate, const float *noise, float eps, hipStream_t s);
 // rbg_spmm_mean_f32 over the plan: out = (srcs[0] + ... + srcs[n - 1] + (partial +) A X) / (n + 1), everything row-major [n_rows, d]
-int sell_spmm_mean(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean, int d, hipStream_t s);
+int sell_spmm_mean(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean, int d, float denom, hipStream_t s);
 bool sell_stride_ok(const rbg_graph *g, int d, int64_t ldx);
 // every layer row-major (the caller reads `layers`, or one graph per layer)
 int sell_forward_rowmajor(const rbg_graph *const *graphs, int n_graphs, const float *user_emb, const float *item_emb, float *out_mean,

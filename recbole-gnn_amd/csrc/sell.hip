@@ -494,7 +494,7 @@ static int sell_spmm_w(const rbg_graph *g, const float *X, int64_t ldx, float *Y
 // row-major (rbg_spmm_mean_f32: the sharded forward's last launch — lightgcn.py:76-78 on a rank's rows)
 template <int W, int NS>
 static int sell_spmm_mean_w(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean,
-                            hipStream_t s) {
+                            float denom, hipStream_t s) {
     const SellDev *sw = g->sell;
     const int n0 = sw->n_class[0];
     SellParams p{};
@@ -510,16 +510,16 @@ static int sell_spmm_mean_w(const rbg_graph *g, const float *X, const float *par
     for (int i = 1; i < n_srcs; ++i) p.prev[i] = srcs[i];
     p.n_prev = n_srcs;
     if (partial) p.prev[p.n_prev++] = partial;
-    p.denom = (float)(n_srcs + 1);
+    p.denom = denom;  // (n_srcs + 1 for the mean; 1 for rbg_spmm_add_f32's Y = Z + A X)
     p.out = out_mean;
     return sell_launch<W, NS>(sw, p, s);
 }
 
 int sell_spmm_mean(const rbg_graph *g, const float *X, const float *partial, const float *const *srcs, int n_srcs, float *out_mean, int d,
-                   hipStream_t s) {
+                   float denom, hipStream_t s) {
     if (n_srcs + (partial ? 1 : 0) > RBG_MAX_FUSED_LAYERS + 1 || !g->sell->ent0 || !opt_sell_rowmajor()) return RBG_EUNSUPPORTED;
     const int W = g->sell->W;
-#define CALL(W_, NS_) sell_spmm_mean_w<W_, NS_>(g, X, partial, srcs, n_srcs, out_mean, s)
+#define CALL(W_, NS_) sell_spmm_mean_w<W_, NS_>(g, X, partial, srcs, n_srcs, out_mean, denom, s)
     RBG_SELL_DISPATCH(W, d, CALL);
 #undef CALL
     return RBG_EUNSUPPORTED;

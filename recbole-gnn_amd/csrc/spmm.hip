@@ -752,7 +752,7 @@ int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, 
         bool al = true;
         for (int i = 0; i < n_srcs; ++i) al = al && aligned16(srcs[i]);
         if (al) {
-            rc = sell_spmm_mean(g, X, partial, srcs, n_srcs, out_mean, d, (hipStream_t)stream);
+            rc = sell_spmm_mean(g, X, partial, srcs, n_srcs, out_mean, d, (float)(n_srcs + 1), (hipStream_t)stream);
             if (rc != RBG_EUNSUPPORTED) return rc;
         }
     }
@@ -767,6 +767,34 @@ int rbg_spmm_mean_f32(const rbg_graph *g, const float *X, const float *partial, 
     p.n_prev = n_srcs - 1;
     for (int i = 1; i < n_srcs; ++i) p.prev[i - 1] = srcs[i];
     p.denom = (float)(n_srcs + 1);
+    return launch_spmm(g, p, d, (hipStream_t)stream);
+}
+
+int rbg_spmm_add_f32(const rbg_graph *g, const float *X, const float *Z, float *Y, int d, void *stream) {
+    clear_error();
+    int rc = check_device_graph(g);
+    if (rc) return rc;
+    if (d <= 0) return fail(RBG_ESHAPE, "d = %d", d);
+    if (g->n_rows == 0) return RBG_OK;
+    if (!X || !Z || !Y) return fail(RBG_EINVAL, "NULL pointer");
+    if (Y == X || Y == Z) return fail(RBG_EINVAL, "Y aliases an input");
+    if ((rc = set_device_for(g->device))) return rc;
+    // the mean epilogue with one addend and no division: (Z + A X) / 1
+    if (sell_plain_applicable(g, d, d) && aligned16(X) && aligned16(Y) && aligned16(Z)) {
+        const float *srcs[1] = {Z};
+        rc = sell_spmm_mean(g, X, nullptr, srcs, 1, Y, d, 1.0f, (hipStream_t)stream);
+        if (rc != RBG_EUNSUPPORTED) return rc;
+    }
+    SpmmParams p{};
+    p.x = make_src(X, X, 0, d);
+    p.y = nullptr;
+    p.ldy = d;
+    p.mode = MODE_MEAN;
+    p.mean_out = Y;
+    p.partial = nullptr;
+    p.e0 = make_src(Z, Z, 0, d);
+    p.n_prev = 0;
+    p.denom = 1.0f;
     return launch_spmm(g, p, d, (hipStream_t)stream);
 }
 

@@ -78,6 +78,21 @@ def spmm(graph, x):
     return _Spmm.apply(x, graph)
 
 
+def spmm_add_raw(graph, x, z, out=None):
+    """Y = Z + Â·X in one launch (no autograd): a Horner step with its own addend (rbg_spmm_add_f32)."""
+    _require_device_graph(graph)
+    _check_dense(x, "x", graph)
+    _check_dense(z, "z", graph)
+    if x.dim() != 2 or x.shape[0] != graph.n_cols or tuple(z.shape) != (graph.n_rows, x.shape[1]):
+        raise ValueError(f"x must be [{graph.n_cols}, d] and z [{graph.n_rows}, d]")
+    x, z = x.contiguous(), z.contiguous()
+    if out is None:
+        out = torch.empty((graph.n_rows, x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.rbg_spmm_add_f32(graph.ptr, c_vp(x.data_ptr()), c_vp(z.data_ptr()), c_vp(out.data_ptr()), x.shape[1], _stream(x)))
+    return out
+
+
 def spmm_noise_raw(graph, x, noise, eps, out=None):
     """Y = Â·X;  Y += sign(Y) * normalize(noise, dim=-1) * eps  (simgcl.py:29-34), no autograd."""
     _require_device_graph(graph)

@@ -571,19 +571,20 @@ class FusedXSimGCLAdam(_FusedContrastStep):
             # (+ gcl at j = layer_cl); Horner from the top layer down
             gt = m.graph.transpose().ptr
             torch.mul(self.gm, 1.0 / k, out=self.gm)
-            cur, nxt = self.t0, self.t1
-            cur.copy_(self.gm)
-            if lc == k:
-                cur.add_(self.gcl)
-            for j in range(k - 1, 0, -1):
-                nxt.copy_(self.gm)
-                if lc == j:
-                    nxt.add_(self.gcl)
-                check(lib.rbg_spmm_f32(gt, p(cur), p(nxt), d, 1, st))  # nxt += A cur
-                cur, nxt = nxt, cur
-            check(lib.rbg_spmm_f32(gt, p(cur), p(self.ge), d, 0, st))
+            # r06: every step is ONE launch  nxt = g_j + A cur  (rbg_spmm_add_f32) — no copy of the addend into the output first;
+            # the layer that also receives the contrast's gradient takes gm + gcl (formed in place in gcl, once)
+            if lc >= 1:
+                self.gcl.add_(self.gm)
+            cur = self.gcl if lc == k else self.gm
+            bufs = (self.t0, self.t1)
+            for n, j in enumerate(range(k - 1, 0, -1)):
+                nxt = bufs[n & 1]
+                check(lib.rbg_spmm_add_f32(gt, p(cur), p(self.gcl if lc == j else self.gm), p(nxt), d, st))
+                cur = nxt
             if lc == 0:
-                self.ge.add_(self.gcl)
+                check(lib.rbg_spmm_add_f32(gt, p(cur), p(self.gcl), p(self.ge), d, st))
+            else:
+                check(lib.rbg_spmm_f32(gt, p(cur), p(self.ge), d, 0, st))
             self._reg_and_adam(user, pos, neg, b, d)
 
 
@@ -669,24 +670,29 @@ class FusedNCLAdam(_FusedStep):
             gt = m.graph.transpose().ptr
             torch.mul(self.gm, 1.0 / (k + 1), out=self.gm)
             h2 = 2 * m.hyper_layers
+            # r06: every step is ONE launch  nxt = g_j + A cur  (rbg_spmm_add_f32) instead of "copy g_j, then accumulate";
+            # g_j = gm (j <= K) + gctx (j = 2 h): the sums that occur are formed in place, once (gctx += gm, g0 += gm)
+            if h2 <= k:
+                self.gctx.add_(self.gm)
+            self.g0.add_(self.gm)
 
-            def g_of(j, out):
-                if j <= k:
-                    out.copy_(self.gm)
-                else:
-                    out.zero_()
+            def g_of(j):
                 if j == h2:
-                    out.add_(self.gctx)
+                    return self.gctx  # (gm + gctx when 2 h <= K, gctx alone above K)
+                if j <= k:
+                    return self.gm
+                return None  # no incoming gradient at this layer
 
-            cur, nxt = self.t0, self.t1
-            g_of(L, cur)
-            for j in range(L - 1, 0, -1):
-                g_of(j, nxt)
-                check(lib.rbg_spmm_f32(gt, p(cur), p(nxt), d, 1, st))  # nxt += A cur
-                cur, nxt = nxt, cur
-            self.ge.copy_(self.gm)
-            self.ge.add_(self.g0)
-            check(lib.rbg_spmm_f32(gt, p(cur), p(self.ge), d, 1, st))
+            cur = g_of(L)
+            bufs = (self.t0, self.t1)
+            for n, j in enumerate(range(L - 1, 0, -1)):
+                nxt, add = bufs[n & 1], g_of(j)
+                if add is None:
+                    check(lib.rbg_spmm_f32(gt, p(cur), p(nxt), d, 0, st))
+                else:
+                    check(lib.rbg_spmm_add_f32(gt, p(cur), p(add), p(nxt), d, st))
+                cur = nxt
+            check(lib.rbg_spmm_add_f32(gt, p(cur), p(self.g0), p(self.ge), d, st))
             check(lib.rbg_emb_reg_grad_nopow_f32(p(uw), p(iw), nu, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge), p(self.loss),
                                                  p(self.reg_ws), st))
             self.table_opt.step(self.ge)

@@ -104,6 +104,29 @@ def test_spmm_vs_oracle(rbg, cuda, golden, d):
     assert torch.equal(rbg.ops.spmm_raw(h, x), y)  # bit-stable run to run (no float atomics)
 
 
+@pytest.mark.parametrize("d", [64, 128, 100, 8])
+def test_spmm_add_vs_oracle(rbg, cuda, golden, d):
+    """r06, rbg_spmm_add_f32: Y = Z + Â·X in one launch (the column-slab kernel's mean epilogue with one addend and no division; the
+    binned kernel at the widths without a plan, and with option "sell" off) against the C oracle's product + Z; X and Z may be the
+    same table (a Horner chain's first step on the gradient itself); every output element is written."""
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    x, z = randn((nu + ni, d), 3 + d, cuda), randn((nu + ni, d), 5 + d, cuda)
+    ref = C.spmm(g["rowptr"], g["col"].astype(np.int64), g["val"], x.cpu().numpy())
+    for sell in (1, 0):
+        rbg.set_option("sell", sell)
+        try:
+            y = rbg.ops.spmm_add_raw(h, x, z, out=torch.full_like(x, float("nan")))
+            close(y, ref + z.cpu().numpy())
+            close(rbg.ops.spmm_add_raw(h, x, x), ref + x.cpu().numpy())
+            assert torch.equal(rbg.ops.spmm_add_raw(h, x, z), y)  # bit-stable
+        finally:
+            rbg.set_option("sell", 1)
+    with pytest.raises(rbg.RbgError):
+        rbg.ops.spmm_add_raw(h, x, z, out=x)
+
+
 def test_spmm_golden_layers(rbg, cuda, golden):
     g = golden
     nu, ni = int(g["n_users"]), int(g["n_items"])
