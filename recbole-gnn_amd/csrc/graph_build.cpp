@@ -56,6 +56,8 @@ static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 static std::atomic<int> g_lse_tr_read{1};
 int opt_lse_tr_read() { return g_lse_tr_read.load(); }
+static std::atomic<int> g_lse_f16{1};
+int opt_lse_f16() { return g_lse_f16.load(); }
 static std::atomic<int> g_lse_image{0};  // (measured neutral to slightly slower, profiles/r06_lse_image.jsonl: off)
 int opt_lse_image() { return g_lse_image.load(); }
 static std::atomic<int> g_sell_c16{1};
@@ -541,6 +543,10 @@ int rbg_set_option(const char *key, int64_t value) {
         g_lse_tr_read = value ? 1 : 0;
         return RBG_OK;
     }
+    if (!strcmp(key, "lse_f16")) {
+        g_lse_f16 = value ? 1 : 0;
+        return RBG_OK;
+    }
     if (!strcmp(key, "topk_image")) {
         g_topk_image = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         return RBG_OK;
@@ -647,6 +653,10 @@ int rbg_get_option(const char *key, int64_t *value) {
     }
     if (!strcmp(key, "lse_tr_read")) {
         *value = g_lse_tr_read.load();
+        return RBG_OK;
+    }
+    if (!strcmp(key, "lse_f16")) {
+        *value = g_lse_f16.load();
         return RBG_OK;
     }
     if (!strcmp(key, "topk_image")) {

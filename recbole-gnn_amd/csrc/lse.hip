@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 #include "internal.h"
@@ -47,7 +48,12 @@ struct LseParams {
     int tiles_per_chunk, n_chunks;
     int64_t own_blocks, total_blocks, blocks_per_xcd;  // workgroup j = chunk * own_blocks + own_block, j < total_blocks
     const char *oth_image;  // r06: `oth` as bf16 planes in the LDS layout (plane_image.h), taken by LDS-DMA; NULL: fetch + split per workgroup
+    // r06, the fp16 form (F16; 0 = not that form): the weights enter the second product as w * w_scale (<= 2^14 by the caller's
+    // choice of w_scale), den_out receives zsum * inv_w_scale, out receives g * out_scale
+    float w_scale, inv_w_scale, out_scale;
 };
+
+constexpr float kF16RowScale = 256.f;  // unit rows as fp16 pairs: x * 2^8 (mfma_common.h, split2_f16)
 
 template <int R>
 struct LseRows {
@@ -75,9 +81,14 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // split into three bf16 terms (mfma_common.h: the accuracy of the fp32 chain, 24 x 32 instead of 32 x 64 cycles per
 // 64 k); the oth tile is then published as three bf16 planes, and — for the gradients, whose second product reads the
 // tile as fp32 columns — as the fp32 tile too.
-template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false>
-__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3) : 1) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
+// F16 (r06, option "lse_f16"; rbg_infonce_f32's unit rows and weights in [0, 1] only): both products on v_mfma_f32_32x32x16_f16 with
+// every operand split into TWO fp16 terms after a power-of-two scale — three products (h h, h l, l h) instead of six, two planes
+// instead of three, 32 instead of 48 own-fragment registers: three workgroups per CU at d <= 64, two at d = 128 (one before).
+template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false>
+__global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 2) : 3) : (F16 ? 2 : 1)) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
+    static_assert(!F16 || (SPLIT && TRR && GRAD && !IMG), "the fp16 form: gradient passes, transpose reads, tiles fetched and split per workgroup");
+    constexpr int NPL = F16 ? 2 : 3;
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
     // who reads s_oth: the exact-fp32 products.  (r03: with split operands the gradients' second product takes its B
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
     // the three terms of every tile element; the per-lane re-split of 16 element pairs per tile is gone, and the fp32 tile with it.)
     constexpr bool kFp32Tile = !SPLIT;
     __shared__ __attribute__((aligned(16))) float s_oth[kFp32Tile ? 2 : 1][kFp32Tile ? 32 : 1][kFp32Tile ? LD : 4];
-    __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][3][SPLIT ? 32 : 1][SPLIT ? LDH : 8];
+    __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][NPL][SPLIT ? 32 : 1][SPLIT ? LDH : 8];  // (F16: two planes of fp16 bit patterns)
     // (r03) the gradients' second product reads the tile by COLUMN (8 oth rows of one feature column per lane): a transposed
     // copy of the planes [plane][column][row], row stride 36 bf16 (8-byte aligned, 18 dwords: b64 reads of 32 columns land in
     // 32 different bank pairs), makes a B fragment two 8-byte reads instead of eight 2-byte reads plus their packing
@@ -109,9 +120,13 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
     float bo[NC][32];
 #pragma unroll
     for (int c = 0; c < NC; ++c) load_run32f<(VEC ? RUN_VEC : RUN_ANY)>(p.own + own_row * p.ld_own, own_ok, c * 64 + h * 32, p.d, bo[c]);
-    std::conditional_t<SPLIT, AFrag3<NC>, int> bo3;
-    if constexpr (SPLIT) split_a(bo, bo3);
-    const float c_own = (GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f;
+    std::conditional_t<SPLIT && !F16, AFrag3<NC>, int> bo3;
+    std::conditional_t<F16, AFrag2<NC>, int> bo2;
+    if constexpr (F16) split_a_f16(bo, kF16RowScale, bo2);
+    else if constexpr (SPLIT) split_a(bo, bo3);
+    // (F16: the product of two scaled rows is x * 2^16, and the weights carry w_scale into the second product)
+    const float s2 = F16 ? p.s2 * (1.0f / (kF16RowScale * kF16RowScale)) : p.s2;
+    const float c_own = ((GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f) * (F16 ? p.w_scale : 1.f);
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zsum = 0.f;
     f32x16 g[GRAD ? NC * 2 : 1];
@@ -151,7 +166,13 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
         for (int k = 0; k < NC * 2; ++k) {
             const int f = tid + 256 * k, row = f / (NC * 16), c4 = (f % (NC * 16)) * 4;
             if constexpr (kFp32Tile) *reinterpret_cast<float4 *>(&s_oth[buf][row][c4]) = stage[k];
-            if constexpr (SPLIT) {
+            if constexpr (F16) {
+                f16x2 h0, l0, h1, l1;
+                split2_f16(stage[k].x, stage[k].y, kF16RowScale, h0, l0);
+                split2_f16(stage[k].z, stage[k].w, kF16RowScale, h1, l1);
+                *reinterpret_cast<f16x4 *>(&s_pl[buf][0][row][c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
+                *reinterpret_cast<f16x4 *>(&s_pl[buf][1][row][c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
+            } else if constexpr (SPLIT) {
                 bf16x2 h0, m0, l0, h1, m1, l1;
                 split2_bf16(stage[k].x, stage[k].y, h0, m0, l0);
                 split2_bf16(stage[k].z, stage[k].w, h1, m1, l1);
@@ -169,7 +190,20 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
     };
     auto compute = [&](const int buf, const int64_t t) __attribute__((always_inline)) {
         f32x16 x = zero;
-        if constexpr (SPLIT) {
+        if constexpr (F16) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = c * 64 + h * 32 + q * 8;
+                    const f16x8 ah = *reinterpret_cast<const f16x8 *>(&s_pl[buf][0][i][off]);
+                    const f16x8 al = *reinterpret_cast<const f16x8 *>(&s_pl[buf][1][i][off]);
+                    const int sidx = c * 4 + q;
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bo2.h[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.l[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.h[sidx], x, 0, 0, 0);
+                }
+        } else if constexpr (SPLIT) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -203,7 +237,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
         if constexpr (!GRAD) {
             LseRows<0>::run([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const float e = __builtin_amdgcn_exp2f(x[r] * p.s2 - p.shift2);
+                const float e = __builtin_amdgcn_exp2f(x[r] * s2 - p.shift2);
                 zsum += (lse_rowmap(r, h) < left) ? e : 0.f;
             });
         } else {
@@ -211,14 +245,44 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
             LseRows<0>::run([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int o = lse_rowmap(r, h);
-                float e = __builtin_amdgcn_exp2f(x[r] * p.s2 - p.shift2) * c_own;
+                float e = __builtin_amdgcn_exp2f(x[r] * s2 - p.shift2) * c_own;
                 if (p.coef_oth) e *= s_coef[buf][o];
                 w[r] = (o < left) ? e : 0.f;
             });
             if (p.den_out) {  // (uniform) forward and own-side gradient in one pass: the weights' row sums are the denominators
                 LseRows<0>::run([&](auto rc) { zsum += w[decltype(rc)::value]; });
             }
-            if constexpr (SPLIT) {
+            if constexpr (F16) {
+                // w <= 2^14 (the caller's w_scale), two fp16 terms; the tile's columns come out of the two planes by transpose reads
+                f16x8 wh[2], wl[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f16x2 hh, ll;
+                        split2_f16(w[8 * u + 2 * j], w[8 * u + 2 * j + 1], 1.f, hh, ll);
+                        wh[u][2 * j] = hh[0], wh[u][2 * j + 1] = hh[1];
+                        wl[u][2 * j] = ll[0], wl[u][2 * j + 1] = ll[1];
+                    }
+#pragma unroll
+                for (int q = 0; q < NC * 2; ++q)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        auto col8 = [&](const int pl) __attribute__((always_inline)) {
+                            typedef short s16x4 __attribute__((ext_vector_type(4)));
+                            const int t = lane & 15;
+                            const __bf16 *src = &s_pl[buf][pl][16 * u + 4 * h + (t >> 2)][q * 32 + (i & 16) + 4 * (t & 3)];
+                            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(src + 8 * LDH));
+                            const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+                            return (f16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                        };
+                        const f16x8 bh = col8(0), bl = col8(1);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[u], bh, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bl, g[q], 0, 0, 0);
+                        g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bh, g[q], 0, 0, 0);
+                    }
+            } else if constexpr (SPLIT) {
                 // second product on the bf16 matrix cores too: MFMA u of a pair covers the oth rows rowmap(8 u + j, h),
                 // j = 0..7 — the weights this lane already holds (A slot) against a column of the fp32 tile (B slot), both
                 // split here, six products of order >= 2^-16
@@ -333,7 +397,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
     } else {
         if (p.den_out) {
             zsum += __shfl_xor(zsum, 32);
-            if (h == 0 && own_ok) p.den_out[chunk * p.n_own + own_row] = zsum;
+            if (h == 0 && own_ok) p.den_out[chunk * p.n_own + own_row] = F16 ? zsum * p.inv_w_scale : zsum;
         }
         // g[q][r]: own row own0 + rowmap(r,h), feature column q*32 + i
         float *base = p.out + chunk * p.n_own * p.d;
@@ -343,7 +407,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG ? 3 : 2) : 3)
             LseRows<0>::run([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int64_t row = own0 + lse_rowmap(r, h);
-                if (row < p.n_own && col < p.d) base[row * p.d + col] = g[q][r];
+                if (row < p.n_own && col < p.d) base[row * p.d + col] = F16 ? g[q][r] * p.out_scale : g[q][r];
             });
         }
     }
@@ -405,13 +469,16 @@ struct LseLayout {
     int tpc_c, nc_c;  // dC (own = C)
     int64_t off_coef, off_q, off_c, off_den, bytes;
 };
-static LseLayout lse_layout(int64_t B, int64_t n, int d) {
+// the fp16 form of the gradient passes (rbg_infonce_f32 without weights; F16 in lse_tile_kernel) is on
+static bool lse_f16_on(int d) { return opt_mfma_split() != 0 && opt_lse_tr_read() && !opt_lse_image() && opt_lse_f16() && d % 4 == 0; }
+
+static LseLayout lse_layout_of(int64_t B, int64_t n, int d, bool f16) {
     LseLayout L{};
     const bool split = opt_mfma_split() != 0;  // (the split kernels hold 48 instead of 32 own registers per chunk)
     // resident workgroups per CU (register-limited; r06: the gradient kernel that takes its tiles from plane images and its column
     // fragments by transpose reads fits three at d <= 64: 168 registers, 28 KB of LDS)
     const bool img3 = split && opt_lse_image() && opt_lse_tr_read();
-    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = d <= 64 ? (split ? (img3 ? 3 : 2) : 3) : 1;
+    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = f16 ? (d <= 64 ? 3 : 2) : d <= 64 ? (split ? (img3 ? 3 : 2) : 3) : 1;
     // one partial array per chunk: own rows x d x 8 bytes (write + read) at ~5 TB/s, in units of a ~1.2 us tile
     auto partial_cost = [&](int64_t rows) { return (double)rows * d * 8.0 / 5e6 / 1.2; };
     lse_geometry(B, n, res_f, 0.02, L.tpc_f, L.nc_f);
@@ -427,6 +494,12 @@ static LseLayout lse_layout(int64_t B, int64_t n, int d) {
     L.bytes = L.off_den + up((int64_t)L.nc_q * B * 4) + 256;
     return L;
 }
+// (a workspace serves either form: the masked InfoNCE keeps the bf16 kernels while the option is on)
+static LseLayout lse_layout(int64_t B, int64_t n, int d, bool f16 = false) {
+    LseLayout L = lse_layout_of(B, n, d, f16);
+    if (lse_f16_on(d)) L.bytes = std::max(L.bytes, lse_layout_of(B, n, d, !f16).bytes);
+    return L;
+}
 
 template <int NC, bool GRAD>
 static void lse_launch(LseParams p, bool vec, hipStream_t s) {
@@ -436,6 +509,10 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     dim3 grid((unsigned)(p.blocks_per_xcd * 8));
     const bool split = opt_mfma_split() != 0;
     if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
+        if (p.w_scale != 0.f) {  // the fp16 form (the caller checked lse_f16_on and the alignment)
+            hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true>), grid, dim3(256), 0, s, p);
+            return;
+        }
         if (split && opt_lse_tr_read()) {
             if (p.oth_image) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true>), grid, dim3(256), 0, s, p);
             else if (vec) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true>), grid, dim3(256), 0, s, p);
@@ -856,11 +933,13 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
                            const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
                            float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr) {
-    const LseLayout L = lse_layout(B, n, d);
+    const bool vec = lse_vec(A, d, C, d, d);
+    // r06, the fp16 form: unit rows and weights in [0, 1] — the plain InfoNCE only (row / candidate weights are the caller's numbers)
+    const bool f16 = !row_w && !col_w && vec && lse_f16_on(d);
+    const LseLayout L = lse_layout(B, n, d, f16);
     char *w = reinterpret_cast<char *>(lse_ws);
     float *coef = reinterpret_cast<float *>(w + L.off_coef), *part_q = reinterpret_cast<float *>(w + L.off_q);
     float *part_c = L.nc_c > 1 ? reinterpret_cast<float *>(w + L.off_c) : dC, *den = reinterpret_cast<float *>(w + L.off_den);
-    const bool vec = lse_vec(A, d, C, d, d);
     // r06: the normalised table and batch rows as plane images (plane_image.h), built once per call: both gradient passes take their
     // oth tiles by LDS-DMA instead of fetching, splitting and publishing them in every workgroup
     const bool img = imgC && imgA && d <= 128 && opt_mfma_split() != 0 && opt_lse_tr_read() && opt_lse_image();
@@ -887,6 +966,10 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     p.out = part_q;
     p.den_out = den;
     p.coef_oth = col_w;  // (masked form: a candidate's weight in every denominator; NULL = 1)
+    if (f16) {  // pass 1: w = exp(..) <= 1 enters as w 2^14; the partials leave as g 2^-14 2^-8, the denominators as zsum 2^-14 (all exact)
+        p.w_scale = 16384.f, p.inv_w_scale = 1.f / 16384.f;
+        p.out_scale = p.inv_w_scale / kF16RowScale;
+    }
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
     hipLaunchKernelGGL(nce_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, den, L.nc_q, pos, row_w, B, scale, scale, weight, term, coef);
@@ -901,6 +984,12 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
     p.out = part_c;
     p.den_out = nullptr;
+    if (f16) {  // pass 2: w = exp(..) coef[b] = (weight scale) x a probability: enters as p 2^14, leaves multiplied back
+        const float ws = weight * scale, k = 16384.f / ws;
+        const bool ok = ws != 0.f && std::isfinite(k) && std::isfinite(ws / 16384.f);
+        p.w_scale = ok ? k : 16384.f, p.inv_w_scale = 1.f / p.w_scale;
+        p.out_scale = (ok ? ws / 16384.f : 1.f / 16384.f) / kF16RowScale;
+    }
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);

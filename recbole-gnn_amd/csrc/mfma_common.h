@@ -219,4 +219,45 @@ struct RowTile3 {
     }
 };
 
+// ---- split-precision operands, fp16 form (r06): fp32 = hi + lo in fp16 after a power-of-two scale -----------------------
+// For operands of known magnitude (unit rows, weights in [0, 1]) two fp16 terms (11 significand bits each: x = h + l up to
+// 2^-22 |x|) and the THREE products h h, h l, l h on v_mfma_f32_32x32x16_f16 stand in for the six bf16 products above at half the
+// matrix-core time, a third less LDS traffic and a third fewer fragment registers; the price is two bits (relative error of a
+// product <= 3 x 2^-22 instead of ~ 2^-23).  The power-of-two `scale` (exact; the caller folds its inverse into what consumes the
+// accumulator) keeps the LOW term a normal fp16 number wherever that matters: l is below fp16's smallest normal 2^-14 only for
+// |x| scale < 2^-3, and is then rounded with an ABSOLUTE error <= 2^-25 / scale (1.2e-10 at scale = 2^8) instead of 2^-11 |l| —
+// should the matrix core flush subnormal inputs the error is |l| < 2^-14 / scale.  Overflow needs |x| scale > 65 504.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2_f16(float x0, float x1, float scale, f16x2 &h, f16x2 &l) {
+    const f32x2v v = {x0 * scale, x1 * scale};                    // (power of two: exact)
+    h = __builtin_convertvector(v, f16x2);                        // v_cvt_pk_f16_f32 (RNE)
+    const f32x2v r = v - __builtin_convertvector(h, f32x2v);     // exact
+    l = __builtin_convertvector(r, f16x2);
+}
+
+template <int NCHUNK>
+struct AFrag2 {  // a lane's operand: NCHUNK runs of 32 floats as two fp16 terms; 32 NCHUNK registers
+    f16x8 h[NCHUNK * 4], l[NCHUNK * 4];
+};
+
+template <int NCHUNK>
+__device__ __forceinline__ void split_a_f16(const float (&a)[NCHUNK][32], float scale, AFrag2<NCHUNK> &f) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f16x2 h, l;
+                split2_f16(a[c][8 * q + 2 * j], a[c][8 * q + 2 * j + 1], scale, h, l);
+                f.h[c * 4 + q][2 * j] = h[0];
+                f.h[c * 4 + q][2 * j + 1] = h[1];
+                f.l[c * 4 + q][2 * j] = l[0];
+                f.l[c * 4 + q][2 * j + 1] = l[1];
+            }
+}
+
 }  // namespace rbg
