@@ -50,7 +50,7 @@ struct LseParams {
     const char *oth_image;  // r06: `oth` as bf16 planes in the LDS layout (plane_image.h), taken by LDS-DMA; NULL: fetch + split per workgroup
     // r06, the fp16 form (F16; 0 = not that form): the weights enter the second product as w * w_scale (<= 2^14 by the caller's
     // choice of w_scale), den_out receives zsum * inv_w_scale, out receives g * out_scale
-    float w_scale, inv_w_scale, out_scale;
+    float w_scale, inv_w_scale, out_scale, w_shift2;
 };
 
 constexpr float kF16RowScale = 256.f;  // unit rows as fp16 pairs: x * 2^8 (mfma_common.h, split2_f16)
@@ -84,10 +84,13 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // F16 (r06, option "lse_f16"; rbg_infonce_f32's unit rows and weights in [0, 1] only): both products on v_mfma_f32_32x32x16_f16 with
 // every operand split into TWO fp16 terms after a power-of-two scale — three products (h h, h l, l h) instead of six, two planes
 // instead of three, 32 instead of 48 own-fragment registers: three workgroups per CU at d <= 64, two at d = 128 (one before).
-template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false>
+// PASS (F16 only) says at compile time what the two launches of the one-pass InfoNCE differ in — 1: denominators, no row weights;
+// 2: the batch rows' coefficients in s_coef, no denominators — so the weights' code has no (uniform) branches between the products.
+template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false, int PASS = 0>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 2) : 3) : (F16 ? 2 : 1)) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
     static_assert(!F16 || (SPLIT && TRR && GRAD && !IMG), "the fp16 form: gradient passes, transpose reads, tiles fetched and split per workgroup");
+    static_assert(F16 == (PASS != 0), "PASS belongs to the fp16 form");
     constexpr int NPL = F16 ? 2 : 3;
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
@@ -126,7 +129,9 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     else if constexpr (SPLIT) split_a(bo, bo3);
     // (F16: the product of two scaled rows is x * 2^16, and the weights carry w_scale into the second product)
     const float s2 = F16 ? p.s2 * (1.0f / (kF16RowScale * kF16RowScale)) : p.s2;
-    const float c_own = ((GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f) * (F16 ? p.w_scale : 1.f);
+    // pass 1 folds its power-of-two w_scale into the exponent (w_shift2 = log2 w_scale, exact), pass 2 multiplies the 32 coefficients of a tile
+    const float shift2 = F16 ? p.shift2 - p.w_shift2 : p.shift2;
+    const float c_own = (!F16 && GRAD && p.coef_own) ? (own_ok ? p.coef_own[own_row] : 0.f) : 1.f;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float zsum = 0.f;
     f32x16 g[GRAD ? NC * 2 : 1];
@@ -159,7 +164,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
             }
             stage[k] = v;
         }
-        if (GRAD && p.coef_oth && tid < 32) stage_coef = (t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] : 0.f;
+        if constexpr (F16) {
+            if (PASS == 2 && tid < 32) stage_coef = (t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] * p.w_scale : 0.f;
+        } else {
+            if (GRAD && p.coef_oth && tid < 32) stage_coef = (t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] : 0.f;
+        }
     };
     auto publish = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -186,7 +195,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
                 }
             }
         }
-        if (GRAD && p.coef_oth && tid < 32) s_coef[buf][tid] = stage_coef;
+        if constexpr (F16) {
+            if (PASS == 2 && tid < 32) s_coef[buf][tid] = stage_coef;
+        } else {
+            if (GRAD && p.coef_oth && tid < 32) s_coef[buf][tid] = stage_coef;
+        }
     };
     auto compute = [&](const int buf, const int64_t t) __attribute__((always_inline)) {
         f32x16 x = zero;
@@ -242,6 +255,23 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
             });
         } else {
             float w[16];
+            if constexpr (F16) {
+                LseRows<0>::run([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const float e = __builtin_amdgcn_exp2f(x[r] * s2 - shift2);
+                    w[r] = PASS == 2 ? e * s_coef[buf][lse_rowmap(r, h)] : e;  // (rows past the end have coefficient 0)
+                });
+                if constexpr (PASS == 1) {
+                    if (left < 32) {  // (uniform: the table's last tile) rows past the end are zero rows, their weight is not
+                        const int left32 = (int)left;
+                        LseRows<0>::run([&](auto rc) {
+                            constexpr int r = decltype(rc)::value;
+                            w[r] = (lse_rowmap(r, h) < left32) ? w[r] : 0.f;
+                        });
+                    }
+                    LseRows<0>::run([&](auto rc) { zsum += w[decltype(rc)::value]; });
+                }
+            } else {
             LseRows<0>::run([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int o = lse_rowmap(r, h);
@@ -251,6 +281,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
             });
             if (p.den_out) {  // (uniform) forward and own-side gradient in one pass: the weights' row sums are the denominators
                 LseRows<0>::run([&](auto rc) { zsum += w[decltype(rc)::value]; });
+            }
             }
             if constexpr (F16) {
                 // w <= 2^14 (the caller's w_scale), two fp16 terms; the tile's columns come out of the two planes by transpose reads
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
         zsum += __shfl_xor(zsum, 32);
         if (h == 0 && own_ok) p.out[chunk * p.n_own + own_row] = zsum;
     } else {
-        if (p.den_out) {
+        if (F16 ? PASS == 1 : p.den_out != nullptr) {
             zsum += __shfl_xor(zsum, 32);
             if (h == 0 && own_ok) p.den_out[chunk * p.n_own + own_row] = F16 ? zsum * p.inv_w_scale : zsum;
         }
@@ -510,7 +541,8 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     const bool split = opt_mfma_split() != 0;
     if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
         if (p.w_scale != 0.f) {  // the fp16 form (the caller checked lse_f16_on and the alignment)
-            hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true>), grid, dim3(256), 0, s, p);
+            if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 1>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 2>), grid, dim3(256), 0, s, p);
             return;
         }
         if (split && opt_lse_tr_read()) {
@@ -967,7 +999,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     p.den_out = den;
     p.coef_oth = col_w;  // (masked form: a candidate's weight in every denominator; NULL = 1)
     if (f16) {  // pass 1: w = exp(..) <= 1 enters as w 2^14; the partials leave as g 2^-14 2^-8, the denominators as zsum 2^-14 (all exact)
-        p.w_scale = 16384.f, p.inv_w_scale = 1.f / 16384.f;
+        p.w_scale = 16384.f, p.inv_w_scale = 1.f / 16384.f, p.w_shift2 = 14.f;
         p.out_scale = p.inv_w_scale / kF16RowScale;
     }
     lse_launch_d<true>(p, vec, s);
@@ -987,7 +1019,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     if (f16) {  // pass 2: w = exp(..) coef[b] = (weight scale) x a probability: enters as p 2^14, leaves multiplied back
         const float ws = weight * scale, k = 16384.f / ws;
         const bool ok = ws != 0.f && std::isfinite(k) && std::isfinite(ws / 16384.f);
-        p.w_scale = ok ? k : 16384.f, p.inv_w_scale = 1.f / p.w_scale;
+        p.w_scale = ok ? k : 16384.f, p.inv_w_scale = 1.f / p.w_scale, p.w_shift2 = 0.f;
         p.out_scale = (ok ? ws / 16384.f : 1.f / 16384.f) / kF16RowScale;
     }
     lse_launch_d<true>(p, vec, s);

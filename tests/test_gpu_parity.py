@@ -1140,6 +1140,45 @@ def test_info_nce_zero_row(rbg, cuda):
     close(g2.grad, b64.grad.float(), tol=2e-5)
 
 
+@pytest.mark.parametrize("f16", [1, 0])
+@pytest.mark.parametrize("n,d,b,tau,w,kind", [
+    (3000, 64, 300, 0.2, 1.0, "normal"), (3000, 64, 300, 0.05, 1e-7, "heavy"), (2000, 128, 257, 0.2, -3.0, "normal"),
+    (1500, 64, 100, 1.0, 250.0, "sparse"), (700, 36, 65, 0.1, 0.05, "heavy"), (900, 62, 40, 0.2, 1.0, "normal")])
+def test_info_nce_fp16_form(rbg, cuda, f16, n, d, b, tau, w, kind):
+    """Option "lse_f16" (r06, default 1): the gradient passes of the unweighted rbg_infonce_f32 split unit rows and weights in
+    [0, 1] into TWO fp16 terms (three products on v_mfma_f32_32x32x16_f16) instead of three bf16 terms (six products).  Both forms
+    against float64 autograd of sgl.py:191-199 at the SAME tolerance — rows with heavy tails (elements 1e-6 .. 1 of the row's norm:
+    fp16's subnormal range after the 2^8 scale), one-hot-like rows, a weight as small as NCL's ssl_reg and a negative one (the
+    weight is divided out of the second product's operand and multiplied back), d = 62 (unaligned rows keep the bf16 kernels)."""
+    gen = torch.Generator().manual_seed(n + d + b)
+    t1, t2 = torch.randn(n, d, generator=gen), torch.randn(n, d, generator=gen)
+    if kind == "heavy":
+        t1 = t1 * torch.exp(4.0 * torch.randn(n, d, generator=gen))
+        t2 = t2 * torch.exp(4.0 * torch.randn(n, d, generator=gen))
+    elif kind == "sparse":
+        t1 = t1 * (torch.rand(n, d, generator=gen) < 0.05)
+        t2 = t2 * (torch.rand(n, d, generator=gen) < 0.05) + 1e-6 * torch.randn(n, d, generator=gen)
+    idx = torch.randint(0, n, (b,), generator=gen)
+    idx[:3] = idx[0]
+    a64, b64 = t1.double().requires_grad_(True), t2.double().requires_grad_(True)
+    nrm = torch.nn.functional.normalize
+    u1, u2, allu = nrm(a64[idx], dim=1), nrm(b64[idx], dim=1), nrm(b64, dim=1)
+    ref = torch.sum(torch.logsumexp(u1.matmul(allu.T) / tau, dim=1) - torch.sum(u1 * u2, dim=1) / tau)
+    (ref * w).backward()
+    old = rbg.get_option("lse_f16")
+    rbg.set_option("lse_f16", f16)
+    try:
+        g1, g2 = t1.to(cuda).requires_grad_(True), t2.to(cuda).requires_grad_(True)
+        out = rbg.ops.info_nce(g1, g2, idx.to(cuda), tau)
+        (out * w).backward()
+    finally:
+        rbg.set_option("lse_f16", old)
+    assert abs(float(out.detach()) - float(ref.detach())) <= 1e-5 * max(1.0, abs(float(ref.detach())))
+    for got, want in ((g1.grad, a64.grad), (g2.grad, b64.grad)):  # relative to the gradient's own size (w = 1e-7 makes it tiny)
+        err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        assert torch.isfinite(got).all() and err <= 1e-5, f"max err / max |grad| = {err:.3e}"
+
+
 def test_sgl_device_sampling(rbg, cuda, golden):
     """SGL views sampled on the GPU (device_sampling, the default): a view built from device-resident interactions and a
     device mask equals the host-built view of the same mask bit for bit; ED keeps exactly int(E (1 - ratio)) interactions
