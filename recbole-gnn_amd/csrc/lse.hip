@@ -53,6 +53,17 @@ struct LseParams {
     float w_scale, inv_w_scale, out_scale, w_shift2;
 };
 
+// diagnostic builds only (devtools/r06_lse_whatif.sh; results are wrong, timings tell what a phase costs): bit 0 = no second product,
+// bit 1 = second product without its transpose reads, bit 2 = weights without exp / split (w = x), bit 3 = no barrier in the tile loop,
+// bit 4 = no fetch / publish after the first tile, bit 5 = no first product
+#ifndef RBG_LSE_WHATIF
+#define RBG_LSE_WHATIF 0
+#endif
+constexpr int kWhatIf = RBG_LSE_WHATIF;
+#ifndef RBG_LSE_STAGGER
+#define RBG_LSE_STAGGER 0
+#endif
+constexpr int kStagger = RBG_LSE_STAGGER;  // experiment: the co-resident workgroups of a CU start 64 x this many cycles apart
 constexpr float kF16RowScale = 256.f;  // unit rows as fp16 pairs: x * 2^8 (mfma_common.h, split2_f16)
 
 template <int R>
@@ -116,6 +127,10 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     const int64_t j = (int64_t)(blockIdx.x & 7) * p.blocks_per_xcd + (blockIdx.x >> 3);
     if (j >= p.total_blocks) return;  // whole workgroup
     const int64_t chunk = j / p.own_blocks, ob = j - chunk * p.own_blocks;
+    if constexpr (F16 && kStagger > 0) {  // an XCD's 32 CUs take its workgroups 32 at a time: slot = (index in the XCD / 32) % 3
+        const int color = (int)((blockIdx.x >> 8) % 3);
+        for (int k = 0; k < color * kStagger; ++k) __builtin_amdgcn_s_sleep(1);
+    }
     const int64_t own0 = (ob * 4 + wave) * 32;
     const bool wave_live = own0 < p.n_own;  // an idle wave still takes part in the tile loads and barriers
     const int64_t own_row = own0 + i;
@@ -212,6 +227,10 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
                     const f16x8 ah = *reinterpret_cast<const f16x8 *>(&s_pl[buf][0][i][off]);
                     const f16x8 al = *reinterpret_cast<const f16x8 *>(&s_pl[buf][1][i][off]);
                     const int sidx = c * 4 + q;
+                    if constexpr (kWhatIf & 32) {
+                        x[q] += (float)ah[0] + (float)al[1];
+                        continue;
+                    }
                     x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bo2.h[sidx], x, 0, 0, 0);
                     x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.l[sidx], x, 0, 0, 0);
                     x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.h[sidx], x, 0, 0, 0);
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
             if constexpr (F16) {
                 LseRows<0>::run([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    const float e = __builtin_amdgcn_exp2f(x[r] * s2 - shift2);
+                    const float e = (kWhatIf & 4) ? x[r] : __builtin_amdgcn_exp2f(x[r] * s2 - shift2);
                     w[r] = PASS == 2 ? e * s_coef[buf][lse_rowmap(r, h)] : e;  // (rows past the end have coefficient 0)
                 });
                 if constexpr (PASS == 1) {
@@ -291,6 +310,9 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         f16x2 hh, ll;
+                        if constexpr (kWhatIf & 4) {
+                            hh = __builtin_bit_cast(f16x2, w[8 * u + 2 * j]), ll = __builtin_bit_cast(f16x2, w[8 * u + 2 * j + 1]);
+                        } else
                         split2_f16(w[8 * u + 2 * j], w[8 * u + 2 * j + 1], 1.f, hh, ll);
                         wh[u][2 * j] = hh[0], wh[u][2 * j + 1] = hh[1];
                         wl[u][2 * j] = ll[0], wl[u][2 * j + 1] = ll[1];
@@ -308,7 +330,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
                             const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
                             return (f16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
                         };
-                        const f16x8 bh = col8(0), bl = col8(1);
+                        if constexpr (kWhatIf & 1) {
+                            g[q][u] += (float)wh[u][0] + (float)wl[u][1];
+                            continue;
+                        }
+                        const f16x8 bh = (kWhatIf & 2) ? wh[u ^ 1] : col8(0), bl = (kWhatIf & 2) ? wl[u ^ 1] : col8(1);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[u], bh, g[q], 0, 0, 0);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bl, g[q], 0, 0, 0);
                         g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bh, g[q], 0, 0, 0);
@@ -416,9 +442,11 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     for (int64_t t = t0; t < t1; ++t) {
         const int buf = (int)(t - t0) & 1;
         if (wave_live) compute(buf, t);
-        if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
-        if (t + 2 < t1) fetch(t + 2);
-        __syncthreads();
+        if constexpr (!(kWhatIf & 16)) {
+            if (t + 1 < t1) publish(buf ^ 1);  // the other buffer was last read before the previous barrier
+            if (t + 2 < t1) fetch(t + 2);
+        }
+        if constexpr (!(kWhatIf & 8)) __syncthreads();
     }
     }
     if (!wave_live) return;
