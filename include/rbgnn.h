@@ -106,8 +106,10 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   softmax probabilities (scaled by 2^14; the call's weight / tau is divided out and multiplied back), so
  *                   x = h + l to 2^-22 |x| without leaving fp16's range, and three products (h h, h l, l h) replace the six of
  *                   the three-term bf16 form: half the matrix-core time, two LDS planes instead of three, 32 instead of 48
- *                   fragment registers — three workgroups per CU at d <= 64, two at d = 128 (one before).  r06: forward +
- *                   backward 333 -> 224 us at 2048 x 40 982 x 64, 1 404 -> 723 us at 2048 x 91 600 x 128; errors against float64
+ *                   fragment registers — three workgroups per CU at d <= 64, two at d = 128 (one before); the row kernels that
+ *                   normalise the table and the batch rows write the two fp16 planes as tile images and the launches take
+ *                   their tiles by LDS-DMA (2 = every workgroup fetches, splits and publishes its tiles: 221 vs 211 us).  r06:
+ *                   forward + backward 333 -> 211 us at 2048 x 40 982 x 64, 1 404 -> 690 us at 2048 x 91 600 x 128; errors against float64
  *                   autograd unchanged (~ 2e-7 of the largest gradient entry; tests at 1e-5 for both forms,
  *                   profiles/r06_lse_f16.jsonl).  Needs "mfma_split" = 1, "lse_tr_read" = 1, "lse_image" = 0, d % 4 == 0; 0 = the bf16 form
  *   "lse_image"   : 0 (default) ; 1 = the gradient launches of rbg_infonce*_f32 take the tiles of the normalised table / batch rows from

@@ -544,7 +544,7 @@ int rbg_set_option(const char *key, int64_t value) {
         return RBG_OK;
     }
     if (!strcmp(key, "lse_f16")) {
-        g_lse_f16 = value ? 1 : 0;
+        g_lse_f16 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
         return RBG_OK;
     }
     if (!strcmp(key, "topk_image")) {

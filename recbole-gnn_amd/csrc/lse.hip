@@ -100,7 +100,7 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false, int PASS = 0>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 2) : 3) : (F16 ? 2 : 1)) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
-    static_assert(!F16 || (SPLIT && TRR && GRAD && !IMG), "the fp16 form: gradient passes, transpose reads, tiles fetched and split per workgroup");
+    static_assert(!F16 || (SPLIT && TRR && GRAD), "the fp16 form: gradient passes, transpose reads");
     static_assert(F16 == (PASS != 0), "PASS belongs to the fp16 form");
     constexpr int NPL = F16 ? 2 : 3;
     constexpr int LD = NC * 64 + 4;
@@ -412,23 +412,24 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
         // r06: the oth tiles come from the plane image by LDS-DMA, one tile ahead; only the tile's 32 weights (gradient of the table
         // side) still travel through registers
         const unsigned lds_pl[2] = {(unsigned)(uintptr_t)&s_pl[0], (unsigned)(uintptr_t)&s_pl[1]};
+        const bool has_coef = F16 ? PASS == 2 : (GRAD && p.coef_oth != nullptr);
         auto coef_of = [&](const int64_t t) __attribute__((always_inline)) {
-            return (GRAD && p.coef_oth && tid < 32 && t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] : 0.f;
+            return (has_coef && tid < 32 && t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] * (F16 ? p.w_scale : 1.f) : 0.f;
         };
         if (t0 < t1) {
-            PlaneImage<NC>::dma(p.oth_image, t0, lds_pl[0], tid, wave);
-            if (GRAD && p.coef_oth && tid < 32) s_coef[0][tid] = coef_of(t0);
+            PlaneImage<NC, NPL>::dma(p.oth_image, t0, lds_pl[0], tid, wave);
+            if (has_coef && tid < 32) s_coef[0][tid] = coef_of(t0);
             dma_drain();
         }
         __syncthreads();
         for (int64_t t = t0; t < t1; ++t) {
             const int buf = (int)(t - t0) & 1;
             if (t + 1 < t1) {
-                PlaneImage<NC>::dma(p.oth_image, t + 1, lds_pl[buf ^ 1], tid, wave);  // (the other buffer was last read before the previous barrier)
+                PlaneImage<NC, NPL>::dma(p.oth_image, t + 1, lds_pl[buf ^ 1], tid, wave);  // (the other buffer was last read before the previous barrier)
                 stage_coef = coef_of(t + 1);
             }
             if (wave_live) compute(buf, t);
-            if (GRAD && p.coef_oth && tid < 32 && t + 1 < t1) s_coef[buf ^ 1][tid] = stage_coef;
+            if (has_coef && tid < 32 && t + 1 < t1) s_coef[buf ^ 1][tid] = stage_coef;
             dma_drain();
             __syncthreads();
         }
@@ -529,15 +530,18 @@ struct LseLayout {
     int64_t off_coef, off_q, off_c, off_den, bytes;
 };
 // the fp16 form of the gradient passes (rbg_infonce_f32 without weights; F16 in lse_tile_kernel) is on
-static bool lse_f16_on(int d) { return opt_mfma_split() != 0 && opt_lse_tr_read() && !opt_lse_image() && opt_lse_f16() && d % 4 == 0; }
+// (1 = its tiles from fp16 plane images by LDS-DMA, 2 = fetched and split per workgroup)
+static int lse_f16_mode(int d) { return (opt_mfma_split() != 0 && opt_lse_tr_read() && !opt_lse_image() && d % 4 == 0) ? opt_lse_f16() : 0; }
+static bool lse_f16_on(int d) { return lse_f16_mode(d) != 0; }
 
-static LseLayout lse_layout_of(int64_t B, int64_t n, int d, bool f16) {
+static LseLayout lse_layout_of(int64_t B, int64_t n, int d, int f16) {  // f16: 0 = the bf16 / fp32 kernels, 1 / 2 = lse_f16_mode
     LseLayout L{};
     const bool split = opt_mfma_split() != 0;  // (the split kernels hold 48 instead of 32 own registers per chunk)
     // resident workgroups per CU (register-limited; r06: the gradient kernel that takes its tiles from plane images and its column
     // fragments by transpose reads fits three at d <= 64: 168 registers, 28 KB of LDS)
     const bool img3 = split && opt_lse_image() && opt_lse_tr_read();
-    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = f16 ? (d <= 64 ? 3 : 2) : d <= 64 ? (split ? (img3 ? 3 : 2) : 3) : 1;
+    const int res_f = d <= 64 ? (split ? 3 : 4) : 2, res_g = f16 ? (d <= 64 ? 3 : 2) :  // (the image form's 124 registers would allow four: chunking for four measured 214-218 vs 211 us)
+                    d <= 64 ? (split ? (img3 ? 3 : 2) : 3) : 1;
     // one partial array per chunk: own rows x d x 8 bytes (write + read) at ~5 TB/s, in units of a ~1.2 us tile
     auto partial_cost = [&](int64_t rows) { return (double)rows * d * 8.0 / 5e6 / 1.2; };
     lse_geometry(B, n, res_f, 0.02, L.tpc_f, L.nc_f);
@@ -554,9 +558,10 @@ static LseLayout lse_layout_of(int64_t B, int64_t n, int d, bool f16) {
     return L;
 }
 // (a workspace serves either form: the masked InfoNCE keeps the bf16 kernels while the option is on)
-static LseLayout lse_layout(int64_t B, int64_t n, int d, bool f16 = false) {
+static LseLayout lse_layout(int64_t B, int64_t n, int d, int f16 = 0) {
     LseLayout L = lse_layout_of(B, n, d, f16);
-    if (lse_f16_on(d)) L.bytes = std::max(L.bytes, lse_layout_of(B, n, d, !f16).bytes);
+    if (lse_f16_on(d))
+        for (int m = 0; m <= 2; ++m) L.bytes = std::max(L.bytes, lse_layout_of(B, n, d, m).bytes);
     return L;
 }
 
@@ -568,9 +573,14 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     dim3 grid((unsigned)(p.blocks_per_xcd * 8));
     const bool split = opt_mfma_split() != 0;
     if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
-        if (p.w_scale != 0.f) {  // the fp16 form (the caller checked lse_f16_on and the alignment)
-            if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 1>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 2>), grid, dim3(256), 0, s, p);
+        if (p.w_scale != 0.f) {  // the fp16 form (the caller checked lse_f16_mode and the alignment)
+            if (p.oth_image) {
+                if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 1>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 2>), grid, dim3(256), 0, s, p);
+            } else {
+                if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 1>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, false, true, 2>), grid, dim3(256), 0, s, p);
+            }
             return;
         }
         if (split && opt_lse_tr_read()) {
@@ -724,12 +734,28 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// r06: row j of a unit-row table as the two fp16 planes of lse_tile_kernel's fp16 form, in the tile image PlaneImage<NC, 2>
+// ([tile][plane][32 rows][64 NC + 8] fp16 bit patterns); lane c holds columns c and c + 64; rows past the end are written as zeros by
+// their would-be waves (the second product multiplies them by a zero weight: they must be finite)
+__device__ __forceinline__ void nce_image_row(char *img, int64_t j, int d, int lane, float v0, float v1) {
+    const int ldh = d <= 64 ? 72 : 136;
+    _Float16 *tile = reinterpret_cast<_Float16 *>(img + (j >> 5) * (int64_t)(2 * 32 * ldh * 2));
+    const int row = (int)(j & 31);
+    f16x2 h, l;
+    split2_f16(v0, v1, kF16RowScale, h, l);
+    if (lane < ldh - 8) tile[row * ldh + lane] = h[0], tile[(32 + row) * ldh + lane] = l[0];
+    if (d > 64) tile[row * ldh + lane + 64] = h[1], tile[(32 + row) * ldh + lane + 64] = l[1];
+}
+
 // C[j] = T[j] / max(||T[j]||, eps), inv[j] = 1 / max(||T[j]||, eps).  One wave per row.
 __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__restrict__ T, int64_t n, int d, float *__restrict__ C,
-                                                             float *__restrict__ inv) {
+                                                             float *__restrict__ inv, char *__restrict__ img16) {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (j >= n) return;
+    if (j >= n) {
+        if (img16 && j < (n + 31) / 32 * 32) nce_image_row(img16, j, d, lane, 0.f, 0.f);
+        return;
+    }
     const float *row = T + j * d;
     float ss = 0.f;
     for (int c = lane; c < d; c += 64) ss = fmaf(row[c], row[c], ss);
@@ -737,15 +763,20 @@ __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__rest
     const float iv = 1.0f / fmaxf(sqrtf(ss), kNormEps);
     for (int c = lane; c < d; c += 64) C[j * d + c] = row[c] * iv;
     if (lane == 0) inv[j] = iv;
+    if (img16) nce_image_row(img16, j, d, lane, lane < d ? row[lane] * iv : 0.f, lane + 64 < d ? row[lane + 64] * iv : 0.f);
 }
 
 // A[b] = normalize(T1[idx[b]]), inv1[b], pos[b] = <A[b], C[idx[b]]>.  One wave per batch row.
 __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__restrict__ T1, const float *__restrict__ C,
                                                              const int64_t *__restrict__ idx, int64_t B, int d,
-                                                             float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos) {
+                                                             float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos,
+                                                             char *__restrict__ img16) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (b >= B) return;
+    if (b >= B) {
+        if (img16 && b < (B + 31) / 32 * 32) nce_image_row(img16, b, d, lane, 0.f, 0.f);
+        return;
+    }
     const int64_t r = idx[b];
     const float *row = T1 + r * d;
     float ss = 0.f;
@@ -763,6 +794,7 @@ __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__rest
         inv1[b] = iv;
         pos[b] = dot;
     }
+    if (img16) nce_image_row(img16, b, d, lane, lane < d ? row[lane] * iv : 0.f, lane + 64 < d ? row[lane + 64] * iv : 0.f);
 }
 
 // *loss += weight * sum_b (lse[b] - scale * pos[b]);  gl[b] = weight (the upstream gradient of every lse[b]).  One block.
@@ -992,17 +1024,19 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 // into the consumers of the chunk partials, which also absorb the chunk reductions: 8 launches per half instead of 13.
 static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
                            const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
-                           float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr) {
+                           float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr,
+                           int f16_mode = 0) {
     const bool vec = lse_vec(A, d, C, d, d);
-    // r06, the fp16 form: unit rows and weights in [0, 1] — the plain InfoNCE only (row / candidate weights are the caller's numbers)
-    const bool f16 = !row_w && !col_w && vec && lse_f16_on(d);
-    const LseLayout L = lse_layout(B, n, d, f16);
+    // r06, the fp16 form: unit rows and weights in [0, 1] — the plain InfoNCE only (row / candidate weights are the caller's numbers);
+    // f16_mode 1: imgC / imgA hold the fp16 plane images the row kernels wrote
+    const bool f16 = f16_mode != 0;
+    const LseLayout L = lse_layout(B, n, d, f16_mode);
     char *w = reinterpret_cast<char *>(lse_ws);
     float *coef = reinterpret_cast<float *>(w + L.off_coef), *part_q = reinterpret_cast<float *>(w + L.off_q);
     float *part_c = L.nc_c > 1 ? reinterpret_cast<float *>(w + L.off_c) : dC, *den = reinterpret_cast<float *>(w + L.off_den);
     // r06: the normalised table and batch rows as plane images (plane_image.h), built once per call: both gradient passes take their
     // oth tiles by LDS-DMA instead of fetching, splitting and publishing them in every workgroup
-    const bool img = imgC && imgA && d <= 128 && opt_mfma_split() != 0 && opt_lse_tr_read() && opt_lse_image();
+    const bool img = !f16 && imgC && imgA && d <= 128 && opt_mfma_split() != 0 && opt_lse_tr_read() && opt_lse_image();
     if (img) {
         const unsigned tc = (unsigned)((n + 31) / 32), ta = (unsigned)((B + 31) / 32);
         if (d <= 64) {
@@ -1021,7 +1055,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 1 (own = the batch rows): denominators' and gradient's partials per chunk
     p.own = A, p.ld_own = d, p.n_own = B;
     p.oth = C, p.ld_oth = d, p.n_oth = n;
-    p.oth_image = img ? imgC : nullptr;
+    p.oth_image = (img || f16_mode == 1) ? imgC : nullptr;
     p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
     p.out = part_q;
     p.den_out = den;
@@ -1039,7 +1073,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 2 (own = the table rows): needs the finished denominators (coef)
     p.own = C, p.n_own = n;
     p.oth = A, p.n_oth = B;
-    p.oth_image = img ? imgA : nullptr;
+    p.oth_image = (img || f16_mode == 1) ? imgA : nullptr;
     p.coef_own = col_w, p.coef_oth = coef;
     p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
     p.out = part_c;
@@ -1093,15 +1127,19 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     hipStream_t s = (hipStream_t)stream;
     const float scale = 1.0f / tau;
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
-    hipLaunchKernelGGL(nce_norm_table_kernel, dim3(nb), dim3(256), 0, s, T2, n, d, C, inv2);
-    RBG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos);
-    RBG_HIP(hipGetLastError());
     const bool grads = grad_T1 || grad_T2;
     const bool masked = row_w || col_w;
     const bool onepass = masked || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
+    // r06: the fp16 form of the gradient launches (the plain InfoNCE with gradients); mode 1: the row kernels write the fp16 plane images too
+    const int f16_mode = (onepass && grads && !masked) ? lse_f16_mode(d) : 0;
+    char *imgC = grads ? w + L.off_imgC : nullptr, *imgA = grads ? w + L.off_imgA : nullptr;
+    const unsigned nb_img = (unsigned)((n + 31) / 32 * 8), bb_img = (unsigned)((B + 31) / 32 * 8);  // (whole tiles: the rows past the end are zeroed)
+    hipLaunchKernelGGL(nce_norm_table_kernel, dim3(f16_mode == 1 ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, f16_mode == 1 ? imgC : nullptr);
+    RBG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(f16_mode == 1 ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, f16_mode == 1 ? imgA : nullptr);
+    RBG_HIP(hipGetLastError());
     if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s,
-                                        grads ? w + L.off_imgC : nullptr, grads ? w + L.off_imgA : nullptr);
+                                        imgC, imgA, f16_mode);
     int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);

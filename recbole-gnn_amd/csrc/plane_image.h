@@ -16,10 +16,11 @@
 
 namespace rbg {
 
-template <int NCHUNK>
+// NPL = 3: the bf16 planes of RowTile3; NPL = 2 (r06): the two fp16 planes of lse.hip's fp16 form (written by its row kernels)
+template <int NCHUNK, int NPL = 3>
 struct PlaneImage {
     static constexpr int LDH = NCHUNK * 64 + 8;
-    static constexpr int kTileBytes = 3 * 32 * LDH * 2;  // 13 824 (d <= 64), 26 112 (d <= 128): multiples of 16
+    static constexpr int kTileBytes = NPL * 32 * LDH * 2;  // NPL = 3: 13 824 (d <= 64), 26 112 (d <= 128); NPL = 2: 9 216, 17 408: multiples of 16
     static constexpr int kRounds = (kTileBytes + 4095) / 4096;
     // all 256 threads: tile t of the image -> the LDS tile at lds_dst (byte address), 16 bytes per lane per round
     static __device__ __forceinline__ void dma(const char *image, int64_t t, unsigned lds_dst, int tid, int wave) {
