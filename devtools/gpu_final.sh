@@ -22,4 +22,6 @@ timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 > gpurun_out/final/be
 echo "n2 rc=$?"; head -c 500 gpurun_out/final/bench_n2.json; echo
 timeout 900 python bench.py --gpus 4 --steps 10 --warmup 3 --shard hybrid > gpurun_out/final/bench_n4_hybrid.json 2> gpurun_out/final/bench_n4_hybrid.err
 echo "n4 hybrid rc=$?"; head -c 400 gpurun_out/final/bench_n4_hybrid.json; echo
+timeout 300 python devtools/r06_lse_f16_probe.py > gpurun_out/final/lse_f16_probe.jsonl 2> gpurun_out/final/lse_f16_probe.err
+tail -2 gpurun_out/final/lse_f16_probe.jsonl | cut -c1-300
 find gpurun_out/prof gpurun_out/traffic -name "*.csv" -size +2M -delete
