@@ -347,6 +347,12 @@ int rbg_spmm_add_f32(const rbg_graph *g, const float *X, const float *Z, float *
  * as the SpMM's epilogue.  sign() has zero gradient, so the backward of this op is the plain Â^T product. */
 int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float *noise, int d, float eps, void *stream);
 
+/* The epilogue of rbg_spmm_noise_f32 on a product that exists already (r06):  out = Y + sign(Y) * F.normalize(noise, dim=-1) * eps.
+ * SimGCL's plain pass and its two perturbed passes (simgcl.py:45-55: three calls of forward()) start with the SAME product Â E_0;
+ * the perturbed first layers are this row kernel on the plain pass's first layer instead of two more propagations.
+ * Y, noise, out: [n, d] contiguous, d <= 128; out may alias Y. */
+int rbg_sign_noise_f32(const float *Y, const float *noise, int64_t n, int d, float eps, float *out, void *stream);
+
 /* Replaces LightGCN.get_ego_embeddings + LightGCN.forward
  *   recbole_gnn/model/general_recommender/lightgcn.py:60-68,70-81  (and SGL.forward,
  *   sgl.py:128-145, where layer k may use its own graph).

@@ -674,6 +674,25 @@ __global__ __launch_bounds__(256) void lgcn_tail_kernel(const LeanTailArgs a) {
     }
 }
 
+// out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps: the epilogue of rbg_spmm_noise_f32 on a product that exists already
+// (r06: SimGCL's three passes share their first product A E_0).  One wave per row, d <= 128: lane c holds columns c and c + 64.
+__global__ __launch_bounds__(256) void sign_noise_kernel(const float *__restrict__ y, const float *__restrict__ noise, int64_t n, int d,
+                                                         float eps, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (row >= n) return;
+    const bool in0 = lane < d, in1 = lane + 64 < d;
+    const float n0 = in0 ? noise[row * d + lane] : 0.f, n1 = in1 ? noise[row * d + lane + 64] : 0.f;
+    const float y0 = in0 ? y[row * d + lane] : 0.f, y1 = in1 ? y[row * d + lane + 64] : 0.f;
+    float ss = fmaf(n0, n0, n1 * n1);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float nsc = eps / fmaxf(sqrtf(ss), 1e-12f);
+    auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };  // torch.sign
+    if (in0) out[row * d + lane] = fmaf(sgn(y0) * n0, nsc, y0);
+    if (in1) out[row * d + lane + 64] = fmaf(sgn(y1) * n1, nsc, y1);
+}
+
 }  // namespace rbg
 
 using namespace rbg;
@@ -864,6 +883,17 @@ int rbg_lightgcn_step_tail_f32(float *user_emb, float *item_emb, int64_t n_users
     if (a.nd == 0) return RBG_OK;
     const unsigned blocks = (unsigned)std::min<int64_t>((a.nd / 4 + 255) / 256, 8192);
     hipLaunchKernelGGL(lgcn_tail_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_sign_noise_f32(const float *Y, const float *noise, int64_t n, int d, float eps, float *out, void *stream) {
+    clear_error();
+    if (n < 0 || d <= 0) return fail(RBG_ESHAPE, "n = %lld, d = %d", (long long)n, d);
+    if (d > 128) return fail(RBG_EUNSUPPORTED, "sign_noise: d = %d > 128", d);
+    if (n == 0) return RBG_OK;
+    if (!Y || !noise || !out) return fail(RBG_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(sign_noise_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y, noise, n, d, eps, out);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

@@ -450,12 +450,18 @@ class _FusedContrastStep(_FusedStep):
         srcs = (c_vp * k)(*[layers[i].data_ptr() for i in range(k)])
         check(lib.rbg_mean_f32(srcs, k, out.numel(), 1.0 / k, self._ptr(out), c_vp(torch.cuda.current_stream(out.device).cuda_stream)))
 
-    def _perturbed_pass(self, layers, k):
+    def _perturbed_pass(self, layers, k, first_product=None):
+        """``first_product``: A E_0 where a plain pass has formed it already (r06: SimGCL's three passes start with the same
+        product) — the first perturbed layer is then the noise epilogue alone (rbg_sign_noise_f32), one propagation less."""
         m, st = self.model, c_vp(torch.cuda.current_stream(self.model.device).cuda_stream)
         x = self.e0
         for i in range(k):
             self.noise.uniform_()  # (= torch.rand_like: the same draws in the same order as SimGCL._layers)
-            check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(self.noise), x.shape[1], float(m.eps), st))
+            if i == 0 and first_product is not None:
+                check(lib.rbg_sign_noise_f32(self._ptr(first_product), self._ptr(self.noise), x.shape[0], x.shape[1], float(m.eps),
+                                             self._ptr(layers[0]), st))
+            else:
+                check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(self.noise), x.shape[1], float(m.eps), st))
             x = layers[i]
 
     def _contrast(self, ta, tb, ga, gb, ids, row0, rows, b, mean_form):
@@ -518,7 +524,7 @@ class FusedSimGCLAdam(_FusedContrastStep):
             ops.lightgcn_forward_raw(m.graph, uw, iw, k, keep_layers=True, out=self.work, layers=self.lay[0])
             self._mean_of(self.lay[0], k, self.mean[0])
             for v in (1, 2):
-                self._perturbed_pass(self.lay[v], k)
+                self._perturbed_pass(self.lay[v], k, first_product=self.lay[0][0])  # (the three passes share A E_0)
                 self._mean_of(self.lay[v], k, self.mean[v])
             # lightgcn.py:93-100 on the plain pass (zeroes gm and the loss), then the contrasts between the perturbed passes
             check(lib.rbg_bpr_grad_f32(p(self.mean[0]), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))

@@ -966,6 +966,32 @@ def test_spmm_noise_epilogue(rbg, cuda, golden, d):
     close(xg.grad, rbg.ops.spmm_raw(h, up))
 
 
+@pytest.mark.parametrize("d", [64, 128, 20, 32])
+def test_sign_noise_is_the_noise_epilogue_alone(rbg, cuda, golden, d):
+    """rbg_sign_noise_f32 (r06): out = Y + sign(Y) * normalize(noise) * eps on a product that exists already == rbg_spmm_noise_f32 of the
+    same product (SimGCL's three passes share A E_0), to the last bits of the row norm's summation order; exact against the float64
+    expression; zero rows stay zero; in place."""
+    from recbole_gnn_amd._lib import lib, check, c_vp
+    g = golden
+    nu, ni = int(g["n_users"]), int(g["n_items"])
+    h = rbg.GraphHandle.from_interactions(g["uid"], g["iid"], nu, ni, device=cuda)
+    n = nu + ni
+    x = randn((n, d), 5, cuda)
+    noise = torch.rand(n, d, generator=torch.Generator().manual_seed(6)).to(cuda)
+    fused = rbg.ops.spmm_noise_raw(h, x, noise, 0.1)
+    y = rbg.ops.spmm_raw(h, x)
+    out = torch.empty_like(y)
+    st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
+    check(lib.rbg_sign_noise_f32(c_vp(y.data_ptr()), c_vp(noise.data_ptr()), n, d, 0.1, c_vp(out.data_ptr()), st))
+    ref = y.cpu().double() + torch.sign(y.cpu().double()) * torch.nn.functional.normalize(noise.cpu().double(), dim=-1) * 0.1
+    assert float((out.cpu().double() - ref).abs().max()) <= 1e-6
+    assert float((out - fused).abs().max()) <= 1e-6  # (the same product bit for bit; the norms are summed in another order)
+    assert torch.all(out[0] == 0) and torch.all(out[nu] == 0)
+    check(lib.rbg_sign_noise_f32(c_vp(y.data_ptr()), c_vp(noise.data_ptr()), n, d, 0.1, c_vp(y.data_ptr()), st))
+    assert torch.equal(y, out)
+    assert lib.rbg_sign_noise_f32(c_vp(y.data_ptr()), c_vp(noise.data_ptr()), n, 129, 0.1, c_vp(y.data_ptr()), st) != 0  # d > 128
+
+
 @pytest.mark.parametrize("name", ["SimGCL", "XSimGCL"])
 def test_simgcl_models(rbg, cuda, golden, name):
     """Model mirrors: clean forward = mean of layers 1..K (no E0); perturbed forward reproduces the reference's expression
