@@ -100,7 +100,7 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   fragments out of the row-major bf16 planes with gfx950's LDS transpose read (ds_read_b64_tr_b16) instead of
  *                   publishing a transposed copy of every tile (r06: InfoNCE forward + backward at 2048 x 40 982 x 64
  *                   354 -> 330 us, at 2048 x 91 600 x 128 1 790 -> 1 396 us; same results bit for bit); 0 = the transposed copy
- *   "lse_f16"     : 1 (default) = the two gradient launches of rbg_infonce_f32 (NOT the weighted rbg_infonce_masked_f32, NOT
+ *   "lse_f16"     : 3 (default), 1, 2 = the two gradient launches of rbg_infonce_f32 (NOT the weighted rbg_infonce_masked_f32, NOT
  *                   rbg_lse_rows*_f32 — their operands are the caller's numbers) run both products on the fp16 matrix cores with TWO
  *                   terms per operand: the rows are unit rows (|x| <= 1, scaled by 2^8) and the weights are exp(.) <= 1 resp.
  *                   softmax probabilities (scaled by 2^14; the call's weight / tau is divided out and multiplied back), so
@@ -108,8 +108,10 @@ int rbg_get_tuning(int *short_max, int *wave_max, int *seg_len);
  *                   the three-term bf16 form: half the matrix-core time, two LDS planes instead of three, 32 instead of 48
  *                   fragment registers — three workgroups per CU at d <= 64, two at d = 128 (one before); the row kernels that
  *                   normalise the table and the batch rows write the two fp16 planes as tile images and the launches take
- *                   their tiles by LDS-DMA (2 = every workgroup fetches, splits and publishes its tiles: 221 vs 211 us).  r06:
- *                   forward + backward 333 -> 211 us at 2048 x 40 982 x 64, 1 404 -> 690 us at 2048 x 91 600 x 128; errors against float64
+ *                   their tiles by LDS-DMA (2 = every workgroup fetches, splits and publishes its tiles: 221 vs 212 us); 3 = as 1
+ *                   with the tile loop software-pipelined inside a wave (the first product of tile t issued in front of the exp2 /
+ *                   split of tile t - 1, three LDS tiles: 212 -> 209 us).  r06:
+ *                   forward + backward 333 -> 209 us at 2048 x 40 982 x 64, 1 404 -> 686 us at 2048 x 91 600 x 128; errors against float64
  *                   autograd unchanged (~ 2e-7 of the largest gradient entry; tests at 1e-5 for both forms,
  *                   profiles/r06_lse_f16.jsonl).  Needs "mfma_split" = 1, "lse_tr_read" = 1, "lse_image" = 0, d % 4 == 0; 0 = the bf16 form
  *   "lse_image"   : 0 (default) ; 1 = the gradient launches of rbg_infonce*_f32 take the tiles of the normalised table / batch rows from

@@ -56,7 +56,7 @@ static std::atomic<int> g_lse_onepass{1};
 int opt_lse_onepass() { return g_lse_onepass.load(); }
 static std::atomic<int> g_lse_tr_read{1};
 int opt_lse_tr_read() { return g_lse_tr_read.load(); }
-static std::atomic<int> g_lse_f16{1};
+static std::atomic<int> g_lse_f16{3};
 int opt_lse_f16() { return g_lse_f16.load(); }
 static std::atomic<int> g_lse_image{0};  // (measured neutral to slightly slower, profiles/r06_lse_image.jsonl: off)
 int opt_lse_image() { return g_lse_image.load(); }
@@ -544,7 +544,7 @@ int rbg_set_option(const char *key, int64_t value) {
         return RBG_OK;
     }
     if (!strcmp(key, "lse_f16")) {
-        g_lse_f16 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
+        g_lse_f16 = value < 0 ? 0 : (value > 3 ? 3 : (int)value);
         return RBG_OK;
     }
     if (!strcmp(key, "topk_image")) {

@@ -60,7 +60,7 @@ int opt_topk_screen();  // rbg_full_sort_topk_f32: one bf16 product per pair scr
 int opt_topk_short_lists();  // rbg_full_sort_topk_f32: 24-entry LDS lists (three workgroups per CU) at k <= 12, d <= 64: 0 never, 1 from 2048 users (default), 2 always
 int opt_deterministic();  // train.hip / lse.hip: row scatters by owner wavefronts in batch order (ordered.h), sums in fixed point: bit-stable
 int opt_lse_tr_read();    // lse.hip gradients: the second product's B fragments by ds_read_b64_tr_b16 from the row-major planes (1, default)
-int opt_lse_f16();        // rbg_infonce_f32 with gradients, no weights: both products of the gradient passes on the fp16 matrix cores, two terms per operand (1, default)
+int opt_lse_f16();        // rbg_infonce_f32 with gradients, no weights: both products of the gradient passes on the fp16 matrix cores, two terms per operand (3, default; see rbgnn.h)
 int opt_lse_image();      // rbg_infonce*_f32 with gradients: the normalised table / batch rows as plane images taken by LDS-DMA (0, default: measured neutral)
 int opt_lse_onepass();    // rbg_infonce_f32: denominators and the batch rows' gradient out of one pass over the table (1, default)
 int opt_score_uniform();  // rbg_score_f32: workgroups take users of one alignment class and store whole lines without shuffles (1, default)

@@ -97,11 +97,16 @@ constexpr int lse_rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 // instead of three, 32 instead of 48 own-fragment registers: three workgroups per CU at d <= 64, two at d = 128 (one before).
 // PASS (F16 only) says at compile time what the two launches of the one-pass InfoNCE differ in — 1: denominators, no row weights;
 // 2: the batch rows' coefficients in s_coef, no denominators — so the weights' code has no (uniform) branches between the products.
-template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false, int PASS = 0>
+// PIPE (F16 + IMG only): the tile loop software-pipelined inside a wave — the first product of tile t is issued in front of the exp2 /
+// split of tile t - 1 (independent: the matrix core works on t while the vector unit finishes t - 1), then the second product of
+// t - 1; three LDS tiles instead of two.
+template <int NC, bool GRAD, bool VEC, bool SPLIT, bool TRR = false, bool IMG = false, bool F16 = false, int PASS = 0, bool PIPE = false>
 __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 2) : 3) : (F16 ? 2 : 1)) : (NC == 1 ? (SPLIT ? 3 : 4) : 2))) void lse_tile_kernel(const LseParams p) {
     static_assert(!IMG || (SPLIT && TRR), "the plane image serves the split products with transpose reads (no fp32 tile, no transposed copy)");
     static_assert(!F16 || (SPLIT && TRR && GRAD), "the fp16 form: gradient passes, transpose reads");
     static_assert(F16 == (PASS != 0), "PASS belongs to the fp16 form");
+    static_assert(!PIPE || (F16 && IMG), "the pipelined loop is written for the fp16 form on plane images");
+    constexpr int NBUF = PIPE ? 3 : 2;
     constexpr int NPL = F16 ? 2 : 3;
     constexpr int LD = NC * 64 + 4;
     constexpr int LDH = NC * 64 + 8;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     // the three terms of every tile element; the per-lane re-split of 16 element pairs per tile is gone, and the fp32 tile with it.)
     constexpr bool kFp32Tile = !SPLIT;
     __shared__ __attribute__((aligned(16))) float s_oth[kFp32Tile ? 2 : 1][kFp32Tile ? 32 : 1][kFp32Tile ? LD : 4];
-    __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? 2 : 1][NPL][SPLIT ? 32 : 1][SPLIT ? LDH : 8];  // (F16: two planes of fp16 bit patterns)
+    __shared__ __attribute__((aligned(16))) __bf16 s_pl[SPLIT ? NBUF : 1][NPL][SPLIT ? 32 : 1][SPLIT ? LDH : 8];  // (F16: two planes of fp16 bit patterns)
     // (r03) the gradients' second product reads the tile by COLUMN (8 oth rows of one feature column per lane): a transposed
     // copy of the planes [plane][column][row], row stride 36 bf16 (8-byte aligned, 18 dwords: b64 reads of 32 columns land in
     // 32 different bank pairs), makes a B fragment two 8-byte reads instead of eight 2-byte reads plus their packing
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     constexpr int LDT = 36;
     constexpr bool kPlT = SPLIT && GRAD && !TRR;
     __shared__ __attribute__((aligned(16))) __bf16 s_plt[kPlT ? 2 : 1][3][kPlT ? NC * 64 : 1][kPlT ? LDT : 4];
-    __shared__ float s_coef[2][32];
+    __shared__ float s_coef[NBUF][32];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform, and known to be)
     const int i = lane & 31, h = lane >> 5;
     const int64_t j = (int64_t)(blockIdx.x & 7) * p.blocks_per_xcd + (blockIdx.x >> 3);
@@ -408,6 +413,120 @@ __global__ __launch_bounds__(256, (GRAD ? (NC == 1 ? (SPLIT ? (IMG || F16 ? 3 : 
     // 40 982 / 29 858 table rows, 479 / 351 with the chunking re-tuned for three — the scratch traffic costs more than the third wave hides.
     // The transposed planes at stride 34 alone (two workgroups per CU): SQ_LDS_BANK_CONFLICT 11.8 M -> 3.9 M cycles per launch (the 2-byte
     // transposed stores of publish() are 4-way conflicted at stride 36), launch time unchanged (398 vs 395 us): not on the critical path.)
+    if constexpr (PIPE) {
+        auto p1 = [&](const int buf) __attribute__((always_inline)) {
+            f32x16 x = zero;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = c * 64 + h * 32 + q * 8;
+                    const f16x8 ah = *reinterpret_cast<const f16x8 *>(&s_pl[buf][0][i][off]);
+                    const f16x8 al = *reinterpret_cast<const f16x8 *>(&s_pl[buf][1][i][off]);
+                    const int sidx = c * 4 + q;
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bo2.h[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.l[sidx], x, 0, 0, 0);
+                    x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bo2.h[sidx], x, 0, 0, 0);
+                }
+            return x;
+        };
+        // exp2, coefficients, end-of-table mask, denominators, fp16 split of tile t (whose coefficients sit in s_coef[buf])
+        auto weights = [&](const f32x16 &x, const int buf, const int64_t t, f16x8 (&wh)[2], f16x8 (&wl)[2]) __attribute__((always_inline)) {
+            float w[16];
+            LseRows<0>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float e = __builtin_amdgcn_exp2f(x[r] * s2 - shift2);
+                w[r] = PASS == 2 ? e * s_coef[buf][lse_rowmap(r, h)] : e;
+            });
+            if constexpr (PASS == 1) {
+                const int64_t left = p.n_oth - t * 32;
+                if (left < 32) {
+                    const int left32 = (int)left;
+                    LseRows<0>::run([&](auto rc) {
+                        constexpr int r = decltype(rc)::value;
+                        w[r] = (lse_rowmap(r, h) < left32) ? w[r] : 0.f;
+                    });
+                }
+                LseRows<0>::run([&](auto rc) { zsum += w[decltype(rc)::value]; });
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    f16x2 hh, ll;
+                    split2_f16(w[8 * u + 2 * jj], w[8 * u + 2 * jj + 1], 1.f, hh, ll);
+                    wh[u][2 * jj] = hh[0], wh[u][2 * jj + 1] = hh[1];
+                    wl[u][2 * jj] = ll[0], wl[u][2 * jj + 1] = ll[1];
+                }
+        };
+        auto p2 = [&](const int buf, const f16x8 (&wh)[2], const f16x8 (&wl)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NC * 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    auto col8 = [&](const int pl) __attribute__((always_inline)) {
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        const int tt = lane & 15;
+                        const __bf16 *src = &s_pl[buf][pl][16 * u + 4 * h + (tt >> 2)][q * 32 + (i & 16) + 4 * (tt & 3)];
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)src);
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(src + 8 * LDH));
+                        const f16x4 l4 = __builtin_bit_cast(f16x4, lo), h4 = __builtin_bit_cast(f16x4, hi);
+                        return (f16x8){l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+                    };
+                    const f16x8 bh = col8(0), bl = col8(1);
+                    g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[u], bh, g[q], 0, 0, 0);
+                    g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bl, g[q], 0, 0, 0);
+                    g[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], bh, g[q], 0, 0, 0);
+                }
+        };
+        const unsigned lds_pl[3] = {(unsigned)(uintptr_t)&s_pl[0], (unsigned)(uintptr_t)&s_pl[1], (unsigned)(uintptr_t)&s_pl[2]};
+        constexpr bool has_coef = PASS == 2;
+        auto coef_of = [&](const int64_t t) __attribute__((always_inline)) {
+            return (has_coef && tid < 32 && t * 32 + tid < p.n_oth) ? p.coef_oth[t * 32 + tid] * p.w_scale : 0.f;
+        };
+        const int T = (int)(t1 - t0);
+        f32x16 xc = zero;
+        if (T > 0) {
+            PlaneImage<NC, NPL>::dma(p.oth_image, t0, lds_pl[0], tid, wave);
+            if (has_coef && tid < 32) s_coef[0][tid] = coef_of(t0);
+            dma_drain();
+        }
+        __syncthreads();
+        if (T > 0) {
+            if (T > 1) {
+                PlaneImage<NC, NPL>::dma(p.oth_image, t0 + 1, lds_pl[1], tid, wave);
+                stage_coef = coef_of(t0 + 1);
+            }
+            if (wave_live) xc = p1(0);
+            if (T > 1 && has_coef && tid < 32) s_coef[1][tid] = stage_coef;
+            dma_drain();
+            __syncthreads();
+        }
+        int cur = 1, prev = 0;  // LDS tiles of tile k and k - 1; the third one receives tile k + 1
+        for (int k = 1; k < T; ++k) {
+            const int nxt = 3 - cur - prev;
+            if (k + 1 < T) {
+                PlaneImage<NC, NPL>::dma(p.oth_image, t0 + k + 1, lds_pl[nxt], tid, wave);  // (last read by tile k - 2, before the previous barrier)
+                stage_coef = coef_of(t0 + k + 1);
+            }
+            if (wave_live) {
+                const f32x16 xp = xc;
+                xc = p1(cur);
+                f16x8 wh[2], wl[2];
+                weights(xp, prev, t0 + k - 1, wh, wl);
+                p2(prev, wh, wl);
+            }
+            if (k + 1 < T && has_coef && tid < 32) s_coef[nxt][tid] = stage_coef;
+            dma_drain();
+            __syncthreads();
+            prev = cur, cur = nxt;
+        }
+        if (T > 0 && wave_live) {
+            f16x8 wh[2], wl[2];
+            weights(xc, prev, t1 - 1, wh, wl);
+            p2(prev, wh, wl);
+        }
+    } else
     if constexpr (IMG) {
         // r06: the oth tiles come from the plane image by LDS-DMA, one tile ahead; only the tile's 32 weights (gradient of the table
         // side) still travel through registers
@@ -530,7 +649,7 @@ struct LseLayout {
     int64_t off_coef, off_q, off_c, off_den, bytes;
 };
 // the fp16 form of the gradient passes (rbg_infonce_f32 without weights; F16 in lse_tile_kernel) is on
-// (1 = its tiles from fp16 plane images by LDS-DMA, 2 = fetched and split per workgroup)
+// (1 = its tiles from fp16 plane images by LDS-DMA, 2 = fetched and split per workgroup, 3 = 1 with the tile loop software-pipelined: default)
 static int lse_f16_mode(int d) { return (opt_mfma_split() != 0 && opt_lse_tr_read() && !opt_lse_image() && d % 4 == 0) ? opt_lse_f16() : 0; }
 static bool lse_f16_on(int d) { return lse_f16_mode(d) != 0; }
 
@@ -574,7 +693,10 @@ static void lse_launch(LseParams p, bool vec, hipStream_t s) {
     const bool split = opt_mfma_split() != 0;
     if constexpr (GRAD) {  // r06: the gradients' second product reads its B fragments by LDS transpose reads (option "lse_tr_read", default 1)
         if (p.w_scale != 0.f) {  // the fp16 form (the caller checked lse_f16_mode and the alignment)
-            if (p.oth_image) {
+            if (p.oth_image && opt_lse_f16() == 3) {  // the software-pipelined loop (default): 212.5 -> 209 us per call, 691 -> 686 at d = 128
+                if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 1, true>), grid, dim3(256), 0, s, p);
+                else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 2, true>), grid, dim3(256), 0, s, p);
+            } else if (p.oth_image) {
                 if (p.den_out) hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 1>), grid, dim3(256), 0, s, p);
                 else hipLaunchKernelGGL((lse_tile_kernel<NC, true, true, true, true, true, true, 2>), grid, dim3(256), 0, s, p);
             } else {
@@ -1055,7 +1177,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 1 (own = the batch rows): denominators' and gradient's partials per chunk
     p.own = A, p.ld_own = d, p.n_own = B;
     p.oth = C, p.ld_oth = d, p.n_oth = n;
-    p.oth_image = (img || f16_mode == 1) ? imgC : nullptr;
+    p.oth_image = (img || (f16_mode & 1)) ? imgC : nullptr;
     p.tiles_per_chunk = L.tpc_q, p.n_chunks = L.nc_q;
     p.out = part_q;
     p.den_out = den;
@@ -1075,7 +1197,7 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     // pass 2 (own = the table rows): needs the finished denominators (coef)
     p.own = C, p.n_own = n;
     p.oth = A, p.n_oth = B;
-    p.oth_image = (img || f16_mode == 1) ? imgA : nullptr;
+    p.oth_image = (img || (f16_mode & 1)) ? imgA : nullptr;
     p.coef_own = col_w, p.coef_oth = coef;
     p.tiles_per_chunk = L.tpc_c, p.n_chunks = L.nc_c;
     p.out = part_c;
@@ -1136,9 +1258,9 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     const int f16_mode = (onepass && grads && !masked) ? lse_f16_mode(d) : 0;
     char *imgC = grads ? w + L.off_imgC : nullptr, *imgA = grads ? w + L.off_imgA : nullptr;
     const unsigned nb_img = (unsigned)((n + 31) / 32 * 8), bb_img = (unsigned)((B + 31) / 32 * 8);  // (whole tiles: the rows past the end are zeroed)
-    hipLaunchKernelGGL(nce_norm_table_kernel, dim3(f16_mode == 1 ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, f16_mode == 1 ? imgC : nullptr);
+    hipLaunchKernelGGL(nce_norm_table_kernel, dim3((f16_mode & 1) ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, (f16_mode & 1) ? imgC : nullptr);
     RBG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3(f16_mode == 1 ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, f16_mode == 1 ? imgA : nullptr);
+    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3((f16_mode & 1) ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, (f16_mode & 1) ? imgA : nullptr);
     RBG_HIP(hipGetLastError());
     if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s,
                                         imgC, imgA, f16_mode);

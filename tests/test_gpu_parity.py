@@ -1166,12 +1166,12 @@ def test_info_nce_zero_row(rbg, cuda):
     close(g2.grad, b64.grad.float(), tol=2e-5)
 
 
-@pytest.mark.parametrize("f16", [1, 2, 0])
+@pytest.mark.parametrize("f16", [1, 2, 3, 0])
 @pytest.mark.parametrize("n,d,b,tau,w,kind", [
     (3000, 64, 300, 0.2, 1.0, "normal"), (3000, 64, 300, 0.05, 1e-7, "heavy"), (2000, 128, 257, 0.2, -3.0, "normal"),
     (1500, 64, 100, 1.0, 250.0, "sparse"), (700, 36, 65, 0.1, 0.05, "heavy"), (900, 62, 40, 0.2, 1.0, "normal")])
 def test_info_nce_fp16_form(rbg, cuda, f16, n, d, b, tau, w, kind):
-    """Option "lse_f16" (r06, default 1; 1 = tiles from fp16 plane images the row kernels write, 2 = fetched and split per workgroup): the gradient passes of the unweighted rbg_infonce_f32 split unit rows and weights in
+    """Option "lse_f16" (r06, default 3; 1 = tiles from fp16 plane images the row kernels write, 2 = fetched and split per workgroup, 3 = 1 with the tile loop software-pipelined): the gradient passes of the unweighted rbg_infonce_f32 split unit rows and weights in
     [0, 1] into TWO fp16 terms (three products on v_mfma_f32_32x32x16_f16) instead of three bf16 terms (six products).  Both forms
     against float64 autograd of sgl.py:191-199 at the SAME tolerance — rows with heavy tails (elements 1e-6 .. 1 of the row's norm:
     fp16's subnormal range after the 2^8 scale), one-hot-like rows, a weight as small as NCL's ssl_reg and a negative one (the
