@@ -19,6 +19,11 @@
 // which is exactly the A-slot layout of a second 32x32x2 MFMA whose k index runs over oth rows; its B slot (oth rows x
 // 32 feature columns) is read from a wave-private LDS copy of the oth tile (row stride d+1: conflict-free both ways).
 // Nothing is accumulated with atomics: chunk partials are summed in a fixed order by small reduce kernels.
+//
+// r06: inside rbg_infonce_f32 (unit rows, weights that are probabilities) the two gradient launches run in the fp16 two-term form
+// (template flag F16, option "lse_f16"): operands as TWO fp16 terms after a power-of-two scale, three products on
+// v_mfma_f32_32x32x16_f16 instead of six bf16 ones, tiles by LDS-DMA from fp16 plane images the row kernels write, the tile loop
+// software-pipelined inside a wave (PIPE).  rbg_lse_rows*_f32 and the weighted InfoNCE (the caller's numbers) keep the bf16 / fp32 forms.
 
 #include <hip/hip_runtime.h>
 
