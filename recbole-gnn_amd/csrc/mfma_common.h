@@ -226,7 +226,8 @@ struct RowTile3 {
 // product <= 3 x 2^-22 instead of ~ 2^-23).  The power-of-two `scale` (exact; the caller folds its inverse into what consumes the
 // accumulator) keeps the LOW term a normal fp16 number wherever that matters: l is below fp16's smallest normal 2^-14 only for
 // |x| scale < 2^-3, and is then rounded with an ABSOLUTE error <= 2^-25 / scale (1.2e-10 at scale = 2^8) instead of 2^-11 |l| —
-// should the matrix core flush subnormal inputs the error is |l| < 2^-14 / scale.  Overflow needs |x| scale > 65 504.
+// (the matrix core does NOT flush subnormal fp16 inputs: devtools/microbench/mfma_f16_denorm.hip, profiles/r06_mfma_f16_denorm.jsonl).
+// Overflow needs |x| scale > 65 504.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
