@@ -355,6 +355,16 @@ int rbg_spmm_noise_f32(const rbg_graph *g, const float *X, float *Y, const float
  * Y, noise, out: [n, d] contiguous, d <= 128; out may alias Y. */
 int rbg_sign_noise_f32(const float *Y, const float *noise, int64_t n, int d, float eps, float *out, void *stream);
 
+/* The one-occurrence mask of a batch's ids and the row weights of rbg_infonce_masked_f32 in one launch (r06; SimGCL / XSimGCL contrast
+ * over torch.unique of the batch without its data-dependent shape, simgcl.py:38-43, xsimgcl.py:50-54):
+ *   once[b] = 1 for exactly ONE position b of every distinct id, 0 for the others  (first_occurrence = 1: the first position — the
+ *             same positions in every run; 0: whichever store stays, cheaper; no loss depends on which: rows of equal ids are equal)
+ *   row_w[b] = once[b]                (mean_form = 0: a sum over the distinct ids)
+ *            = once[b] / sum(once)    (mean_form = 1: their mean)
+ * ids [B] int64 in [0, n_ids); slot: scratch of n_ids int64 (no reset needed between calls); once, row_w: [B] fp32. */
+int rbg_once_mask_f32(const int64_t *ids, int64_t B, int64_t n_ids, int64_t *slot, int first_occurrence, int mean_form, float *once,
+                      float *row_w, void *stream);
+
 /* Replaces LightGCN.get_ego_embeddings + LightGCN.forward
  *   recbole_gnn/model/general_recommender/lightgcn.py:60-68,70-81  (and SGL.forward,
  *   sgl.py:128-145, where layer k may use its own graph).

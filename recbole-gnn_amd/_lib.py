@@ -59,6 +59,7 @@ SIGNATURES = {
     "rbg_spmm_noise_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_vp]),
     "rbg_spmm_add_f32": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "rbg_sign_noise_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_vp]),
+    "rbg_once_mask_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "rbg_lightgcn_forward_f32": (c_int, [P(c_vp), c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_u32, c_vp]),
     "rbg_lightgcn_backward_f32": (c_int, [P(c_vp), c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "rbg_bignn_conv_f32": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int,

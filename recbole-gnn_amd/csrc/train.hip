@@ -674,6 +674,39 @@ __global__ __launch_bounds__(256) void lgcn_tail_kernel(const LeanTailArgs a) {
     }
 }
 
+// r06: the one-occurrence mask of a batch's ids (models._once_mask: what torch.unique selects, with static shapes) and the row weights of
+// the masked InfoNCE in ONE single-block launch instead of five or six torch launches: every position writes its index into its id's
+// slot (first = 1: an integer minimum, so the FIRST occurrence stays — option "deterministic"), the position that finds itself there
+// is the occurrence kept; row_w = once (SimGCL's sum over the distinct ids) or once / count (XSimGCL's mean, xsimgcl.py:54).
+// slot [n_ids] needs no reset: only the slots written here are read.
+__global__ __launch_bounds__(1024) void once_mask_kernel(const int64_t *__restrict__ ids, int64_t B, long long *__restrict__ slot, int first,
+                                                         int mean_form, float *__restrict__ once, float *__restrict__ row_w) {
+    __shared__ float part[16];
+    const int tid = threadIdx.x;
+    if (first) {
+        for (int64_t b = tid; b < B; b += 1024) slot[ids[b]] = 0x7fffffffffffffffLL;
+        __syncthreads();
+        for (int64_t b = tid; b < B; b += 1024) atomicMin(&slot[ids[b]], (long long)b);
+    } else {
+        for (int64_t b = tid; b < B; b += 1024) slot[ids[b]] = (long long)b;  // (racing stores of different positions: one of them stays)
+    }
+    __syncthreads();
+    float cnt = 0.f;
+    for (int64_t b = tid; b < B; b += 1024) {
+        const float o = (__hip_atomic_load(&slot[ids[b]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (long long)b) ? 1.f : 0.f;
+        once[b] = o;
+        cnt += o;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if ((tid & 63) == 0) part[tid >> 6] = cnt;
+    __syncthreads();
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) total += part[k];
+    for (int64_t b = tid; b < B; b += 1024) row_w[b] = mean_form ? once[b] / total : once[b];
+}
+
 // out = y + sign(y) * noise / max(|noise row|, 1e-12) * eps: the epilogue of rbg_spmm_noise_f32 on a product that exists already
 // (r06: SimGCL's three passes share their first product A E_0).  One wave per row, d <= 128: lane c holds columns c and c + 64.
 __global__ __launch_bounds__(256) void sign_noise_kernel(const float *__restrict__ y, const float *__restrict__ noise, int64_t n, int d,
@@ -894,6 +927,18 @@ int rbg_sign_noise_f32(const float *Y, const float *noise, int64_t n, int d, flo
     if (n == 0) return RBG_OK;
     if (!Y || !noise || !out) return fail(RBG_EINVAL, "NULL pointer");
     hipLaunchKernelGGL(sign_noise_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, Y, noise, n, d, eps, out);
+    RBG_HIP(hipGetLastError());
+    return RBG_OK;
+}
+
+int rbg_once_mask_f32(const int64_t *ids, int64_t B, int64_t n_ids, int64_t *slot, int first_occurrence, int mean_form, float *once,
+                      float *row_w, void *stream) {
+    clear_error();
+    if (B < 0 || n_ids < 0) return fail(RBG_ESHAPE, "B = %lld, n_ids = %lld", (long long)B, (long long)n_ids);
+    if (B == 0) return RBG_OK;
+    if (!ids || !slot || !once || !row_w) return fail(RBG_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(once_mask_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ids, B, reinterpret_cast<long long *>(slot),
+                       first_occurrence, mean_form, once, row_w);
     RBG_HIP(hipGetLastError());
     return RBG_OK;
 }

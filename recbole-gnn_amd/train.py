@@ -437,6 +437,7 @@ class _FusedContrastStep(_FusedStep):
         self.t0, self.t1, self.work = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
         self.loss, self.reg_ws = torch.zeros((), **f), torch.zeros(3, **f)
         self._scratch = {}
+        self._once = {}
         self.table_opt = _TableAdam(model, lr, betas, eps)
         model.user_embedding.weight.grad = self.ge[:nu]  # (for inspection; the tables are updated from ge directly)
         model.item_embedding.weight.grad = self.ge[nu:]
@@ -467,7 +468,6 @@ class _FusedContrastStep(_FusedStep):
     def _contrast(self, ta, tb, ga, gb, ids, row0, rows, b, mean_form):
         """cl_rate x InfoNCE between rows `ids` of tables ta and tb (rows [row0, row0 + rows) of the [N, d] buffers): the value is
         added to self.loss, the gradients w.r.t. the two tables' rows are scattered onto ga / gb (either may be the same buffer)."""
-        from .models import _once_mask
         m = self.model
         d = ta.shape[1]
         st = c_vp(torch.cuda.current_stream(m.device).cuda_stream)
@@ -476,8 +476,14 @@ class _FusedContrastStep(_FusedStep):
             check(lib.rbg_infonce_workspace(b, b, d, _lib.ctypes.byref(nbytes)))
             self._scratch[b] = (torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device), torch.arange(b, device=m.device))
         work, ar = self._scratch[b]
-        once = _once_mask(ids, rows).to(torch.float32)
-        row_w = once / once.sum() if mean_form else once  # (xsimgcl.py:54: a mean over the distinct ids)
+        # r06: the mask and the row weights in ONE launch (rbg_once_mask_f32) instead of scatter / gather / compare / cast (/ sum / divide)
+        key = (b, int(rows))
+        if key not in self._once:
+            self._once[key] = (torch.empty(int(rows), dtype=torch.int64, device=m.device),
+                               torch.empty(b, dtype=torch.float32, device=m.device), torch.empty(b, dtype=torch.float32, device=m.device))
+        slot, once, row_w = self._once[key]  # (xsimgcl.py:54: mean_form = a mean over the distinct ids)
+        check(lib.rbg_once_mask_f32(self._ptr(ids), b, int(rows), self._ptr(slot), int(bool(_get_option("deterministic"))), int(bool(mean_form)),
+                                    self._ptr(once), self._ptr(row_w), st))
         xa, xb = ta[row0:row0 + rows].index_select(0, ids), tb[row0:row0 + rows].index_select(0, ids)
         gxa, gxb = torch.zeros_like(xa), torch.zeros_like(xb)
         check(lib.rbg_infonce_masked_f32(self._ptr(xa), self._ptr(xb), b, d, self._ptr(ar), b, float(m.temperature), float(m.cl_rate),

@@ -660,3 +660,31 @@ def test_bpr_and_embloss_scatters_in_both_modes(rbg, cuda, scatter_mode, b, d, r
         args2 = args[:-2] + (vp(ge2.data_ptr()), vp(le2.data_ptr()))
         rbg._lib.check(lib.rbg_emb_reg_grad_f32(*args2, st) if require_pow else lib.rbg_emb_reg_grad_nopow_f32(*args2, vp(ws.data_ptr()), st))
         assert torch.equal(ge, ge2) and torch.equal(le, le2)
+
+
+@pytest.mark.parametrize("b,n_ids", [(2048, 29859), (7, 5), (5000, 300), (1, 1)])
+def test_once_mask_in_one_launch(rbg, cuda, b, n_ids):
+    """rbg_once_mask_f32 (r06) == models._once_mask + the row weights of the masked InfoNCE: exactly one position of every distinct id
+    carries 1; first_occurrence = 1 keeps the FIRST position (what option "deterministic" asks for); mean_form divides by the number
+    of distinct ids; the slot scratch needs no reset between calls."""
+    from recbole_gnn_amd._lib import lib, check, c_vp
+    gen = torch.Generator().manual_seed(b + n_ids)
+    st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
+    slot = torch.full((n_ids,), -7, dtype=torch.int64, device=cuda)  # (garbage on purpose)
+    for trial in range(3):
+        ids = torch.randint(0, n_ids, (b,), generator=gen).to(cuda)
+        distinct = int(torch.unique(ids).numel())
+        for first in (0, 1):
+            for mean_form in (0, 1):
+                once, row_w = torch.empty(b, device=cuda), torch.empty(b, device=cuda)
+                check(lib.rbg_once_mask_f32(c_vp(ids.data_ptr()), b, n_ids, c_vp(slot.data_ptr()), first, mean_form, c_vp(once.data_ptr()),
+                                            c_vp(row_w.data_ptr()), st))
+                assert set(once.unique().tolist()) <= {0.0, 1.0} and int(once.sum()) == distinct
+                kept = ids[once > 0]
+                assert kept.unique().numel() == distinct  # one position per distinct id
+                if first:
+                    pos = torch.nonzero(once > 0).flatten().cpu()
+                    want = torch.tensor([int((ids.cpu() == v).nonzero()[0]) for v in ids.cpu()[pos]])
+                    assert torch.equal(pos, want)
+                ref_w = once / distinct if mean_form else once
+                assert torch.equal(row_w, ref_w) or float((row_w - ref_w).abs().max()) <= 1e-9
