@@ -561,6 +561,16 @@ int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, c
                            const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
                            void *stream);
 
+/* The same contrast AMONG THE ROWS OF A BATCH, straight on the tables (r06): with a = normalize(TA[ids]), c = normalize(TB[ids])
+ *   *loss += weight * sum_b row_w[b] * ( log sum_j col_w[j] exp(<a_b, c_j> / tau) - <a_b, c_b> / tau )      b, j = positions 0..B-1
+ *   grad_TA[ids[b]] += d/da_b ...,  grad_TB[ids[j]] += d/dc_j ...   (float atomics: ids repeat; both tables or none)
+ * = rbg_infonce_masked_f32 on the gathered rows (T1 = TA[ids], T2 = TB[ids], idx = 0..B-1, n = B) followed by two index_add_ of the
+ * row gradients — without the two gathers, the two zero-filled gradient blocks and the two scatters (simgcl.py:38-57,
+ * xsimgcl.py:50-54,86-89 with the one-occurrence mask of rbg_once_mask_f32 as row_w / col_w).  `workspace`: rbg_infonce_workspace(B, B, d). */
+int rbg_infonce_batch_f32(const float *TA, const float *TB, int d, const int64_t *ids, int64_t B, float tau, float weight,
+                          const float *row_w, const float *col_w, float *loss, float *grad_TA, float *grad_TB, void *workspace,
+                          void *stream);
+
 /* Full-sort evaluation of one batch without the [B, n_items] score matrix.
  * Replaces full_sort_predict (lightgcn.py:123-133) + RecBole's Trainer._full_sort_batch_eval [recbole==1.1.1]:
  *   scores = user_all[users] @ item_all.T;  scores[:, 0] = -inf;  scores[history_index] = -inf;  topk(scores, k)

@@ -874,16 +874,18 @@ __device__ __forceinline__ void nce_image_row(char *img, int64_t j, int d, int l
     if (d > 64) tile[row * ldh + lane + 64] = h[1], tile[(32 + row) * ldh + lane + 64] = l[1];
 }
 
-// C[j] = T[j] / max(||T[j]||, eps), inv[j] = 1 / max(||T[j]||, eps).  One wave per row.
+// C[j] = T[j] / max(||T[j]||, eps), inv[j] = 1 / max(||T[j]||, eps).  One wave per row.  gidx != NULL (r06, the batch form:
+// rbg_infonce_batch_f32): row j of the candidate table is row gidx[j] of T.
 __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__restrict__ T, int64_t n, int d, float *__restrict__ C,
-                                                             float *__restrict__ inv, char *__restrict__ img16) {
+                                                             float *__restrict__ inv, char *__restrict__ img16,
+                                                             const int64_t *__restrict__ gidx) {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= n) {
         if (img16 && j < (n + 31) / 32 * 32) nce_image_row(img16, j, d, lane, 0.f, 0.f);
         return;
     }
-    const float *row = T + j * d;
+    const float *row = T + (gidx ? gidx[j] : j) * d;
     float ss = 0.f;
     for (int c = lane; c < d; c += 64) ss = fmaf(row[c], row[c], ss);
     ss = wave_sum(ss);
@@ -893,11 +895,12 @@ __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__rest
     if (img16) nce_image_row(img16, j, d, lane, lane < d ? row[lane] * iv : 0.f, lane + 64 < d ? row[lane + 64] * iv : 0.f);
 }
 
-// A[b] = normalize(T1[idx[b]]), inv1[b], pos[b] = <A[b], C[idx[b]]>.  One wave per batch row.
+// A[b] = normalize(T1[idx[b]]), inv1[b], pos[b] = <A[b], C[idx[b]]>.  One wave per batch row.  c_by_pos (the batch form): the
+// candidate table IS the batch, its row of position b is C[b].
 __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__restrict__ T1, const float *__restrict__ C,
                                                              const int64_t *__restrict__ idx, int64_t B, int d,
                                                              float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos,
-                                                             char *__restrict__ img16) {
+                                                             char *__restrict__ img16, int c_by_pos) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= B) {
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__rest
     for (int c = lane; c < d; c += 64) {
         const float a = row[c] * iv;
         A[b * d + c] = a;
-        dot = fmaf(a, C[r * d + c], dot);
+        dot = fmaf(a, C[(c_by_pos ? b : r) * d + c], dot);
     }
     dot = wave_sum(dot);
     if (lane == 0) {
@@ -1046,13 +1049,14 @@ struct NceBackPartsArgs {
     int d;
     float ws;
     float *dC, *grad_T1;
+    int c_by_pos;  // the batch form: C and dC are indexed by the position b, grad_T1 by idx[b]
 };
 
 template <bool ORDERED>
 __device__ __forceinline__ void nce_batch_back_parts_elem(const NceBackPartsArgs &a, int64_t b, int lane) {
     const int d = a.d;
     const int64_t B = a.B;
-    const int64_t r = a.idx[b];
+    const int64_t r = a.idx[b], rc = a.c_by_pos ? b : r;
     const float cb = a.coef[b];
     const float ws = a.row_w ? a.ws * a.row_w[b] : a.ws;  // the positive term carries the row's weight too
     float g0 = 0.f, g1 = 0.f;  // d <= 128: columns lane and lane + 64
@@ -1063,19 +1067,19 @@ __device__ __forceinline__ void nce_batch_back_parts_elem(const NceBackPartsArgs
         g0 += in0 ? src[lane] : 0.f;
         g1 += in1 ? src[lane + 64] : 0.f;
     }
-    g0 = lane < d ? g0 * cb - ws * a.C[r * d + lane] : 0.f;
-    g1 = lane + 64 < d ? g1 * cb - ws * a.C[r * d + lane + 64] : 0.f;
+    g0 = lane < d ? g0 * cb - ws * a.C[rc * d + lane] : 0.f;
+    g1 = lane + 64 < d ? g1 * cb - ws * a.C[rc * d + lane + 64] : 0.f;
     const float a0 = lane < d ? a.A[b * d + lane] : 0.f, a1 = lane + 64 < d ? a.A[b * d + lane + 64] : 0.f;
     const float dot = wave_sum(fmaf(g0, a0, g1 * a1));
     const float iv = a.inv1[b];
     const bool clamped = iv >= 1.0f / kNormEps;
     if (lane < d) {
         if (a.grad_T1) row_add<ORDERED>(a.grad_T1 + r * d + lane, (clamped ? g0 : g0 - a0 * dot) * iv);
-        row_add<ORDERED>(a.dC + r * d + lane, -ws * a0);
+        row_add<ORDERED>(a.dC + rc * d + lane, -ws * a0);
     }
     if (lane + 64 < d) {
         if (a.grad_T1) row_add<ORDERED>(a.grad_T1 + r * d + lane + 64, (clamped ? g1 : g1 - a1 * dot) * iv);
-        row_add<ORDERED>(a.dC + r * d + lane + 64, -ws * a1);
+        row_add<ORDERED>(a.dC + rc * d + lane + 64, -ws * a1);
     }
 }
 
@@ -1097,8 +1101,11 @@ struct NceBackPartsRows {
 
 // nce_table_back_kernel with g = sum_c part_c[c][j] formed here (the chunk reduction of the table-side gradient; the batch rows'
 // positive-term contributions were added onto chunk 0 by the kernel above)
+// sidx != NULL (the batch form): candidate j is row sidx[j] of the gradient table; ids repeat, so the rows are added with float atomics
+// (a repeated id's other positions carry zero weight: they add exact zeros — the sum does not depend on the order)
 __global__ __launch_bounds__(256) void nce_table_back_parts_kernel(const float *__restrict__ part_c, int n_chunks, const float *__restrict__ C,
-                                                                   const float *__restrict__ inv, int64_t n, int d, float *__restrict__ grad_T2) {
+                                                                   const float *__restrict__ inv, int64_t n, int d, float *__restrict__ grad_T2,
+                                                                   const int64_t *__restrict__ sidx) {
     const int lane = threadIdx.x & 63;
     const int64_t j = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (j >= n) return;
@@ -1114,6 +1121,12 @@ __global__ __launch_bounds__(256) void nce_table_back_parts_kernel(const float *
     const float dot = wave_sum(fmaf(g0, c0, g1 * c1));
     const float iv = inv[j];
     const bool clamped = iv >= 1.0f / kNormEps;
+    if (sidx) {
+        float *dst = grad_T2 + sidx[j] * d;
+        if (lane < d) atomicAdd(dst + lane, (clamped ? g0 : g0 - c0 * dot) * iv);
+        if (lane + 64 < d) atomicAdd(dst + lane + 64, (clamped ? g1 : g1 - c1 * dot) * iv);
+        return;
+    }
     if (lane < d) grad_T2[j * d + lane] += (clamped ? g0 : g0 - c0 * dot) * iv;
     if (lane + 64 < d) grad_T2[j * d + lane + 64] += (clamped ? g1 : g1 - c1 * dot) * iv;
 }
@@ -1152,7 +1165,7 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
                            const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
                            float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr,
-                           int f16_mode = 0) {
+                           int f16_mode = 0, const int64_t *batch_ids = nullptr) {
     const bool vec = lse_vec(A, d, C, d, d);
     // r06, the fp16 form: unit rows and weights in [0, 1] — the plain InfoNCE only (row / candidate weights are the caller's numbers);
     // f16_mode 1: imgC / imgA hold the fp16 plane images the row kernels wrote
@@ -1217,13 +1230,13 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     RBG_HIP(hipGetLastError());
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
     {
-        const NceBackPartsArgs ba{part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale, part_c, grad_T1};
+        const NceBackPartsArgs ba{part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale, part_c, grad_T1, batch_ids ? 1 : 0};
         if (opt_deterministic()) launch_ordered_scatter(NceBackPartsRows{ba}, B, s);
         else hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, ba);
     }
     RBG_HIP(hipGetLastError());
     if (grad_T2) {
-        hipLaunchKernelGGL(nce_table_back_parts_kernel, dim3(nb), dim3(256), 0, s, part_c, L.nc_c, C, inv2, n, d, grad_T2);
+        hipLaunchKernelGGL(nce_table_back_parts_kernel, dim3(nb), dim3(256), 0, s, part_c, L.nc_c, C, inv2, n, d, grad_T2, batch_ids);
         RBG_HIP(hipGetLastError());
     }
     return RBG_OK;
@@ -1239,8 +1252,10 @@ int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes) {
     return RBG_OK;
 }
 
+// batch_form (rbg_infonce_batch_f32): the candidates are the batch's own rows T2[idx[b]] (n = B), the gradients go to rows idx[b] of both tables
 static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau, float weight,
-                        const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
+                        const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream,
+                        bool batch_form = false) {
     clear_error();
     if (B < 0 || n <= 0 || d <= 0) return fail(RBG_ESHAPE, "B = %lld, n = %lld, d = %d", (long long)B, (long long)n, d);
     if (d > 128) return fail(RBG_EUNSUPPORTED, "infonce: d = %d > 128", d);
@@ -1258,17 +1273,19 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
     const bool grads = grad_T1 || grad_T2;
     const bool masked = row_w || col_w;
-    const bool onepass = masked || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
+    const bool onepass = masked || batch_form || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
+    const int64_t *bids = batch_form ? idx : nullptr;
     // r06: the fp16 form of the gradient launches (the plain InfoNCE with gradients); mode 1: the row kernels write the fp16 plane images too
     const int f16_mode = (onepass && grads && !masked) ? lse_f16_mode(d) : 0;
     char *imgC = grads ? w + L.off_imgC : nullptr, *imgA = grads ? w + L.off_imgA : nullptr;
     const unsigned nb_img = (unsigned)((n + 31) / 32 * 8), bb_img = (unsigned)((B + 31) / 32 * 8);  // (whole tiles: the rows past the end are zeroed)
-    hipLaunchKernelGGL(nce_norm_table_kernel, dim3((f16_mode & 1) ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, (f16_mode & 1) ? imgC : nullptr);
+    hipLaunchKernelGGL(nce_norm_table_kernel, dim3((f16_mode & 1) ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, (f16_mode & 1) ? imgC : nullptr, bids);
     RBG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3((f16_mode & 1) ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, (f16_mode & 1) ? imgA : nullptr);
+    hipLaunchKernelGGL(nce_batch_prep_kernel, dim3((f16_mode & 1) ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, (f16_mode & 1) ? imgA : nullptr,
+                       batch_form ? 1 : 0);
     RBG_HIP(hipGetLastError());
     if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s,
-                                        imgC, imgA, f16_mode);
+                                        imgC, imgA, f16_mode, bids);
     int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
@@ -1298,6 +1315,14 @@ int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, c
                            const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
                            void *stream) {
     return infonce_impl(T1, T2, n, d, idx, B, tau, weight, row_w, col_w, loss, grad_T1, grad_T2, workspace, stream);
+}
+
+int rbg_infonce_batch_f32(const float *TA, const float *TB, int d, const int64_t *ids, int64_t B, float tau, float weight,
+                          const float *row_w, const float *col_w, float *loss, float *grad_TA, float *grad_TB, void *workspace,
+                          void *stream) {
+    if (B > 0 && ((grad_TA != nullptr) != (grad_TB != nullptr)))
+        return fail(RBG_EINVAL, "infonce_batch: both gradient tables or none");
+    return infonce_impl(TA, TB, B > 0 ? B : 1, d, ids, B, tau, weight, row_w, col_w, loss, grad_TA, grad_TB, workspace, stream, true);
 }
 
 }  // extern "C"

@@ -484,13 +484,12 @@ class _FusedContrastStep(_FusedStep):
         slot, once, row_w = self._once[key]  # (xsimgcl.py:54: mean_form = a mean over the distinct ids)
         check(lib.rbg_once_mask_f32(self._ptr(ids), b, int(rows), self._ptr(slot), int(bool(_get_option("deterministic"))), int(bool(mean_form)),
                                     self._ptr(once), self._ptr(row_w), st))
-        xa, xb = ta[row0:row0 + rows].index_select(0, ids), tb[row0:row0 + rows].index_select(0, ids)
-        gxa, gxb = torch.zeros_like(xa), torch.zeros_like(xb)
-        check(lib.rbg_infonce_masked_f32(self._ptr(xa), self._ptr(xb), b, d, self._ptr(ar), b, float(m.temperature), float(m.cl_rate),
-                                         self._ptr(row_w), self._ptr(once), self._ptr(self.loss), self._ptr(gxa), self._ptr(gxb), self._ptr(work), st))
-        # (rows of a repeated id carry zero weight but one: the scatter's float atomics add zeros — deterministic)
-        ga[row0:row0 + rows].index_add_(0, ids, gxa)
-        gb[row0:row0 + rows].index_add_(0, ids, gxb)
+        # r06: the contrast among the batch's rows straight on the tables (rbg_infonce_batch_f32) — no gathered copies, no zero-filled
+        # gradient blocks, no index_add_: the row kernels gather, the backward kernels scatter (rows of a repeated id carry zero
+        # weight but one: the float atomics add zeros — the sums do not depend on the order)
+        check(lib.rbg_infonce_batch_f32(self._ptr(ta[row0:row0 + rows]), self._ptr(tb[row0:row0 + rows]), d, self._ptr(ids), b,
+                                        float(m.temperature), float(m.cl_rate), self._ptr(row_w), self._ptr(once), self._ptr(self.loss),
+                                        self._ptr(ga[row0:row0 + rows]), self._ptr(gb[row0:row0 + rows]), self._ptr(work), st))
 
     def _reg_and_adam(self, user, pos, neg, b, d):
         m = self.model

@@ -688,3 +688,46 @@ def test_once_mask_in_one_launch(rbg, cuda, b, n_ids):
                     assert torch.equal(pos, want)
                 ref_w = once / distinct if mean_form else once
                 assert torch.equal(row_w, ref_w) or float((row_w - ref_w).abs().max()) <= 1e-9
+
+
+@pytest.mark.parametrize("det", [0, 1])
+@pytest.mark.parametrize("rows,b,d,mean_form", [(3000, 300, 64, False), (500, 700, 64, True), (2000, 257, 128, True), (64, 33, 36, False)])
+def test_infonce_batch_form_equals_the_gathered_form(rbg, cuda, det, rows, b, d, mean_form):
+    """rbg_infonce_batch_f32 (r06: the contrast among the batch's rows straight on the tables) == rbg_infonce_masked_f32 on the gathered
+    rows followed by index_add_ of the row gradients (what train._contrast did): the same loss, the same gradient tables (ids repeat:
+    the masked positions add zeros); also in "deterministic" mode (ordered row scatters)."""
+    from recbole_gnn_amd._lib import lib, check, c_vp, c_i64
+    import ctypes
+    gen = torch.Generator().manual_seed(rows + b + d)
+    ta, tb = torch.randn(rows, d, generator=gen).to(cuda), torch.randn(rows, d, generator=gen).to(cuda)
+    ids = torch.randint(0, rows, (b,), generator=gen).to(cuda)
+    st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
+    p = lambda t: c_vp(t.data_ptr())  # noqa: E731
+    old = rbg.get_option("deterministic")
+    rbg.set_option("deterministic", det)
+    try:
+        slot = torch.empty(rows, dtype=torch.int64, device=cuda)
+        once, row_w = torch.empty(b, device=cuda), torch.empty(b, device=cuda)
+        check(lib.rbg_once_mask_f32(p(ids), b, rows, p(slot), 1, int(mean_form), p(once), p(row_w), st))
+        nbytes = c_i64()
+        check(lib.rbg_infonce_workspace(b, b, d, ctypes.byref(nbytes)))
+        work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=cuda)
+        # the gathered form
+        xa, xb = ta.index_select(0, ids), tb.index_select(0, ids)
+        gxa, gxb, loss0 = torch.zeros_like(xa), torch.zeros_like(xb), torch.zeros((), device=cuda)
+        ar = torch.arange(b, device=cuda)
+        check(lib.rbg_infonce_masked_f32(p(xa), p(xb), b, d, p(ar), b, 0.2, 0.37, p(row_w), p(once), p(loss0), p(gxa), p(gxb), p(work), st))
+        ga0, gb0 = torch.zeros_like(ta).index_add_(0, ids, gxa), torch.zeros_like(tb).index_add_(0, ids, gxb)
+        # the batch form
+        ga1, gb1, loss1 = torch.zeros_like(ta), torch.zeros_like(tb), torch.zeros((), device=cuda)
+        check(lib.rbg_infonce_batch_f32(p(ta), p(tb), d, p(ids), b, 0.2, 0.37, p(row_w), p(once), p(loss1), p(ga1), p(gb1), p(work), st))
+        # value only
+        loss2 = torch.zeros((), device=cuda)
+        check(lib.rbg_infonce_batch_f32(p(ta), p(tb), d, p(ids), b, 0.2, 0.37, p(row_w), p(once), p(loss2), None, None, p(work), st))
+    finally:
+        rbg.set_option("deterministic", old)
+    assert torch.isfinite(loss1) and abs(float(loss1) - float(loss0)) <= 1e-6 * max(1.0, abs(float(loss0)))
+    assert abs(float(loss2) - float(loss0)) <= 1e-6 * max(1.0, abs(float(loss0)))
+    for got, want in ((ga1, ga0), (gb1, gb0)):
+        assert float((got - want).abs().max()) <= 1e-6 * max(1e-6, float(want.abs().max()))
+    assert lib.rbg_infonce_batch_f32(p(ta), p(tb), d, p(ids), b, 0.2, 0.37, p(row_w), p(once), p(loss1), p(ga1), None, p(work), st) != 0
