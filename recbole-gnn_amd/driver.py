@@ -138,8 +138,12 @@ class BPRSampler:
         perm = torch.randperm(self.uid.numel(), generator=self.gen, device=self.device)
         users, items = self.uid[perm], self.iid[perm]
         neg = self._negatives(users)
+        # (r06: the three columns in ONE [3, E] block — a batch's triples are one strided view of it, "_triples", which the captured steps
+        #  copy into their static batch with one launch instead of three)
+        trip = torch.stack([users, items, neg])
         for s in range(0, perm.numel(), self.batch_size):
-            yield {"user_id": users[s:s + self.batch_size], "item_id": items[s:s + self.batch_size], "neg_item_id": neg[s:s + self.batch_size]}
+            e = s + self.batch_size
+            yield {"user_id": trip[0, s:e], "item_id": trip[1, s:e], "neg_item_id": trip[2, s:e], "_triples": trip[:, s:e]}
 
     def __len__(self):
         n = len(self.uid) if self.device is None else self.uid.numel()
@@ -269,7 +273,7 @@ def fit(model, train_uid, train_iid, epochs=1, lr=1e-3, batch_size=2048, seed=20
         if own_total:
             stepper.loss_total.zero_()
         for batch in sampler:
-            batch = {k: v.to(model.device) for k, v in batch.items()}
+            batch = {k: v.to(model.device) for k, v in batch.items() if fused or not k.startswith("_")}  # ("_triples": for the captured steps)
             if own_total:
                 stepper.step(batch)
             elif fused:

@@ -205,7 +205,8 @@ class _FusedStep:
                     self._enqueue(user, pos, neg)
                 torch.cuda.current_stream(dev).wait_stream(side)
                 return self.loss
-            self._static = tuple(t.clone() for t in (user, pos, neg))
+            self._static3 = torch.stack([user, pos, neg])  # ONE [3, B] block: a sampler's "_triples" view is copied in with one launch
+            self._static = tuple(self._static3[i] for i in range(3))
             self._keep = self._handles()  # (a captured graph has their device pointers baked in)
             self._key = key
             self._graph = torch.cuda.CUDAGraph()
@@ -218,8 +219,13 @@ class _FusedStep:
                 self._enqueue(user, pos, neg)
             torch.cuda.current_stream(dev).wait_stream(side)
             return self.loss
-        for dst, src in zip(self._static, (user, pos, neg)):
-            dst.copy_(src)
+        trip = interaction.get("_triples") if isinstance(interaction, dict) else None
+        if (trip is not None and trip.dtype == torch.int64 and trip.device == self._static3.device and trip.shape == self._static3.shape
+                and trip[0].data_ptr() == user.data_ptr()):  # (driver.BPRSampler: the batch's three columns as one strided view)
+            self._static3.copy_(trip)
+        else:
+            for dst, src in zip(self._static, (user, pos, neg)):
+                dst.copy_(src)
         self._graph.replay()
         return self.loss
 
