@@ -185,9 +185,9 @@ class _FusedStep:
         if not self.graphed:
             self._enqueue(user, pos, neg)
             return self.loss
-        # (the option "deterministic" picks kernels and fixed-point slots on the host at launch time: a captured graph has the choice
-        # baked in, so a toggle re-warms and re-captures like new views do — ADVICE r05)
-        key = tuple(id(h) for h in self._handles()) + tuple(self._variant()) + (int(_get_option("deterministic")),)
+        # (the options "deterministic" and "lse_f16" pick kernels (and fixed-point slots) on the host at launch time: a captured graph has
+        # the choice baked in, so a toggle re-warms and re-captures like new views do — ADVICE r05)
+        key = tuple(id(h) for h in self._handles()) + tuple(self._variant()) + (int(_get_option("deterministic")), int(_get_option("lse_f16")))
         if self._graph is not None and key != self._key:
             self._graph, self._calls = None, 1  # new views: their plans exist, one eager step re-warms
         if self._graph is not None and user.shape[0] > self._full:  # (a larger batch than the captured one: capture again for it)
