@@ -522,6 +522,12 @@ int rbg_adam_step_dev_f32(float *user_emb, float *item_emb, int64_t n_users, int
                           float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
                           float eps, void *stream);
 
+/* The same, and the step's finished loss joins a running total in the launch that counts the step (r06: a training driver reads
+ * *loss_total once per epoch instead of adding a device scalar per step; trainer.py's `total_loss += loss.item()` without the sync). */
+int rbg_adam_step_dev_total_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                                float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                                float eps, const float *loss, float *loss_total, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * contrastive (InfoNCE) denominator without the [B, n] matrix
  * ------------------------------------------------------------------------------------------- */

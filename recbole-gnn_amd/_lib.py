@@ -71,6 +71,7 @@ SIGNATURES = {
     "rbg_concat_bpr_begin_f32": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
     "rbg_concat_bpr_scatter_f32": (c_int, [c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_i64, c_f32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rbg_adam_step_dev_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    "rbg_adam_step_dev_total_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     "rbg_lightgcn_step_head_f32": (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp]),
     "rbg_lightgcn_step_tail_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "rbg_adam_step_f32": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),

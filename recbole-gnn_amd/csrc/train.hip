@@ -476,9 +476,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ user_emb,
 // The same update with the step count in DEVICE memory (a HIP-graph replay must not bake the bias corrections in): a one-thread
 // launch increments *step and writes {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)}; the update reads them.  float4 lanes when the user
 // table's float count is a multiple of 4 (d % 4 == 0).
-__global__ void adam_tick_kernel(int64_t *__restrict__ step, float lr, float beta1, float beta2, float *__restrict__ factors) {
+// (r06: loss_total != NULL: the step's finished loss joins a running total here — the driver reads it once per epoch instead of
+//  adding a device scalar per step)
+__global__ void adam_tick_kernel(int64_t *__restrict__ step, float lr, float beta1, float beta2, float *__restrict__ factors,
+                                 const float *__restrict__ loss, float *__restrict__ loss_total) {
     const int64_t t = *step + 1;
     *step = t;
+    if (loss_total) *loss_total += *loss;
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     factors[0] = (float)((double)lr / bc1);
     factors[1] = (float)(1.0 / sqrt(bc2));
@@ -858,16 +862,38 @@ int rbg_adam_step_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t
     return RBG_OK;
 }
 
+static int adam_step_dev(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                         float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                         float eps, const float *loss, float *loss_total, void *stream);
+
 int rbg_adam_step_dev_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
                           float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
                           float eps, void *stream) {
+    return adam_step_dev(user_emb, item_emb, n_users, n_items, d, grad, exp_avg, exp_avg_sq, step, factors, lr, beta1, beta2, eps, nullptr,
+                         nullptr, stream);
+}
+
+int rbg_adam_step_dev_total_f32(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                                float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                                float eps, const float *loss, float *loss_total, void *stream) {
+    if (!loss || !loss_total) {
+        clear_error();
+        return fail(RBG_EINVAL, "NULL pointer");
+    }
+    return adam_step_dev(user_emb, item_emb, n_users, n_items, d, grad, exp_avg, exp_avg_sq, step, factors, lr, beta1, beta2, eps, loss,
+                         loss_total, stream);
+}
+
+static int adam_step_dev(float *user_emb, float *item_emb, int64_t n_users, int64_t n_items, int d, const float *grad,
+                         float *exp_avg, float *exp_avg_sq, int64_t *step, float *factors, float lr, float beta1, float beta2,
+                         float eps, const float *loss, float *loss_total, void *stream) {
     clear_error();
     if (n_users < 0 || n_items < 0 || d <= 0) return fail(RBG_ESHAPE, "bad shape");
     if (d % 4) return fail(RBG_EUNSUPPORTED, "rbg_adam_step_dev_f32: d = %d is not a multiple of 4", d);
     if (!step || !factors) return fail(RBG_EINVAL, "NULL pointer");
     const int64_t nd = (n_users + n_items) * d;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, lr, beta1, beta2, factors);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, s, step, lr, beta1, beta2, factors, loss, loss_total);
     RBG_HIP(hipGetLastError());
     if (nd == 0) return RBG_OK;
     if (!grad || !exp_avg || !exp_avg_sq || (n_users && !user_emb) || (n_items && !item_emb)) return fail(RBG_EINVAL, "NULL pointer");

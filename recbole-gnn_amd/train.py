@@ -138,14 +138,25 @@ class _TableAdam:
         self.exp_avg, self.exp_avg_sq = torch.zeros((n, d), **f), torch.zeros((n, d), **f)
         self.step_dev = torch.zeros((), dtype=torch.int64, device=uw.device)
         self.factors = torch.zeros(2, **f)
+        self.loss_total = torch.zeros((), **f)  # r06: the running sum of the steps' losses (``step(grad, loss)``); a driver reads it per epoch
 
-    def step(self, grad):
+    def step(self, grad, loss=None):
+        """``loss``: the step's finished loss (device scalar) — it joins ``loss_total`` in the launch that counts the step
+        (rbg_adam_step_dev_total_f32): no add launch per step in the driver."""
         m = self.model
         uw, iw = m.user_embedding.weight.data, m.item_embedding.weight.data
+        st = c_vp(torch.cuda.current_stream(uw.device).cuda_stream)
+        if loss is not None and uw.shape[1] % 4 == 0:
+            check(lib.rbg_adam_step_dev_total_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, uw.shape[1],
+                                                  c_vp(grad.data_ptr()), c_vp(self.exp_avg.data_ptr()), c_vp(self.exp_avg_sq.data_ptr()),
+                                                  c_vp(self.step_dev.data_ptr()), c_vp(self.factors.data_ptr()), self.lr, self.betas[0],
+                                                  self.betas[1], self.eps, c_vp(loss.data_ptr()), c_vp(self.loss_total.data_ptr()), st))
+            return
         check(lib.rbg_adam_step_dev_f32(c_vp(uw.data_ptr()), c_vp(iw.data_ptr()), m.n_users, m.n_items, uw.shape[1], c_vp(grad.data_ptr()),
                                         c_vp(self.exp_avg.data_ptr()), c_vp(self.exp_avg_sq.data_ptr()), c_vp(self.step_dev.data_ptr()),
-                                        c_vp(self.factors.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps,
-                                        c_vp(torch.cuda.current_stream(uw.device).cuda_stream)))
+                                        c_vp(self.factors.data_ptr()), self.lr, self.betas[0], self.betas[1], self.eps, st))
+        if loss is not None:
+            self.loss_total += loss
 
 
 class _FusedStep:
@@ -281,6 +292,7 @@ class FusedNGCFAdam(_FusedStep):
         # the two tables (all but 25 k of the 4.6 M parameters at the Gowalla shape): one library launch on the ego gradient;
         # the layers' weights and biases: torch's fused Adam, one multi-tensor launch
         self.table_opt = _TableAdam(model, lr, betas, eps)
+        self.loss_total = self.table_opt.loss_total  # (driver.fit reads it once per epoch)
         self.opt = torch.optim.Adam([p for gnn in model.GNNlayers for p in gnn.parameters()], lr=lr, betas=betas, eps=eps,
                                     capturable=True, fused=True)
 
@@ -329,7 +341,7 @@ class FusedNGCFAdam(_FusedStep):
                                                  c_vp(self.g[t - 1].data_ptr()), c_vp(gnn.lin1.weight.grad.data_ptr()),
                                                  c_vp(gnn.lin2.weight.grad.data_ptr()), c_vp(self.gb[t - 1].data_ptr()),
                                                  c_vp(self.work.data_ptr()), st))
-            self.table_opt.step(self.g[0])
+            self.table_opt.step(self.g[0], self.loss)
             self.opt.step()
 
 
@@ -363,6 +375,7 @@ class FusedSGLAdam(_FusedStep):
         if len(list(model.parameters())) != 2:
             raise TypeError("FusedSGLAdam updates the two embedding tables; this model has other parameters")
         self.table_opt = _TableAdam(model, lr, betas, eps)
+        self.loss_total = self.table_opt.loss_total  # (driver.fit reads it once per epoch)
         model.user_embedding.weight.grad = self.ge[0][:nu]  # (for inspection; the tables are updated from ge[0] directly)
         model.item_embedding.weight.grad = self.ge[0][nu:]
 
@@ -412,7 +425,7 @@ class FusedSGLAdam(_FusedStep):
             self.ge[0].add_(self.ge[1]).add_(self.ge[2])
             check(lib.rbg_emb_reg_grad_nopow_f32(ptr(uw), ptr(iw), nu, ptr(user), ptr(pos), ptr(neg), b, d, float(m.reg_weight),
                                                  ptr(self.ge[0]), ptr(self.loss), ptr(self.reg_ws), st))
-            self.table_opt.step(self.ge[0])
+            self.table_opt.step(self.ge[0], self.loss)
 
 
 class _FusedContrastStep(_FusedStep):
@@ -445,6 +458,7 @@ class _FusedContrastStep(_FusedStep):
         self._scratch = {}
         self._once = {}
         self.table_opt = _TableAdam(model, lr, betas, eps)
+        self.loss_total = self.table_opt.loss_total  # (driver.fit reads it once per epoch)
         model.user_embedding.weight.grad = self.ge[:nu]  # (for inspection; the tables are updated from ge directly)
         model.item_embedding.weight.grad = self.ge[nu:]
         return n, d, k, f
@@ -507,7 +521,7 @@ class _FusedContrastStep(_FusedStep):
         else:
             check(lib.rbg_emb_reg_grad_nopow_f32(p(uw), p(iw), m.n_users, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge),
                                                  p(self.loss), p(self.reg_ws), st))
-        self.table_opt.step(self.ge)
+        self.table_opt.step(self.ge, self.loss)
 
 
 class FusedSimGCLAdam(_FusedContrastStep):
@@ -638,6 +652,7 @@ class FusedNCLAdam(_FusedStep):
         self.loss, self.reg_ws = torch.zeros((), **f), torch.zeros(3, **f)
         self._scratch = {}
         self.table_opt = _TableAdam(model, lr, betas, eps)
+        self.loss_total = self.table_opt.loss_total  # (driver.fit reads it once per epoch)
         model.user_embedding.weight.grad = self.ge[:nu]
         model.item_embedding.weight.grad = self.ge[nu:]
 
@@ -712,7 +727,7 @@ class FusedNCLAdam(_FusedStep):
             check(lib.rbg_spmm_add_f32(gt, p(cur), p(self.g0), p(self.ge), d, st))
             check(lib.rbg_emb_reg_grad_nopow_f32(p(uw), p(iw), nu, p(user), p(pos), p(neg), b, d, float(m.reg_weight), p(self.ge), p(self.loss),
                                                  p(self.reg_ws), st))
-            self.table_opt.step(self.ge)
+            self.table_opt.step(self.ge, self.loss)
 
 
 
