@@ -358,6 +358,45 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
                 ex["full_sort_topk_exact_passes_us"] = time_us(lambda: model.full_sort_topk({"user_id": users}, 10), iters=10, warm=2)
             finally:
                 rbg.set_option("topk_screen", 1)
+    # r06: one InfoNCE half (sgl.py:191-199: 2048 batch rows against all item rows, value + both table gradients, one C call) — the fp16
+    # two-term form of the gradient launches (option lse_f16) and the bf16 three-term form beside it
+    try:
+        import ctypes as _ct
+        from recbole_gnn_amd._lib import lib as _lib_c, check as _check, c_vp as _vp, c_i64 as _i64
+        nb_, tau_ = 2048, 0.2
+        gen_n = torch.Generator(device=dev).manual_seed(3)
+        t1n = torch.randn(ni, d, device=dev, generator=gen_n) * 0.1
+        t2n = 0.5 * t1n + torch.randn(ni, d, device=dev, generator=gen_n) * 0.1
+        idxn = torch.randint(1, ni, (nb_,), device=dev, generator=gen_n)
+        g1n, g2n, lossn = torch.zeros_like(t1n), torch.zeros_like(t2n), torch.zeros((), device=dev)
+        nbytes = _i64()
+        _check(_lib_c.rbg_infonce_workspace(nb_, ni, d, _ct.byref(nbytes)))
+        wsn = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=dev)
+        st_ = _vp(torch.cuda.current_stream(dev).cuda_stream)
+
+        def nce_call():
+            _check(_lib_c.rbg_infonce_f32(_vp(t1n.data_ptr()), _vp(t2n.data_ptr()), ni, d, _vp(idxn.data_ptr()), nb_, tau_, 1.0,
+                                          _vp(lossn.data_ptr()), _vp(g1n.data_ptr()), _vp(g2n.data_ptr()), _vp(wsn.data_ptr()), st_))
+
+        mode0 = int(rbg.get_option("lse_f16"))
+        nce_us = time_us(nce_call, iters=20, warm=3)
+        ex[f"infonce_us({nb_} x {ni} x {d}, value + both gradients)"] = nce_us
+        rbg.set_option("lse_f16", 0)
+        try:
+            ex["infonce_bf16_three_term_form_us"] = time_us(nce_call, iters=20, warm=3)
+        finally:
+            rbg.set_option("lse_f16", mode0)
+        terms = 3 if mode0 and d % 4 == 0 else 6
+        nce_flop = 4 * 2.0 * nb_ * ni * d * terms  # four [B, n] x d products (scores twice, dA, dC), each `terms` matrix-core products
+        ex["infonce_roofline"] = {"bound": "mfma", "flop": nce_flop, "achieved": nce_flop / (nce_us * 1e-6) / 1e12, "peak": 2500.0,
+                                  "unit": "TFLOP/s", "frac": nce_flop / (nce_us * 1e-6) / 1e12 / 2500.0, "terms_per_product": terms,
+                                  "note": "matrix-core flops of the call (4 products of 2 B n d, each as 3 fp16 products on two-term operands — "
+                                          "6 bf16 products in the three-term form) against the dense 16-bit MFMA peak; the call is 8 launches, "
+                                          "the two lse_tile_kernel launches are ~ 70 % of it (matrix pipe busy 41 % / 34 % in them: "
+                                          "profiles/r06_lse_f16_pmc.json)"}
+        del t1n, t2n, g1n, g2n, wsn
+    except Exception as e:  # noqa: BLE001  (an extra: never fail the line)
+        ex["infonce_us"] = f"not measured: {type(e).__name__}: {e}"
     fused = rbg.FusedBPRAdam(model, lr=1e-3)
     ex["train_step_fused_us(batch 2048, fwd + BPR + bwd + Adam)"] = time_us(lambda: fused.step(batch))
     rbg.set_option("deterministic", 1)  # the same step with ordered row scatters and fixed-point sums (bit-stable; csrc/ordered.h)
