@@ -15,6 +15,8 @@ from ._lib import c_vp, check, lib
 from .graph import get_option as _get_option
 from .models import LightGCN
 
+_CONCURRENT_HALVES = __import__("os").environ.get("RBG_CONCURRENT_HALVES", "1") != "0"  # (A/B switch of _FusedStep._two_halves)
+
 
 def fused_step_applies(model):
     """True when the model's training objective is exactly lightgcn.py:83-110 (what the fused step implements)."""
@@ -176,6 +178,18 @@ class _FusedStep:
     def _variant(self):
         """What else a captured step has baked in (NCL: whether the prototype term is part of the loss)."""
         return ()
+
+    def _two_halves(self, dev, first, second):
+        """The two InfoNCE halves of a step (users / items: disjoint row ranges of every table they touch, their own workspaces and
+        loss words) on two streams (r06): each half is eight dependent launches of which six are latency-bound row kernels — issued
+        side by side, one half's small kernels run in the shadow of the other's matrix-core launches.  ``first`` runs on the
+        current stream, ``second`` on a side stream forked from it; joined before returning.  Sequential in "deterministic" mode
+        (its fixed-point slots are per stream) and when ``self.concurrent_halves`` is False."""
+        if not getattr(self, "concurrent_halves", _CONCURRENT_HALVES) or _get_option("deterministic"):
+            first()
+            second()
+            return
+        ops._fork_join([first, second], dev)
 
     def _side_stream(self, dev):
         """ONE side stream per stepper for the eager steps beside a captured graph (warm-up, an epoch's short last batch) — a fresh
@@ -400,8 +414,9 @@ class FusedSGLAdam(_FusedStep):
             for rows in (nu, ni):
                 check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
                 need = max(need, nbytes.value)
-            self._scratch[b] = (torch.empty(b, dtype=torch.float32, device=dev), torch.empty(need, dtype=torch.uint8, device=dev))
-        self.coef, self.nce_work = self._scratch[b]
+            self._scratch[b] = (torch.empty(b, dtype=torch.float32, device=dev), torch.empty(need, dtype=torch.uint8, device=dev),
+                                torch.empty(need, dtype=torch.uint8, device=dev), torch.zeros((), dtype=torch.float32, device=dev))
+        self.coef, self.nce_work, nce_work2, loss2 = self._scratch[b]
         st = c_vp(torch.cuda.current_stream(dev).cuda_stream)
         ptr = lambda t, row=0: c_vp(t.data_ptr() + 4 * row * d)  # noqa: E731  (rows [row, ...) of a contiguous [*, d] table)
         with torch.cuda.device(dev):
@@ -414,10 +429,19 @@ class FusedSGLAdam(_FusedStep):
             check(lib.rbg_concat_bpr_scatter_f32(ptr(self.mean[0]), d, nu, ptr(user), ptr(pos), ptr(neg), b, 0.0, 0, ptr(self.coef),
                                                  ptr(self.sums), ptr(self.gm[0]), None, st))
             # sgl.py:176-209: users, then items, between the two views
-            for row0, rows, idx in ((0, nu, user), (nu, ni, pos)):
-                check(lib.rbg_infonce_f32(ptr(self.mean[1], row0), ptr(self.mean[2], row0), rows, d, ptr(idx), b, float(m.ssl_tau),
-                                          float(m.ssl_weight), ptr(self.loss), ptr(self.gm[1], row0), ptr(self.gm[2], row0),
-                                          ptr(self.nce_work), st))
+            def half(row0, rows, idx, loss, work):
+                def run():  # (the stream is looked up when it runs: the second half is issued on a side stream)
+                    check(lib.rbg_infonce_f32(ptr(self.mean[1], row0), ptr(self.mean[2], row0), rows, d, ptr(idx), b, float(m.ssl_tau),
+                                              float(m.ssl_weight), ptr(loss), ptr(self.gm[1], row0), ptr(self.gm[2], row0), ptr(work),
+                                              c_vp(torch.cuda.current_stream(dev).cuda_stream)))
+                return run
+
+            def users_half():
+                loss2.zero_()
+                half(0, nu, user, loss2, nce_work2)()
+
+            self._two_halves(dev, half(nu, ni, pos, self.loss, self.nce_work), users_half)
+            self.loss.add_(loss2)
             for v in range(3):
                 ts = [g.transpose() for g in views[v]]
                 arr = (c_vp * len(ts))(*[g.ptr for g in ts])
@@ -671,8 +695,9 @@ class FusedNCLAdam(_FusedStep):
             for rows in (nu, ni):
                 check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
                 need = max(need, nbytes.value)
-            self._scratch[b] = torch.empty(need, dtype=torch.uint8, device=dev)
-        work = self._scratch[b]
+            self._scratch[b] = (torch.empty(need, dtype=torch.uint8, device=dev), torch.empty(need, dtype=torch.uint8, device=dev),
+                                torch.zeros((), dtype=torch.float32, device=dev))
+        work, work2, loss2 = self._scratch[b]
         with torch.cuda.device(dev):
             torch.cat([uw, iw], dim=0, out=self.e0)
             # ncl.py:93-104: E_1 .. E_L row-major; the mean over E_0 .. E_K (the chain's own mean when K = L)
@@ -687,9 +712,18 @@ class FusedNCLAdam(_FusedStep):
             # ncl.py:137-165: the context layer E_(2 h) against the center E_0, users then items (x alpha)
             ctx = self.lay[2 * m.hyper_layers - 1]
             self._gz.zero_()  # gctx, g0
-            for row0, rows, idx, wgt in ((0, nu, user, m.ssl_reg), (nu, ni, pos, m.ssl_reg * m.alpha)):
-                check(lib.rbg_infonce_f32(p(ctx, row0), p(self.e0, row0), rows, d, p(idx), b, float(m.ssl_temp), float(wgt), p(self.loss),
-                                          p(self.gctx, row0), p(self.g0, row0), p(work), st))
+            def half(row0, rows, idx, wgt, loss, ws):
+                def run():  # (the stream is looked up when it runs: the second half is issued on a side stream)
+                    check(lib.rbg_infonce_f32(p(ctx, row0), p(self.e0, row0), rows, d, p(idx), b, float(m.ssl_temp), float(wgt), p(loss),
+                                              p(self.gctx, row0), p(self.g0, row0), p(ws), c_vp(torch.cuda.current_stream(dev).cuda_stream)))
+                return run
+
+            def users_half():
+                loss2.zero_()
+                half(0, nu, user, m.ssl_reg, loss2, work2)()
+
+            self._two_halves(dev, half(nu, ni, pos, m.ssl_reg * m.alpha, self.loss, work), users_half)
+            self.loss.add_(loss2)
             if self.with_proto:  # ncl.py:106-135 on the batch's rows of E_0: the model's formula, differentiated by torch
                 with torch.enable_grad():
                     leaf = self.e0.detach().requires_grad_(True)
