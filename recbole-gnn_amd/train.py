@@ -509,19 +509,38 @@ class _FusedContrastStep(_FusedStep):
                 check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(self.noise), x.shape[1], float(m.eps), st))
             x = layers[i]
 
-    def _contrast(self, ta, tb, ga, gb, ids, row0, rows, b, mean_form):
+    def _contrast_scratch(self, b, d):
+        """Two workspaces and a second loss word per batch size: the step's two contrasts run on two streams (_two_halves)."""
+        if b not in self._scratch:
+            m, nbytes = self.model, _lib.c_i64()
+            check(lib.rbg_infonce_workspace(b, b, d, _lib.ctypes.byref(nbytes)))
+            self._scratch[b] = (torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device),
+                                torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device),
+                                torch.zeros((), dtype=torch.float32, device=m.device))
+        return self._scratch[b]
+
+    def _contrasts(self, ta, tb, ga, gb, user, pos, b, mean_form):
+        """The step's two contrasts — the users' rows and the positive items' rows (disjoint row ranges of every table) — side by
+        side on two streams (r06): each is ten launches of which eight are latency-bound; their losses meet in self.loss."""
+        m = self.model
+        nu, ni = m.n_users, m.n_items
+        work, work2, loss2 = self._contrast_scratch(b, ta.shape[1])
+
+        def users():
+            loss2.zero_()
+            self._contrast(ta, tb, ga, gb, user, 0, nu, b, mean_form, loss2, work2)
+
+        self._two_halves(m.device, lambda: self._contrast(ta, tb, ga, gb, pos, nu, ni, b, mean_form, self.loss, work), users)
+        self.loss.add_(loss2)
+
+    def _contrast(self, ta, tb, ga, gb, ids, row0, rows, b, mean_form, loss, work):
         """cl_rate x InfoNCE between rows `ids` of tables ta and tb (rows [row0, row0 + rows) of the [N, d] buffers): the value is
-        added to self.loss, the gradients w.r.t. the two tables' rows are scattered onto ga / gb (either may be the same buffer)."""
+        added to `loss`, the gradients w.r.t. the two tables' rows are scattered onto ga / gb (either may be the same buffer)."""
         m = self.model
         d = ta.shape[1]
         st = c_vp(torch.cuda.current_stream(m.device).cuda_stream)
-        if b not in self._scratch:
-            nbytes = _lib.c_i64()
-            check(lib.rbg_infonce_workspace(b, b, d, _lib.ctypes.byref(nbytes)))
-            self._scratch[b] = (torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=m.device), torch.arange(b, device=m.device))
-        work, ar = self._scratch[b]
         # r06: the mask and the row weights in ONE launch (rbg_once_mask_f32) instead of scatter / gather / compare / cast (/ sum / divide)
-        key = (b, int(rows))
+        key = (b, int(rows), int(row0))  # (the users' and the items' contrast run side by side: their own buffers even when n_users = n_items)
         if key not in self._once:
             self._once[key] = (torch.empty(int(rows), dtype=torch.int64, device=m.device),
                                torch.empty(b, dtype=torch.float32, device=m.device), torch.empty(b, dtype=torch.float32, device=m.device))
@@ -532,7 +551,7 @@ class _FusedContrastStep(_FusedStep):
         # gradient blocks, no index_add_: the row kernels gather, the backward kernels scatter (rows of a repeated id carry zero
         # weight but one: the float atomics add zeros — the sums do not depend on the order)
         check(lib.rbg_infonce_batch_f32(self._ptr(ta[row0:row0 + rows]), self._ptr(tb[row0:row0 + rows]), d, self._ptr(ids), b,
-                                        float(m.temperature), float(m.cl_rate), self._ptr(row_w), self._ptr(once), self._ptr(self.loss),
+                                        float(m.temperature), float(m.cl_rate), self._ptr(row_w), self._ptr(once), self._ptr(loss),
                                         self._ptr(ga[row0:row0 + rows]), self._ptr(gb[row0:row0 + rows]), self._ptr(work), st))
 
     def _reg_and_adam(self, user, pos, neg, b, d):
@@ -579,8 +598,7 @@ class FusedSimGCLAdam(_FusedContrastStep):
             check(lib.rbg_bpr_grad_f32(p(self.mean[0]), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
             self.g12.zero_()
             # (the gradients w.r.t. the two perturbed means go through the same linear chain: they are added into ONE buffer)
-            self._contrast(self.mean[1], self.mean[2], self.g12, self.g12, user, 0, nu, b, False)
-            self._contrast(self.mean[1], self.mean[2], self.g12, self.g12, pos, nu, ni, b, False)
+            self._contrasts(self.mean[1], self.mean[2], self.g12, self.g12, user, pos, b, False)
             self.gm.add_(self.g12)
             # out = (A + A^2 + .. + A^K) E0 / K for every pass  =>  dE0 = A (g + A g + .. + A^(K-1) g) / K
             if k > 1:
@@ -620,8 +638,7 @@ class FusedXSimGCLAdam(_FusedContrastStep):
             cl = self.lay[lc - 1] if lc else self.e0
             check(lib.rbg_bpr_grad_f32(p(self.mean), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
             self.gcl.zero_()
-            self._contrast(self.mean, cl, self.gm, self.gcl, user, 0, nu, b, True)
-            self._contrast(self.mean, cl, self.gm, self.gcl, pos, nu, ni, b, True)
+            self._contrasts(self.mean, cl, self.gm, self.gcl, user, pos, b, True)
             # mean = (E_1 + .. + E_K) / K, E_j = A E_(j-1) (+ noise, no gradient): dE0 = A (g_1 + A (g_2 + .. A g_K)), g_j = gm / K
             # (+ gcl at j = layer_cl); Horner from the top layer down
             gt = m.graph.transpose().ptr
