@@ -475,6 +475,7 @@ class _FusedContrastStep(_FusedStep):
         f = dict(dtype=torch.float32, device=dev)
         self.e0 = torch.empty((n, d), **f)
         self.noise = torch.empty((n, d), **f)
+        self._noises = []
         self.gm = torch.empty((n, d), **f)     # dLoss / d(mean of the pass the BPR term reads); ends as the chain's input
         self.ge = torch.empty((n, d), **f)     # dLoss / dE0
         self.t0, self.t1, self.work = torch.empty((n, d), **f), torch.empty((n, d), **f), torch.empty((n, d), **f)
@@ -495,18 +496,42 @@ class _FusedContrastStep(_FusedStep):
         srcs = (c_vp * k)(*[layers[i].data_ptr() for i in range(k)])
         check(lib.rbg_mean_f32(srcs, k, out.numel(), 1.0 / k, self._ptr(out), c_vp(torch.cuda.current_stream(out.device).cuda_stream)))
 
-    def _perturbed_pass(self, layers, k, first_product=None):
+    def _noise_buffers(self, count):
+        """``count`` [N, d] noise tables (r06): a step's draws are issued up front — in the reference's order, on a side stream — and
+        run beside the propagations instead of between them (11 us of a launch that leaves most of the GPU idle, per layer and pass)."""
+        while len(self._noises) < count:
+            self._noises.append(torch.empty_like(self.noise))
+        return self._noises[:count]
+
+    def _draw_noise(self, dev, noises, beside):
+        """uniform_ (= torch.rand_like: the same draws in the same order as SimGCL._layers) into every table of ``noises`` on a side
+        stream while ``beside()`` issues launches on the current one; joined before returning."""
+        def draw():
+            for t in noises:
+                t.uniform_()
+        if not noises:
+            beside()
+        elif not getattr(self, "concurrent_halves", _CONCURRENT_HALVES):
+            draw()
+            beside()
+        else:
+            ops._fork_join([beside, draw], dev)
+
+    def _perturbed_pass(self, layers, k, first_product=None, noises=None):
         """``first_product``: A E_0 where a plain pass has formed it already (r06: SimGCL's three passes start with the same
-        product) — the first perturbed layer is then the noise epilogue alone (rbg_sign_noise_f32), one propagation less."""
+        product) — the first perturbed layer is then the noise epilogue alone (rbg_sign_noise_f32), one propagation less.
+        ``noises``: the pass's k noise tables, drawn already (``_draw_noise``); None draws each layer's in place."""
         m, st = self.model, c_vp(torch.cuda.current_stream(self.model.device).cuda_stream)
         x = self.e0
         for i in range(k):
-            self.noise.uniform_()  # (= torch.rand_like: the same draws in the same order as SimGCL._layers)
+            if noises is None:
+                self.noise.uniform_()  # (= torch.rand_like: the same draws in the same order as SimGCL._layers)
+            nz = self.noise if noises is None else noises[i]
             if i == 0 and first_product is not None:
-                check(lib.rbg_sign_noise_f32(self._ptr(first_product), self._ptr(self.noise), x.shape[0], x.shape[1], float(m.eps),
+                check(lib.rbg_sign_noise_f32(self._ptr(first_product), self._ptr(nz), x.shape[0], x.shape[1], float(m.eps),
                                              self._ptr(layers[0]), st))
             else:
-                check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(self.noise), x.shape[1], float(m.eps), st))
+                check(lib.rbg_spmm_noise_f32(m.graph.ptr, self._ptr(x), self._ptr(layers[i]), self._ptr(nz), x.shape[1], float(m.eps), st))
             x = layers[i]
 
     def _contrast_scratch(self, b, d):
@@ -589,10 +614,15 @@ class FusedSimGCLAdam(_FusedContrastStep):
         with torch.cuda.device(dev):
             torch.cat([uw, iw], dim=0, out=self.e0)
             # simgcl.py:25-36 without noise: E_1 .. E_K row-major, their mean (no E_0)
-            ops.lightgcn_forward_raw(m.graph, uw, iw, k, keep_layers=True, out=self.work, layers=self.lay[0])
-            self._mean_of(self.lay[0], k, self.mean[0])
+            noises = self._noise_buffers(2 * k)  # (pass 1's k draws, then pass 2's: the reference's order)
+
+            def plain():
+                ops.lightgcn_forward_raw(m.graph, uw, iw, k, keep_layers=True, out=self.work, layers=self.lay[0])
+                self._mean_of(self.lay[0], k, self.mean[0])
+
+            self._draw_noise(dev, noises, plain)  # the 2 k draws run beside the plain pass
             for v in (1, 2):
-                self._perturbed_pass(self.lay[v], k, first_product=self.lay[0][0])  # (the three passes share A E_0)
+                self._perturbed_pass(self.lay[v], k, first_product=self.lay[0][0], noises=noises[(v - 1) * k:v * k])  # (the three passes share A E_0)
                 self._mean_of(self.lay[v], k, self.mean[v])
             # lightgcn.py:93-100 on the plain pass (zeroes gm and the loss), then the contrasts between the perturbed passes
             check(lib.rbg_bpr_grad_f32(p(self.mean[0]), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
@@ -633,7 +663,18 @@ class FusedXSimGCLAdam(_FusedContrastStep):
         lc = m.layer_cl if 1 <= m.layer_cl <= k else 0  # 0: the contrast's second view is E_0 itself (xsimgcl.py:29, 39-41)
         with torch.cuda.device(dev):
             torch.cat([uw, iw], dim=0, out=self.e0)
-            self._perturbed_pass(self.lay, k)
+            noises = self._noise_buffers(k)
+            noises[0].uniform_()  # (the first layer needs its draw at once; the others' run beside its propagation)
+
+            def first_layer():
+                check(lib.rbg_spmm_noise_f32(m.graph.ptr, p(self.e0), p(self.lay[0]), p(noises[0]), d, float(m.eps),
+                                             c_vp(torch.cuda.current_stream(dev).cuda_stream)))
+
+            self._draw_noise(dev, noises[1:], first_layer)
+            x = self.lay[0]
+            for i in range(1, k):
+                check(lib.rbg_spmm_noise_f32(m.graph.ptr, p(x), p(self.lay[i]), p(noises[i]), d, float(m.eps), st))
+                x = self.lay[i]
             self._mean_of(self.lay, k, self.mean)
             cl = self.lay[lc - 1] if lc else self.e0
             check(lib.rbg_bpr_grad_f32(p(self.mean), nu, ni, p(user), p(pos), p(neg), b, d, p(self.gm), p(self.loss), st))
