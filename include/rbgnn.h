@@ -567,6 +567,15 @@ int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, c
                            const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
                            void *stream);
 
+/* InfoNCE of rows of one table against ALL rows of another, the positive of a row given by a map (r06; NCL's prototype contrast,
+ * ncl.py:106-135: the batch's rows of E_0 against the k centroids, the positive = the row's cluster):
+ *   a = normalize(T1[idx]);  c = normalize(T2)  (T2 [n2, d]; already-unit rows stay what they are to rounding)
+ *   *loss += weight * sum_b ( log sum_j exp(<a_b, c_j> / tau)  -  <a_b, c_(pos_map[idx[b]])> / tau )
+ *   grad_T1[idx[b]] += d/da_b ...  (float atomics; NULL = value only);  grad_T2 [n2, d] += ... or NULL (constant prototypes: the table
+ *   pass is skipped).  pos_map: int64 per row of T1's table, values in [0, n2).  `workspace`: rbg_infonce_workspace(B, n2, d). */
+int rbg_infonce_map_f32(const float *T1, const float *T2, int64_t n2, int d, const int64_t *idx, const int64_t *pos_map, int64_t B, float tau,
+                        float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream);
+
 /* The same contrast AMONG THE ROWS OF A BATCH, straight on the tables (r06): with a = normalize(TA[ids]), c = normalize(TB[ids])
  *   *loss += weight * sum_b row_w[b] * ( log sum_j col_w[j] exp(<a_b, c_j> / tau) - <a_b, c_b> / tau )      b, j = positions 0..B-1
  *   grad_TA[ids[b]] += d/da_b ...,  grad_TB[ids[j]] += d/dc_j ...   (float atomics: ids repeat; both tables or none)

@@ -108,6 +108,7 @@ SIGNATURES = {
     "rbg_infonce_workspace": (c_int, [c_i64, c_i64, c_int, P(c_i64)]),
     "rbg_infonce_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rbg_infonce_masked_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rbg_infonce_map_f32": (c_int, [c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rbg_infonce_batch_f32": (c_int, [c_vp, c_vp, c_int, c_vp, c_i64, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rbg_lse_rows_workspace": (c_int, [c_i64, c_i64, c_int, P(c_i64)]),
     "rbg_lse_rows_f32": (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_int, c_f32, c_f32, c_vp, c_vp, c_vp]),

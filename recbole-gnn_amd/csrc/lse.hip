@@ -896,11 +896,11 @@ __global__ __launch_bounds__(256) void nce_norm_table_kernel(const float *__rest
 }
 
 // A[b] = normalize(T1[idx[b]]), inv1[b], pos[b] = <A[b], C[idx[b]]>.  One wave per batch row.  c_by_pos (the batch form): the
-// candidate table IS the batch, its row of position b is C[b].
+// candidate table IS the batch, its row of position b is C[b].  pos_map (rbg_infonce_map_f32): the positive of row r is C[pos_map[r]].
 __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__restrict__ T1, const float *__restrict__ C,
                                                              const int64_t *__restrict__ idx, int64_t B, int d,
                                                              float *__restrict__ A, float *__restrict__ inv1, float *__restrict__ pos,
-                                                             char *__restrict__ img16, int c_by_pos) {
+                                                             char *__restrict__ img16, int c_by_pos, const int64_t *__restrict__ pos_map) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (b >= B) {
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(256) void nce_batch_prep_kernel(const float *__rest
     for (int c = lane; c < d; c += 64) {
         const float a = row[c] * iv;
         A[b * d + c] = a;
-        dot = fmaf(a, C[(c_by_pos ? b : r) * d + c], dot);
+        dot = fmaf(a, C[(pos_map ? pos_map[r] : (c_by_pos ? b : r)) * d + c], dot);
     }
     dot = wave_sum(dot);
     if (lane == 0) {
@@ -1050,13 +1050,14 @@ struct NceBackPartsArgs {
     float ws;
     float *dC, *grad_T1;
     int c_by_pos;  // the batch form: C and dC are indexed by the position b, grad_T1 by idx[b]
+    const int64_t *pos_map;  // rbg_infonce_map_f32: C and dC are indexed by pos_map[idx[b]]
 };
 
 template <bool ORDERED>
 __device__ __forceinline__ void nce_batch_back_parts_elem(const NceBackPartsArgs &a, int64_t b, int lane) {
     const int d = a.d;
     const int64_t B = a.B;
-    const int64_t r = a.idx[b], rc = a.c_by_pos ? b : r;
+    const int64_t r = a.idx[b], rc = a.pos_map ? a.pos_map[r] : (a.c_by_pos ? b : r);
     const float cb = a.coef[b];
     const float ws = a.row_w ? a.ws * a.row_w[b] : a.ws;  // the positive term carries the row's weight too
     float g0 = 0.f, g1 = 0.f;  // d <= 128: columns lane and lane + 64
@@ -1165,7 +1166,7 @@ static NceLayout nce_layout(int64_t B, int64_t n, int d) {
 static int infonce_onepass(const float *A, const float *C, const float *inv1, const float *inv2, const float *pos, float *term, float *dC,
                            const int64_t *idx, const float *row_w, const float *col_w, int64_t n, int d, int64_t B, float scale, float weight,
                            float *loss, float *grad_T1, float *grad_T2, void *lse_ws, hipStream_t s, char *imgC = nullptr, char *imgA = nullptr,
-                           int f16_mode = 0, const int64_t *batch_ids = nullptr) {
+                           int f16_mode = 0, const int64_t *batch_ids = nullptr, const int64_t *pos_map = nullptr) {
     const bool vec = lse_vec(A, d, C, d, d);
     // r06, the fp16 form: unit rows and weights in [0, 1] — the plain InfoNCE only (row / candidate weights are the caller's numbers);
     // f16_mode 1: imgC / imgA hold the fp16 plane images the row kernels wrote
@@ -1212,7 +1213,9 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     hipLaunchKernelGGL(nce_sum_kernel, dim3(1), dim3(256), 0, s, term, B, weight, loss);
     RBG_HIP(hipGetLastError());
     if (!grad_T1 && !grad_T2) return RBG_OK;  // (value only; the masked form has no other forward)
-    // pass 2 (own = the table rows): needs the finished denominators (coef)
+    // pass 2 (own = the table rows): needs the finished denominators (coef); only for the table's gradient (r06: rbg_infonce_map_f32
+    // against constant prototypes asks for the batch rows' alone — its positive term still lands in part_c, a scratch nobody reads)
+    if (grad_T2) {
     p.own = C, p.n_own = n;
     p.oth = A, p.n_oth = B;
     p.oth_image = (img || (f16_mode & 1)) ? imgA : nullptr;
@@ -1228,9 +1231,10 @@ static int infonce_onepass(const float *A, const float *C, const float *inv1, co
     }
     lse_launch_d<true>(p, vec, s);
     RBG_HIP(hipGetLastError());
+    }
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
     {
-        const NceBackPartsArgs ba{part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale, part_c, grad_T1, batch_ids ? 1 : 0};
+        const NceBackPartsArgs ba{part_q, L.nc_q, coef, A, C, inv1, idx, row_w, B, d, weight * scale, part_c, grad_T1, batch_ids ? 1 : 0, pos_map};
         if (opt_deterministic()) launch_ordered_scatter(NceBackPartsRows{ba}, B, s);
         else hipLaunchKernelGGL(nce_batch_back_parts_kernel, dim3(bb), dim3(256), 0, s, ba);
     }
@@ -1255,7 +1259,7 @@ int rbg_infonce_workspace(int64_t B, int64_t n, int d, int64_t *bytes) {
 // batch_form (rbg_infonce_batch_f32): the candidates are the batch's own rows T2[idx[b]] (n = B), the gradients go to rows idx[b] of both tables
 static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, const int64_t *idx, int64_t B, float tau, float weight,
                         const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream,
-                        bool batch_form = false) {
+                        bool batch_form = false, const int64_t *pos_map = nullptr) {
     clear_error();
     if (B < 0 || n <= 0 || d <= 0) return fail(RBG_ESHAPE, "B = %lld, n = %lld, d = %d", (long long)B, (long long)n, d);
     if (d > 128) return fail(RBG_EUNSUPPORTED, "infonce: d = %d > 128", d);
@@ -1273,7 +1277,7 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     const unsigned nb = (unsigned)((n + 3) / 4), bb = (unsigned)((B + 3) / 4);
     const bool grads = grad_T1 || grad_T2;
     const bool masked = row_w || col_w;
-    const bool onepass = masked || batch_form || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
+    const bool onepass = masked || batch_form || pos_map || (grads && opt_lse_onepass());  // denominators and dA out of one pass over the table
     const int64_t *bids = batch_form ? idx : nullptr;
     // r06: the fp16 form of the gradient launches (the plain InfoNCE with gradients); mode 1: the row kernels write the fp16 plane images too
     const int f16_mode = (onepass && grads && !masked) ? lse_f16_mode(d) : 0;
@@ -1282,10 +1286,10 @@ static int infonce_impl(const float *T1, const float *T2, int64_t n, int d, cons
     hipLaunchKernelGGL(nce_norm_table_kernel, dim3((f16_mode & 1) ? nb_img : nb), dim3(256), 0, s, T2, n, d, C, inv2, (f16_mode & 1) ? imgC : nullptr, bids);
     RBG_HIP(hipGetLastError());
     hipLaunchKernelGGL(nce_batch_prep_kernel, dim3((f16_mode & 1) ? bb_img : bb), dim3(256), 0, s, T1, C, idx, B, d, A, inv1, pos, (f16_mode & 1) ? imgA : nullptr,
-                       batch_form ? 1 : 0);
+                       batch_form ? 1 : 0, pos_map);
     RBG_HIP(hipGetLastError());
     if (onepass) return infonce_onepass(A, C, inv1, inv2, pos, gl, dC, idx, row_w, col_w, n, d, B, scale, weight, loss, grad_T1, grad_T2, lse_ws, s,
-                                        imgC, imgA, f16_mode, bids);
+                                        imgC, imgA, f16_mode, bids, pos_map);
     int rc = rbg_lse_rows_f32(A, d, B, C, d, n, d, scale, scale, lse, lse_ws, stream);  // unit rows: shift = 1/tau
     if (rc) return rc;
     hipLaunchKernelGGL(nce_loss_kernel, dim3(1), dim3(256), 0, s, lse, pos, B, scale, weight, loss, gl);
@@ -1315,6 +1319,15 @@ int rbg_infonce_masked_f32(const float *T1, const float *T2, int64_t n, int d, c
                            const float *row_w, const float *col_w, float *loss, float *grad_T1, float *grad_T2, void *workspace,
                            void *stream) {
     return infonce_impl(T1, T2, n, d, idx, B, tau, weight, row_w, col_w, loss, grad_T1, grad_T2, workspace, stream);
+}
+
+int rbg_infonce_map_f32(const float *T1, const float *T2, int64_t n2, int d, const int64_t *idx, const int64_t *pos_map, int64_t B, float tau,
+                        float weight, float *loss, float *grad_T1, float *grad_T2, void *workspace, void *stream) {
+    if (B > 0 && !pos_map) {
+        clear_error();
+        return fail(RBG_EINVAL, "infonce_map: pos_map is NULL");
+    }
+    return infonce_impl(T1, T2, n2, d, idx, B, tau, weight, nullptr, nullptr, loss, grad_T1, grad_T2, workspace, stream, false, pos_map);
 }
 
 int rbg_infonce_batch_f32(const float *TA, const float *TB, int d, const int64_t *ids, int64_t B, float tau, float weight,

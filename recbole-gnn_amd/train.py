@@ -750,7 +750,7 @@ class FusedNCLAdam(_FusedStep):
         p = lambda t, row=0: c_vp(t.data_ptr() + 4 * row * d)  # noqa: E731
         if b not in self._scratch:
             nbytes, need = _lib.c_i64(), 8
-            for rows in (nu, ni):
+            for rows in (nu, ni, int(m.k)):  # (the structure contrast over all rows of a side, the prototype contrast over the k centroids)
                 check(lib.rbg_infonce_workspace(b, rows, d, _lib.ctypes.byref(nbytes)))
                 need = max(need, nbytes.value)
             self._scratch[b] = (torch.empty(need, dtype=torch.uint8, device=dev), torch.empty(need, dtype=torch.uint8, device=dev),
@@ -770,25 +770,28 @@ class FusedNCLAdam(_FusedStep):
             # ncl.py:137-165: the context layer E_(2 h) against the center E_0, users then items (x alpha)
             ctx = self.lay[2 * m.hyper_layers - 1]
             self._gz.zero_()  # gctx, g0
-            def half(row0, rows, idx, wgt, loss, ws):
+            if self.with_proto and m.user_centroids is None:
+                raise RuntimeError("NCL.e_step() has not run: no prototypes yet (NCLTrainer calls it before the first epoch)")
+
+            def half(row0, rows, idx, wgt, loss, ws, centroids, node2cluster):
                 def run():  # (the stream is looked up when it runs: the second half is issued on a side stream)
+                    sth = c_vp(torch.cuda.current_stream(dev).cuda_stream)
                     check(lib.rbg_infonce_f32(p(ctx, row0), p(self.e0, row0), rows, d, p(idx), b, float(m.ssl_temp), float(wgt), p(loss),
-                                              p(self.gctx, row0), p(self.g0, row0), p(ws), c_vp(torch.cuda.current_stream(dev).cuda_stream)))
+                                              p(self.gctx, row0), p(self.g0, row0), p(ws), sth))
+                    if self.with_proto:
+                        # ncl.py:106-135, r06: the batch's rows of E_0 against the side's k centroids (constants), the positive = the row's
+                        # cluster — one library call (value + the rows' gradient onto g0) instead of ~ 35 torch launches under autograd
+                        check(lib.rbg_infonce_map_f32(p(self.e0, row0), c_vp(centroids.data_ptr()), centroids.shape[0], d, p(idx),
+                                                      c_vp(node2cluster.data_ptr()), b, float(m.ssl_temp), float(m.proto_reg), p(loss),
+                                                      p(self.g0, row0), None, p(ws), sth))
                 return run
 
             def users_half():
                 loss2.zero_()
-                half(0, nu, user, m.ssl_reg, loss2, work2)()
+                half(0, nu, user, m.ssl_reg, loss2, work2, m.user_centroids, m.user_2cluster)()
 
-            self._two_halves(dev, half(nu, ni, pos, m.ssl_reg * m.alpha, self.loss, work), users_half)
+            self._two_halves(dev, half(nu, ni, pos, m.ssl_reg * m.alpha, self.loss, work, m.item_centroids, m.item_2cluster), users_half)
             self.loss.add_(loss2)
-            if self.with_proto:  # ncl.py:106-135 on the batch's rows of E_0: the model's formula, differentiated by torch
-                with torch.enable_grad():
-                    leaf = self.e0.detach().requires_grad_(True)
-                    proto = m.ProtoNCE_loss(leaf, user, pos)
-                    (gp,) = torch.autograd.grad(proto, leaf)
-                self.g0.add_(gp)
-                self.loss.add_(proto.detach())
             # mean = (E_0 + .. + E_K) / (K + 1), E_j = A E_(j-1):  dE0 = g_0 + A (g_1 + A (g_2 + .. A g_L)),
             # g_j = gm / (K + 1) for j <= K  (+ gctx at j = 2 h),  g_0 = gm / (K + 1) + the direct gradients on E_0
             gt = m.graph.transpose().ptr

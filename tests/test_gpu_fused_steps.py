@@ -731,3 +731,43 @@ def test_infonce_batch_form_equals_the_gathered_form(rbg, cuda, det, rows, b, d,
     for got, want in ((ga1, ga0), (gb1, gb0)):
         assert float((got - want).abs().max()) <= 1e-6 * max(1e-6, float(want.abs().max()))
     assert lib.rbg_infonce_batch_f32(p(ta), p(tb), d, p(ids), b, 0.2, 0.37, p(row_w), p(once), p(loss1), p(ga1), None, p(work), st) != 0
+
+
+@pytest.mark.parametrize("n1,k,b,d,tau", [(3000, 100, 300, 64, 0.1), (500, 1000, 257, 64, 0.05), (2000, 37, 64, 128, 0.2), (90, 5, 33, 36, 1.0)])
+def test_infonce_against_mapped_positives(rbg, cuda, n1, k, b, d, tau):
+    """rbg_infonce_map_f32 (r06) == NCL's prototype contrast of one side (ncl.py:106-123) in float64 autograd: rows of a table against
+    ALL k (unit) centroids, the positive of a row = its cluster's centroid; value, the rows' gradient (ids repeat), no table gradient;
+    with a table gradient too (the general form)."""
+    from recbole_gnn_amd._lib import lib, check, c_vp, c_i64
+    import ctypes
+    gen = torch.Generator().manual_seed(n1 + k + b)
+    t1 = torch.randn(n1, d, generator=gen)
+    cent = torch.nn.functional.normalize(torch.randn(k, d, generator=gen), dim=1)
+    node2c = torch.randint(0, k, (n1,), generator=gen)
+    idx = torch.randint(0, n1, (b,), generator=gen)
+    idx[:3] = idx[0]
+    w = 0.37
+    a64, c64 = t1.double().requires_grad_(True), cent.double().requires_grad_(True)
+    a = torch.nn.functional.normalize(a64[idx], dim=1)
+    cn = torch.nn.functional.normalize(c64, dim=1)
+    pos = (a * cn[node2c[idx]]).sum(1) / tau
+    ref = w * (torch.logsumexp(a @ cn.T / tau, dim=1) - pos).sum()
+    ref.backward()
+    T1, C, N2C, IDX = t1.to(cuda), cent.to(cuda), node2c.to(cuda), idx.to(cuda)
+    st = c_vp(torch.cuda.current_stream(cuda).cuda_stream)
+    p = lambda t: c_vp(t.data_ptr())  # noqa: E731
+    nbytes = c_i64()
+    check(lib.rbg_infonce_workspace(b, k, d, ctypes.byref(nbytes)))
+    work = torch.empty(max(nbytes.value, 8), dtype=torch.uint8, device=cuda)
+    g1, loss = torch.zeros_like(T1), torch.zeros((), device=cuda)
+    check(lib.rbg_infonce_map_f32(p(T1), p(C), k, d, p(IDX), p(N2C), b, tau, w, p(loss), p(g1), None, p(work), st))
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert float((g1.cpu().double() - a64.grad).abs().max()) <= 1e-5 * max(1e-3, float(a64.grad.abs().max()))
+    g1b, g2b, loss_b = torch.zeros_like(T1), torch.zeros_like(C), torch.zeros((), device=cuda)
+    check(lib.rbg_infonce_map_f32(p(T1), p(C), k, d, p(IDX), p(N2C), b, tau, w, p(loss_b), p(g1b), p(g2b), p(work), st))
+    assert abs(float(loss_b) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert float((g1b.cpu().double() - a64.grad).abs().max()) <= 1e-5 * max(1e-3, float(a64.grad.abs().max()))
+    assert float((g2b.cpu().double() - c64.grad).abs().max()) <= 1e-5 * max(1e-3, float(c64.grad.abs().max()))
+    loss_v = torch.zeros((), device=cuda)
+    check(lib.rbg_infonce_map_f32(p(T1), p(C), k, d, p(IDX), p(N2C), b, tau, w, p(loss_v), None, None, p(work), st))
+    assert abs(float(loss_v) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
