@@ -547,10 +547,13 @@ def extras_n1(rbg, graph, uid, iid, nu, ni, d, k_layers, dev):
     # re-sampled per epoch): seconds for the SECOND epoch of every model = 502 batches of 2048 at the Gowalla shape
     try:
         ep = {}
-        for name in ("LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL", "NCL"):
+        for name in ("LightGCN", "NGCF", "SGL", "SimGCL", "XSimGCL", "NCL", "NCL(prototype term on: after warm_up_step)"):
             torch.manual_seed(0)
             np.random.seed(0)
-            mm = getattr(rbg, name)({"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "require_pow": True}, ds)
+            cfg = {"device": str(dev), "enable_sparse": True, "embedding_size": d, "n_layers": k_layers, "require_pow": True}
+            if name.startswith("NCL("):  # (NCL.yaml's warm_up_step = 20: the epochs timed as "NCL" run WITHOUT ProtoNCE_loss, ncl.py:106-135)
+                cfg["warm_up_step"] = 0
+            mm = getattr(rbg, name.split("(")[0])(cfg, ds)
             marks = []
 
             def mark(_msg, marks=marks):
